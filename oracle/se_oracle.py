@@ -1,0 +1,491 @@
+"""CPU oracle for the SCP-GAN / CMGAN hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain functional torch-CPU code driven by a flat
+``state_dict``, the arithmetic of the reference hot path (citations are into
+/root/reference).  It is *not* part of the product: only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it, and only as the checker.  The product path
+(``speech-enhancement_amd``) never imports this module and has no CPU fallback.
+
+Parity pin: every function here is checked in ``tests/test_oracle_golden.py``
+against golden vectors produced by importing the reference itself in the build
+container (``tests/golden/make_golden.py``, committed with its outputs).
+PESQ labels are third-party arithmetic (PyPI ``pesq``, un-pinned, absent): they
+are *inputs* to this oracle -> PESQ parity is unpinned.
+
+Floating point: everything is fp32 (or fp64 when the caller passes doubles);
+tolerances are stated in the tests.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+N_FFT = 400
+HOP = 100
+MAX_POS = 512
+EPS_NORM = 1e-5
+
+
+# --------------------------------------------------------------------------
+# Front-end: core/function.py:625-703
+# --------------------------------------------------------------------------
+def hamming_periodic(n: int = N_FFT, dtype=torch.float32) -> Tensor:
+    """torch.hamming_window(n) (periodic) -- core/function.py:668."""
+    k = torch.arange(n, dtype=torch.float64)
+    return (0.54 - 0.46 * torch.cos(2.0 * math.pi * k / n)).to(dtype)
+
+
+def normalize_pair(clean: Tensor, noisy: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """c = sqrt(L / sum(noisy^2)); both signals scaled by c (core/function.py:647-659)."""
+    c = torch.sqrt(noisy.shape[-1] / torch.sum(noisy * noisy, dim=-1))
+    return clean * c[:, None], noisy * c[:, None], c
+
+
+def _compress(re: Tensor, im: Tensor, comp: Optional[str]) -> Tuple[Tensor, Tensor]:
+    """power_compress (core/function.py:625-634): mag' * (cos, sin)(atan2(im, re))."""
+    mag = torch.sqrt(re * re + im * im)
+    ph = torch.atan2(im, re)
+    if comp == 'pow':
+        mag = mag ** 0.3
+    elif comp == 'log':
+        mag = torch.log1p(mag)
+    return mag * torch.cos(ph), mag * torch.sin(ph)
+
+
+def _uncompress(re: Tensor, im: Tensor, comp: Optional[str]) -> Tuple[Tensor, Tensor]:
+    """power_uncompress (core/function.py:636-645)."""
+    mag = torch.sqrt(re * re + im * im)
+    ph = torch.atan2(im, re)
+    if comp == 'pow':
+        mag = mag ** (1.0 / 0.3)
+    if comp == 'log':
+        mag = torch.expm1(mag)
+    return mag * torch.cos(ph), mag * torch.sin(ph)
+
+
+def stft_frames(x: Tensor, n_fft: int = N_FFT, hop: int = HOP) -> Tensor:
+    """reflect-pad n_fft/2, frame, window, one-sided DFT -> complex [B, F, T] (torch.stft
+    semantics used at core/function.py:690-691)."""
+    w = hamming_periodic(n_fft, x.dtype)
+    xp = F.pad(x[:, None, :], (n_fft // 2, n_fft // 2), mode='reflect')[:, 0, :]
+    fr = xp.unfold(-1, n_fft, hop) * w            # [B, T, n_fft]
+    return torch.fft.rfft(fr, dim=-1).transpose(1, 2)
+
+
+def compressed_stft(x: Tensor, n_fft: int = N_FFT, hop: int = HOP,
+                    comp: Optional[str] = 'pow') -> Tensor:
+    """core/function.py:685-693 -> complex [B, F, T]."""
+    z = stft_frames(x, n_fft, hop)
+    if comp == 'norm':
+        z = z * (n_fft ** -0.5)
+    re, im = _compress(z.real, z.imag, comp)
+    return torch.complex(re, im)
+
+
+def uncompressed_istft(spec: Tensor, n_fft: int = N_FFT, hop: int = HOP,
+                       comp: Optional[str] = 'pow') -> Tensor:
+    """core/function.py:695-703: un-compress, irfft, window, overlap-add, / sum w^2, trim."""
+    re, im = _uncompress(spec.real, spec.imag, comp)
+    z = torch.complex(re, im)
+    if comp == 'norm':
+        z = z * (n_fft ** 0.5)
+    B, Fq, T = z.shape
+    w = hamming_periodic(n_fft, re.dtype)
+    fr = torch.fft.irfft(z.transpose(1, 2), n=n_fft, dim=-1) * w   # [B, T, n_fft]
+    Lp = n_fft + hop * (T - 1)
+    y = torch.zeros(B, Lp, dtype=re.dtype)
+    env = torch.zeros(Lp, dtype=re.dtype)
+    w2 = w * w
+    for t in range(T):
+        y[:, t * hop:t * hop + n_fft] = y[:, t * hop:t * hop + n_fft] + fr[:, t]
+        env[t * hop:t * hop + n_fft] += w2
+    h = n_fft // 2
+    return y[:, h:Lp - h] / env[h:Lp - h]
+
+
+# --------------------------------------------------------------------------
+# Generator: models/generator.py, models/conformer.py
+# --------------------------------------------------------------------------
+def _inorm_prelu(x: Tensor, g: Tensor, b: Tensor, a: Optional[Tensor]) -> Tensor:
+    """InstanceNorm2d(affine) eps 1e-5 biased var over (T,F) + PReLU(C)."""
+    m = x.mean(dim=(2, 3), keepdim=True)
+    v = ((x - m) ** 2).mean(dim=(2, 3), keepdim=True)
+    y = (x - m) / torch.sqrt(v + EPS_NORM) * g[None, :, None, None] + b[None, :, None, None]
+    if a is not None:
+        y = torch.where(y >= 0, y, y * a[None, :, None, None])
+    return y
+
+
+def dilated_dense(sd: SD, p: str, x: Tensor) -> Tensor:
+    """DilatedDenseNet (generator.py:6-32): 4 causal-in-time dilated (2,3) convs over a
+    growing skip stack, newest output first in the channel order."""
+    skip = x
+    out = x
+    for i in range(4):
+        d = 2 ** i
+        xin = F.pad(skip, (1, 1, d, 0))
+        out = F.conv2d(xin, sd[f'{p}.conv{i+1}.weight'], sd[f'{p}.conv{i+1}.bias'], dilation=(d, 1))
+        out = _inorm_prelu(out, sd[f'{p}.norm{i+1}.weight'], sd[f'{p}.norm{i+1}.bias'],
+                           sd[f'{p}.prelu{i+1}.weight'])
+        skip = torch.cat([out, skip], dim=1)
+    return out
+
+
+def dense_encoder(sd: SD, p: str, x: Tensor) -> Tensor:
+    """generator.py:35-54."""
+    x = F.conv2d(x, sd[f'{p}.conv_1.0.weight'], sd[f'{p}.conv_1.0.bias'])
+    x = _inorm_prelu(x, sd[f'{p}.conv_1.1.weight'], sd[f'{p}.conv_1.1.bias'], sd[f'{p}.conv_1.2.weight'])
+    x = dilated_dense(sd, f'{p}.dilated_dense', x)
+    x = F.conv2d(x, sd[f'{p}.conv_2.0.weight'], sd[f'{p}.conv_2.0.bias'], stride=(1, 2), padding=(0, 1))
+    x = _inorm_prelu(x, sd[f'{p}.conv_2.1.weight'], sd[f'{p}.conv_2.1.bias'], sd[f'{p}.conv_2.2.weight'])
+    return x
+
+
+def _ln(x: Tensor, g: Tensor, b: Tensor) -> Tensor:
+    m = x.mean(-1, keepdim=True)
+    v = ((x - m) ** 2).mean(-1, keepdim=True)
+    return (x - m) / torch.sqrt(v + EPS_NORM) * g + b
+
+
+def _swish(x: Tensor) -> Tensor:
+    return x * torch.sigmoid(x)
+
+
+def feed_forward(sd: SD, p: str, x: Tensor) -> Tensor:
+    """Scale(0.5, PreNorm(FeedForward)) (conformer.py:53-71,128-145); dropout off."""
+    h = _ln(x, sd[f'{p}.fn.norm.weight'], sd[f'{p}.fn.norm.bias'])
+    h = h @ sd[f'{p}.fn.fn.net.0.weight'].T + sd[f'{p}.fn.fn.net.0.bias']
+    h = _swish(h)
+    h = h @ sd[f'{p}.fn.fn.net.3.weight'].T + sd[f'{p}.fn.fn.net.3.bias']
+    return 0.5 * h
+
+
+def rel_attention(sd: SD, p: str, x: Tensor, heads: int = 4) -> Tensor:
+    """PreNorm(Attention) with Shaw relative positions (conformer.py:74-125); dropout off.
+    logits[i,j] = scale * (q_i.k_j + q_i.E[clamp(i-j,-512,512)+512])."""
+    Bs, n, D = x.shape
+    h = _ln(x, sd[f'{p}.norm.weight'], sd[f'{p}.norm.bias'])
+    q = h @ sd[f'{p}.fn.to_q.weight'].T
+    kv = h @ sd[f'{p}.fn.to_kv.weight'].T
+    k, v = kv[..., :D], kv[..., D:]
+    dh = D // heads
+    q = q.view(Bs, n, heads, dh).transpose(1, 2)
+    k = k.view(Bs, n, heads, dh).transpose(1, 2)
+    v = v.view(Bs, n, heads, dh).transpose(1, 2)
+    scale = dh ** -0.5
+    idx = torch.arange(n)
+    rel = (idx[:, None] - idx[None, :]).clamp(-MAX_POS, MAX_POS) + MAX_POS
+    E = sd[f'{p}.fn.rel_pos_emb.weight'][rel]                  # [n, n, dh]
+    logits = (q @ k.transpose(-1, -2) + torch.einsum('bhid,ijd->bhij', q, E)) * scale
+    a = torch.softmax(logits, dim=-1)
+    o = (a @ v).transpose(1, 2).reshape(Bs, n, D)
+    return o @ sd[f'{p}.fn.to_out.weight'].T + sd[f'{p}.fn.to_out.bias']
+
+
+def conv_module(sd: SD, p: str, x: Tensor, train: bool, bn_out: Optional[dict]) -> Tensor:
+    """ConformerConvModule (conformer.py:148-175): LN, pw 64->256, GLU, depthwise k31 pad 15,
+    BatchNorm1d(128) (batch stats in train), Swish, pw 128->64."""
+    h = _ln(x, sd[f'{p}.net.0.weight'], sd[f'{p}.net.0.bias']).transpose(1, 2)    # [Bs, 64, n]
+    h = F.conv1d(h, sd[f'{p}.net.2.weight'], sd[f'{p}.net.2.bias'])
+    a, g = h.chunk(2, dim=1)
+    h = a * torch.sigmoid(g)
+    h = F.conv1d(F.pad(h, (15, 15)), sd[f'{p}.net.4.conv.weight'], sd[f'{p}.net.4.conv.bias'],
+                 groups=h.shape[1])
+    if train:
+        m = h.mean(dim=(0, 2))
+        var = ((h - m[None, :, None]) ** 2).mean(dim=(0, 2))
+        if bn_out is not None:
+            cnt = h.shape[0] * h.shape[2]
+            bn_out[f'{p}.net.5.running_mean'] = 0.9 * sd[f'{p}.net.5.running_mean'] + 0.1 * m.detach()
+            bn_out[f'{p}.net.5.running_var'] = 0.9 * sd[f'{p}.net.5.running_var'] + \
+                0.1 * var.detach() * cnt / max(cnt - 1, 1)
+            bn_out[f'{p}.net.5.num_batches_tracked'] = sd[f'{p}.net.5.num_batches_tracked'] + 1
+    else:
+        m, var = sd[f'{p}.net.5.running_mean'], sd[f'{p}.net.5.running_var']
+    h = (h - m[None, :, None]) / torch.sqrt(var[None, :, None] + EPS_NORM)
+    h = h * sd[f'{p}.net.5.weight'][None, :, None] + sd[f'{p}.net.5.bias'][None, :, None]
+    h = _swish(h)
+    h = F.conv1d(h, sd[f'{p}.net.7.weight'], sd[f'{p}.net.7.bias'])
+    return h.transpose(1, 2)
+
+
+def conformer_block(sd: SD, p: str, x: Tensor, train: bool = True,
+                    bn_out: Optional[dict] = None) -> Tensor:
+    """ConformerBlock.forward (conformer.py:206-212)."""
+    x = x + feed_forward(sd, f'{p}.ff1', x)
+    x = x + rel_attention(sd, f'{p}.attn', x)
+    x = x + conv_module(sd, f'{p}.conv', x, train, bn_out)
+    x = x + feed_forward(sd, f'{p}.ff2', x)
+    return _ln(x, sd[f'{p}.post_norm.weight'], sd[f'{p}.post_norm.bias'])
+
+
+def tscb(sd: SD, p: str, x: Tensor, train: bool, bn_out: Optional[dict]) -> Tensor:
+    """TSCB (generator.py:57-74): time conformer over T for each (b,f), then frequency
+    conformer over F for each (b,t); each adds its own input after the post-LayerNorm."""
+    B, C, T, Fq = x.shape
+    xt = x.permute(0, 3, 2, 1).reshape(B * Fq, T, C)
+    xt = conformer_block(sd, f'{p}.time_conformer', xt, train, bn_out) + xt
+    xf = xt.view(B, Fq, T, C).permute(0, 2, 1, 3).reshape(B * T, Fq, C)
+    xf = conformer_block(sd, f'{p}.freq_conformer', xf, train, bn_out) + xf
+    return xf.view(B, T, Fq, C).permute(0, 3, 1, 2)
+
+
+def sub_pixel(sd: SD, p: str, x: Tensor) -> Tensor:
+    """SPConvTranspose2d r=2 (generator.py:77-92): conv(1,3) to 2C channels, channel r*C+c
+    becomes frequency 2f+r of channel c."""
+    y = F.conv2d(F.pad(x, (1, 1, 0, 0)), sd[f'{p}.conv.weight'], sd[f'{p}.conv.bias'])
+    B, C2, T, Fq = y.shape
+    y = y.view(B, 2, C2 // 2, T, Fq).permute(0, 2, 3, 4, 1)
+    return y.reshape(B, C2 // 2, T, Fq * 2)
+
+
+def mask_decoder(sd: SD, p: str, x: Tensor) -> Tensor:
+    """generator.py:95-112 -> [B,1,T,F]."""
+    x = dilated_dense(sd, f'{p}.dense_block', x)
+    x = sub_pixel(sd, f'{p}.sub_pixel', x)
+    x = F.conv2d(x, sd[f'{p}.conv_1.weight'], sd[f'{p}.conv_1.bias'])
+    x = _inorm_prelu(x, sd[f'{p}.norm.weight'], sd[f'{p}.norm.bias'], sd[f'{p}.prelu.weight'])
+    x = F.conv2d(x, sd[f'{p}.final_conv.weight'], sd[f'{p}.final_conv.bias'])   # [B,1,T,F]
+    a = sd[f'{p}.prelu_out.weight']                                              # [F]
+    return torch.where(x >= 0, x, x * a[None, None, None, :])
+
+
+def complex_decoder(sd: SD, p: str, x: Tensor) -> Tensor:
+    """generator.py:115-129 -> [B,2,T,F]."""
+    x = dilated_dense(sd, f'{p}.dense_block', x)
+    x = sub_pixel(sd, f'{p}.sub_pixel', x)
+    x = _inorm_prelu(x, sd[f'{p}.norm.weight'], sd[f'{p}.norm.bias'], sd[f'{p}.prelu.weight'])
+    return F.conv2d(x, sd[f'{p}.conv.weight'], sd[f'{p}.conv.bias'])
+
+
+def tscnet_forward(sd: SD, spec: Tensor, train: bool = True,
+                   bn_out: Optional[dict] = None) -> Tuple[Tensor, Tensor]:
+    """TSCNet.forward (generator.py:145-167). spec complex [B,F,T] -> (real, imag) [B,1,T,F]."""
+    re = spec.real.transpose(1, 2)[:, None]
+    im = spec.imag.transpose(1, 2)[:, None]
+    mag = torch.sqrt(re * re + im * im)
+    ph = torch.atan2(im, re)
+    x = torch.cat([mag, re, im], dim=1)
+    x = dense_encoder(sd, 'dense_encoder', x)
+    for i in range(1, 5):
+        x = tscb(sd, f'TSCB_{i}', x, train, bn_out)
+    mask = mask_decoder(sd, 'mask_decoder', x)
+    cplx = complex_decoder(sd, 'complex_decoder', x)
+    out_mag = mask * mag
+    return out_mag * torch.cos(ph) + cplx[:, 0:1], out_mag * torch.sin(ph) + cplx[:, 1:2]
+
+
+# --------------------------------------------------------------------------
+# Discriminator: models/discriminator.py:35-62 (old-style spectral_norm hook)
+# --------------------------------------------------------------------------
+D_SN_LAYERS = (0, 3, 6, 9, 14, 17)
+
+
+def _l2n(v: Tensor, eps: float = 1e-12) -> Tensor:
+    return v / torch.clamp(v.norm(), min=eps)
+
+
+def spectral_weight(sd: SD, p: str, train: bool, sn_out: Optional[dict]) -> Tensor:
+    """One power iteration in train mode (u, v advanced under no_grad), then W / sigma with
+    sigma = u^T W v differentiated w.r.t. W only."""
+    W = sd[f'{p}.weight_orig']
+    Wm = W.reshape(W.shape[0], -1)
+    u, v = sd[f'{p}.weight_u'], sd[f'{p}.weight_v']
+    if train:
+        with torch.no_grad():
+            v = _l2n(Wm.detach().T @ u)
+            u = _l2n(Wm.detach() @ v)
+        if sn_out is not None:
+            sn_out[f'{p}.weight_u'] = u
+            sn_out[f'{p}.weight_v'] = v
+    sigma = u @ (Wm @ v)
+    return W / sigma
+
+
+def discriminator_forward(sd: SD, x: Tensor, y: Tensor, train: bool = True,
+                          sn_out: Optional[dict] = None) -> Tensor:
+    """x, y: [B,1,F,T] magnitudes; returns [B,1].  Dropout(0.3) off."""
+    h = torch.cat([x, y], dim=1)
+    for li in (0, 3, 6, 9):
+        W = spectral_weight(sd, f'layers.{li}', train, sn_out)
+        h = F.conv2d(h, W, None, stride=2, padding=1)
+        h = _inorm_prelu(h, sd[f'layers.{li+1}.weight'], sd[f'layers.{li+1}.bias'],
+                         sd[f'layers.{li+2}.weight'])
+    h = h.amax(dim=(2, 3))
+    W = spectral_weight(sd, 'layers.14', train, sn_out)
+    h = h @ W.T + sd['layers.14.bias']
+    a = sd['layers.16.weight']
+    h = torch.where(h >= 0, h, h * a[None, :])
+    W = spectral_weight(sd, 'layers.17', train, sn_out)
+    h = h @ W.T + sd['layers.17.bias']
+    return torch.sigmoid(sd['layers.18.slope'] * h)
+
+
+# --------------------------------------------------------------------------
+# Losses / step logic: core/function.py:206-317, 705-760
+# --------------------------------------------------------------------------
+def _mse(a: Tensor, b: Tensor) -> Tensor:
+    return ((a - b) ** 2).mean()
+
+
+def generator_losses(sd_g: SD, sd_d: SD, clean: Tensor, noisy: Tensor, arch: str = 'cmgan',
+                     train: bool = True, bn_out=None, sn_out=None, comp: str = 'pow'):
+    """Forward part of the G step (core/function.py:218-262).  clean/noisy already normalised.
+    Returns dict with loss terms and tensors needed by the D step."""
+    noisy_spec = compressed_stft(noisy)
+    clean_spec = compressed_stft(clean)
+    est_real, est_imag = tscnet_forward(sd_g, noisy_spec, train, bn_out)
+    est_real, est_imag = est_real.permute(0, 1, 3, 2), est_imag.permute(0, 1, 3, 2)   # [B,1,F,T]
+    est_mag = torch.sqrt(est_real ** 2 + est_imag ** 2)
+    clean_mag = clean_spec.abs()[:, None]
+    est_audio = uncompressed_istft(torch.complex(est_real[:, 0], est_imag[:, 0]))
+    if arch in ('scp', 'cp'):
+        ep = compressed_stft(est_audio, comp=comp)
+        clean_audio_p = uncompressed_istft(clean_spec)
+        cp = compressed_stft(clean_audio_p, comp=comp)
+        loss_mag = _mse(ep.abs(), cp.abs())
+        time_loss = (est_audio - clean_audio_p).abs().mean()
+        loss_ri = _mse(ep.real, cp.real) + _mse(ep.imag, cp.imag)
+    else:
+        loss_mag = _mse(est_mag, clean_mag)
+        time_loss = (est_audio - clean).abs().mean()
+        loss_ri = _mse(est_real[:, 0], clean_spec.real) + _mse(est_imag[:, 0], clean_spec.imag)
+    d_fake = discriminator_forward(sd_d, clean_mag, est_mag, train, sn_out)
+    gan = _mse(d_fake.flatten(), torch.ones(clean.shape[0], dtype=clean.dtype))
+    return dict(loss_ri=loss_ri, loss_mag=loss_mag, time_loss=time_loss, gan=gan,
+                est_mag=est_mag, clean_mag=clean_mag, est_audio=est_audio,
+                noisy_mag=noisy_spec.abs()[:, None], est_real=est_real, est_imag=est_imag)
+
+
+def self_correcting_weights(CE: float, CN: float, EN: float, EE: float, NN: float):
+    """Piecewise weights of compute_self_correcting_loss_weights (core/function.py:736-748).
+    EE and NN already include the +1e-14."""
+    if CE > 0:
+        wE = 1.0
+        wN = 1.0 if (CN + wE * EN) > 0 else -(CN) / NN - (EN) / NN
+    else:
+        wE = -(CE) / EE
+        wN = 1.0 if (CN + wE * EN) > 0 else -(CN) / NN + (CE * EN) / (EE * NN)
+    return 1.0, wE, wN
+
+
+def lr_at(epoch_float: float, lr: float, epochs: int, cycle_limit: int = 4,
+          warmup: int = 4) -> float:
+    """adjust_learning_rate (utils/utils.py:78-90): value written into the param groups."""
+    cycle = epochs // cycle_limit
+    q, r = divmod(epoch_float, cycle)
+    if r < warmup:
+        return 0.5 ** q * lr * r / warmup
+    return lr * 0.5 ** (q + 1) * (1.0 + math.cos(math.pi * (r - warmup) / (cycle - warmup)))
+
+
+def adamw_update(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+                 wd: float, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.AdamW single-tensor rule (the reference calls optim.AdamW,
+    core/optimizer.py:36)."""
+    p = p * (1 - lr * wd)
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    mhat = m / (1 - b1 ** step)
+    vhat = v / (1 - b2 ** step)
+    return p - lr * mhat / (vhat.sqrt() + eps), m, v
+
+
+def sgd_nesterov_update(p: Tensor, g: Tensor, buf: Optional[Tensor], lr: float, momentum: float = 0.9):
+    """torch.optim.SGD(momentum, nesterov=True), no weight decay (core/optimizer.py:33-35)."""
+    buf = g.clone() if buf is None else momentum * buf + g
+    return p - lr * (g + momentum * buf), buf
+
+
+def no_decay(name: str, p: Tensor) -> bool:
+    """set_weight_decay (core/optimizer.py:47-60): 1-D params and biases get weight_decay 0."""
+    return p.dim() == 1 or name.endswith('.bias')
+
+
+def train_step(sd_g: SD, sd_d: SD, clean: Tensor, noisy: Tensor, q_est: Tensor,
+               arch: str = 'cmgan', weights=(0.1, 0.9, 0.2, 0.05), lr: float = 5e-4,
+               wd: float = 0.01, opt_state: Optional[dict] = None,
+               q_clean: Optional[Tensor] = None, q_noisy: Optional[Tensor] = None,
+               optimizer: str = 'adamw', momentum: float = 0.9):
+    """One train_gan iteration (core/function.py:206-317), AdamW or nesterov-SGD, dropout off,
+    PESQ labels q_* supplied as inputs.  Returns (losses, new_sd_g, new_sd_d, opt_state)."""
+    G = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
+         for k, v in sd_g.items()}
+    D = {k: (v.clone().requires_grad_(True)
+             if v.is_floating_point() and not k.endswith(('_u', '_v')) else v)
+         for k, v in sd_d.items()}
+    gp = [k for k, v in G.items() if v.requires_grad]
+    dp = [k for k, v in D.items() if v.requires_grad]
+    clean_n, noisy_n, _ = normalize_pair(clean, noisy)
+    bn_out, sn1 = {}, {}
+    r = generator_losses(G, D, clean_n, noisy_n, arch, True, bn_out, sn1)
+    loss_g = weights[0] * r['loss_ri'] + weights[1] * r['loss_mag'] + \
+        weights[2] * r['time_loss'] + weights[3] * r['gan']
+    grads_g = torch.autograd.grad(loss_g, [G[k] for k in gp])
+    D.update(sn1)
+    est_mag = r['est_mag'].detach()
+    clean_mag = r['clean_mag'].detach()
+    sn2, sn3, sn4 = {}, {}, {}
+    d_gx = discriminator_forward(D, clean_mag, est_mag, True, sn2)
+    D.update(sn2)
+    d_yy = discriminator_forward(D, clean_mag, clean_mag, True, sn3)
+    D.update(sn3)
+    L_E = _mse(d_gx.flatten(), q_est)
+    out = dict(loss_ri=r['loss_ri'], loss_mag=r['loss_mag'], time_loss=r['time_loss'],
+               gan=r['gan'], loss_g=loss_g, L_E=L_E)
+    params_d = [D[k] for k in dp]
+    if arch in ('scp', 'sc'):
+        L_C = _mse(d_yy.flatten(), q_clean)
+        d_xy = discriminator_forward(D, clean_mag, r['noisy_mag'].detach(), True, sn4)
+        D.update(sn4)
+        L_N = _mse(d_xy.flatten(), q_noisy)
+        gC = torch.autograd.grad(L_C, params_d, retain_graph=True, allow_unused=True)
+        gE = torch.autograd.grad(L_E, params_d, retain_graph=True, allow_unused=True)
+        gN = torch.autograd.grad(L_N, params_d, retain_graph=True, allow_unused=True)
+        fl = lambda gs: torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1)
+                                   for g, p in zip(gs, params_d)])
+        C, E, N = fl(gC), fl(gE), fl(gN)
+        EE = float(E @ E) + 1e-14
+        NN = float(N @ N) + 1e-14
+        wC, wE, wN = self_correcting_weights(float(C @ E), float(C @ N), float(E @ N), EE, NN)
+        loss_d = wC * L_C + wE * L_E + wN * L_N
+        # the reference writes param.grad = sum w*g and then calls backward on the weighted
+        # loss again -> the optimizer sees twice that gradient.
+        comb = wC * C + wE * E + wN * N
+        flat_d = 2.0 * comb
+        grads_d, o = [], 0
+        for p in params_d:
+            grads_d.append(flat_d[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        out.update(L_C=L_C, L_N=L_N, w_E=torch.tensor(wE), w_N=torch.tensor(wN))
+    else:
+        L_C = _mse(d_yy.flatten(), torch.ones_like(q_est))
+        loss_d = L_C + L_E
+        grads_d = torch.autograd.grad(loss_d, params_d, allow_unused=True)
+        grads_d = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads_d, params_d)]
+        out.update(L_C=L_C)
+    out['loss_d'] = loss_d
+    st = opt_state or {'step': 0, 'g': {}, 'd': {}}
+    st['step'] += 1
+    new_g = {k: v.detach() for k, v in G.items()}
+    new_g.update({k: v.detach() for k, v in bn_out.items()})
+    new_d = {k: v.detach() for k, v in D.items()}
+    for names, grads, store, new in ((gp, grads_g, st['g'], new_g), (dp, grads_d, st['d'], new_d)):
+        for k, g in zip(names, grads):
+            if optimizer == 'sgd':
+                new[k], store[k] = sgd_nesterov_update(new[k], g.detach(), store.get(k), lr, momentum)
+                continue
+            m, v = store.get(k, (torch.zeros_like(g), torch.zeros_like(g)))
+            w = 0.0 if no_decay(k, new[k]) else wd
+            pn, m, v = adamw_update(new[k], g.detach(), m, v, st['step'], lr, w)
+            new[k] = pn
+            store[k] = (m, v)
+    out = {k: float(v.detach()) for k, v in out.items()}
+    return out, new_g, new_d, st, dict(zip(gp, grads_g)), dict(zip(dp, grads_d))
