@@ -1,0 +1,65 @@
+"""ctypes binding of libse_hip.so (include/se_hip.h).  There is NO fallback: if the library is
+missing or a call fails, the product raises."""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libse_hip.so')
+SE_MAX_TAPS = 16
+
+PRO_NONE, PRO_LN, PRO_SWISH, PRO_AFFINE_SWISH = 0, 1, 2, 3
+EPI_BIAS, EPI_ACCUM, EPI_RESID, EPI_GLU, EPI_STATS, EPI_SWISH_GRAD, EPI_SHUFFLE2 = 1, 2, 4, 8, 16, 32, 64
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [('B', C.c_int), ('To', C.c_int), ('Fo', C.c_int), ('Ti', C.c_int), ('Fi', C.c_int),
+                ('st', C.c_int), ('sf', C.c_int), ('up', C.c_int), ('ntap', C.c_int),
+                ('dt', C.c_int * SE_MAX_TAPS), ('df', C.c_int * SE_MAX_TAPS),
+                ('C', C.c_int), ('lda', C.c_int), ('a_off', C.c_int),
+                ('N', C.c_int), ('ldc', C.c_int), ('c_off', C.c_int), ('ldw', C.c_int),
+                ('prologue', C.c_int), ('epilogue', C.c_int), ('alpha', C.c_float),
+                ('ldr', C.c_int), ('r_off', C.c_int), ('ldx', C.c_int), ('x_off', C.c_int)]
+
+
+class SeHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SeHipError(f'{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) first; '
+                             'there is no CPU / PyTorch fallback for the hot path')
+        _lib = C.CDLL(LIB_PATH)
+        _lib.se_last_error.restype = C.c_char_p
+    return _lib
+
+
+def ptr(t):
+    """device pointer of a tensor (or NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        raise SeHipError(f'{name} failed ({rc}): {lib().se_last_error().decode()}')
+
+
+def check_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise SeHipError('hot-path tensors must live on the GPU (no CPU fallback)')

@@ -1,0 +1,465 @@
+// fp32-exact MFMA "tap GEMM" family for gfx950 (v_mfma_f32_32x32x2_f32).
+//
+//   Y[m][n] = epi( sum_tap sum_c pro(A[src(m,tap)][c]) * W[n][tap*C + c] )
+//
+// One kernel body serves nn.Linear, 1x1 / (2,3)-dilated / (1,3) / 4x4-strided convolutions (implicit
+// GEMM: the A tile is gathered per tap straight from the channels-last feature map, nothing is
+// im2col'ed), their input gradients (same kernel, transposed packed weights, negated taps) and the
+// DFT / inverse DFT of the STFT front-end (frames are rows with lda = hop).
+// A second kernel computes weight gradients (reduction over rows, fp32 atomics across row chunks).
+//
+// Tile: 128 rows x 64 cols per 256-thread workgroup (4 waves, each 32 rows x 64 cols = two 32x32
+// accumulators), K staged through LDS in BK-float slabs; both LDS tiles are row-major with a +4
+// pad (conflict-free ds_read_b128: 16-lane groups hit 16 distinct 4-bank slots, stride 36 or 20).
+// K order inside a slab is permuted so that each lane reads ONE contiguous BK/2 run
+// (lane half h supplies k in [h*BK/2, (h+1)*BK/2)) -> b128 LDS reads feed 4 MFMAs each.
+#include "se_common.h"
+
+struct GemmArgs {
+  se_gemm_desc d;
+  const float* A; const float* W; const float* bias; float* Y; const float* R; float* AUX;
+  const float* rowstats; const float* ps; const float* pb; double* stats;
+};
+
+// source pixel of output pixel (t, f) for one tap; returns -1 when outside the input grid
+static __device__ __forceinline__ long src_pixel(const se_gemm_desc& d, int b, int t, int f, int tap) {
+  int ti, fi;
+  if (!d.up) {
+    ti = t * d.st + d.dt[tap];
+    fi = f * d.sf + d.df[tap];
+    if (ti < 0 || ti >= d.Ti || fi < 0 || fi >= d.Fi) return -1;
+  } else {
+    int tt = t + d.dt[tap], ff = f + d.df[tap];
+    if (tt < 0 || ff < 0 || (tt % d.st) != 0 || (ff % d.sf) != 0) return -1;
+    ti = tt / d.st; fi = ff / d.sf;
+    if (ti >= d.Ti || fi >= d.Fi) return -1;
+  }
+  return ((long)b * d.Ti + ti) * d.Fi + fi;
+}
+
+template <int PRO>
+static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float mean, float rstd,
+                                                   const float* ps, const float* pb) {
+  if (PRO == SE_PRO_NONE) return v;
+  float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int cc = c + j;
+    if (cc < C) {
+      if (PRO == SE_PRO_LN) x[j] = (x[j] - mean) * rstd * ps[cc] + pb[cc];
+      else if (PRO == SE_PRO_SWISH) x[j] = swishf_(x[j]);
+      else if (PRO == SE_PRO_AFFINE_SWISH) x[j] = swishf_(x[j] * ps[cc] + pb[cc]);
+    } else {
+      x[j] = 0.f;
+    }
+  }
+  return make_float4(x[0], x[1], x[2], x[3]);
+}
+
+template <int BK, int PRO>
+__global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 64, SA = BK + 4;
+  constexpr int KQ = BK / 4;        // float4 per tile row
+  constexpr int RPP = 256 / KQ;     // tile rows covered per staging pass
+  constexpr int NA = BM / RPP, NB = BN / RPP;
+  __shared__ __attribute__((aligned(16))) float As[BM * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * SA];
+  __shared__ float red[4 * 64 * 2];
+
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, by = blockIdx.y;
+  const int Mb = d.To * d.Fo;
+  const int m0 = blockIdx.x * BM;
+  const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
+  const int kq = tid % KQ, r0 = tid / KQ;
+
+  int rt[NA], rf[NA];
+  bool rok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    int m = m0 + r0 + i * RPP;
+    rok[i] = m < Mb;
+    rt[i] = m / d.Fo;
+    rf[i] = m - rt[i] * d.Fo;
+  }
+  // W rows of this column block (GLU pairs value column j with gate column N/2 + j)
+  long wrow[NB];
+  bool wok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    int j = r0 + i * RPP;
+    int n;
+    if (glu) { n = (j >> 5) * (d.N / 2) + by * 32 + (j & 31); wok[i] = (by * 32 + (j & 31)) < d.N / 2; }
+    else { n = by * 64 + j; wok[i] = n < d.N; }
+    wrow[i] = (long)n * d.ldw;
+  }
+  float ln_mean[NA], ln_rstd[NA];
+  if (PRO == SE_PRO_LN) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      long p = rok[i] ? src_pixel(d, b, rt[i], rf[i], 0) : -1;
+      ln_mean[i] = p >= 0 ? g.rowstats[2 * p] : 0.f;
+      ln_rstd[i] = p >= 0 ? g.rowstats[2 * p + 1] : 0.f;
+    }
+  }
+
+  const int nchunk = (d.C + BK - 1) / BK;
+  const int NI = d.ntap * nchunk;
+  float4 ra[NA], rb[NB];
+  bool aok[NA];
+  int cur_c = 0;
+
+  auto load_tiles = [&](int it) {
+    int tap = it / nchunk;
+    int c0 = (it - tap * nchunk) * BK;
+    int c = c0 + kq * 4;
+    cur_c = c;
+    bool cok = c < d.C;   // C is a multiple of 4
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      long p = (rok[i] && cok) ? src_pixel(d, b, rt[i], rf[i], tap) : -1;
+      aok[i] = p >= 0;
+      ra[i] = aok[i] ? *reinterpret_cast<const float4*>(g.A + p * d.lda + d.a_off + c)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      rb[i] = (wok[i] && cok) ? *reinterpret_cast<const float4*>(g.W + wrow[i] + (long)tap * d.C + c)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+  load_tiles(0);
+  const float* Ap = &As[(wave * 32 + (lane & 31)) * SA + (lane >> 5) * (BK / 2)];
+  const float* Bp0 = &Bs[(lane & 31) * SA + (lane >> 5) * (BK / 2)];
+  const float* Bp1 = Bp0 + 32 * SA;
+
+  for (int it = 0; it < NI; ++it) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      float4 v = ra[i];
+      if (PRO != SE_PRO_NONE && aok[i]) v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], g.ps, g.pb);
+      *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * SA + kq * 4]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<float4*>(&Bs[(r0 + i * RPP) * SA + kq * 4]) = rb[i];
+    __syncthreads();
+    if (it + 1 < NI) load_tiles(it + 1);
+#pragma unroll
+    for (int s4 = 0; s4 < BK / 2; s4 += 4) {
+      float4 a = *reinterpret_cast<const float4*>(Ap + s4);
+      float4 b0 = *reinterpret_cast<const float4*>(Bp0 + s4);
+      float4 b1 = *reinterpret_cast<const float4*>(Bp1 + s4);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------ epilogue ------------------------------
+  const int ep = d.epilogue;
+  const int col = lane & 31, half = lane >> 5;
+  int n0, n1;           // original output-channel index of the two accumulators' column
+  bool nok0, nok1;
+  if (glu) {
+    n0 = by * 32 + col; n1 = d.N / 2 + n0;
+    nok0 = nok1 = n0 < d.N / 2;
+  } else {
+    n0 = by * 64 + col; n1 = n0 + 32;
+    nok0 = n0 < d.N; nok1 = n1 < d.N;
+  }
+  float bias0 = 0.f, bias1 = 0.f;
+  if (ep & SE_EPI_BIAS) {
+    if (nok0) bias0 = g.bias[n0];
+    if (nok1) bias1 = g.bias[n1];
+  }
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  const int No = d.N / 2;   // SHUFFLE2 / GLU output channels
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    int m = m0 + row;
+    if (m >= Mb) continue;
+    long p = (long)b * Mb + m;
+    float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+    if (ep & SE_EPI_STATS) { if (nok0) { s0 += v0; q0 += v0 * v0; } if (nok1) { s1 += v1; q1 += v1 * v1; } }
+    if (glu) {
+      if (nok0) {
+        if (g.AUX) { g.AUX[p * d.ldx + d.x_off + n0] = v0; g.AUX[p * d.ldx + d.x_off + n1] = v1; }
+        g.Y[p * d.ldc + d.c_off + n0] = v0 * sigmoidf_(v1);
+      }
+      continue;
+    }
+    if (ep & SE_EPI_SWISH_GRAD) {
+      if (nok0) v0 *= swish_gradf_(g.AUX[p * d.ldx + d.x_off + n0]);
+      if (nok1) v1 *= swish_gradf_(g.AUX[p * d.ldx + d.x_off + n1]);
+    }
+    if (ep & SE_EPI_RESID) {
+      if (nok0) v0 = g.R[p * d.ldr + d.r_off + n0] + d.alpha * v0;
+      if (nok1) v1 = g.R[p * d.ldr + d.r_off + n1] + d.alpha * v1;
+    }
+    if (ep & SE_EPI_SHUFFLE2) {
+      int t = m / d.Fo, f = m - t * d.Fo;
+      if (nok0) { long po = ((long)b * d.To + t) * (2 * d.Fo) + 2 * f + (n0 >= No);
+                  g.Y[po * d.ldc + d.c_off + (n0 >= No ? n0 - No : n0)] = v0; }
+      if (nok1) { long po = ((long)b * d.To + t) * (2 * d.Fo) + 2 * f + (n1 >= No);
+                  g.Y[po * d.ldc + d.c_off + (n1 >= No ? n1 - No : n1)] = v1; }
+      continue;
+    }
+    float* y = g.Y + p * d.ldc + d.c_off;
+    if (ep & SE_EPI_ACCUM) { if (nok0) y[n0] += v0; if (nok1) y[n1] += v1; }
+    else { if (nok0) y[n0] = v0; if (nok1) y[n1] = v1; }
+  }
+  if (ep & SE_EPI_STATS) {
+    // rows live in registers (16 per lane) and in the two lane halves: fold halves, then waves via LDS
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+    if (half == 0) {
+      red[(wave * 64 + col) * 2] = s0; red[(wave * 64 + col) * 2 + 1] = q0;
+      red[(wave * 64 + 32 + col) * 2] = s1; red[(wave * 64 + 32 + col) * 2 + 1] = q1;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+      int n = by * 64 + tid;
+      if (n < d.N) {
+        int ns = (ep & SE_EPI_SHUFFLE2) ? (n >= No ? n - No : n) : n;
+        int Ns = (ep & SE_EPI_SHUFFLE2) ? No : d.N;
+        atomicAdd(&g.stats[((long)b * Ns + ns) * 2], (double)s);
+        atomicAdd(&g.stats[((long)b * Ns + ns) * 2 + 1], (double)q);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  dW[n][tap*C + c] += sum_m dY[m][n] * pro(A[src(m,tap)][c])
+// grid: (row chunks, ntap * ceil(C/64), ceil(N/64)); 4 waves = 2x2 tiles of 32(n) x 32(c).
+struct WgradArgs {
+  se_gemm_desc d;
+  const float* A; const float* dY; float* dW; float* dbias;
+  const float* rowstats; const float* ps; const float* pb;
+  long rows_per_chunk;
+};
+
+template <int PRO>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
+  constexpr int SY = 68;            // 64 + 4 pad (float4-aligned rows)
+  __shared__ __attribute__((aligned(16))) float Ys[32 * SY];
+  __shared__ __attribute__((aligned(16))) float Xs[32 * SY];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64;
+  const int tap = blockIdx.y / ncb, cb = blockIdx.y - tap * ncb, nb = blockIdx.z;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)blockIdx.x * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, r0 = tid >> 4;    // float4 column / tile row (2 passes of 16 rows)
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && blockIdx.y == 0;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+
+  const int n_ld = nb * 64 + q * 4;        // dY column of this thread's float4
+  const int c_ld = cb * 64 + q * 4;        // A channel of this thread's float4
+  const bool nok = n_ld < d.N;             // N multiple of 4 assumed for vector loads (checked on host)
+  const bool cok = c_ld < d.C;
+
+  float4 ry[2], rx[2];
+  float mean[2], rstd[2];
+  bool xok[2];
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      long mg = mbase + r0 + i * 16;
+      bool ok = mg < mend;
+      int b = 0, t = 0, f = 0;
+      if (ok) { b = (int)(mg / Mb); int m = (int)(mg - (long)b * Mb); t = m / d.Fo; f = m - t * d.Fo; }
+      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(g.dY + mg * d.ldc + d.c_off + n_ld)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      long p = (ok && cok) ? src_pixel(d, b, t, f, tap) : -1;
+      xok[i] = p >= 0;
+      rx[i] = xok[i] ? *reinterpret_cast<const float4*>(g.A + p * d.lda + d.a_off + c_ld)
+                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO == SE_PRO_LN) {
+        mean[i] = xok[i] ? g.rowstats[2 * p] : 0.f;
+        rstd[i] = xok[i] ? g.rowstats[2 * p + 1] : 0.f;
+      }
+    }
+  };
+
+  if (mbeg < mend) load_tiles(mbeg);
+  for (long mb = mbeg; mb < mend; mb += 32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v = rx[i];
+      if (PRO != SE_PRO_NONE && xok[i]) v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], g.ps, g.pb);
+      *reinterpret_cast<float4*>(&Xs[(r0 + i * 16) * SY + q * 4]) = v;
+      *reinterpret_cast<float4*>(&Ys[(r0 + i * 16) * SY + q * 4]) = ry[i];
+    }
+    __syncthreads();
+    if (mb + 32 < mend) load_tiles(mb + 32);
+    const float* yp = &Ys[(lane >> 5) * 16 * SY + wn * 32 + (lane & 31)];
+    const float* xp = &Xs[(lane >> 5) * 16 * SY + wc * 32 + (lane & 31)];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s * SY], xp[s * SY], acc, 0, 0, 0);
+    if (do_bias && tid < 64) {
+#pragma unroll
+      for (int r = 0; r < 32; ++r) bsum += Ys[r * SY + tid];
+    }
+    __syncthreads();
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[r]);
+  }
+  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], bsum);
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void repack_kernel(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt,
+                              long si, int rev, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)No * Nt * Ni;
+  if (idx >= total) return;
+  int i = (int)(idx % Ni);
+  int t = (int)((idx / Ni) % Nt);
+  int o = (int)(idx / ((long)Ni * Nt));
+  int is = i, os = o;
+  if (rev == 1) { int ns = Ni / 64; is = (ns - 1 - i / 64) * 64 + (i & 63); }
+  if (rev == 2) { int ns = No / 64; os = (ns - 1 - o / 64) * 64 + (o & 63); }
+  float v = src[os * so + is * si + t * stt];
+  if (accumulate) dst[idx] += v; else dst[idx] = v;
+}
+
+// scatter form used to fold a packed gradient back into the PyTorch layout:
+// dst[o*so + i*si + t*stt] (+)= src[o][t][i]
+__global__ void unpack_kernel(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt,
+                              long si, int rev, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long total = (long)No * Nt * Ni;
+  if (idx >= total) return;
+  int i = (int)(idx % Ni);
+  int t = (int)((idx / Ni) % Nt);
+  int o = (int)(idx / ((long)Ni * Nt));
+  int is = i, os = o;
+  if (rev == 1) { int ns = Ni / 64; is = (ns - 1 - i / 64) * 64 + (i & 63); }
+  if (rev == 2) { int ns = No / 64; os = (ns - 1 - o / 64) * 64 + (o & 63); }
+  float* p = &dst[os * so + is * si + t * stt];
+  if (accumulate) *p += src[idx]; else *p = src[idx];
+}
+
+// ---------------------------------------------------------------------------------------------
+static int check_desc(const se_gemm_desc* d) {
+  SE_REQUIRE(d->ntap >= 1 && d->ntap <= SE_MAX_TAPS, "gemm: ntap %d out of range", d->ntap);
+  SE_REQUIRE(d->C > 0 && (d->C % 4) == 0, "gemm: C=%d must be a positive multiple of 4", d->C);
+  SE_REQUIRE((d->lda % 4) == 0 && (d->a_off % 4) == 0, "gemm: lda/a_off must be multiples of 4");
+  SE_REQUIRE((d->ldw % 4) == 0 && d->ldw >= d->ntap * d->C, "gemm: ldw=%d too small / unaligned", d->ldw);
+  SE_REQUIRE(d->B > 0 && d->To > 0 && d->Fo > 0 && d->Ti > 0 && d->Fi > 0, "gemm: empty grid");
+  SE_REQUIRE(d->st >= 1 && d->sf >= 1, "gemm: bad strides");
+  SE_REQUIRE(d->N > 0, "gemm: N=%d", d->N);
+  if (d->prologue == SE_PRO_LN) SE_REQUIRE(d->ntap == 1, "gemm: LN prologue needs ntap==1");
+  return 0;
+}
+
+extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W, const float* bias,
+                           float* Y, const float* R, float* AUX, const float* rowstats,
+                           const float* pro_scale, const float* pro_shift, double* stats, void* stream) {
+  if (int e = check_desc(d)) return e;
+  const int ep = d->epilogue;
+  SE_REQUIRE(A && W && Y, "gemm: null operand");
+  SE_REQUIRE(!(ep & SE_EPI_BIAS) || bias, "gemm: bias flag without bias");
+  SE_REQUIRE(!(ep & SE_EPI_RESID) || R, "gemm: resid flag without R");
+  SE_REQUIRE(!(ep & SE_EPI_SWISH_GRAD) || AUX, "gemm: swish-grad flag without AUX");
+  SE_REQUIRE(!(ep & SE_EPI_STATS) || stats, "gemm: stats flag without buffer");
+  SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
+  if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
+  if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");
+  GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats};
+  const int Mb = d->To * d->Fo;
+  const int ncols = (ep & SE_EPI_GLU) ? cdiv(d->N / 2, 32) : cdiv(d->N, 64);
+  dim3 grid(cdiv(Mb, 128), ncols, d->B), block(256);
+  hipStream_t s = as_stream(stream);
+  const bool bk16 = d->C < 32;
+#define LAUNCH(BK, PRO) hipLaunchKernelGGL((gemm_tap_kernel<BK, PRO>), grid, block, 0, s, g)
+  switch (d->prologue) {
+    case SE_PRO_NONE: if (bk16) LAUNCH(16, SE_PRO_NONE); else LAUNCH(32, SE_PRO_NONE); break;
+    case SE_PRO_LN: if (bk16) LAUNCH(16, SE_PRO_LN); else LAUNCH(32, SE_PRO_LN); break;
+    case SE_PRO_SWISH: if (bk16) LAUNCH(16, SE_PRO_SWISH); else LAUNCH(32, SE_PRO_SWISH); break;
+    case SE_PRO_AFFINE_SWISH: if (bk16) LAUNCH(16, SE_PRO_AFFINE_SWISH); else LAUNCH(32, SE_PRO_AFFINE_SWISH); break;
+    default: return se_fail("gemm: unknown prologue %d", d->prologue);
+  }
+#undef LAUNCH
+  return se_check_launch("se_gemm_tap");
+}
+
+extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW,
+                                 float* dbias, const float* rowstats, const float* pro_scale,
+                                 const float* pro_shift, int chunks, void* stream) {
+  if (int e = check_desc(d)) return e;
+  SE_REQUIRE(A && dY && dW, "wgrad: null operand");
+  SE_REQUIRE((d->N % 4) == 0 && (d->ldc % 4) == 0 && (d->c_off % 4) == 0, "wgrad: N/ldc/c_off must be multiples of 4");
+  if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "wgrad: LN prologue operands");
+  if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "wgrad: affine prologue operands");
+  const long Mtot = (long)d->B * d->To * d->Fo;
+  if (chunks < 1) chunks = 1;
+  long rpc = (Mtot + chunks - 1) / chunks;
+  rpc = ((rpc + 31) / 32) * 32;
+  chunks = (int)((Mtot + rpc - 1) / rpc);
+  WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc};
+  dim3 grid(chunks, d->ntap * cdiv(d->C, 64), cdiv(d->N, 64)), block(256);
+  hipStream_t s = as_stream(stream);
+  switch (d->prologue) {
+    case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_NONE>), grid, block, 0, s, g); break;
+    case SE_PRO_LN: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_LN>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_SWISH>), grid, block, 0, s, g); break;
+    case SE_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_AFFINE_SWISH>), grid, block, 0, s, g); break;
+    default: return se_fail("wgrad: unknown prologue %d", d->prologue);
+  }
+  return se_check_launch("se_gemm_tap_wgrad");
+}
+
+extern "C" int se_repack(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt, long si,
+                         int rev, int accumulate, void* stream) {
+  SE_REQUIRE(src && dst && No > 0 && Nt > 0 && Ni > 0, "repack: bad arguments");
+  if (rev == 1) SE_REQUIRE(Ni % 64 == 0, "repack: slab reversal needs Ni %% 64 == 0");
+  if (rev == 2) SE_REQUIRE(No % 64 == 0, "repack: slab reversal needs No %% 64 == 0");
+  long total = (long)No * Nt * Ni;
+  hipLaunchKernelGGL(repack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), src, dst, No, Nt,
+                     Ni, so, stt, si, rev, accumulate);
+  return se_check_launch("se_repack");
+}
+
+extern "C" int se_unpack(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt, long si,
+                         int rev, int accumulate, void* stream) {
+  SE_REQUIRE(src && dst && No > 0 && Nt > 0 && Ni > 0, "unpack: bad arguments");
+  if (rev == 1) SE_REQUIRE(Ni % 64 == 0, "unpack: slab reversal needs Ni %% 64 == 0");
+  if (rev == 2) SE_REQUIRE(No % 64 == 0, "unpack: slab reversal needs No %% 64 == 0");
+  long total = (long)No * Nt * Ni;
+  hipLaunchKernelGGL(unpack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), src, dst, No, Nt,
+                     Ni, so, stt, si, rev, accumulate);
+  return se_check_launch("se_unpack");
+}

@@ -1,0 +1,87 @@
+"""Python side of the tap-GEMM family (csrc/se_gemm.hip): descriptors, weight packing, launches."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import GemmDesc
+
+
+def conv_taps(kh, kw, dil=(1, 1), pad=(0, 0)):
+    """tap offsets (dt, df) of a cross-correlation kernel, tap index = kh_i*kw + kw_i."""
+    return [(i * dil[0] - pad[0], j * dil[1] - pad[1]) for i in range(kh) for j in range(kw)]
+
+
+def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=None, st=1, sf=1, up=0,
+              prologue=L.PRO_NONE, epilogue=0, alpha=1.0, ldr=0, r_off=0, ldx=0, x_off=0):
+    d = GemmDesc()
+    d.B, d.To, d.Fo, d.Ti, d.Fi = B, To, Fo, Ti, Fi
+    d.st, d.sf, d.up = st, sf, up
+    d.ntap = len(taps)
+    for i, (dt, df) in enumerate(taps):
+        d.dt[i], d.df[i] = dt, df
+    d.C, d.lda, d.a_off = C_in, lda, a_off
+    d.N, d.ldc, d.c_off = N, ldc, c_off
+    d.ldw = ldw if ldw is not None else len(taps) * C_in
+    d.prologue, d.epilogue, d.alpha = prologue, epilogue, alpha
+    d.ldr, d.r_off, d.ldx, d.x_off = ldr, r_off, ldx, x_off
+    return d
+
+
+def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
+    """plain row GEMM: M rows, one tap."""
+    return make_desc(1, 1, M, 1, M, [(0, 0)], C_in, lda or C_in, N, ldc or N, **kw)
+
+
+def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb=None, stats=None):
+    L.check_cuda(A, W, Y, bias, R, AUX, rowstats, ps, pb, stats)
+    L.call('se_gemm_tap', C.byref(d), L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Y), L.ptr(R), L.ptr(AUX),
+           L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream())
+    return Y
+
+
+def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, chunks=None):
+    L.check_cuda(A, dY, dW, dbias, rowstats, ps, pb)
+    if chunks is None:
+        M = d.B * d.To * d.Fo
+        nblk = d.ntap * ((d.C + 63) // 64) * ((d.N + 63) // 64)
+        chunks = max(1, min((M + 255) // 256, (2048 + nblk - 1) // nblk))
+    L.call('se_gemm_tap_wgrad', C.byref(d), L.ptr(A), L.ptr(dY), L.ptr(dW), L.ptr(dbias), L.ptr(rowstats),
+           L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream())
+    return dW
+
+
+def repack(src, No, Nt, Ni, so, stt, si, rev=0, out=None, accumulate=False):
+    """dst[o][t][i] = src[o*so + i*si + t*stt]."""
+    if out is None:
+        out = torch.empty(No, Nt * Ni, device=src.device, dtype=torch.float32)
+    L.call('se_repack', L.ptr(src), L.ptr(out), C.c_int(No), C.c_int(Nt), C.c_int(Ni), C.c_long(so),
+           C.c_long(stt), C.c_long(si), C.c_int(rev), C.c_int(int(accumulate)), L.stream())
+    return out
+
+
+def unpack(src, dst, No, Nt, Ni, so, stt, si, rev=0, accumulate=False):
+    """dst[o*so + i*si + t*stt] (+)= src[o][t][i]."""
+    L.call('se_unpack', L.ptr(src), L.ptr(dst), C.c_int(No), C.c_int(Nt), C.c_int(Ni), C.c_long(so),
+           C.c_long(stt), C.c_long(si), C.c_int(rev), C.c_int(int(accumulate)), L.stream())
+    return dst
+
+
+def pack_conv_fwd(w, rev_slabs=False):
+    """PyTorch conv weight [N, Cin, kh, kw] -> [N][tap][Cin] (optionally un-reversing the
+    newest-first slab order of DilatedDenseNet)."""
+    N, Cin, kh, kw = w.shape
+    return repack(w, N, kh * kw, Cin, Cin * kh * kw, 1, kh * kw, rev=1 if rev_slabs else 0)
+
+
+def pack_conv_dgrad(w, rev_slabs=False):
+    """[N, Cin, kh, kw] -> [Cin][tap][N] for the input-gradient GEMM (taps negated by the caller)."""
+    N, Cin, kh, kw = w.shape
+    return repack(w, Cin, kh * kw, N, kh * kw, 1, Cin * kh * kw, rev=2 if rev_slabs else 0)
+
+
+def unpack_conv_wgrad(dwp, dw, rev_slabs=False, accumulate=False):
+    """packed gradient [N][tap][Cin] -> PyTorch layout [N, Cin, kh, kw]."""
+    N, Cin, kh, kw = dw.shape
+    return unpack(dwp, dw, N, kh * kw, Cin, Cin * kh * kw, 1, kh * kw, rev=1 if rev_slabs else 0,
+                  accumulate=accumulate)

@@ -1,0 +1,219 @@
+"""GPU parity of the tap-GEMM family against plain PyTorch fp32/fp64 references of the same op."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def G():
+    from speech_enhancement_amd import gemm, _lib
+    return gemm, _lib
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.mark.parametrize('M,Cin,N', [(1000, 64, 64), (257, 64, 192), (4096, 256, 64), (130, 128, 64),
+                                      (100, 16, 32), (100, 4, 16), (333, 400, 402)])
+def test_linear(G, M, Cin, N):
+    gemm, L = G
+    x, w, b = rnd(M, Cin, seed=1), rnd(N, Cin, seed=2, scale=Cin ** -0.5), rnd(N, seed=3)
+    y = torch.empty(M, N, device='cuda')
+    gemm.gemm_tap(gemm.linear_desc(M, Cin, N, epilogue=L.EPI_BIAS), x, w, y, bias=b)
+    ref = x.double() @ w.double().T + b.double()
+    assert relerr(y, ref) < 2e-6
+
+
+def test_prologues(G):
+    gemm, L = G
+    M, Cin, N = 777, 64, 256
+    x, w = rnd(M, Cin, seed=1) * 2 + 0.5, rnd(N, Cin, seed=2, scale=0.125)
+    g, b = rnd(Cin, seed=4) * 0.1 + 1, rnd(Cin, seed=5) * 0.1
+    mean = x.mean(-1)
+    rstd = (x.var(-1, unbiased=False) + 1e-5).rsqrt()
+    stats = torch.stack([mean, rstd], -1).contiguous()
+    y = torch.empty(M, N, device='cuda')
+    gemm.gemm_tap(gemm.linear_desc(M, Cin, N, prologue=L.PRO_LN), x, w, y, rowstats=stats, ps=g, pb=b)
+    ref = F.layer_norm(x.double(), (Cin,), g.double(), b.double(), 1e-5) @ w.double().T
+    assert relerr(y, ref) < 5e-6
+    gemm.gemm_tap(gemm.linear_desc(M, Cin, N, prologue=L.PRO_SWISH), x, w, y)
+    assert relerr(y, F.silu(x.double()) @ w.double().T) < 5e-6
+    gemm.gemm_tap(gemm.linear_desc(M, Cin, N, prologue=L.PRO_AFFINE_SWISH), x, w, y, ps=g, pb=b)
+    assert relerr(y, F.silu(x.double() * g.double() + b.double()) @ w.double().T) < 5e-6
+
+
+def test_epilogues(G):
+    gemm, L = G
+    M, Cin, N = 500, 64, 256
+    x, w, b = rnd(M, Cin, seed=1), rnd(N, Cin, seed=2, scale=0.125), rnd(N, seed=3)
+    lin = x.double() @ w.double().T + b.double()
+    # GLU (+ pre-GLU Z)
+    y = torch.empty(M, N // 2, device='cuda')
+    z = torch.empty(M, N, device='cuda')
+    d = gemm.linear_desc(M, Cin, N, ldc=N // 2, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=N)
+    gemm.gemm_tap(d, x, w, y, bias=b, AUX=z)
+    assert relerr(z, lin) < 2e-6
+    assert relerr(y, lin[:, :N // 2] * torch.sigmoid(lin[:, N // 2:])) < 2e-6
+    # residual with alpha
+    r = rnd(M, N, seed=7)
+    y = torch.empty(M, N, device='cuda')
+    gemm.gemm_tap(gemm.linear_desc(M, Cin, N, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=0.5, ldr=N), x, w, y, bias=b, R=r)
+    assert relerr(y, r.double() + 0.5 * lin) < 2e-6
+    # accumulate into a slab of a wider buffer
+    buf = rnd(M, 512, seed=8)
+    ref = buf.double().clone()
+    ref[:, 128:128 + N] += lin
+    gemm.gemm_tap(gemm.linear_desc(M, Cin, N, ldc=512, c_off=128, epilogue=L.EPI_BIAS | L.EPI_ACCUM), x, w, buf, bias=b)
+    assert relerr(buf, ref) < 2e-6
+    # swish-grad
+    zz = rnd(M, N, seed=9)
+    gemm.gemm_tap(gemm.linear_desc(M, Cin, N, epilogue=L.EPI_BIAS | L.EPI_SWISH_GRAD, ldx=N), x, w, y, bias=b, AUX=zz)
+    s = torch.sigmoid(zz.double())
+    assert relerr(y, lin * (s * (1 + zz.double() * (1 - s)))) < 2e-6
+
+
+def _conv_case(G, B, T, Fq, Cin, N, kh, kw, dil, pad, stride=(1, 1), lda=None, a_off=0, seed=0):
+    gemm, L = G
+    lda = lda or Cin
+    xbuf = rnd(B, T, Fq, lda, seed=seed)
+    x = xbuf[..., a_off:a_off + Cin]
+    w = rnd(N, Cin, kh, kw, seed=seed + 1, scale=(Cin * kh * kw) ** -0.5)
+    b = rnd(N, seed=seed + 2)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=stride, padding=pad,
+                   dilation=dil).permute(0, 2, 3, 1).contiguous()
+    To, Fo = ref.shape[1], ref.shape[2]
+    taps = gemm.conv_taps(kh, kw, dil, pad)
+    wp = gemm.pack_conv_fwd(w)
+    d = gemm.make_desc(B, To, Fo, T, Fq, taps, Cin, lda, N, N, a_off=a_off, st=stride[0], sf=stride[1],
+                       epilogue=L.EPI_BIAS | L.EPI_STATS)
+    y = torch.empty(B, To, Fo, N, device='cuda')
+    stats = torch.zeros(B, N, 2, device='cuda', dtype=torch.float64)
+    gemm.gemm_tap(d, xbuf, wp, y, bias=b, stats=stats)
+    assert relerr(y, ref) < 3e-6
+    assert relerr(stats[..., 0], ref.sum((1, 2))) < 1e-5
+    assert relerr(stats[..., 1], (ref ** 2).sum((1, 2))) < 1e-5
+    return xbuf, x, w, b, ref, taps
+
+
+def test_dilated_conv_from_skip_stack(G):
+    # DilatedDenseNet layer 3: dilation 4 on T, causal pad (top only), input = 3 slabs of a 256-wide stack
+    gemm, L = G
+    B, T, Fq = 2, 21, 37
+    xbuf = rnd(B, T, Fq, 256, seed=3)
+    w = rnd(64, 192, 2, 3, seed=4, scale=0.03)
+    b = rnd(64, seed=5)
+    x = xbuf[..., :192].permute(0, 3, 1, 2).double()
+    ref = F.conv2d(F.pad(x, (1, 1, 4, 0)), w.double(), b.double(), dilation=(4, 1)).permute(0, 2, 3, 1)
+    taps = gemm.conv_taps(2, 3, (4, 1), (4, 1))
+    wp = gemm.pack_conv_fwd(w)
+    d = gemm.make_desc(B, T, Fq, T, Fq, taps, 192, 256, 64, 64, epilogue=L.EPI_BIAS)
+    y = torch.empty(B, T, Fq, 64, device='cuda')
+    gemm.gemm_tap(d, xbuf, wp, y, bias=b)
+    assert relerr(y, ref) < 3e-6
+    # slab-reversed packing: reference channel order newest-first
+    w_ref = torch.cat([w[:, 128:192], w[:, 64:128], w[:, 0:64]], 1).contiguous()
+    wp2 = gemm.pack_conv_fwd(w_ref, rev_slabs=True)
+    assert torch.equal(wp, wp2)
+
+
+def test_conv_variants(G):
+    _conv_case(G, 2, 9, 41, 64, 64, 1, 3, (1, 1), (0, 1), stride=(1, 2))          # encoder conv_2
+    _conv_case(G, 2, 9, 21, 64, 128, 1, 3, (1, 1), (0, 1))                          # sub-pixel conv
+    _conv_case(G, 2, 41, 33, 4, 16, 4, 4, (1, 1), (1, 1), stride=(2, 2), seed=5)    # D layer 1 (C padded to 4)
+    _conv_case(G, 2, 20, 16, 16, 32, 4, 4, (1, 1), (1, 1), stride=(2, 2), seed=6)   # D layer 2
+    _conv_case(G, 1, 12, 10, 64, 128, 4, 4, (1, 1), (1, 1), stride=(2, 2), seed=7)  # D layer 4
+
+
+def test_shuffle2(G):
+    gemm, L = G
+    B, T, Fq, Cin = 2, 5, 11, 64
+    x = rnd(B, T, Fq, Cin, seed=1)
+    w = rnd(128, Cin, 1, 3, seed=2, scale=0.07)
+    b = rnd(128, seed=3)
+    conv = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=(0, 1))   # [B,128,T,F]
+    ref = conv.view(B, 2, 64, T, Fq).permute(0, 2, 3, 4, 1).reshape(B, 64, T, 2 * Fq).permute(0, 2, 3, 1)
+    d = gemm.make_desc(B, T, Fq, T, Fq, gemm.conv_taps(1, 3, (1, 1), (0, 1)), Cin, Cin, 128, 64,
+                       epilogue=L.EPI_BIAS | L.EPI_SHUFFLE2 | L.EPI_STATS)
+    y = torch.empty(B, T, 2 * Fq, 64, device='cuda')
+    stats = torch.zeros(B, 64, 2, device='cuda', dtype=torch.float64)
+    gemm.gemm_tap(d, x, gemm.pack_conv_fwd(w), y, bias=b, stats=stats)
+    assert relerr(y, ref) < 3e-6
+    assert relerr(stats[..., 0], ref.sum((1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize('case', ['dilated', 'strided', 'dconv'])
+def test_conv_backward(G, case):
+    gemm, L = G
+    if case == 'dilated':
+        B, T, Fq, Cin, N, kh, kw, dil, pad, stride = 2, 19, 23, 128, 64, 2, 3, (2, 1), (2, 1), (1, 1)
+    elif case == 'strided':
+        B, T, Fq, Cin, N, kh, kw, dil, pad, stride = 2, 7, 41, 64, 64, 1, 3, (1, 1), (0, 1), (1, 2)
+    else:
+        B, T, Fq, Cin, N, kh, kw, dil, pad, stride = 2, 20, 17, 16, 32, 4, 4, (1, 1), (1, 1), (2, 2)
+    x = rnd(B, T, Fq, Cin, seed=1).double().requires_grad_(True)
+    w = rnd(N, Cin, kh, kw, seed=2, scale=(Cin * kh * kw) ** -0.5).double().requires_grad_(True)
+    b = rnd(N, seed=3).double().requires_grad_(True)
+    xin = x.permute(0, 3, 1, 2)
+    if case == 'dilated':
+        out = F.conv2d(F.pad(xin, (1, 1, 2, 0)), w, b, dilation=dil)
+    else:
+        out = F.conv2d(xin, w, b, stride=stride, padding=pad, dilation=dil)
+    out = out.permute(0, 2, 3, 1)
+    To, Fo = out.shape[1], out.shape[2]
+    dy = rnd(B, To, Fo, N, seed=9)
+    out.backward(dy.double())
+    taps = gemm.conv_taps(kh, kw, dil, pad)
+    x32, w32 = x.detach().float().contiguous(), w.detach().float().contiguous()
+    # input gradient: same kernel, transposed packing, negated taps, up-mode for strides
+    wd = gemm.pack_conv_dgrad(w32)
+    dd = gemm.make_desc(B, T, Fq, To, Fo, [(-a, -c) for a, c in taps], N, N, Cin, Cin,
+                        st=stride[0], sf=stride[1], up=1 if stride != (1, 1) else 0)
+    dx = torch.empty(B, T, Fq, Cin, device='cuda')
+    gemm.gemm_tap(dd, dy, wd, dx)
+    assert relerr(dx, x.grad) < 5e-6
+    # weight / bias gradient
+    dwp = torch.zeros(N, kh * kw * Cin, device='cuda')
+    db = torch.zeros(N, device='cuda')
+    fd = gemm.make_desc(B, To, Fo, T, Fq, taps, Cin, Cin, N, N, st=stride[0], sf=stride[1])
+    gemm.gemm_tap_wgrad(fd, x32, dy, dwp, db)
+    dw = torch.zeros(N, Cin, kh, kw, device='cuda')
+    gemm.unpack_conv_wgrad(dwp, dw)
+    assert relerr(dw, w.grad) < 2e-5
+    assert relerr(db, b.grad) < 2e-5
+
+
+def test_wgrad_prologues(G):
+    gemm, L = G
+    M, Cin, N = 3001, 64, 256
+    x, dy = rnd(M, Cin, seed=1) + 0.3, rnd(M, N, seed=2)
+    g, b = rnd(Cin, seed=4) * 0.1 + 1, rnd(Cin, seed=5) * 0.1
+    stats = torch.stack([x.mean(-1), (x.var(-1, unbiased=False) + 1e-5).rsqrt()], -1).contiguous()
+    for pro, fn in ((L.PRO_LN, lambda v: F.layer_norm(v, (Cin,), g.double(), b.double(), 1e-5)),
+                    (L.PRO_SWISH, F.silu),
+                    (L.PRO_AFFINE_SWISH, lambda v: F.silu(v * g.double() + b.double())),
+                    (L.PRO_NONE, lambda v: v)):
+        dw = torch.zeros(N, Cin, device='cuda')
+        db = torch.zeros(N, device='cuda')
+        gemm.gemm_tap_wgrad(gemm.linear_desc(M, Cin, N, prologue=pro), x, dy, dw, db, rowstats=stats, ps=g, pb=b)
+        assert relerr(dw, dy.double().T @ fn(x.double())) < 2e-5, pro
+        assert relerr(db, dy.double().sum(0)) < 2e-5
+
+
+def test_missing_operand_is_loud(G):
+    gemm, L = G
+    x, w = rnd(64, 64), rnd(64, 64)
+    y = torch.empty(64, 64, device='cuda')
+    with pytest.raises(L.SeHipError):
+        gemm.gemm_tap(gemm.linear_desc(64, 64, 64, epilogue=L.EPI_BIAS), x, w, y)
+    with pytest.raises(L.SeHipError):
+        gemm.gemm_tap(gemm.linear_desc(64, 64, 64), x.cpu(), w, y)
