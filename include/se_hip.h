@@ -77,28 +77,104 @@ int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, fl
 int se_repack(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt, long si,
               int rev, int accumulate, void* stream);
 
-/* ---- norms / elementwise (se_norms.hip, se_elem.hip) -------------------------------------- */
-/* per-row mean / rstd over C channels (LayerNorm statistics, models/conformer.py:67,162,204) */
+int se_unpack(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt, long si,
+              int rev, int accumulate, void* stream);
+
+/* ---- normalisation (csrc/se_norms.hip) ------------------------------------------------------ */
+/* per-row (mean, rstd) over C=64 channels: the statistics of every nn.LayerNorm(64) that feeds a GEMM
+ * prologue (models/conformer.py:67,162) */
 int se_row_stats(const float* X, float* stats, long M, int C, int ld, float eps, void* stream);
-/* Y = LN(X)*g + b (+ R): the ConformerBlock post_norm + TSCB residual (conformer.py:211, generator.py:70,72) */
+/* Y = LN(X)*g + b (+ R): ConformerBlock.post_norm + the TSCB residual (conformer.py:204,211;
+ * generator.py:70,72).  stats (optional) receives (mean, rstd) per row. */
 int se_layernorm_fwd(const float* X, const float* g, const float* b, const float* R, float* Y,
                      float* stats, long M, int C, float eps, void* stream);
-/* dX (+)= LN backward; dg, db accumulated with atomics (must be zeroed) */
-int se_layernorm_bwd(const float* X, const float* stats, const float* g, const float* dY, float* dX,
-                     float* dg, float* db, long M, int C, int accumulate, int affine_in_dy, void* stream);
-/* InstanceNorm2d(affine)+PReLU apply from fp64 (sum, sumsq) stats: Y[..c_off+c] (generator.py:21-22 etc.) */
-int se_inorm_prelu_fwd(const float* X, int ldx, const double* stats, const float* g, const float* b,
-                       const float* slope, float* Y, int ldy, int y_off, int B, long P, int C,
-                       float eps, void* stream);
-int se_inorm_prelu_bwd_reduce(const float* X, int ldx, const double* stats, const float* g, const float* b,
-                              const float* slope, const float* dY, int ldy, int y_off, double* red,
-                              int B, long P, int C, float eps, void* stream);
-int se_inorm_prelu_bwd_apply(const float* X, int ldx, const double* stats, const float* g, const float* b,
-                             const float* slope, const float* dY, int ldy, int y_off, const double* red,
-                             float* dX, float* dg, float* db, float* dslope, int B, long P, int C,
-                             float eps, void* stream);
-/* column statistics (sum, sumsq) of X[M][C] per batch into fp64 stats[B][C][2] (atomics, zeroed by caller) */
+/* dX = (dR) + (dR2) + LayerNorm backward of dY; dg += sum dY*xhat, db += sum dY (fp32 atomics; caller zeroes) */
+int se_layernorm_bwd(const float* X, const float* stats, const float* g, const float* dY,
+                     const float* dR, const float* dR2, float* dX, float* dg, float* db, long M, int C,
+                     void* stream);
+/* stats[b][c][2] += (sum, sumsq) over the P pixels of batch b (fp64 atomics; caller zeroes).  Feeds
+ * nn.InstanceNorm2d (generator.py:21,40,46,101,120; discriminator.py:40-49) and nn.BatchNorm1d
+ * (conformer.py:167) when the producer kernel did not already emit them. */
 int se_col_stats(const float* X, int ld, int x_off, double* stats, int B, long P, int C, void* stream);
+/* (sum, sumsq) -> mr[nb][C][2] = (mean, rstd) and ss[nb][C][2] = (rstd*g, beta - mean*rstd*g); when
+ * running_mean != NULL also the BatchNorm running-statistics update (momentum, unbiased var). */
+int se_norm_finalize(const double* stats, const float* g, const float* beta, float* mr, float* ss,
+                     int nb, int C, double count, float eps, float* running_mean, float* running_var,
+                     float momentum, void* stream);
+int se_bn_eval_scale(const float* rm, const float* rv, const float* g, const float* beta, float* ss,
+                     float* mr, int C, float eps, void* stream);
+/* Y[.., y_off+c] = prelu(X*scale + shift): the apply pass of InstanceNorm2d(affine)+PReLU */
+int se_affine_prelu(const float* X, int ldx, int x_off, const float* ss, const float* slope, float* Y,
+                    int ldy, int y_off, int B, long P, int C, void* stream);
+/* backward of Y = act(xhat*g + beta), act = PReLU (act=0; slope NULL = identity) or Swish (act=1), for
+ * instance (per_batch=1) or batch (per_batch=0; BatchNorm1d+Swish, conformer.py:167-168) statistics;
+ * red: workspace double[nb][C][3]; dg/dbeta/dslope accumulate.  phase bits: 1 = reduction, 4 = parameter
+ * gradients (from the local sums), 2 = apply (data-parallel SyncBatchNorm all-reduces `red` between 1|4 and 2); count = elements per
+ * statistic (global count under SyncBatchNorm). */
+int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const float* g,
+                      const float* beta, const float* slope, const float* dY, int ldy, int y_off,
+                      double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,
+                      float* dslope, int B, long P, int C, int per_batch, int act, int phase, double count,
+                      void* stream);
+
+/* ---- fused relative-position attention (csrc/se_attn.hip) ----------------------------------- */
+/* Attention.forward without the projections (models/conformer.py:103-122): QKV [tokens][192] (q|k|v, head h =
+ * columns 16h..16h+15 of each third), E = rel_pos_emb.weight [2*maxpos+1][16] -> O [tokens][64], LSE
+ * [tokens][4].  token(s,p) = (s/inner)*outer_stride + (s%inner)*inner_stride + p*pos_stride. */
+int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq, int n, int inner,
+                long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
+/* backward: dQKV [tokens][192] written, dE accumulated (atomics; caller zeroes); Dl = workspace [tokens][4] */
+int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
+                float* Dl, float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
+                long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* stream);
+
+/* ---- depthwise conv k=31 along the sequence axis (csrc/se_dwconv.hip) -------------------------- */
+/* DepthWiseConv1d forward (models/conformer.py:40-48,166) on [tokens][128] (+ fp64 BatchNorm statistics
+ * [128][2] when stats != NULL); flip=1 with bias=NULL is the input gradient. */
+int se_dwconv31(const float* X, const float* W, const float* bias, float* Y, double* stats, int flip,
+                int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, void* stream);
+int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, float* dbias, int nseq, int n, int inner,
+                      long outer_stride, long inner_stride, long pos_stride, void* stream);
+
+/* ---- front-end glue, output assembly, losses, optimizers (csrc/se_elem.hip) --------------------- */
+/* normalize_batch (core/function.py:647-659): c[b] = sqrt(L / sum x^2) */
+int se_clip_scale(const float* x, float* c, int B, int L, void* stream);
+/* center=True reflect padding of torch.stft (core/function.py:690) fused with the clip scale */
+int se_reflect_pad_scale(const float* x, const float* c, float* xp, int B, int L, int pad, void* stream);
+int se_reflect_pad_bwd(const float* dxp, const float* c, float* dx, int B, int L, int pad, void* stream);
+/* power_compress / power_uncompress (core/function.py:625-645); comp: 0 none, 1 pow 0.3, 2 log1p */
+int se_compress_planes(const float* R, int ldr, float* P, long rows, int F, int comp, float pre_scale, void* stream);
+int se_compress_planes_bwd(const float* R, int ldr, const float* dP, float* dR, long rows, int F, int comp,
+                           float pre_scale, void* stream);
+int se_uncompress_rows(const float* P, float* A, int lda, long rows, int F, int comp, float post_scale, void* stream);
+int se_uncompress_rows_bwd(const float* P, const float* dA, int lda, float* dP, long rows, int F, int comp,
+                           float post_scale, void* stream);
+/* overlap-add / envelope division / trim of torch.istft (core/function.py:701-702) and its transpose */
+int se_ola(const float* Fr, const float* env, float* y, int B, int T, int n_fft, int hop, int trim, int L, void* stream);
+int se_ola_bwd(const float* dy, const float* env, float* dFr, int B, int T, int n_fft, int hop, void* stream);
+/* TSCNet output assembly (models/generator.py:158-167) and MaskDecoder tail (:110-112) */
+int se_assemble(const float* mask, int ldm, const float* nin, const float* cplx, float* est, long n, void* stream);
+int se_assemble_bwd(const float* est, const float* dest, const float* nin, float* dmask, int ldm, float* dcplx,
+                    long n, void* stream);
+int se_mask_tail(const float* U, int ldu, const float* wb, const float* slope, float* M, long n, int F, void* stream);
+int se_mask_tail_bwd(const float* U, int ldu, const float* wb, const float* slope, const float* dM, float* dU,
+                     double* dwb, float* dslope, long n, int F, void* stream);
+/* GLU backward (models/conformer.py:30-37) */
+int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, int H, void* stream);
+/* loss reductions of train_gan (core/function.py:251-258) and their gradient seeds (`up` = device scalars) */
+int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream);
+int se_spec_loss_bwd(const float* A, const float* Bp, float* dA, const float* up, float cmag, float cri, long n,
+                     int accumulate, void* stream);
+int se_l1_loss(const float* a, long lda, const float* b, long ldb, double* sums, long rows, int L, void* stream);
+int se_l1_loss_bwd(const float* a, long lda, const float* b, long ldb, float* da, const float* up, float ck,
+                   long rows, int L, void* stream);
+/* flat-buffer optimizers (core/optimizer.py:33-36) and the self-correcting-weight helpers (:719-752) */
+int se_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+             float wd, int step, void* stream);
+int se_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, float momentum, int first, void* stream);
+int se_dot(const float* a, const float* b, double* out, long n, void* stream);
+int se_axpbypcz(const float* a, const float* b, const float* c, float* y, float alpha, float beta, float gamma,
+                long n, void* stream);
 
 #ifdef __cplusplus
 }

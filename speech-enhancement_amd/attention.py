@@ -1,0 +1,39 @@
+"""Python side of the fused relative-position attention (csrc/se_attn.hip)."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def seq_geometry(B, T, Fq, axis):
+    """token = (b*T + t)*Fq + f.  axis 'time': sequences (b, f) over t (generator.py:69);
+    axis 'freq': sequences (b, t) over f (generator.py:71).
+    returns (nseq, n, inner, outer_stride, inner_stride, pos_stride)."""
+    if axis == 'time':
+        return (B * Fq, T, Fq, T * Fq, 1, Fq)
+    return (B * T, Fq, 1, Fq, 0, 1)
+
+
+def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True):
+    L.check_cuda(qkv, E)
+    ntok = qkv.shape[0]
+    O = torch.empty(ntok, 64, device=qkv.device, dtype=torch.float32)
+    lse = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32) if need_lse else None
+    nseq, n, inner, os_, is_, ps = geom
+    L.call('se_attn_fwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner),
+           C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos), C.c_float(scale), L.stream())
+    return O, lse
+
+
+def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
+    """returns dQKV [ntok,192]; accumulates into dE [2*maxpos+1, 16]."""
+    L.check_cuda(qkv, E, O, dO, lse, dE)
+    ntok = qkv.shape[0]
+    dqkv = torch.empty(ntok, 192, device=qkv.device, dtype=torch.float32)
+    dl = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32)
+    nseq, n, inner, os_, is_, ps = geom
+    L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dl), L.ptr(dqkv), L.ptr(dE),
+           C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
+           C.c_int(maxpos), C.c_float(scale), L.stream())
+    return dqkv

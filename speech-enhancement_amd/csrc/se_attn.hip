@@ -1,0 +1,501 @@
+// Fused Shaw-relative-position multi-head attention for the Conformer blocks (models/conformer.py:74-125),
+// fp32-exact on v_mfma_f32_16x16x4_f32.  heads = 4, dim_head = 16: one MFMA K-chain (4 steps) covers a head.
+//
+//   logits[i][j] = scale * ( q_i . k_j  +  q_i . E[clamp(i-j, -P, P) + P] ),  softmax over j,  out = P v
+//
+// Nothing n x n is ever written: per (sequence, head, 32-query block) one wave sweeps the keys 16 at a
+// time with an online softmax.  All three contractions are MFMAs:
+//   S^T  = K  . Q^T      (16 keys x 16 queries; query on the lane, 4 keys in the registers)
+//   U    = Ew . Q^T      (16 relative offsets x 16 queries) -> skewed through 2 KB of wave-private LDS
+//                         so that lane (query c, key j) picks U[c_abs - j]; the offset window slides by 16
+//                         per key step, so only ONE new U tile is computed per step (no 2x rel-pos work)
+//   O^T += V^T . P^T     (P^T's accumulator registers ARE the B operand: k-index g <-> key 4g+r)
+// K / V / E fragments are read straight from global memory (L2-resident, 64-B head rows); the fp32 MFMA
+// (32 cycles per 16x16x4) leaves the vector-memory pipe idle enough that LDS staging buys nothing here.
+//
+// Token geometry: token(s, p) = (s / inner) * outer_stride + (s % inner) * inner_stride + p * pos_stride, so
+// the time Conformer ([B*F', T, C] in the reference, generator.py:69) and the frequency Conformer
+// ([B*T, F', C], generator.py:71) both run on the one channels-last [B, T, F', C] buffer with no transposes.
+#include "se_common.h"
+
+struct AttnGeom {
+  int nseq, n;             // sequences, positions per sequence
+  int inner;               // sequences per outer group
+  long outer_stride, inner_stride, pos_stride;   // in tokens
+};
+
+struct AttnArgs {
+  AttnGeom g;
+  const float* QKV;  // [tokens][192]: q | k | v, head h at columns h*16 .. h*16+15 of each third
+  const float* E;    // [2*maxpos+1][16]
+  float* O;          // [tokens][64]
+  float* LSE;        // [tokens][4]   log-sum-exp of the scaled logits (natural log)
+  int maxpos;
+  float scale;
+};
+
+static __device__ __forceinline__ long tok_of(const AttnGeom& g, int s, int p) {
+  return (long)(s / g.inner) * g.outer_stride + (long)(s % g.inner) * g.inner_stride + (long)p * g.pos_stride;
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// one wave = one (sequence, head, 32-query block)
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  __shared__ float Ul[4][2][3][16 * 16];     // [wave][query tile][ring slot][rel row][query]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n = a.g.n;
+  const int qblocks = (n + 31) / 32;
+  long item = (long)blockIdx.x * 4 + wave;
+  const long nitems = (long)a.g.nseq * 4 * qblocks;
+  if (item >= nitems) return;
+  const int qb = (int)(item % qblocks);
+  const int head = (int)((item / qblocks) % 4);
+  const int seq = (int)(item / ((long)qblocks * 4));
+  const int i0 = qb * 32;
+  const float* qkv = a.QKV + head * 16;
+  const float l2e = 1.4426950408889634f * a.scale;
+
+  // Q^T fragments (B operand): lane (query c, kgrp g) supplies Q[i][4s+g]
+  float qf[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int qi = i0 + 16 * t + c;
+    if (qi > n - 1) qi = n - 1;
+    const float* qp = qkv + tok_of(a.g, seq, qi) * 192;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[t][s] = qp[4 * s + g];
+  }
+  f32x4 o[2][2];
+  float m[2], l[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    m[t] = -1e30f; l[t] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) o[t][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // relative-offset tiles: U_t(D) holds offsets delta in [D, D+15] for query tile t.
+  // For key tile j0 and query tile t: D0 = i0 + 16t - j0; needed tiles U_t(D0) (delta_local >= 0) and
+  // U_t(D0-16).  U_t(D0) of this step == U_t(D0'-16) of the previous step, so one new tile per step.
+  auto e_frag = [&](int D, float (&ef)[4]) {   // A operand: lane (row i=c, kgrp g) supplies E[clamp(D+c)][4s+g]
+    int d = D + c;
+    d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+    const float* ep = a.E + (long)(d + a.maxpos) * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) ef[s] = ep[4 * s + g];
+  };
+  auto u_tile = [&](const float (&ef)[4], int t, int slot) {
+    f32x4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) u = MFMA16(ef[s], qf[t][s], u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ul[wave][t][slot][(4 * g + r) * 16 + c] = u[r];
+  };
+  // prime: U_t(D0) for the first key tile (j0 = 0): D0 = i0 + 16t
+  {
+    float ef[4];
+    e_frag(i0, ef);        u_tile(ef, 0, 0);
+    e_frag(i0 + 16, ef);   u_tile(ef, 1, 0);
+  }
+  int slot_hi = 0;   // ring slot holding U_t(D0)
+  const int nkt = (n + 15) / 16;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int j0 = kt * 16;
+    const int slot_lo = slot_hi == 2 ? 0 : slot_hi + 1;
+    // new low tiles U_t(D0 - 16); the two query tiles need E rows 16 apart
+    float ef0[4], ef1[4];
+    e_frag(i0 - j0 - 16, ef0);
+    e_frag(i0 - j0, ef1);
+    u_tile(ef0, 0, slot_lo);
+    u_tile(ef1, 1, slot_lo);
+    // K fragment (A operand): lane (key c, kgrp g) supplies K[j0+c][4s+g]; V^T fragment: lane (d=c, g) supplies
+    // V[j0 + 4g + r][d] for PV step r
+    int kj = j0 + c;
+    if (kj > n - 1) kj = n - 1;
+    const float* kp = qkv + tok_of(a.g, seq, kj) * 192 + 64;
+    float kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[s] = kp[4 * s + g];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int vj = j0 + 4 * g + r;
+      if (vj > n - 1) vj = n - 1;
+      vf[r] = qkv[tok_of(a.g, seq, vj) * 192 + 128 + c];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) s4 = MFMA16(kf[s], qf[t][s], s4);
+      // add the skewed relative term, mask keys beyond n, online softmax
+      float sc[4], tmax = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int dl = c - (4 * g + r);                 // delta - D0, in [-15, 15]
+        float u = dl >= 0 ? Ul[wave][t][slot_hi][dl * 16 + c] : Ul[wave][t][slot_lo][(16 + dl) * 16 + c];
+        sc[r] = (j0 + 4 * g + r < n) ? (s4[r] + u) * l2e : -1e30f;
+        tmax = fmaxf(tmax, sc[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      float mn = fmaxf(m[t], tmax);
+      float corr = __builtin_amdgcn_exp2f(m[t] - mn);
+      m[t] = mn;
+      float p[4], ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mn); ps += p[r]; }
+      l[t] = l[t] * corr + ps;
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][e][r] *= corr;
+      // O^T[d][query] += V^T[d][key] * P^T[key][query]; two accumulators break the dependent chain
+      o[t][0] = MFMA16(vf[0], p[0], o[t][0]);
+      o[t][1] = MFMA16(vf[1], p[1], o[t][1]);
+      o[t][0] = MFMA16(vf[2], p[2], o[t][0]);
+      o[t][1] = MFMA16(vf[3], p[3], o[t][1]);
+    }
+    slot_hi = slot_lo;
+  }
+  // finish: the 4 lane groups of a query hold partial sums of l; O^T rows d = 4g+r live in the registers
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float lt = l[t];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    int qi = i0 + 16 * t + c;
+    if (qi < n) {
+      long tok = tok_of(a.g, seq, qi);
+      float inv = 1.0f / lt;
+      float4 ov = make_float4((o[t][0][0] + o[t][1][0]) * inv, (o[t][0][1] + o[t][1][1]) * inv,
+                              (o[t][0][2] + o[t][1][2]) * inv, (o[t][0][3] + o[t][1][3]) * inv);
+      *reinterpret_cast<float4*>(a.O + tok * 64 + head * 16 + 4 * g) = ov;
+      if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt)) * 0.6931471805599453f;
+    }
+  }
+}
+
+// delta[token][head] = sum_d dO * O  (softmax backward row constant)
+__global__ void attn_delta_kernel(const float* __restrict__ dO, const float* __restrict__ O, float* __restrict__ D,
+                                  long ntok) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (token, head, quarter) -> 4 floats
+  if (idx >= ntok * 16) return;
+  float4 a = *reinterpret_cast<const float4*>(dO + idx * 4);
+  float4 b = *reinterpret_cast<const float4*>(O + idx * 4);
+  float s = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if ((idx & 3) == 0) D[idx >> 2] = s;
+}
+
+struct AttnBwdArgs {
+  AttnGeom g;
+  const float* QKV; const float* E; const float* dO; const float* LSE; const float* Dl;
+  float* dQKV;      // [tokens][192]; dq written by the dq kernel, dk|dv by the dkv kernel
+  float* dE;        // [2*maxpos+1][16], accumulated with atomics
+  int maxpos;
+  float scale;
+};
+
+// ---- backward kernel 1: dK, dV.  One wave = (sequence, head, 32-key block); sweeps the queries 16 at a time.
+// Orientation: key on the lane:  S[q][k] tile C-layout row = query 4g+r, col = key c.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs a) {
+  __shared__ float Ul[4][2][3][16 * 16];     // [wave][key tile][-, hi, lo][query row][delta col]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n = a.g.n;
+  const int kblocks = (n + 31) / 32;
+  long item = (long)blockIdx.x * 4 + wave;
+  const long nitems = (long)a.g.nseq * 4 * kblocks;
+  if (item >= nitems) return;
+  const int kb = (int)(item % kblocks);
+  const int head = (int)((item / kblocks) % 4);
+  const int seq = (int)(item / ((long)kblocks * 4));
+  const int j0 = kb * 32;
+  const float* qkv = a.QKV + head * 16;
+  const float l2e = 1.4426950408889634f;
+
+  // K^T / V^T fragments as B operands (lane (key c, kgrp g) supplies K[j][4s+g]) for both key tiles
+  float kf[2][4], vf[2][4];
+  bool kvalid[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int kj = j0 + 16 * t + c;
+    kvalid[t] = kj < n;
+    if (kj > n - 1) kj = n - 1;
+    const float* kp = qkv + tok_of(a.g, seq, kj) * 192;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { kf[t][s] = kp[64 + 4 * s + g]; vf[t][s] = kp[128 + 4 * s + g]; }
+  }
+  f32x4 dk[2], dv[2];     // dK^T / dV^T tiles: row d = 4g+r, col key c
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { dk[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  // U_t(q0; D) = Q_tile . Ew(D)^T : rows = queries, cols = offsets delta in [D, D+15].
+  // For query tile q0 and key tile t: D0 = q0 - (j0+16t); lane (key c), row query 4g+r needs
+  // delta_local = (4g+r) - c in [-15,15] -> tile D0 (>=0) or D0-16 (<0).  The rows are the CURRENT queries,
+  // so (unlike the forward, where the rows are offsets) both tiles are recomputed per step.
+  auto u_tile = [&](const float (&qa)[4], int D, int t, int slot) {
+    // B operand: E^T: lane (delta col c, kgrp g) supplies E[clamp(D+c)][4s+g]
+    int d = D + c;
+    d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+    const float* ep = a.E + (long)(d + a.maxpos) * 16;
+    f32x4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) u = MFMA16(qa[s], ep[4 * s + g], u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ul[wave][t][slot][(4 * g + r) * 16 + c] = u[r];
+  };
+  const int nqt = (n + 15) / 16;
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int q0 = qt * 16;
+    // A operands: Q (lane (query row c, kgrp g) supplies Q[q0+c][4s+g]), dO likewise
+    int qi = q0 + c; if (qi > n - 1) qi = n - 1;
+    const long qtok = tok_of(a.g, seq, qi);
+    float qa[4], doa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { qa[s] = qkv[qtok * 192 + 4 * s + g]; doa[s] = a.dO[qtok * 64 + head * 16 + 4 * s + g]; }
+    // per-row (query 4g+r) constants
+    float lse[4], dl[4];
+    bool qvalid[4];
+    // A^T operands for the dK/dV products: lane (d = c, k-index g) supplies X[q0 + 4g + r][d]
+    float qT[4], doT[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int qr = q0 + 4 * g + r;
+      qvalid[r] = qr < n;
+      if (qr > n - 1) qr = n - 1;
+      long tk = tok_of(a.g, seq, qr);
+      lse[r] = a.LSE[tk * 4 + head];
+      dl[r] = a.Dl[tk * 4 + head];
+      qT[r] = qkv[tk * 192 + c];
+      doT[r] = a.dO[tk * 64 + head * 16 + c];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int D0 = q0 - (j0 + 16 * t);
+      u_tile(qa, D0, t, 1);
+      u_tile(qa, D0 - 16, t, 2);
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { s4 = MFMA16(qa[s], kf[t][s], s4); dp = MFMA16(doa[s], vf[t][s], dp); }
+      float p[4], ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int dlc = (4 * g + r) - c;
+        float u = dlc >= 0 ? Ul[wave][t][1][(4 * g + r) * 16 + dlc] : Ul[wave][t][2][(4 * g + r) * 16 + 16 + dlc];
+        float sv = (s4[r] + u) * a.scale;
+        bool ok = qvalid[r] && kvalid[t];
+        p[r] = ok ? __builtin_amdgcn_exp2f((sv - lse[r]) * l2e) : 0.f;
+        ds[r] = p[r] * (dp[r] - dl[r]) * a.scale;
+      }
+      // dV^T[d][key] += dO^T[d][q] * P[q][key];  dK^T[d][key] += Q^T[d][q] * dS[q][key]   (k-index g <-> query 4g+r)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dv[t] = MFMA16(doT[r], p[r], dv[t]); dk[t] = MFMA16(qT[r], ds[r], dk[t]); }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int kj = j0 + 16 * t + c;
+    if (kj < n) {
+      long tok = tok_of(a.g, seq, kj);
+      *reinterpret_cast<float4*>(a.dQKV + tok * 192 + 64 + head * 16 + 4 * g) = make_float4(dk[t][0], dk[t][1], dk[t][2], dk[t][3]);
+      *reinterpret_cast<float4*>(a.dQKV + tok * 192 + 128 + head * 16 + 4 * g) = make_float4(dv[t][0], dv[t][1], dv[t][2], dv[t][3]);
+    }
+  }
+}
+
+// ---- backward kernel 2: dQ and dE.  One wave = (sequence, head, 16-query tile), query on the lane (as forward).
+// dE is accumulated per workgroup in LDS over all the items the (persistent) workgroup processes and flushed
+// once with global atomics.
+template <int NPAD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int items_per_block) {
+  extern __shared__ float smem[];
+  // layout: dEacc [(2*NPAD) rows][16] | per-wave scratch: dU[2 slots... ] see below
+  float* dEacc = smem;                                 // rows: delta + NPAD, delta in [-NPAD, NPAD)
+  float* scratch = smem + 2 * NPAD * 16;               // [wave][4 tiles][256]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n = a.g.n;
+  float* Uf = scratch + wave * 4 * 256;                // forward skew tiles: [2][256]
+  float* dU = Uf + 2 * 256;                            // backward skew tiles: [2][256] (hi, lo)
+  for (int i = threadIdx.x; i < 2 * NPAD * 16; i += 256) dEacc[i] = 0.f;
+  __syncthreads();
+  const int qtiles = (n + 15) / 16;
+  const long nitems = (long)a.g.nseq * 4 * qtiles;
+  const long ibeg = (long)blockIdx.x * items_per_block;
+  const float l2e = 1.4426950408889634f;
+  const int nkt = (n + 15) / 16;
+  for (long it = ibeg + wave; it < ibeg + items_per_block && it < nitems; it += 4) {
+    const int qt = (int)(it % qtiles);
+    const int head = (int)((it / qtiles) % 4);
+    const int seq = (int)(it / ((long)qtiles * 4));
+    const int i0 = qt * 16;
+    const float* qkv = a.QKV + head * 16;
+    int qi = i0 + c;
+    const bool qok = qi < n;
+    if (qi > n - 1) qi = n - 1;
+    const long qtok = tok_of(a.g, seq, qi);
+    // B operands: Q^T, dO^T: lane (query c, kgrp g)
+    float qf[4], dof[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { qf[s] = qkv[qtok * 192 + 4 * s + g]; dof[s] = a.dO[qtok * 64 + head * 16 + 4 * s + g]; }
+    // A operand for dE: Q^T with lane (d = c, k-index g) supplying Q[i0 + 4g + r][d]
+    float qT[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int qr = i0 + 4 * g + r; if (qr > n - 1) qr = n - 1;
+      qT[r] = qkv[tok_of(a.g, seq, qr) * 192 + c];
+    }
+    const float lse = a.LSE[qtok * 4 + head], dlt = a.Dl[qtok * 4 + head];
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};      // dQ^T tile: row d = 4g+r, col query c
+    // zero the backward skew tiles
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dU[r * 64 + lane] = 0.f;
+    int hi = 0;    // dU slot holding offsets [D0, D0+15]
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int j0 = kt * 16;
+      const int D0 = i0 - j0;
+      const int lo = hi ^ 1;
+      // forward skew tiles U(D0), U(D0-16) for the logits
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int d = D0 - 16 * h + c;
+        d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+        const float* ep = a.E + (long)(d + a.maxpos) * 16;
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) u = MFMA16(ep[4 * s + g], qf[s], u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Uf[h * 256 + (4 * g + r) * 16 + c] = u[r];
+      }
+      int kj = j0 + c; if (kj > n - 1) kj = n - 1;
+      const float* kp = qkv + tok_of(a.g, seq, kj) * 192;
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { s4 = MFMA16(kp[64 + 4 * s + g], qf[s], s4); dp = MFMA16(kp[128 + 4 * s + g], dof[s], dp); }
+      float ds[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int dlc = c - (4 * g + r);
+        float u = dlc >= 0 ? Uf[dlc * 16 + c] : Uf[256 + (16 + dlc) * 16 + c];
+        float sv = (s4[r] + u) * a.scale;
+        bool ok = qok && (j0 + 4 * g + r < n);
+        float p = ok ? __builtin_amdgcn_exp2f((sv - lse) * l2e) : 0.f;
+        ds[r] = p * (dp[r] - dlt) * a.scale;
+        // scatter into the offset-major tiles (each (row, query) cell is hit by exactly one key)
+        if (dlc >= 0) dU[hi * 256 + dlc * 16 + c] += ds[r]; else dU[lo * 256 + (16 + dlc) * 16 + c] += ds[r];
+      }
+      // dQ^T[d][q] += K^T[d][key] * dS^T[key][q]   (A: lane (d=c, g) supplies K[j0+4g+r][d])
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int kr = j0 + 4 * g + r; if (kr > n - 1) kr = n - 1;
+        dq = MFMA16(qkv[tok_of(a.g, seq, kr) * 192 + 64 + c], ds[r], dq);
+      }
+      // tile `hi` (offsets [D0, D0+15]) is now complete: consume it
+      {
+        // dQ^T[d][q] += E^T[d][delta] * dU[delta][q]   (A: lane (d=c, g) supplies E[clamp(D0+4g+r)][d])
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int d = D0 + 4 * g + r;
+          d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+          dq = MFMA16(a.E[(long)(d + a.maxpos) * 16 + c], dU[hi * 256 + (4 * g + r) * 16 + c], dq);
+        }
+        // dE^T[d][delta] += Q^T[d][q] * dU^T[q][delta]   (B: lane (delta c, k-index g) supplies dU[delta c][q 4g+r])
+        f32x4 de = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) de = MFMA16(qT[r], dU[hi * 256 + c * 16 + 4 * g + r], de);
+        int d = D0 + c;
+        d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+        if (d >= -NPAD && d < NPAD) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(&dEacc[(d + NPAD) * 16 + 4 * g + r], de[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(&a.dE[(long)(d + a.maxpos) * 16 + 4 * g + r], de[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dU[hi * 256 + r * 64 + lane] = 0.f;
+      }
+      hi = lo;
+    }
+    // the last low tile (offsets [D0_last - 16, D0_last - 1]) still holds contributions
+    {
+      const int D0 = i0 - (nkt - 1) * 16 - 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int d = D0 + 4 * g + r;
+        d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+        dq = MFMA16(a.E[(long)(d + a.maxpos) * 16 + c], dU[hi * 256 + (4 * g + r) * 16 + c], dq);
+      }
+      f32x4 de = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) de = MFMA16(qT[r], dU[hi * 256 + c * 16 + 4 * g + r], de);
+      int d = D0 + c;
+      d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+      if (d >= -NPAD && d < NPAD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&dEacc[(d + NPAD) * 16 + 4 * g + r], de[r]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&a.dE[(long)(d + a.maxpos) * 16 + 4 * g + r], de[r]);
+      }
+    }
+    if (qok) *reinterpret_cast<float4*>(a.dQKV + qtok * 192 + head * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * NPAD * 16; i += 256) {
+    float v = dEacc[i];
+    int d = i / 16 - NPAD;
+    if (v != 0.f && d >= -a.maxpos && d <= a.maxpos) atomicAdd(&a.dE[(long)(d + a.maxpos) * 16 + (i & 15)], v);
+  }
+}
+
+static int check_geom(const AttnGeom& g) {
+  SE_REQUIRE(g.nseq > 0 && g.n > 0 && g.inner > 0, "attention: bad geometry");
+  return 0;
+}
+
+extern "C" int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq, int n, int inner,
+                           long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale,
+                           void* stream) {
+  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale};
+  if (int e = check_geom(a.g)) return e;
+  SE_REQUIRE(QKV && E && O, "attn_fwd: null operand");
+  long items = (long)nseq * 4 * ((n + 31) / 32);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(items, 4)), dim3(256), 0, as_stream(stream), a);
+  return se_check_launch("se_attn_fwd");
+}
+
+extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
+                           float* Dl, float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
+                           long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* stream) {
+  AttnBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, dO, LSE, Dl, dQKV, dE, maxpos, scale};
+  if (int e = check_geom(a.g)) return e;
+  SE_REQUIRE(QKV && E && O && dO && LSE && Dl && dQKV && dE, "attn_bwd: null operand");
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
+  long items = (long)nseq * 4 * ((n + 31) / 32);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(items, 4)), dim3(256), 0, s, a);
+  long qitems = (long)nseq * 4 * ((n + 15) / 16);
+  int nblk = 1024;
+  int ipb = (int)((qitems + nblk - 1) / nblk);
+  ipb = ((ipb + 3) / 4) * 4;
+  if (ipb < 4) ipb = 4;
+  nblk = (int)((qitems + ipb - 1) / ipb);
+  if (n <= 128) {
+    size_t sh = (2 * 128 * 16 + 4 * 4 * 256) * sizeof(float);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(nblk), dim3(256), sh, s, a, ipb);
+  } else if (n <= 352) {
+    size_t sh = (2 * 352 * 16 + 4 * 4 * 256) * sizeof(float);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<352>), dim3(nblk), dim3(256), sh, s, a, ipb);
+  } else {
+    size_t sh = (2 * 1024 * 16 + 4 * 4 * 256) * sizeof(float);
+    SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<1024>), dim3(nblk), dim3(256), sh, s, a, ipb);
+  }
+  return se_check_launch("se_attn_bwd");
+}

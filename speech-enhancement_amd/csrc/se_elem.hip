@@ -1,0 +1,469 @@
+// Elementwise / small-reduction kernels of the hot path (gfx950): STFT front-end glue (normalise, reflect-pad,
+// power (un)compression, overlap-add), generator output assembly, GLU backward, spectral / time losses with
+// their gradient seeds, flat-buffer optimizers.  All are HBM-bound streaming kernels: 16 B per lane where the
+// layout allows, grid-stride over at most 2048 workgroups, block reductions through wave shuffles + LDS and one
+// fp64 atomic per workgroup.
+#include "se_common.h"
+
+static __device__ __forceinline__ void block_sum_atomic(double v, double* dst) {
+  __shared__ double part[4];
+  v = wave_sum_d(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, part[0] + part[1] + part[2] + part[3]);
+  __syncthreads();
+}
+static inline int gs_grid(long n, int per_block) {
+  long nb = (n + per_block - 1) / per_block;
+  return (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
+}
+
+// ---------------------------------------------------------------------------------------------
+// c[b] = sqrt(L / sum x^2)   (normalize_batch, core/function.py:647-659; inference_gan.py:79-81)
+__global__ __launch_bounds__(256) void clip_scale_kernel(const float* __restrict__ x, float* __restrict__ c, int L) {
+  __shared__ double part[4];
+  const float* xb = x + (long)blockIdx.x * L;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < L; i += 256) { float v = xb[i]; s += (double)v * v; }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) c[blockIdx.x] = (float)sqrt((double)L / (part[0] + part[1] + part[2] + part[3]));
+}
+
+// xp[b][i] = c[b] * x[b][reflect(i - pad)]   (center=True reflect padding of torch.stft)
+__global__ void reflect_pad_scale_kernel(const float* __restrict__ x, const float* __restrict__ c, float* __restrict__ xp,
+                                         int L, int pad, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int Lp = L + 2 * pad;
+  int b = (int)(idx / Lp), i = (int)(idx % Lp) - pad;
+  if (i < 0) i = -i;
+  if (i >= L) i = 2 * (L - 1) - i;
+  xp[idx] = x[(long)b * L + i] * (c ? c[b] : 1.0f);
+}
+
+// frames R[row][ldr]: re at column f, im at column F+f  ->  planes P[row][f][4] = (mag', re', im', 0) with the
+// power / log compression of power_compress (core/function.py:625-634)
+__global__ void compress_planes_kernel(const float* __restrict__ R, int ldr, float* __restrict__ P, long rows, int F,
+                                       int comp, float pre_scale) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * F) return;
+  long row = idx / F;
+  int f = (int)(idx - row * F);
+  float re = R[row * ldr + f] * pre_scale, im = R[row * ldr + F + f] * pre_scale;
+  float mag = sqrtf(re * re + im * im), m2 = mag;
+  if (comp == 1) m2 = powf(mag, 0.3f);
+  else if (comp == 2) m2 = log1pf(mag);
+  float k = mag > 0.f ? m2 / mag : 0.f;
+  // angle(0) = 0 -> (cos, sin) = (1, 0): a zero bin stays (0, 0) because m2 = 0 for every mode
+  *reinterpret_cast<float4*>(P + idx * 4) = make_float4(m2, re * k, im * k, 0.f);
+}
+
+// planes P[row][f][4] (compressed re at [1], im at [2]) -> un-compressed GEMM operand A[row][lda]: re_u | im_u
+// (power_uncompress, core/function.py:636-645)
+__global__ void uncompress_rows_kernel(const float* __restrict__ P, float* __restrict__ A, int lda, long rows, int F,
+                                       int comp, float post_scale) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * F) return;
+  long row = idx / F;
+  int f = (int)(idx - row * F);
+  float4 p = *reinterpret_cast<const float4*>(P + idx * 4);
+  float mag = sqrtf(p.y * p.y + p.z * p.z), m2 = mag;
+  if (comp == 1) m2 = powf(mag, 1.0f / 0.3f);
+  else if (comp == 2) m2 = expm1f(mag);
+  float k = mag > 0.f ? m2 / mag * post_scale : 0.f;
+  A[row * lda + f] = p.y * k;
+  A[row * lda + F + f] = p.z * k;
+}
+
+// backward of the 'pow' un-compression u = z |z|^a (a = 1/0.3 - 1): dP[.., 1:3] (+)= J^T dA
+__global__ void uncompress_rows_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dA, int lda,
+                                           float* __restrict__ dP, long rows, int F, int comp, float post_scale) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * F) return;
+  long row = idx / F;
+  int f = (int)(idx - row * F);
+  float4 p = *reinterpret_cast<const float4*>(P + idx * 4);
+  float x = p.y, y = p.z;
+  float du = dA[row * lda + f] * post_scale, dv = dA[row * lda + F + f] * post_scale;
+  float r2 = x * x + y * y, r = sqrtf(r2);
+  float gx = 0.f, gy = 0.f;
+  if (r > 0.f) {
+    float h, hp;     // u = z * h(r);  hp = h'(r) / r
+    if (comp == 1) { const float a = 1.0f / 0.3f - 1.0f; h = powf(r, a); hp = a * powf(r, a - 2.0f); }
+    else if (comp == 2) { float e = expm1f(r); h = e / r; hp = ((e + 1.0f) * r - e) / (r2 * r); }
+    else { h = 1.0f; hp = 0.f; }
+    float t = (du * x + dv * y) * hp;
+    gx = du * h + t * x;
+    gy = dv * h + t * y;
+  }
+  float4 o = *reinterpret_cast<float4*>(dP + idx * 4);
+  o.y += gx; o.z += gy;
+  *reinterpret_cast<float4*>(dP + idx * 4) = o;
+}
+
+// overlap-add of windowed frames Fr[b][t][n_fft] at hop, divided by the window envelope, trimmed by n_fft/2
+// (torch.istft, core/function.py:701-702).  env[Lp] is precomputed on the host.
+__global__ void ola_kernel(const float* __restrict__ Fr, const float* __restrict__ env, float* __restrict__ y,
+                           int T, int n_fft, int hop, int L, int trim, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int b = (int)(idx / L), s = (int)(idx % L) + trim;
+  int t1 = s / hop;
+  float acc = 0.f;
+  for (int t = t1; t >= 0 && s - t * hop < n_fft; --t)
+    if (t < T) acc += Fr[((long)b * T + t) * n_fft + (s - t * hop)];
+  y[idx] = env ? acc / env[s] : acc;
+}
+
+// backward of reflect_pad_scale: dx[b][i] = c[b] * (dxp[pad+i] + mirrored contributions)
+__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dxp, const float* __restrict__ c, float* __restrict__ dx,
+                                       int L, int pad, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int Lp = L + 2 * pad;
+  int b = (int)(idx / L), i = (int)(idx % L);
+  const float* d = dxp + (long)b * Lp;
+  float acc = d[pad + i];
+  if (i >= 1 && i <= pad) acc += d[pad - i];
+  if (i <= L - 2 && i >= L - 1 - pad) acc += d[pad + 2 * (L - 1) - i];
+  dx[idx] = acc * (c ? c[b] : 1.0f);
+}
+
+// backward of compress_planes: dP planes (d mag', d re', d im') -> dR[row][ldr] (d re | d im of the raw DFT)
+__global__ void compress_planes_bwd_kernel(const float* __restrict__ R, int ldr, const float* __restrict__ dP,
+                                           float* __restrict__ dR, long rows, int F, int comp, float pre_scale) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * F) return;
+  long row = idx / F;
+  int f = (int)(idx - row * F);
+  float x = R[row * ldr + f] * pre_scale, y = R[row * ldr + F + f] * pre_scale;
+  float4 d = *reinterpret_cast<const float4*>(dP + idx * 4);
+  float r2 = x * x + y * y, r = sqrtf(r2);
+  float gx = 0.f, gy = 0.f;
+  if (r > 0.f) {     // the reference's pow(0, 0.3) backward is NaN at an exactly-zero bin; here that bin gets 0
+    float gp, h, hp;   // m2 = g(r), gp = g'(r);  z' = z * h(r), h = g/r, hp = h'(r)/r
+    if (comp == 1) { gp = 0.3f * powf(r, -0.7f); h = powf(r, -0.7f); hp = -0.7f * powf(r, -2.7f); }
+    else if (comp == 2) { float lg = log1pf(r); gp = 1.0f / (1.0f + r); h = lg / r; hp = (gp * r - lg) / (r2 * r); }
+    else { gp = 1.0f; h = 1.0f; hp = 0.f; }
+    float t = (d.y * x + d.z * y) * hp + d.x * gp / r;
+    gx = d.y * h + t * x;
+    gy = d.z * h + t * y;
+  }
+  dR[row * ldr + f] = gx * pre_scale;
+  dR[row * ldr + F + f] = gy * pre_scale;
+}
+// transpose of ola: dFr[b][t][k] = dy[b][t*hop + k - n_fft/2] / env[t*hop + k]
+__global__ void ola_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ env, float* __restrict__ dFr,
+                               int T, int n_fft, int hop, int L, long total) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int k = (int)(idx % n_fft);
+  long bt = idx / n_fft;
+  int t = (int)(bt % T), b = (int)(bt / T);
+  int sp = t * hop + k, s = sp - n_fft / 2;
+  dFr[idx] = (s >= 0 && s < L) ? dy[(long)b * L + s] / env[sp] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generator output (models/generator.py:158-167): est = mask * noisy + complex_out;  planes (|est|, re, im, 0)
+__global__ void assemble_kernel(const float* __restrict__ mask, int ldm, const float* __restrict__ nin,
+                                const float* __restrict__ cplx, float* __restrict__ est, long n) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float m = mask[idx * ldm];
+  float4 x = *reinterpret_cast<const float4*>(nin + idx * 4);
+  float4 c = *reinterpret_cast<const float4*>(cplx + idx * 4);
+  float re = m * x.y + c.x, im = m * x.z + c.y;
+  *reinterpret_cast<float4*>(est + idx * 4) = make_float4(sqrtf(re * re + im * im), re, im, 0.f);
+}
+// d_est planes (dmag, dre, dim, -) -> dmask (ld ldm, channel 0), dcplx planes (d0, d1, 0, 0)
+__global__ void assemble_bwd_kernel(const float* __restrict__ est, const float* __restrict__ dest,
+                                    const float* __restrict__ nin, float* __restrict__ dmask, int ldm,
+                                    float* __restrict__ dcplx, long n) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float4 e = *reinterpret_cast<const float4*>(est + idx * 4);
+  float4 d = *reinterpret_cast<const float4*>(dest + idx * 4);
+  float4 x = *reinterpret_cast<const float4*>(nin + idx * 4);
+  float k = e.x > 0.f ? d.x / e.x : 0.f;
+  float dre = d.y + k * e.y, dim = d.z + k * e.z;
+  dmask[idx * ldm] = dre * x.y + dim * x.z;
+  *reinterpret_cast<float4*>(dcplx + idx * 4) = make_float4(dre, dim, 0.f, 0.f);
+}
+
+// MaskDecoder tail (generator.py:110-112): v = u*w + b (final_conv 1x1, 1->1), mask = PReLU_F(v) (slope per f)
+__global__ void mask_tail_kernel(const float* __restrict__ U, int ldu, const float* __restrict__ wb,
+                                 const float* __restrict__ slope, float* __restrict__ M, long n, int F) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float v = U[idx * ldu] * wb[0] + wb[1];
+  M[idx] = v >= 0.f ? v : v * slope[idx % F];
+}
+// backward: dU (channel 0 of an ld-4 buffer, channels 1..3 zeroed), dwb[2] += , dslope[F] +=
+__global__ __launch_bounds__(256) void mask_tail_bwd_kernel(const float* __restrict__ U, int ldu, const float* __restrict__ wb,
+                                                            const float* __restrict__ slope, const float* __restrict__ dM,
+                                                            float* __restrict__ dU, double* __restrict__ dwb,
+                                                            float* __restrict__ dslope, long n, int F) {
+  double sw = 0.0, sb = 0.0;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    int f = (int)(idx % F);
+    float u = U[idx * ldu];
+    float v = u * wb[0] + wb[1];
+    float dm = dM[idx];
+    float dv = v >= 0.f ? dm : dm * slope[f];
+    if (v < 0.f) atomicAdd(&dslope[f], dm * v);
+    sw += (double)dv * u; sb += dv;
+    *reinterpret_cast<float4*>(dU + idx * 4) = make_float4(dv * wb[0], 0.f, 0.f, 0.f);
+  }
+  block_sum_atomic(sw, dwb);
+  block_sum_atomic(sb, dwb + 1);
+}
+
+// GLU backward (models/conformer.py:30-37): Z = [a | g] (2H), dU (H) -> dZ
+__global__ void glu_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dU, float* __restrict__ dZ,
+                               long M, int H) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of H per thread
+  int hq = H >> 2;
+  if (idx >= M * hq) return;
+  long row = idx / hq;
+  int q = (int)(idx - row * hq);
+  float4 a = *reinterpret_cast<const float4*>(Z + row * 2 * H + q * 4);
+  float4 g = *reinterpret_cast<const float4*>(Z + row * 2 * H + H + q * 4);
+  float4 d = *reinterpret_cast<const float4*>(dU + row * H + q * 4);
+  float av[4] = {a.x, a.y, a.z, a.w}, gv[4] = {g.x, g.y, g.z, g.w}, dv[4] = {d.x, d.y, d.z, d.w}, da[4], dg[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float s = sigmoidf_(gv[j]);
+    da[j] = dv[j] * s;
+    dg[j] = dv[j] * av[j] * s * (1.f - s);
+  }
+  *reinterpret_cast<float4*>(dZ + row * 2 * H + q * 4) = make_float4(da[0], da[1], da[2], da[3]);
+  *reinterpret_cast<float4*>(dZ + row * 2 * H + H + q * 4) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// spectral losses on planes (mag, re, im, -): sums[0] += sum (mag-mag')^2, sums[1] += sum (re-re')^2 + (im-im')^2
+__global__ __launch_bounds__(256) void spec_loss_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
+                                                        double* __restrict__ sums, long n) {
+  double sm = 0.0, sr = 0.0;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    float4 a = *reinterpret_cast<const float4*>(A + idx * 4);
+    float4 b = *reinterpret_cast<const float4*>(Bp + idx * 4);
+    float dm = a.x - b.x, dr = a.y - b.y, di = a.z - b.z;
+    sm += (double)dm * dm;
+    sr += (double)dr * dr + (double)di * di;
+  }
+  block_sum_atomic(sm, sums);
+  block_sum_atomic(sr, sums + 1);
+}
+// dA planes = (kmag*(mag-mag'), kri*(re-re'), kri*(im-im'), 0)   [kmag = 2*w_mag/N * upstream, ...]
+__global__ void spec_loss_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bp, float* __restrict__ dA,
+                                     const float* __restrict__ up, float cmag, float cri, long n, int accumulate) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float kmag = up[0] * cmag, kri = up[1] * cri;     // upstream gradients stay on the device
+  float4 a = *reinterpret_cast<const float4*>(A + idx * 4);
+  float4 b = *reinterpret_cast<const float4*>(Bp + idx * 4);
+  float4 o = make_float4(kmag * (a.x - b.x), kri * (a.y - b.y), kri * (a.z - b.z), 0.f);
+  if (accumulate) {
+    float4 p = *reinterpret_cast<float4*>(dA + idx * 4);
+    o.x += p.x; o.y += p.y; o.z += p.z;
+  }
+  *reinterpret_cast<float4*>(dA + idx * 4) = o;
+}
+// sums[0] += sum |a - b| over rows of length L (a: row stride lda, b: row stride ldb)
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
+                                                      long ldb, double* __restrict__ sums, int L, long n) {
+  double s = 0.0;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    long r = idx / L; int i = (int)(idx - r * L);
+    s += fabsf(a[r * lda + i] - b[r * ldb + i]);
+  }
+  block_sum_atomic(s, sums);
+}
+__global__ void l1_loss_bwd_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b, long ldb,
+                                   float* __restrict__ da, const float* __restrict__ up, float ck, int L, long n) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const float k = up[0] * ck;
+  long r = idx / L; int i = (int)(idx - r * L);
+  float d = a[r * lda + i] - b[r * ldb + i];
+  da[idx] = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat-buffer optimizers (torch.optim.AdamW / SGD(nesterov) as built by core/optimizer.py:33-36)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float gi = g[idx], pi = p[idx];
+  pi *= 1.0f - lr * wd;
+  float mi = b1 * m[idx] + (1.0f - b1) * gi;
+  float vi = b2 * v[idx] + (1.0f - b2) * gi * gi;
+  m[idx] = mi; v[idx] = vi;
+  float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[idx] = pi - (lr / bc1) * mi / denom;
+}
+__global__ void sgd_nesterov_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+                                    float lr, float momentum, int first) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  float gi = g[idx];
+  float bi = first ? gi : momentum * buf[idx] + gi;
+  buf[idx] = bi;
+  p[idx] -= lr * (gi + momentum * bi);
+}
+// out[0] += dot(a, b)   (self-correcting discriminator weights, core/function.py:719-732)
+__global__ __launch_bounds__(256) void dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  double* __restrict__ out, long n) {
+  double s = 0.0;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) s += (double)a[idx] * b[idx];
+  block_sum_atomic(s, out);
+}
+// y = alpha*a + beta*b + gamma*c
+__global__ void axpbypcz_kernel(const float* a, const float* b, const float* c, float* y, float alpha, float beta,
+                                float gamma, long n) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  y[idx] = alpha * a[idx] + beta * b[idx] + gamma * c[idx];
+}
+
+// =============================================================================================
+#define EW_LAUNCH(kernel, n, s, ...) hipLaunchKernelGGL(kernel, dim3(cdiv((n), 256)), dim3(256), 0, as_stream(s), __VA_ARGS__)
+
+extern "C" int se_clip_scale(const float* x, float* c, int B, int L, void* stream) {
+  SE_REQUIRE(x && c && B > 0 && L > 0, "clip_scale: bad arguments");
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(B), dim3(256), 0, as_stream(stream), x, c, L);
+  return se_check_launch("se_clip_scale");
+}
+extern "C" int se_reflect_pad_scale(const float* x, const float* c, float* xp, int B, int L, int pad, void* stream) {
+  SE_REQUIRE(x && xp && B > 0 && L > pad && pad >= 0, "reflect_pad_scale: bad arguments (L=%d pad=%d)", L, pad);
+  long total = (long)B * (L + 2 * pad);
+  EW_LAUNCH(reflect_pad_scale_kernel, total, stream, x, c, xp, L, pad, total);
+  return se_check_launch("se_reflect_pad_scale");
+}
+extern "C" int se_compress_planes(const float* R, int ldr, float* P, long rows, int F, int comp, float pre_scale,
+                                  void* stream) {
+  SE_REQUIRE(R && P && rows > 0 && F > 0 && ldr >= 2 * F, "compress_planes: bad arguments");
+  EW_LAUNCH(compress_planes_kernel, rows * F, stream, R, ldr, P, rows, F, comp, pre_scale);
+  return se_check_launch("se_compress_planes");
+}
+extern "C" int se_uncompress_rows(const float* P, float* A, int lda, long rows, int F, int comp, float post_scale,
+                                  void* stream) {
+  SE_REQUIRE(P && A && rows > 0 && F > 0 && lda >= 2 * F, "uncompress_rows: bad arguments");
+  EW_LAUNCH(uncompress_rows_kernel, rows * F, stream, P, A, lda, rows, F, comp, post_scale);
+  return se_check_launch("se_uncompress_rows");
+}
+extern "C" int se_uncompress_rows_bwd(const float* P, const float* dA, int lda, float* dP, long rows, int F, int comp,
+                                      float post_scale, void* stream) {
+  SE_REQUIRE(P && dA && dP && rows > 0 && F > 0 && lda >= 2 * F, "uncompress_rows_bwd: bad arguments");
+  EW_LAUNCH(uncompress_rows_bwd_kernel, rows * F, stream, P, dA, lda, dP, rows, F, comp, post_scale);
+  return se_check_launch("se_uncompress_rows_bwd");
+}
+extern "C" int se_ola(const float* Fr, const float* env, float* y, int B, int T, int n_fft, int hop, int trim,
+                      int L, void* stream) {
+  SE_REQUIRE(Fr && y && B > 0 && T > 0 && hop > 0 && n_fft >= hop, "ola: bad arguments");
+  SE_REQUIRE(L > 0 && trim >= 0 && trim + L <= n_fft + hop * (T - 1), "ola: output range [%d, %d) outside the frames", trim, trim + L);
+  long total = (long)B * L;
+  EW_LAUNCH(ola_kernel, total, stream, Fr, env, y, T, n_fft, hop, L, trim, total);
+  return se_check_launch("se_ola");
+}
+extern "C" int se_reflect_pad_bwd(const float* dxp, const float* c, float* dx, int B, int L, int pad, void* stream) {
+  SE_REQUIRE(dxp && dx && B > 0 && L > pad && pad >= 0, "reflect_pad_bwd: bad arguments");
+  long total = (long)B * L;
+  EW_LAUNCH(reflect_pad_bwd_kernel, total, stream, dxp, c, dx, L, pad, total);
+  return se_check_launch("se_reflect_pad_bwd");
+}
+extern "C" int se_compress_planes_bwd(const float* R, int ldr, const float* dP, float* dR, long rows, int F, int comp,
+                                      float pre_scale, void* stream) {
+  SE_REQUIRE(R && dP && dR && rows > 0 && F > 0 && ldr >= 2 * F, "compress_planes_bwd: bad arguments");
+  EW_LAUNCH(compress_planes_bwd_kernel, rows * F, stream, R, ldr, dP, dR, rows, F, comp, pre_scale);
+  return se_check_launch("se_compress_planes_bwd");
+}
+extern "C" int se_ola_bwd(const float* dy, const float* env, float* dFr, int B, int T, int n_fft, int hop, void* stream) {
+  SE_REQUIRE(dy && env && dFr && B > 0 && T > 1, "ola_bwd: bad arguments");
+  int L = hop * (T - 1);
+  long total = (long)B * T * n_fft;
+  EW_LAUNCH(ola_bwd_kernel, total, stream, dy, env, dFr, T, n_fft, hop, L, total);
+  return se_check_launch("se_ola_bwd");
+}
+extern "C" int se_assemble(const float* mask, int ldm, const float* nin, const float* cplx, float* est, long n, void* stream) {
+  SE_REQUIRE(mask && nin && cplx && est && n > 0, "assemble: bad arguments");
+  EW_LAUNCH(assemble_kernel, n, stream, mask, ldm, nin, cplx, est, n);
+  return se_check_launch("se_assemble");
+}
+extern "C" int se_assemble_bwd(const float* est, const float* dest, const float* nin, float* dmask, int ldm,
+                               float* dcplx, long n, void* stream) {
+  SE_REQUIRE(est && dest && nin && dmask && dcplx && n > 0, "assemble_bwd: bad arguments");
+  EW_LAUNCH(assemble_bwd_kernel, n, stream, est, dest, nin, dmask, ldm, dcplx, n);
+  return se_check_launch("se_assemble_bwd");
+}
+extern "C" int se_mask_tail(const float* U, int ldu, const float* wb, const float* slope, float* M, long n, int F, void* stream) {
+  SE_REQUIRE(U && wb && slope && M && n > 0 && F > 0, "mask_tail: bad arguments");
+  EW_LAUNCH(mask_tail_kernel, n, stream, U, ldu, wb, slope, M, n, F);
+  return se_check_launch("se_mask_tail");
+}
+extern "C" int se_mask_tail_bwd(const float* U, int ldu, const float* wb, const float* slope, const float* dM, float* dU,
+                                double* dwb, float* dslope, long n, int F, void* stream) {
+  SE_REQUIRE(U && wb && slope && dM && dU && dwb && dslope && n > 0, "mask_tail_bwd: bad arguments");
+  hipLaunchKernelGGL(mask_tail_bwd_kernel, dim3(gs_grid(n, 256)), dim3(256), 0, as_stream(stream), U, ldu, wb, slope, dM,
+                     dU, dwb, dslope, n, F);
+  return se_check_launch("se_mask_tail_bwd");
+}
+extern "C" int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, int H, void* stream) {
+  SE_REQUIRE(Z && dU && dZ && M > 0 && H > 0 && (H % 4) == 0, "glu_bwd: bad arguments");
+  EW_LAUNCH(glu_bwd_kernel, M * (H / 4), stream, Z, dU, dZ, M, H);
+  return se_check_launch("se_glu_bwd");
+}
+extern "C" int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream) {
+  SE_REQUIRE(A && Bp && sums && n > 0, "spec_loss: bad arguments");
+  hipLaunchKernelGGL(spec_loss_kernel, dim3(gs_grid(n, 256)), dim3(256), 0, as_stream(stream), A, Bp, sums, n);
+  return se_check_launch("se_spec_loss");
+}
+extern "C" int se_spec_loss_bwd(const float* A, const float* Bp, float* dA, const float* up, float cmag, float cri, long n,
+                                int accumulate, void* stream) {
+  SE_REQUIRE(A && Bp && dA && up && n > 0, "spec_loss_bwd: bad arguments");
+  EW_LAUNCH(spec_loss_bwd_kernel, n, stream, A, Bp, dA, up, cmag, cri, n, accumulate);
+  return se_check_launch("se_spec_loss_bwd");
+}
+extern "C" int se_l1_loss(const float* a, long lda, const float* b, long ldb, double* sums, long rows, int L, void* stream) {
+  SE_REQUIRE(a && b && sums && rows > 0 && L > 0, "l1_loss: bad arguments");
+  long n = rows * L;
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(gs_grid(n, 256)), dim3(256), 0, as_stream(stream), a, lda, b, ldb, sums, L, n);
+  return se_check_launch("se_l1_loss");
+}
+extern "C" int se_l1_loss_bwd(const float* a, long lda, const float* b, long ldb, float* da, const float* up, float ck,
+                              long rows, int L, void* stream) {
+  SE_REQUIRE(a && b && da && up && rows > 0 && L > 0, "l1_loss_bwd: bad arguments");
+  long n = rows * L;
+  EW_LAUNCH(l1_loss_bwd_kernel, n, stream, a, lda, b, ldb, da, up, ck, L, n);
+  return se_check_launch("se_l1_loss_bwd");
+}
+extern "C" int se_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                        float wd, int step, void* stream) {
+  SE_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw: bad arguments");
+  float bc1 = 1.0f - powf(b1, (float)step), bc2 = 1.0f - powf(b2, (float)step);
+  EW_LAUNCH(adamw_kernel, n, stream, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2);
+  return se_check_launch("se_adamw");
+}
+extern "C" int se_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, float momentum, int first,
+                               void* stream) {
+  SE_REQUIRE(p && g && buf && n > 0, "sgd_nesterov: bad arguments");
+  EW_LAUNCH(sgd_nesterov_kernel, n, stream, p, g, buf, n, lr, momentum, first);
+  return se_check_launch("se_sgd_nesterov");
+}
+extern "C" int se_dot(const float* a, const float* b, double* out, long n, void* stream) {
+  SE_REQUIRE(a && b && out && n > 0, "dot: bad arguments");
+  hipLaunchKernelGGL(dot_kernel, dim3(gs_grid(n, 256)), dim3(256), 0, as_stream(stream), a, b, out, n);
+  return se_check_launch("se_dot");
+}
+extern "C" int se_axpbypcz(const float* a, const float* b, const float* c, float* y, float alpha, float beta, float gamma,
+                           long n, void* stream) {
+  SE_REQUIRE(a && b && c && y && n > 0, "axpbypcz: bad arguments");
+  EW_LAUNCH(axpbypcz_kernel, n, stream, a, b, c, y, alpha, beta, gamma, n);
+  return se_check_launch("se_axpbypcz");
+}

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void layernorm64_fwd_kernel(const float* __res
 // dg += sum dY * xh, db += sum dY   (fp32 atomics, one per channel per workgroup)
 __global__ __launch_bounds__(256) void layernorm64_bwd_kernel(const float* __restrict__ X, const float* __restrict__ stats,
                                                               const float* __restrict__ g, const float* __restrict__ dY,
-                                                              const float* __restrict__ dR, float* __restrict__ dX,
+                                                              const float* __restrict__ dR, const float* __restrict__ dR2,
+                                                              float* __restrict__ dX,
                                                               float* __restrict__ dg, float* __restrict__ db, long M) {
   __shared__ float red[16 * 64 * 2];
   const int q = threadIdx.x & 15, sub = threadIdx.x >> 4;
@@ -88,6 +89,10 @@ __global__ __launch_bounds__(256) void layernorm64_bwd_kernel(const float* __res
     for (int j = 0; j < 4; ++j) o[j] = rstd * (dxh[j] - s1 - xh[j] * s2);
     if (dR) {
       float4 r = *reinterpret_cast<const float4*>(dR + row * 64 + q * 4);
+      o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+    if (dR2) {
+      float4 r = *reinterpret_cast<const float4*>(dR2 + row * 64 + q * 4);
       o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
     }
     *reinterpret_cast<float4*>(dX + row * 64 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void affine_prelu_kernel(const float* __restri
 __global__ __launch_bounds__(256) void norm_prelu_bwd_reduce_kernel(
     const float* __restrict__ X, int ldx, int x_off, const float* __restrict__ mr, const float* __restrict__ g,
     const float* __restrict__ beta, const float* __restrict__ slope, const float* __restrict__ dY, int ldy, int y_off,
-    double* __restrict__ red, long P, int C, int per_batch) {
+    double* __restrict__ red, long P, int C, int per_batch, int act) {
   ChanIter it(C);
   const int b = blockIdx.y;
   const int sb = per_batch ? b : 0;
@@ -227,9 +232,9 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_reduce_kernel(
     for (int j = 0; j < 4; ++j) {
       float xh = (x[j] - mean[j]) * rstd[j];
       float u = xh * gg[j] + bt[j];
-      float du = u >= 0.f ? dy[j] : dy[j] * sl[j];
+      float du = act ? dy[j] * swish_gradf_(u) : (u >= 0.f ? dy[j] : dy[j] * sl[j]);
       acc[0][j] += du; acc[1][j] += du * xh;
-      acc[2][j] += u >= 0.f ? 0.f : dy[j] * u;
+      acc[2][j] += (act || u >= 0.f) ? 0.f : dy[j] * u;
     }
   }
   block_reduce_atomic_d<3>(acc, it, C, red + (long)sb * C * 3);
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
     const float* __restrict__ X, int ldx, int x_off, const float* __restrict__ mr, const float* __restrict__ g,
     const float* __restrict__ beta, const float* __restrict__ slope, const float* __restrict__ dY, int ldy, int y_off,
     const double* __restrict__ red, float* __restrict__ dX, int lddx, int dx_off, long P, int C, int per_batch,
-    double count) {
+    double count, int act) {
   ChanIter it(C);
   const int b = blockIdx.y;
   const int sb = per_batch ? b : 0;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
     for (int j = 0; j < 4; ++j) {
       float xh = (x[j] - mean[j]) * rstd[j];
       float u = xh * gg[j] + bt[j];
-      float du = u >= 0.f ? dy[j] : dy[j] * sl[j];
+      float du = act ? dy[j] * swish_gradf_(u) : (u >= 0.f ? dy[j] : dy[j] * sl[j]);
       o[j] = rstd[j] * gg[j] * (du - m1[j] - xh * m2[j]);
     }
     *reinterpret_cast<float4*>(dX + pix * lddx + dx_off + it.q * 4) = make_float4(o[0], o[1], o[2], o[3]);
@@ -306,12 +311,13 @@ extern "C" int se_layernorm_fwd(const float* X, const float* g, const float* b, 
 }
 
 extern "C" int se_layernorm_bwd(const float* X, const float* stats, const float* g, const float* dY,
-                                const float* dR, float* dX, float* dg, float* db, long M, int C, void* stream) {
+                                const float* dR, const float* dR2, float* dX, float* dg, float* db, long M, int C,
+                                void* stream) {
   SE_REQUIRE(X && stats && g && dY && dX && dg && db && M > 0, "layernorm_bwd: bad arguments");
   SE_REQUIRE(C == 64, "layernorm_bwd: only C == 64 is built");
   long nb = (M + 15) / 16;
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(layernorm64_bwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), X, stats, g, dY, dR, dX,
+  hipLaunchKernelGGL(layernorm64_bwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), X, stats, g, dY, dR, dR2, dX,
                      dg, db, M);
   return se_check_launch("se_layernorm_bwd");
 }
@@ -357,23 +363,26 @@ extern "C" int se_affine_prelu(const float* X, int ldx, int x_off, const float* 
 extern "C" int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const float* g,
                                  const float* beta, const float* slope, const float* dY, int ldy, int y_off,
                                  double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,
-                                 float* dslope, int B, long P, int C, int per_batch, void* stream) {
+                                 float* dslope, int B, long P, int C, int per_batch, int act, int phase, double count,
+                                 void* stream) {
   SE_REQUIRE(X && mr && g && beta && dY && red && dX && dg && dbeta && B > 0 && P > 0 && chan_ok(C),
              "norm_prelu_bwd: bad arguments (C=%d)", C);
   SE_REQUIRE((ldx % 4) == 0 && (x_off % 4) == 0 && (ldy % 4) == 0 && (y_off % 4) == 0 && (lddx % 4) == 0 &&
              (dx_off % 4) == 0, "norm_prelu_bwd: alignment");
   hipStream_t s = as_stream(stream);
   int nbs = per_batch ? B : 1;
-  hipMemsetAsync(red, 0, sizeof(double) * 3 * nbs * C, s);
   int psub = 256 / (C / 4);
   long nb = (P + psub - 1) / psub;
-  if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(norm_prelu_bwd_reduce_kernel, dim3((int)nb, B), dim3(256), 0, s, X, ldx, x_off, mr, g, beta,
-                     slope, dY, ldy, y_off, red, P, C, per_batch);
-  double count = per_batch ? (double)P : (double)P * B;
-  if (nb < 1024) nb = (P + psub - 1) / psub > 1024 ? 1024 : (P + psub - 1) / psub;
-  hipLaunchKernelGGL(norm_prelu_bwd_apply_kernel, dim3((int)nb, B), dim3(256), 0, s, X, ldx, x_off, mr, g, beta, slope,
-                     dY, ldy, y_off, red, dX, lddx, dx_off, P, C, per_batch, count);
-  hipLaunchKernelGGL(norm_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, red, dg, dbeta, dslope, nbs, C);
+  if (phase & 1) {      // reduce (a data-parallel caller all-reduces `red` between the two phases: SyncBatchNorm)
+    (void)hipMemsetAsync(red, 0, sizeof(double) * 3 * nbs * C, s);
+    hipLaunchKernelGGL(norm_prelu_bwd_reduce_kernel, dim3((int)(nb > 512 ? 512 : nb), B), dim3(256), 0, s, X, ldx,
+                       x_off, mr, g, beta, slope, dY, ldy, y_off, red, P, C, per_batch, act);
+  }
+  if (phase & 4)        // parameter gradients from the LOCAL sums (before any cross-rank all-reduce)
+    hipLaunchKernelGGL(norm_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, red, dg, dbeta, dslope, nbs, C);
+  if (phase & 2) {
+    hipLaunchKernelGGL(norm_prelu_bwd_apply_kernel, dim3((int)(nb > 1024 ? 1024 : nb), B), dim3(256), 0, s, X, ldx,
+                       x_off, mr, g, beta, slope, dY, ldy, y_off, red, dX, lddx, dx_off, P, C, per_batch, count, act);
+  }
   return se_check_launch("se_norm_prelu_bwd");
 }

@@ -1,0 +1,169 @@
+"""Metric discriminator behind the reference's surface (models/discriminator.py:35-62).
+
+The four spectral-norm conv4x4/s2 + InstanceNorm + PReLU stages (all of the discriminator's FLOPs and bytes) run
+on the HIP tap-GEMM / norm kernels with a hand-written backward; the spectral-norm power iteration (weight-sized
+mat-vecs), the global max-pool over the final 12x20 map and the 128->64->1 head act on [B,128]-sized tensors and
+stay torch ops (launch-latency plumbing; listed as "next" in DESIGN.md).
+The image is processed as [B, T, F, C] (channels-last, T x F transposed w.r.t. the reference's [B, C, F, T]); the
+4x4 taps are transposed accordingly, so no data is ever permuted.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import layers as LY
+from . import ops as O
+
+# weight index (kh over F, kw over T)  ->  tap offset on the [T, F] grid
+D_TAPS = [(kw - 1, kh - 1) for kh in range(4) for kw in range(4)]
+
+
+def batch_pesq(clean, noisy):
+    """models/discriminator.py:25-32.  PESQ is third-party arithmetic (PyPI `pesq`, absent here): the labels
+    must come from a provider; see train.set_pesq_provider."""
+    from . import train
+    return train.pesq_labels(clean, noisy)
+
+
+class LearnableSigmoid(nn.Module):
+    def __init__(self, in_features, beta=1):
+        super().__init__()
+        self.beta = beta
+        self.slope = nn.Parameter(torch.ones(in_features))
+
+    def forward(self, x):
+        return self.beta * torch.sigmoid(self.slope * x)
+
+
+class _SNHolder(nn.Module):
+    """parameter container with the state_dict names of the old-style torch spectral_norm hook."""
+
+    def __init__(self, shape, bias=False):
+        super().__init__()
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(shape[0]))
+        w = torch.empty(shape)
+        nn.init.kaiming_uniform_(w, a=5 ** 0.5)
+        self.weight_orig = nn.Parameter(w)
+        h, wd = shape[0], w.numel() // shape[0]
+        self.register_buffer('weight_u', F.normalize(torch.randn(h), dim=0, eps=1e-12))
+        self.register_buffer('weight_v', F.normalize(torch.randn(wd), dim=0, eps=1e-12))
+
+    def weight(self, train):
+        W = self.weight_orig
+        Wm = W.reshape(W.shape[0], -1)
+        if train:
+            with torch.no_grad():
+                v = F.normalize(Wm.t() @ self.weight_u, dim=0, eps=1e-12)
+                u = F.normalize(Wm @ v, dim=0, eps=1e-12)
+                self.weight_v.copy_(v)
+                self.weight_u.copy_(u)
+        u, v = self.weight_u.clone(), self.weight_v.clone()
+        sigma = torch.dot(u, Wm @ v)
+        return W / sigma
+
+
+def _out(n):
+    return (n + 2 - 4) // 2 + 1
+
+
+class _DConvStackFn(torch.autograd.Function):
+    """xy planes [B,T,F,4] -> [B,T/16,F/16,128]; 4 x (conv4x4 s2 p1 (no bias), InstanceNorm(affine), PReLU)."""
+
+    @staticmethod
+    def forward(ctx, xy, *wts):
+        Ws, gs, bs, sl = wts[0:4], wts[4:8], wts[8:12], wts[12:16]
+        B, T, Fq, _ = xy.shape
+        x, Ti, Fi, Cin = xy.contiguous(), T, Fq, 4
+        saved = []
+        for i in range(4):
+            N = Ws[i].shape[0]
+            To, Fo = _out(Ti), _out(Fi)
+            wp = LY.pack_w(Ws[i].contiguous(), C_pad=Cin)
+            d = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2, epilogue=L.EPI_STATS)
+            R = torch.empty(B, To, Fo, N, device=x.device, dtype=torch.float32)
+            stats = torch.zeros(B, N, 2, device=x.device, dtype=torch.float64)
+            LY.GM.gemm_tap(d, x, wp, R, stats=stats)
+            a = torch.empty_like(R)
+            mr = LY.inorm_prelu_fwd(R, stats, gs[i], bs[i], sl[i], a, N, 0)
+            saved.append((x, R, mr, Ti, Fi, To, Fo, Cin, N))
+            x, Ti, Fi, Cin = a, To, Fo, N
+        ctx.saved, ctx.wts, ctx.B = saved, wts, B
+        return x
+
+    @staticmethod
+    def backward(ctx, dout):
+        Ws, gs, bs, sl = ctx.wts[0:4], ctx.wts[4:8], ctx.wts[8:12], ctx.wts[12:16]
+        B = ctx.B
+        dW = [torch.zeros_like(w) for w in Ws]
+        dg = [torch.zeros_like(t) for t in gs]
+        db = [torch.zeros_like(t) for t in bs]
+        ds = [torch.zeros_like(t) for t in sl]
+        dy = dout.contiguous()
+        dxy = None
+        for i in (3, 2, 1, 0):
+            x, R, mr, Ti, Fi, To, Fo, Cin, N = ctx.saved[i]
+            dR = LY.inorm_prelu_bwd(R, mr, gs[i], bs[i], sl[i], dy, N, 0, dg[i], db[i], ds[i])
+            need_dx = i > 0 or ctx.needs_input_grad[0]
+            if ctx.needs_input_grad[1 + i]:
+                fd = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2)
+                dwp = torch.zeros(N, 16 * Cin, device=dR.device, dtype=torch.float32)
+                LY.GM.gemm_tap_wgrad(fd, x, dR, dwp, None)
+                LY._unpack_w(dwp, dW[i], Cin, False)
+            if need_dx:
+                wd = LY.GM.pack_conv_dgrad(Ws[i].contiguous())            # [Cin_true][16][N]
+                if wd.shape[0] != Cin:
+                    wd = torch.cat([wd, wd.new_zeros(Cin - wd.shape[0], wd.shape[1])], 0)
+                dx = torch.empty(B, Ti, Fi, Cin, device=dR.device, dtype=torch.float32)
+                dd = LY.GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in D_TAPS], N, N, Cin, Cin, st=2, sf=2, up=1)
+                LY.GM.gemm_tap(dd, dR, wd, dx)
+                dy = dx
+                if i == 0:
+                    dxy = dx
+        ctx.saved = None
+        return (dxy,) + tuple(dW) + tuple(dg) + tuple(db) + tuple(ds)
+
+
+class Discriminator(nn.Module):
+    """Discriminator(ndf, in_channel=2).forward(x, y): x, y [B,1,F,T] -> [B,1]."""
+
+    def __init__(self, ndf, in_channel=2):
+        super().__init__()
+        if in_channel != 2:
+            raise ValueError('the HIP conv stack is built for in_channel == 2')
+        chans = [in_channel, ndf, ndf * 2, ndf * 4, ndf * 8]
+        mods = []
+        for i in range(4):
+            mods += [_SNHolder((chans[i + 1], chans[i], 4, 4)), nn.InstanceNorm2d(chans[i + 1], affine=True),
+                     nn.PReLU(chans[i + 1])]
+        mods += [nn.AdaptiveMaxPool2d(1), nn.Flatten(), _SNHolder((ndf * 4, ndf * 8), bias=True), nn.Dropout(0.3),
+                 nn.PReLU(ndf * 4), _SNHolder((1, ndf * 4), bias=True), LearnableSigmoid(1)]
+        self.layers = nn.Sequential(*mods)
+
+    def forward_planes(self, pa, pb, detach_params=False):
+        """pa, pb: planes [B,T,F,4] whose channel 0 is the magnitude (clean first, like the reference's callers).
+        detach_params: the generator step only needs the gradient w.r.t. pb (the reference computes and then
+        discards the discriminator's weight gradients there, core/function.py:261-279)."""
+        z = torch.zeros_like(pa[..., 0])
+        xy = torch.stack([pa[..., 0], pb[..., 0], z, z], -1)
+        ly = self.layers
+        train = self.training
+        dt = (lambda t: t.detach()) if detach_params else (lambda t: t)
+        Ws = [dt(ly[i].weight(train)) for i in (0, 3, 6, 9)]
+        args = Ws + [dt(ly[i].weight) for i in (1, 4, 7, 10)] + [dt(ly[i].bias) for i in (1, 4, 7, 10)] + \
+            [dt(ly[i].weight) for i in (2, 5, 8, 11)]
+        a4 = _DConvStackFn.apply(xy, *args)
+        h = a4.amax(dim=(1, 2))
+        h = F.linear(h, dt(ly[14].weight(train)), dt(ly[14].bias))
+        h = ly[15](h)
+        h = F.prelu(h, dt(ly[16].weight))
+        h = F.linear(h, dt(ly[17].weight(train)), dt(ly[17].bias))
+        return self.layers[18].beta * torch.sigmoid(dt(ly[18].slope) * h)
+
+    def forward(self, x, y):
+        def planes(m):          # [B,1,F,T] -> [B,T,F,4]
+            mm = m[:, 0].transpose(1, 2)
+            z = torch.zeros_like(mm)
+            return torch.stack([mm, z, z, z], -1)
+        return self.forward_planes(planes(x), planes(y))

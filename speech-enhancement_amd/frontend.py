@@ -1,0 +1,190 @@
+"""STFT / iSTFT + power-compression front-end (core/function.py:625-703) on the HIP kernels.
+
+The 400-point real DFT of every frame is one fp32-MFMA tap GEMM: the reflect-padded (and normalised) signal is
+the A operand with a row stride of one hop (frames overlap in memory, nothing is unfolded), the windowed DFT
+matrix is the weight.  iSTFT = un-compress -> GEMM with the windowed inverse-DFT matrix -> overlap-add.
+Internal layout: "planes" [B, T, F, 4] = (|z|, Re z, Im z, 0), channels-last like every other feature map.
+"""
+import math
+
+import torch
+
+from . import _lib as L
+from . import gemm as GM
+from . import ops as O
+
+_CACHE = {}
+
+
+def hamming(n_fft, device):
+    k = torch.arange(n_fft, dtype=torch.float64, device=device)
+    return 0.54 - 0.46 * torch.cos(2.0 * math.pi * k / n_fft)
+
+
+def _ceil4(x):
+    return (x + 3) // 4 * 4
+
+
+def dft_matrices(n_fft, hop, device):
+    """(Wf [2F_pad][n_fft], Wi [n_fft][K_pad], env [Lmax...]) in fp32, built once per device in fp64."""
+    key = (n_fft, hop, str(device))
+    if key in _CACHE:
+        return _CACHE[key]
+    Fq = n_fft // 2 + 1
+    w = hamming(n_fft, device)
+    k = torch.arange(n_fft, dtype=torch.float64, device=device)
+    f = torch.arange(Fq, dtype=torch.float64, device=device)
+    ang = 2.0 * math.pi * f[:, None] * k[None, :] / n_fft             # [F, n_fft]
+    Wf = torch.cat([torch.cos(ang) * w, -torch.sin(ang) * w], 0)        # rows: re_f | im_f
+    # inverse: frame[k] = w[k]/n * sum_f c_f (re_f cos - im_f sin), c_0 = c_{n/2} = 1 else 2
+    c = torch.full((Fq,), 2.0, dtype=torch.float64, device=device)
+    c[0] = 1.0
+    if n_fft % 2 == 0:
+        c[-1] = 1.0
+    Kp = _ceil4(2 * Fq)
+    Wi = torch.zeros(n_fft, Kp, dtype=torch.float64, device=device)
+    Wi[:, :Fq] = (torch.cos(ang) * c[:, None]).T * w[:, None] / n_fft
+    Wi[:, Fq:2 * Fq] = (-torch.sin(ang) * c[:, None]).T * w[:, None] / n_fft
+    out = (Wf.float().contiguous(), Wi.float().contiguous(), w)
+    _CACHE[key] = out
+    return out
+
+
+def envelope(n_fft, hop, T, device):
+    key = ('env', n_fft, hop, T, str(device))
+    if key not in _CACHE:
+        w2 = hamming(n_fft, device) ** 2
+        Lp = n_fft + hop * (T - 1)
+        env = torch.zeros(Lp, dtype=torch.float64, device=device)
+        for t in range(T):
+            env[t * hop:t * hop + n_fft] += w2
+        _CACHE[key] = env.float().contiguous()
+    return _CACHE[key]
+
+
+def stft_planes(x, n_fft=400, hop=100, comp='pow', scale=None):
+    """x [B, L] (L a multiple of hop) -> planes [B, T, F, 4].  scale: optional per-clip factor c[b] applied
+    while padding (fuses normalize_batch, core/function.py:647-659)."""
+    L.check_cuda(x)
+    B, Ls = x.shape
+    if Ls % hop != 0 or n_fft % hop != 0 or hop % 4 != 0:
+        raise L.SeHipError(f'stft: need L % hop == 0, n_fft % hop == 0, hop % 4 == 0 (L={Ls}, hop={hop})')
+    T = Ls // hop + 1
+    Fq = n_fft // 2 + 1
+    xp = O.reflect_pad_scale(x.contiguous(), scale, n_fft // 2)          # [B, L + n_fft]
+    Wf, _, _ = dft_matrices(n_fft, hop, x.device)
+    ldr = _ceil4(2 * Fq)
+    R = torch.empty(B * T, ldr, device=x.device, dtype=torch.float32)
+    rows_per_b = (Ls + n_fft) // hop                                      # "pixels" of stride hop per clip
+    d = GM.make_desc(B, 1, T, 1, rows_per_b, [(0, 0)], n_fft, hop, 2 * Fq, ldr, ldw=n_fft)
+    GM.gemm_tap(d, xp, Wf, R)
+    pre = n_fft ** -0.5 if comp == 'norm' else 1.0
+    return O.compress_planes(R, ldr, B * T, Fq, comp, pre).view(B, T, Fq, 4), xp
+
+
+class _STFTFn(torch.autograd.Function):
+    """differentiable STFT (the consistency-preserving re-STFT of est_audio, core/function.py:234-236)."""
+
+    @staticmethod
+    def forward(ctx, x, n_fft, hop, comp):
+        B, Ls = x.shape
+        T = Ls // hop + 1
+        Fq = n_fft // 2 + 1
+        xp = O.reflect_pad_scale(x.contiguous(), None, n_fft // 2)
+        Wf, _, _ = dft_matrices(n_fft, hop, x.device)
+        ldr = _ceil4(2 * Fq)
+        R = torch.zeros(B * T, ldr, device=x.device, dtype=torch.float32)
+        d = GM.make_desc(B, 1, T, 1, (Ls + n_fft) // hop, [(0, 0)], n_fft, hop, 2 * Fq, ldr, ldw=n_fft)
+        GM.gemm_tap(d, xp, Wf, R)
+        pre = n_fft ** -0.5 if comp == 'norm' else 1.0
+        ctx.save_for_backward(R)
+        ctx.cfg = (B, Ls, T, Fq, n_fft, hop, comp, ldr, pre)
+        return O.compress_planes(R, ldr, B * T, Fq, comp, pre).view(B, T, Fq, 4)
+
+    @staticmethod
+    def backward(ctx, dP):
+        (R,) = ctx.saved_tensors
+        B, Ls, T, Fq, n_fft, hop, comp, ldr, pre = ctx.cfg
+        Wf, _, _ = dft_matrices(n_fft, hop, R.device)
+        dR = O.compress_planes_bwd(R, ldr, dP.contiguous(), B * T, Fq, comp, pre)
+        key = ('WfT', n_fft, hop, str(R.device))
+        if key not in _CACHE:          # [n_fft][ldr]: transposed DFT matrix, zero-padded columns
+            WfT = torch.zeros(n_fft, ldr, device=R.device, dtype=torch.float32)
+            WfT[:, :2 * Fq] = Wf.t()
+            _CACHE[key] = WfT.contiguous()
+        dfr = torch.empty(B * T, n_fft, device=R.device, dtype=torch.float32)
+        GM.gemm_tap(GM.linear_desc(B * T, ldr, n_fft), dR, _CACHE[key], dfr)
+        dxp = O.ola(dfr, None, B, T, n_fft, hop, trim=0, L_out=Ls + n_fft)
+        return O.reflect_pad_bwd(dxp, None, B, Ls, n_fft // 2), None, None, None
+
+
+def stft_planes_grad(x, n_fft=400, hop=100, comp='pow'):
+    return _STFTFn.apply(x, n_fft, hop, comp)
+
+
+class _ISTFTFn(torch.autograd.Function):
+    """planes [B,T,F,4] (compressed Re/Im in channels 1,2) -> audio [B, hop*(T-1)]."""
+
+    @staticmethod
+    def forward(ctx, planes, n_fft, hop, comp):
+        B, T, Fq, _ = planes.shape
+        _, Wi, _ = dft_matrices(n_fft, hop, planes.device)
+        lda = Wi.shape[1]
+        post = n_fft ** 0.5 if comp == 'norm' else 1.0
+        Au = O.uncompress_rows(planes, B * T, Fq, lda, comp, post)
+        frames = torch.empty(B * T, n_fft, device=planes.device, dtype=torch.float32)
+        GM.gemm_tap(GM.linear_desc(B * T, lda, n_fft), Au, Wi, frames)
+        env = envelope(n_fft, hop, T, planes.device)
+        y = O.ola(frames, env, B, T, n_fft, hop)
+        ctx.save_for_backward(planes)
+        ctx.cfg = (n_fft, hop, comp, lda, post)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (planes,) = ctx.saved_tensors
+        n_fft, hop, comp, lda, post = ctx.cfg
+        B, T, Fq, _ = planes.shape
+        _, Wi, _ = dft_matrices(n_fft, hop, planes.device)
+        env = envelope(n_fft, hop, T, planes.device)
+        dfr = O.ola_bwd(dy.contiguous(), env, B, T, n_fft, hop)
+        dA = torch.empty(B * T, lda, device=planes.device, dtype=torch.float32)
+        GM.gemm_tap(GM.linear_desc(B * T, n_fft, lda), dfr, Wi.t().contiguous(), dA)
+        dP = torch.zeros_like(planes)
+        O.uncompress_rows_bwd(planes, dA, lda, dP, B * T, Fq, comp, post)
+        return dP, None, None, None
+
+
+def istft_planes(planes, n_fft=400, hop=100, comp='pow'):
+    return _ISTFTFn.apply(planes, n_fft, hop, comp)
+
+
+# ---- reference-shaped public API (complex [B, F, T] tensors) ---------------------------------------
+def spec_to_planes(spec):
+    """complex [B, F, T] -> planes [B, T, F, 4] (layout plumbing for external callers)."""
+    re = spec.real.transpose(1, 2)
+    im = spec.imag.transpose(1, 2)
+    return torch.stack([torch.sqrt(re * re + im * im), re, im, torch.zeros_like(re)], -1).contiguous()
+
+
+def planes_to_spec(planes):
+    return torch.complex(planes[..., 1], planes[..., 2]).transpose(1, 2)
+
+
+def compressed_stft(signal, n_fft, hop_length, window=None, comp_type='pow'):
+    """core/function.py:685-693.  `window` is accepted for signature parity; the kernel path uses the periodic
+    Hamming window the reference always passes (core/function.py:668)."""
+    planes, _ = stft_planes(signal, n_fft, hop_length, comp_type)
+    return planes_to_spec(planes)
+
+
+def uncompressed_istft(spec, n_fft, hop_length, window=None, comp_type='pow'):
+    """core/function.py:695-703."""
+    return istft_planes(spec_to_planes(spec), n_fft, hop_length, comp_type)
+
+
+def normalize_batch(batch, args=None):
+    """core/function.py:647-659 (device placement is the caller's business here)."""
+    clean, noisy = batch['audio'], batch['noisy']
+    c = O.clip_scale(noisy.contiguous())
+    return clean * c[:, None], noisy * c[:, None]

@@ -1,0 +1,146 @@
+"""TSCNet generator behind the reference's constructor / forward / state_dict surface
+(models/generator.py:132-167), computed by the HIP kernels through ``layers.py``.
+
+The nn.Module tree below only *holds* parameters and buffers under the reference's names (so reference
+checkpoints load with ``load_state_dict`` and ours load into the reference); none of the torch.nn forward
+methods is ever called -- ``TSCNet.forward`` runs ``_TSCNetFn``, whose forward/backward are hand-written.
+"""
+import torch
+import torch.nn as nn
+
+from . import layers as LY
+from . import frontend as FE
+
+
+def _dilated_dense(ch=64):
+    m = nn.Module()
+    for i in range(4):
+        setattr(m, f'conv{i+1}', nn.Conv2d(ch * (i + 1), ch, (2, 3), dilation=(2 ** i, 1)))
+        setattr(m, f'norm{i+1}', nn.InstanceNorm2d(ch, affine=True))
+        setattr(m, f'prelu{i+1}', nn.PReLU(ch))
+    return m
+
+
+def _feed_forward(dim):
+    ff = nn.Module()
+    ff.net = nn.Sequential(nn.Linear(dim, dim * 4), nn.Identity(), nn.Identity(), nn.Linear(dim * 4, dim), nn.Identity())
+    pre = nn.Module()
+    pre.fn, pre.norm = ff, nn.LayerNorm(dim)
+    sc = nn.Module()
+    sc.fn = pre
+    return sc
+
+
+def _attention(dim, heads=4, max_pos=512):
+    at = nn.Module()
+    at.to_q = nn.Linear(dim, dim, bias=False)
+    at.to_kv = nn.Linear(dim, dim * 2, bias=False)
+    at.to_out = nn.Linear(dim, dim)
+    at.rel_pos_emb = nn.Embedding(2 * max_pos + 1, dim // heads)
+    pre = nn.Module()
+    pre.fn, pre.norm = at, nn.LayerNorm(dim)
+    return pre
+
+
+def _conv_module(dim, k=31):
+    inner = dim * 2
+    dw = nn.Module()
+    dw.conv = nn.Conv1d(inner, inner, k, groups=inner)
+    cm = nn.Module()
+    cm.net = nn.Sequential(nn.LayerNorm(dim), nn.Identity(), nn.Conv1d(dim, inner * 2, 1), nn.Identity(), dw,
+                           nn.BatchNorm1d(inner), nn.Identity(), nn.Conv1d(inner, dim, 1), nn.Identity(), nn.Identity())
+    return cm
+
+
+def _conformer(dim=64):
+    m = nn.Module()
+    m.ff1 = _feed_forward(dim)
+    m.attn = _attention(dim)
+    m.conv = _conv_module(dim)
+    m.ff2 = _feed_forward(dim)
+    m.post_norm = nn.LayerNorm(dim)
+    return m
+
+
+def _tscb(ch):
+    m = nn.Module()
+    m.time_conformer = _conformer(ch)
+    m.freq_conformer = _conformer(ch)
+    return m
+
+
+def _sp_conv(ch):
+    m = nn.Module()
+    m.conv = nn.Conv2d(ch, ch * 2, (1, 3))
+    return m
+
+
+class _TSCNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, xin, *params):
+        P = dict(zip(model._pnames, params))
+        P.update(model._buffer_dict())
+        train = model.training
+        with torch.no_grad():
+            est, c = LY.tscnet_fwd(P, xin.contiguous(), train=train, dp=model.dp,
+                                   buffers=model._buffer_dict() if train else None)
+        ctx.c, ctx.P, ctx.model = c, P, model
+        return est
+
+    @staticmethod
+    def backward(ctx, dest):
+        model, P = ctx.model, ctx.P
+        with torch.no_grad():
+            G = {k: torch.zeros_like(P[k]) for k in model._pnames}
+            LY.tscnet_bwd(P, G, ctx.c, dest.contiguous(), dp=model.dp)
+        ctx.c = None
+        return (None, None) + tuple(G[k] for k in model._pnames)
+
+
+class TSCNet(nn.Module):
+    """TSCNet(num_channel=64, num_features=201): forward(x complex [B, F, T]) -> (real, imag) [B, 1, T, F]."""
+
+    def __init__(self, num_channel=64, num_features=201):
+        super().__init__()
+        if num_channel != 64:
+            raise ValueError('the HIP kernels are built for num_channel == 64 (LayerNorm(64), 4 heads x 16)')
+        ch = num_channel
+        enc = nn.Module()
+        enc.conv_1 = nn.Sequential(nn.Conv2d(3, ch, (1, 1)), nn.InstanceNorm2d(ch, affine=True), nn.PReLU(ch))
+        enc.dilated_dense = _dilated_dense(ch)
+        enc.conv_2 = nn.Sequential(nn.Conv2d(ch, ch, (1, 3), (1, 2), padding=(0, 1)),
+                                   nn.InstanceNorm2d(ch, affine=True), nn.PReLU(ch))
+        self.dense_encoder = enc
+        for i in range(1, 5):
+            setattr(self, f'TSCB_{i}', _tscb(ch))
+        md = nn.Module()
+        md.dense_block = _dilated_dense(ch)
+        md.sub_pixel = _sp_conv(ch)
+        md.conv_1 = nn.Conv2d(ch, 1, (1, 2))
+        md.norm = nn.InstanceNorm2d(1, affine=True)
+        md.prelu = nn.PReLU(1)
+        md.final_conv = nn.Conv2d(1, 1, (1, 1))
+        md.prelu_out = nn.PReLU(num_features, init=-0.25)
+        self.mask_decoder = md
+        cd = nn.Module()
+        cd.dense_block = _dilated_dense(ch)
+        cd.sub_pixel = _sp_conv(ch)
+        cd.prelu = nn.PReLU(ch)
+        cd.norm = nn.InstanceNorm2d(ch, affine=True)
+        cd.conv = nn.Conv2d(ch, 2, (1, 2))
+        self.complex_decoder = cd
+        self.num_features = num_features
+        self.dp = LY.NO_DP
+        self._pnames = [k for k, _ in self.named_parameters()]
+
+    def _buffer_dict(self):
+        return dict(self.named_buffers())
+
+    def forward_planes(self, xin):
+        """xin planes [B,T,F,4] -> est planes [B,T,F,4] (|est|, Re, Im, 0); the native entry of the train step."""
+        return _TSCNetFn.apply(self, xin, *[p for _, p in self.named_parameters()])
+
+    def forward(self, x, diffusion_step=None):
+        xin = FE.spec_to_planes(x)
+        est = self.forward_planes(xin)
+        return est[..., 1].unsqueeze(1), est[..., 2].unsqueeze(1)

@@ -1,0 +1,507 @@
+"""Functional forward / backward of the TSCNet generator on the HIP kernels.
+
+Everything is channels-last fp32: feature maps [B, T, F, C], Conformer tokens = the same buffer viewed as
+[B*T*F, C] (the reference's two permute+contiguous copies per TSCB, models/generator.py:69,71, become token
+strides).  Each ``*_fwd`` returns (output, ctx); each ``*_bwd`` consumes the ctx, returns the input gradient and
+adds parameter gradients into ``G`` (dict name -> tensor, fp32, zero-initialised by the caller).
+Parameter names are the reference's state_dict keys.
+"""
+import torch
+
+from . import _lib as L
+from . import attention as A
+from . import gemm as GM
+from . import ops as O
+
+EPS = 1e-5
+
+
+class DPHooks:
+    """Data-parallel hooks: SyncBatchNorm statistic exchange (main_gan.py:154-155).  Single-GPU default: none."""
+    world = 1
+
+    def allreduce(self, t):
+        return t
+
+
+NO_DP = DPHooks()
+
+
+def _T(w):
+    """[N, K] -> contiguous [K, N] (weight-sized plumbing)."""
+    return w.t().contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# conv (+ InstanceNorm + PReLU) building block
+# ------------------------------------------------------------------------------------------------
+def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None, sf=1, shuffle2=False,
+             want_stats=True):
+    """raw conv output R [B, To, Fo(*2 if shuffle2), N(/2)] (+ fp64 (sum, sumsq) statistics)."""
+    To = To or Ti
+    Fo = Fo or Fi
+    ep = L.EPI_BIAS | (L.EPI_STATS if want_stats else 0) | (L.EPI_SHUFFLE2 if shuffle2 else 0)
+    No = N // 2 if shuffle2 else N
+    d = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, No, a_off=a_off, sf=sf, epilogue=ep)
+    R = torch.empty(B, To, Fo * (2 if shuffle2 else 1), No, device=x.device, dtype=torch.float32)
+    stats = torch.zeros(B, No, 2, device=x.device, dtype=torch.float64) if want_stats else None
+    GM.gemm_tap(d, x, wp, R, bias=bias, stats=stats)
+    return R, stats
+
+
+def inorm_prelu_fwd(R, stats, g, b, slope, out, ldy, y_off):
+    B = R.shape[0]
+    C_ = R.shape[-1]
+    P = R.numel() // (B * C_)
+    mr, ss = O.norm_finalize(stats, g, b, B, C_, float(P))
+    O.affine_prelu(R, C_, 0, ss, slope, out, ldy, y_off, B, P, C_)
+    return mr
+
+
+def inorm_prelu_bwd(R, mr, g, b, slope, dy, ldy, y_off, dg, db, dslope):
+    B = R.shape[0]
+    C_ = R.shape[-1]
+    P = R.numel() // (B * C_)
+    dR = torch.empty_like(R)
+    O.norm_prelu_bwd(R, C_, 0, mr, g, b, slope, dy, ldy, y_off, dR, C_, 0, dg, db, dslope, B, P, C_, per_batch=True)
+    return dR
+
+
+def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=1, rev=False, dx=None, lddx=None,
+             dx_off=0, accumulate=False, need_dx=True, w_for_dgrad=None):
+    """gradients of a (non-shuffled) conv: weight/bias into dw/dbias (PyTorch layout, accumulated), input
+    gradient into dx[..., dx_off:dx_off+C_in] (pixel stride lddx)."""
+    N = dR.shape[-1]
+    ntap = len(taps)
+    fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf)
+    dwp = torch.zeros(N, ntap * C_in, device=dR.device, dtype=torch.float32)
+    GM.gemm_tap_wgrad(fd, x, dR, dwp, dbias)
+    _unpack_w(dwp, dw, C_in, rev)
+    if not need_dx:
+        return None
+    wd = GM.pack_conv_dgrad(w_for_dgrad if w_for_dgrad is not None else w, rev_slabs=rev)   # [Cin][tap][N]
+    if wd.shape[0] != C_in:      # channel-padded input (Cin 3 -> 4 etc.)
+        wd = torch.cat([wd, wd.new_zeros(C_in - wd.shape[0], wd.shape[1])], 0)
+    if dx is None:
+        dx = torch.empty(B, Ti, Fi, C_in, device=dR.device, dtype=torch.float32)
+        lddx = C_in
+    dd = GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in taps], N, N, C_in, lddx, c_off=dx_off, sf=sf,
+                      up=1 if sf != 1 else 0, epilogue=L.EPI_ACCUM if accumulate else 0)
+    GM.gemm_tap(dd, dR, wd, dx)
+    return dx
+
+
+def _unpack_w(dwp, dw, C_in, rev):
+    """packed [N][tap][C_in] -> accumulate into PyTorch-layout dw [N, Cin_true, kh, kw] (Cin_true <= C_in)."""
+    N, Ct, kh, kw = dw.shape
+    if Ct == C_in:
+        GM.unpack_conv_wgrad(dwp, dw, rev_slabs=rev, accumulate=True)
+    else:   # padded input channels: drop the pad
+        tmp = torch.zeros(N, C_in, kh, kw, device=dw.device, dtype=torch.float32)
+        GM.unpack_conv_wgrad(dwp, tmp, rev_slabs=False, accumulate=False)
+        dw += tmp[:, :Ct]
+
+
+def pack_w(w, C_pad=None, rev=False):
+    """PyTorch conv weight -> [N][tap][C] (optionally zero-padding the input channels to C_pad)."""
+    if C_pad is not None and w.shape[1] != C_pad:
+        w = torch.cat([w, w.new_zeros(w.shape[0], C_pad - w.shape[1], w.shape[2], w.shape[3])], 1).contiguous()
+    return GM.pack_conv_fwd(w, rev_slabs=rev)
+
+
+def pad_rows(w, n):
+    """zero-pad the leading (output-channel) dim to n."""
+    if w.shape[0] == n:
+        return w.contiguous()
+    return torch.cat([w, w.new_zeros(n - w.shape[0], *w.shape[1:])], 0).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# DilatedDenseNet (models/generator.py:6-32)
+# ------------------------------------------------------------------------------------------------
+def dense_taps(i):
+    d = 2 ** i
+    return GM.conv_taps(2, 3, (d, 1), (d, 1))      # causal in time: dt in {-d, 0}, df in {-1, 0, 1}
+
+
+def dense_block_fwd(P, p, skip, B, T, Fq):
+    """skip: [B,T,Fq,256] whose slab 0 already holds the block input.  Returns (out [B,T,Fq,64], ctx)."""
+    ctx = {'skip': skip, 'R': [], 'mr': []}
+    out = None
+    for i in range(4):
+        C_in = 64 * (i + 1)
+        wp = pack_w(P[f'{p}.conv{i+1}.weight'], rev=True)
+        R, stats = conv_fwd(skip, B, T, Fq, 256, 0, C_in, wp, P[f'{p}.conv{i+1}.bias'], dense_taps(i), 64)
+        if i < 3:
+            mr = inorm_prelu_fwd(R, stats, P[f'{p}.norm{i+1}.weight'], P[f'{p}.norm{i+1}.bias'],
+                                 P[f'{p}.prelu{i+1}.weight'], skip, 256, 64 * (i + 1))
+        else:
+            out = torch.empty(B, T, Fq, 64, device=skip.device, dtype=torch.float32)
+            mr = inorm_prelu_fwd(R, stats, P[f'{p}.norm{i+1}.weight'], P[f'{p}.norm{i+1}.bias'],
+                                 P[f'{p}.prelu{i+1}.weight'], out, 64, 0)
+        ctx['R'].append(R)
+        ctx['mr'].append(mr)
+    return out, ctx
+
+
+def dense_block_bwd(P, G, p, ctx, dout, B, T, Fq):
+    """returns dskip [B,T,Fq,256]; its slab 0 is the gradient of the block input."""
+    skip = ctx['skip']
+    dskip = torch.empty_like(skip)
+    for i in (3, 2, 1, 0):
+        C_in = 64 * (i + 1)
+        if i == 3:
+            dy, ldy, yoff = dout, 64, 0
+        else:
+            dy, ldy, yoff = dskip, 256, 64 * (i + 1)
+        dR = inorm_prelu_bwd(ctx['R'][i], ctx['mr'][i], P[f'{p}.norm{i+1}.weight'], P[f'{p}.norm{i+1}.bias'],
+                             P[f'{p}.prelu{i+1}.weight'], dy, ldy, yoff, G[f'{p}.norm{i+1}.weight'],
+                             G[f'{p}.norm{i+1}.bias'], G[f'{p}.prelu{i+1}.weight'])
+        conv_bwd(skip, B, T, Fq, 256, 0, C_in, P[f'{p}.conv{i+1}.weight'], dense_taps(i), dR, T, Fq,
+                 G[f'{p}.conv{i+1}.weight'], G[f'{p}.conv{i+1}.bias'], rev=True, dx=dskip, lddx=256, dx_off=0,
+                 accumulate=(i != 3))
+        ctx['R'][i] = None
+    return dskip
+
+
+# ------------------------------------------------------------------------------------------------
+# DenseEncoder (models/generator.py:35-54)
+# ------------------------------------------------------------------------------------------------
+TAPS_1x1 = [(0, 0)]
+TAPS_1x3 = [(0, -1), (0, 0), (0, 1)]
+TAPS_1x2 = [(0, 0), (0, 1)]
+
+
+def encoder_fwd(P, xin, B, T, Fq):
+    p = 'dense_encoder'
+    ctx = {'xin': xin}
+    R0, st0 = conv_fwd(xin, B, T, Fq, 4, 0, 4, pack_w(P[f'{p}.conv_1.0.weight'], C_pad=4),
+                       P[f'{p}.conv_1.0.bias'], TAPS_1x1, 64)
+    skip = torch.empty(B, T, Fq, 256, device=xin.device, dtype=torch.float32)
+    ctx['mr0'] = inorm_prelu_fwd(R0, st0, P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
+                                 P[f'{p}.conv_1.2.weight'], skip, 256, 0)
+    ctx['R0'] = R0
+    a2, ctx['dense'] = dense_block_fwd(P, f'{p}.dilated_dense', skip, B, T, Fq)
+    Fo = (Fq + 2 - 3) // 2 + 1
+    R5, st5 = conv_fwd(a2, B, T, Fq, 64, 0, 64, pack_w(P[f'{p}.conv_2.0.weight']), P[f'{p}.conv_2.0.bias'],
+                       TAPS_1x3, 64, To=T, Fo=Fo, sf=2)
+    out = torch.empty(B, T, Fo, 64, device=xin.device, dtype=torch.float32)
+    ctx['mr5'] = inorm_prelu_fwd(R5, st5, P[f'{p}.conv_2.1.weight'], P[f'{p}.conv_2.1.bias'],
+                                 P[f'{p}.conv_2.2.weight'], out, 64, 0)
+    ctx.update(a2=a2, R5=R5, Fo=Fo)
+    return out, ctx
+
+
+def encoder_bwd(P, G, ctx, dout, B, T, Fq):
+    p = 'dense_encoder'
+    Fo = ctx['Fo']
+    dR5 = inorm_prelu_bwd(ctx['R5'], ctx['mr5'], P[f'{p}.conv_2.1.weight'], P[f'{p}.conv_2.1.bias'],
+                          P[f'{p}.conv_2.2.weight'], dout, 64, 0, G[f'{p}.conv_2.1.weight'],
+                          G[f'{p}.conv_2.1.bias'], G[f'{p}.conv_2.2.weight'])
+    da2 = conv_bwd(ctx['a2'], B, T, Fq, 64, 0, 64, P[f'{p}.conv_2.0.weight'], TAPS_1x3, dR5, T, Fo,
+                   G[f'{p}.conv_2.0.weight'], G[f'{p}.conv_2.0.bias'], sf=2)
+    dskip = dense_block_bwd(P, G, f'{p}.dilated_dense', ctx['dense'], da2, B, T, Fq)
+    dR0 = inorm_prelu_bwd(ctx['R0'], ctx['mr0'], P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
+                          P[f'{p}.conv_1.2.weight'], dskip, 256, 0, G[f'{p}.conv_1.1.weight'],
+                          G[f'{p}.conv_1.1.bias'], G[f'{p}.conv_1.2.weight'])
+    conv_bwd(ctx['xin'], B, T, Fq, 4, 0, 4, P[f'{p}.conv_1.0.weight'], TAPS_1x1, dR0, T, Fq,
+             G[f'{p}.conv_1.0.weight'], G[f'{p}.conv_1.0.bias'], need_dx=False)
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+# Conformer block (models/conformer.py:180-212) on the token view of [B, T, F', 64]
+# ------------------------------------------------------------------------------------------------
+def _ff_fwd(P, p, x, M):
+    """x + 0.5 * FF(LN(x)) (Scale(0.5, PreNorm(FeedForward)), conformer.py:53-71,128-145; dropout p=0)."""
+    st = O.row_stats(x, M)
+    z = torch.empty(M, 256, device=x.device, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, epilogue=L.EPI_BIAS), x, P[f'{p}.fn.fn.net.0.weight'], z,
+                bias=P[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
+    y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=0.5, ldr=64),
+                z, P[f'{p}.fn.fn.net.3.weight'], y, bias=P[f'{p}.fn.fn.net.3.bias'], R=x)
+    return y, (x, st, z)
+
+
+def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
+    """dy = gradient of (x + 0.5 FF(LN x)); returns dx (= dy + LN-path gradient (+ dR2))."""
+    x, st, z = saved
+    W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
+    # dz = 0.5 * (dy @ W2) * swish'(z)
+    dz = torch.empty(M, 256, device=x.device, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 64, 256, epilogue=L.EPI_SWISH_GRAD, ldx=256), dy, _T(W2) * 0.5, dz, AUX=z)
+    # dW2 = 0.5 * dy^T swish(z);  db2 = 0.5 * sum dy
+    dW2 = torch.zeros(64, 256, device=x.device, dtype=torch.float32)
+    db2 = torch.zeros(64, device=x.device, dtype=torch.float32)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH), z, dy, dW2, db2)
+    G[f'{p}.fn.fn.net.3.weight'].add_(dW2, alpha=0.5)
+    G[f'{p}.fn.fn.net.3.bias'].add_(db2, alpha=0.5)
+    # dW1 = dz^T LN(x);  db1 = sum dz
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, G[f'{p}.fn.fn.net.0.weight'],
+                      G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
+    dh = torch.empty(M, 64, device=x.device, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 256, 64), dz, _T(W1), dh)
+    return O.layernorm_bwd(x, st, P[f'{p}.fn.norm.weight'], dh, G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'],
+                           dR=dy, dR2=dR2)
+
+
+def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None):
+    """x: [B*T*Fq, 64] tokens; returns LN(y4) + x (the TSCB adds the block input, generator.py:70,72)."""
+    M = x.shape[0]
+    geom = A.seq_geometry(B, T, Fq, axis)
+    ctx = {'geom': geom}
+    y1, ctx['ff1'] = _ff_fwd(P, f'{p}.ff1', x, M)
+    # attention
+    st2 = O.row_stats(y1, M)
+    Wqkv = torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0).contiguous()
+    qkv = torch.empty(M, 192, device=x.device, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, Wqkv, qkv, rowstats=st2,
+                ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
+    E = P[f'{p}.attn.fn.rel_pos_emb.weight']
+    maxpos = (E.shape[0] - 1) // 2
+    o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25)
+    y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=1.0, ldr=64), o,
+                P[f'{p}.attn.fn.to_out.weight'], y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1)
+    ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos)
+    # conv module
+    st3 = O.row_stats(y2, M)
+    u = torch.empty(M, 128, device=x.device, dtype=torch.float32)
+    zc = torch.empty(M, 256, device=x.device, dtype=torch.float32)
+    Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
+    GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=256), y2,
+                Wpw1, u, bias=P[f'{p}.conv.net.2.bias'], AUX=zc, rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
+                pb=P[f'{p}.conv.net.0.bias'])
+    Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
+    g_bn, b_bn = P[f'{p}.conv.net.5.weight'], P[f'{p}.conv.net.5.bias']
+    count = float(M * dp.world)
+    if train:
+        bnstats = torch.zeros(1, 128, 2, device=x.device, dtype=torch.float64)
+        h = O.dwconv31(u, Wdw, P[f'{p}.conv.net.4.conv.bias'], geom, stats=bnstats)
+        dp.allreduce(bnstats)
+        rm = buffers[f'{p}.conv.net.5.running_mean'] if buffers is not None else None
+        rv = buffers[f'{p}.conv.net.5.running_var'] if buffers is not None else None
+        mr, ss = O.norm_finalize(bnstats, g_bn, b_bn, 1, 128, count, running_mean=rm, running_var=rv, momentum=0.1)
+        if buffers is not None:
+            buffers[f'{p}.conv.net.5.num_batches_tracked'] += 1
+    else:
+        h = O.dwconv31(u, Wdw, P[f'{p}.conv.net.4.conv.bias'], geom)
+        mr, ss = O.bn_eval_scale(P[f'{p}.conv.net.5.running_mean'], P[f'{p}.conv.net.5.running_var'], g_bn, b_bn)
+    sc = ss[0, :, 0].contiguous()
+    sh = ss[0, :, 1].contiguous()
+    y3 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
+    Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
+    GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=1.0,
+                               ldr=64), h, Wpw2, y3, bias=P[f'{p}.conv.net.7.bias'], R=y2, ps=sc, pb=sh)
+    ctx['conv'] = (y2, st3, zc, u, h, mr, sc, sh, count)
+    y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M)
+    out, st5 = O.layernorm_fwd(y4, P[f'{p}.post_norm.weight'], P[f'{p}.post_norm.bias'], R=x)
+    ctx['post'] = (y4, st5)
+    return out, ctx
+
+
+def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
+    M = dout.shape[0]
+    geom = ctx['geom']
+    dev = dout.device
+    y4, st5 = ctx['post']
+    dy4 = O.layernorm_bwd(y4, st5, P[f'{p}.post_norm.weight'], dout, G[f'{p}.post_norm.weight'],
+                          G[f'{p}.post_norm.bias'])
+    dy3 = _ff_bwd(P, G, f'{p}.ff2', ctx['ff2'], dy4, M)
+    ctx['ff2'] = ctx['post'] = None
+    # conv module: y3 = y2 + swish(bn(h)) @ Wpw2^T + b
+    y2, st3, zc, u, h, mr, sc, sh, count = ctx['conv']
+    Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
+    dact = torch.empty(M, 128, device=dev, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 64, 128), dy3, _T(Wpw2), dact)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH), h, dy3,
+                      G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
+    dh = torch.empty(M, 128, device=dev, dtype=torch.float32)
+    g_bn, b_bn = P[f'{p}.conv.net.5.weight'], P[f'{p}.conv.net.5.bias']
+    if train:
+        O.norm_prelu_bwd(h, 128, 0, mr, g_bn, b_bn, None, dact, 128, 0, dh, 128, 0, G[f'{p}.conv.net.5.weight'],
+                         G[f'{p}.conv.net.5.bias'], None, 1, M, 128, per_batch=False, act=1,
+                         allreduce=(dp.allreduce if dp.world > 1 else None), count=count)
+    else:
+        raise L.SeHipError('conformer_bwd in eval mode is not supported (BatchNorm uses running statistics)')
+    Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
+    du = O.dwconv31(dh, Wdw, None, geom, flip=True)
+    O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
+    dzc = O.glu_bwd(zc, du, M, 128)
+    Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
+    dl3 = torch.empty(M, 64, device=dev, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 256, 64), dzc, _T(Wpw1), dl3)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), y2, dzc, G[f'{p}.conv.net.2.weight'].view(256, 64),
+                      G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
+                      pb=P[f'{p}.conv.net.0.bias'])
+    dy2 = O.layernorm_bwd(y2, st3, P[f'{p}.conv.net.0.weight'], dl3, G[f'{p}.conv.net.0.weight'],
+                          G[f'{p}.conv.net.0.bias'], dR=dy3)
+    ctx['conv'] = None
+    del dact, dh, du, dzc, dl3, dy3, dy4
+    # attention: y2 = y1 + o @ Wo^T + bo
+    y1, st2, Wqkv, qkv, o, lse, maxpos = ctx['attn']
+    Wo = P[f'{p}.attn.fn.to_out.weight']
+    do = torch.empty(M, 64, device=dev, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 64, 64), dy2, _T(Wo), do)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64), o, dy2, G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
+    dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
+                      G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25)
+    dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, _T(Wqkv), dl2)
+    dWqkv = torch.zeros(192, 64, device=dev, dtype=torch.float32)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, dqkv, dWqkv, None, rowstats=st2,
+                      ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
+    G[f'{p}.attn.fn.to_q.weight'] += dWqkv[:64]
+    G[f'{p}.attn.fn.to_kv.weight'] += dWqkv[64:]
+    dy1 = O.layernorm_bwd(y1, st2, P[f'{p}.attn.norm.weight'], dl2, G[f'{p}.attn.norm.weight'],
+                          G[f'{p}.attn.norm.bias'], dR=dy2)
+    ctx['attn'] = None
+    del do, dqkv, dl2, dy2
+    # ff1, plus the TSCB residual (out = LN(y4) + x)
+    dx = _ff_bwd(P, G, f'{p}.ff1', ctx['ff1'], dy1, M, dR2=dout)
+    ctx['ff1'] = None
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# decoders (models/generator.py:77-129)
+# ------------------------------------------------------------------------------------------------
+def _decoder_head_fwd(P, p, x, B, T, Fq):
+    skip = torch.empty(B, T, Fq, 256, device=x.device, dtype=torch.float32)
+    skip[..., :64].copy_(x.view(B, T, Fq, 64))      # strided slab copy (plumbing; the only one per decoder)
+    return dense_block_fwd(P, f'{p}.dense_block', skip, B, T, Fq)
+
+
+def mask_decoder_fwd(P, x, B, T, Fq):
+    p = 'mask_decoder'
+    ctx = {}
+    d4, ctx['dense'] = _decoder_head_fwd(P, p, x, B, T, Fq)
+    S, _ = conv_fwd(d4, B, T, Fq, 64, 0, 64, pack_w(P[f'{p}.sub_pixel.conv.weight']), P[f'{p}.sub_pixel.conv.bias'],
+                    TAPS_1x3, 128, shuffle2=True, want_stats=False)                       # [B,T,2Fq,64]
+    F2 = 2 * Fq
+    Fo = F2 - 1
+    w1 = pack_w(pad_rows(P[f'{p}.conv_1.weight'], 4))
+    b1 = pad_rows(P[f'{p}.conv_1.bias'], 4)
+    r, st = conv_fwd(S, B, T, F2, 64, 0, 64, w1, b1, TAPS_1x2, 4, To=T, Fo=Fo)            # [B,T,Fo,4], channel 0
+    g4, be4, a4 = pad_rows(P[f'{p}.norm.weight'], 4), pad_rows(P[f'{p}.norm.bias'], 4), pad_rows(P[f'{p}.prelu.weight'], 4)
+    uact = torch.empty_like(r)
+    mr = inorm_prelu_fwd(r, st, g4, be4, a4, uact, 4, 0)
+    wb = torch.cat([P[f'{p}.final_conv.weight'].view(1), P[f'{p}.final_conv.bias'].view(1)])
+    mask = O.mask_tail(uact, 4, wb, P[f'{p}.prelu_out.weight'], B * T * Fo, Fo)
+    ctx.update(d4=d4, S=S, r=r, mr=mr, uact=uact, wb=wb, pads=(g4, be4, a4), Fo=Fo)
+    return mask, ctx
+
+
+def mask_decoder_bwd(P, G, ctx, dmask, B, T, Fq):
+    p = 'mask_decoder'
+    Fo, F2 = ctx['Fo'], 2 * Fq
+    dev = dmask.device
+    n = B * T * Fo
+    duact = torch.empty(B, T, Fo, 4, device=dev, dtype=torch.float32)
+    dwb = torch.zeros(2, device=dev, dtype=torch.float64)
+    O.mask_tail_bwd(ctx['uact'], 4, ctx['wb'], P[f'{p}.prelu_out.weight'], dmask, duact, dwb,
+                    G[f'{p}.prelu_out.weight'], n, Fo)
+    G[f'{p}.final_conv.weight'] += dwb[0].float().view(1, 1, 1, 1)
+    G[f'{p}.final_conv.bias'] += dwb[1].float().view(1)
+    g4, be4, a4 = ctx['pads']
+    dg4, db4, da4 = (torch.zeros(4, device=dev) for _ in range(3))
+    dr = inorm_prelu_bwd(ctx['r'], ctx['mr'], g4, be4, a4, duact, 4, 0, dg4, db4, da4)
+    G[f'{p}.norm.weight'] += dg4[:1]
+    G[f'{p}.norm.bias'] += db4[:1]
+    G[f'{p}.prelu.weight'] += da4[:1]
+    dw1 = torch.zeros(4, 64, 1, 2, device=dev)
+    dbias1 = torch.zeros(4, device=dev)
+    dS = conv_bwd(ctx['S'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv_1.weight'], 4), TAPS_1x2, dr, T, Fo, dw1, dbias1)
+    G[f'{p}.conv_1.weight'] += dw1[:1]
+    G[f'{p}.conv_1.bias'] += dbias1[:1]
+    dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq)
+    dskip = dense_block_bwd(P, G, f'{p}.dense_block', ctx['dense'], dd4, B, T, Fq)
+    return dskip        # slab 0 = input gradient
+
+
+def _subpixel_bwd(P, G, p, x, dS, B, T, Fq):
+    """SPConvTranspose2d backward: dS [B,T,2Fq,64] is the un-shuffled gradient; view it as [B,T,Fq,128] with
+    channel r*64+c <- pixel 2f+r (the pixel shuffle is a pure re-indexing of the same memory)."""
+    dconv = dS.view(B, T, Fq, 128)                      # [.., f, (r, c)] : memory order is already (f, r, c)
+    w = P[f'{p}.conv.weight']
+    dw = G[f'{p}.conv.weight']
+    return conv_bwd(x, B, T, Fq, 64, 0, 64, w, TAPS_1x3, dconv, T, Fq, dw, G[f'{p}.conv.bias'])
+
+
+def complex_decoder_fwd(P, x, B, T, Fq):
+    p = 'complex_decoder'
+    ctx = {}
+    d4, ctx['dense'] = _decoder_head_fwd(P, p, x, B, T, Fq)
+    S, st = conv_fwd(d4, B, T, Fq, 64, 0, 64, pack_w(P[f'{p}.sub_pixel.conv.weight']), P[f'{p}.sub_pixel.conv.bias'],
+                     TAPS_1x3, 128, shuffle2=True, want_stats=True)
+    F2 = 2 * Fq
+    Fo = F2 - 1
+    a = torch.empty_like(S)
+    mr = inorm_prelu_fwd(S, st, P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], a, 64, 0)
+    wc = pack_w(pad_rows(P[f'{p}.conv.weight'], 4))
+    bc = pad_rows(P[f'{p}.conv.bias'], 4)
+    cplx, _ = conv_fwd(a, B, T, F2, 64, 0, 64, wc, bc, TAPS_1x2, 4, To=T, Fo=Fo, want_stats=False)
+    ctx.update(d4=d4, S=S, mr=mr, a=a, Fo=Fo)
+    return cplx, ctx
+
+
+def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
+    p = 'complex_decoder'
+    Fo, F2 = ctx['Fo'], 2 * Fq
+    dev = dcplx.device
+    dwc = torch.zeros(4, 64, 1, 2, device=dev)
+    dbc = torch.zeros(4, device=dev)
+    da = conv_bwd(ctx['a'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv.weight'], 4), TAPS_1x2, dcplx, T, Fo, dwc, dbc)
+    G[f'{p}.conv.weight'] += dwc[:2]
+    G[f'{p}.conv.bias'] += dbc[:2]
+    dS = inorm_prelu_bwd(ctx['S'], ctx['mr'], P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], da,
+                         64, 0, G[f'{p}.norm.weight'], G[f'{p}.norm.bias'], G[f'{p}.prelu.weight'])
+    dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq)
+    return dense_block_bwd(P, G, f'{p}.dense_block', ctx['dense'], dd4, B, T, Fq)
+
+
+# ------------------------------------------------------------------------------------------------
+# TSCNet (models/generator.py:132-167)
+# ------------------------------------------------------------------------------------------------
+def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None):
+    """xin: planes [B, T, F, 4] = (|x|, Re x, Im x, 0) of the compressed noisy spectrum.
+    returns est planes [B, T, F, 4] = (|est|, Re est, Im est, 0) and the ctx for tscnet_bwd."""
+    B, T, Fq, _ = xin.shape
+    ctx = {'xin': xin, 'dims': (B, T, Fq)}
+    x, ctx['enc'] = encoder_fwd(P, xin, B, T, Fq)
+    Fp = x.shape[2]
+    ctx['Fp'] = Fp
+    tok = x.view(B * T * Fp, 64)
+    ctx['tscb'] = []
+    for i in range(1, 5):
+        tok, c1 = conformer_fwd(P, f'TSCB_{i}.time_conformer', tok, B, T, Fp, 'time', train, dp, buffers)
+        tok, c2 = conformer_fwd(P, f'TSCB_{i}.freq_conformer', tok, B, T, Fp, 'freq', train, dp, buffers)
+        ctx['tscb'].append((c1, c2))
+    mask, ctx['mask'] = mask_decoder_fwd(P, tok, B, T, Fp)
+    cplx, ctx['cplx'] = complex_decoder_fwd(P, tok, B, T, Fp)
+    est = O.assemble(mask, 1, xin, cplx)
+    ctx['est'] = est
+    return est, ctx
+
+
+def tscnet_bwd(P, G, ctx, dest, dp=NO_DP):
+    """dest: gradient w.r.t. the est planes (dmag, dre, dim, -).  Parameter gradients are added into G."""
+    B, T, Fq = ctx['dims']
+    Fp = ctx['Fp']
+    dev = dest.device
+    dmask = torch.empty(B * T * Fq, device=dev, dtype=torch.float32)
+    dcplx = torch.empty(B, T, Fq, 4, device=dev, dtype=torch.float32)
+    O.assemble_bwd(ctx['est'], dest, ctx['xin'], dmask, 1, dcplx)
+    dsk_c = complex_decoder_bwd(P, G, ctx['cplx'], dcplx, B, T, Fp)
+    dsk_m = mask_decoder_bwd(P, G, ctx['mask'], dmask, B, T, Fp)
+    dtok = (dsk_c[..., :64] + dsk_m[..., :64]).reshape(B * T * Fp, 64)      # plumbing: sum of the two decoder branches
+    del dsk_c, dsk_m
+    ctx['cplx'] = ctx['mask'] = None
+    for i in (4, 3, 2, 1):
+        c1, c2 = ctx['tscb'][i - 1]
+        dtok = conformer_bwd(P, G, f'TSCB_{i}.freq_conformer', c2, dtok, B, T, Fp, dp)
+        dtok = conformer_bwd(P, G, f'TSCB_{i}.time_conformer', c1, dtok, B, T, Fp, dp)
+        ctx['tscb'][i - 1] = None
+    encoder_bwd(P, G, ctx['enc'], dtok.view(B, T, Fp, 64), B, T, Fq)
+    return None

@@ -1,0 +1,287 @@
+"""The GAN train / validation step of core/function.py (train_gan :182-343, validate_gan :346-451,
+compute_self_correcting_loss_weights :705-760, batch_stft :664-683) on the HIP path.
+
+One process per GPU.  Data parallelism (main_gan.py:133-188) = utterance sharding + one RCCL all-reduce of the
+flat generator gradient buffer and one of the flat discriminator gradient buffer per step (torch.distributed
+backend "nccl" == RCCL over xGMI) + the SyncBatchNorm statistic exchanges inside the Conformer conv modules.
+PESQ labels are third-party CPU arithmetic (PyPI `pesq`, not available offline): they come from a pluggable
+provider (`set_pesq_provider`); parity / bench runs supply them as inputs.
+"""
+import time
+
+import torch
+import torch.distributed as dist
+
+from . import frontend as FE
+from . import layers as LY
+from . import losses as LS
+from . import ops as O
+from .utils import AverageMeter, adjust_learning_rate
+
+_PESQ_PROVIDER = None
+
+
+def set_pesq_provider(fn):
+    """fn(clean_list, noisy_list) -> FloatTensor [B] of (pesq - 1) / 3.5 on the current device."""
+    global _PESQ_PROVIDER
+    _PESQ_PROVIDER = fn
+
+
+def pesq_labels(clean_list, noisy_list):
+    if _PESQ_PROVIDER is not None:
+        return _PESQ_PROVIDER(clean_list, noisy_list)
+    try:
+        from pesq import pesq          # noqa: F401  (third-party; models/discriminator.py:17-32)
+    except ImportError as e:
+        raise RuntimeError('no PESQ provider: install `pesq` or call train.set_pesq_provider(fn)') from e
+    import numpy as np
+    from joblib import Parallel, delayed
+
+    def one(c, n):
+        try:
+            return pesq(16000, c, n, 'wb')
+        except Exception:
+            return -1
+    s = np.array(Parallel(n_jobs=-1)(delayed(one)(c, n) for c, n in zip(clean_list, noisy_list)))
+    return torch.FloatTensor((s - 1) / 3.5).to('cuda')
+
+
+class DataParallelHooks(LY.DPHooks):
+    """RCCL hooks: SyncBatchNorm statistic all-reduce + flat gradient all-reduce (average)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+
+    def allreduce(self, t):
+        dist.all_reduce(t, group=self.group)
+        return t
+
+    def average_grads(self, optimizer):
+        for g in optimizer.flat_grads():
+            dist.all_reduce(g, group=self.group)
+            g.mul_(1.0 / self.world)
+
+
+def attach_data_parallel(model, discriminator, group=None):
+    """main_gan.py:154-171 counterpart: broadcast rank-0 parameters/buffers once, install the hooks."""
+    hooks = DataParallelHooks(group)
+    for m in (model, discriminator):
+        for t in list(m.parameters()) + list(m.buffers()):
+            dist.broadcast(t.data, 0, group=group)
+    model.dp = hooks
+    return hooks
+
+
+def batch_stft(batch, args, config):
+    """core/function.py:664-683 on the kernel path.  Returns the reference's 8-tuple (complex [B,F,T] specs)."""
+    clean, noisy = batch['audio'], batch['noisy']
+    if getattr(args, 'gpu', None) is not None:
+        clean, noisy = clean.cuda(args.gpu, non_blocking=True), noisy.cuda(args.gpu, non_blocking=True)
+    c = O.clip_scale(noisy.contiguous())
+    npl, npad = FE.stft_planes(noisy, config.N_FFT, config.HOP_SAMPLES, 'pow', scale=c)
+    cpl, cpad = FE.stft_planes(clean, config.N_FFT, config.HOP_SAMPLES, 'pow', scale=c)
+    h = config.N_FFT // 2
+    clean_n, noisy_n = cpad[:, h:h + clean.shape[1]], npad[:, h:h + noisy.shape[1]]
+    clean_spec, noisy_spec = FE.planes_to_spec(cpl), FE.planes_to_spec(npl)
+    one_labels = torch.ones(len(clean), device=clean.device)
+    window = torch.hamming_window(config.N_FFT, device=clean.device)
+    return clean_n, noisy_n, clean_spec, noisy_spec, clean_spec.real.unsqueeze(1), clean_spec.imag.unsqueeze(1), \
+        one_labels, window
+
+
+def _mse(a, b):
+    return ((a - b) ** 2).mean()
+
+
+def self_correcting_weights(CE, CN, EN, EE, NN):
+    """core/function.py:736-748 (EE, NN include the +1e-14)."""
+    if CE > 0:
+        wE = 1.0
+        wN = 1.0 if (CN + wE * EN) > 0 else -(CN) / NN - (EN) / NN
+    else:
+        wE = -(CE) / EE
+        wN = 1.0 if (CN + wE * EN) > 0 else -(CN) / NN + (CE * EN) / (EE * NN)
+    return 1.0, wE, wN
+
+
+def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch, loss_weights, n_fft=400, hop=100,
+             comp_type='pow', max_norm=0.0, gan_on=True, labels=None, hooks=None):
+    """One iteration of the train_gan loop body (core/function.py:216-315).  `labels`: dict with 'est'
+    (and 'clean', 'noisy' for scp/sc) giving the PESQ targets directly; if None the PESQ provider is called on the
+    audio like the reference does.  Returns a dict of python-float-convertible loss tensors (no host sync here)."""
+    B, Ls = clean.shape
+    out = {}
+    optimizer.zero_grad()
+    c = O.clip_scale(noisy.contiguous())
+    noisy_pl, noisy_pad = FE.stft_planes(noisy, n_fft, hop, 'pow', scale=c)
+    clean_pl, clean_pad = FE.stft_planes(clean, n_fft, hop, 'pow', scale=c)
+    h = n_fft // 2
+    clean_n = clean_pad[:, h:h + Ls]
+    est = model.forward_planes(noisy_pl)
+    est_audio = FE.istft_planes(est, n_fft, hop, 'pow')
+    if arch in ('scp', 'cp'):
+        est_p = FE.stft_planes_grad(est_audio, n_fft, hop, comp_type)
+        with torch.no_grad():
+            clean_audio_p = FE.istft_planes(clean_pl, n_fft, hop, 'pow')
+            clean_p, _ = FE.stft_planes(clean_audio_p, n_fft, hop, comp_type)
+        loss_mag, loss_ri = LS.spec_losses(est_p, clean_p)
+        time_loss = LS.l1_time_loss(est_audio, clean_audio_p)
+    else:
+        loss_mag, loss_ri = LS.spec_losses(est, clean_pl)
+        time_loss = LS.l1_time_loss(est_audio, clean_n)
+    w = loss_weights
+    ones = torch.ones(B, device=clean.device)
+    if gan_on:
+        gen_gan = _mse(discriminator.forward_planes(clean_pl, est, detach_params=True).flatten(), ones)
+        loss = w[0] * loss_ri + w[1] * loss_mag + w[2] * time_loss + w[3] * gen_gan
+    else:
+        gen_gan = torch.zeros((), device=clean.device)
+        loss = w[0] * loss_ri + w[1] * loss_mag + w[2] * time_loss
+    loss.backward()
+    if hooks is not None:
+        hooks.average_grads(optimizer)
+    if max_norm != 0.0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+    optimizer.step()
+    out.update(loss_ri=loss_ri.detach(), loss_mag=loss_mag.detach(), time_loss=time_loss.detach(),
+               gan=gen_gan.detach(), loss_g=loss.detach())
+
+    optimizer_disc.zero_grad()
+    if not gan_on:
+        out['loss_d'] = torch.zeros((), device=clean.device)
+        return out
+    est_d = est.detach()
+    if labels is None:
+        length = est_audio.size(-1)
+        est_list = list(est_audio.detach().cpu().numpy())
+        clean_list = list(clean_n.cpu().numpy()[:, :length])
+    d_gx = discriminator.forward_planes(clean_pl, est_d)
+    q_est = labels['est'] if labels is not None else pesq_labels(clean_list, est_list)
+    d_yy = discriminator.forward_planes(clean_pl, clean_pl)
+    L_E = _mse(d_gx.flatten(), q_est)
+    if arch in ('scp', 'sc'):
+        q_clean = labels['clean'] if labels is not None else pesq_labels(clean_list, clean_list)
+        L_C = _mse(d_yy.flatten(), q_clean)
+        d_xy = discriminator.forward_planes(clean_pl, noisy_pl)
+        if labels is None:
+            noisy_list = list(noisy_pad[:, h:h + Ls].cpu().numpy()[:, :length])
+        q_noisy = labels['noisy'] if labels is not None else pesq_labels(clean_list, noisy_list)
+        L_N = _mse(d_xy.flatten(), q_noisy)
+        loss_d, wE, wN = _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hooks)
+        out.update(L_N=L_N.detach(), w_E=wE, w_N=wN)
+    else:
+        L_C = _mse(d_yy.flatten(), ones)
+        loss_d = L_C + L_E
+        loss_d.backward()
+        if hooks is not None:
+            hooks.average_grads(optimizer_disc)
+    if max_norm != 0.0:
+        torch.nn.utils.clip_grad_norm_(discriminator.parameters(), max_norm)
+    optimizer_disc.step()
+    out.update(L_C=L_C.detach(), L_E=L_E.detach(), loss_d=loss_d.detach())
+    return out
+
+
+def _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hooks):
+    """compute_self_correcting_loss_weights + the caller's backward (core/function.py:705-760, 310): three
+    gradient vectors, six dot products, piecewise weights; the optimizer then sees 2x the combined gradient, as in
+    the reference (param.grad is written, then backward() on the weighted loss adds the same quantity again).
+    Multi-GPU semantics (undefined in the reference): the three gradients are averaged over
+    ranks BEFORE the dot products, so every rank computes identical weights == the single-process result at the
+    global batch."""
+    params = [p for p in discriminator.parameters()]
+    flats = []
+    for L_ in (L_C, L_E, L_N):
+        gs = torch.autograd.grad(L_, params, retain_graph=True, allow_unused=True)
+        flats.append(torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]))
+    if hooks is not None:
+        for f in flats:
+            hooks.allreduce(f)
+            f.mul_(1.0 / hooks.world)
+    C, E, N = flats
+    dots = torch.zeros(5, device=C.device, dtype=torch.float64)
+    for i, (a, b) in enumerate(((E, E), (N, N), (C, E), (C, N), (E, N))):
+        O.dot(a, b, dots[i:i + 1])
+    EE, NN, CE, CN, EN = (float(v) for v in dots.cpu())
+    wC, wE, wN = self_correcting_weights(CE, CN, EN, EE + 1e-14, NN + 1e-14)
+    comb = O.axpbypcz(C, E, N, 2.0 * wC, 2.0 * wE, 2.0 * wN)
+    o = 0
+    for p in params:
+        k = p.numel()
+        p.grad.copy_(comb[o:o + k].view_as(p))
+        o += k
+    return (wC * L_C + wE * L_E + wN * L_N), wE, wN
+
+
+def train_gan(train_loader, model, discriminator, criterion, optimizer, optimizer_disc, logger, epoch, args, config):
+    """core/function.py:182-343: same signature and return values (avg generator / discriminator loss)."""
+    if getattr(args, 'debug', False):
+        torch.autograd.set_detect_anomaly(True)
+    batch_time, data_time, gen_losses, disc_losses = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
+    model.train()
+    discriminator.train()
+    hooks = model.dp if getattr(model.dp, 'world', 1) > 1 else None
+    start = end = time.time()
+    iters = len(train_loader)
+    for idx, batch in enumerate(train_loader):
+        data_time.update(time.time() - end)
+        adjust_learning_rate([optimizer, optimizer_disc], epoch + idx / iters, config)
+        clean, noisy = batch['audio'], batch['noisy']
+        if getattr(args, 'gpu', None) is not None:
+            clean, noisy = clean.cuda(args.gpu, non_blocking=True), noisy.cuda(args.gpu, non_blocking=True)
+        gan_on = epoch >= int(args.epochs * 0.3) or not args.gen_first
+        out = gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, args.arch, config.LOSS_WEIGHTS,
+                       config.N_FFT, config.HOP_SAMPLES, args.comp_type, args.max_norm, gan_on,
+                       labels=batch.get('labels'), hooks=hooks)
+        torch.cuda.synchronize()
+        gen_losses.update(out['loss_g'].item(), clean.size(0))
+        disc_losses.update(out['loss_d'].item(), clean.size(0))
+        batch_time.update(time.time() - end)
+        end = time.time()
+        if idx % args.print_freq == 0 and logger is not None:
+            logger.info(f'Train: [{epoch}/{args.epochs}][{idx}/{iters}]\t'
+                        f'lr {optimizer.param_groups[0]["lr"]:.6f}\ttime {batch_time.val:.4f} ({batch_time.avg:.4f})\t'
+                        f'generator loss {gen_losses.val:.4f} ({gen_losses.avg:.4f})\t'
+                        f'discriminator loss {disc_losses.val:.4f} ({disc_losses.avg:.4f})\t'
+                        f'mem {torch.cuda.max_memory_allocated() / 2 ** 20:.0f}MB')
+    if logger is not None:
+        logger.info(f'EPOCH {epoch} training takes {time.time() - start:.0f}s')
+    return gen_losses.avg, disc_losses.avg
+
+
+@torch.no_grad()
+def validate_gan(valid_loader, model, discriminator, criterion, logger, epoch, args, config):
+    """core/function.py:346-451: no backward, always L_C(ones) + L_E."""
+    model.eval()
+    discriminator.eval()
+    gen_losses, disc_losses = AverageMeter(), AverageMeter()
+    w = config.LOSS_WEIGHTS
+    for batch in valid_loader:
+        clean, noisy = batch['audio'], batch['noisy']
+        if getattr(args, 'gpu', None) is not None:
+            clean, noisy = clean.cuda(args.gpu, non_blocking=True), noisy.cuda(args.gpu, non_blocking=True)
+        B, Ls = clean.shape
+        c = O.clip_scale(noisy.contiguous())
+        noisy_pl, _ = FE.stft_planes(noisy, config.N_FFT, config.HOP_SAMPLES, 'pow', scale=c)
+        clean_pl, clean_pad = FE.stft_planes(clean, config.N_FFT, config.HOP_SAMPLES, 'pow', scale=c)
+        h = config.N_FFT // 2
+        clean_n = clean_pad[:, h:h + Ls]
+        est = model.forward_planes(noisy_pl)
+        est_audio = FE.istft_planes(est, config.N_FFT, config.HOP_SAMPLES, 'pow')
+        loss_mag, loss_ri = LS.spec_losses(est, clean_pl)
+        time_loss = LS.l1_time_loss(est_audio, clean_n)
+        ones = torch.ones(B, device=clean.device)
+        d_gx = discriminator.forward_planes(clean_pl, est)
+        gan = _mse(d_gx.flatten(), ones)
+        loss = w[0] * loss_ri + w[1] * loss_mag + w[2] * time_loss + w[3] * gan
+        labels = batch.get('labels')
+        if labels is not None:
+            q = labels['est']
+        else:
+            q = pesq_labels(list(clean_n.cpu().numpy()), list(est_audio.cpu().numpy()))
+        d_yy = discriminator.forward_planes(clean_pl, clean_pl)
+        loss_d = _mse(d_yy.flatten(), ones) + _mse(d_gx.flatten(), q)
+        gen_losses.update(loss.item(), B)
+        disc_losses.update(loss_d.item(), B)
+    return gen_losses.avg, disc_losses.avg

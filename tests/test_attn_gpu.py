@@ -1,0 +1,54 @@
+"""GPU parity of the fused relative-position attention against a plain PyTorch fp64 restatement."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_attention(qkv, E, B, T, Fq, axis, maxpos, scale):
+    """qkv [B,T,Fq,192] fp64 -> O [B,T,Fq,64] (materialises n x n; test sizes only)."""
+    x = qkv if axis == 'freq' else qkv.transpose(1, 2)          # [B, outer, n, 192]
+    n = x.shape[2]
+    q, k, v = x[..., :64], x[..., 64:128], x[..., 128:]
+    sp = lambda t: t.reshape(*t.shape[:3], 4, 16).transpose(2, 3)   # [B, outer, 4, n, 16]
+    q, k, v = sp(q), sp(k), sp(v)
+    idx = torch.arange(n, device=qkv.device)
+    rel = (idx[:, None] - idx[None, :]).clamp(-maxpos, maxpos) + maxpos
+    Er = E[rel]                                                     # [n, n, 16]
+    logits = (q @ k.transpose(-1, -2) + torch.einsum('bohid,ijd->bohij', q, Er)) * scale
+    o = torch.softmax(logits, -1) @ v                               # [B, outer, 4, n, 16]
+    o = o.transpose(2, 3).reshape(*x.shape[:3], 64)
+    return o if axis == 'freq' else o.transpose(1, 2)
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / max(float(b.detach().abs().max()), 1e-2))
+
+
+CASES = [(2, 37, 19, 'time', 512), (2, 37, 19, 'freq', 512), (1, 321, 3, 'time', 512), (3, 5, 101, 'freq', 512),
+         (1, 40, 2, 'time', 8), (2, 3, 50, 'freq', 5), (1, 600, 1, 'time', 512), (1, 16, 4, 'time', 512),
+         (1, 1, 1, 'freq', 512)]
+
+
+@pytest.mark.parametrize('B,T,Fq,axis,maxpos', CASES)
+def test_attention_fwd_bwd(B, T, Fq, axis, maxpos):
+    from speech_enhancement_amd import attention as A
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + Fq)
+    qkv = (torch.randn(B, T, Fq, 192, generator=g) * 1.5).cuda()
+    E = (torch.randn(2 * maxpos + 1, 16, generator=g) * 0.7).cuda()
+    dO = torch.randn(B, T, Fq, 64, generator=g).cuda()
+    geom = A.seq_geometry(B, T, Fq, axis)
+    O, lse = A.attn_fwd(qkv.view(-1, 192), E, geom, maxpos=maxpos)
+    q64 = qkv.double().requires_grad_(True)
+    E64 = E.double().requires_grad_(True)
+    ref = ref_attention(q64, E64, B, T, Fq, axis, maxpos, 0.25)
+    assert relerr(O.view(B, T, Fq, 64), ref) < 5e-6
+    ref.backward(dO.double())
+    dE = torch.zeros_like(E)
+    dqkv = A.attn_bwd(qkv.view(-1, 192), E, O, dO.view(-1, 64), lse, geom, dE, maxpos=maxpos)
+    dq = dqkv.view(B, T, Fq, 192)
+    assert relerr(dq[..., :64], q64.grad[..., :64]) < 2e-5, 'dq'
+    assert relerr(dq[..., 64:128], q64.grad[..., 64:128]) < 2e-5, 'dk'
+    assert relerr(dq[..., 128:], q64.grad[..., 128:]) < 2e-5, 'dv'
+    assert relerr(dE, E64.grad) < 2e-5, 'dE'

@@ -1,0 +1,207 @@
+"""GPU parity of the whole hot path (front-end, generator fwd/bwd, discriminator, train step) against the
+committed golden vectors produced by the reference, and against the oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+import formula
+
+pytestmark = pytest.mark.gpu
+
+
+def rms(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a)).cuda()
+
+
+def cplx(a):
+    a = t(a)
+    return torch.complex(a[..., 0], a[..., 1])
+
+
+@pytest.fixture(scope='module')
+def S():
+    import speech_enhancement_amd as S
+    return S
+
+
+def load_g(S, train=True):
+    g = S.TSCNet(64, 201)
+    g.load_state_dict(formula.formula_state('generator'))
+    g.cuda()
+    g.train(train)
+    return g
+
+
+def load_d(S, train=True):
+    d = S.Discriminator(16)
+    d.load_state_dict(formula.formula_state('discriminator'))
+    d.cuda()
+    for m in d.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    d.train(train)
+    return d
+
+
+def test_frontend(S, golden):
+    from speech_enhancement_amd import frontend as FE, ops as O
+    noisy = t(golden['fe_noisy'])
+    c = O.clip_scale(noisy)
+    for comp in ('pow', 'log', 'norm', 'none'):
+        planes, xp = FE.stft_planes(noisy, 400, 100, comp, scale=c)
+        spec = torch.view_as_real(FE.planes_to_spec(planes))
+        ref = golden[f'fe_spec_{comp}']
+        assert rms(spec, ref) < 3e-5 * max(1.0, float(np.abs(ref).max())), comp
+        y = S.uncompressed_istft(cplx(ref), 400, 100, None, comp_type=comp)
+        assert rms(y, golden[f'fe_istft_{comp}']) < 3e-5, comp
+    assert rms(xp[:, 200:-200], golden['fe_noisy_n']) < 1e-6
+    s = S.compressed_stft(t(golden['fe_noisy_n']), 400, 100, None)
+    assert rms(torch.view_as_real(s), golden['fe_spec_pow']) < 3e-5
+
+
+@pytest.mark.parametrize('tag', ['t17', 'f101'])
+def test_conformer_block(S, golden, tag):
+    """one Conformer block vs the reference's (golden): outputs, input gradient, rel-pos / depthwise gradients,
+    BatchNorm running statistics."""
+    from speech_enhancement_amd import layers as LY
+    g = load_g(S)
+    p = 'TSCB_1.time_conformer'
+    P = {k: v for k, v in g.named_parameters()}
+    P.update(dict(g.named_buffers()))
+    x = t(golden[f'cf_{tag}_x'])                       # [Bs, n, 64] -> B=Bs, T=n, F'=1, time axis
+    Bs, n, _ = x.shape
+    with torch.no_grad():
+        tok = x.reshape(Bs * n, 64).contiguous()
+        y, ctx = LY.conformer_fwd(P, p, tok, Bs, n, 1, 'time', True, LY.NO_DP, dict(g.named_buffers()))
+        y = y - tok                                    # the kernel path folds the TSCB residual in
+        assert rms(y.view(Bs, n, 64), golden[f'cf_{tag}_y_train']) < 3e-5
+        assert rms(P[f'{p}.conv.net.5.running_mean'], golden[f'cf_{tag}_rm']) < 1e-6
+        assert rms(P[f'{p}.conv.net.5.running_var'], golden[f'cf_{tag}_rv']) < 1e-6
+        G = {k: torch.zeros_like(v) for k, v in g.named_parameters()}
+        dy = torch.cos(torch.arange(y.numel(), device='cuda').view(Bs, n, 64) * 0.01).reshape(Bs * n, 64)
+        dx = LY.conformer_bwd(P, G, p, ctx, dy.contiguous(), Bs, n, 1) - dy
+        for got, key in ((dx.view(Bs, n, 64), 'dx'), (G[f'{p}.attn.fn.rel_pos_emb.weight'], 'dE'),
+                         (G[f'{p}.conv.net.4.conv.weight'], 'dWdw')):
+            ref = golden[f'cf_{tag}_{key}']
+            assert rms(got, ref) < 2e-4 * float(np.abs(ref).max()), key
+        g.load_state_dict(formula.formula_state('generator'))
+        ye, _ = LY.conformer_fwd(P, p, tok, Bs, n, 1, 'time', False)
+        assert rms((ye - tok).view(Bs, n, 64), golden[f'cf_{tag}_y_eval']) < 3e-5
+
+
+def test_tscnet_forward_backward(S, golden):
+    g = load_g(S)
+    spec = cplx(golden['fe_spec_pow'])
+    er, ei = g(spec)
+    assert rms(er, golden['g_real']) < 2e-4 and rms(ei, golden['g_imag']) < 2e-4
+    wr = torch.cos(torch.arange(er.numel(), device='cuda').view_as(er) * 0.013)
+    wi = torch.sin(torch.arange(ei.numel(), device='cuda').view_as(ei) * 0.017)
+    (er * wr + ei * wi).sum().backward()
+    names = [k for k, _ in g.named_parameters()]
+    gn = np.array([float(p.grad.norm()) for _, p in g.named_parameters()])
+    ref = golden['g64_gradnorm']
+    bad = [(names[i], gn[i], ref[i]) for i in range(len(names))
+           if abs(gn[i] - ref[i]) > 5e-3 * ref[i] + 5e-5 * ref.max()]
+    assert not bad, bad[:10]
+    grads = dict((k, p.grad) for k, p in g.named_parameters())
+    for k in golden.files:
+        if k.startswith('g64_grad:'):
+            r = golden[k]
+            assert rms(grads[k[9:]], r) < 2e-3 * float(np.abs(r).max()), k
+    g.load_state_dict(formula.formula_state('generator'))      # the train-mode pass advanced the BN running stats
+    g.eval()
+    with torch.no_grad():
+        er, ei = g(spec)
+    assert rms(er, golden['g_real_eval']) < 2e-4 and rms(ei, golden['g_imag_eval']) < 2e-4
+
+
+def test_discriminator(S, golden):
+    d = load_d(S)
+    cm = t(golden['d_in_clean_mag'])
+    nm = t(golden['d_in_noisy_mag']).requires_grad_(True)
+    y = d(cm, nm)
+    assert rms(y, golden['d_out_train']) < 1e-5
+    (y.flatten() * torch.tensor([1.0, -2.0], device='cuda')).sum().backward()
+    assert rms(nm.grad, golden['d64_dnoisy']) < 1e-3 * float(np.abs(golden['d64_dnoisy']).max())
+    gn = np.array([float(p.grad.norm()) for _, p in d.named_parameters()])
+    np.testing.assert_allclose(gn, golden['d64_gradnorm'], rtol=5e-3, atol=2e-5 * float(gn.max()))
+    sd = d.state_dict()
+    for li in (0, 3, 6, 9, 14, 17):
+        assert rms(sd[f'layers.{li}.weight_u'], golden[f'd_u{li}']) < 1e-5
+        assert rms(sd[f'layers.{li}.weight_v'], golden[f'd_v{li}']) < 1e-5
+    d2 = load_d(S, train=False)
+    with torch.no_grad():
+        assert rms(d2(cm, nm.detach()), golden['d_out_eval']) < 1e-5
+
+
+@pytest.mark.parametrize('arch,weights,optname', [('cmgan', (0.1, 0.9, 0.2, 0.05), 'sgd'),
+                                                  ('cmgan', (0.1, 0.9, 0.2, 0.05), 'adamw'),
+                                                  ('scp', (0.3, 0.7, 0.2, 0.05), 'sgd')])
+def test_train_step_vs_reference_loop(S, golden, arch, weights, optname):
+    """one train_gan iteration of the reference (golden, fp32 and fp64 runs) vs gan_step on the GPU."""
+    import types
+    from speech_enhancement_amd import train as TR, optim
+    from oracle import se_oracle as Or
+    g, d = load_g(S), load_d(S)
+    base_lr = 0.01 if optname == 'sgd' else 5e-4
+    args = types.SimpleNamespace(optimizer=optname, lr=base_lr, weight_decay=0.01, momentum=0.9, max_norm=0.0)
+    og, od = optim.build_optimizer(args, g), optim.build_optimizer(args, d, lr=base_lr * 2)
+    lr = Or.lr_at(10.0, base_lr, 100)
+    for o in (og, od):
+        for grp in o.param_groups:
+            grp['lr'] = lr
+    labels = {k: t(golden[f'q_{k}']) for k in ('est', 'clean', 'noisy')}
+    out = TR.gan_step(g, d, og, od, t(golden['fe_clean']), t(golden['fe_noisy']), arch, weights, labels=labels)
+    pre = f'step_{arch}_{optname}_f64_'
+    mse = golden[pre + 'mse_calls']
+    assert abs(float(out['loss_mag']) - mse[0]) < 2e-4 * mse[0]
+    assert abs(float(out['loss_ri']) - (mse[1] + mse[2])) < 2e-4 * (mse[1] + mse[2])
+    assert abs(float(out['gan']) - mse[3]) < 2e-4 * mse[3] + 1e-6
+    assert abs(float(out['L_E']) - mse[4]) < 1e-3 * mse[4] + 1e-6
+    assert abs(float(out['L_C']) - mse[5]) < 1e-3 * mse[5] + 1e-6
+    assert abs(float(out['loss_g']) - float(golden[pre + 'gen_loss'])) < 2e-4 * abs(float(out['loss_g']))
+    if arch == 'scp':
+        return      # the fp32 consistency-path gradient is ill-conditioned; losses only
+    gs, ds = g.state_dict(), d.state_dict()
+    gnorm = np.array([float(v.double().norm()) for v in gs.values()])
+    dnorm = np.array([float(v.double().norm()) for v in ds.values()])
+    ref_g, ref_d = golden[pre + 'g_norm'], golden[pre + 'd_norm']
+    if optname == 'sgd':
+        np.testing.assert_allclose(gnorm, ref_g, rtol=3e-4, atol=1e-5)
+        np.testing.assert_allclose(dnorm, ref_d, rtol=3e-4, atol=1e-5)
+        for k in golden.files:
+            if k.startswith(pre + 'g:') or k.startswith(pre + 'd:'):
+                name = k.split(':', 1)[1]
+                new = gs[name] if k.startswith(pre + 'g:') else ds[name]
+                src = formula.formula_state('generator' if k.startswith(pre + 'g:') else 'discriminator')[name]
+                if name.endswith(('_u', '_v')):
+                    assert rms(new, golden[k]) < 1e-5, k
+                    continue
+                upd_ref = golden[k].astype(np.float64) - src.double().numpy()
+                upd = new.double().cpu().numpy() - src.double().numpy()
+                assert rms(upd, upd_ref) < 1e-2 * np.sqrt(np.mean(upd_ref ** 2)) + 1e-9, k
+    else:
+        numel_g = np.array([v.numel() for v in gs.values()])
+        assert np.all(np.abs(gnorm - ref_g) < 3e-4 * ref_g + 2 * lr * np.sqrt(0.05 * numel_g) + 2 * lr)
+
+
+def test_full_size_enhanced_magnitude(S, golden):
+    """north_star parity bar: RMS(|est| - |est_ref|) <= 1e-3 on the compressed enhanced magnitude of a 2 s clip."""
+    from speech_enhancement_amd import frontend as FE, ops as O
+    g = load_g(S)
+    noisy = t(golden['full_noisy'])
+    planes, _ = FE.stft_planes(noisy, 400, 100, 'pow', scale=O.clip_scale(noisy))
+    with torch.no_grad():
+        est = g.forward_planes(planes)
+        audio = FE.istft_planes(est, 400, 100, 'pow')
+    ref = golden['full_est_mag']
+    e = rms(est[0, :, :, 0], ref)
+    print('enhanced-magnitude RMS error', e, 'reference RMS', float(np.sqrt(np.mean(ref.astype(np.float64) ** 2))))
+    assert e < 1e-3
+    assert rms(audio, golden['full_est_audio']) < 1e-3

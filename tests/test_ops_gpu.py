@@ -1,0 +1,130 @@
+"""GPU parity of the normalisation / depthwise / elementwise kernels against plain PyTorch references."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-6))
+
+
+def test_layernorm_fwd_bwd():
+    from speech_enhancement_amd import ops as O
+    M = 1237
+    x, g, b, r, dy = rnd(M, 64, seed=1) * 2 + 0.3, rnd(64, seed=2) * 0.1 + 1, rnd(64, seed=3) * 0.1, rnd(M, 64, seed=4), rnd(M, 64, seed=5)
+    y, st = O.layernorm_fwd(x, g, b, R=r)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.layer_norm(x64, (64,), g64, b64, 1e-5) + r.double()
+    assert relerr(y, ref) < 1e-5
+    st2 = O.row_stats(x, M)
+    assert relerr(st2, st) < 1e-5
+    ref.backward(dy.double())
+    dg, db = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    dx = O.layernorm_bwd(x, st, g, dy, dg, db, dR=r, dR2=r)
+    assert relerr(dx, x64.grad + 2 * r.double()) < 2e-5
+    assert relerr(dg, g64.grad) < 2e-5 and relerr(db, b64.grad) < 2e-5
+
+
+@pytest.mark.parametrize('C', [64, 4, 16, 128])
+def test_instance_norm_prelu(C):
+    from speech_enhancement_amd import ops as O
+    B, T, Fq = 3, 13, 29
+    P = T * Fq
+    x = rnd(B, T, Fq, C, seed=1) * 1.7 + 0.4
+    g, be, a = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.2, rnd(C, seed=4) * 0.1 + 0.25
+    dy = rnd(B, T, Fq, 2 * C, seed=5)
+    stats = O.col_stats(x, C, 0, B, P, C)
+    mr, ss = O.norm_finalize(stats, g, be, B, C, float(P))
+    y = torch.zeros(B, T, Fq, 2 * C, device='cuda')
+    O.affine_prelu(x, C, 0, ss, a, y, 2 * C, C, B, P, C)
+    x64 = x.double().requires_grad_(True)
+    p64 = [t.double().requires_grad_(True) for t in (g, be, a)]
+    xn = F.instance_norm(x64.permute(0, 3, 1, 2), weight=p64[0], bias=p64[1], eps=1e-5)
+    ref = F.prelu(xn, p64[2]).permute(0, 2, 3, 1)
+    assert relerr(y[..., C:], ref) < 1e-5 and float(y[..., :C].abs().max()) == 0.0
+    ref.backward(dy[..., C:].double())
+    dg, db, da = (torch.zeros(C, device='cuda') for _ in range(3))
+    dx = torch.empty_like(x)
+    O.norm_prelu_bwd(x, C, 0, mr, g, be, a, dy, 2 * C, C, dx, C, 0, dg, db, da, B, P, C, per_batch=True)
+    assert relerr(dx, x64.grad) < 5e-5
+    assert relerr(dg, p64[0].grad) < 5e-5 and relerr(db, p64[1].grad) < 5e-5 and relerr(da, p64[2].grad) < 5e-5
+
+
+def test_batchnorm_swish_bwd_and_running_stats():
+    from speech_enhancement_amd import ops as O
+    M, C = 5000, 128
+    x = rnd(M, C, seed=1) * 1.3 - 0.2
+    g, be = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.2
+    dy = rnd(M, C, seed=4)
+    rm, rv = rnd(C, seed=6) * 0.1, rnd(C, seed=7).abs() + 0.5
+    rm0, rv0 = rm.clone(), rv.clone()
+    stats = O.col_stats(x, C, 0, 1, M, C)
+    mr, ss = O.norm_finalize(stats, g, be, 1, C, float(M), running_mean=rm, running_var=rv, momentum=0.1)
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = g.double().requires_grad_(True), be.double().requires_grad_(True)
+    rm64, rv64 = rm0.double(), rv0.double()
+    ref = F.silu(F.batch_norm(x64, rm64, rv64, g64, b64, True, 0.1, 1e-5))
+    assert relerr(rm, rm64) < 1e-5 and relerr(rv, rv64) < 1e-5
+    ref.backward(dy.double())
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dx = torch.empty_like(x)
+    O.norm_prelu_bwd(x, C, 0, mr, g, be, None, dy, C, 0, dx, C, 0, dg, db, None, 1, M, C, per_batch=False, act=1)
+    assert relerr(dx, x64.grad) < 5e-5 and relerr(dg, g64.grad) < 5e-5 and relerr(db, b64.grad) < 5e-5
+
+
+@pytest.mark.parametrize('axis,B,T,Fq', [('time', 2, 70, 5), ('freq', 2, 3, 101), ('time', 1, 321, 2), ('freq', 1, 2, 17)])
+def test_dwconv31(axis, B, T, Fq):
+    from speech_enhancement_amd import ops as O, attention as A
+    x = rnd(B, T, Fq, 128, seed=1)
+    w, b = rnd(128, 1, 31, seed=2, scale=0.2), rnd(128, seed=3)
+    dy = rnd(B, T, Fq, 128, seed=4)
+    geom = A.seq_geometry(B, T, Fq, axis)
+    stats = torch.zeros(1, 128, 2, device='cuda', dtype=torch.float64)
+    y = O.dwconv31(x.view(-1, 128), w.view(128, 31), b, geom, stats=stats).view(B, T, Fq, 128)
+    x64 = x.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    seqs = x64.permute(0, 2, 3, 1) if axis == 'time' else x64.permute(0, 1, 3, 2)          # [B, o, 128, n]
+    sh = seqs.shape
+    r = F.conv1d(F.pad(seqs.reshape(-1, 128, sh[-1]), (15, 15)), w64, b64, groups=128).reshape(sh)
+    ref = r.permute(0, 3, 1, 2) if axis == 'time' else r.permute(0, 1, 3, 2)
+    assert relerr(y, ref) < 1e-5
+    assert relerr(stats[0, :, 0], ref.sum((0, 1, 2))) < 1e-5 and relerr(stats[0, :, 1], (ref ** 2).sum((0, 1, 2))) < 1e-5
+    ref.backward(dy.double())
+    dx = O.dwconv31(dy.view(-1, 128), w.view(128, 31), None, geom, flip=True).view(B, T, Fq, 128)
+    assert relerr(dx, x64.grad) < 1e-5
+    dw, db = torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda')
+    O.dwconv31_wgrad(x.view(-1, 128), dy.view(-1, 128), dw, db, geom)
+    assert relerr(dw, w64.grad.view(128, 31)) < 2e-5 and relerr(db, b64.grad) < 2e-5
+
+
+def test_glu_bwd_and_optimizers():
+    from speech_enhancement_amd import ops as O
+    M = 777
+    z, du = rnd(M, 256, seed=1), rnd(M, 128, seed=2)
+    z64 = z.double().requires_grad_(True)
+    (z64[:, :128] * torch.sigmoid(z64[:, 128:])).backward(du.double())
+    assert relerr(O.glu_bwd(z, du, M, 128), z64.grad) < 1e-5
+    # AdamW / nesterov SGD vs torch.optim on one flat tensor
+    p0, g1, g2 = rnd(1000, seed=3), rnd(1000, seed=4), rnd(1000, seed=5)
+    for kind in ('adamw', 'sgd'):
+        p = torch.nn.Parameter(p0.clone().double())
+        opt = torch.optim.AdamW([p], lr=1e-2, weight_decay=0.01) if kind == 'adamw' else \
+            torch.optim.SGD([p], lr=1e-2, momentum=0.9, nesterov=True)
+        q, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        for step, g in enumerate((g1, g2), 1):
+            p.grad = g.double()
+            opt.step()
+            if kind == 'adamw':
+                O.adamw(q, g, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, step)
+            else:
+                O.sgd_nesterov(q, g, m, 1e-2, 0.9, step == 1)
+        assert relerr(q, p.data) < 1e-5, kind
