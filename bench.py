@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/sec of the CMGAN train step (generator fwd+bwd+AdamW, discriminator 3x fwd +
+bwd + AdamW, 2 STFT + 1 iSTFT fwd + 1 iSTFT bwd) on synthetic 2 s / 16 kHz clips, batch 16 per MI355X
+(BASELINE.json configs[1]).  One process per GPU; N > 1 is launched by torch.distributed.run (RCCL).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).  `roofline` is measured live
+with HIP events around every launch of the dominant kernel family during the timed steps; `cpu_baseline` times
+the CPU oracle (a torch-CPU port of the same step) on a bounded sample on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (== fp32 vector peak)
+PEAK_HBM_GBS = 8000.0
+GFLOP_PER_UTT_STEP = 440.0        # 3 x 145.96 (G fwd+bwd) + ~1.9 (D)
+
+
+def synth_batch(B, L, seed, device):
+    """BASELINE.md section 2 inputs: clean = 0.1 N(0,1), noisy = clean + 0.05 N(0,1), Q ~ U(0.2, 0.9)."""
+    g = torch.Generator().manual_seed(seed)
+    clean = 0.1 * torch.randn(B, L, generator=g)
+    noisy = clean + 0.05 * torch.randn(B, L, generator=g)
+    q = 0.2 + 0.7 * torch.rand(B, generator=torch.Generator().manual_seed(seed + 1))
+    return clean.to(device), noisy.to(device), q.to(device)
+
+
+def cpu_baseline(seconds_cap=40.0):
+    """one oracle train step (B=2, 2 s clips, AdamW, PESQ labels supplied) on the host cores."""
+    from oracle import se_oracle as Or
+    import formula
+    torch.manual_seed(0)
+    gsd, dsd = formula.formula_state('generator'), formula.formula_state('discriminator')
+    clean, noisy, q = synth_batch(2, 32000, 1, 'cpu')
+    t0 = time.time()
+    Or.train_step(gsd, dsd, clean, noisy, q, 'cmgan', (0.1, 0.9, 0.2, 0.05), lr=5e-4)
+    dt = time.time() - t0
+    return {'value': round(2.0 / dt, 4), 'unit': 'utterances/sec', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'1 CMGAN train step of the CPU oracle (torch-CPU port of the reference step), batch 2, '
+                      f'2 s clips, AdamW, PESQ labels supplied; {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=16, help='utterances per GPU per step')
+    ap.add_argument('--arch', default='cmgan')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    import speech_enhancement_amd as S
+    from speech_enhancement_amd import _lib, optim, train as TR
+
+    torch.manual_seed(0)
+    G, D = S.TSCNet(64, 201), S.Discriminator(16)
+    G.apply(S.kaiming_init)
+    D.apply(S.kaiming_init)
+    G.to(dev).train()
+    D.to(dev).train()
+    hooks = TR.attach_data_parallel(G, D) if world > 1 else None
+    oargs = types.SimpleNamespace(optimizer='adamw', lr=5e-4, weight_decay=0.01, momentum=0.9, max_norm=0.0)
+    og, od = optim.build_optimizer(oargs, G), optim.build_optimizer(oargs, D)
+    weights = (0.1, 0.9, 0.2, 0.05) if a.arch in ('cmgan', 'cp') else (0.3, 0.7, 0.2, 0.05)
+    B, L = a.batch, 32000
+    clean, noisy, q = synth_batch(B, L, 1 + rank, dev)
+    labels = {'est': q, 'clean': torch.full_like(q, 0.97), 'noisy': q * 0.5}
+
+    def step():
+        return TR.gan_step(G, D, og, od, clean, noisy, a.arch, weights, labels=labels, hooks=hooks)
+
+    for _ in range(a.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    _lib.TIMER.start()
+    t0 = time.time()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.time() - t0
+    _lib.TIMER.stop()
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    summ = _lib.TIMER.summary()
+    dom = max(summ.items(), key=lambda kv: kv[1]['ms']) if summ else None
+    roof = None
+    if dom is not None:
+        k, v = dom
+        ach = v['flops'] / (v['ms'] * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': k, 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': v['launches'] // a.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                'share_of_step_time': round(v['ms'] / (dt * 1e3), 3),
+                'families': {kk: {'ms_per_step': round(vv['ms'] / a.steps, 3),
+                                  'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)}
+                             for kk, vv in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}}
+    res = {
+        'metric': 'utterances/sec (2 s @16 kHz) CMGAN train step', 'value': round(world * B * a.steps / dt, 3),
+        'unit': 'utterances/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(dt / a.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{a.arch} generator+discriminator train step (main_gan.py train_gan loop body), '
+                               f'batch {B}/GPU, 2 s @ 16 kHz, n_fft=400 hop=100, AdamW lr 5e-4, PESQ labels supplied, '
+                               f'kaiming-init weights',
+                   'global_batch': world * B, 'parallelism': f'dp{world}',
+                   'effective_tflops': round(world * B * a.steps * GFLOP_PER_UTT_STEP / dt / 1e3, 2),
+                   'dropout': 'generator dropout masks (p=0.2) not yet generated in-kernel: see DESIGN.md'},
+        'losses': {k: round(float(v), 5) for k, v in out.items() if hasattr(v, 'item') or isinstance(v, float)},
+        'roofline': roof,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -52,9 +52,46 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def call(name, *args):
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (used by bench.py for the roofline object:
+    algorithmic FLOPs or bytes of each launch / its measured duration).  Off by default: zero overhead."""
+
+    def __init__(self):
+        self.active = False
+        self.records = []
+
+    def start(self):
+        self.records = []
+        self.active = True
+
+    def stop(self):
+        self.active = False
+
+    def summary(self):
+        """key -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for key, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            d['launches'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+            d['flops'] += flops
+            d['bytes'] += nbytes
+        return out
+
+
+TIMER = KernelTimer()
+
+
+def call(name, *args, _key=None, _flops=0.0, _bytes=0.0):
     fn = getattr(lib(), name)
-    rc = fn(*args)
+    if TIMER.active and _key is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        TIMER.records.append((_key, _flops, _bytes, e0, e1))
+    else:
+        rc = fn(*args)
     if rc != 0:
         raise SeHipError(f'{name} failed ({rc}): {lib().se_last_error().decode()}')
 

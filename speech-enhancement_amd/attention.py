@@ -22,7 +22,8 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True):
     lse = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32) if need_lse else None
     nseq, n, inner, os_, is_, ps = geom
     L.call('se_attn_fwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner),
-           C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos), C.c_float(scale), L.stream())
+           C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos), C.c_float(scale), L.stream(),
+           _key='attn_fwd_kernel', _flops=nseq * 4 * 3 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 256)
     return O, lse
 
 
@@ -35,5 +36,6 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
     nseq, n, inner, os_, is_, ps = geom
     L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dl), L.ptr(dqkv), L.ptr(dE),
            C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
-           C.c_int(maxpos), C.c_float(scale), L.stream())
+           C.c_int(maxpos), C.c_float(scale), L.stream(), _key='attn_bwd (delta+dkv+dq kernels)',
+           _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
     return dqkv

@@ -35,8 +35,11 @@ def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
 
 def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb=None, stats=None):
     L.check_cuda(A, W, Y, bias, R, AUX, rowstats, ps, pb, stats)
+    M = d.B * d.To * d.Fo
     L.call('se_gemm_tap', C.byref(d), L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Y), L.ptr(R), L.ptr(AUX),
-           L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream())
+           L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream(),
+           _key=f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>', _flops=2.0 * M * d.N * d.ntap * d.C,
+           _bytes=4.0 * M * (d.C + d.N))
     return Y
 
 
@@ -46,8 +49,10 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
         M = d.B * d.To * d.Fo
         nblk = d.ntap * ((d.C + 63) // 64) * ((d.N + 63) // 64)
         chunks = max(1, min((M + 255) // 256, (2048 + nblk - 1) // nblk))
+    Mt = d.B * d.To * d.Fo
     L.call('se_gemm_tap_wgrad', C.byref(d), L.ptr(A), L.ptr(dY), L.ptr(dW), L.ptr(dbias), L.ptr(rowstats),
-           L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream())
+           L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream(), _key=f'wgrad_kernel<{d.prologue}>',
+           _flops=2.0 * Mt * d.N * d.ntap * d.C, _bytes=4.0 * Mt * (d.C + d.N))
     return dW
 
 
