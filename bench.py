@@ -141,7 +141,8 @@ def main():
                                f'kaiming-init weights',
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'effective_tflops': round(world * B * a.steps * GFLOP_PER_UTT_STEP / dt / 1e3, 2),
-                   'dropout': 'generator dropout masks (p=0.2) not yet generated in-kernel: see DESIGN.md'},
+                   'dropout': 'generator ff/attn dropout p=0.2 on (counter-based masks in the GEMM pro/epilogues); '
+                              'discriminator Dropout(0.3) on'},
         'losses': {k: round(float(v), 5) for k, v in out.items() if hasattr(v, 'item') or isinstance(v, float)},
         'roofline': roof,
     }

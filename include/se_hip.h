@@ -22,7 +22,9 @@ extern "C" {
 #define SE_MAX_TAPS 16
 
 /* prologue applied to the A operand while it is staged into LDS */
-enum { SE_PRO_NONE = 0, SE_PRO_LN = 1, SE_PRO_SWISH = 2, SE_PRO_AFFINE_SWISH = 3 };
+enum { SE_PRO_NONE = 0, SE_PRO_LN = 1, SE_PRO_SWISH = 2, SE_PRO_AFFINE_SWISH = 3,
+       SE_PRO_SWISH_DROP = 4,   /* swish then dropout (nn.Dropout after Swish, models/conformer.py:139)  */
+       SE_PRO_DROP = 5 };       /* dropout only (backward of an output dropout: mask * dY as the A operand) */
 /* epilogue flags (bit mask) */
 enum {
   SE_EPI_BIAS = 1,       /* + bias[n]                                                   */
@@ -31,7 +33,9 @@ enum {
   SE_EPI_GLU = 8,        /* N = 2*No: Y[.., j] = a * sigmoid(g); also stores pre-GLU Z   */
   SE_EPI_STATS = 16,     /* per-(b, n) sum / sum-of-squares of the result (fp64 atomics) */
   SE_EPI_SWISH_GRAD = 32,/* Y = result * swish'(AUX[m][n])                              */
-  SE_EPI_SHUFFLE2 = 64   /* sub-pixel: channel r*No+c -> pixel 2f+r, channel c (N = 2*No) */
+  SE_EPI_SHUFFLE2 = 64,  /* sub-pixel: channel r*No+c -> pixel 2f+r, channel c (N = 2*No) */
+  SE_EPI_DROP = 128      /* dropout on the (bias-added) result, mask = hash(epi_seed, m*N + n) (nn.Dropout after a
+                            Linear, conformer.py:94,141); in se_gemm_tap_wgrad: the same mask applied to dY      */
 };
 
 /* One "tap GEMM":  Y[m][n] = epi( sum_tap sum_c pro(A[src(m,tap)][a_off+c]) * W[n][tap*C+c] )
@@ -53,6 +57,8 @@ typedef struct {
   float alpha;           /* SE_EPI_RESID scale                                              */
   int ldr, r_off;        /* residual pixel stride / channel offset                          */
   int ldx, x_off;        /* AUX (SWISH_GRAD) or Z (GLU) pixel stride / channel offset        */
+  unsigned pro_seed, epi_seed;   /* dropout streams of the prologue / epilogue masks             */
+  float drop_p;          /* dropout probability (0 = off); kept elements are scaled by 1/(1-p) */
 } se_gemm_desc;
 
 int se_version(void);

@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libse_hip.so')
 SE_MAX_TAPS = 16
 
-PRO_NONE, PRO_LN, PRO_SWISH, PRO_AFFINE_SWISH = 0, 1, 2, 3
-EPI_BIAS, EPI_ACCUM, EPI_RESID, EPI_GLU, EPI_STATS, EPI_SWISH_GRAD, EPI_SHUFFLE2 = 1, 2, 4, 8, 16, 32, 64
+PRO_NONE, PRO_LN, PRO_SWISH, PRO_AFFINE_SWISH, PRO_SWISH_DROP, PRO_DROP = 0, 1, 2, 3, 4, 5
+EPI_BIAS, EPI_ACCUM, EPI_RESID, EPI_GLU, EPI_STATS, EPI_SWISH_GRAD, EPI_SHUFFLE2, EPI_DROP = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class GemmDesc(C.Structure):
@@ -20,7 +20,8 @@ class GemmDesc(C.Structure):
                 ('C', C.c_int), ('lda', C.c_int), ('a_off', C.c_int),
                 ('N', C.c_int), ('ldc', C.c_int), ('c_off', C.c_int), ('ldw', C.c_int),
                 ('prologue', C.c_int), ('epilogue', C.c_int), ('alpha', C.c_float),
-                ('ldr', C.c_int), ('r_off', C.c_int), ('ldx', C.c_int), ('x_off', C.c_int)]
+                ('ldr', C.c_int), ('r_off', C.c_int), ('ldx', C.c_int), ('x_off', C.c_int),
+                ('pro_seed', C.c_uint), ('epi_seed', C.c_uint), ('drop_p', C.c_float)]
 
 
 class SeHipError(RuntimeError):

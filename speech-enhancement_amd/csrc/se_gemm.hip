@@ -37,9 +37,18 @@ static __device__ __forceinline__ long src_pixel(const se_gemm_desc& d, int b, i
   return ((long)b * d.Ti + ti) * d.Fi + fi;
 }
 
+// Counter-based dropout mask: keep(element) = murmur3-finalizer(seed, element index) >= p * 2^32.  The same
+// (seed, index) pair is re-evaluated in the backward kernels, so no mask is ever stored.
+static __device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, unsigned thr, float inv_keep) {
+  unsigned x = idx * 0x9E3779B1u ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x >= thr ? inv_keep : 0.f;
+}
+
 template <int PRO>
 static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float mean, float rstd,
-                                                   const float* ps, const float* pb) {
+                                                   const float* ps, const float* pb, long pix, unsigned seed,
+                                                   unsigned thr, float inv_keep) {
   if (PRO == SE_PRO_NONE) return v;
   float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -49,6 +58,8 @@ static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float
       if (PRO == SE_PRO_LN) x[j] = (x[j] - mean) * rstd * ps[cc] + pb[cc];
       else if (PRO == SE_PRO_SWISH) x[j] = swishf_(x[j]);
       else if (PRO == SE_PRO_AFFINE_SWISH) x[j] = swishf_(x[j] * ps[cc] + pb[cc]);
+      else if (PRO == SE_PRO_SWISH_DROP) x[j] = swishf_(x[j]) * drop_scale(seed, (unsigned)(pix * C + cc), thr, inv_keep);
+      else if (PRO == SE_PRO_DROP) x[j] = x[j] * drop_scale(seed, (unsigned)(pix * C + cc), thr, inv_keep);
     } else {
       x[j] = 0.f;
     }
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     else { n = by * 64 + j; wok[i] = n < d.N; }
     wrow[i] = (long)n * d.ldw;
   }
-  float ln_mean[NA], ln_rstd[NA];
+  float ln_mean[NA] = {}, ln_rstd[NA] = {};
   if (PRO == SE_PRO_LN) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -108,7 +119,10 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   const int NI = d.ntap * nchunk;
   float4 ra[NA], rb[NB];
   bool aok[NA];
+  long apix[NA];
   int cur_c = 0;
+  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
+  const float inv_keep = 1.0f / (1.0f - d.drop_p);
 
   auto load_tiles = [&](int it) {
     int tap = it / nchunk;
@@ -120,6 +134,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     for (int i = 0; i < NA; ++i) {
       long p = (rok[i] && cok) ? src_pixel(d, b, rt[i], rf[i], tap) : -1;
       aok[i] = p >= 0;
+      apix[i] = p;
       ra[i] = aok[i] ? *reinterpret_cast<const float4*>(g.A + p * d.lda + d.a_off + c)
                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -143,7 +158,8 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       float4 v = ra[i];
-      if (PRO != SE_PRO_NONE && aok[i]) v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], g.ps, g.pb);
+      if (PRO != SE_PRO_NONE && aok[i])
+        v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], g.ps, g.pb, apix[i], d.pro_seed, thr, inv_keep);
       *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * SA + kq * 4]) = v;
     }
 #pragma unroll
@@ -201,6 +217,11 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
         g.Y[p * d.ldc + d.c_off + n0] = v0 * sigmoidf_(v1);
       }
       continue;
+    }
+    if (ep & SE_EPI_DROP) {       // dropout of the (bias-added) result, or of the hidden activation whose
+                                   // gradient this is (with SWISH_GRAD): mask index = output element
+      v0 *= drop_scale(d.epi_seed, (unsigned)(p * d.N + n0), thr, inv_keep);
+      v1 *= drop_scale(d.epi_seed, (unsigned)(p * d.N + n1), thr, inv_keep);
     }
     if (ep & SE_EPI_SWISH_GRAD) {
       if (nok0) v0 *= swish_gradf_(g.AUX[p * d.ldx + d.x_off + n0]);
@@ -285,8 +306,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
   const bool cok = c_ld < d.C;
 
   float4 ry[2], rx[2];
-  float mean[2], rstd[2];
+  float mean[2] = {}, rstd[2] = {};
   bool xok[2];
+  long xpix[2];
+  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
+  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
   auto load_tiles = [&](long mbase) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -296,8 +321,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
       if (ok) { b = (int)(mg / Mb); int m = (int)(mg - (long)b * Mb); t = m / d.Fo; f = m - t * d.Fo; }
       ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(g.dY + mg * d.ldc + d.c_off + n_ld)
                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy_drop && ok && nok) {
+        unsigned base = (unsigned)(mg * d.N + n_ld);
+        ry[i].x *= drop_scale(d.epi_seed, base, thr, inv_keep);
+        ry[i].y *= drop_scale(d.epi_seed, base + 1, thr, inv_keep);
+        ry[i].z *= drop_scale(d.epi_seed, base + 2, thr, inv_keep);
+        ry[i].w *= drop_scale(d.epi_seed, base + 3, thr, inv_keep);
+      }
       long p = (ok && cok) ? src_pixel(d, b, t, f, tap) : -1;
       xok[i] = p >= 0;
+      xpix[i] = p;
       rx[i] = xok[i] ? *reinterpret_cast<const float4*>(g.A + p * d.lda + d.a_off + c_ld)
                      : make_float4(0.f, 0.f, 0.f, 0.f);
       if (PRO == SE_PRO_LN) {
@@ -312,7 +345,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float4 v = rx[i];
-      if (PRO != SE_PRO_NONE && xok[i]) v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], g.ps, g.pb);
+      if (PRO != SE_PRO_NONE && xok[i])
+        v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], g.ps, g.pb, xpix[i], d.pro_seed, thr, inv_keep);
       *reinterpret_cast<float4*>(&Xs[(r0 + i * 16) * SY + q * 4]) = v;
       *reinterpret_cast<float4*>(&Ys[(r0 + i * 16) * SY + q * 4]) = ry[i];
     }
@@ -382,6 +416,9 @@ static int check_desc(const se_gemm_desc* d) {
   SE_REQUIRE(d->st >= 1 && d->sf >= 1, "gemm: bad strides");
   SE_REQUIRE(d->N > 0, "gemm: N=%d", d->N);
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(d->ntap == 1, "gemm: LN prologue needs ntap==1");
+  SE_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f out of range", d->drop_p);
+  if (d->prologue == SE_PRO_SWISH_DROP || d->prologue == SE_PRO_DROP || (d->epilogue & SE_EPI_DROP))
+    SE_REQUIRE((long)d->B * d->Ti * d->Fi * (d->C > d->N ? d->C : d->N) < 4294967296L, "gemm: dropout index exceeds 32 bits");
   return 0;
 }
 
@@ -410,6 +447,8 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     case SE_PRO_LN: if (bk16) LAUNCH(16, SE_PRO_LN); else LAUNCH(32, SE_PRO_LN); break;
     case SE_PRO_SWISH: if (bk16) LAUNCH(16, SE_PRO_SWISH); else LAUNCH(32, SE_PRO_SWISH); break;
     case SE_PRO_AFFINE_SWISH: if (bk16) LAUNCH(16, SE_PRO_AFFINE_SWISH); else LAUNCH(32, SE_PRO_AFFINE_SWISH); break;
+    case SE_PRO_SWISH_DROP: if (bk16) LAUNCH(16, SE_PRO_SWISH_DROP); else LAUNCH(32, SE_PRO_SWISH_DROP); break;
+    case SE_PRO_DROP: if (bk16) LAUNCH(16, SE_PRO_DROP); else LAUNCH(32, SE_PRO_DROP); break;
     default: return se_fail("gemm: unknown prologue %d", d->prologue);
   }
 #undef LAUNCH
@@ -437,6 +476,8 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
     case SE_PRO_LN: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_LN>), grid, block, 0, s, g); break;
     case SE_PRO_SWISH: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_SWISH>), grid, block, 0, s, g); break;
     case SE_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_AFFINE_SWISH>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH_DROP: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_SWISH_DROP>), grid, block, 0, s, g); break;
+    case SE_PRO_DROP: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_DROP>), grid, block, 0, s, g); break;
     default: return se_fail("wgrad: unknown prologue %d", d->prologue);
   }
   return se_check_launch("se_gemm_tap_wgrad");

@@ -13,7 +13,8 @@ def conv_taps(kh, kw, dil=(1, 1), pad=(0, 0)):
 
 
 def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=None, st=1, sf=1, up=0,
-              prologue=L.PRO_NONE, epilogue=0, alpha=1.0, ldr=0, r_off=0, ldx=0, x_off=0):
+              prologue=L.PRO_NONE, epilogue=0, alpha=1.0, ldr=0, r_off=0, ldx=0, x_off=0, pro_seed=0, epi_seed=0,
+              drop_p=0.0):
     d = GemmDesc()
     d.B, d.To, d.Fo, d.Ti, d.Fi = B, To, Fo, Ti, Fi
     d.st, d.sf, d.up = st, sf, up
@@ -25,6 +26,7 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
     d.ldw = ldw if ldw is not None else len(taps) * C_in
     d.prologue, d.epilogue, d.alpha = prologue, epilogue, alpha
     d.ldr, d.r_off, d.ldx, d.x_off = ldr, r_off, ldx, x_off
+    d.pro_seed, d.epi_seed, d.drop_p = pro_seed & 0xFFFFFFFF, epi_seed & 0xFFFFFFFF, drop_p
     return d
 
 

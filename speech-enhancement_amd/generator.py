@@ -82,8 +82,11 @@ class _TSCNetFn(torch.autograd.Function):
         P.update(model._buffer_dict())
         train = model.training
         with torch.no_grad():
+            model._drop_calls += 1
+            seed = (torch.initial_seed() * 2654435761 + model._drop_calls * 40503) & 0xFFFFFFFF
             est, c = LY.tscnet_fwd(P, xin.contiguous(), train=train, dp=model.dp,
-                                   buffers=model._buffer_dict() if train else None)
+                                   buffers=model._buffer_dict() if train else None,
+                                   drop=(model.ff_dropout, model.attn_dropout), seed=seed)
         ctx.c, ctx.P, ctx.model = c, P, model
         return est
 
@@ -130,8 +133,16 @@ class TSCNet(nn.Module):
         cd.conv = nn.Conv2d(ch, 2, (1, 2))
         self.complex_decoder = cd
         self.num_features = num_features
+        # TSCB builds its Conformers with attn_dropout=0.2, ff_dropout=0.2, conv_dropout=0 (generator.py:60-65)
+        self.ff_dropout, self.attn_dropout = 0.2, 0.2
+        self._drop_calls = 0
         self.dp = LY.NO_DP
         self._pnames = [k for k, _ in self.named_parameters()]
+
+    def set_dropout(self, ff=0.2, attn=0.2):
+        """train-mode dropout probabilities (parity runs use 0, like the fixtures)."""
+        self.ff_dropout, self.attn_dropout = float(ff), float(attn)
+        return self
 
     def _buffer_dict(self):
         return dict(self.named_buffers())

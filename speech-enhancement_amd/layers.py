@@ -212,29 +212,43 @@ def encoder_bwd(P, G, ctx, dout, B, T, Fq):
 # ------------------------------------------------------------------------------------------------
 # Conformer block (models/conformer.py:180-212) on the token view of [B, T, F', 64]
 # ------------------------------------------------------------------------------------------------
-def _ff_fwd(P, p, x, M):
-    """x + 0.5 * FF(LN(x)) (Scale(0.5, PreNorm(FeedForward)), conformer.py:53-71,128-145; dropout p=0)."""
+def site_seed(base, idx):
+    """dropout stream of one (layer, site): a 32-bit mix of the per-step base seed and the site index."""
+    return (base * 0x9E3779B1 + (idx + 1) * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF
+
+
+def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0):
+    """x + 0.5 * Drop(W2 Drop(Swish(W1 LN(x)))) (Scale(0.5, PreNorm(FeedForward)), conformer.py:53-71,128-145).
+    The two dropout masks are counter-based (hash(seed, element)) and re-evaluated in the backward."""
     st = O.row_stats(x, M)
     z = torch.empty(M, 256, device=x.device, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, epilogue=L.EPI_BIAS), x, P[f'{p}.fn.fn.net.0.weight'], z,
                 bias=P[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
     y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=0.5, ldr=64),
+    dr = drop > 0.0
+    GM.gemm_tap(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH,
+                               epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if dr else 0), alpha=0.5, ldr=64,
+                               pro_seed=seed_h, epi_seed=seed_o, drop_p=drop),
                 z, P[f'{p}.fn.fn.net.3.weight'], y, bias=P[f'{p}.fn.fn.net.3.bias'], R=x)
-    return y, (x, st, z)
+    return y, (x, st, z, drop, seed_h, seed_o)
 
 
 def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     """dy = gradient of (x + 0.5 FF(LN x)); returns dx (= dy + LN-path gradient (+ dR2))."""
-    x, st, z = saved
+    x, st, z, drop, seed_h, seed_o = saved
+    dr = drop > 0.0
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
-    # dz = 0.5 * (dy @ W2) * swish'(z)
+    # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z)
     dz = torch.empty(M, 256, device=x.device, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 256, epilogue=L.EPI_SWISH_GRAD, ldx=256), dy, _T(W2) * 0.5, dz, AUX=z)
-    # dW2 = 0.5 * dy^T swish(z);  db2 = 0.5 * sum dy
+    GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_DROP if dr else L.PRO_NONE,
+                               epilogue=L.EPI_SWISH_GRAD | (L.EPI_DROP if dr else 0), ldx=256, pro_seed=seed_o,
+                               epi_seed=seed_h, drop_p=drop), dy, _T(W2) * 0.5, dz, AUX=z)
+    # dW2 = 0.5 * (mask_o * dy)^T (mask_h * swish(z));  db2 = 0.5 * sum mask_o * dy
     dW2 = torch.zeros(64, 256, device=x.device, dtype=torch.float32)
     db2 = torch.zeros(64, device=x.device, dtype=torch.float32)
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH), z, dy, dW2, db2)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH,
+                                     epilogue=L.EPI_DROP if dr else 0, pro_seed=seed_h, epi_seed=seed_o, drop_p=drop),
+                      z, dy, dW2, db2)
     G[f'{p}.fn.fn.net.3.weight'].add_(dW2, alpha=0.5)
     G[f'{p}.fn.fn.net.3.bias'].add_(db2, alpha=0.5)
     # dW1 = dz^T LN(x);  db1 = sum dz
@@ -246,12 +260,15 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
                            dR=dy, dR2=dR2)
 
 
-def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None):
-    """x: [B*T*Fq, 64] tokens; returns LN(y4) + x (the TSCB adds the block input, generator.py:70,72)."""
+def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed=0):
+    """x: [B*T*Fq, 64] tokens; returns LN(y4) + x (the TSCB adds the block input, generator.py:70,72).
+    drop = (ff_dropout, attn_dropout) (generator.py:60-65: 0.2 / 0.2, conv dropout 0); seed: base of this
+    block's five dropout streams."""
     M = x.shape[0]
     geom = A.seq_geometry(B, T, Fq, axis)
     ctx = {'geom': geom}
-    y1, ctx['ff1'] = _ff_fwd(P, f'{p}.ff1', x, M)
+    pf, pa = (drop if train else (0.0, 0.0))
+    y1, ctx['ff1'] = _ff_fwd(P, f'{p}.ff1', x, M, pf, site_seed(seed, 0), site_seed(seed, 1))
     # attention
     st2 = O.row_stats(y1, M)
     Wqkv = torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0).contiguous()
@@ -262,9 +279,11 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None):
     maxpos = (E.shape[0] - 1) // 2
     o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25)
     y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=1.0, ldr=64), o,
+    sa = site_seed(seed, 2)
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if pa > 0 else 0), alpha=1.0,
+                               ldr=64, epi_seed=sa, drop_p=pa), o,
                 P[f'{p}.attn.fn.to_out.weight'], y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1)
-    ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos)
+    ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa)
     # conv module
     st3 = O.row_stats(y2, M)
     u = torch.empty(M, 128, device=x.device, dtype=torch.float32)
@@ -295,7 +314,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None):
     GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=1.0,
                                ldr=64), h, Wpw2, y3, bias=P[f'{p}.conv.net.7.bias'], R=y2, ps=sc, pb=sh)
     ctx['conv'] = (y2, st3, zc, u, h, mr, sc, sh, count)
-    y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M)
+    y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M, pf, site_seed(seed, 3), site_seed(seed, 4))
     out, st5 = O.layernorm_fwd(y4, P[f'{p}.post_norm.weight'], P[f'{p}.post_norm.bias'], R=x)
     ctx['post'] = (y4, st5)
     return out, ctx
@@ -340,11 +359,13 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     ctx['conv'] = None
     del dact, dh, du, dzc, dl3, dy3, dy4
     # attention: y2 = y1 + o @ Wo^T + bo
-    y1, st2, Wqkv, qkv, o, lse, maxpos = ctx['attn']
+    y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa = ctx['attn']
     Wo = P[f'{p}.attn.fn.to_out.weight']
     do = torch.empty(M, 64, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 64), dy2, _T(Wo), do)
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64), o, dy2, G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa),
+                dy2, _T(Wo), do)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa), o, dy2,
+                      G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25)
     dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
@@ -464,7 +485,7 @@ def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
 # ------------------------------------------------------------------------------------------------
 # TSCNet (models/generator.py:132-167)
 # ------------------------------------------------------------------------------------------------
-def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None):
+def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed=0):
     """xin: planes [B, T, F, 4] = (|x|, Re x, Im x, 0) of the compressed noisy spectrum.
     returns est planes [B, T, F, 4] = (|est|, Re est, Im est, 0) and the ctx for tscnet_bwd."""
     B, T, Fq, _ = xin.shape
@@ -475,8 +496,10 @@ def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None):
     tok = x.view(B * T * Fp, 64)
     ctx['tscb'] = []
     for i in range(1, 5):
-        tok, c1 = conformer_fwd(P, f'TSCB_{i}.time_conformer', tok, B, T, Fp, 'time', train, dp, buffers)
-        tok, c2 = conformer_fwd(P, f'TSCB_{i}.freq_conformer', tok, B, T, Fp, 'freq', train, dp, buffers)
+        tok, c1 = conformer_fwd(P, f'TSCB_{i}.time_conformer', tok, B, T, Fp, 'time', train, dp, buffers, drop,
+                                site_seed(seed, 100 + 2 * i))
+        tok, c2 = conformer_fwd(P, f'TSCB_{i}.freq_conformer', tok, B, T, Fp, 'freq', train, dp, buffers, drop,
+                                site_seed(seed, 101 + 2 * i))
         ctx['tscb'].append((c1, c2))
     mask, ctx['mask'] = mask_decoder_fwd(P, tok, B, T, Fp)
     cplx, ctx['cplx'] = complex_decoder_fwd(P, tok, B, T, Fp)

@@ -23,7 +23,7 @@ def ref_attention(qkv, E, B, T, Fq, axis, maxpos, scale):
 
 def relerr(a, b):
     a, b = a.double(), b.double()
-    return float((a - b).abs().max() / max(float(b.detach().abs().max()), 1e-2))
+    return float((a - b).abs().max() / max(float(b.detach().abs().max()), 1e-1))
 
 
 CASES = [(2, 37, 19, 'time', 512), (2, 37, 19, 'freq', 512), (1, 321, 3, 'time', 512), (3, 5, 101, 'freq', 512),

@@ -217,3 +217,46 @@ def test_missing_operand_is_loud(G):
         gemm.gemm_tap(gemm.linear_desc(64, 64, 64, epilogue=L.EPI_BIAS), x, w, y)
     with pytest.raises(L.SeHipError):
         gemm.gemm_tap(gemm.linear_desc(64, 64, 64), x.cpu(), w, y)
+
+
+def _mask(seed, rows, cols, p):
+    """torch restatement of the kernels' counter-based dropout mask (murmur3 finalizer of seed ^ idx*golden)."""
+    M32 = 0xFFFFFFFF
+    idx = torch.arange(rows * cols, device='cuda', dtype=torch.int64)
+    x = ((idx * 0x9E3779B1) & M32) ^ seed
+    x = x ^ (x >> 16)
+    x = (x * 0x85EBCA6B) & M32
+    x = x ^ (x >> 13)
+    x = (x * 0xC2B2AE35) & M32
+    x = x ^ (x >> 16)
+    thr = int(p * 4294967296.0)
+    return ((x >= thr).double() / (1.0 - p)).view(rows, cols)
+
+
+def test_feed_forward_with_dropout_fwd_bwd(G):
+    """x + 0.5 * Drop(W2 Drop(Swish(W1 LN x))) with counter-based masks: forward and every gradient against a
+    fp64 torch restatement using the SAME masks (so the backward provably re-creates the forward's masks)."""
+    from speech_enhancement_amd import layers as LY
+    M, p = 1500, 0.2
+    g = torch.Generator().manual_seed(3)
+    P = {'ff.fn.norm.weight': 1 + 0.1 * torch.randn(64, generator=g), 'ff.fn.norm.bias': 0.1 * torch.randn(64, generator=g),
+         'ff.fn.fn.net.0.weight': torch.randn(256, 64, generator=g) / 8, 'ff.fn.fn.net.0.bias': 0.1 * torch.randn(256, generator=g),
+         'ff.fn.fn.net.3.weight': torch.randn(64, 256, generator=g) / 16, 'ff.fn.fn.net.3.bias': 0.1 * torch.randn(64, generator=g)}
+    P = {k: v.cuda() for k, v in P.items()}
+    x, dy = rnd(M, 64, seed=5) + 0.2, rnd(M, 64, seed=6)
+    sh, so = 0x1234ABCD, 0x0BADF00D
+    y, saved = LY._ff_fwd(P, 'ff', x, M, p, sh, so)
+    Gd = {k: torch.zeros_like(v) for k, v in P.items()}
+    dx = LY._ff_bwd(P, Gd, 'ff', saved, dy, M)
+    mh, mo = _mask(sh, M, 256, p), _mask(so, M, 64, p)
+    assert abs(float(mh.mean()) - 1.0) < 0.02 and abs(float((mo > 0).double().mean()) - 0.8) < 0.02
+    P64 = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    x64 = x.double().requires_grad_(True)
+    h = F.layer_norm(x64, (64,), P64['ff.fn.norm.weight'], P64['ff.fn.norm.bias'], 1e-5)
+    h = F.silu(h @ P64['ff.fn.fn.net.0.weight'].T + P64['ff.fn.fn.net.0.bias']) * mh
+    ref = x64 + 0.5 * mo * (h @ P64['ff.fn.fn.net.3.weight'].T + P64['ff.fn.fn.net.3.bias'])
+    assert relerr(y, ref) < 5e-6
+    ref.backward(dy.double())
+    assert relerr(dx, x64.grad) < 3e-5
+    for k in P:
+        assert relerr(Gd[k], P64[k].grad) < 5e-5, k

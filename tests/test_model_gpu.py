@@ -35,6 +35,7 @@ def load_g(S, train=True):
     g.load_state_dict(formula.formula_state('generator'))
     g.cuda()
     g.train(train)
+    g.set_dropout(0.0, 0.0)          # the fixtures were generated with every nn.Dropout at p = 0
     return g
 
 
