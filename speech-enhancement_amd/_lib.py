@@ -46,6 +46,8 @@ def ptr(t):
     """device pointer of a tensor (or NULL)."""
     if t is None:
         return C.c_void_p(0)
+    if not t.is_cuda:
+        raise SeHipError('hot-path tensors must live on the GPU: there is no CPU fallback')
     return C.c_void_p(t.data_ptr())
 
 

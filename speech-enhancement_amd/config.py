@@ -58,7 +58,13 @@ class CfgNode(dict):
             if parts[-1] not in node:
                 raise KeyError(f'non-existent config key: {k}')
             old = node[parts[-1]]
-            node[parts[-1]] = yaml.safe_load(v) if isinstance(v, str) and not isinstance(old, str) else v
+            if isinstance(v, str) and not isinstance(old, str):
+                v = yaml.safe_load(v)
+                if isinstance(v, str) and isinstance(old, (int, float)):     # '1e-5' is a string in YAML 1.1
+                    v = type(old)(float(v))
+                elif isinstance(old, float) and isinstance(v, int):
+                    v = float(v)
+            node[parts[-1]] = v
 
 
 def defaults():

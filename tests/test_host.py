@@ -1,0 +1,161 @@
+"""CPU-only tests of the host logic: state_dict compatibility, C-ABI symbols, config surface, LR schedule,
+self-correcting weights, data-parallel hooks over gloo (world size 2), and "no silent fallback"."""
+import json
+import os
+import re
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def S():
+    import __graft_entry__
+    __graft_entry__.build()
+    import speech_enhancement_amd as S
+    return S
+
+
+def test_state_dict_names_match_reference(S):
+    spec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'state_spec.json')))
+    for which, m in (('generator', S.TSCNet(64, 201)), ('discriminator', S.Discriminator(16))):
+        ref = [(e[0], tuple(e[1]), e[2]) for e in spec[which]]
+        mine = [(k, tuple(v.shape), str(v.dtype).replace('torch.', '')) for k, v in m.state_dict().items()]
+        assert sorted(ref) == sorted(mine), which
+    import formula
+    g = S.TSCNet()
+    g.load_state_dict(formula.formula_state('generator'))          # strict load of a reference-shaped checkpoint
+    assert sum(p.numel() for p in g.parameters()) == 1834833
+    assert sum(p.numel() for p in S.Discriminator(16).parameters()) == 181650
+
+
+def test_abi_exports_every_declared_symbol(S):
+    import ctypes
+    hdr = open(os.path.join(ROOT, 'include', 'se_hip.h')).read()
+    names = set(re.findall(r'\b(se_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 40
+    lib = ctypes.CDLL(os.path.join(ROOT, 'speech-enhancement_amd', 'libse_hip.so'))
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.se_version() >= 1
+
+
+def test_no_silent_cpu_fallback(S):
+    from speech_enhancement_amd import ops, _lib, gemm
+    with pytest.raises(_lib.SeHipError):
+        ops.clip_scale(torch.randn(2, 100))
+    with pytest.raises(_lib.SeHipError):
+        gemm.gemm_tap(gemm.linear_desc(4, 64, 64), torch.randn(4, 64), torch.randn(64, 64), torch.empty(4, 64))
+    with pytest.raises(_lib.SeHipError):
+        S.compressed_stft(torch.randn(1, 1600), 400, 100)
+
+
+def test_config_surface(S, tmp_path):
+    base = tmp_path / 'base.yaml'
+    base.write_text('DATA:\n  BATCH_SIZE: 8\nLOSS_WEIGHTS: [0.3, 0.7, 0.2, 0.05]\n')
+    child = tmp_path / 'child.yaml'
+    child.write_text('BASE: ["base.yaml"]\nCROP_LEN: 3\n')
+    args = types.SimpleNamespace(cfg=str(child), opts=['TRAIN.SCHEDULER.MIN_LR', '1e-5', 'N_FFT', '512'],
+                                 batch_size=None, arch='scp', output='out', tag='t', lr=5e-4, epochs=120, crop_len=2)
+    c = S.get_config(args)
+    assert c.DATA.BATCH_SIZE == 8 and c.LOSS_WEIGHTS == [0.3, 0.7, 0.2, 0.05]
+    assert c.CROP_LEN == 2 and c.N_FFT == 512 and c.TRAIN.SCHEDULER.MIN_LR == 1e-5
+    assert c.TRAIN.SCHEDULER.LR == 5e-4 and c.TRAIN.SCHEDULER.EPOCHS == 120 and c.MODEL.NAME == 'scp'
+    assert c.OUTPUT == os.path.join('out', 'scp', 't')
+    with pytest.raises(AttributeError):
+        c.N_FFT = 1
+    d = S.get_config(types.SimpleNamespace(cfg=None))
+    assert (d.SAMPLE_RATE, d.N_FFT, d.HOP_SAMPLES, d.CROP_FRAMES) == (16000, 400, 100, 160)
+    assert d.LOSS_WEIGHTS == [0.1, 0.9, 0.2, 0.05] and d.TRAIN.SCHEDULER.CYCLE_LIMIT == 4
+    with pytest.raises(KeyError):
+        S.get_config(types.SimpleNamespace(cfg=None, opts=['NOPE', '1']))
+
+
+def test_lr_schedule_matches_reference(S, golden):
+    cfg = S.get_config(types.SimpleNamespace(cfg=None, lr=0.01, epochs=100))
+    opt = types.SimpleNamespace(param_groups=[{'lr': 1.0}, {'lr': 2.0}])
+    got = []
+    for e in golden['lr_epochs']:
+        r = S.adjust_learning_rate([opt], float(e), cfg)
+        assert opt.param_groups[0]['lr'] == opt.param_groups[1]['lr']
+        assert abs(r - opt.param_groups[0]['lr'] - 1e-6) < 1e-15
+        got.append(opt.param_groups[0]['lr'])
+    np.testing.assert_allclose(got, golden['lr_values'], rtol=1e-12, atol=1e-15)
+
+
+def test_self_correcting_weights_match_oracle(S):
+    from speech_enhancement_amd.train import self_correcting_weights
+    from oracle import se_oracle as Or
+    rs = np.random.RandomState(0)
+    for _ in range(200):
+        CE, CN, EN = rs.randn(3)
+        EE, NN = rs.rand(2) + 1e-3
+        assert self_correcting_weights(CE, CN, EN, EE, NN) == Or.self_correcting_weights(CE, CN, EN, EE, NN)
+
+
+def test_weight_decay_groups(S):
+    g = S.TSCNet()
+    decay, no_decay = S.set_weight_decay(g)
+    names = dict((id(p), k) for k, p in g.named_parameters())
+    nd = {names[id(p)] for p in no_decay['params']}
+    assert no_decay['weight_decay'] == 0.0
+    assert 'dense_encoder.conv_1.0.bias' in nd and 'TSCB_1.time_conformer.post_norm.weight' in nd
+    assert 'mask_decoder.prelu_out.weight' in nd and 'dense_encoder.conv_1.0.weight' not in nd
+    assert 'TSCB_1.time_conformer.attn.fn.rel_pos_emb.weight' not in nd
+    assert len(decay['params']) + len(no_decay['params']) == 335
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, ROOT)
+    from speech_enhancement_amd.train import DataParallelHooks
+    hooks = DataParallelHooks()
+    # SyncBatchNorm statistics: per-rank (sum, sumsq) of a sharded batch == statistics of the whole batch
+    full = torch.arange(40, dtype=torch.float64).view(4, 10) * 0.37 - 3.0
+    shard = full[rank * 2:(rank + 1) * 2]
+    st = torch.stack([shard.sum(0), (shard ** 2).sum(0)], -1)
+    hooks.allreduce(st)
+    ok1 = torch.allclose(st, torch.stack([full.sum(0), (full ** 2).sum(0)], -1))
+    # gradient averaging over the flat buffers of an optimizer
+    fake = types.SimpleNamespace(flat_grads=lambda: bufs)
+    bufs = [torch.full((5,), float(rank + 1)), torch.full((3,), float(10 * (rank + 1)))]
+    hooks.average_grads(fake)
+    ok2 = torch.allclose(bufs[0], torch.full((5,), 1.5)) and torch.allclose(bufs[1], torch.full((3,), 15.0))
+    # scp semantics: averaged gradient vectors -> identical dot products / weights on every rank
+    gvec = torch.tensor([1.0, -2.0, 0.5]) * (rank + 1)
+    hooks.allreduce(gvec)
+    gvec /= world
+    q.put((rank, bool(ok1), bool(ok2), float(gvec @ gvec), hooks.world))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_hooks_gloo_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] and r[4] == 2 for r in res)
+    assert res[0][3] == res[1][3]
