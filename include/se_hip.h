@@ -129,10 +129,12 @@ int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const
  * [tokens][4].  token(s,p) = (s/inner)*outer_stride + (s%inner)*inner_stride + p*pos_stride. */
 int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq, int n, int inner,
                 long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
-/* backward: dQKV [tokens][192] written, dE accumulated (atomics; caller zeroes); Dl = workspace [tokens][4] */
+/* backward: dQKV [tokens][192] written, dE accumulated (atomics; caller zeroes); Dl = workspace [tokens][4];
+ * Et (optional) = E transposed, [16][et_ld] with et_ld % 4 == 0: enables the single-pass LDS-staged kernel */
 int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                 float* Dl, float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
-                long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* stream);
+                long inner_stride, long pos_stride, long ntok, int maxpos, float scale, const float* Et,
+                int et_ld, void* stream);
 
 /* ---- depthwise conv k=31 along the sequence axis (csrc/se_dwconv.hip) -------------------------- */
 /* DepthWiseConv1d forward (models/conformer.py:40-48,166) on [tokens][128] (+ fp64 BatchNorm statistics

@@ -34,8 +34,11 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
     dqkv = torch.empty(ntok, 192, device=qkv.device, dtype=torch.float32)
     dl = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32)
     nseq, n, inner, os_, is_, ps = geom
+    et_ld = (E.shape[0] + 3) // 4 * 4
+    Et = torch.zeros(16, et_ld, device=E.device, dtype=torch.float32)      # transposed table (weight-sized plumbing)
+    Et[:, :E.shape[0]] = E.t()
     L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dl), L.ptr(dqkv), L.ptr(dE),
            C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
-           C.c_int(maxpos), C.c_float(scale), L.stream(), _key='attn_bwd (delta+dkv+dq kernels)',
+           C.c_int(maxpos), C.c_float(scale), L.ptr(Et), C.c_int(et_ld), L.stream(), _key='attn_bwd (delta+dkv+dq kernels)',
            _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
     return dqkv

@@ -17,6 +17,7 @@
 // the time Conformer ([B*F', T, C] in the reference, generator.py:69) and the frequency Conformer
 // ([B*T, F', C], generator.py:71) both run on the one channels-last [B, T, F', C] buffer with no transposes.
 #include "se_common.h"
+#include <stdlib.h>
 
 struct AttnGeom {
   int nseq, n;             // sequences, positions per sequence
@@ -197,6 +198,7 @@ struct AttnBwdArgs {
   float* dE;        // [2*maxpos+1][16], accumulated with atomics
   int maxpos;
   float scale;
+  int dbg;          // ablation switches for profiling builds (0 in production)
 };
 
 // ---- backward kernel 1: dK, dV.  One wave = (sequence, head, 32-key block); sweeps the queries 16 at a time.
@@ -453,6 +455,316 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ite
   }
 }
 
+
+// =====================================================================================================================
+// v2 kernels: one workgroup = one (sequence, head); K / V of the head staged once in LDS and shared by the 4 waves,
+// fragment loads are single 16-byte LDS / global accesses (contraction index d = 4g + s, so a lane's 4 MFMA steps read
+// one contiguous float4), token address arithmetic hoisted out of the loops.
+// =====================================================================================================================
+static __device__ __forceinline__ long seq_base(const AttnGeom& g, int s) {
+  return (long)(s / g.inner) * g.outer_stride + (long)(s % g.inner) * g.inner_stride;
+}
+static __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+
+// LDS: Ks[NP][16] | Vt[16][NP+4] | per-wave U ring [4][2 tiles][2 slots][256]
+__global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs a, int NP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vt = Ks + NP * 16;
+  const int VS = NP + 4;
+  float* Ubase = Vt + 16 * VS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n = a.g.n;
+  const int head = blockIdx.x & 3, seq = blockIdx.x >> 2;
+  const long base = seq_base(a.g, seq), ps = a.g.pos_stride;
+  const float* qkv = a.QKV + head * 16;
+  for (int i = tid; i < NP * 4; i += 256) {
+    int j = i >> 2, q = i & 3;
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+    if (j < n) {
+      const float* p = qkv + (base + (long)j * ps) * 192;
+      k4 = *reinterpret_cast<const float4*>(p + 64 + 4 * q);
+      v4 = *reinterpret_cast<const float4*>(p + 128 + 4 * q);
+    }
+    *reinterpret_cast<float4*>(&Ks[j * 16 + 4 * q]) = k4;
+    Vt[(4 * q + 0) * VS + j] = v4.x; Vt[(4 * q + 1) * VS + j] = v4.y;
+    Vt[(4 * q + 2) * VS + j] = v4.z; Vt[(4 * q + 3) * VS + j] = v4.w;
+  }
+  __syncthreads();
+  float* Ul = Ubase + wave * 1024;      // [tile t][slot][256]
+  const float l2e = 1.4426950408889634f * a.scale;
+  const int qblocks = (n + 31) / 32, nkt = (n + 15) / 16;
+  for (int qb = wave; qb < qblocks; qb += 4) {
+    const int i0 = qb * 32;
+    float4 qf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      int qi = i0 + 16 * t + c; if (qi > n - 1) qi = n - 1;
+      qf[t] = *reinterpret_cast<const float4*>(qkv + (base + (long)qi * ps) * 192 + 4 * g);
+    }
+    f32x4 o[2][2];
+    float m[2], l[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      m[t] = -1e30f; l[t] = 0.f;
+      o[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto u_tile = [&](int D, int t, int slot) {
+      int d = D + c;
+      d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+      float4 e = *reinterpret_cast<const float4*>(a.E + (long)(d + a.maxpos) * 16 + 4 * g);
+      f32x4 u = {0.f, 0.f, 0.f, 0.f};
+      u = MFMA16(e.x, qf[t].x, u); u = MFMA16(e.y, qf[t].y, u); u = MFMA16(e.z, qf[t].z, u); u = MFMA16(e.w, qf[t].w, u);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ul[(t * 2 + slot) * 256 + (4 * g + r) * 16 + c] = u[r];
+    };
+    u_tile(i0, 0, 0);
+    u_tile(i0 + 16, 1, 0);
+    int hi = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int j0 = kt * 16, lo = hi ^ 1;
+      u_tile(i0 - j0 - 16, 0, lo);
+      u_tile(i0 - j0, 1, lo);
+      float4 kf = *reinterpret_cast<const float4*>(&Ks[(j0 + c) * 16 + 4 * g]);
+      float4 vf = *reinterpret_cast<const float4*>(&Vt[c * VS + j0 + 4 * g]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+        s4 = MFMA16(kf.x, qf[t].x, s4); s4 = MFMA16(kf.y, qf[t].y, s4);
+        s4 = MFMA16(kf.z, qf[t].z, s4); s4 = MFMA16(kf.w, qf[t].w, s4);
+        float sc[4], tmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int dl = c - (4 * g + r);
+          float u = dl >= 0 ? Ul[(t * 2 + hi) * 256 + dl * 16 + c] : Ul[(t * 2 + lo) * 256 + (16 + dl) * 16 + c];
+          sc[r] = (j0 + 4 * g + r < n) ? (s4[r] + u) * l2e : -1e30f;
+          tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        float mn = fmaxf(m[t], tmax);
+        float corr = __builtin_amdgcn_exp2f(m[t] - mn);
+        m[t] = mn;
+        float p[4], psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mn); psum += p[r]; }
+        l[t] = l[t] * corr + psum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[t][0][r] *= corr; o[t][1][r] *= corr; }
+        o[t][0] = MFMA16(vf.x, p[0], o[t][0]);
+        o[t][1] = MFMA16(vf.y, p[1], o[t][1]);
+        o[t][0] = MFMA16(vf.z, p[2], o[t][0]);
+        o[t][1] = MFMA16(vf.w, p[3], o[t][1]);
+      }
+      hi = lo;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float lt = l[t];
+      lt += __shfl_xor(lt, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+      int qi = i0 + 16 * t + c;
+      if (qi < n) {
+        long tok = base + (long)qi * ps;
+        float inv = 1.0f / lt;
+        *reinterpret_cast<float4*>(a.O + tok * 64 + head * 16 + 4 * g) =
+            make_float4((o[t][0][0] + o[t][1][0]) * inv, (o[t][0][1] + o[t][1][1]) * inv,
+                        (o[t][0][2] + o[t][1][2]) * inv, (o[t][0][3] + o[t][1][3]) * inv);
+        if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt)) * 0.6931471805599453f;
+      }
+    }
+  }
+}
+
+// Single-pass backward: one workgroup walks (sequence, head) items; per item K, V are staged in LDS, each wave owns
+// 16-query tiles (dQ in registers, sliding rel-pos window as in the forward), dK / dV are accumulated in LDS with
+// ds_add_f32 and written once per item, dE is accumulated in LDS over ALL items of the workgroup and flushed once with
+// global atomics.  P^T / dS^T tiles are transposed through wave-private LDS to serve as the B operands of the
+// dV / dK products.  Requires |i - j| <= maxpos for all pairs (no clamp aliasing): NP <= maxpos.
+// LDS (floats): Ks[NP][16] Vs[NP][16] | dKa[16][NP+4] dVa[16][NP+4] dEa[16][2NP+4] (transposed: the 16 lanes of a
+// lane group add to 16 consecutive words, row strides = 4 mod 8 -> conflict-free ds_add) | scratch[4][6 tiles][16][20]
+template <int NP>
+__global__ __launch_bounds__(256) void attn_bwd2_kernel(AttnBwdArgs a, const float* __restrict__ Et, int ET, int items_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int LK = NP + 4, LE = 2 * NP + 4, TS = 20, TILE = 16 * TS;
+  float* Ks = smem;
+  float* Vs = Ks + NP * 16;
+  float* dKa = Vs + NP * 16;
+  float* dVa = dKa + 16 * LK;
+  float* dEa = dVa + 16 * LK;
+  float* scratch = dEa + 16 * LE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n = a.g.n;
+  float* Uf = scratch + wave * 6 * TILE;   // [2 slots]
+  float* dU = Uf + 2 * TILE;               // [2]
+  float* Pl = dU + 2 * TILE;               // [key][query]
+  float* dSl = Pl + TILE;
+  for (int i = tid; i < 16 * LE; i += 256) dEa[i] = 0.f;
+  const long nitems = (long)a.g.nseq * 4;
+  const long ibeg = (long)blockIdx.x * items_per_block;
+  const int qtiles = (n + 15) / 16, nkt = (n + 15) / 16;
+  const float l2e = 1.4426950408889634f;
+  const long ps = a.g.pos_stride;
+  for (long it = ibeg; it < ibeg + items_per_block && it < nitems; ++it) {
+    const int head = (int)(it & 3), seq = (int)(it >> 2);
+    const long base = seq_base(a.g, seq);
+    const float* qkv = a.QKV + head * 16;
+    __syncthreads();
+    for (int i = tid; i < NP * 4; i += 256) {
+      int j = i >> 2, q = i & 3;
+      float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
+      if (j < n) {
+        const float* p = qkv + (base + (long)j * ps) * 192;
+        k4 = *reinterpret_cast<const float4*>(p + 64 + 4 * q);
+        v4 = *reinterpret_cast<const float4*>(p + 128 + 4 * q);
+      }
+      *reinterpret_cast<float4*>(&Ks[i * 4]) = k4;
+      *reinterpret_cast<float4*>(&Vs[i * 4]) = v4;
+    }
+    for (int i = tid; i < 16 * LK; i += 256) { dKa[i] = 0.f; dVa[i] = 0.f; }
+    __syncthreads();
+    // Lock-step schedule instead of LDS atomics (ds_add_f32 costs ~500 cycles per wave-instruction here): in every
+    // step the 4 waves work on 4 DIFFERENT key tiles (wave w starts its key sweep at tile 2w and wraps), so their
+    // read-modify-writes of dKa / dVa (indexed by key tile) and dEa (indexed by the offset tile q - k, distinct
+    // because (s_w' - s_w) mod nkt != w' - w) never overlap; one barrier per phase orders successive steps.
+    const int nwact = nkt >= 7 ? 4 : 1;                 // tiny sequences: a single wave (no conflicts possible)
+    const int rounds = (qtiles + nwact - 1) / nwact;
+    const int sw = 2 * wave;
+    for (int round = 0; round < rounds; ++round) {
+      const int qt = wave + nwact * round;
+      const bool active = wave < nwact && qt < qtiles;
+      const int i0 = qt * 16;
+      int qi = i0 + c;
+      const bool qok = active && qi < n;
+      if (qi > n - 1) qi = n - 1;
+      if (qi < 0) qi = 0;
+      const long qtok = base + (long)qi * ps;
+      float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), dof = qf;
+      float qT[4] = {0.f, 0.f, 0.f, 0.f}, doT[4] = {0.f, 0.f, 0.f, 0.f};
+      float lse = 0.f, dlt = 0.f;
+      if (active) {
+        qf = *reinterpret_cast<const float4*>(qkv + qtok * 192 + 4 * g);
+        dof = *reinterpret_cast<const float4*>(a.dO + qtok * 64 + head * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int qr = i0 + 4 * g + r; if (qr > n - 1) qr = n - 1;
+          long tk = base + (long)qr * ps;
+          qT[r] = qkv[tk * 192 + c];
+          doT[r] = a.dO[tk * 64 + head * 16 + c];
+        }
+        lse = a.LSE[qtok * 4 + head];
+        dlt = a.Dl[qtok * 4 + head];
+      }
+      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+      auto u_tile = [&](int D, int slot) {
+        float4 e = *reinterpret_cast<const float4*>(a.E + (long)(D + c + a.maxpos) * 16 + 4 * g);
+        f32x4 u = {0.f, 0.f, 0.f, 0.f};
+        u = MFMA16(e.x, qf.x, u); u = MFMA16(e.y, qf.y, u); u = MFMA16(e.z, qf.z, u); u = MFMA16(e.w, qf.w, u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Uf[slot * TILE + (4 * g + r) * TS + c] = u[r];
+      };
+      // consume a finished offset tile (offsets [D, D+15]): dQ += E^T dU ; dE^T += Q^T dU^T (plain RMW, see above)
+      auto consume = [&](int D, int slot) {
+        float4 et = *reinterpret_cast<const float4*>(Et + (long)c * ET + (D + 4 * g + a.maxpos));   // E[D+4g+r][d=c]
+        dq = MFMA16(et.x, dU[slot * TILE + (4 * g + 0) * TS + c], dq);
+        dq = MFMA16(et.y, dU[slot * TILE + (4 * g + 1) * TS + c], dq);
+        dq = MFMA16(et.z, dU[slot * TILE + (4 * g + 2) * TS + c], dq);
+        dq = MFMA16(et.w, dU[slot * TILE + (4 * g + 3) * TS + c], dq);
+        float4 du = *reinterpret_cast<const float4*>(&dU[slot * TILE + c * TS + 4 * g]);       // dU[delta c][q 4g+r]
+        f32x4 de = {0.f, 0.f, 0.f, 0.f};
+        de = MFMA16(qT[0], du.x, de); de = MFMA16(qT[1], du.y, de); de = MFMA16(qT[2], du.z, de); de = MFMA16(qT[3], du.w, de);
+        int row = D + c + NP;                 // de[r] = dE[delta = D + c][d = 4g + r]
+        if (row >= 0 && row < 2 * NP) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dEa[(4 * g + r) * LE + row] += de[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dU[slot * TILE + (4 * g + r) * TS + c] = 0.f; }
+      };
+      int hi = 0;
+      for (int t = 0; t < nkt; ++t) {
+        int kt = t + sw;
+        if (kt >= nkt) kt -= nkt;
+        if (nwact == 1) kt = t;
+        const int j0 = kt * 16, D0 = i0 - j0;
+        __syncthreads();
+        if (active) {
+          if (t == 0 || kt == 0) {           // start of a monotone run of key tiles: prime the window
+#pragma unroll
+            for (int r = 0; r < 10; ++r) dU[r * 64 + lane] = 0.f;
+            hi = 0;
+            u_tile(D0, 0);
+          }
+          const int lo = hi ^ 1;
+          u_tile(D0 - 16, lo);
+          const float4 kf = *reinterpret_cast<const float4*>(&Ks[(j0 + c) * 16 + 4 * g]);
+          const float4 vf = *reinterpret_cast<const float4*>(&Vs[(j0 + c) * 16 + 4 * g]);
+          f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          s4 = MFMA16(kf.x, qf.x, s4); dp = MFMA16(vf.x, dof.x, dp);
+          s4 = MFMA16(kf.y, qf.y, s4); dp = MFMA16(vf.y, dof.y, dp);
+          s4 = MFMA16(kf.z, qf.z, s4); dp = MFMA16(vf.z, dof.z, dp);
+          s4 = MFMA16(kf.w, qf.w, s4); dp = MFMA16(vf.w, dof.w, dp);
+          float ds[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int dlc = c - (4 * g + r);
+            float u = dlc >= 0 ? Uf[hi * TILE + dlc * TS + c] : Uf[lo * TILE + (16 + dlc) * TS + c];
+            float sv = (s4[r] + u) * a.scale;
+            bool ok = qok && (j0 + 4 * g + r < n);
+            float p = ok ? __builtin_amdgcn_exp2f((sv - lse) * l2e) : 0.f;
+            ds[r] = p * (dp[r] - dlt) * a.scale;
+            if (dlc >= 0) dU[hi * TILE + dlc * TS + c] += ds[r]; else dU[lo * TILE + (16 + dlc) * TS + c] += ds[r];
+            Pl[(4 * g + r) * TS + c] = p;
+            dSl[(4 * g + r) * TS + c] = ds[r];
+          }
+          // dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (A: lane (d=c, g) supplies K[j0+4g+r][c])
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dq = MFMA16(Ks[(j0 + 4 * g + r) * 16 + c], ds[r], dq);
+          // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+          // B: lane (key c, k-index g) supplies X[q 4g+r][key c] = Xl[key c][4g + r]
+          const float4 pb = *reinterpret_cast<const float4*>(&Pl[c * TS + 4 * g]);
+          const float4 sb = *reinterpret_cast<const float4*>(&dSl[c * TS + 4 * g]);
+          f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f};
+          dv = MFMA16(doT[0], pb.x, dv); dk = MFMA16(qT[0], sb.x, dk);
+          dv = MFMA16(doT[1], pb.y, dv); dk = MFMA16(qT[1], sb.y, dk);
+          dv = MFMA16(doT[2], pb.z, dv); dk = MFMA16(qT[2], sb.z, dk);
+          dv = MFMA16(doT[3], pb.w, dv); dk = MFMA16(qT[3], sb.w, dk);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {      // dv[r] = dV[key j0+c][d = 4g+r]; this wave owns key tile kt in this step
+            dVa[(4 * g + r) * LK + j0 + c] += dv[r];
+            dKa[(4 * g + r) * LK + j0 + c] += dk[r];
+          }
+          consume(D0, hi);
+          hi = lo;
+        }
+        __syncthreads();
+        if (active && (kt == nkt - 1 || t == nkt - 1)) consume(D0 - 16, hi);   // end of a run: the last low tile
+      }
+      if (qok) *reinterpret_cast<float4*>(a.dQKV + qtok * 192 + head * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+    __syncthreads();
+    for (int i = tid; i < NP * 4; i += 256) {
+      int j = i >> 2, q = i & 3;
+      if (j < n) {
+        float* p = a.dQKV + (base + (long)j * ps) * 192 + head * 16 + 4 * q;
+        *reinterpret_cast<float4*>(p + 64) = make_float4(dKa[(4 * q) * LK + j], dKa[(4 * q + 1) * LK + j],
+                                                         dKa[(4 * q + 2) * LK + j], dKa[(4 * q + 3) * LK + j]);
+        *reinterpret_cast<float4*>(p + 128) = make_float4(dVa[(4 * q) * LK + j], dVa[(4 * q + 1) * LK + j],
+                                                          dVa[(4 * q + 2) * LK + j], dVa[(4 * q + 3) * LK + j]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 16 * 2 * NP; i += 256) {
+    int dch = i / (2 * NP), row = i - dch * (2 * NP);
+    float v = dEa[dch * LE + row];
+    int d = row - NP;
+    if (v != 0.f && d >= -a.maxpos && d <= a.maxpos) atomicAdd(&a.dE[(long)(d + a.maxpos) * 16 + dch], v);
+  }
+}
+
 static int check_geom(const AttnGeom& g) {
   SE_REQUIRE(g.nseq > 0 && g.n > 0 && g.inner > 0, "attention: bad geometry");
   return 0;
@@ -464,19 +776,63 @@ extern "C" int se_attn_fwd(const float* QKV, const float* E, float* O, float* LS
   AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale};
   if (int e = check_geom(a.g)) return e;
   SE_REQUIRE(QKV && E && O, "attn_fwd: null operand");
-  long items = (long)nseq * 4 * ((n + 31) / 32);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(items, 4)), dim3(256), 0, as_stream(stream), a);
+  const int NP = ((n + 15) / 16) * 16;
+  const size_t sh = ((size_t)NP * 16 + 16 * (size_t)(NP + 4) + 4096) * sizeof(float);
+  if (sh <= 160 * 1024) {       // K / V of one (sequence, head) fit in LDS: staged kernel
+    static size_t raised = 0;
+    if (sh > 64 * 1024 && sh > raised) {
+      SE_REQUIRE(hipFuncSetAttribute((const void*)attn_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) ==
+                     hipSuccess, "attn_fwd: cannot raise the dynamic LDS limit to %zu", sh);
+      raised = sh;
+    }
+    hipLaunchKernelGGL(attn_fwd2_kernel, dim3(nseq * 4), dim3(256), sh, as_stream(stream), a, NP);
+  } else {
+    long items = (long)nseq * 4 * ((n + 31) / 32);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(items, 4)), dim3(256), 0, as_stream(stream), a);
+  }
   return se_check_launch("se_attn_fwd");
 }
 
 extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                            float* Dl, float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
-                           long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* stream) {
-  AttnBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, dO, LSE, Dl, dQKV, dE, maxpos, scale};
+                           long inner_stride, long pos_stride, long ntok, int maxpos, float scale, const float* Et,
+                           int et_ld, void* stream) {
+  AttnBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, dO, LSE, Dl, dQKV, dE, maxpos, scale, 0};
+  if (const char* e = getenv("SE_ATTN_DBG")) a.dbg = atoi(e);
   if (int e = check_geom(a.g)) return e;
   SE_REQUIRE(QKV && E && O && dO && LSE && Dl && dQKV && dE, "attn_bwd: null operand");
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
+  if (Et && (et_ld % 4) == 0 && et_ld >= 2 * maxpos + 1 && n <= 336 && maxpos >= 352) {
+    // single-pass staged kernel (no clamp aliasing possible: |i-j| < 352 <= maxpos)
+    const long items2 = (long)nseq * 4;
+    if (n <= 112) {
+      const size_t sh = (2 * 112 * 16 + 2 * 16 * 116 + 16 * 228 + 4 * 6 * 320) * sizeof(float);
+      static bool raised = false;
+      if (!raised) {
+        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<112>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
+        raised = true;
+      }
+      int nb = items2 < 512 ? (int)items2 : 512;
+      int ipb = (int)((items2 + nb - 1) / nb);
+      nb = (int)((items2 + ipb - 1) / ipb);
+      hipLaunchKernelGGL((attn_bwd2_kernel<112>), dim3(nb), dim3(256), sh, s, a, Et, et_ld, ipb);
+    } else {
+      const size_t sh = (2 * 336 * 16 + 2 * 16 * 340 + 16 * 676 + 4 * 6 * 320) * sizeof(float);
+      static bool raised = false;
+      if (!raised) {
+        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<336>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
+        raised = true;
+      }
+      int nb = items2 < 256 ? (int)items2 : 256;
+      int ipb = (int)((items2 + nb - 1) / nb);
+      nb = (int)((items2 + ipb - 1) / ipb);
+      hipLaunchKernelGGL((attn_bwd2_kernel<336>), dim3(nb), dim3(256), sh, s, a, Et, et_ld, ipb);
+    }
+    return se_check_launch("se_attn_bwd");
+  }
   long items = (long)nseq * 4 * ((n + 31) / 32);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(items, 4)), dim3(256), 0, s, a);
   long qitems = (long)nseq * 4 * ((n + 15) / 16);
