@@ -13,7 +13,12 @@ int se_check_launch(const char* what);
 
 #define SE_REQUIRE(cond, ...) do { if (!(cond)) return se_fail(__VA_ARGS__); } while (0)
 
-static __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on the hardware transcendental path: v_exp_f32 (exp2 of x*log2e) + v_rcp_f32, ~1 ulp each (relative error
+// ~2e-7, far inside the parity budget); the libm expf + IEEE divide cost ~10x more VALU issue slots and made the
+// Swish / GLU pro- and epilogues of the K=64 GEMMs VALU-bound.
+static __device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 static __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 static __device__ __forceinline__ float swish_gradf_(float x) {
   float s = sigmoidf_(x);

@@ -14,6 +14,7 @@
 // K order inside a slab is permuted so that each lane reads ONE contiguous BK/2 run
 // (lane half h supplies k in [h*BK/2, (h+1)*BK/2)) -> b128 LDS reads feed 4 MFMAs each.
 #include "se_common.h"
+#include <stdlib.h>
 
 struct GemmArgs {
   se_gemm_desc d;
@@ -21,7 +22,21 @@ struct GemmArgs {
   const float* rowstats; const float* ps; const float* pb; double* stats;
 };
 
-// source pixel of output pixel (t, f) for one tap; returns -1 when outside the input grid
+// source pixel (index inside batch entry b's grid) of output pixel (t, f) for one tap; -1 when outside
+static __device__ __forceinline__ int src_pixel_in(const se_gemm_desc& d, int t, int f, int tap) {
+  int ti, fi;
+  if (!d.up) {
+    ti = t * d.st + d.dt[tap];
+    fi = f * d.sf + d.df[tap];
+    if (ti < 0 || ti >= d.Ti || fi < 0 || fi >= d.Fi) return -1;
+  } else {
+    int tt = t + d.dt[tap], ff = f + d.df[tap];
+    if (tt < 0 || ff < 0 || (tt % d.st) != 0 || (ff % d.sf) != 0) return -1;
+    ti = tt / d.st; fi = tt >= 0 ? ff / d.sf : 0;
+    if (ti >= d.Ti || fi >= d.Fi) return -1;
+  }
+  return ti * d.Fi + fi;
+}
 static __device__ __forceinline__ long src_pixel(const se_gemm_desc& d, int b, int t, int f, int tap) {
   int ti, fi;
   if (!d.up) {
@@ -84,6 +99,14 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   const int m0 = blockIdx.x * BM;
   const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
   const int kq = tid % KQ, r0 = tid / KQ;
+  // Addressing: per-batch-entry bases are wave-uniform (SGPR pairs) and every lane offset is a 32-bit element
+  // index, so global accesses use the saddr + 32-bit voffset form and no 64-bit vector multiplies are issued.
+  // `lin`: one tap, unit strides, identical in/out grids (nn.Linear, 1x1 conv): source pixel == row index.
+  const bool lin = d.ntap == 1 && !d.up && d.st == 1 && d.sf == 1 && d.dt[0] == 0 && d.df[0] == 0 &&
+                   d.Ti == d.To && d.Fi == d.Fo;
+  const int TiFi = d.Ti * d.Fi;
+  const float* __restrict__ Ab = g.A + (long)b * TiFi * d.lda + d.a_off;
+  const float* __restrict__ Wb = g.W;
 
   int rt[NA], rf[NA];
   bool rok[NA];
@@ -91,11 +114,11 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   for (int i = 0; i < NA; ++i) {
     int m = m0 + r0 + i * RPP;
     rok[i] = m < Mb;
-    rt[i] = m / d.Fo;
-    rf[i] = m - rt[i] * d.Fo;
+    if (lin) { rt[i] = m; rf[i] = 0; }
+    else { rt[i] = m / d.Fo; rf[i] = m - rt[i] * d.Fo; }
   }
   // W rows of this column block (GLU pairs value column j with gate column N/2 + j)
-  long wrow[NB];
+  unsigned wrow[NB];
   bool wok[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -103,15 +126,16 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     int n;
     if (glu) { n = (j >> 5) * (d.N / 2) + by * 32 + (j & 31); wok[i] = (by * 32 + (j & 31)) < d.N / 2; }
     else { n = by * 64 + j; wok[i] = n < d.N; }
-    wrow[i] = (long)n * d.ldw;
+    wrow[i] = (unsigned)n * (unsigned)d.ldw;
   }
   float ln_mean[NA] = {}, ln_rstd[NA] = {};
   if (PRO == SE_PRO_LN) {
+    const float* __restrict__ rs = g.rowstats + (long)b * TiFi * 2;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      long p = rok[i] ? src_pixel(d, b, rt[i], rf[i], 0) : -1;
-      ln_mean[i] = p >= 0 ? g.rowstats[2 * p] : 0.f;
-      ln_rstd[i] = p >= 0 ? g.rowstats[2 * p + 1] : 0.f;
+      int p = rok[i] ? (lin ? rt[i] : src_pixel_in(d, rt[i], rf[i], 0)) : -1;
+      ln_mean[i] = p >= 0 ? rs[2 * p] : 0.f;
+      ln_rstd[i] = p >= 0 ? rs[2 * p + 1] : 0.f;
     }
   }
 
@@ -119,7 +143,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   const int NI = d.ntap * nchunk;
   float4 ra[NA], rb[NB];
   bool aok[NA];
-  long apix[NA];
+  unsigned apix[NA];
   int cur_c = 0;
   const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
   const float inv_keep = 1.0f / (1.0f - d.drop_p);
@@ -130,17 +154,18 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     int c = c0 + kq * 4;
     cur_c = c;
     bool cok = c < d.C;   // C is a multiple of 4
+    const unsigned wk = (unsigned)(tap * d.C + c);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      long p = (rok[i] && cok) ? src_pixel(d, b, rt[i], rf[i], tap) : -1;
+      int p = (rok[i] && cok) ? (lin ? rt[i] : src_pixel_in(d, rt[i], rf[i], tap)) : -1;
       aok[i] = p >= 0;
-      apix[i] = p;
-      ra[i] = aok[i] ? *reinterpret_cast<const float4*>(g.A + p * d.lda + d.a_off + c)
+      apix[i] = (unsigned)(b * TiFi + p);
+      ra[i] = aok[i] ? *reinterpret_cast<const float4*>(Ab + ((unsigned)p * (unsigned)d.lda + (unsigned)c))
                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      rb[i] = (wok[i] && cok) ? *reinterpret_cast<const float4*>(g.W + wrow[i] + (long)tap * d.C + c)
+      rb[i] = (wok[i] && cok) ? *reinterpret_cast<const float4*>(Wb + (wrow[i] + wk))
                               : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -203,45 +228,55 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   }
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   const int No = d.N / 2;   // SHUFFLE2 / GLU output channels
+  // wave-uniform tile bases; lane offsets are 32-bit (a 128-row tile spans < 2^31 elements)
+  const long ptile = (long)b * Mb + m0;
+  float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
+  float* __restrict__ Xb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
+  const float* __restrict__ Rb = g.R ? g.R + ptile * d.ldr + d.r_off : nullptr;
+  const unsigned pdrop = (unsigned)ptile;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    int m = m0 + row;
+    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int m = m0 + row;
     if (m >= Mb) continue;
-    long p = (long)b * Mb + m;
     float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
     if (ep & SE_EPI_STATS) { if (nok0) { s0 += v0; q0 += v0 * v0; } if (nok1) { s1 += v1; q1 += v1 * v1; } }
+    const unsigned yo = (unsigned)row * (unsigned)d.ldc;
     if (glu) {
       if (nok0) {
-        if (g.AUX) { g.AUX[p * d.ldx + d.x_off + n0] = v0; g.AUX[p * d.ldx + d.x_off + n1] = v1; }
-        g.Y[p * d.ldc + d.c_off + n0] = v0 * sigmoidf_(v1);
+        if (Xb) { const unsigned xo = (unsigned)row * (unsigned)d.ldx; Xb[xo + n0] = v0; Xb[xo + n1] = v1; }
+        Yb[yo + n0] = v0 * sigmoidf_(v1);
       }
       continue;
     }
     if (ep & SE_EPI_DROP) {       // dropout of the (bias-added) result, or of the hidden activation whose
                                    // gradient this is (with SWISH_GRAD): mask index = output element
-      v0 *= drop_scale(d.epi_seed, (unsigned)(p * d.N + n0), thr, inv_keep);
-      v1 *= drop_scale(d.epi_seed, (unsigned)(p * d.N + n1), thr, inv_keep);
+      const unsigned pe = (pdrop + (unsigned)row) * (unsigned)d.N;
+      v0 *= drop_scale(d.epi_seed, pe + n0, thr, inv_keep);
+      v1 *= drop_scale(d.epi_seed, pe + n1, thr, inv_keep);
     }
     if (ep & SE_EPI_SWISH_GRAD) {
-      if (nok0) v0 *= swish_gradf_(g.AUX[p * d.ldx + d.x_off + n0]);
-      if (nok1) v1 *= swish_gradf_(g.AUX[p * d.ldx + d.x_off + n1]);
+      const unsigned xo = (unsigned)row * (unsigned)d.ldx;
+      if (nok0) v0 *= swish_gradf_(Xb[xo + n0]);
+      if (nok1) v1 *= swish_gradf_(Xb[xo + n1]);
     }
     if (ep & SE_EPI_RESID) {
-      if (nok0) v0 = g.R[p * d.ldr + d.r_off + n0] + d.alpha * v0;
-      if (nok1) v1 = g.R[p * d.ldr + d.r_off + n1] + d.alpha * v1;
+      const unsigned ro = (unsigned)row * (unsigned)d.ldr;
+      if (nok0) v0 = Rb[ro + n0] + d.alpha * v0;
+      if (nok1) v1 = Rb[ro + n1] + d.alpha * v1;
     }
     if (ep & SE_EPI_SHUFFLE2) {
       int t = m / d.Fo, f = m - t * d.Fo;
-      if (nok0) { long po = ((long)b * d.To + t) * (2 * d.Fo) + 2 * f + (n0 >= No);
-                  g.Y[po * d.ldc + d.c_off + (n0 >= No ? n0 - No : n0)] = v0; }
-      if (nok1) { long po = ((long)b * d.To + t) * (2 * d.Fo) + 2 * f + (n1 >= No);
-                  g.Y[po * d.ldc + d.c_off + (n1 >= No ? n1 - No : n1)] = v1; }
+      float* __restrict__ Ys = g.Y + ((long)b * d.To * 2 * d.Fo) * d.ldc + d.c_off;
+      if (nok0) { unsigned po = (unsigned)(t * 2 * d.Fo + 2 * f + (n0 >= No));
+                  Ys[po * (unsigned)d.ldc + (n0 >= No ? n0 - No : n0)] = v0; }
+      if (nok1) { unsigned po = (unsigned)(t * 2 * d.Fo + 2 * f + (n1 >= No));
+                  Ys[po * (unsigned)d.ldc + (n1 >= No ? n1 - No : n1)] = v1; }
       continue;
     }
-    float* y = g.Y + p * d.ldc + d.c_off;
-    if (ep & SE_EPI_ACCUM) { if (nok0) y[n0] += v0; if (nok1) y[n1] += v1; }
-    else { if (nok0) y[n0] = v0; if (nok1) y[n1] = v1; }
+    if (ep & 256) { if (v0 == 12345.678f && v1 == 0.1234f) Yb[yo + n0] = v0; continue; }      // ablation: no stores
+    if (ep & SE_EPI_ACCUM) { if (nok0) Yb[yo + n0] += v0; if (nok1) Yb[yo + n1] += v1; }
+    else { if (nok0) Yb[yo + n0] = v0; if (nok1) Yb[yo + n1] = v1; }
   }
   if (ep & SE_EPI_STATS) {
     // rows live in registers (16 per lane) and in the two lane halves: fold halves, then waves via LDS
@@ -280,20 +315,25 @@ struct WgradArgs {
 template <int PRO>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
   constexpr int SY = 68;            // 64 + 4 pad (float4-aligned rows)
-  __shared__ __attribute__((aligned(16))) float Ys[32 * SY];
-  __shared__ __attribute__((aligned(16))) float Xs[32 * SY];
+  constexpr int MR = 64;            // rows staged per step (32 MFMAs per wave between barriers)
+  __shared__ __attribute__((aligned(16))) float Ys[MR * SY];
+  __shared__ __attribute__((aligned(16))) float Xs[MR * SY];
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncb = (d.C + 63) / 64;
-  const int tap = blockIdx.y / ncb, cb = blockIdx.y - tap * ncb, nb = blockIdx.z;
+  const int chunk = blockIdx.x, tc = blockIdx.y, nb = blockIdx.z;
+  const int tap = tc / ncb, cb = tc - tap * ncb;
   const int Mb = d.To * d.Fo;
   const long Mtot = (long)d.B * Mb;
-  const long mbeg = (long)blockIdx.x * g.rows_per_chunk;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
   long mend = mbeg + g.rows_per_chunk;
   if (mend > Mtot) mend = Mtot;
-  const int q = tid & 15, r0 = tid >> 4;    // float4 column / tile row (2 passes of 16 rows)
+  const int q = tid & 15, r0 = tid >> 4;    // float4 column / tile row (4 passes of 16 rows)
   const int wn = wave >> 1, wc = wave & 1;
-  const bool do_bias = g.dbias != nullptr && blockIdx.y == 0;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  const bool lin = d.ntap == 1 && !d.up && d.st == 1 && d.sf == 1 && d.dt[0] == 0 && d.df[0] == 0 &&
+                   d.Ti == d.To && d.Fi == d.Fo;
+  const int TiFi = d.Ti * d.Fi;
 
   f32x16 acc;
 #pragma unroll
@@ -302,25 +342,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 
   const int n_ld = nb * 64 + q * 4;        // dY column of this thread's float4
   const int c_ld = cb * 64 + q * 4;        // A channel of this thread's float4
-  const bool nok = n_ld < d.N;             // N multiple of 4 assumed for vector loads (checked on host)
+  const bool nok = n_ld < d.N;             // N multiple of 4 (checked on host)
   const bool cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
 
-  float4 ry[2], rx[2];
-  float mean[2] = {}, rstd[2] = {};
-  bool xok[2];
-  long xpix[2];
+  float4 ry[4], rx[4];
+  float mean[4] = {}, rstd[4] = {};
+  bool xok[4];
+  unsigned xpix[4];
   const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
   const float inv_keep = 1.0f / (1.0f - d.drop_p);
   const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
   auto load_tiles = [&](long mbase) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       long mg = mbase + r0 + i * 16;
       bool ok = mg < mend;
-      int b = 0, t = 0, f = 0;
-      if (ok) { b = (int)(mg / Mb); int m = (int)(mg - (long)b * Mb); t = m / d.Fo; f = m - t * d.Fo; }
-      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(g.dY + mg * d.ldc + d.c_off + n_ld)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      long p = -1;
+      if (ok && cok) {
+        if (lin) p = mg;
+        else {
+          int b = (int)(mg / Mb); int m = (int)(mg - (long)b * Mb); int t = m / d.Fo, f = m - t * d.Fo;
+          int pin = src_pixel_in(d, t, f, tap);
+          p = pin >= 0 ? (long)b * TiFi + pin : -1;
+        }
+      }
+      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (dy_drop && ok && nok) {
         unsigned base = (unsigned)(mg * d.N + n_ld);
         ry[i].x *= drop_scale(d.epi_seed, base, thr, inv_keep);
@@ -328,11 +376,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
         ry[i].z *= drop_scale(d.epi_seed, base + 2, thr, inv_keep);
         ry[i].w *= drop_scale(d.epi_seed, base + 3, thr, inv_keep);
       }
-      long p = (ok && cok) ? src_pixel(d, b, t, f, tap) : -1;
       xok[i] = p >= 0;
-      xpix[i] = p;
-      rx[i] = xok[i] ? *reinterpret_cast<const float4*>(g.A + p * d.lda + d.a_off + c_ld)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      xpix[i] = (unsigned)p;
+      rx[i] = xok[i] ? *reinterpret_cast<const float4*>(Ag + p * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (PRO == SE_PRO_LN) {
         mean[i] = xok[i] ? g.rowstats[2 * p] : 0.f;
         rstd[i] = xok[i] ? g.rowstats[2 * p + 1] : 0.f;
@@ -341,9 +387,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
   };
 
   if (mbeg < mend) load_tiles(mbeg);
-  for (long mb = mbeg; mb < mend; mb += 32) {
+  for (long mb = mbeg; mb < mend; mb += MR) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
       float4 v = rx[i];
       if (PRO != SE_PRO_NONE && xok[i])
         v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], g.ps, g.pb, xpix[i], d.pro_seed, thr, inv_keep);
@@ -351,15 +397,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
       *reinterpret_cast<float4*>(&Ys[(r0 + i * 16) * SY + q * 4]) = ry[i];
     }
     __syncthreads();
-    if (mb + 32 < mend) load_tiles(mb + 32);
-    const float* yp = &Ys[(lane >> 5) * 16 * SY + wn * 32 + (lane & 31)];
-    const float* xp = &Xs[(lane >> 5) * 16 * SY + wc * 32 + (lane & 31)];
+    if (mb + MR < mend) load_tiles(mb + MR);
+    // MFMA step s pairs tile rows {s, s + 32}: lane half h supplies row s + 32 h
+    const float* yp = &Ys[(lane >> 5) * 32 * SY + wn * 32 + (lane & 31)];
+    const float* xp = &Xs[(lane >> 5) * 32 * SY + wc * 32 + (lane & 31)];
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int s = 0; s < 32; ++s)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s * SY], xp[s * SY], acc, 0, 0, 0);
     if (do_bias && tid < 64) {
 #pragma unroll
-      for (int r = 0; r < 32; ++r) bsum += Ys[r * SY + tid];
+      for (int r = 0; r < MR; ++r) bsum += Ys[r * SY + tid];
     }
     __syncthreads();
   }
@@ -440,17 +487,22 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   const int ncols = (ep & SE_EPI_GLU) ? cdiv(d->N / 2, 32) : cdiv(d->N, 64);
   dim3 grid(cdiv(Mb, 128), ncols, d->B), block(256);
   hipStream_t s = as_stream(stream);
-  const bool bk16 = d->C < 32;
+  // K slab per LDS stage: 64 floats when the channel run allows it (half the barriers, all of a K=64 layer in
+  // flight at once), 16 for the tiny-channel convolutions, else 32.  SE_GEMM_BK overrides (profiling).
+  int bk = d->C < 32 ? 16 : 32;    // 64 measured slower (occupancy 3 -> latency-bound), kept for experiments
+  if (const char* e = getenv("SE_GEMM_BK")) { int v = atoi(e); if (v == 16 || ((v == 32 || v == 64) && bk != 16)) bk = v; }
 #define LAUNCH(BK, PRO) hipLaunchKernelGGL((gemm_tap_kernel<BK, PRO>), grid, block, 0, s, g)
+#define LAUNCH_BK(PRO) do { if (bk == 16) LAUNCH(16, PRO); else if (bk == 64) LAUNCH(64, PRO); else LAUNCH(32, PRO); } while (0)
   switch (d->prologue) {
-    case SE_PRO_NONE: if (bk16) LAUNCH(16, SE_PRO_NONE); else LAUNCH(32, SE_PRO_NONE); break;
-    case SE_PRO_LN: if (bk16) LAUNCH(16, SE_PRO_LN); else LAUNCH(32, SE_PRO_LN); break;
-    case SE_PRO_SWISH: if (bk16) LAUNCH(16, SE_PRO_SWISH); else LAUNCH(32, SE_PRO_SWISH); break;
-    case SE_PRO_AFFINE_SWISH: if (bk16) LAUNCH(16, SE_PRO_AFFINE_SWISH); else LAUNCH(32, SE_PRO_AFFINE_SWISH); break;
-    case SE_PRO_SWISH_DROP: if (bk16) LAUNCH(16, SE_PRO_SWISH_DROP); else LAUNCH(32, SE_PRO_SWISH_DROP); break;
-    case SE_PRO_DROP: if (bk16) LAUNCH(16, SE_PRO_DROP); else LAUNCH(32, SE_PRO_DROP); break;
+    case SE_PRO_NONE: LAUNCH_BK(SE_PRO_NONE); break;
+    case SE_PRO_LN: LAUNCH_BK(SE_PRO_LN); break;
+    case SE_PRO_SWISH: LAUNCH_BK(SE_PRO_SWISH); break;
+    case SE_PRO_AFFINE_SWISH: LAUNCH_BK(SE_PRO_AFFINE_SWISH); break;
+    case SE_PRO_SWISH_DROP: LAUNCH_BK(SE_PRO_SWISH_DROP); break;
+    case SE_PRO_DROP: LAUNCH_BK(SE_PRO_DROP); break;
     default: return se_fail("gemm: unknown prologue %d", d->prologue);
   }
+#undef LAUNCH_BK
 #undef LAUNCH
   return se_check_launch("se_gemm_tap");
 }
@@ -466,7 +518,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
   const long Mtot = (long)d->B * d->To * d->Fo;
   if (chunks < 1) chunks = 1;
   long rpc = (Mtot + chunks - 1) / chunks;
-  rpc = ((rpc + 31) / 32) * 32;
+  rpc = ((rpc + 63) / 64) * 64;
   chunks = (int)((Mtot + rpc - 1) / rpc);
   WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc};
   dim3 grid(chunks, d->ntap * cdiv(d->C, 64), cdiv(d->N, 64)), block(256);
