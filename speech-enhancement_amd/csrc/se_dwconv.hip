@@ -27,50 +27,63 @@ struct DwArgs {
 __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[DW_ROWS * DW_C];
   const int tid = threadIdx.x, cl = tid & 31, ps = tid >> 5;
-  const int seq = blockIdx.y, p0 = blockIdx.x * DW_TILE, n = a.g.n;
-  // taps of this lane's 4 channels
-  float4 w[DW_K];
-#pragma unroll
-  for (int k = 0; k < DW_K; ++k) {
-    int kk = a.flip ? DW_K - 1 - k : k;
-    w[k] = make_float4(a.W[(cl * 4 + 0) * DW_K + kk], a.W[(cl * 4 + 1) * DW_K + kk], a.W[(cl * 4 + 2) * DW_K + kk],
-                       a.W[(cl * 4 + 3) * DW_K + kk]);
-  }
-  for (int i = tid; i < DW_ROWS * 32; i += 256) {
-    int row = i >> 5, q = i & 31;
-    int p = p0 - 15 + row;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p >= 0 && p < n) v = *reinterpret_cast<const float4*>(a.X + tok_of(a.g, seq, p) * DW_C + q * 4);
-    *reinterpret_cast<float4*>(&xs[row * DW_C + q * 4]) = v;
+  const int n = a.g.n;
+  // taps of this lane's 4 channels: the 128 x 31 table is read ONCE per (persistent) workgroup with coalesced
+  // loads into LDS and picked up as float4 channel groups (per-thread strided global loads of the table -- 124
+  // scalar loads touching 32 cache lines each -- made the first version of this kernel 5x slower than HBM).
+  for (int i = tid; i < DW_C * DW_K; i += 256) {
+    int ch = i / DW_K, k = i - ch * DW_K;
+    xs[(a.flip ? DW_K - 1 - k : k) * DW_C + ch] = a.W[i];
   }
   __syncthreads();
+  float4 w[DW_K];
+#pragma unroll
+  for (int k = 0; k < DW_K; ++k) w[k] = *reinterpret_cast<const float4*>(&xs[k * DW_C + cl * 4]);
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cl * 4);
-  float4 acc[8];
+  float s[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0};
+  const int tiles = (n + DW_TILE - 1) / DW_TILE;
+  const long nitems = (long)a.g.nseq * tiles;
+  for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * DW_TILE;
+    const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
+    const float* __restrict__ Xb = a.X + base * DW_C;
+    float* __restrict__ Yb = a.Y + base * DW_C;
+    const long rs = a.g.pos_stride * DW_C;      // floats between consecutive positions
+    __syncthreads();                           // previous tile (or the weight table) fully consumed
+    for (int i = tid; i < DW_ROWS * 32; i += 256) {
+      int row = i >> 5, q = i & 31;
+      int p = p0 - 15 + row;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p >= 0 && p < n) v = *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4);
+      *reinterpret_cast<float4*>(&xs[row * DW_C + q * 4]) = v;
+    }
+    __syncthreads();
+    float4 acc[8];
 #pragma unroll
-  for (int o = 0; o < 8; ++o) acc[o] = bv;
+    for (int o = 0; o < 8; ++o) acc[o] = bv;
 #pragma unroll
-  for (int i = 0; i < 8 + DW_K - 1; ++i) {
-    float4 x = *reinterpret_cast<const float4*>(&xs[(ps * 8 + i) * DW_C + cl * 4]);
+    for (int i = 0; i < 8 + DW_K - 1; ++i) {
+      float4 x = *reinterpret_cast<const float4*>(&xs[(ps * 8 + i) * DW_C + cl * 4]);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int k = i - o;
+        if (k >= 0 && k < DW_K) {
+          acc[o].x += x.x * w[k].x; acc[o].y += x.y * w[k].y; acc[o].z += x.z * w[k].z; acc[o].w += x.w * w[k].w;
+        }
+      }
+    }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      const int k = i - o;
-      if (k >= 0 && k < DW_K) {
-        acc[o].x += x.x * w[k].x; acc[o].y += x.y * w[k].y; acc[o].z += x.z * w[k].z; acc[o].w += x.w * w[k].w;
+      int p = p0 + ps * 8 + o;
+      if (p < n) {
+        *reinterpret_cast<float4*>(Yb + (long)p * rs + cl * 4) = acc[o];
+        s[0] += acc[o].x; s[1] += acc[o].y; s[2] += acc[o].z; s[3] += acc[o].w;
+        q2[0] += acc[o].x * acc[o].x; q2[1] += acc[o].y * acc[o].y; q2[2] += acc[o].z * acc[o].z; q2[3] += acc[o].w * acc[o].w;
       }
     }
   }
-  float s[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    int p = p0 + ps * 8 + o;
-    if (p < n) {
-      *reinterpret_cast<float4*>(a.Y + tok_of(a.g, seq, p) * DW_C + cl * 4) = acc[o];
-      s[0] += acc[o].x; s[1] += acc[o].y; s[2] += acc[o].z; s[3] += acc[o].w;
-      q2[0] += acc[o].x * acc[o].x; q2[1] += acc[o].y * acc[o].y; q2[2] += acc[o].z * acc[o].z; q2[3] += acc[o].w * acc[o].w;
-    }
-  }
-  if (a.stats) {
+  if (a.stats) {            // one fp64 atomic per (channel, moment) per workgroup
     __syncthreads();
     float* red = xs;            // [8 slots][128][2]
 #pragma unroll
@@ -101,19 +114,23 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradArgs a) {
   float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
     const int seq = (int)(it / tiles), p0 = (int)(it % tiles) * DW_TILE;
+    const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
+    const float* __restrict__ Xb = a.X + base * DW_C;
+    const float* __restrict__ Gb = a.dY + base * DW_C;
+    const long rs = a.g.pos_stride * DW_C;
     __syncthreads();
     for (int i = tid; i < DW_ROWS * 32; i += 256) {
       int row = i >> 5, q = i & 31;
       int p = p0 - 15 + row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p >= 0 && p < n) v = *reinterpret_cast<const float4*>(a.X + tok_of(a.g, seq, p) * DW_C + q * 4);
+      if (p >= 0 && p < n) v = *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4);
       *reinterpret_cast<float4*>(&xs[row * DW_C + q * 4]) = v;
     }
     for (int i = tid; i < DW_TILE * 32; i += 256) {
       int row = i >> 5, q = i & 31;
       int p = p0 + row;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < n) v = *reinterpret_cast<const float4*>(a.dY + tok_of(a.g, seq, p) * DW_C + q * 4);
+      if (p < n) v = *reinterpret_cast<const float4*>(Gb + (long)p * rs + q * 4);
       *reinterpret_cast<float4*>(&ys[row * DW_C + q * 4]) = v;
     }
     __syncthreads();
@@ -164,7 +181,9 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
                            void* stream) {
   SE_REQUIRE(X && W && Y && nseq > 0 && n > 0 && inner > 0, "dwconv31: bad arguments");
   DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, W, bias, Y, stats, flip};
-  hipLaunchKernelGGL(dwconv_kernel, dim3(cdiv(n, DW_TILE), nseq), dim3(256), 0, as_stream(stream), a);
+  long nitems = (long)nseq * cdiv(n, DW_TILE);
+  int nblk = nitems < 768 ? (int)nitems : 768;          // persistent: 3 workgroups (48 KB LDS each) per CU
+  hipLaunchKernelGGL(dwconv_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31");
 }
 
