@@ -584,24 +584,25 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs a, int NP) {
 // dV / dK products.  Requires |i - j| <= maxpos for all pairs (no clamp aliasing): NP <= maxpos.
 // LDS (floats): Ks[NP][16] Vs[NP][16] | dKa[16][NP+4] dVa[16][NP+4] dEa[16][2NP+4] (transposed: the 16 lanes of a
 // lane group add to 16 consecutive words, row strides = 4 mod 8 -> conflict-free ds_add) | scratch[4][6 tiles][16][20]
-template <int NP>
-__global__ __launch_bounds__(256) void attn_bwd2_kernel(AttnBwdArgs a, const float* __restrict__ Et, int ET, int items_per_block) {
+// NW = waves per workgroup (8 for the long time-axis sequences: two waves per SIMD hide each other's LDS / MFMA
+// latency chains; the LDS budget then only allows K to be staged, V fragments come from global/L2), SV = V staged.
+template <int NP, int NW, bool SV>
+__global__ __launch_bounds__(NW * 64) void attn_bwd2_kernel(AttnBwdArgs a, const float* __restrict__ Et, int ET, int items_per_block) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int LK = NP + 4, LE = 2 * NP + 4, TS = 20, TILE = 16 * TS;
+  constexpr int LK = NP + 4, LE = 2 * NP + 4, TS = 20, TILE = 16 * TS, NT = NW * 64;
   float* Ks = smem;
   float* Vs = Ks + NP * 16;
-  float* dKa = Vs + NP * 16;
+  float* dKa = Vs + (SV ? NP * 16 : 0);
   float* dVa = dKa + 16 * LK;
   float* dEa = dVa + 16 * LK;
   float* scratch = dEa + 16 * LE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int n = a.g.n;
-  float* Uf = scratch + wave * 6 * TILE;   // [2 slots]
+  float* Uf = scratch + wave * 5 * TILE;   // [2 slots]; the consumed `hi` slot doubles as the P^T tile
   float* dU = Uf + 2 * TILE;               // [2]
-  float* Pl = dU + 2 * TILE;               // [key][query]
-  float* dSl = Pl + TILE;
-  for (int i = tid; i < 16 * LE; i += 256) dEa[i] = 0.f;
+  float* dSl = dU + 2 * TILE;              // [key][query]
+  for (int i = tid; i < 16 * LE; i += NT) dEa[i] = 0.f;
   const long nitems = (long)a.g.nseq * 4;
   const long ibeg = (long)blockIdx.x * items_per_block;
   const int qtiles = (n + 15) / 16, nkt = (n + 15) / 16;
@@ -612,24 +613,25 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(AttnBwdArgs a, const flo
     const long base = seq_base(a.g, seq);
     const float* qkv = a.QKV + head * 16;
     __syncthreads();
-    for (int i = tid; i < NP * 4; i += 256) {
+    for (int i = tid; i < NP * 4; i += NT) {
       int j = i >> 2, q = i & 3;
       float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
       if (j < n) {
         const float* p = qkv + (base + (long)j * ps) * 192;
         k4 = *reinterpret_cast<const float4*>(p + 64 + 4 * q);
-        v4 = *reinterpret_cast<const float4*>(p + 128 + 4 * q);
+        if (SV) v4 = *reinterpret_cast<const float4*>(p + 128 + 4 * q);
       }
       *reinterpret_cast<float4*>(&Ks[i * 4]) = k4;
-      *reinterpret_cast<float4*>(&Vs[i * 4]) = v4;
+      if (SV) *reinterpret_cast<float4*>(&Vs[i * 4]) = v4;
     }
-    for (int i = tid; i < 16 * LK; i += 256) { dKa[i] = 0.f; dVa[i] = 0.f; }
+    for (int i = tid; i < 16 * LK; i += NT) { dKa[i] = 0.f; dVa[i] = 0.f; }
     __syncthreads();
     // Lock-step schedule instead of LDS atomics (ds_add_f32 costs ~500 cycles per wave-instruction here): in every
     // step the 4 waves work on 4 DIFFERENT key tiles (wave w starts its key sweep at tile 2w and wraps), so their
     // read-modify-writes of dKa / dVa (indexed by key tile) and dEa (indexed by the offset tile q - k, distinct
     // because (s_w' - s_w) mod nkt != w' - w) never overlap; one barrier per phase orders successive steps.
-    const int nwact = nkt >= 7 ? 4 : 1;                 // tiny sequences: a single wave (no conflicts possible)
+    // start offsets 2w need 2 (NW-1) < nkt; tiny sequences: a single wave (no conflicts possible)
+    const int nwact = nkt >= 2 * NW - 1 ? NW : (nkt >= 7 ? 4 : 1);
     const int rounds = (qtiles + nwact - 1) / nwact;
     const int sw = 2 * wave;
     for (int round = 0; round < rounds; ++round) {
@@ -700,17 +702,26 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(AttnBwdArgs a, const flo
           const int lo = hi ^ 1;
           u_tile(D0 - 16, lo);
           const float4 kf = *reinterpret_cast<const float4*>(&Ks[(j0 + c) * 16 + 4 * g]);
-          const float4 vf = *reinterpret_cast<const float4*>(&Vs[(j0 + c) * 16 + 4 * g]);
+          float4 vf;
+          if (SV) vf = *reinterpret_cast<const float4*>(&Vs[(j0 + c) * 16 + 4 * g]);
+          else { int kj = j0 + c; if (kj > n - 1) kj = n - 1;
+                 vf = *reinterpret_cast<const float4*>(qkv + (base + (long)kj * ps) * 192 + 128 + 4 * g); }
           f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
           s4 = MFMA16(kf.x, qf.x, s4); dp = MFMA16(vf.x, dof.x, dp);
           s4 = MFMA16(kf.y, qf.y, s4); dp = MFMA16(vf.y, dof.y, dp);
           s4 = MFMA16(kf.z, qf.z, s4); dp = MFMA16(vf.z, dof.z, dp);
           s4 = MFMA16(kf.w, qf.w, s4); dp = MFMA16(vf.w, dof.w, dp);
-          float ds[4];
+          float ds[4], uu[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {            // all skew reads first: the `hi` slot is recycled as Pl below
+            int dlc = c - (4 * g + r);
+            uu[r] = dlc >= 0 ? Uf[hi * TILE + dlc * TS + c] : Uf[lo * TILE + (16 + dlc) * TS + c];
+          }
+          float* Pl = Uf + hi * TILE;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             int dlc = c - (4 * g + r);
-            float u = dlc >= 0 ? Uf[hi * TILE + dlc * TS + c] : Uf[lo * TILE + (16 + dlc) * TS + c];
+            float u = uu[r];
             float sv = (s4[r] + u) * a.scale;
             bool ok = qok && (j0 + 4 * g + r < n);
             float p = ok ? __builtin_amdgcn_exp2f((sv - lse) * l2e) : 0.f;
@@ -745,7 +756,7 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(AttnBwdArgs a, const flo
       if (qok) *reinterpret_cast<float4*>(a.dQKV + qtok * 192 + head * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
     __syncthreads();
-    for (int i = tid; i < NP * 4; i += 256) {
+    for (int i = tid; i < NP * 4; i += NT) {
       int j = i >> 2, q = i & 3;
       if (j < n) {
         float* p = a.dQKV + (base + (long)j * ps) * 192 + head * 16 + 4 * q;
@@ -757,7 +768,7 @@ __global__ __launch_bounds__(256) void attn_bwd2_kernel(AttnBwdArgs a, const flo
     }
   }
   __syncthreads();
-  for (int i = tid; i < 16 * 2 * NP; i += 256) {
+  for (int i = tid; i < 16 * 2 * NP; i += NT) {
     int dch = i / (2 * NP), row = i - dch * (2 * NP);
     float v = dEa[dch * LE + row];
     int d = row - NP;
@@ -807,29 +818,29 @@ extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, con
     // single-pass staged kernel (no clamp aliasing possible: |i-j| < 352 <= maxpos)
     const long items2 = (long)nseq * 4;
     if (n <= 112) {
-      const size_t sh = (2 * 112 * 16 + 2 * 16 * 116 + 16 * 228 + 4 * 6 * 320) * sizeof(float);
+      const size_t sh = (2 * 112 * 16 + 2 * 16 * 116 + 16 * 228 + 4 * 5 * 320) * sizeof(float);
       static bool raised = false;
       if (!raised) {
-        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<112>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<112, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
         raised = true;
       }
       int nb = items2 < 512 ? (int)items2 : 512;
       int ipb = (int)((items2 + nb - 1) / nb);
       nb = (int)((items2 + ipb - 1) / ipb);
-      hipLaunchKernelGGL((attn_bwd2_kernel<112>), dim3(nb), dim3(256), sh, s, a, Et, et_ld, ipb);
+      hipLaunchKernelGGL((attn_bwd2_kernel<112, 4, true>), dim3(nb), dim3(256), sh, s, a, Et, et_ld, ipb);
     } else {
-      const size_t sh = (2 * 336 * 16 + 2 * 16 * 340 + 16 * 676 + 4 * 6 * 320) * sizeof(float);
+      const size_t sh = (336 * 16 + 2 * 16 * 340 + 16 * 676 + 8 * 5 * 320) * sizeof(float);
       static bool raised = false;
       if (!raised) {
-        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<336>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<336, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
         raised = true;
       }
       int nb = items2 < 256 ? (int)items2 : 256;
       int ipb = (int)((items2 + nb - 1) / nb);
       nb = (int)((items2 + ipb - 1) / ipb);
-      hipLaunchKernelGGL((attn_bwd2_kernel<336>), dim3(nb), dim3(256), sh, s, a, Et, et_ld, ipb);
+      hipLaunchKernelGGL((attn_bwd2_kernel<336, 8, false>), dim3(nb), dim3(512), sh, s, a, Et, et_ld, ipb);
     }
     return se_check_launch("se_attn_bwd");
   }

@@ -1,0 +1,20 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from speech_enhancement_amd import gemm as GM, _lib as L, layers as LY
+B, T, Fq = 16, 321, 201
+Cin = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+skip = torch.randn(B, T, Fq, 256, device='cuda')
+w = torch.randn(64, Cin, 2, 3, device='cuda') * 0.02
+wp = GM.pack_conv_fwd(w)
+y = torch.empty(B, T, Fq, 64, device='cuda')
+d = GM.make_desc(B, T, Fq, T, Fq, LY.dense_taps(3), Cin, 256, 64, 64)
+import time
+for _ in range(3):
+    GM.gemm_tap(d, skip, wp, y)
+torch.cuda.synchronize()
+t0 = time.time()
+for _ in range(5):
+    GM.gemm_tap(d, skip, wp, y)
+torch.cuda.synchronize()
+dt = (time.time() - t0) / 5
+print(f'conv Cin={Cin}: {dt*1e6:.0f} us, {2.0*B*T*Fq*64*6*Cin/dt/1e12:.1f} TF')
