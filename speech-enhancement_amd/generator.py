@@ -93,10 +93,16 @@ class _TSCNetFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dest):
         model, P = ctx.model, ctx.P
+        # If every parameter already owns a .grad buffer (the flat-buffer optimizers keep .grad aliased into one
+        # contiguous gradient buffer), the kernels accumulate straight into it and autograd gets nothing to add:
+        # this removes 335 zero-fills and 335 accumulate launches per step.
+        direct = all(P[k].grad is not None and P[k].grad.is_contiguous() for k in model._pnames)
         with torch.no_grad():
-            G = {k: torch.zeros_like(P[k]) for k in model._pnames}
+            G = {k: (P[k].grad if direct else torch.zeros_like(P[k])) for k in model._pnames}
             LY.tscnet_bwd(P, G, ctx.c, dest.contiguous(), dp=model.dp)
         ctx.c = None
+        if direct:
+            return (None, None) + (None,) * len(model._pnames)
         return (None, None) + tuple(G[k] for k in model._pnames)
 
 
