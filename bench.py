@@ -65,7 +65,8 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    force_dp = os.environ.get('SE_FORCE_DP') == '1'       # exercise the RCCL hooks on a single rank (self-test)
+    if world > 1 or force_dp:
         dist.init_process_group('nccl', device_id=dev)
 
     import __graft_entry__
@@ -82,7 +83,9 @@ def main():
     D.apply(S.kaiming_init)
     G.to(dev).train()
     D.to(dev).train()
-    hooks = TR.attach_data_parallel(G, D) if world > 1 else None
+    hooks = TR.attach_data_parallel(G, D) if (world > 1 or force_dp) else None
+    if hooks is not None and force_dp:
+        hooks.world = 2          # take the multi-rank code paths (SyncBN exchange, grad averaging); 1 rank => x0.5 grads
     oargs = types.SimpleNamespace(optimizer='adamw', lr=5e-4, weight_decay=0.01, momentum=0.9, max_norm=0.0)
     og, od = optim.build_optimizer(oargs, G), optim.build_optimizer(oargs, D)
     weights = (0.1, 0.9, 0.2, 0.05) if a.arch in ('cmgan', 'cp') else (0.3, 0.7, 0.2, 0.05)
@@ -149,7 +152,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline()
     print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

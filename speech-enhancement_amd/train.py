@@ -58,8 +58,15 @@ class DataParallelHooks(LY.DPHooks):
         return t
 
     def average_grads(self, optimizer):
-        for g in optimizer.flat_grads():
-            dist.all_reduce(g, group=self.group)
+        self.finish_average(self.start_average(optimizer))
+
+    def start_average(self, optimizer):
+        """launch the all-reduce of the flat gradient buffers asynchronously (RCCL runs on its own stream)"""
+        return [(g, dist.all_reduce(g, group=self.group, async_op=True)) for g in optimizer.flat_grads()]
+
+    def finish_average(self, works):
+        for g, w in works:
+            w.wait()
             g.mul_(1.0 / self.world)
 
 
@@ -139,16 +146,28 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
         gen_gan = torch.zeros((), device=clean.device)
         loss = w[0] * loss_ri + w[1] * loss_mag + w[2] * time_loss
     loss.backward()
-    if hooks is not None:
-        hooks.average_grads(optimizer)
-    if max_norm != 0.0:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
-    optimizer.step()
+    # Data parallel: the generator-gradient all-reduce (7.3 MB over xGMI) is launched asynchronously and only waited
+    # for after the discriminator step has been issued -- the discriminator step reads est.detach() and no generator
+    # parameter, so deferring optimizer.step() past it changes no result and hides the collective behind the three
+    # discriminator forwards + backward (on a single GPU the order below is exactly the reference's).
+    g_works = hooks.start_average(optimizer) if hooks is not None else None
+
+    def finish_generator_step():
+        if g_works is not None:
+            hooks.finish_average(g_works)
+        if max_norm != 0.0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        optimizer.step()
+
+    if hooks is None:
+        finish_generator_step()
     out.update(loss_ri=loss_ri.detach(), loss_mag=loss_mag.detach(), time_loss=time_loss.detach(),
                gan=gen_gan.detach(), loss_g=loss.detach())
 
     optimizer_disc.zero_grad()
     if not gan_on:
+        if hooks is not None:
+            finish_generator_step()
         out['loss_d'] = torch.zeros((), device=clean.device)
         return out
     est_d = est.detach()
@@ -179,6 +198,8 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
     if max_norm != 0.0:
         torch.nn.utils.clip_grad_norm_(discriminator.parameters(), max_norm)
     optimizer_disc.step()
+    if hooks is not None:
+        finish_generator_step()
     out.update(L_C=L_C.detach(), L_E=L_E.detach(), loss_d=loss_d.detach())
     return out
 
