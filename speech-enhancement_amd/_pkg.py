@@ -8,3 +8,6 @@ from .train import train_gan, validate_gan, batch_stft, gan_step, set_pesq_provi
 from .optim import build_optimizer, set_weight_decay, LARS, Lamb  # noqa: F401
 from .utils import adjust_learning_rate, kaiming_init, save_checkpoint  # noqa: F401
 from .config import get_config  # noqa: F401
+from .inference import load_model, predict  # noqa: F401
+from .criterion import build_criterion  # noqa: F401
+from .frontend import disassemble_spectrogram, power_compress, power_uncompress  # noqa: F401

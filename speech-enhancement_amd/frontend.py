@@ -188,3 +188,23 @@ def normalize_batch(batch, args=None):
     clean, noisy = batch['audio'], batch['noisy']
     c = O.clip_scale(noisy.contiguous())
     return clean * c[:, None], noisy * c[:, None]
+
+
+def disassemble_spectrogram(spec):
+    """core/function.py:661-662."""
+    return spec.abs(), spec.real, spec.imag
+
+
+def power_compress(spec, comp_type=None):
+    """core/function.py:625-634 on a complex [B,F,T] tensor (reference-shaped API; the train step never leaves the
+    planes layout)."""
+    B, Fq, T = spec.shape
+    R = torch.cat([spec.real.transpose(1, 2), spec.imag.transpose(1, 2)], -1).reshape(B * T, 2 * Fq).contiguous()
+    return planes_to_spec(O.compress_planes(R, 2 * Fq, B * T, Fq, comp_type).view(B, T, Fq, 4))
+
+
+def power_uncompress(spec, comp_type=None):
+    """core/function.py:636-645."""
+    B, Fq, T = spec.shape
+    A = O.uncompress_rows(spec_to_planes(spec), B * T, Fq, 2 * Fq, comp_type).view(B, T, 2 * Fq)
+    return torch.complex(A[..., :Fq], A[..., Fq:]).transpose(1, 2)

@@ -312,6 +312,20 @@ def main():
         lrs.append(opt.param_groups[0]['lr'])
     out['lr_values'] = np.array(lrs, np.float64)
 
+    # ---- 6b. LARS / Lamb: two steps of the reference's optimizers on a toy parameter set ------------------
+    from core.optimizer import LARS as RefLARS, Lamb as RefLamb
+    for oname, ctor in (('lars', lambda ps: RefLARS(ps, lr=0.1, weight_decay=0.01, momentum=0.9)),
+                        ('lamb', lambda ps: RefLamb(ps, lr=0.01, weight_decay=0.01, max_grad_norm=1.0))):
+        w = torch.nn.Parameter(torch.from_numpy(np.sin(np.arange(24) * 0.7).reshape(4, 6).astype(np.float32)))
+        bb = torch.nn.Parameter(torch.from_numpy(np.cos(np.arange(4) * 1.3).astype(np.float32)))
+        opt = ctor([{'params': [w]}, {'params': [bb], 'weight_decay': 0.}])
+        for stp in range(2):
+            w.grad = torch.from_numpy(np.cos(np.arange(24) * 0.3 + stp).reshape(4, 6).astype(np.float32))
+            bb.grad = torch.from_numpy(np.sin(np.arange(4) * 0.9 + stp).astype(np.float32))
+            opt.step()
+        out[f'opt_{oname}_w'] = w.detach().numpy().copy()
+        out[f'opt_{oname}_b'] = bb.detach().numpy().copy()
+
     # ---- 7. full-size (2 s) generator forward: the headline parity quantity -
     clean2, noisy2 = signals(1, 32000, 7)
     cn2, nn2 = RF.normalize_batch({'audio': clean2, 'noisy': noisy2}, types.SimpleNamespace(gpu=None))

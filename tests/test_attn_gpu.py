@@ -28,7 +28,8 @@ def relerr(a, b):
 
 CASES = [(2, 37, 19, 'time', 512), (2, 37, 19, 'freq', 512), (1, 321, 3, 'time', 512), (3, 5, 101, 'freq', 512),
          (1, 40, 2, 'time', 8), (2, 3, 50, 'freq', 5), (1, 600, 1, 'time', 512), (1, 16, 4, 'time', 512),
-         (1, 1, 1, 'freq', 512)]
+         (1, 1, 1, 'freq', 512),
+         (1, 1601, 1, 'time', 512)]       # 10 s utterance (inference shape): K/V exceed LDS -> streaming kernels
 
 
 @pytest.mark.parametrize('B,T,Fq,axis,maxpos', CASES)

@@ -159,3 +159,38 @@ def test_data_parallel_hooks_gloo_world2():
         assert p.exitcode == 0
     assert all(r[1] and r[2] and r[4] == 2 for r in res)
     assert res[0][3] == res[1][3]
+
+
+@pytest.mark.parametrize('oname', ['lars', 'lamb'])
+def test_lars_lamb_match_reference(S, golden, oname):
+    """two steps of core/optimizer.py's LARS / Lamb (golden) vs the restated optimizers."""
+    from speech_enhancement_amd import optim
+    w = torch.nn.Parameter(torch.from_numpy(np.sin(np.arange(24) * 0.7).reshape(4, 6).astype(np.float32)))
+    b = torch.nn.Parameter(torch.from_numpy(np.cos(np.arange(4) * 1.3).astype(np.float32)))
+    groups = [{'params': [w]}, {'params': [b], 'weight_decay': 0.}]
+    opt = optim.LARS(groups, lr=0.1, weight_decay=0.01, momentum=0.9) if oname == 'lars' else \
+        optim.Lamb(groups, lr=0.01, weight_decay=0.01, max_grad_norm=1.0)
+    for stp in range(2):
+        w.grad = torch.from_numpy(np.cos(np.arange(24) * 0.3 + stp).reshape(4, 6).astype(np.float32))
+        b.grad = torch.from_numpy(np.sin(np.arange(4) * 0.9 + stp).astype(np.float32))
+        opt.step()
+    np.testing.assert_allclose(w.detach().numpy(), golden[f'opt_{oname}_w'], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(b.detach().numpy(), golden[f'opt_{oname}_b'], rtol=2e-6, atol=1e-7)
+
+
+def test_cli_surface(S, tmp_path):
+    from speech_enhancement_amd import main_gan, inference_gan
+    cfgdir = os.path.join(ROOT, 'speech-enhancement_amd', 'configs')
+    a, c = main_gan.parse_option(['--cfg', os.path.join(cfgdir, 'scp.yaml'), '-a', 'scp', '-b', '64', '--optimizer',
+                                  'adamw', '--lr', '5e-4', '--crop-len', '2', '--gen-first', '--comp-type', 'log',
+                                  '--max-norm', '5', '--wd', '0.02', '-p', '3', '--opts', 'N_FFT', '400'])
+    assert (a.arch, a.batch_size, a.optimizer, a.crop_len, a.gen_first, a.comp_type) == ('scp', 64, 'adamw', 2, True, 'log')
+    assert a.max_norm == 5 and a.weight_decay == 0.02 and a.print_freq == 3 and a.dist_backend == 'nccl'
+    assert c.LOSS_WEIGHTS == [0.3, 0.7, 0.2, 0.05] and c.CROP_LEN == 2 and c.TRAIN.SCHEDULER.LR == 5e-4
+    assert c.DATA.TEST_NOISY_DIR.endswith('noisy_testset_wav')
+    a, _ = main_gan.parse_option(['--cfg', os.path.join(cfgdir, 'baseline.yaml')])
+    assert a.arch == 'cmgan' and a.optimizer == 'sgd' and a.lr == 0.01 and a.epochs == 100     # reference defaults
+    a, c = inference_gan.parse_option(['-o', 'out', '-m', 'ck.pth.tar', '--cfg', os.path.join(cfgdir, 'baseline.yaml'),
+                                       '--save', '--gpu', '0'])
+    assert a.save and a.model_path == 'ck.pth.tar' and c.HOP_SAMPLES == 100
+    assert S.build_criterion('l1').__class__.__name__ == 'L1Loss' and S.build_criterion('MSE').__class__.__name__ == 'MSELoss'
