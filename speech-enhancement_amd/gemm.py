@@ -14,7 +14,7 @@ def conv_taps(kh, kw, dil=(1, 1), pad=(0, 0)):
 
 def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=None, st=1, sf=1, up=0,
               prologue=L.PRO_NONE, epilogue=0, alpha=1.0, ldr=0, r_off=0, ldx=0, x_off=0, pro_seed=0, epi_seed=0,
-              drop_p=0.0):
+              drop_p=0.0, precision=0):
     d = GemmDesc()
     d.B, d.To, d.Fo, d.Ti, d.Fi = B, To, Fo, Ti, Fi
     d.st, d.sf, d.up = st, sf, up
@@ -27,6 +27,7 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
     d.prologue, d.epilogue, d.alpha = prologue, epilogue, alpha
     d.ldr, d.r_off, d.ldx, d.x_off = ldr, r_off, ldx, x_off
     d.pro_seed, d.epi_seed, d.drop_p = pro_seed & 0xFFFFFFFF, epi_seed & 0xFFFFFFFF, drop_p
+    d.precision = precision
     return d
 
 
@@ -40,7 +41,8 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     M = d.B * d.To * d.Fo
     L.call('se_gemm_tap', C.byref(d), L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Y), L.ptr(R), L.ptr(AUX),
            L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream(),
-           _key=f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>', _flops=2.0 * M * d.N * d.ntap * d.C,
+           _key=(f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
+                 f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>'), _flops=2.0 * M * d.N * d.ntap * d.C,
            _bytes=4.0 * M * (d.C + d.N))
     return Y
 

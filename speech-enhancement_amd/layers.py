@@ -15,6 +15,18 @@ from . import ops as O
 
 EPS = 1e-5
 
+# Arithmetic of the MFMA-bound convolution GEMMs (dilated dense stacks, sub-pixel, strided convs): 'f32' = exact
+# fp32 MFMA; 'bf16x6' (default) = every fp32 operand split EXACTLY into three bf16 parts, six bf16 MFMAs per product,
+# fp32 accumulation: fp32-equivalent results (dropped terms <= 2^-24) at 16/6 of the fp32 MFMA rate; 'bf16x3' = two
+# parts / three MFMAs, ~1.5e-5 relative per product (meets the 1e-3 bar with less margin; opt-in).
+import os as _os
+CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_CONV_PRECISION', 'bf16x6')]
+
+
+def set_conv_precision(name):
+    global CONV_PRECISION
+    CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[name]
+
 
 class DPHooks:
     """Data-parallel hooks: SyncBatchNorm statistic exchange (main_gan.py:154-155).  Single-GPU default: none."""
@@ -42,7 +54,8 @@ def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None
     Fo = Fo or Fi
     ep = L.EPI_BIAS | (L.EPI_STATS if want_stats else 0) | (L.EPI_SHUFFLE2 if shuffle2 else 0)
     No = N // 2 if shuffle2 else N
-    d = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, No, a_off=a_off, sf=sf, epilogue=ep)
+    d = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, No, a_off=a_off, sf=sf, epilogue=ep,
+                     precision=CONV_PRECISION)
     R = torch.empty(B, To, Fo * (2 if shuffle2 else 1), No, device=x.device, dtype=torch.float32)
     stats = torch.zeros(B, No, 2, device=x.device, dtype=torch.float64) if want_stats else None
     GM.gemm_tap(d, x, wp, R, bias=bias, stats=stats)
@@ -86,7 +99,7 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
         dx = torch.empty(B, Ti, Fi, C_in, device=dR.device, dtype=torch.float32)
         lddx = C_in
     dd = GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in taps], N, N, C_in, lddx, c_off=dx_off, sf=sf,
-                      up=1 if sf != 1 else 0, epilogue=L.EPI_ACCUM if accumulate else 0)
+                      up=1 if sf != 1 else 0, epilogue=L.EPI_ACCUM if accumulate else 0, precision=CONV_PRECISION)
     GM.gemm_tap(dd, dR, wd, dx)
     return dx
 

@@ -260,3 +260,36 @@ def test_feed_forward_with_dropout_fwd_bwd(G):
     assert relerr(dx, x64.grad) < 3e-5
     for k in P:
         assert relerr(Gd[k], P64[k].grad) < 5e-5, k
+
+
+def test_split_bf16_precision_mode(G):
+    """precision=1 (hi/lo bf16 split, 3 bf16 MFMAs, fp32 accumulate) on a dilated conv from a skip stack and its input
+    gradient: error vs fp64 must stay ~1e-5 of the output scale (plain bf16 would be ~4e-3)."""
+    gemm, L = G
+    B, T, Fq = 2, 33, 45
+    xbuf = rnd(B, T, Fq, 256, seed=3)
+    w = rnd(64, 256, 2, 3, seed=4, scale=0.03)
+    b = rnd(64, seed=5)
+    x = xbuf.permute(0, 3, 1, 2).double()
+    ref = F.conv2d(F.pad(x, (1, 1, 8, 0)), w.double(), b.double(), dilation=(8, 1)).permute(0, 2, 3, 1)
+    taps = gemm.conv_taps(2, 3, (8, 1), (8, 1))
+    wp = gemm.pack_conv_fwd(w)
+    errs = {}
+    for prec in (0, 1, 2):
+        d = gemm.make_desc(B, T, Fq, T, Fq, taps, 256, 256, 64, 64, epilogue=L.EPI_BIAS | L.EPI_STATS, precision=prec)
+        y = torch.empty(B, T, Fq, 64, device='cuda')
+        st = torch.zeros(B, 64, 2, device='cuda', dtype=torch.float64)
+        gemm.gemm_tap(d, xbuf, wp, y, bias=b, stats=st)
+        errs[prec] = relerr(y, ref)
+        assert relerr(st[..., 1], (ref ** 2).sum((1, 2))) < 1e-4
+    print('conv relerr fp32 %.2e  bf16x3 %.2e  bf16x6 %.2e' % (errs[0], errs[1], errs[2]))
+    assert errs[0] < 3e-6 and errs[1] < 1e-4 and errs[2] < 3e-6
+    # input gradient (dgrad) through the same path
+    dy = rnd(B, T, Fq, 64, seed=9)
+    x64 = xbuf.double().requires_grad_(True)
+    F.conv2d(F.pad(x64.permute(0, 3, 1, 2), (1, 1, 8, 0)), w.double(), None, dilation=(8, 1)).permute(0, 2, 3, 1).backward(dy.double())
+    wd = gemm.pack_conv_dgrad(w)
+    dd = gemm.make_desc(B, T, Fq, T, Fq, [(-a, -c) for a, c in taps], 64, 64, 256, 256, precision=1)
+    dx = torch.empty(B, T, Fq, 256, device='cuda')
+    gemm.gemm_tap(dd, dy, wd, dx)
+    assert relerr(dx, x64.grad) < 1e-4
