@@ -23,7 +23,7 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True):
     nseq, n, inner, os_, is_, ps = geom
     L.call('se_attn_fwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner),
            C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos), C.c_float(scale), L.stream(),
-           _key='attn_fwd_kernel', _flops=nseq * 4 * 3 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 256)
+           _key=('attn_fwd2_kernel' if (n + 15) // 16 * 16 <= 1200 else 'attn_fwd_kernel'), _flops=nseq * 4 * 3 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 256)
     return O, lse
 
 
@@ -39,6 +39,8 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
     Et[:, :E.shape[0]] = E.t()
     L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dl), L.ptr(dqkv), L.ptr(dE),
            C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
-           C.c_int(maxpos), C.c_float(scale), L.ptr(Et), C.c_int(et_ld), L.stream(), _key='attn_bwd (delta+dkv+dq kernels)',
+           C.c_int(maxpos), C.c_float(scale), L.ptr(Et), C.c_int(et_ld), L.stream(), _key=('attn_bwd2_kernel<112, 4, true> (+delta)' if n <= 112 and maxpos >= 352 else
+                 'attn_bwd2_kernel<336, 8, false> (+delta)' if n <= 336 and maxpos >= 352 else
+                 'attn_bwd_dkv + attn_bwd_dq (+delta)'),
            _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
     return dqkv

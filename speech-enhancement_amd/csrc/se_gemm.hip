@@ -20,6 +20,7 @@ struct GemmArgs {
   se_gemm_desc d;
   const float* A; const float* W; const float* bias; float* Y; const float* R; float* AUX;
   const float* rowstats; const float* ps; const float* pb; double* stats;
+  int ncb;      // column blocks per row tile
 };
 
 // source pixel (index inside batch entry b's grid) of output pixel (t, f) for one tap; -1 when outside
@@ -80,6 +81,107 @@ static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float
     }
   }
   return make_float4(x[0], x[1], x[2], x[3]);
+}
+
+// Vectorised epilogue (bias / dropout / swish-gradient / residual / accumulate / plain store): each 32x32 accumulator
+// is transposed through a wave-private LDS patch so that every lane then owns 4 consecutive output columns: the
+// AUX / R reads and the Y writes are 16-byte accesses (8 lanes = one 128-B row segment) and there are 4 of them per
+// lane and tile instead of 16 four-byte ones.  cs: the wave's [32][cs_ld] patch (reuses the A staging tile).
+static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
+                                                         int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
+                                                         float inv_keep) {
+  const se_gemm_desc& d = g.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Mb = d.To * d.Fo, ep = d.epilogue;
+  const long ptile = (long)b * Mb + m0;
+  float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
+  const float* __restrict__ Xb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
+  const float* __restrict__ Rb = g.R ? g.R + ptile * d.ldr + d.r_off : nullptr;
+  const unsigned pdrop = (unsigned)ptile;
+  const int col = lane & 31, half = lane >> 5;
+  const int cq = lane & 7, rr = lane >> 3;          // read-back role: float4 column, row within an 8-row pass
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const f32x16& acc = nt ? acc1 : acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc[r];
+    const int n = by * 64 + nt * 32 + cq * 4;        // first of this lane's 4 output columns
+    if (n < d.N) {                                   // N % 4 == 0 (host-checked)
+      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ep & SE_EPI_BIAS) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + rr + 8 * i;
+        if (m0 + row >= Mb) continue;
+        float4 v = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (ep & SE_EPI_DROP) {
+          const unsigned pe = (pdrop + (unsigned)row) * (unsigned)d.N + (unsigned)n;
+          v.x *= drop_scale(d.epi_seed, pe, thr, inv_keep); v.y *= drop_scale(d.epi_seed, pe + 1, thr, inv_keep);
+          v.z *= drop_scale(d.epi_seed, pe + 2, thr, inv_keep); v.w *= drop_scale(d.epi_seed, pe + 3, thr, inv_keep);
+        }
+        if (ep & SE_EPI_SWISH_GRAD) {
+          float4 z = *reinterpret_cast<const float4*>(Xb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n));
+          v.x *= swish_gradf_(z.x); v.y *= swish_gradf_(z.y); v.z *= swish_gradf_(z.z); v.w *= swish_gradf_(z.w);
+        }
+        if (ep & SE_EPI_RESID) {
+          float4 rv = *reinterpret_cast<const float4*>(Rb + ((unsigned)row * (unsigned)d.ldr + (unsigned)n));
+          v.x = rv.x + d.alpha * v.x; v.y = rv.y + d.alpha * v.y; v.z = rv.z + d.alpha * v.z; v.w = rv.w + d.alpha * v.w;
+        }
+        float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
+        if (ep & SE_EPI_ACCUM) { float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *yp = v;
+      }
+    }
+  }
+}
+// GLU flavour of the vectorised epilogue: accumulator 0 = value columns, accumulator 1 = gate columns of the same 32
+// outputs.  The gate tile is transposed first and parked in registers, then the value tile; Y = a * sigmoid(g) and
+// the pre-GLU Z (both halves) leave as float4 stores.
+static __device__ __forceinline__ void gemm_epilogue_glu_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
+                                                             int m0, int by, int b, float* cs, int cs_ld) {
+  const se_gemm_desc& d = g.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Mb = d.To * d.Fo, No = d.N / 2;
+  const long ptile = (long)b * Mb + m0;
+  float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
+  float* __restrict__ Zb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
+  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  const int n = by * 32 + cq * 4;                  // value column; gate column = No + n
+  float4 gate[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc1[r];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gate[i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc0[r];
+  if (n >= No) return;
+  float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+  if (d.epilogue & SE_EPI_BIAS) { ba = *reinterpret_cast<const float4*>(g.bias + n); bg = *reinterpret_cast<const float4*>(g.bias + No + n); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + rr + 8 * i;
+    if (m0 + row >= Mb) continue;
+    float4 a = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
+    float4 gt = gate[i];
+    a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
+    gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
+    if (Zb) {
+      *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n)) = a;
+      *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)(No + n))) = gt;
+    }
+    *reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n)) =
+        make_float4(a.x * sigmoidf_(gt.x), a.y * sigmoidf_(gt.y), a.z * sigmoidf_(gt.z), a.w * sigmoidf_(gt.w));
+  }
+}
+static __device__ __forceinline__ bool epilogue_glu_vec_ok(const se_gemm_desc& d) {
+  return (d.epilogue & SE_EPI_GLU) && !(d.epilogue & (SE_EPI_STATS | SE_EPI_SHUFFLE2 | SE_EPI_DROP | SE_EPI_RESID | SE_EPI_ACCUM |
+                                                      SE_EPI_SWISH_GRAD | 256)) &&
+         (d.N & 7) == 0 && (d.ldc & 3) == 0 && (d.c_off & 3) == 0 && (d.ldx & 3) == 0 && (d.x_off & 3) == 0;
+}
+static __device__ __forceinline__ bool epilogue_vec_ok(const se_gemm_desc& d) {
+  return !(d.epilogue & (SE_EPI_GLU | SE_EPI_STATS | SE_EPI_SHUFFLE2 | 256)) && (d.N & 3) == 0 && (d.ldc & 3) == 0 &&
+         (d.c_off & 3) == 0 && (d.ldx & 3) == 0 && (d.x_off & 3) == 0 && (d.ldr & 3) == 0 && (d.r_off & 3) == 0;
 }
 
 // epilogue shared by the fp32 and the split-bf16 kernels: acc0 / acc1 = the wave's two 32x32 accumulators
@@ -309,7 +411,101 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
+  if (SA >= 36 && epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA, thr, inv_keep);
+  else if (SA >= 36 && epilogue_glu_vec_ok(d)) gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA);
+  else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-panel variant for the token-wise layers with K = 64 and several column blocks (LN -> 256 / 192 / GLU-256,
+// dY(64) -> 256): the A tile [128 rows x 64] is fetched, transformed by the prologue (LayerNorm / dropout hash) and
+// staged in LDS ONCE, then the workgroup sweeps all column blocks streaming only the 16 KB W tiles (L2-resident).
+// The per-column-block version re-read and re-transformed A once per column block.
+template <int PRO>
+__global__ __launch_bounds__(256) void gemm_rowpanel64_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 64, K = 64, SA = K + 4;
+  __shared__ __attribute__((aligned(16))) float As[BM * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * SA];
+  __shared__ float red[4 * 64 * 2];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int Mb = d.To * d.Fo;
+  const int m0 = blockIdx.x * BM;
+  const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
+  const int q = tid & 15, r0 = tid >> 4;           // float4 column (16 per row), row within a 16-row pass
+  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
+  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const float* __restrict__ Ab = g.A + (long)b * Mb * d.lda + d.a_off;
+  const float* __restrict__ Wb = g.W;
+  // ---- A panel: 8 passes of 16 rows
+  {
+    float4 ra[8];
+    bool ok[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int m = m0 + r0 + 16 * i;
+      ok[i] = m < Mb;
+      ra[i] = ok[i] ? *reinterpret_cast<const float4*>(Ab + ((unsigned)m * (unsigned)d.lda + (unsigned)(q * 4)))
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float4 v = ra[i];
+      if (PRO != SE_PRO_NONE && ok[i]) {
+        int m = m0 + r0 + 16 * i;
+        float mean = 0.f, rstd = 0.f;
+        if (PRO == SE_PRO_LN) { const float* rs = g.rowstats + ((long)b * Mb + m) * 2; mean = rs[0]; rstd = rs[1]; }
+        v = apply_pro<PRO>(v, q * 4, K, mean, rstd, g.ps, g.pb, (unsigned)(b * Mb + m), d.pro_seed, thr, inv_keep);
+      }
+      *reinterpret_cast<float4*>(&As[(r0 + 16 * i) * SA + q * 4]) = v;
+    }
+  }
+  const int ncb = g.ncb;
+  float4 rb[4];
+  auto load_w = [&](int cb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int j = r0 + 16 * i;
+      int n; bool ok;
+      if (glu) { n = (j >> 5) * (d.N / 2) + cb * 32 + (j & 31); ok = (cb * 32 + (j & 31)) < d.N / 2; }
+      else { n = cb * 64 + j; ok = n < d.N; }
+      rb[i] = ok ? *reinterpret_cast<const float4*>(Wb + ((unsigned)n * (unsigned)d.ldw + (unsigned)(q * 4)))
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_w(0);
+  for (int cb = 0; cb < ncb; ++cb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 16 * i) * SA + q * 4]) = rb[i];
+    __syncthreads();
+    if (cb + 1 < ncb) load_w(cb + 1);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {            // two 32-wide K chunks, lane half h supplies k in [32ch+16h, +16)
+      const float* Ap = &As[(wave * 32 + (lane & 31)) * SA + 32 * ch + (lane >> 5) * 16];
+      const float* Bp0 = &Bs[(lane & 31) * SA + 32 * ch + (lane >> 5) * 16];
+      const float* Bp1 = Bp0 + 32 * SA;
+#pragma unroll
+      for (int s4 = 0; s4 < 16; s4 += 4) {
+        float4 a = *reinterpret_cast<const float4*>(Ap + s4);
+        float4 b0 = *reinterpret_cast<const float4*>(Bp0 + s4);
+        float4 b1 = *reinterpret_cast<const float4*>(Bp1 + s4);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+      }
+    }
+    __syncthreads();          // Bs free for the next column block
+    gemm_epilogue(g, acc0, acc1, m0, cb, b, red, thr, inv_keep);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,7 +653,9 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     }
     __syncthreads();
   }
-  gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
+  float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;        // the staging planes are free now
+  if (epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep);
+  else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -640,13 +838,36 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
   if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");
-  GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats};
+  GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats, 0};
   const int Mb = d->To * d->Fo;
   const int ncols = (ep & SE_EPI_GLU) ? cdiv(d->N / 2, 32) : cdiv(d->N, 64);
   dim3 grid(cdiv(Mb, 128), ncols, d->B), block(256);
+  g.ncb = ncols;
   hipStream_t s = as_stream(stream);
   // K slab per LDS stage: 64 floats when the channel run allows it (half the barriers, all of a K=64 layer in
   // flight at once), 16 for the tiny-channel convolutions, else 32.  SE_GEMM_BK overrides (profiling).
+  {
+    const bool lin = d->ntap == 1 && !d->up && d->st == 1 && d->sf == 1 && d->dt[0] == 0 && d->df[0] == 0 &&
+                     d->Ti == d->To && d->Fi == d->Fo;
+    // measured: slower than the per-column-block kernel (4x fewer workgroups in flight -> less memory-level
+    // parallelism); kept behind SE_GEMM_PANEL=1 for experiments
+    static const bool no_panel = getenv("SE_GEMM_PANEL") == nullptr;
+    if (lin && d->C == 64 && ncols >= 2 && d->precision == 0 && !(ep & SE_EPI_STATS) && !no_panel) {
+      dim3 pgrid(cdiv(Mb, 128), 1, d->B);
+#define LAUNCHP(PRO) hipLaunchKernelGGL((gemm_rowpanel64_kernel<PRO>), pgrid, block, 0, s, g)
+      switch (d->prologue) {
+        case SE_PRO_NONE: LAUNCHP(SE_PRO_NONE); break;
+        case SE_PRO_LN: LAUNCHP(SE_PRO_LN); break;
+        case SE_PRO_SWISH: LAUNCHP(SE_PRO_SWISH); break;
+        case SE_PRO_AFFINE_SWISH: LAUNCHP(SE_PRO_AFFINE_SWISH); break;
+        case SE_PRO_SWISH_DROP: LAUNCHP(SE_PRO_SWISH_DROP); break;
+        case SE_PRO_DROP: LAUNCHP(SE_PRO_DROP); break;
+        default: return se_fail("gemm: unknown prologue %d", d->prologue);
+      }
+#undef LAUNCHP
+      return se_check_launch("se_gemm_tap(rowpanel)");
+    }
+  }
   if ((d->precision == 1 || d->precision == 2) && d->C >= 32) {      // split-bf16 paths (BK = 32 only)
 #define LAUNCHB(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 2>), grid, block, 0, s, g); \
                           else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 3>), grid, block, 0, s, g); } while (0)

@@ -5,6 +5,9 @@ from speech_enhancement_amd import gemm as GM, _lib as L
 M = 16 * 321 * 101
 
 
+PREC = int(os.environ.get('PREC', '0'))
+
+
 def run(name, C, N, pro=0, epi=0, aux=False, bias=False, resid=False, ldc=None, reps=5):
     x = torch.randn(M, C, device='cuda')
     w = torch.randn(N, C, device='cuda') * C ** -0.5
@@ -23,7 +26,7 @@ def run(name, C, N, pro=0, epi=0, aux=False, bias=False, resid=False, ldc=None, 
         kw['rowstats'] = torch.stack([x.mean(-1), x.var(-1).rsqrt()], -1).contiguous()
         kw['ps'] = torch.ones(C, device='cuda'); kw['pb'] = torch.zeros(C, device='cuda')
     d = GM.linear_desc(M, C, N, ldc=ldc or No, prologue=pro, epilogue=epi, ldx=ldx, ldr=N if resid else 0, drop_p=0.2 if (epi & L.EPI_DROP or pro in (4, 5)) else 0.0,
-                       pro_seed=123, epi_seed=456)
+                       pro_seed=123, epi_seed=456, precision=PREC)
     for _ in range(2):
         GM.gemm_tap(d, x, w, y, **kw)
     torch.cuda.synchronize()
