@@ -24,62 +24,77 @@ struct DwArgs {
   const float* X; const float* W; const float* bias; float* Y; double* stats; int flip;
 };
 
-__global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
+// 512 threads: lane pair-channel cl = tid & 63 (2 channels), position slot ps = tid >> 6 (8 slots x 8 positions).
+// Two channels per lane (instead of four) keep the 31 taps + 8 accumulators + the next tile's prefetch registers
+// under ~100 VGPRs, so 3 workgroups (24 waves) stay resident per CU and the next tile's global loads are in flight
+// while the current tile is computed.
+__global__ __launch_bounds__(512) void dwconv_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[DW_ROWS * DW_C];
-  const int tid = threadIdx.x, cl = tid & 31, ps = tid >> 5;
+  const int tid = threadIdx.x, cl = tid & 63, ps = tid >> 6;
   const int n = a.g.n;
-  // taps of this lane's 4 channels: the 128 x 31 table is read ONCE per (persistent) workgroup with coalesced
-  // loads into LDS and picked up as float4 channel groups (per-thread strided global loads of the table -- 124
-  // scalar loads touching 32 cache lines each -- made the first version of this kernel 5x slower than HBM).
-  for (int i = tid; i < DW_C * DW_K; i += 256) {
+  for (int i = tid; i < DW_C * DW_K; i += 512) {
     int ch = i / DW_K, k = i - ch * DW_K;
     xs[(a.flip ? DW_K - 1 - k : k) * DW_C + ch] = a.W[i];
   }
   __syncthreads();
-  float4 w[DW_K];
+  float2 w[DW_K];
 #pragma unroll
-  for (int k = 0; k < DW_K; ++k) w[k] = *reinterpret_cast<const float4*>(&xs[k * DW_C + cl * 4]);
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a.bias) bv = *reinterpret_cast<const float4*>(a.bias + cl * 4);
-  float s[4] = {0, 0, 0, 0}, q2[4] = {0, 0, 0, 0};
+  for (int k = 0; k < DW_K; ++k) w[k] = *reinterpret_cast<const float2*>(&xs[k * DW_C + cl * 2]);
+  float2 bv = make_float2(0.f, 0.f);
+  if (a.bias) bv = *reinterpret_cast<const float2*>(a.bias + cl * 2);
+  float s[2] = {0, 0}, q2[2] = {0, 0};
   const int tiles = (n + DW_TILE - 1) / DW_TILE;
   const long nitems = (long)a.g.nseq * tiles;
-  for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
+  constexpr int NPRE = (DW_ROWS * 32 + 511) / 512;      // float4 per thread per tile (6)
+  float4 pre[NPRE];
+  auto fetch = [&](long it) {
     const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * DW_TILE;
     const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
     const float* __restrict__ Xb = a.X + base * DW_C;
-    float* __restrict__ Yb = a.Y + base * DW_C;
-    const long rs = a.g.pos_stride * DW_C;      // floats between consecutive positions
-    __syncthreads();                           // previous tile (or the weight table) fully consumed
-    for (int i = tid; i < DW_ROWS * 32; i += 256) {
+    const long rs = a.g.pos_stride * DW_C;
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      int i = tid + k * 512;
       int row = i >> 5, q = i & 31;
       int p = p0 - 15 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p >= 0 && p < n) v = *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4);
-      *reinterpret_cast<float4*>(&xs[row * DW_C + q * 4]) = v;
+      pre[k] = (row < DW_ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  long it = blockIdx.x;
+  if (it < nitems) fetch(it);
+  for (; it < nitems; it += gridDim.x) {
+    const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * DW_TILE;
+    const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
+    float* __restrict__ Yb = a.Y + base * DW_C;
+    const long rs = a.g.pos_stride * DW_C;
+    __syncthreads();                           // previous tile (or the tap table) fully consumed
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k) {
+      int i = tid + k * 512;
+      if (i < DW_ROWS * 32) *reinterpret_cast<float4*>(&xs[(i >> 5) * DW_C + (i & 31) * 4]) = pre[k];
     }
     __syncthreads();
-    float4 acc[8];
+    if (it + gridDim.x < nitems) fetch(it + gridDim.x);
+    float2 acc[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = bv;
 #pragma unroll
     for (int i = 0; i < 8 + DW_K - 1; ++i) {
-      float4 x = *reinterpret_cast<const float4*>(&xs[(ps * 8 + i) * DW_C + cl * 4]);
+      float2 x = *reinterpret_cast<const float2*>(&xs[(ps * 8 + i) * DW_C + cl * 2]);
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
         const int k = i - o;
-        if (k >= 0 && k < DW_K) {
-          acc[o].x += x.x * w[k].x; acc[o].y += x.y * w[k].y; acc[o].z += x.z * w[k].z; acc[o].w += x.w * w[k].w;
-        }
+        if (k >= 0 && k < DW_K) { acc[o].x += x.x * w[k].x; acc[o].y += x.y * w[k].y; }
       }
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       int p = p0 + ps * 8 + o;
       if (p < n) {
-        *reinterpret_cast<float4*>(Yb + (long)p * rs + cl * 4) = acc[o];
-        s[0] += acc[o].x; s[1] += acc[o].y; s[2] += acc[o].z; s[3] += acc[o].w;
-        q2[0] += acc[o].x * acc[o].x; q2[1] += acc[o].y * acc[o].y; q2[2] += acc[o].z * acc[o].z; q2[3] += acc[o].w * acc[o].w;
+        *reinterpret_cast<float2*>(Yb + (long)p * rs + cl * 2) = acc[o];
+        s[0] += acc[o].x; s[1] += acc[o].y;
+        q2[0] += acc[o].x * acc[o].x; q2[1] += acc[o].y * acc[o].y;
       }
     }
   }
@@ -87,12 +102,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwArgs a) {
     __syncthreads();
     float* red = xs;            // [8 slots][128][2]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[(ps * DW_C + cl * 4 + j) * 2] = s[j]; red[(ps * DW_C + cl * 4 + j) * 2 + 1] = q2[j]; }
+    for (int j = 0; j < 2; ++j) { red[(ps * DW_C + cl * 2 + j) * 2] = s[j]; red[(ps * DW_C + cl * 2 + j) * 2 + 1] = q2[j]; }
     __syncthreads();
-    float t = 0.f;              // tid -> (channel tid>>1, which tid&1)
+    if (tid < 256) {
+      float t = 0.f;              // tid -> (channel tid>>1, which tid&1)
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) t += red[(sl * DW_C) * 2 + tid];
-    atomicAdd(&a.stats[tid], (double)t);
+      for (int sl = 0; sl < 8; ++sl) t += red[(sl * DW_C) * 2 + tid];
+      atomicAdd(&a.stats[tid], (double)t);
+    }
   }
 }
 
@@ -101,54 +118,68 @@ struct DwWgradArgs {
   const float* X; const float* dY; float* dW; float* dbias;
 };
 
-__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradArgs a) {
+// weight gradient, same thread layout (512 threads, 2 channels per lane, 8 slots x 8 positions): 31 float2
+// accumulators per lane, persistent over tiles, one flush per workgroup.
+__global__ __launch_bounds__(512) void dwconv_wgrad_kernel(DwWgradArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[DW_ROWS * DW_C];
   __shared__ __attribute__((aligned(16))) float ys[DW_TILE * DW_C];
-  const int tid = threadIdx.x, cl = tid & 31, ps = tid >> 5;
+  const int tid = threadIdx.x, cl = tid & 63, ps = tid >> 6;
   const int n = a.g.n;
   const int tiles = (n + DW_TILE - 1) / DW_TILE;
   const long nitems = (long)a.g.nseq * tiles;
-  float4 acc[DW_K];
+  float2 acc[DW_K];
 #pragma unroll
-  for (int k = 0; k < DW_K; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 bacc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
+  for (int k = 0; k < DW_K; ++k) acc[k] = make_float2(0.f, 0.f);
+  float2 bacc = make_float2(0.f, 0.f);
+  constexpr int NPX = (DW_ROWS * 32 + 511) / 512, NPY = DW_TILE * 32 / 512;     // 6, 4
+  float4 prx[NPX], pry[NPY];
+  auto fetch = [&](long it) {
     const int seq = (int)(it / tiles), p0 = (int)(it % tiles) * DW_TILE;
     const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
     const float* __restrict__ Xb = a.X + base * DW_C;
     const float* __restrict__ Gb = a.dY + base * DW_C;
     const long rs = a.g.pos_stride * DW_C;
-    __syncthreads();
-    for (int i = tid; i < DW_ROWS * 32; i += 256) {
-      int row = i >> 5, q = i & 31;
-      int p = p0 - 15 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p >= 0 && p < n) v = *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4);
-      *reinterpret_cast<float4*>(&xs[row * DW_C + q * 4]) = v;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      int i = tid + k * 512, row = i >> 5, q = i & 31, p = p0 - 15 + row;
+      prx[k] = (row < DW_ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int i = tid; i < DW_TILE * 32; i += 256) {
-      int row = i >> 5, q = i & 31;
-      int p = p0 + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p < n) v = *reinterpret_cast<const float4*>(Gb + (long)p * rs + q * 4);
-      *reinterpret_cast<float4*>(&ys[row * DW_C + q * 4]) = v;
+#pragma unroll
+    for (int k = 0; k < NPY; ++k) {
+      int i = tid + k * 512, row = i >> 5, q = i & 31, p = p0 + row;
+      pry[k] = (p < n) ? *reinterpret_cast<const float4*>(Gb + (long)p * rs + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  long it = blockIdx.x;
+  if (it < nitems) fetch(it);
+  for (; it < nitems; it += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+      int i = tid + k * 512;
+      if (i < DW_ROWS * 32) *reinterpret_cast<float4*>(&xs[(i >> 5) * DW_C + (i & 31) * 4]) = prx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NPY; ++k) {
+      int i = tid + k * 512;
+      *reinterpret_cast<float4*>(&ys[(i >> 5) * DW_C + (i & 31) * 4]) = pry[k];
     }
     __syncthreads();
-    float4 dy[8];
+    if (it + gridDim.x < nitems) fetch(it + gridDim.x);
+    float2 dy[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      dy[o] = *reinterpret_cast<const float4*>(&ys[(ps * 8 + o) * DW_C + cl * 4]);
-      bacc.x += dy[o].x; bacc.y += dy[o].y; bacc.z += dy[o].z; bacc.w += dy[o].w;
+      dy[o] = *reinterpret_cast<const float2*>(&ys[(ps * 8 + o) * DW_C + cl * 2]);
+      bacc.x += dy[o].x; bacc.y += dy[o].y;
     }
 #pragma unroll
     for (int i = 0; i < 8 + DW_K - 1; ++i) {
-      float4 x = *reinterpret_cast<const float4*>(&xs[(ps * 8 + i) * DW_C + cl * 4]);
+      float2 x = *reinterpret_cast<const float2*>(&xs[(ps * 8 + i) * DW_C + cl * 2]);
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
         const int k = i - o;
-        if (k >= 0 && k < DW_K) {
-          acc[k].x += dy[o].x * x.x; acc[k].y += dy[o].y * x.y; acc[k].z += dy[o].z * x.z; acc[k].w += dy[o].w * x.w;
-        }
+        if (k >= 0 && k < DW_K) { acc[k].x += dy[o].x * x.x; acc[k].y += dy[o].y * x.y; }
       }
     }
   }
@@ -160,11 +191,11 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwWgradArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int k = k0 + kk;
-      float4 v = k < DW_K ? acc[k < DW_K ? k : 0] : bacc;      // slot k == 31 carries the bias gradient
-      *reinterpret_cast<float4*>(&red[((ps * 8 + kk) * DW_C) + cl * 4]) = v;
+      float2 v = k < DW_K ? acc[k < DW_K ? k : 0] : bacc;      // slot k == 31 carries the bias gradient
+      *reinterpret_cast<float2*>(&red[((ps * 8 + kk) * DW_C) + cl * 2]) = v;
     }
     __syncthreads();
-    for (int i = tid; i < 8 * DW_C; i += 256) {
+    for (int i = tid; i < 8 * DW_C; i += 512) {
       int kk = i >> 7, ch = i & 127;
       float t = 0.f;
 #pragma unroll
@@ -183,7 +214,7 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
   DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, W, bias, Y, stats, flip};
   long nitems = (long)nseq * cdiv(n, DW_TILE);
   int nblk = nitems < 768 ? (int)nitems : 768;          // persistent: 3 workgroups (48 KB LDS each) per CU
-  hipLaunchKernelGGL(dwconv_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(dwconv_kernel, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31");
 }
 
@@ -193,6 +224,6 @@ extern "C" int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, flo
   DwWgradArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, dY, dW, dbias};
   long nitems = (long)nseq * cdiv(n, DW_TILE);
   int nblk = nitems < 512 ? (int)nitems : 512;
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31_wgrad");
 }
