@@ -89,7 +89,7 @@ static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float
 // lane and tile instead of 16 four-byte ones.  cs: the wave's [32][cs_ld] patch (reuses the A staging tile).
 static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
                                                          int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
-                                                         float inv_keep) {
+                                                         float inv_keep, float* red = nullptr) {
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Mb = d.To * d.Fo, ep = d.epilogue;
@@ -106,6 +106,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc[r];
     const int n = by * 64 + nt * 32 + cq * 4;        // first of this lane's 4 output columns
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), qsum = ssum;
     if (n < d.N) {                                   // N % 4 == 0 (host-checked)
       float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ep & SE_EPI_BIAS) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
@@ -115,6 +116,10 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         if (m0 + row >= Mb) continue;
         float4 v = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
         v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (ep & SE_EPI_STATS) {
+          ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+          qsum.x += v.x * v.x; qsum.y += v.y * v.y; qsum.z += v.z * v.z; qsum.w += v.w * v.w;
+        }
         if (ep & SE_EPI_DROP) {
           const unsigned pe = (pdrop + (unsigned)row) * (unsigned)d.N + (unsigned)n;
           v.x *= drop_scale(d.epi_seed, pe, thr, inv_keep); v.y *= drop_scale(d.epi_seed, pe + 1, thr, inv_keep);
@@ -131,6 +136,29 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
         if (ep & SE_EPI_ACCUM) { float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *yp = v;
+      }
+    }
+    if (ep & SE_EPI_STATS) {      // fold the 8 row-lanes that share this column group, park per-wave partials in LDS
+      float sv[8] = {ssum.x, ssum.y, ssum.z, ssum.w, qsum.x, qsum.y, qsum.z, qsum.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sv[k] += __shfl_xor(sv[k], 8, 64); sv[k] += __shfl_xor(sv[k], 16, 64); sv[k] += __shfl_xor(sv[k], 32, 64); }
+      if (rr == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sv[j]; red[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sv[4 + j]; }
+      }
+    }
+  }
+  if (ep & SE_EPI_STATS) {
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+      float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s_ += red[(w * 64 + tid) * 2]; q_ += red[(w * 64 + tid) * 2 + 1]; }
+      int nn = by * 64 + tid;
+      if (nn < d.N) {
+        atomicAdd(&g.stats[((long)b * d.N + nn) * 2], (double)s_);
+        atomicAdd(&g.stats[((long)b * d.N + nn) * 2 + 1], (double)q_);
       }
     }
   }
@@ -180,7 +208,7 @@ static __device__ __forceinline__ bool epilogue_glu_vec_ok(const se_gemm_desc& d
          (d.N & 7) == 0 && (d.ldc & 3) == 0 && (d.c_off & 3) == 0 && (d.ldx & 3) == 0 && (d.x_off & 3) == 0;
 }
 static __device__ __forceinline__ bool epilogue_vec_ok(const se_gemm_desc& d) {
-  return !(d.epilogue & (SE_EPI_GLU | SE_EPI_STATS | SE_EPI_SHUFFLE2 | 256)) && (d.N & 3) == 0 && (d.ldc & 3) == 0 &&
+  return !(d.epilogue & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | 256)) && (d.N & 3) == 0 && (d.ldc & 3) == 0 &&
          (d.c_off & 3) == 0 && (d.ldx & 3) == 0 && (d.x_off & 3) == 0 && (d.ldr & 3) == 0 && (d.r_off & 3) == 0;
 }
 
@@ -411,7 +439,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  if (SA >= 36 && epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA, thr, inv_keep);
+  if (SA >= 36 && epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA, thr, inv_keep, red);
   else if (SA >= 36 && epilogue_glu_vec_ok(d)) gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     __syncthreads();
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;        // the staging planes are free now
-  if (epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep);
+  if (epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
 
