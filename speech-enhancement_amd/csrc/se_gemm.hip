@@ -21,7 +21,23 @@ struct GemmArgs {
   const float* A; const float* W; const float* bias; float* Y; const float* R; float* AUX;
   const float* rowstats; const float* ps; const float* pb; double* stats;
   int ncb;      // column blocks per row tile
+  int tiles;    // row tiles per batch entry
+  int nouter;   // B * tiles
+  int contig;   // 1: every XCD sweeps a contiguous range of row tiles (tap convolutions: the dt-shifted rows of a
+                //    tile are the dt = 0 rows of a tile the same L2 has just seen); 0: round-robin
 };
+
+// Workgroups are dispatched round-robin over the 8 XCDs, each with a private L2.  The `ninner` siblings of one
+// `outer` work item (column blocks sharing an A tile; (tap, channel, n) blocks sharing a row chunk) are decoded so
+// that they sit on the same XCD and next to each other in dispatch order: the shared operand is fetched into that
+// L2 once instead of once per sibling from the fabric.  The launch pads `nouter` to a multiple of 8.
+struct WorkId { int inner, outer; };
+static __device__ __forceinline__ WorkId decode_work(int ninner, int nouter, int contig) {
+  const unsigned w = blockIdx.x, xcd = w & 7u, slot = w >> 3;
+  const unsigned inner = slot % (unsigned)ninner, ol = slot / (unsigned)ninner;
+  const unsigned per = ((unsigned)nouter + 7u) >> 3;
+  return {(int)inner, (int)(contig ? xcd * per + ol : ol * 8u + xcd)};
+}
 
 // source pixel (index inside batch entry b's grid) of output pixel (t, f) for one tap; -1 when outside
 static __device__ __forceinline__ int src_pixel_in(const se_gemm_desc& d, int t, int f, int tap) {
@@ -324,9 +340,11 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, by = blockIdx.y;
+  const WorkId wk_ = decode_work(g.ncb, g.nouter, g.contig);
+  if (wk_.outer >= g.nouter) return;
+  const int b = wk_.outer / g.tiles, by = wk_.inner;
   const int Mb = d.To * d.Fo;
-  const int m0 = blockIdx.x * BM;
+  const int m0 = (wk_.outer - b * g.tiles) * BM;
   const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
   const int kq = tid % KQ, r0 = tid / KQ;
   // Addressing: per-batch-entry bases are wave-uniform (SGPR pairs) and every lane offset is a 32-bit element
@@ -379,8 +397,9 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   const float inv_keep = 1.0f / (1.0f - d.drop_p);
 
   auto load_tiles = [&](int it) {
-    int tap = it / nchunk;
-    int c0 = (it - tap * nchunk) * BK;
+    int chunk = it / d.ntap;             // channel chunk outer, tap inner: the taps of one chunk re-touch the same
+    int tap = it - chunk * d.ntap;       // 128-B lines (df = -1, 0, 1) while they are still in L1 / L2
+    int c0 = chunk * BK;
     int c = c0 + kq * 4;
     cur_c = c;
     bool cok = c < d.C;   // C is a multiple of 4
@@ -445,98 +464,6 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row-panel variant for the token-wise layers with K = 64 and several column blocks (LN -> 256 / 192 / GLU-256,
-// dY(64) -> 256): the A tile [128 rows x 64] is fetched, transformed by the prologue (LayerNorm / dropout hash) and
-// staged in LDS ONCE, then the workgroup sweeps all column blocks streaming only the 16 KB W tiles (L2-resident).
-// The per-column-block version re-read and re-transformed A once per column block.
-template <int PRO>
-__global__ __launch_bounds__(256) void gemm_rowpanel64_kernel(GemmArgs g) {
-  constexpr int BM = 128, BN = 64, K = 64, SA = K + 4;
-  __shared__ __attribute__((aligned(16))) float As[BM * SA];
-  __shared__ __attribute__((aligned(16))) float Bs[BN * SA];
-  __shared__ float red[4 * 64 * 2];
-  const se_gemm_desc& d = g.d;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z;
-  const int Mb = d.To * d.Fo;
-  const int m0 = blockIdx.x * BM;
-  const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
-  const int q = tid & 15, r0 = tid >> 4;           // float4 column (16 per row), row within a 16-row pass
-  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
-  const float inv_keep = 1.0f / (1.0f - d.drop_p);
-  const float* __restrict__ Ab = g.A + (long)b * Mb * d.lda + d.a_off;
-  const float* __restrict__ Wb = g.W;
-  // ---- A panel: 8 passes of 16 rows
-  {
-    float4 ra[8];
-    bool ok[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int m = m0 + r0 + 16 * i;
-      ok[i] = m < Mb;
-      ra[i] = ok[i] ? *reinterpret_cast<const float4*>(Ab + ((unsigned)m * (unsigned)d.lda + (unsigned)(q * 4)))
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float4 v = ra[i];
-      if (PRO != SE_PRO_NONE && ok[i]) {
-        int m = m0 + r0 + 16 * i;
-        float mean = 0.f, rstd = 0.f;
-        if (PRO == SE_PRO_LN) { const float* rs = g.rowstats + ((long)b * Mb + m) * 2; mean = rs[0]; rstd = rs[1]; }
-        v = apply_pro<PRO>(v, q * 4, K, mean, rstd, g.ps, g.pb, (unsigned)(b * Mb + m), d.pro_seed, thr, inv_keep);
-      }
-      *reinterpret_cast<float4*>(&As[(r0 + 16 * i) * SA + q * 4]) = v;
-    }
-  }
-  const int ncb = g.ncb;
-  float4 rb[4];
-  auto load_w = [&](int cb) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int j = r0 + 16 * i;
-      int n; bool ok;
-      if (glu) { n = (j >> 5) * (d.N / 2) + cb * 32 + (j & 31); ok = (cb * 32 + (j & 31)) < d.N / 2; }
-      else { n = cb * 64 + j; ok = n < d.N; }
-      rb[i] = ok ? *reinterpret_cast<const float4*>(Wb + ((unsigned)n * (unsigned)d.ldw + (unsigned)(q * 4)))
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  load_w(0);
-  for (int cb = 0; cb < ncb; ++cb) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[(r0 + 16 * i) * SA + q * 4]) = rb[i];
-    __syncthreads();
-    if (cb + 1 < ncb) load_w(cb + 1);
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {            // two 32-wide K chunks, lane half h supplies k in [32ch+16h, +16)
-      const float* Ap = &As[(wave * 32 + (lane & 31)) * SA + 32 * ch + (lane >> 5) * 16];
-      const float* Bp0 = &Bs[(lane & 31) * SA + 32 * ch + (lane >> 5) * 16];
-      const float* Bp1 = Bp0 + 32 * SA;
-#pragma unroll
-      for (int s4 = 0; s4 < 16; s4 += 4) {
-        float4 a = *reinterpret_cast<const float4*>(Ap + s4);
-        float4 b0 = *reinterpret_cast<const float4*>(Bp0 + s4);
-        float4 b1 = *reinterpret_cast<const float4*>(Bp1 + s4);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
-      }
-    }
-    __syncthreads();          // Bs free for the next column block
-    gemm_epilogue(g, acc0, acc1, m0, cb, b, red, thr, inv_keep);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Split-bf16 ("bf16x3") variant for the MFMA-bound layers (the dilated dense convolutions, K = 384..1536):
 // every fp32 operand is split on the fly into hi = bf16(x), lo = bf16(x - hi) and the product is evaluated as
 // a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Each operand is then
@@ -571,9 +498,11 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, by = blockIdx.y;
+  const WorkId wk_ = decode_work(g.ncb, g.nouter, g.contig);
+  if (wk_.outer >= g.nouter) return;
+  const int b = wk_.outer / g.tiles, by = wk_.inner;
   const int Mb = d.To * d.Fo;
-  const int m0 = blockIdx.x * BM;
+  const int m0 = (wk_.outer - b * g.tiles) * BM;
   const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
   const int kq = tid % KQ, r0 = tid / KQ;
   const bool lin = d.ntap == 1 && !d.up && d.st == 1 && d.sf == 1 && d.dt[0] == 0 && d.df[0] == 0 &&
@@ -621,8 +550,9 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   const float inv_keep = 1.0f / (1.0f - d.drop_p);
 
   auto load_tiles = [&](int it) {
-    int tap = it / nchunk;
-    int c0 = (it - tap * nchunk) * BK;
+    int chunk = it / d.ntap;             // channel chunk outer, tap inner: the taps of one chunk re-touch the same
+    int tap = it - chunk * d.ntap;       // 128-B lines (df = -1, 0, 1) while they are still in L1 / L2
+    int c0 = chunk * BK;
     int c = c0 + kq * 4;
     cur_c = c;
     bool cok = c < d.C;
@@ -694,6 +624,7 @@ struct WgradArgs {
   const float* A; const float* dY; float* dW; float* dbias;
   const float* rowstats; const float* ps; const float* pb;
   long rows_per_chunk;
+  int nchunks;
 };
 
 template <int PRO>
@@ -705,7 +636,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncb = (d.C + 63) / 64;
-  const int chunk = blockIdx.x, tc = blockIdx.y, nb = blockIdx.z;
+  // siblings = the (tap, channel block, n block) workgroups of one row chunk: same XCD, adjacent in dispatch order,
+  // so the dY / A rows they share come out of that XCD's L2
+  const int nnb = (d.N + 63) / 64;
+  const WorkId wk_ = decode_work(d.ntap * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
   const int tap = tc / ncb, cb = tc - tap * ncb;
   const int Mb = d.To * d.Fo;
   const long Mtot = (long)d.B * Mb;
@@ -866,36 +802,16 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
   if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");
-  GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats, 0};
+  GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats, 0, 0, 0, 0};
   const int Mb = d->To * d->Fo;
   const int ncols = (ep & SE_EPI_GLU) ? cdiv(d->N / 2, 32) : cdiv(d->N, 64);
-  dim3 grid(cdiv(Mb, 128), ncols, d->B), block(256);
   g.ncb = ncols;
+  g.tiles = cdiv(Mb, 128);
+  g.nouter = d->B * g.tiles;
+  g.contig = d->ntap > 1;
+  if (const char* e = getenv("SE_GEMM_CONTIG")) g.contig = atoi(e);
+  dim3 grid((unsigned)(ncols * (((long)g.nouter + 7) / 8 * 8))), block(256);
   hipStream_t s = as_stream(stream);
-  // K slab per LDS stage: 64 floats when the channel run allows it (half the barriers, all of a K=64 layer in
-  // flight at once), 16 for the tiny-channel convolutions, else 32.  SE_GEMM_BK overrides (profiling).
-  {
-    const bool lin = d->ntap == 1 && !d->up && d->st == 1 && d->sf == 1 && d->dt[0] == 0 && d->df[0] == 0 &&
-                     d->Ti == d->To && d->Fi == d->Fo;
-    // measured: slower than the per-column-block kernel (4x fewer workgroups in flight -> less memory-level
-    // parallelism); kept behind SE_GEMM_PANEL=1 for experiments
-    static const bool no_panel = getenv("SE_GEMM_PANEL") == nullptr;
-    if (lin && d->C == 64 && ncols >= 2 && d->precision == 0 && !(ep & SE_EPI_STATS) && !no_panel) {
-      dim3 pgrid(cdiv(Mb, 128), 1, d->B);
-#define LAUNCHP(PRO) hipLaunchKernelGGL((gemm_rowpanel64_kernel<PRO>), pgrid, block, 0, s, g)
-      switch (d->prologue) {
-        case SE_PRO_NONE: LAUNCHP(SE_PRO_NONE); break;
-        case SE_PRO_LN: LAUNCHP(SE_PRO_LN); break;
-        case SE_PRO_SWISH: LAUNCHP(SE_PRO_SWISH); break;
-        case SE_PRO_AFFINE_SWISH: LAUNCHP(SE_PRO_AFFINE_SWISH); break;
-        case SE_PRO_SWISH_DROP: LAUNCHP(SE_PRO_SWISH_DROP); break;
-        case SE_PRO_DROP: LAUNCHP(SE_PRO_DROP); break;
-        default: return se_fail("gemm: unknown prologue %d", d->prologue);
-      }
-#undef LAUNCHP
-      return se_check_launch("se_gemm_tap(rowpanel)");
-    }
-  }
   if ((d->precision == 1 || d->precision == 2) && d->C >= 32) {      // split-bf16 paths (BK = 32 only)
 #define LAUNCHB(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 2>), grid, block, 0, s, g); \
                           else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 3>), grid, block, 0, s, g); } while (0)
@@ -942,8 +858,8 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
   long rpc = (Mtot + chunks - 1) / chunks;
   rpc = ((rpc + 63) / 64) * 64;
   chunks = (int)((Mtot + rpc - 1) / rpc);
-  WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc};
-  dim3 grid(chunks, d->ntap * cdiv(d->C, 64), cdiv(d->N, 64)), block(256);
+  WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc, chunks};
+  dim3 grid((unsigned)((long)d->ntap * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8))), block(256);
   hipStream_t s = as_stream(stream);
   switch (d->prologue) {
     case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_NONE>), grid, block, 0, s, g); break;

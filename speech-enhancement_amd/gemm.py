@@ -31,8 +31,12 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
     return d
 
 
+LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'f32')]
+
+
 def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
     """plain row GEMM: M rows, one tap."""
+    kw.setdefault('precision', LINEAR_PRECISION)
     return make_desc(1, 1, M, 1, M, [(0, 0)], C_in, lda or C_in, N, ldc or N, **kw)
 
 
