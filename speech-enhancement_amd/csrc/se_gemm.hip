@@ -77,19 +77,22 @@ static __device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, 
   return x >= thr ? inv_keep : 0.f;
 }
 
+// ps4 / pb4: the per-channel scale / shift of this float4's 4 channels (LN gamma / beta, BN-affine), fetched with the
+// tile as two 16-B loads -- per-element scalar loads here cost 8 VMEM instructions per float4 of A.
 template <int PRO>
 static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float mean, float rstd,
-                                                   const float* ps, const float* pb, long pix, unsigned seed,
+                                                   float4 ps4, float4 pb4, long pix, unsigned seed,
                                                    unsigned thr, float inv_keep) {
   if (PRO == SE_PRO_NONE) return v;
   float x[4] = {v.x, v.y, v.z, v.w};
+  const float ps[4] = {ps4.x, ps4.y, ps4.z, ps4.w}, pb[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int cc = c + j;
     if (cc < C) {
-      if (PRO == SE_PRO_LN) x[j] = (x[j] - mean) * rstd * ps[cc] + pb[cc];
+      if (PRO == SE_PRO_LN) x[j] = (x[j] - mean) * rstd * ps[j] + pb[j];
       else if (PRO == SE_PRO_SWISH) x[j] = swishf_(x[j]);
-      else if (PRO == SE_PRO_AFFINE_SWISH) x[j] = swishf_(x[j] * ps[cc] + pb[cc]);
+      else if (PRO == SE_PRO_AFFINE_SWISH) x[j] = swishf_(x[j] * ps[j] + pb[j]);
       else if (PRO == SE_PRO_SWISH_DROP) x[j] = swishf_(x[j]) * drop_scale(seed, (unsigned)(pix * C + cc), thr, inv_keep);
       else if (PRO == SE_PRO_DROP) x[j] = x[j] * drop_scale(seed, (unsigned)(pix * C + cc), thr, inv_keep);
     } else {
@@ -98,6 +101,13 @@ static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float
   }
   return make_float4(x[0], x[1], x[2], x[3]);
 }
+template <int PRO>
+static __device__ __forceinline__ void load_pro_vec(const float* ps, const float* pb, int c, bool ok, float4& ps4, float4& pb4) {
+  if (PRO == SE_PRO_LN || PRO == SE_PRO_AFFINE_SWISH) {
+    ps4 = ok ? *reinterpret_cast<const float4*>(ps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    pb4 = ok ? *reinterpret_cast<const float4*>(pb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
 
 // Vectorised epilogue (bias / dropout / swish-gradient / residual / accumulate / plain store): each 32x32 accumulator
 // is transposed through a wave-private LDS patch so that every lane then owns 4 consecutive output columns: the
@@ -105,7 +115,7 @@ static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float
 // lane and tile instead of 16 four-byte ones.  cs: the wave's [32][cs_ld] patch (reuses the A staging tile).
 static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
                                                          int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
-                                                         float inv_keep, float* red = nullptr) {
+                                                         float inv_keep, float* red, const float* bias_s) {
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Mb = d.To * d.Fo, ep = d.epilogue;
@@ -124,8 +134,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
     const int n = by * 64 + nt * 32 + cq * 4;        // first of this lane's 4 output columns
     float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), qsum = ssum;
     if (n < d.N) {                                   // N % 4 == 0 (host-checked)
-      float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ep & SE_EPI_BIAS) bias4 = *reinterpret_cast<const float4*>(g.bias + n);
+      const float4 bias4 = *reinterpret_cast<const float4*>(bias_s + nt * 32 + cq * 4);   // staged before the K loop
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + rr + 8 * i;
@@ -177,6 +186,14 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         atomicAdd(&g.stats[((long)b * d.N + nn) * 2 + 1], (double)q_);
       }
     }
+  }
+}
+// the vector epilogue's bias operands go to LDS before the K loop (its barriers order the hand-off): a global load
+// at the tail of the workgroup would expose one full memory latency per tile
+static __device__ __forceinline__ void stage_bias(const GemmArgs& g, int by, float* bias_s) {
+  if (threadIdx.x < 64) {
+    const int n = by * 64 + threadIdx.x;
+    bias_s[threadIdx.x] = ((g.d.epilogue & SE_EPI_BIAS) && n < g.d.N) ? g.bias[n] : 0.f;
   }
 }
 // GLU flavour of the vectorised epilogue: accumulator 0 = value columns, accumulator 1 = gate columns of the same 32
@@ -337,6 +354,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM * SA];
   __shared__ __attribute__((aligned(16))) float Bs[BN * SA];
   __shared__ float red[4 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
 
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -382,8 +400,9 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int p = rok[i] ? (lin ? rt[i] : src_pixel_in(d, rt[i], rf[i], 0)) : -1;
-      ln_mean[i] = p >= 0 ? rs[2 * p] : 0.f;
-      ln_rstd[i] = p >= 0 ? rs[2 * p + 1] : 0.f;
+      float2 mr = p >= 0 ? *reinterpret_cast<const float2*>(rs + 2 * p) : make_float2(0.f, 0.f);
+      ln_mean[i] = mr.x;
+      ln_rstd[i] = mr.y;
     }
   }
 
@@ -393,6 +412,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   bool aok[NA];
   unsigned apix[NA];
   int cur_c = 0;
+  float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
   const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
   const float inv_keep = 1.0f / (1.0f - d.drop_p);
 
@@ -404,6 +424,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     cur_c = c;
     bool cok = c < d.C;   // C is a multiple of 4
     const unsigned wk = (unsigned)(tap * d.C + c);
+    load_pro_vec<PRO>(g.ps, g.pb, c, cok, ps4, pb4);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int p = (rok[i] && cok) ? (lin ? rt[i] : src_pixel_in(d, rt[i], rf[i], tap)) : -1;
@@ -422,6 +443,8 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  const bool vec_ep = epilogue_vec_ok(d);
+  if (vec_ep) stage_bias(g, by, bias_s);
 
   load_tiles(0);
   const float* Ap = &As[(wave * 32 + (lane & 31)) * SA + (lane >> 5) * (BK / 2)];
@@ -433,7 +456,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     for (int i = 0; i < NA; ++i) {
       float4 v = ra[i];
       if (PRO != SE_PRO_NONE && aok[i])
-        v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], g.ps, g.pb, apix[i], d.pro_seed, thr, inv_keep);
+        v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], ps4, pb4, apix[i], d.pro_seed, thr, inv_keep);
       *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * SA + kq * 4]) = v;
     }
 #pragma unroll
@@ -458,7 +481,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  if (SA >= 36 && epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA, thr, inv_keep, red);
+  if (SA >= 36 && vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA, thr, inv_keep, red, bias_s);
   else if (SA >= 36 && epilogue_glu_vec_ok(d)) gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
@@ -495,6 +518,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) __bf16 Ap[NPL * PA];
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
   __shared__ float red[4 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
 
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -536,8 +560,9 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int p = rok[i] ? (lin ? rt[i] : src_pixel_in(d, rt[i], rf[i], 0)) : -1;
-      ln_mean[i] = p >= 0 ? rs[2 * p] : 0.f;
-      ln_rstd[i] = p >= 0 ? rs[2 * p + 1] : 0.f;
+      float2 mr = p >= 0 ? *reinterpret_cast<const float2*>(rs + 2 * p) : make_float2(0.f, 0.f);
+      ln_mean[i] = mr.x;
+      ln_rstd[i] = mr.y;
     }
   }
   const int nchunk = (d.C + BK - 1) / BK;
@@ -546,6 +571,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   bool aok[NA];
   unsigned apix[NA];
   int cur_c = 0;
+  float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
   const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
   const float inv_keep = 1.0f / (1.0f - d.drop_p);
 
@@ -557,6 +583,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     cur_c = c;
     bool cok = c < d.C;
     const unsigned wk = (unsigned)(tap * d.C + c);
+    load_pro_vec<PRO>(g.ps, g.pb, c, cok, ps4, pb4);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       int p = (rok[i] && cok) ? (lin ? rt[i] : src_pixel_in(d, rt[i], rf[i], tap)) : -1;
@@ -573,6 +600,8 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   f32x16 acc0, acc1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  const bool vec_ep = epilogue_vec_ok(d);
+  if (vec_ep) stage_bias(g, by, bias_s);
   load_tiles(0);
   // operand fragments: lane (r = lane & 31, h = lane >> 5) holds k = 16 ks + 8 h .. + 7 of row r (16 contiguous bytes)
   const int frag = (lane & 31) * SA + 8 * (lane >> 5);
@@ -581,7 +610,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     for (int i = 0; i < NA; ++i) {
       float4 v = ra[i];
       if (PRO != SE_PRO_NONE && aok[i])
-        v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], g.ps, g.pb, apix[i], d.pro_seed, thr, inv_keep);
+        v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], ps4, pb4, apix[i], d.pro_seed, thr, inv_keep);
       split_store<NPL>(v, &Ap[(r0 + i * RPP) * SA + kq * 4], PA);
     }
 #pragma unroll
@@ -612,7 +641,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     __syncthreads();
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;        // the staging planes are free now
-  if (epilogue_vec_ok(d)) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red);
+  if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
 
@@ -700,19 +729,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
       xpix[i] = (unsigned)p;
       rx[i] = xok[i] ? *reinterpret_cast<const float4*>(Ag + p * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (PRO == SE_PRO_LN) {
-        mean[i] = xok[i] ? g.rowstats[2 * p] : 0.f;
-        rstd[i] = xok[i] ? g.rowstats[2 * p + 1] : 0.f;
+        float2 mr = xok[i] ? *reinterpret_cast<const float2*>(g.rowstats + 2 * p) : make_float2(0.f, 0.f);
+        mean[i] = mr.x;
+        rstd[i] = mr.y;
       }
     }
   };
 
+  float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
+  load_pro_vec<PRO>(g.ps, g.pb, c_ld, cok, ps4, pb4);      // this thread's 4 channels never change
   if (mbeg < mend) load_tiles(mbeg);
   for (long mb = mbeg; mb < mend; mb += MR) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float4 v = rx[i];
       if (PRO != SE_PRO_NONE && xok[i])
-        v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], g.ps, g.pb, xpix[i], d.pro_seed, thr, inv_keep);
+        v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], ps4, pb4, xpix[i], d.pro_seed, thr, inv_keep);
       *reinterpret_cast<float4*>(&Xs[(r0 + i * 16) * SY + q * 4]) = v;
       *reinterpret_cast<float4*>(&Ys[(r0 + i * 16) * SY + q * 4]) = ry[i];
     }
