@@ -703,19 +703,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
   const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
   const float inv_keep = 1.0f / (1.0f - d.drop_p);
   const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
+  // (batch entry, t, f) of this thread's 4 rows, advanced by MR rows per step with adds and compares: the two
+  // divisions per row and step they replace (one of them 64-bit) cost more VALU issue slots than the step's MFMAs
+  int cb_[4], ct_[4], cf_[4];
+  const int adv_t = MR / d.Fo, adv_f = MR - adv_t * d.Fo;
+  if (!lin) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long mg = mbeg + r0 + i * 16;
+      cb_[i] = (int)(mg / Mb);
+      int m = (int)(mg - (long)cb_[i] * Mb);
+      ct_[i] = m / d.Fo;
+      cf_[i] = m - ct_[i] * d.Fo;
+    }
+  }
   auto load_tiles = [&](long mbase) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       long mg = mbase + r0 + i * 16;
       bool ok = mg < mend;
       long p = -1;
-      if (ok && cok) {
-        if (lin) p = mg;
-        else {
-          int b = (int)(mg / Mb); int m = (int)(mg - (long)b * Mb); int t = m / d.Fo, f = m - t * d.Fo;
-          int pin = src_pixel_in(d, t, f, tap);
-          p = pin >= 0 ? (long)b * TiFi + pin : -1;
+      if (lin) { if (ok && cok) p = mg; }
+      else {
+        if (ok && cok) {
+          int pin = src_pixel_in(d, ct_[i], cf_[i], tap);
+          p = pin >= 0 ? (long)cb_[i] * TiFi + pin : -1;
         }
+        cf_[i] += adv_f; ct_[i] += adv_t;
+        if (cf_[i] >= d.Fo) { cf_[i] -= d.Fo; ct_[i] += 1; }
+        while (ct_[i] >= d.To) { ct_[i] -= d.To; cb_[i] += 1; }
       }
       ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (dy_drop && ok && nok) {

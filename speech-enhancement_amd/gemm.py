@@ -56,7 +56,11 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
     if chunks is None:
         M = d.B * d.To * d.Fo
         nblk = d.ntap * ((d.C + 63) // 64) * ((d.N + 63) // 64)
-        chunks = max(1, min((M + 255) // 256, (2048 + nblk - 1) // nblk))
+        # 4 workgroups are resident per CU (LDS-bound): aim at a whole number of 1024-workgroup rounds -- a partial
+        # last round costs a full one (2112 workgroups ran as 3 rounds, not 2.06) -- and at >= 4 rounds when the
+        # rows allow it, so that the unequal start times of the first round even out
+        rounds = 4 if M * nblk >= 4 * 1024 * 1024 else 2
+        chunks = max(1, min((M + 255) // 256, (rounds * 1024) // nblk))
     Mt = d.B * d.To * d.Fo
     L.call('se_gemm_tap_wgrad', C.byref(d), L.ptr(A), L.ptr(dY), L.ptr(dW), L.ptr(dbias), L.ptr(rowstats),
            L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream(), _key=f'wgrad_kernel<{d.prologue}>',
