@@ -789,6 +789,183 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-bf16 weight gradient (precision 1 / 2, same operand splits as gemm_tap_bf16x3_kernel).  The contraction index
+// of dW = dY^T X is the ROW index m, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane: both tiles are
+// therefore staged TRANSPOSED in LDS ([column][m], m contiguous).  Every thread owns a 4 (rows) x 4 (columns) block:
+// four 16-B global loads (one per row, 16 lanes = one 256-B row segment), a register transpose, and per column one
+// 8-B store of 4 consecutive m per plane.  LDS rows are laid out in 16-B cells, cell(r, ch) = 9 r + (r >> 4) + ch:
+// the 16-lane groups of both the fragment reads (16 consecutive rows, same ch) and the transposed stores (rows 4 l + j)
+// then touch 16 distinct bank groups -- conflict-free (searched exhaustively; plain padding gives 4-way write conflicts).
+template <int PRO, int NPL>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
+  constexpr int MR = 64;
+  constexpr int PLN = (9 * 64 + 4) * 8;          // bf16 elements of one [64 columns][64 m] plane
+  __shared__ __attribute__((aligned(16))) __bf16 Yt[NPL * PLN];
+  __shared__ __attribute__((aligned(16))) __bf16 Xt[NPL * PLN];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64;
+  const int nnb = (d.N + 63) / 64;
+  const WorkId wk_ = decode_work(d.ntap * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int tap = tc / ncb, cb = tc - tap * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, rg = tid >> 4;        // float4 column / group of 4 consecutive tile rows
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  const bool lin = d.ntap == 1 && !d.up && d.st == 1 && d.sf == 1 && d.dt[0] == 0 && d.df[0] == 0 &&
+                   d.Ti == d.To && d.Fi == d.Fo;
+  const int TiFi = d.Ti * d.Fi;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int n_ld = nb * 64 + q * 4, c_ld = cb * 64 + q * 4;
+  const bool nok = n_ld < d.N, cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+
+  // two register sets: the loads of step s + 2 are in flight while steps s and s + 1 run (one step of MFMAs is shorter
+  // than a memory round trip and only 2 workgroups fit per CU, so a single-step prefetch left the latency exposed)
+  struct Regs { float4 ry[4], rx[4]; float mean[4], rstd[4]; bool xok[4]; unsigned xpix[4]; };
+  Regs R0, R1;
+  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
+  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
+  int cb_[4], ct_[4], cf_[4];
+  const int adv_t = MR / d.Fo, adv_f = MR - adv_t * d.Fo;
+  if (!lin) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long mg = mbeg + rg * 4 + i;
+      cb_[i] = (int)(mg / Mb);
+      int m = (int)(mg - (long)cb_[i] * Mb);
+      ct_[i] = m / d.Fo;
+      cf_[i] = m - ct_[i] * d.Fo;
+    }
+  }
+  auto load_tiles = [&](long mbase, Regs& R) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long mg = mbase + rg * 4 + i;
+      bool ok = mg < mend;
+      long p = -1;
+      if (lin) { if (ok && cok) p = mg; }
+      else {
+        if (ok && cok) {
+          int pin = src_pixel_in(d, ct_[i], cf_[i], tap);
+          p = pin >= 0 ? (long)cb_[i] * TiFi + pin : -1;
+        }
+        cf_[i] += adv_f; ct_[i] += adv_t;
+        if (cf_[i] >= d.Fo) { cf_[i] -= d.Fo; ct_[i] += 1; }
+        while (ct_[i] >= d.To) { ct_[i] -= d.To; cb_[i] += 1; }
+      }
+      R.ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy_drop && ok && nok) {
+        unsigned base = (unsigned)(mg * d.N + n_ld);
+        R.ry[i].x *= drop_scale(d.epi_seed, base, thr, inv_keep);
+        R.ry[i].y *= drop_scale(d.epi_seed, base + 1, thr, inv_keep);
+        R.ry[i].z *= drop_scale(d.epi_seed, base + 2, thr, inv_keep);
+        R.ry[i].w *= drop_scale(d.epi_seed, base + 3, thr, inv_keep);
+      }
+      R.xok[i] = p >= 0;
+      R.xpix[i] = (unsigned)p;
+      R.rx[i] = R.xok[i] ? *reinterpret_cast<const float4*>(Ag + p * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO == SE_PRO_LN) {
+        float2 mr = R.xok[i] ? *reinterpret_cast<const float2*>(g.rowstats + 2 * p) : make_float2(0.f, 0.f);
+        R.mean[i] = mr.x;
+        R.rstd[i] = mr.y;
+      }
+    }
+  };
+  // register transpose + split + store of one thread block: v[i] = row 4 rg + i, columns 4 q .. 4 q + 3
+  auto stage_t = [&](const float4 (&v)[4], __bf16* T) {
+    const float x[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      __bf16* dst = T + (9 * r + (r >> 4)) * 8 + 4 * rg;
+      float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h[i] = (__bf16)e[i]; e[i] -= (float)h[i]; }
+        *reinterpret_cast<bf16x4*>(dst + pl * PLN) = h;
+      }
+    }
+  };
+
+  float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
+  load_pro_vec<PRO>(g.ps, g.pb, c_ld, cok, ps4, pb4);
+  if (mbeg < mend) load_tiles(mbeg, R0);
+  if (mbeg + MR < mend) load_tiles(mbeg + MR, R1); else R1 = R0;
+  const int ra_ = wn * 32 + (lane & 31), rb_ = wc * 32 + (lane & 31);
+  const __bf16* yfrag = Yt + (9 * ra_ + (ra_ >> 4)) * 8 + 8 * (lane >> 5);
+  const __bf16* xfrag = Xt + (9 * rb_ + (rb_ >> 4)) * 8 + 8 * (lane >> 5);
+  auto step = [&](long mb, Regs& R) {
+    if (PRO != SE_PRO_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (R.xok[i]) R.rx[i] = apply_pro<PRO>(R.rx[i], c_ld, d.C, R.mean[i], R.rstd[i], ps4, pb4, R.xpix[i], d.pro_seed, thr, inv_keep);
+    }
+    stage_t(R.rx, Xt);
+    stage_t(R.ry, Yt);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bsum.x += R.ry[i].x; bsum.y += R.ry[i].y; bsum.z += R.ry[i].z; bsum.w += R.ry[i].w; }
+    }
+    __syncthreads();
+    if (mb + 2 * MR < mend) load_tiles(mb + 2 * MR, R);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[NPL], bf[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        af[pl] = *reinterpret_cast<const bf16x8*>(yfrag + pl * PLN + 16 * ks);
+        bf[pl] = *reinterpret_cast<const bf16x8*>(xfrag + pl * PLN + 16 * ks);
+      }
+#pragma unroll
+      for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf[ord - qa], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (long mb = mbeg; mb < mend; mb += 2 * MR) {
+    step(mb, R0);
+    if (mb + MR < mend) step(mb + MR, R1);
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[r]);
+  }
+  if (do_bias) {       // column sums of dY: fold the 16 row groups through LDS (the tiles are free now)
+    float* red = reinterpret_cast<float*>(Yt);
+    *reinterpret_cast<float4*>(&red[rg * 64 + 4 * q]) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_ += red[r * 64 + tid];
+      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], s_);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void repack_kernel(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt,
                               long si, int rev, int accumulate) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -909,6 +1086,21 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
   WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc, chunks};
   dim3 grid((unsigned)((long)d->ntap * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8))), block(256);
   hipStream_t s = as_stream(stream);
+  if (d->precision == 1 || d->precision == 2) {
+#define LAUNCHWB(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 2>), grid, block, 0, s, g); \
+                           else hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 3>), grid, block, 0, s, g); } while (0)
+    switch (d->prologue) {
+      case SE_PRO_NONE: LAUNCHWB(SE_PRO_NONE); break;
+      case SE_PRO_LN: LAUNCHWB(SE_PRO_LN); break;
+      case SE_PRO_SWISH: LAUNCHWB(SE_PRO_SWISH); break;
+      case SE_PRO_AFFINE_SWISH: LAUNCHWB(SE_PRO_AFFINE_SWISH); break;
+      case SE_PRO_SWISH_DROP: LAUNCHWB(SE_PRO_SWISH_DROP); break;
+      case SE_PRO_DROP: LAUNCHWB(SE_PRO_DROP); break;
+      default: return se_fail("wgrad: unknown prologue %d", d->prologue);
+    }
+#undef LAUNCHWB
+    return se_check_launch("se_gemm_tap_wgrad(bf16)");
+  }
   switch (d->prologue) {
     case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_NONE>), grid, block, 0, s, g); break;
     case SE_PRO_LN: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_LN>), grid, block, 0, s, g); break;

@@ -23,9 +23,16 @@ import os as _os
 CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_CONV_PRECISION', 'bf16x6')]
 
 
-def set_conv_precision(name):
+# weight-gradient GEMMs of the same convolutions (contraction over pixels; same operand splits, transposed staging).
+# Default f32: measured on the dense-layer shapes the six-product kernel is VALU-bound by its own splits (77 TF vs 83
+# for fp32 MFMA); the three-product one reaches 116 TF and stays opt-in like the forward's.
+WGRAD_PRECISION = [{'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_WGRAD_PRECISION', 'f32')]]
+
+
+def set_conv_precision(name, wgrad=None):
     global CONV_PRECISION
     CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[name]
+    WGRAD_PRECISION[0] = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[wgrad or ('bf16x3' if name == 'bf16x3' else 'f32')]
 
 
 class DPHooks:
@@ -86,7 +93,7 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     gradient into dx[..., dx_off:dx_off+C_in] (pixel stride lddx)."""
     N = dR.shape[-1]
     ntap = len(taps)
-    fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf)
+    fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf, precision=WGRAD_PRECISION[0])
     dwp = torch.zeros(N, ntap * C_in, device=dR.device, dtype=torch.float32)
     GM.gemm_tap_wgrad(fd, x, dR, dwp, dbias)
     _unpack_w(dwp, dw, C_in, rev)

@@ -293,3 +293,28 @@ def test_split_bf16_precision_mode(G):
     dx = torch.empty(B, T, Fq, 256, device='cuda')
     gemm.gemm_tap(dd, dy, wd, dx)
     assert relerr(dx, x64.grad) < 1e-4
+    # weight / bias gradient through the transposed-staging split-bf16 kernel (all three modes), LN-prologue linear too
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    F.conv2d(F.pad(x, (1, 1, 8, 0)), w64, b64, dilation=(8, 1)).permute(0, 2, 3, 1).backward(dy.double())
+    for prec, tol in ((0, 3e-6), (1, 1e-4), (2, 3e-6)):
+        fd = gemm.make_desc(B, T, Fq, T, Fq, taps, 256, 256, 64, 64, precision=prec)
+        dwp = torch.zeros(64, len(taps) * 256, device='cuda')
+        db = torch.zeros(64, device='cuda')
+        gemm.gemm_tap_wgrad(fd, xbuf, dy, dwp, db, chunks=5)
+        dw = torch.zeros_like(w)
+        gemm.unpack_conv_wgrad(dwp, dw)
+        assert relerr(dw, w64.grad) < tol, (prec, relerr(dw, w64.grad))
+        assert relerr(db, b64.grad) < 1e-5, prec
+    M = 1000
+    xl = rnd(M, 64, seed=11)
+    dyl = rnd(M, 192, seed=12)
+    gam, bet = rnd(64, seed=13), rnd(64, seed=14)
+    xn = F.layer_norm(xl.double(), (64,), gam.double(), bet.double())
+    refw = dyl.double().t() @ xn
+    st = torch.stack([xl.mean(-1), (xl.var(-1, unbiased=False) + 1e-5).rsqrt()], -1).contiguous()
+    for prec, tol in ((0, 3e-6), (1, 1e-4), (2, 3e-6)):
+        dl = gemm.linear_desc(M, 64, 192, prologue=L.PRO_LN, precision=prec)
+        dwl = torch.zeros(192, 64, device='cuda')
+        gemm.gemm_tap_wgrad(dl, xl, dyl, dwl, None, rowstats=st, ps=gam, pb=bet, chunks=3)
+        assert relerr(dwl, refw) < tol, (prec, relerr(dwl, refw))

@@ -10,7 +10,7 @@ skip = torch.randn(B, T, Fq, 256, device='cuda')
 dR = torch.randn(B, T, Fq, 64, device='cuda')
 taps = LY.dense_taps(3)
 if mode == 'wgrad':
-    d = GM.make_desc(B, T, Fq, T, Fq, taps, Cin, 256, 64, 64)
+    d = GM.make_desc(B, T, Fq, T, Fq, taps, Cin, 256, 64, 64, precision=prec)
     dwp = torch.zeros(64, len(taps) * Cin, device='cuda')
     ch = int(os.environ['CHUNKS']) if 'CHUNKS' in os.environ else None
     f = lambda: GM.gemm_tap_wgrad(d, skip, dR, dwp, None, chunks=ch)
