@@ -644,6 +644,114 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Row-panel kernel for the token-wise layers with K = 64 and N >= 128 (LN -> 256 / 192 / GLU-256, dY(64) -> 256), split
+// bf16.  The per-column-block kernel above is issue-bound on these shapes: every one of the N/64 sibling workgroups
+// re-loads, re-normalises and re-splits the same A rows and pays the same ~700 VALU instructions of set-up per wave for
+// 64 MFMAs.  Here one workgroup owns 128 rows and sweeps ALL column blocks: each wave loads its 32 rows straight into
+// the MFMA A-fragment layout (lane = row, 8 consecutive k), applies the prologue and the bf16 split ONCE and keeps the
+// fragments in 16 * NPL VGPRs; only the 64 x 64 weight blocks stream through LDS (next block prefetched in registers).
+template <int PRO, int NPL>
+__global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
+  constexpr int SB = 72, PB = 64 * SB;         // 64 + 8 bf16 per W row: 144-B stride, conflict-free b128 fragment reads
+  __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 36];
+  __shared__ float red[4 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Mb = d.To * d.Fo;                  // row GEMM: B == 1
+  const int m0 = blockIdx.x * 128;
+  const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
+  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
+  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+
+  // ---- A fragments: row = lane & 31 of this wave's 32 rows, k = 16 ks + 8 (lane >> 5) .. + 7
+  const int row = m0 + wave * 32 + (lane & 31), kg = lane >> 5;
+  const bool rok = row < Mb;
+  bf16x8 af[4][NPL];
+  {
+    const float* __restrict__ ap = g.A + (long)row * d.lda + d.a_off + 8 * kg;
+    float mean = 0.f, rstd = 0.f;
+    if (PRO == SE_PRO_LN && rok) { float2 mr = *reinterpret_cast<const float2*>(g.rowstats + 2 * (long)row); mean = mr.x; rstd = mr.y; }
+    float4 v[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v[ks][0] = rok ? *reinterpret_cast<const float4*>(ap + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[ks][1] = rok ? *reinterpret_cast<const float4*>(ap + 16 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * ks + 8 * kg + 4 * h;
+        float4 w = v[ks][h];
+        if (PRO != SE_PRO_NONE && rok) {
+          float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
+          load_pro_vec<PRO>(g.ps, g.pb, c, true, ps4, pb4);
+          w = apply_pro<PRO>(w, c, 64, mean, rstd, ps4, pb4, (unsigned)row, d.pro_seed, thr, inv_keep);
+        }
+        x[4 * h] = w.x; x[4 * h + 1] = w.y; x[4 * h + 2] = w.z; x[4 * h + 3] = w.w;
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+        af[ks][pl] = hh;
+      }
+    }
+  }
+  // ---- W blocks: 64 rows x 64 k, 4 float4 per thread
+  const int kq = tid & 15, r0 = tid >> 4;
+  const int ncb = g.ncb;
+  float4 rb[4];
+  auto load_w = [&](int by) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = r0 + 16 * i;
+      int n; bool ok;
+      if (glu) { n = (j >> 5) * (d.N / 2) + by * 32 + (j & 31); ok = (by * 32 + (j & 31)) < d.N / 2; }
+      else { n = by * 64 + j; ok = n < d.N; }
+      rb[i] = ok ? *reinterpret_cast<const float4*>(g.W + (unsigned)n * (unsigned)d.ldw + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_w(0);
+  const bool vec_ep = epilogue_vec_ok(d);
+  const int frag = (lane & 31) * SB + 8 * (lane >> 5);
+  float* cs = patch + wave * 32 * 36;
+  for (int by = 0; by < ncb; ++by) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 16 * i) * SB + kq * 4], PB);
+    if (vec_ep) stage_bias(g, by, bias_s);
+    __syncthreads();
+    if (by + 1 < ncb) load_w(by + 1);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 bf0[NPL], bf1[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf0[pl] = *reinterpret_cast<const bf16x8*>(&Bp[pl * PB + frag + 16 * ks]);
+        bf1[pl] = *reinterpret_cast<const bf16x8*>(&Bp[pl * PB + 32 * SB + frag + 16 * ks]);
+      }
+#pragma unroll
+      for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+        }
+    }
+    if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, red, bias_s);
+    else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, 0, cs, 36);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient:  dW[n][tap*C + c] += sum_m dY[m][n] * pro(A[src(m,tap)][c])
 // grid: (row chunks, ntap * ceil(C/64), ceil(N/64)); 4 waves = 2x2 tiles of 32(n) x 32(c).
 struct WgradArgs {
@@ -1037,6 +1145,31 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   const bool lin = d->ntap == 1 && !d->up && d->st == 1 && d->sf == 1 && d->dt[0] == 0 && d->df[0] == 0 &&
                    d->Ti == d->To && d->Fi == d->Fo;
   hipStream_t s = as_stream(stream);
+  {
+    const bool vec_ok = !(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | SE_EPI_STATS | 256)) && (d->N & 3) == 0 && (d->ldc & 3) == 0 &&
+                        (d->c_off & 3) == 0 && (d->ldx & 3) == 0 && (d->x_off & 3) == 0 && (d->ldr & 3) == 0 && (d->r_off & 3) == 0;
+    const bool glu_ok = (ep & SE_EPI_GLU) && !(ep & (SE_EPI_STATS | SE_EPI_SHUFFLE2 | SE_EPI_DROP | SE_EPI_RESID | SE_EPI_ACCUM |
+                                                       SE_EPI_SWISH_GRAD | 256)) &&
+                        (d->N & 7) == 0 && (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldx & 3) == 0 && (d->x_off & 3) == 0;
+    static const bool no_panel = getenv("SE_GEMM_NO_PANEL") != nullptr;
+    if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && (d->precision == 1 || d->precision == 2) && (vec_ok || glu_ok) &&
+        !(ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ACCUM)) && !no_panel) {   // second-operand epilogues: latency-exposed here
+      dim3 pgrid(g.tiles);
+#define LAUNCHP(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2>), pgrid, block, 0, s, g); \
+                          else hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3>), pgrid, block, 0, s, g); } while (0)
+      switch (d->prologue) {
+        case SE_PRO_NONE: LAUNCHP(SE_PRO_NONE); break;
+        case SE_PRO_LN: LAUNCHP(SE_PRO_LN); break;
+        case SE_PRO_SWISH: LAUNCHP(SE_PRO_SWISH); break;
+        case SE_PRO_AFFINE_SWISH: LAUNCHP(SE_PRO_AFFINE_SWISH); break;
+        case SE_PRO_SWISH_DROP: LAUNCHP(SE_PRO_SWISH_DROP); break;
+        case SE_PRO_DROP: LAUNCHP(SE_PRO_DROP); break;
+        default: return se_fail("gemm: unknown prologue %d", d->prologue);
+      }
+#undef LAUNCHP
+      return se_check_launch("se_gemm_tap(k64 panel)");
+    }
+  }
   if ((d->precision == 1 || d->precision == 2) && d->C >= 32) {      // split-bf16 paths (BK = 32 only)
 #define LAUNCHB2(PRO, LIN_) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 2, LIN_>), grid, block, 0, s, g); \
                           else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 3, LIN_>), grid, block, 0, s, g); } while (0)

@@ -31,12 +31,19 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
     return d
 
 
-LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'f32')]
+# Arithmetic of the token-wise K = 64 -> N >= 128 layers (FF in-projection, qkv, pointwise-GLU): 'bf16x6' (default) routes
+# them to the row-panel kernel (exact three-way bf16 split, six MFMAs per product, fp32-equivalent); 'f32' keeps the
+# per-column-block fp32-MFMA kernel; 'bf16x3' is the opt-in two-way split.  Everything else (K > 64, N = 64, epilogues
+# that read a second operand, weight gradients) measured faster on the fp32-MFMA kernels and stays there.
+LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'bf16x6')]
+WGRAD_LINEAR_PRECISION = 0
 
 
 def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
     """plain row GEMM: M rows, one tap."""
-    kw.setdefault('precision', LINEAR_PRECISION)
+    if 'precision' not in kw:
+        second_operand = kw.get('epilogue', 0) & (L.EPI_SWISH_GRAD | L.EPI_RESID | L.EPI_ACCUM)
+        kw['precision'] = LINEAR_PRECISION if (C_in == 64 and N >= 128 and not second_operand) else 0
     return make_desc(1, 1, M, 1, M, [(0, 0)], C_in, lda or C_in, N, ldc or N, **kw)
 
 
@@ -45,13 +52,16 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     M = d.B * d.To * d.Fo
     L.call('se_gemm_tap', C.byref(d), L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Y), L.ptr(R), L.ptr(AUX),
            L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream(),
-           _key=(f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
+           _key=(f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>'
+                 if d.precision in (1, 2) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1
+                 and not d.epilogue & (L.EPI_SWISH_GRAD | L.EPI_RESID | L.EPI_ACCUM | L.EPI_STATS | L.EPI_SHUFFLE2) else
+                 f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
                  f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>'), _flops=2.0 * M * d.N * d.ntap * d.C,
            _bytes=4.0 * M * (d.C + d.N))
     return Y
 
 
-def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, chunks=None):
+def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, chunks=None, explicit_precision=False):
     L.check_cuda(A, dY, dW, dbias, rowstats, ps, pb)
     if chunks is None:
         M = d.B * d.To * d.Fo
@@ -62,6 +72,18 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
         rounds = 4 if M * nblk >= 4 * 1024 * 1024 else 2
         chunks = max(1, min((M + 255) // 256, (rounds * 1024) // nblk))
     Mt = d.B * d.To * d.Fo
+    lin = d.ntap == 1 and d.B == 1 and d.To == 1
+    saved = d.precision
+    if lin and not explicit_precision:
+        d.precision = WGRAD_LINEAR_PRECISION      # the forward descriptor's choice is about the forward kernel only
+    try:
+        _wgrad_call(d, A, dY, dW, dbias, rowstats, ps, pb, chunks, Mt)
+    finally:
+        d.precision = saved
+    return dW
+
+
+def _wgrad_call(d, A, dY, dW, dbias, rowstats, ps, pb, chunks, Mt):
     L.call('se_gemm_tap_wgrad', C.byref(d), L.ptr(A), L.ptr(dY), L.ptr(dW), L.ptr(dbias), L.ptr(rowstats),
            L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream(), _key=f'wgrad_kernel<{d.prologue}>',
            _flops=2.0 * Mt * d.N * d.ntap * d.C, _bytes=4.0 * Mt * (d.C + d.N))

@@ -316,5 +316,5 @@ def test_split_bf16_precision_mode(G):
     for prec, tol in ((0, 3e-6), (1, 1e-4), (2, 3e-6)):
         dl = gemm.linear_desc(M, 64, 192, prologue=L.PRO_LN, precision=prec)
         dwl = torch.zeros(192, 64, device='cuda')
-        gemm.gemm_tap_wgrad(dl, xl, dyl, dwl, None, rowstats=st, ps=gam, pb=bet, chunks=3)
+        gemm.gemm_tap_wgrad(dl, xl, dyl, dwl, None, rowstats=st, ps=gam, pb=bet, chunks=3, explicit_precision=True)
         assert relerr(dwl, refw) < tol, (prec, relerr(dwl, refw))
