@@ -113,9 +113,11 @@ static __device__ __forceinline__ void load_pro_vec(const float* ps, const float
 // is transposed through a wave-private LDS patch so that every lane then owns 4 consecutive output columns: the
 // AUX / R reads and the Y writes are 16-byte accesses (8 lanes = one 128-B row segment) and there are 4 of them per
 // lane and tile instead of 16 four-byte ones.  cs: the wave's [32][cs_ld] patch (reuses the A staging tile).
+template <bool HASPRE = false>
 static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
                                                          int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
-                                                         float inv_keep, float* red, const float* bias_s) {
+                                                         float inv_keep, float* red, const float* bias_s,
+                                                         const float4 (&pre)[8] = {}) {   // pre[nt*4+i]: AUX / R values fetched early
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Mb = d.To * d.Fo, ep = d.epilogue;
@@ -151,11 +153,11 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
           v.z *= drop_scale(d.epi_seed, pe + 2, thr, inv_keep); v.w *= drop_scale(d.epi_seed, pe + 3, thr, inv_keep);
         }
         if (ep & SE_EPI_SWISH_GRAD) {
-          float4 z = *reinterpret_cast<const float4*>(Xb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n));
+          float4 z = HASPRE ? pre[nt * 4 + i] : *reinterpret_cast<const float4*>(Xb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n));
           v.x *= swish_gradf_(z.x); v.y *= swish_gradf_(z.y); v.z *= swish_gradf_(z.z); v.w *= swish_gradf_(z.w);
         }
         if (ep & SE_EPI_RESID) {
-          float4 rv = *reinterpret_cast<const float4*>(Rb + ((unsigned)row * (unsigned)d.ldr + (unsigned)n));
+          float4 rv = HASPRE ? pre[nt * 4 + i] : *reinterpret_cast<const float4*>(Rb + ((unsigned)row * (unsigned)d.ldr + (unsigned)n));
           v.x = rv.x + d.alpha * v.x; v.y = rv.y + d.alpha * v.y; v.z = rv.z + d.alpha * v.z; v.w = rv.w + d.alpha * v.w;
         }
         float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 // 64 MFMAs.  Here one workgroup owns 128 rows and sweeps ALL column blocks: each wave loads its 32 rows straight into
 // the MFMA A-fragment layout (lane = row, 8 consecutive k), applies the prologue and the bf16 split ONCE and keeps the
 // fragments in 16 * NPL VGPRs; only the 64 x 64 weight blocks stream through LDS (next block prefetched in registers).
-template <int PRO, int NPL>
+template <int PRO, int NPL, bool PRE2>
 __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   constexpr int SB = 72, PB = 64 * SB;         // 64 + 8 bf16 per W row: 144-B stride, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
@@ -726,6 +728,21 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
     if (vec_ep) stage_bias(g, by, bias_s);
     __syncthreads();
     if (by + 1 < ncb) load_w(by + 1);
+    // second epilogue operand (pre-activation for the swish gradient, or the residual) of this column block: issued
+    // before the MFMAs -- with 2 waves per SIMD nothing else would cover its latency at the tail
+    float4 pre[8];
+    if (PRE2) {
+      const float* __restrict__ src = (d.epilogue & SE_EPI_SWISH_GRAD) ? g.AUX + (long)m0 * d.ldx + d.x_off : g.R + (long)m0 * d.ldr + d.r_off;
+      const unsigned ld2 = (d.epilogue & SE_EPI_SWISH_GRAD) ? d.ldx : d.ldr;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int prow = wave * 32 + (lane >> 3) + 8 * i, pn = by * 64 + nt * 32 + (lane & 7) * 4;
+          pre[nt * 4 + i] = (m0 + prow < Mb && pn < d.N) ? *reinterpret_cast<const float4*>(src + ((unsigned)prow * ld2 + (unsigned)pn))
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -745,7 +762,7 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
           acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
         }
     }
-    if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, red, bias_s);
+    if (vec_ep) gemm_epilogue_vec<PRE2>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, red, bias_s, pre);
     else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, 0, cs, 36);
     __syncthreads();
   }
@@ -1153,10 +1170,12 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                         (d->N & 7) == 0 && (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldx & 3) == 0 && (d->x_off & 3) == 0;
     static const bool no_panel = getenv("SE_GEMM_NO_PANEL") != nullptr;
     if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && (d->precision == 1 || d->precision == 2) && (vec_ok || glu_ok) &&
-        !(ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ACCUM)) && !no_panel) {   // second-operand epilogues: latency-exposed here
+        !(ep & SE_EPI_ACCUM) && !((ep & SE_EPI_SWISH_GRAD) && (ep & SE_EPI_RESID)) && !no_panel) {
       dim3 pgrid(g.tiles);
-#define LAUNCHP(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2>), pgrid, block, 0, s, g); \
-                          else hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3>), pgrid, block, 0, s, g); } while (0)
+      const bool pre2 = (ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) != 0;
+#define LAUNCHP2(PRO, P2) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2>), pgrid, block, 0, s, g); \
+                          else hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3, P2>), pgrid, block, 0, s, g); } while (0)
+#define LAUNCHP(PRO) do { if (pre2) LAUNCHP2(PRO, true); else LAUNCHP2(PRO, false); } while (0)
       switch (d->prologue) {
         case SE_PRO_NONE: LAUNCHP(SE_PRO_NONE); break;
         case SE_PRO_LN: LAUNCHP(SE_PRO_LN); break;
@@ -1167,6 +1186,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
         default: return se_fail("gemm: unknown prologue %d", d->prologue);
       }
 #undef LAUNCHP
+#undef LAUNCHP2
       return se_check_launch("se_gemm_tap(k64 panel)");
     }
   }

@@ -42,7 +42,7 @@ WGRAD_LINEAR_PRECISION = 0
 def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
     """plain row GEMM: M rows, one tap."""
     if 'precision' not in kw:
-        second_operand = kw.get('epilogue', 0) & (L.EPI_SWISH_GRAD | L.EPI_RESID | L.EPI_ACCUM)
+        second_operand = kw.get('epilogue', 0) & L.EPI_ACCUM
         kw['precision'] = LINEAR_PRECISION if (C_in == 64 and N >= 128 and not second_operand) else 0
     return make_desc(1, 1, M, 1, M, [(0, 0)], C_in, lda or C_in, N, ldc or N, **kw)
 
@@ -54,7 +54,7 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
            L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream(),
            _key=(f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>'
                  if d.precision in (1, 2) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1
-                 and not d.epilogue & (L.EPI_SWISH_GRAD | L.EPI_RESID | L.EPI_ACCUM | L.EPI_STATS | L.EPI_SHUFFLE2) else
+                 and not d.epilogue & (L.EPI_ACCUM | L.EPI_STATS | L.EPI_SHUFFLE2) else
                  f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
                  f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>'), _flops=2.0 * M * d.N * d.ntap * d.C,
            _bytes=4.0 * M * (d.C + d.N))
