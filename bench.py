@@ -22,6 +22,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (== fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
 GFLOP_PER_UTT_STEP = 440.0        # 3 x 145.96 (G fwd+bwd) + ~1.9 (D)
 
@@ -126,21 +127,33 @@ def main():
     roof = None
     if dom is not None:
         k, v = dom
-        ach = v['flops'] / (v['ms'] * 1e-3) / 1e12
-        note = ('algorithmic fp32 FLOPs; peak = fp32 matrix peak (v_mfma_f32_*), the precision the results are '
-                'equivalent to')
-        if 'bf16x6' in k or 'bf16x3' in k:
-            parts = 6 if 'bf16x6' in k else 3
-            note += (f'; this kernel evaluates each product as {parts} bf16 MFMAs (exact hi/mid/lo split, fp32 '
-                     f'accumulate): hardware bf16 MFMA rate = {round(ach * parts, 1)} TFLOP/s = '
-                     f'{round(ach * parts / 2500.0, 3)} of the 2.5 PFLOP/s dense bf16 peak')
-        roof = {'bound': 'mfma', 'kernel': k, 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None, 'note': note,
-                'launches_per_step': v['launches'] // a.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
-                'share_of_step_time': round(v['ms'] / (dt * 1e3), 3),
-                'families': {kk: {'ms_per_step': round(vv['ms'] / a.steps, 3),
-                                  'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)}
-                             for kk, vv in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}}
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(tpath):      # PMC passes are separate rocprofv3 runs; per launch, bytes
+            traffic = json.load(open(tpath)).get('kernels', {}).get(k, {}).get('traffic_bytes_per_launch')
+        if k.startswith('gemm_k64_panel') or k.startswith('dwconv'):
+            ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'kernel': k, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                    'frac': round(ach / 8000.0, 4), 'traffic': traffic,
+                    'note': 'algorithmic bytes (operands read once + result written once) / launch time; peak = HBM3E spec'}
+        else:
+            ach = v['flops'] / (v['ms'] * 1e-3) / 1e12
+            if 'bf16x6' in k or 'bf16x3' in k:
+                parts = 6 if 'bf16x6' in k else 3
+                peak = PEAK_BF16_MFMA_TFLOPS / parts
+                note = (f'algorithmic (fp32-equivalent) FLOPs; the kernel evaluates every product as {parts} bf16 MFMAs '
+                        f'(exact hi/mid/lo operand split, fp32 accumulate), so its peak is the dense bf16 MFMA peak / '
+                        f'{parts} = {round(peak, 1)} TFLOP/s; executed bf16 MFMA rate = {round(ach * parts, 1)} TFLOP/s')
+            else:
+                peak = PEAK_F32_MFMA_TFLOPS
+                note = 'algorithmic fp32 FLOPs; peak = dense fp32 MFMA (v_mfma_f32_*)'
+            roof = {'bound': 'mfma', 'kernel': k, 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': traffic, 'note': note}
+        roof.update({'launches_per_step': v['launches'] // a.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                     'share_of_step_time': round(v['ms'] / (dt * 1e3), 3),
+                     'families': {kk: {'ms_per_step': round(vv['ms'] / a.steps, 3),
+                                       'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)}
+                                  for kk, vv in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}})
     res = {
         'metric': 'utterances/sec (2 s @16 kHz) CMGAN train step', 'value': round(world * B * a.steps / dt, 3),
         'unit': 'utterances/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -148,7 +161,8 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'{a.arch} generator+discriminator train step (main_gan.py train_gan loop body), '
                                f'batch {B}/GPU, 2 s @ 16 kHz, n_fft=400 hop=100, AdamW lr 5e-4, PESQ labels supplied, '
-                               f'kaiming-init weights, conv GEMMs in split-bf16x6 (fp32-equivalent), everything else fp32',
+                               f'kaiming-init weights; fp32 results throughout: conv and K=64 token GEMMs as exact 3-way bf16 splits '
+                               f'(6 MFMAs per product, fp32 accumulate), everything else fp32 MFMA / fp32 VALU',
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'effective_tflops': round(world * B * a.steps * GFLOP_PER_UTT_STEP / dt / 1e3, 2),
                    'dropout': 'generator ff/attn dropout p=0.2 on (counter-based masks in the GEMM pro/epilogues); '

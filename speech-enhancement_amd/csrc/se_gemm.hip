@@ -646,6 +646,130 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-bf16 kernel for the unit-stride convolutions whose taps come in frequency triples (dt, {-1, 0, +1}): the
+// dilated dense layers (2 x 3 taps), the sub-pixel convolutions (1 x 3) and their input gradients -- 90 % of the
+// convolution FLOPs.  The three taps of a triple read the SAME input rows shifted by one pixel, so the A tile is staged
+// once per (channel chunk, dt) as a 130-row halo tile (flattened pixels m0 - 1 .. m0 + 128 of the dt-shifted row
+// range) and the three taps read their MFMA fragments from it at row offsets 0 / 1 / 2: a third of the global loads,
+// bf16 splits and LDS writes of the generic kernel (which is VALU-bound by exactly those).  The frequency padding
+// (f = 0 with df = -1, f = F - 1 with df = +1) wraps to the neighbouring time row in flattened order and is masked per
+// lane on the fragment instead.
+template <int NPL>
+__global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 64, BK = 32, SA = 40, HR = BM + 2;
+  constexpr int PA = HR * SA, PB = BN * SA;
+  __shared__ __attribute__((aligned(16))) __bf16 Ap[NPL * PA];
+  __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
+  __shared__ float red[4 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const WorkId wk_ = decode_work(g.ncb, g.nouter, g.contig);
+  if (wk_.outer >= g.nouter) return;
+  const int b = wk_.outer / g.tiles, by = wk_.inner;
+  const int Mb = d.To * d.Fo;                 // == Ti * Fi (host-checked)
+  const int m0 = (wk_.outer - b * g.tiles) * BM;
+  const int kq = tid & 7, r0 = tid >> 3;      // float4 column of the 32-channel chunk, row within a 32-row pass
+  const float* __restrict__ Ab = g.A + (long)b * Mb * d.lda + d.a_off;
+  const float* __restrict__ Wb = g.W;
+  unsigned wrow[2];
+  bool wok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { int n = by * 64 + r0 + 32 * i; wok[i] = n < d.N; wrow[i] = (unsigned)n * (unsigned)d.ldw; }
+  // frequency-edge masks of this lane's output pixel (fragment row lane & 31 of the wave's 32 rows)
+  const int fpix = (m0 + wave * 32 + (lane & 31)) % d.Fo;
+  const bool edgeL = fpix == 0, edgeR = fpix == d.Fo - 1;
+  const int nchunk = (d.C + BK - 1) / BK, ngrp = d.ntap / 3;
+  const int NI = nchunk * d.ntap;
+  const unsigned thr = 0u;
+  const float inv_keep = 1.f;
+
+  float4 ra[4], rh, rb[2];
+  auto load_a = [&](int grp_it) {             // halo tile of (chunk, triple) number grp_it
+    const int chunk = grp_it / ngrp, gi = grp_it - chunk * ngrp;
+    const int c = chunk * BK + kq * 4;
+    const bool cok = c < d.C;
+    const int q0 = m0 - 1 + d.dt[3 * gi] * d.Fo;          // flattened source pixel of halo row 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = q0 + 1 + r0 + 32 * i;
+      ra[i] = (cok && q >= 0 && q < Mb) ? *reinterpret_cast<const float4*>(Ab + ((unsigned)q * (unsigned)d.lda + (unsigned)c))
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 16) {                            // halo rows 0 and 129
+      const int q = q0 + (tid >> 3) * (HR - 1);
+      rh = (cok && q >= 0 && q < Mb) ? *reinterpret_cast<const float4*>(Ab + ((unsigned)q * (unsigned)d.lda + (unsigned)c))
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto load_b = [&](int it) {
+    const int chunk = it / d.ntap, tap = it - chunk * d.ntap;
+    const int c = chunk * BK + kq * 4;
+    const bool cok = c < d.C;
+    const unsigned wk = (unsigned)(tap * d.C + c);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      rb[i] = (wok[i] && cok) ? *reinterpret_cast<const float4*>(Wb + (wrow[i] + wk)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  const bool vec_ep = epilogue_vec_ok(d);
+  if (vec_ep) stage_bias(g, by, bias_s);
+  load_a(0);
+  load_b(0);
+  const int frag = (lane & 31) * SA + 8 * (lane >> 5);
+  int it = 0, gi = 0;
+  for (int gq = 0; gq < nchunk * ngrp; ++gq, gi = (gi + 1 == ngrp ? 0 : gi + 1)) {
+    // stage the halo tile of this (chunk, triple); the previous iteration's trailing barrier freed Ap
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store<NPL>(ra[i], &Ap[(1 + r0 + 32 * i) * SA + kq * 4], PA);
+    if (tid < 16) split_store<NPL>(rh, &Ap[((tid >> 3) * (HR - 1)) * SA + kq * 4], PA);
+#pragma unroll 1
+    for (int s3 = 0; s3 < 3; ++s3, ++it) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
+      __syncthreads();
+      if (it + 1 < NI) load_b(it + 1);
+      if (s3 == 0 && gq + 1 < nchunk * ngrp) load_a(gq + 1);
+      const int df = d.df[3 * gi + s3];
+      const bool kill = (df < 0 && edgeL) || (df > 0 && edgeR);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int ao = (wave * 32 + 1 + df) * SA + frag + 16 * ks, bo = frag + 16 * ks;
+        bf16x8 af[NPL], bf0[NPL], bf1[NPL];
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+          af[q] = *reinterpret_cast<const bf16x8*>(&Ap[q * PA + ao]);
+          bf0[q] = *reinterpret_cast<const bf16x8*>(&Bp[q * PB + bo]);
+          bf1[q] = *reinterpret_cast<const bf16x8*>(&Bp[q * PB + 32 * SA + bo]);
+        }
+        if (df != 0) {
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) {
+            f32x4 z = kill ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(&af[q]);
+            af[q] = *reinterpret_cast<bf16x8*>(&z);
+          }
+        }
+#pragma unroll
+        for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa) {
+            const int qb = ord - qa;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf0[qb], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf1[qb], acc1, 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+  float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;
+  if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
+  else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row-panel kernel for the token-wise layers with K = 64 and N >= 128 (LN -> 256 / 192 / GLU-256, dY(64) -> 256), split
 // bf16.  The per-column-block kernel above is issue-bound on these shapes: every one of the N/64 sibling workgroups
 // re-loads, re-normalises and re-splits the same A rows and pays the same ~700 VALU instructions of set-up per wave for
@@ -1188,6 +1312,23 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
 #undef LAUNCHP
 #undef LAUNCHP2
       return se_check_launch("se_gemm_tap(k64 panel)");
+    }
+  }
+  if ((d->precision == 1 || d->precision == 2) && d->C >= 32 && d->prologue == SE_PRO_NONE && !d->up && d->st == 1 && d->sf == 1 &&
+      d->Ti == d->To && d->Fi == d->Fo && d->ntap >= 3 && d->ntap % 3 == 0 && !(ep & (SE_EPI_GLU | SE_EPI_DROP)) && d->Fo >= 2) {
+    bool triples = getenv("SE_GEMM_NO_CONV3") == nullptr;
+    for (int t3 = 0; t3 < d->ntap && triples; t3 += 3) {
+      int seen = 0;
+      for (int j = 0; j < 3; ++j) {
+        if (d->dt[t3 + j] != d->dt[t3] || d->df[t3 + j] < -1 || d->df[t3 + j] > 1) triples = false;
+        else seen |= 1 << (d->df[t3 + j] + 1);
+      }
+      if (seen != 7) triples = false;
+    }
+    if (triples) {
+      if (d->precision == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2>), grid, block, 0, s, g);
+      else hipLaunchKernelGGL((conv3_bf16_kernel<3>), grid, block, 0, s, g);
+      return se_check_launch("se_gemm_tap(conv3)");
     }
   }
   if ((d->precision == 1 || d->precision == 2) && d->C >= 32) {      // split-bf16 paths (BK = 32 only)
