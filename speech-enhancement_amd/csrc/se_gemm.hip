@@ -1036,6 +1036,142 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Weight gradient of the unit-stride convolutions whose taps come in frequency triples (see conv3_bf16_kernel): one
+// workgroup owns (row chunk, dt, channel block, n block) and accumulates the THREE taps df = -1, 0, +1 at once from one
+// dY tile and one 66-row halo tile of A (flattened pixels m - 1 .. m + 64 of the dt-shifted rows): a third of the
+// loads and LDS stores per MFMA of wgrad_kernel.  Rows whose frequency neighbour is padding are masked through a
+// per-row multiplier table (mask[df][row], built at staging time).  fp32 MFMA.
+__global__ __launch_bounds__(256) void wgrad3_kernel(WgradArgs g) {
+  constexpr int SY = 68, MR = 64, HR = MR + 2;
+  __shared__ __attribute__((aligned(16))) float Ys[MR * SY];
+  __shared__ __attribute__((aligned(16))) float Xs[HR * SY];
+  __shared__ float msk[2][MR];               // [0]: df = -1 allowed, [1]: df = +1 allowed
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64, nnb = (d.N + 63) / 64, ngrp = d.ntap / 3;
+  const WorkId wk_ = decode_work(ngrp * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int gi = tc / ncb, cb = tc - gi * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, r0 = tid >> 4;
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  // accumulator slot s <-> tap 3 gi + s; its frequency offset
+  int dfs[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) dfs[s3] = d.df[3 * gi + s3];
+  const long shift = (long)d.dt[3 * gi] * d.Fo;           // flattened pixel shift of this triple's rows
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s3][r] = 0.f;
+  float bsum = 0.f;
+  const int n_ld = nb * 64 + q * 4, c_ld = cb * 64 + q * 4;
+  const bool nok = n_ld < d.N, cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+
+  float4 ry[4], rx[4], rh;
+  // (entry base row, in-entry pixel) of this thread's 4 tile rows and of its halo row, advanced by MR per step with
+  // adds and compares (MR <= Mb is host-checked)
+  long eb[5];
+  int ip[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const long mg = mbeg + (i < 4 ? r0 + i * 16 : ((tid >> 4) & 1) * (MR - 1));
+    const long bq = mg / Mb;
+    eb[i] = bq * Mb;
+    ip[i] = (int)(mg - eb[i]);
+  }
+  const int ishift = (int)shift;
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long mg = mbase + r0 + i * 16;
+      const bool ok = mg < mend;
+      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int inb = ip[i] + ishift;
+      const bool v = ok && cok && inb >= 0 && inb < Mb;
+      rx[i] = v ? *reinterpret_cast<const float4*>(Ag + (eb[i] + inb) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 32) {                            // halo rows: source pixel of (first row) - 1 and of (last row) + 1
+      const int hsel = tid >> 4;
+      const long mg = hsel ? mbase + MR - 1 : mbase;
+      const int inb = ip[4] + ishift;
+      // out-of-entry / out-of-range neighbours are only ever read under a frequency-edge mask or for rows >= mend
+      const int nbp = hsel ? inb + 1 : inb - 1;
+      const bool v = mg < mend && cok && inb >= 0 && inb < Mb && nbp >= 0 && nbp < Mb;
+      rh = v ? *reinterpret_cast<const float4*>(Ag + (eb[4] + nbp) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      ip[i] += MR;
+      if (ip[i] >= Mb) { ip[i] -= Mb; eb[i] += Mb; }
+    }
+  };
+  int fm = (tid < MR) ? (int)(((mbeg + tid) % Mb) % d.Fo) : 0;      // frequency index of row mb + tid (mask builder)
+  const int fadv = MR % d.Fo;
+
+  if (mbeg < mend) load_tiles(mbeg);
+  for (long mb = mbeg; mb < mend; mb += MR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&Xs[(1 + r0 + i * 16) * SY + q * 4]) = rx[i];
+      *reinterpret_cast<float4*>(&Ys[(r0 + i * 16) * SY + q * 4]) = ry[i];
+    }
+    if (tid < 32) *reinterpret_cast<float4*>(&Xs[((tid >> 4) * (HR - 1)) * SY + q * 4]) = rh;
+    if (tid < MR) {                            // frequency-edge masks of the 64 rows of this step
+      msk[0][tid] = fm == 0 ? 0.f : 1.f;
+      msk[1][tid] = fm == d.Fo - 1 ? 0.f : 1.f;
+      fm += fadv;                              // Mb is a multiple of Fo, so entry boundaries do not disturb f
+      if (fm >= d.Fo) fm -= d.Fo;
+    }
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+    const int hrow = (lane >> 5) * 32;
+    const float* yp = &Ys[hrow * SY + wn * 32 + (lane & 31)];
+    const float* xp = &Xs[(1 + hrow) * SY + wc * 32 + (lane & 31)];
+    // tap order inside the loop: the three accumulator chains are independent, so consecutive MFMAs never wait on
+    // each other's result; row s of A serves df = -1 at output row s + 1, df = 0 at s, df = +1 at s - 1
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float yv = yp[s * SY];
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int df = dfs[s3];
+        float xv = xp[(s + df) * SY];
+        if (df != 0) xv *= (df < 0 ? msk[0] : msk[1])[hrow + s];
+        acc[s3] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, xv, acc[s3], 0, 0, 0);
+      }
+    }
+    if (do_bias && tid < 64) {
+#pragma unroll
+      for (int r = 0; r < MR; ++r) bsum += Ys[r * SY + tid];
+    }
+    __syncthreads();
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int tap = 3 * gi + s3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[s3][r]);
+    }
+  }
+  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], bsum);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Split-bf16 weight gradient (precision 1 / 2, same operand splits as gemm_tap_bf16x3_kernel).  The contraction index
 // of dW = dY^T X is the ROW index m, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane: both tiles are
 // therefore staged TRANSPOSED in LDS ([column][m], m contiguous).  Every thread owns a 4 (rows) x 4 (columns) block:
@@ -1383,6 +1519,24 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
   WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc, chunks};
   dim3 grid((unsigned)((long)d->ntap * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8))), block(256);
   hipStream_t s = as_stream(stream);
+  if (d->precision == 0 && d->prologue == SE_PRO_NONE && !(d->epilogue & SE_EPI_DROP) && !d->up && d->st == 1 && d->sf == 1 &&
+      d->Ti == d->To && d->Fi == d->Fo && d->ntap >= 3 && d->ntap % 3 == 0 && d->Fo >= 2 && d->To * d->Fo >= 64 &&
+      getenv("SE_GEMM_NO_CONV3") == nullptr) {
+    bool triples = true;
+    for (int t3 = 0; t3 < d->ntap && triples; t3 += 3) {
+      int seen = 0;
+      for (int j = 0; j < 3; ++j) {
+        if (d->dt[t3 + j] != d->dt[t3] || d->df[t3 + j] < -1 || d->df[t3 + j] > 1) triples = false;
+        else seen |= 1 << (d->df[t3 + j] + 1);
+      }
+      if (seen != 7) triples = false;
+    }
+    if (triples) {
+      dim3 g3((unsigned)((long)(d->ntap / 3) * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8)));
+      hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
+      return se_check_launch("se_gemm_tap_wgrad(conv3)");
+    }
+  }
   if (d->precision == 1 || d->precision == 2) {
 #define LAUNCHWB(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 2>), grid, block, 0, s, g); \
                            else hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 3>), grid, block, 0, s, g); } while (0)
