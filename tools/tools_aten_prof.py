@@ -1,6 +1,6 @@
 """count the aten ops (PyTorch glue) in one train step"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech_enhancement_amd as S
 from speech_enhancement_amd import train as TR, optim as OP
 from torch.profiler import profile, ProfilerActivity

@@ -1,6 +1,6 @@
 """micro-benchmark of the attention kernels at the bench shapes (B=16): ablation via SE_ATTN_DBG."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speech_enhancement_amd import attention as A
 B, T, Fq = 16, 321, 101
 g = torch.Generator().manual_seed(0)

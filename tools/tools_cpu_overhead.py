@@ -1,6 +1,6 @@
 """host-side enqueue time of one train step vs its GPU time"""
 import os, sys, time, types, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import speech_enhancement_amd as S
 from speech_enhancement_amd import train as TR, optim as OP, _lib
 torch.manual_seed(0)

@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speech_enhancement_amd import ops as O, attention as A
 B, T, Fq = 16, 321, 101
 x = torch.randn(B * T * Fq, 128, device='cuda'); dy = torch.randn_like(x)

@@ -1,6 +1,6 @@
 """one Conformer-shaped linear GEMM, for rocprofv3 --pmc runs: args C N [pro] [epi] [prec]"""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speech_enhancement_amd import gemm as GM, _lib as L
 M = 16 * 321 * 101
 C, N = int(sys.argv[1]), int(sys.argv[2])

@@ -1,6 +1,6 @@
 """micro-benchmark of the conv weight-gradient kernel (dense layer shape) and of the split-bf16 conv forward."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from speech_enhancement_amd import gemm as GM, _lib as L, layers as LY
 B, T, Fq = 16, 321, 201
 Cin = int(sys.argv[1]) if len(sys.argv) > 1 else 256
