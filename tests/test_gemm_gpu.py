@@ -318,3 +318,37 @@ def test_split_bf16_precision_mode(G):
         dwl = torch.zeros(192, 64, device='cuda')
         gemm.gemm_tap_wgrad(dl, xl, dyl, dwl, None, rowstats=st, ps=gam, pb=bet, chunks=3, explicit_precision=True)
         assert relerr(dwl, refw) < tol, (prec, relerr(dwl, refw))
+
+
+@pytest.mark.parametrize('B,T,Fq,dil,C', [(1, 1, 2, 1, 64), (2, 3, 3, 2, 32), (1, 5, 7, 1, 96), (2, 4, 130, 2, 64), (3, 9, 65, 4, 128)])
+def test_triple_tap_kernels_edge_shapes(G, B, T, Fq, dil, C):
+    """conv3_bf16_kernel / wgrad3_kernel (one halo tile shared by the df = -1, 0, +1 taps): frequency-edge masks,
+    time padding, tiles that straddle time rows and batch entries, tiny grids -- against fp64 conv2d autograd."""
+    gemm, L = G
+    xbuf = rnd(B, T, Fq, C, seed=21)
+    w = rnd(64, C, 2, 3, seed=22, scale=0.05)
+    dy = rnd(B, T, Fq, 64, seed=23)
+    x64 = xbuf.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.conv2d(F.pad(x64.permute(0, 3, 1, 2), (1, 1, dil, 0)), w64, None, dilation=(dil, 1)).permute(0, 2, 3, 1)
+    y64.backward(dy.double())
+    taps = gemm.conv_taps(2, 3, (dil, 1), (dil, 1))
+    wp = gemm.pack_conv_fwd(w)
+    for prec, tol in ((2, 3e-6), (1, 1e-4)):
+        d = gemm.make_desc(B, T, Fq, T, Fq, taps, C, C, 64, 64, precision=prec)
+        y = torch.empty(B, T, Fq, 64, device='cuda')
+        gemm.gemm_tap(d, xbuf, wp, y)
+        assert relerr(y, y64) < tol, (prec, relerr(y, y64))
+        dd = gemm.make_desc(B, T, Fq, T, Fq, [(-a, -c) for a, c in taps], 64, 64, C, C, precision=prec)
+        dx = torch.empty(B, T, Fq, C, device='cuda')
+        gemm.gemm_tap(dd, dy, gemm.pack_conv_dgrad(w), dx)
+        assert relerr(dx, x64.grad) < tol, (prec, relerr(dx, x64.grad))
+    for chunks in (1, 3):
+        fd = gemm.make_desc(B, T, Fq, T, Fq, taps, C, C, 64, 64)
+        dwp = torch.zeros(64, len(taps) * C, device='cuda')
+        db = torch.zeros(64, device='cuda')
+        gemm.gemm_tap_wgrad(fd, xbuf, dy, dwp, db, chunks=chunks)
+        dw = torch.zeros_like(w)
+        gemm.unpack_conv_wgrad(dwp, dw)
+        assert relerr(dw, w64.grad) < 3e-6, (chunks, relerr(dw, w64.grad))
+        assert relerr(db, dy.double().sum((0, 1, 2))) < 1e-5
