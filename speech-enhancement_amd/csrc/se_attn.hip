@@ -467,19 +467,21 @@ static __device__ __forceinline__ long seq_base(const AttnGeom& g, int s) {
 static __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
 // LDS: Ks[NP][16] | Vt[16][NP+4] | per-wave U ring [4][2 tiles][2 slots][256]
-__global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs a, int NP) {
+template <int TQ>      // 16-query tiles per wave block: 2 amortises the K / V fragment reads, 1 balances long sequences over 8 waves
+__global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a, int NP) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
   float* Vt = Ks + NP * 16;
   const int VS = NP + 4;
   float* Ubase = Vt + 16 * VS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NT = blockDim.x, NW = NT >> 6;      // waves per workgroup: launch parameter (LDS sized to match)
   const int c = lane & 15, g = lane >> 4;
   const int n = a.g.n;
   const int head = blockIdx.x & 3, seq = blockIdx.x >> 2;
   const long base = seq_base(a.g, seq), ps = a.g.pos_stride;
   const float* qkv = a.QKV + head * 16;
-  for (int i = tid; i < NP * 4; i += 256) {
+  for (int i = tid; i < NP * 4; i += NT) {
     int j = i >> 2, q = i & 3;
     float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
     if (j < n) {
@@ -492,21 +494,21 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs a, int NP) {
     Vt[(4 * q + 2) * VS + j] = v4.z; Vt[(4 * q + 3) * VS + j] = v4.w;
   }
   __syncthreads();
-  float* Ul = Ubase + wave * 1024;      // [tile t][slot][256]
+  float* Ul = Ubase + wave * (TQ * 512);      // [tile t][slot][256]
   const float l2e = 1.4426950408889634f * a.scale;
-  const int qblocks = (n + 31) / 32, nkt = (n + 15) / 16;
-  for (int qb = wave; qb < qblocks; qb += 4) {
-    const int i0 = qb * 32;
-    float4 qf[2];
+  const int qblocks = (n + 16 * TQ - 1) / (16 * TQ), nkt = (n + 15) / 16;
+  for (int qb = wave; qb < qblocks; qb += NW) {
+    const int i0 = qb * 16 * TQ;
+    float4 qf[TQ];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TQ; ++t) {
       int qi = i0 + 16 * t + c; if (qi > n - 1) qi = n - 1;
       qf[t] = *reinterpret_cast<const float4*>(qkv + (base + (long)qi * ps) * 192 + 4 * g);
     }
-    f32x4 o[2][2];
-    float m[2], l[2];
+    f32x4 o[TQ][2];
+    float m[TQ], l[TQ];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TQ; ++t) {
       m[t] = -1e30f; l[t] = 0.f;
       o[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
@@ -519,17 +521,17 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs a, int NP) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Ul[(t * 2 + slot) * 256 + (4 * g + r) * 16 + c] = u[r];
     };
-    u_tile(i0, 0, 0);
-    u_tile(i0 + 16, 1, 0);
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) u_tile(i0 + 16 * t, t, 0);
     int hi = 0;
     for (int kt = 0; kt < nkt; ++kt) {
       const int j0 = kt * 16, lo = hi ^ 1;
-      u_tile(i0 - j0 - 16, 0, lo);
-      u_tile(i0 - j0, 1, lo);
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) u_tile(i0 + 16 * t - j0 - 16, t, lo);
       float4 kf = *reinterpret_cast<const float4*>(&Ks[(j0 + c) * 16 + 4 * g]);
       float4 vf = *reinterpret_cast<const float4*>(&Vt[c * VS + j0 + 4 * g]);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < TQ; ++t) {
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
         s4 = MFMA16(kf.x, qf[t].x, s4); s4 = MFMA16(kf.y, qf[t].y, s4);
         s4 = MFMA16(kf.z, qf[t].z, s4); s4 = MFMA16(kf.w, qf[t].w, s4);
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256) void attn_fwd2_kernel(AttnArgs a, int NP) {
       hi = lo;
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < TQ; ++t) {
       float lt = l[t];
       lt += __shfl_xor(lt, 16, 64);
       lt += __shfl_xor(lt, 32, 64);
@@ -788,15 +790,26 @@ extern "C" int se_attn_fwd(const float* QKV, const float* E, float* O, float* LS
   if (int e = check_geom(a.g)) return e;
   SE_REQUIRE(QKV && E && O, "attn_fwd: null operand");
   const int NP = ((n + 15) / 16) * 16;
-  const size_t sh = ((size_t)NP * 16 + 16 * (size_t)(NP + 4) + 4096) * sizeof(float);
+  // waves per workgroup: 32-query blocks are dealt round-robin to the waves; long sequences get 6 or 8 waves so that
+  // 3-4 waves share a SIMD (the per-step chain S -> softmax -> PV is latency-bound with 2), short ones 4
+  // waves per workgroup / 16-query tiles per wave block (measured at B = 16): short sequences (n <= 128) 4 waves x 1 tile
+  // (n = 101: 0.37 ms vs 0.41 with 2 tiles), long ones 8 waves x 2 tiles (n = 321: 1.09 ms vs 1.39 with 4 waves -- the
+  // per-step chain S -> softmax -> PV is latency-bound with 2 waves per SIMD, 8-wave workgroups put 4 there)
+  const int qb32 = (n + 31) / 32;
+  int nw = qb32 <= 4 ? 4 : 8, tq = qb32 <= 4 ? 1 : 2;
+  if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v == 4 || v == 6 || v == 8) nw = v; }
+  if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq = v; }
+  const size_t sh = ((size_t)NP * 16 + 16 * (size_t)(NP + 4) + 512 * (size_t)tq * nw) * sizeof(float);
   if (sh <= 160 * 1024) {       // K / V of one (sequence, head) fit in LDS: staged kernel
-    static size_t raised = 0;
-    if (sh > 64 * 1024 && sh > raised) {
-      SE_REQUIRE(hipFuncSetAttribute((const void*)attn_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) ==
+    static size_t raised[3] = {0, 0, 0};
+    if (sh > 64 * 1024 && sh > raised[tq]) {
+      const void* fn = tq == 1 ? (const void*)attn_fwd2_kernel<1> : (const void*)attn_fwd2_kernel<2>;
+      SE_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) ==
                      hipSuccess, "attn_fwd: cannot raise the dynamic LDS limit to %zu", sh);
-      raised = sh;
+      raised[tq] = sh;
     }
-    hipLaunchKernelGGL(attn_fwd2_kernel, dim3(nseq * 4), dim3(256), sh, as_stream(stream), a, NP);
+    if (tq == 1) hipLaunchKernelGGL(attn_fwd2_kernel<1>, dim3(nseq * 4), dim3(64 * nw), sh, as_stream(stream), a, NP);
+    else hipLaunchKernelGGL(attn_fwd2_kernel<2>, dim3(nseq * 4), dim3(64 * nw), sh, as_stream(stream), a, NP);
   } else {
     long items = (long)nseq * 4 * ((n + 31) / 32);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(items, 4)), dim3(256), 0, as_stream(stream), a);
