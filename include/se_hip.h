@@ -58,7 +58,7 @@ typedef struct {
   int ldr, r_off;        /* residual pixel stride / channel offset                          */
   int ldx, x_off;        /* AUX (SWISH_GRAD) or Z (GLU) pixel stride / channel offset        */
   unsigned pro_seed, epi_seed;   /* dropout streams of the prologue / epilogue masks             */
-  float drop_p;          /* dropout probability (0 = off); kept elements are scaled by 1/(1-p) */
+  float drop_p;          /* dropout probability (0 = off), realised as round(p * 65536) / 65536; kept elements are scaled by the exact inverse keep probability */
   int precision;         /* 0: fp32 MFMA; 1: split-bf16 hi/lo (3 bf16 MFMAs per product, ~1.5e-5 relative);
                             2: split-bf16 hi/mid/lo (6 bf16 MFMAs, exact 24-bit split: fp32-equivalent, ~1e-7)   */
 } se_gemm_desc;

@@ -69,13 +69,35 @@ static __device__ __forceinline__ long src_pixel(const se_gemm_desc& d, int b, i
   return ((long)b * d.Ti + ti) * d.Fi + fi;
 }
 
-// Counter-based dropout mask: keep(element) = murmur3-finalizer(seed, element index) >= p * 2^32.  The same
-// (seed, index) pair is re-evaluated in the backward kernels, so no mask is ever stored.
-static __device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, unsigned thr, float inv_keep) {
-  unsigned x = idx * 0x9E3779B1u ^ seed;
+// Counter-based dropout mask.  Elements are hashed in aligned groups of 4 (every user processes float4s): one murmur3
+// finalizer of (seed, idx >> 2) plus one multiply-xorshift step give 64 bits = four 16-bit fields, element j of the
+// group is kept iff field_j >= thr16 = round(p * 65536); survivors are scaled by 65536 / (65536 - thr16), the exact
+// inverse of the realised keep probability.  (The per-element 32-bit hash this replaces cost 3 quarter-rate integer
+// multiplies per element -- more issue slots than the Swish it was fused with.)  The same (seed, index) pair is
+// re-evaluated in the backward kernels, so no mask is ever stored.
+static __device__ __forceinline__ void drop_fields(unsigned seed, unsigned grp, unsigned (&f)[4]) {
+  unsigned x = grp * 0x9E3779B1u ^ seed;
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-  return x >= thr ? inv_keep : 0.f;
+  unsigned y = x * 0x9E3779B1u + 0x7F4A7C15u;
+  y ^= y >> 15;
+  f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
 }
+// scales of the 4 elements idx .. idx + 3 (idx a multiple of 4)
+static __device__ __forceinline__ float4 drop_scale4(unsigned seed, unsigned idx, unsigned thr, float inv_keep) {
+  unsigned f[4];
+  drop_fields(seed, idx >> 2, f);
+  return make_float4(f[0] >= thr ? inv_keep : 0.f, f[1] >= thr ? inv_keep : 0.f, f[2] >= thr ? inv_keep : 0.f,
+                     f[3] >= thr ? inv_keep : 0.f);
+}
+static __device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, unsigned thr, float inv_keep) {
+  unsigned f[4];
+  drop_fields(seed, idx >> 2, f);
+  const unsigned j = idx & 3u;
+  const unsigned fj = j == 0 ? f[0] : (j == 1 ? f[1] : (j == 2 ? f[2] : f[3]));
+  return fj >= thr ? inv_keep : 0.f;
+}
+static __device__ __forceinline__ unsigned drop_thr(float p) { return (unsigned)(p * 65536.0f + 0.5f); }
+static __device__ __forceinline__ float drop_inv_keep(float p) { return 65536.0f / (65536.0f - (float)drop_thr(p)); }
 
 // ps4 / pb4: the per-channel scale / shift of this float4's 4 channels (LN gamma / beta, BN-affine), fetched with the
 // tile as two 16-B loads -- per-element scalar loads here cost 8 VMEM instructions per float4 of A.
@@ -86,6 +108,11 @@ static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float
   if (PRO == SE_PRO_NONE) return v;
   float x[4] = {v.x, v.y, v.z, v.w};
   const float ps[4] = {ps4.x, ps4.y, ps4.z, ps4.w}, pb[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+  float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+  if (PRO == SE_PRO_SWISH_DROP || PRO == SE_PRO_DROP) {      // c and C are multiples of 4: one aligned group
+    const float4 d4 = drop_scale4(seed, (unsigned)(pix * C + c), thr, inv_keep);
+    dsc[0] = d4.x; dsc[1] = d4.y; dsc[2] = d4.z; dsc[3] = d4.w;
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int cc = c + j;
@@ -93,8 +120,8 @@ static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float
       if (PRO == SE_PRO_LN) x[j] = (x[j] - mean) * rstd * ps[j] + pb[j];
       else if (PRO == SE_PRO_SWISH) x[j] = swishf_(x[j]);
       else if (PRO == SE_PRO_AFFINE_SWISH) x[j] = swishf_(x[j] * ps[j] + pb[j]);
-      else if (PRO == SE_PRO_SWISH_DROP) x[j] = swishf_(x[j]) * drop_scale(seed, (unsigned)(pix * C + cc), thr, inv_keep);
-      else if (PRO == SE_PRO_DROP) x[j] = x[j] * drop_scale(seed, (unsigned)(pix * C + cc), thr, inv_keep);
+      else if (PRO == SE_PRO_SWISH_DROP) x[j] = swishf_(x[j]) * dsc[j];
+      else if (PRO == SE_PRO_DROP) x[j] = x[j] * dsc[j];
     } else {
       x[j] = 0.f;
     }
@@ -149,8 +176,8 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         }
         if (ep & SE_EPI_DROP) {
           const unsigned pe = (pdrop + (unsigned)row) * (unsigned)d.N + (unsigned)n;
-          v.x *= drop_scale(d.epi_seed, pe, thr, inv_keep); v.y *= drop_scale(d.epi_seed, pe + 1, thr, inv_keep);
-          v.z *= drop_scale(d.epi_seed, pe + 2, thr, inv_keep); v.w *= drop_scale(d.epi_seed, pe + 3, thr, inv_keep);
+          const float4 d4 = drop_scale4(d.epi_seed, pe, thr, inv_keep);       // pe is a multiple of 4 (N % 4 == 0, n % 4 == 0)
+          v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
         }
         if (ep & SE_EPI_SWISH_GRAD) {
           float4 z = HASPRE ? pre[nt * 4 + i] : *reinterpret_cast<const float4*>(Xb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n));
@@ -414,8 +441,8 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
   unsigned apix[NA];
   int cur_c = 0;
   float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
-  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
-  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
 
   auto load_tiles = [&](int it) {
     int chunk = lin ? it : it / d.ntap;  // channel chunk outer, tap inner: the taps of one chunk re-touch the same
@@ -572,8 +599,8 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   unsigned apix[NA];
   int cur_c = 0;
   float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
-  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
-  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
 
   auto load_tiles = [&](int it) {
     int chunk = lin ? it : it / d.ntap;  // channel chunk outer, tap inner: the taps of one chunk re-touch the same
@@ -788,8 +815,8 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   const int Mb = d.To * d.Fo;                  // row GEMM: B == 1
   const int m0 = blockIdx.x * 128;
   const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
-  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
-  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
 
   // ---- A fragments: row = lane & 31 of this wave's 32 rows, k = 16 ks + 8 (lane >> 5) .. + 7
   const int row = m0 + wave * 32 + (lane & 31), kg = lane >> 5;
@@ -947,8 +974,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
   float mean[4] = {}, rstd[4] = {};
   bool xok[4];
   unsigned xpix[4];
-  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
-  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
   const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
   // (batch entry, t, f) of this thread's 4 rows, advanced by MR rows per step with adds and compares: the two
   // divisions per row and step they replace (one of them 64-bit) cost more VALU issue slots than the step's MFMAs
@@ -983,10 +1010,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
       ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (dy_drop && ok && nok) {
         unsigned base = (unsigned)(mg * d.N + n_ld);
-        ry[i].x *= drop_scale(d.epi_seed, base, thr, inv_keep);
-        ry[i].y *= drop_scale(d.epi_seed, base + 1, thr, inv_keep);
-        ry[i].z *= drop_scale(d.epi_seed, base + 2, thr, inv_keep);
-        ry[i].w *= drop_scale(d.epi_seed, base + 3, thr, inv_keep);
+        const float4 d4 = drop_scale4(d.epi_seed, base, thr, inv_keep);
+        ry[i].x *= d4.x; ry[i].y *= d4.y; ry[i].z *= d4.z; ry[i].w *= d4.w;
       }
       xok[i] = p >= 0;
       xpix[i] = (unsigned)p;
@@ -1219,8 +1244,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
   // than a memory round trip and only 2 workgroups fit per CU, so a single-step prefetch left the latency exposed)
   struct Regs { float4 ry[4], rx[4]; float mean[4], rstd[4]; bool xok[4]; unsigned xpix[4]; };
   Regs R0, R1;
-  const unsigned thr = (unsigned)((double)d.drop_p * 4294967296.0);
-  const float inv_keep = 1.0f / (1.0f - d.drop_p);
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
   const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
   int cb_[4], ct_[4], cf_[4];
   const int adv_t = MR / d.Fo, adv_f = MR - adv_t * d.Fo;
@@ -1253,10 +1278,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
       R.ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (dy_drop && ok && nok) {
         unsigned base = (unsigned)(mg * d.N + n_ld);
-        R.ry[i].x *= drop_scale(d.epi_seed, base, thr, inv_keep);
-        R.ry[i].y *= drop_scale(d.epi_seed, base + 1, thr, inv_keep);
-        R.ry[i].z *= drop_scale(d.epi_seed, base + 2, thr, inv_keep);
-        R.ry[i].w *= drop_scale(d.epi_seed, base + 3, thr, inv_keep);
+        const float4 d4 = drop_scale4(d.epi_seed, base, thr, inv_keep);
+        R.ry[i].x *= d4.x; R.ry[i].y *= d4.y; R.ry[i].z *= d4.z; R.ry[i].w *= d4.w;
       }
       R.xok[i] = p >= 0;
       R.xpix[i] = (unsigned)p;

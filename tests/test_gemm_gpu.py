@@ -220,17 +220,21 @@ def test_missing_operand_is_loud(G):
 
 
 def _mask(seed, rows, cols, p):
-    """torch restatement of the kernels' counter-based dropout mask (murmur3 finalizer of seed ^ idx*golden)."""
+    """torch restatement of the kernels' counter-based dropout mask: aligned groups of 4 elements, murmur3 finalizer of
+    (seed, group) + one multiply-xorshift step = four 16-bit fields, keep iff field >= round(p * 65536)."""
     M32 = 0xFFFFFFFF
-    idx = torch.arange(rows * cols, device='cuda', dtype=torch.int64)
-    x = ((idx * 0x9E3779B1) & M32) ^ seed
+    grp = torch.arange(rows * cols // 4, device='cuda', dtype=torch.int64)
+    x = ((grp * 0x9E3779B1) & M32) ^ seed
     x = x ^ (x >> 16)
     x = (x * 0x85EBCA6B) & M32
     x = x ^ (x >> 13)
     x = (x * 0xC2B2AE35) & M32
     x = x ^ (x >> 16)
-    thr = int(p * 4294967296.0)
-    return ((x >= thr).double() / (1.0 - p)).view(rows, cols)
+    y = (x * 0x9E3779B1 + 0x7F4A7C15) & M32
+    y = y ^ (y >> 15)
+    f = torch.stack([x & 0xFFFF, x >> 16, y & 0xFFFF, y >> 16], -1).reshape(-1)
+    thr = int(p * 65536.0 + 0.5)
+    return ((f >= thr).double() * (65536.0 / (65536.0 - thr))).view(rows, cols)
 
 
 def test_feed_forward_with_dropout_fwd_bwd(G):
