@@ -72,6 +72,15 @@ int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W, const flo
                 float* Y, const float* R, float* AUX, const float* rowstats,
                 const float* pro_scale, const float* pro_shift, double* stats, void* stream);
 
+/* Fused feed-forward forward of a Conformer block (models/conformer.py:53-71,128-145: Scale(0.5, PreNorm(FeedForward))):
+   Y = X + alpha * Drop_o(W2 Drop_h(Swish(W1 LN(X) + b1)) + b2), H = W1 LN(X) + b1 [M, hid] kept for the backward.
+   X, Y: [M, 64]; rowstats: [M, 2] (mean, rstd) from se_row_stats; W1: [hid, 64]; W2: [64, hid]; hid % 64 == 0;
+   precision: 1 / 2 as in se_gemm_desc; dropout masks as in se_gemm_tap (prologue seed = seed_h on H, epilogue = seed_o). */
+int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
+              const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid, float drop_p,
+              unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream);
+
+
 /* weight gradient: dW[n][tap*C + c] += sum_m dY[m][n] * pro(A[src(m,tap)][c]);  dW must be zeroed by
  * the caller (fp32 atomics across row chunks).  If dbias != NULL also dbias[n] += sum_m dY[m][n].
  * Replaces the weight-gradient kernels of the same ATen ops as se_gemm_tap. */

@@ -920,6 +920,208 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused feed-forward forward:  Y = X + alpha * Drop_o( W2 Drop_h( Swish( W1 LN(X) + b1 ) ) + b2 ),  H = W1 LN(X) + b1 kept
+// for the backward (conformer.py:53-71, Scale(0.5, PreNorm(FeedForward))).  Same skeleton as the K = 64 row-panel
+// kernel: every wave keeps the split LN(X) fragments of its 32 rows in registers and sweeps the hidden units in blocks
+// of 64; the block of H it has just produced is written out, activated, re-split and fed -- through a wave-private LDS
+// transpose -- straight back as the A operand of the second GEMM, whose 32 x 64 result stays in registers across the
+// sweep.  H is written once and never re-read in the forward (unfused: + one 4 M hid-byte read and a second kernel).
+struct FfArgs {
+  const float* X; const float* rowstats; const float* gamma; const float* beta;
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  float* H; float* Y; long M; int hid; float drop_p; unsigned seed_h, seed_o; float alpha;
+};
+
+template <int NPL>
+__global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 workgroups per CU: VGPR + AGPR <= 256
+  constexpr int SB = 72, PB = 64 * SB, SP = 36;
+  __shared__ __attribute__((aligned(16))) __bf16 W1p[NPL * PB];
+  __shared__ __attribute__((aligned(16))) __bf16 W2p[NPL * PB];
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * SP];    // wave-private 32 x 32 transposes
+  __shared__ __attribute__((aligned(16))) float b1s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* cs = patch + wave * 32 * SP;
+  const long m0 = (long)blockIdx.x * 128;
+  const long row = m0 + wave * 32 + (lane & 31);
+  const int kg = lane >> 5;
+  const bool rok = row < a.M;
+  const unsigned thr = drop_thr(a.drop_p);
+  const float inv_keep = drop_inv_keep(a.drop_p);
+  const bool dr = a.drop_p > 0.f;
+
+  bf16x8 af1[4][NPL];
+  {
+    const float* __restrict__ xp = a.X + row * 64 + 8 * kg;
+    float mean = 0.f, rstd = 0.f;
+    if (rok) { float2 mr = *reinterpret_cast<const float2*>(a.rowstats + 2 * row); mean = mr.x; rstd = mr.y; }
+    float4 v[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v[ks][0] = rok ? *reinterpret_cast<const float4*>(xp + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[ks][1] = rok ? *reinterpret_cast<const float4*>(xp + 16 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * ks + 8 * kg + 4 * h;
+        const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c), bt = *reinterpret_cast<const float4*>(a.beta + c);
+        const float4 w = v[ks][h];
+        x[4 * h] = rok ? (w.x - mean) * rstd * gm.x + bt.x : 0.f;
+        x[4 * h + 1] = rok ? (w.y - mean) * rstd * gm.y + bt.y : 0.f;
+        x[4 * h + 2] = rok ? (w.z - mean) * rstd * gm.z + bt.z : 0.f;
+        x[4 * h + 3] = rok ? (w.w - mean) * rstd * gm.w + bt.w : 0.f;
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+        af1[ks][pl] = hh;
+      }
+    }
+  }
+  const int kq = tid & 15, r0 = tid >> 4;
+  const int nb = a.hid / 64;
+  float4 rw1[4], rw2[4];
+  auto load_w = [&](int jb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = r0 + 16 * i;
+      rw1[i] = *reinterpret_cast<const float4*>(a.W1 + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
+      rw2[i] = *reinterpret_cast<const float4*>(a.W2 + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
+    }
+  };
+  load_w(0);
+  f32x16 y0, y1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { y0[r] = 0.f; y1[r] = 0.f; }
+  const int frag = (lane & 31) * SB + 8 * kg;
+  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  for (int jb = 0; jb < nb; ++jb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      split_store<NPL>(rw1[i], &W1p[(r0 + 16 * i) * SB + kq * 4], PB);
+      split_store<NPL>(rw2[i], &W2p[(r0 + 16 * i) * SB + kq * 4], PB);
+    }
+    if (tid < 64) b1s[tid] = a.b1[jb * 64 + tid];
+    __syncthreads();
+    if (jb + 1 < nb) load_w(jb + 1);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 bf0[NPL], bf1[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf0[pl] = *reinterpret_cast<const bf16x8*>(&W1p[pl * PB + frag + 16 * ks]);
+        bf1[pl] = *reinterpret_cast<const bf16x8*>(&W1p[pl * PB + 32 * SB + frag + 16 * ks]);
+      }
+#pragma unroll
+      for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+        }
+    }
+    const float bb0 = b1s[col], bb1 = b1s[32 + col];
+    // per 32-column half of the block: transpose through the wave's patch, write H, re-split, second GEMM
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+        cs[rl * SP + col] = nt ? acc1[r] + bb1 : acc0[r] + bb0;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = rr + 8 * i;
+        const long rg = m0 + wave * 32 + rl;
+        if (rg < a.M)
+          *reinterpret_cast<float4*>(a.H + rg * a.hid + jb * 64 + nt * 32 + cq * 4) =
+              *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int ks = 2 * nt + k2;
+        float x[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int kl = 16 * k2 + 8 * kg + 4 * h;                 // column inside this half
+          const float4 pv = *reinterpret_cast<const float4*>(&cs[(lane & 31) * SP + kl]);
+          float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (dr) sc = drop_scale4(a.seed_h, (unsigned)(row * a.hid + jb * 64 + nt * 32 + kl), thr, inv_keep);
+          x[4 * h] = swishf_(pv.x) * sc.x; x[4 * h + 1] = swishf_(pv.y) * sc.y;
+          x[4 * h + 2] = swishf_(pv.z) * sc.z; x[4 * h + 3] = swishf_(pv.w) * sc.w;
+        }
+        bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          bf16x8 hh;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+          af2[pl] = hh;
+          bf0[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + frag + 16 * ks]);
+          bf1[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + 32 * SB + frag + 16 * ks]);
+        }
+#pragma unroll
+        for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa) {
+            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf0[ord - qa], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf1[ord - qa], y1, 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // Y = X + alpha * Drop_o(acc + b2)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      cs[rl * SP + col] = nt ? y1[r] : y0[r];
+    }
+    const int n = nt * 32 + cq * 4;
+    const float4 b2v = *reinterpret_cast<const float4*>(a.b2 + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = rr + 8 * i;
+      const long rg = m0 + wave * 32 + rl;
+      if (rg >= a.M) continue;
+      float4 v = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+      v.x += b2v.x; v.y += b2v.y; v.z += b2v.z; v.w += b2v.w;
+      if (dr) {
+        const float4 d4 = drop_scale4(a.seed_o, (unsigned)(rg * 64 + n), thr, inv_keep);
+        v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
+      }
+      const float4 xr = *reinterpret_cast<const float4*>(a.X + rg * 64 + n);
+      *reinterpret_cast<float4*>(a.Y + rg * 64 + n) =
+          make_float4(xr.x + a.alpha * v.x, xr.y + a.alpha * v.y, xr.z + a.alpha * v.z, xr.w + a.alpha * v.w);
+    }
+  }
+}
+
+extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
+                         const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid,
+                         float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
+  SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && H && Y, "ff_fwd: null operand");
+  SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_fwd: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
+  SE_REQUIRE(precision == 1 || precision == 2, "ff_fwd: precision must be 1 (bf16x3) or 2 (bf16x6)");
+  SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_fwd: drop_p=%f out of range", drop_p);
+  SE_REQUIRE(M * (long)hid < 4294967296L, "ff_fwd: dropout index exceeds 32 bits");
+  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha};
+  dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(ff_fwd_kernel<3>, grid, block, 0, as_stream(stream), a);
+  return se_check_launch("se_ff_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------
 // weight gradient:  dW[n][tap*C + c] += sum_m dY[m][n] * pro(A[src(m,tap)][c])
 // grid: (row chunks, ntap * ceil(C/64), ceil(N/64)); 4 waves = 2x2 tiles of 32(n) x 32(c).
 struct WgradArgs {

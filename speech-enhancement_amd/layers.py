@@ -241,6 +241,12 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0):
     """x + 0.5 * Drop(W2 Drop(Swish(W1 LN(x)))) (Scale(0.5, PreNorm(FeedForward)), conformer.py:53-71,128-145).
     The two dropout masks are counter-based (hash(seed, element)) and re-evaluated in the backward."""
     st = O.row_stats(x, M)
+    W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
+    if GM.LINEAR_PRECISION in (1, 2) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0:
+        # one fused kernel: the hidden activations are written once (for the backward) and never re-read here
+        y, z = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1, P[f'{p}.fn.fn.net.0.bias'], W2,
+                         P[f'{p}.fn.fn.net.3.bias'], drop, seed_h, seed_o, 0.5)
+        return y, (x, st, z, drop, seed_h, seed_o)
     z = torch.empty(M, 256, device=x.device, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, epilogue=L.EPI_BIAS), x, P[f'{p}.fn.fn.net.0.weight'], z,
                 bias=P[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
