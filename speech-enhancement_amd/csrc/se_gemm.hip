@@ -1106,6 +1106,187 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
   }
 }
 
+// Fused feed-forward input-gradient chain (the two dgrad GEMMs of the same module):
+//   dZ  = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H))      [M, hid]   (W2s = alpha * W2, passed transposed)
+//   dLN = dZ W1                                               [M, 64]    (input of the LayerNorm backward)
+// dZ is written once (the weight-gradient GEMM reads it) and fed from registers / the wave's LDS patch into the second
+// GEMM; unfused it was written, re-read by a second kernel, and H and dY each cost one more pass.
+struct FfBwdArgs {
+  const float* dY; const float* H; const float* W2T; const float* W1T;
+  float* dZ; float* dLN; long M; int hid; float drop_p; unsigned seed_h, seed_o;
+};
+
+template <int NPL>
+__global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
+  constexpr int SB = 72, PB = 64 * SB, SP = 36;
+  __shared__ __attribute__((aligned(16))) __bf16 Wa[NPL * PB];         // W2T block: rows = hidden units, k = channel
+  __shared__ __attribute__((aligned(16))) __bf16 Wb[NPL * PB];         // W1T block: rows = channel, k = hidden units
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* cs = patch + wave * 32 * SP;
+  const long m0 = (long)blockIdx.x * 128;
+  const long row = m0 + wave * 32 + (lane & 31);
+  const int kg = lane >> 5;
+  const bool rok = row < a.M;
+  const unsigned thr = drop_thr(a.drop_p);
+  const float inv_keep = drop_inv_keep(a.drop_p);
+  const bool dr = a.drop_p > 0.f;
+
+  bf16x8 af1[4][NPL];
+  {
+    const float* __restrict__ yp = a.dY + row * 64 + 8 * kg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * ks + 8 * kg + 4 * h;
+        float4 w = rok ? *reinterpret_cast<const float4*>(yp + 16 * ks + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dr && rok) {
+          const float4 d4 = drop_scale4(a.seed_o, (unsigned)(row * 64 + c), thr, inv_keep);
+          w.x *= d4.x; w.y *= d4.y; w.z *= d4.z; w.w *= d4.w;
+        }
+        x[4 * h] = w.x; x[4 * h + 1] = w.y; x[4 * h + 2] = w.z; x[4 * h + 3] = w.w;
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+        af1[ks][pl] = hh;
+      }
+    }
+  }
+  const int kq = tid & 15, r0 = tid >> 4;
+  const int nb = a.hid / 64;
+  f32x16 g0, g1;                              // dLN accumulators (32 rows x 64 channels)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+  const int frag = (lane & 31) * SB + 8 * kg;
+  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  for (int jb = 0; jb < nb; ++jb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = r0 + 16 * i;
+      const float4 wa = *reinterpret_cast<const float4*>(a.W2T + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
+      const float4 wb = *reinterpret_cast<const float4*>(a.W1T + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
+      split_store<NPL>(wa, &Wa[j * SB + kq * 4], PB);
+      split_store<NPL>(wb, &Wb[j * SB + kq * 4], PB);
+    }
+    // pre-activations of this block for the Swish gradient: issued before the MFMAs, consumed in the epilogue
+    float4 hp[8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long rg = m0 + wave * 32 + rr + 8 * i;
+        hp[nt * 4 + i] = rg < a.M ? *reinterpret_cast<const float4*>(a.H + rg * a.hid + jb * 64 + nt * 32 + cq * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 bf0[NPL], bf1[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wa[pl * PB + frag + 16 * ks]);
+        bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wa[pl * PB + 32 * SB + frag + 16 * ks]);
+      }
+#pragma unroll
+      for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+        cs[rl * SP + col] = nt ? acc1[r] : acc0[r];
+      }
+      // dZ in the row-major lane layout: coalesced H / dZ accesses; the result goes back into the patch in place
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = rr + 8 * i;
+        const long rg = m0 + wave * 32 + rl;
+        float4 v = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+        const float4 hz = hp[nt * 4 + i];
+        if (dr) {
+          const float4 d4 = drop_scale4(a.seed_h, (unsigned)(rg * a.hid + jb * 64 + nt * 32 + cq * 4), thr, inv_keep);
+          v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
+        }
+        v.x *= swish_gradf_(hz.x); v.y *= swish_gradf_(hz.y); v.z *= swish_gradf_(hz.z); v.w *= swish_gradf_(hz.w);
+        if (rg >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        else *reinterpret_cast<float4*>(a.dZ + rg * a.hid + jb * 64 + nt * 32 + cq * 4) = v;
+        *reinterpret_cast<float4*>(&cs[rl * SP + cq * 4]) = v;
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int ks = 2 * nt + k2;
+        float x[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 pv = *reinterpret_cast<const float4*>(&cs[(lane & 31) * SP + 16 * k2 + 8 * kg + 4 * h]);
+          x[4 * h] = pv.x; x[4 * h + 1] = pv.y; x[4 * h + 2] = pv.z; x[4 * h + 3] = pv.w;
+        }
+        bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          bf16x8 hh;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+          af2[pl] = hh;
+          bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + frag + 16 * ks]);
+          bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + 32 * SB + frag + 16 * ks]);
+        }
+#pragma unroll
+        for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa) {
+            g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf0[ord - qa], g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf1[ord - qa], g1, 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      cs[rl * SP + col] = nt ? g1[r] : g0[r];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = rr + 8 * i;
+      const long rg = m0 + wave * 32 + rl;
+      if (rg < a.M)
+        *reinterpret_cast<float4*>(a.dLN + rg * 64 + nt * 32 + cq * 4) = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+    }
+  }
+}
+
+extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN,
+                               long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision, void* stream) {
+  SE_REQUIRE(dY && H && W2T && W1T && dZ && dLN, "ff_bwd_dgrad: null operand");
+  SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_bwd_dgrad: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
+  SE_REQUIRE(precision == 1 || precision == 2, "ff_bwd_dgrad: precision must be 1 (bf16x3) or 2 (bf16x6)");
+  SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_bwd_dgrad: drop_p=%f out of range", drop_p);
+  SE_REQUIRE(M * (long)hid < 4294967296L, "ff_bwd_dgrad: dropout index exceeds 32 bits");
+  FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o};
+  dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(ff_bwd_kernel<3>, grid, block, 0, as_stream(stream), a);
+  return se_check_launch("se_ff_bwd_dgrad");
+}
+
 extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
                          const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid,
                          float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {

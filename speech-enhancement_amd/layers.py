@@ -264,11 +264,15 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     x, st, z, drop, seed_h, seed_o = saved
     dr = drop > 0.0
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
-    # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z)
-    dz = torch.empty(M, 256, device=x.device, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_DROP if dr else L.PRO_NONE,
-                               epilogue=L.EPI_SWISH_GRAD | (L.EPI_DROP if dr else 0), ldx=256, pro_seed=seed_o,
-                               epi_seed=seed_h, drop_p=drop), dy, _T(W2) * 0.5, dz, AUX=z)
+    fused = GM.LINEAR_PRECISION in (1, 2) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0
+    # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z);  dh = dz @ W1
+    if fused:
+        dz, dh = GM.ff_bwd_dgrad(dy, z, _T(W2) * 0.5, _T(W1), drop, seed_h, seed_o)
+    else:
+        dz = torch.empty(M, 256, device=x.device, dtype=torch.float32)
+        GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_DROP if dr else L.PRO_NONE,
+                                   epilogue=L.EPI_SWISH_GRAD | (L.EPI_DROP if dr else 0), ldx=256, pro_seed=seed_o,
+                                   epi_seed=seed_h, drop_p=drop), dy, _T(W2) * 0.5, dz, AUX=z)
     # dW2 = 0.5 * (mask_o * dy)^T (mask_h * swish(z));  db2 = 0.5 * sum mask_o * dy
     dW2 = torch.zeros(64, 256, device=x.device, dtype=torch.float32)
     db2 = torch.zeros(64, device=x.device, dtype=torch.float32)
@@ -280,8 +284,9 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     # dW1 = dz^T LN(x);  db1 = sum dz
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, G[f'{p}.fn.fn.net.0.weight'],
                       G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
-    dh = torch.empty(M, 64, device=x.device, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 256, 64), dz, _T(W1), dh)
+    if not fused:
+        dh = torch.empty(M, 64, device=x.device, dtype=torch.float32)
+        GM.gemm_tap(GM.linear_desc(M, 256, 64), dz, _T(W1), dh)
     return O.layernorm_bwd(x, st, P[f'{p}.fn.norm.weight'], dh, G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'],
                            dR=dy, dR2=dR2)
 
