@@ -82,11 +82,14 @@ int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const f
 
 
 /* Fused input-gradient chain of the same feed-forward module (the backward of se_ff_fwd without the weight gradients):
-   dZ = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H)) [M, hid],  dLN = dZ W1 [M, 64] (input of se_layernorm_bwd).
-   W2T = (alpha * W2)^T [hid, 64], W1T = W1^T [64, hid]; masks / seeds as in se_ff_fwd. */
+   dZ = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H)) [M, hid],  dLN = dZ W1 [M, 64].
+   W2T = (alpha * W2)^T [hid, 64], W1T = W1^T [64, hid]; masks / seeds as in se_ff_fwd.
+   With X != NULL the LayerNorm backward (se_layernorm_bwd with dR = dY, optional dR2) is applied to dLN in registers:
+   dX [M, 64] is written instead of dLN and dgamma / dbeta [64] are accumulated. */
 int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN, long M,
-                    int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision, void* stream);
-
+                    int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision, const float* X,
+                    const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
+                    void* stream);
 
 /* weight gradient: dW[n][tap*C + c] += sum_m dY[m][n] * pro(A[src(m,tap)][c]);  dW must be zeroed by
  * the caller (fp32 atomics across row chunks).  If dbias != NULL also dbias[n] += sum_m dY[m][n].

@@ -1114,6 +1114,9 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
 struct FfBwdArgs {
   const float* dY; const float* H; const float* W2T; const float* W1T;
   float* dZ; float* dLN; long M; int hid; float drop_p; unsigned seed_h, seed_o;
+  // optional fused LayerNorm backward (X != nullptr): dX = dY + dR2 + LNbwd(dLN) is written instead of dLN, and the
+  // gamma / beta gradients are accumulated (one atomic per channel per workgroup)
+  const float* X; const float* stats; const float* gamma; const float* dR2; float* dX; float* dgamma; float* dbeta;
 };
 
 template <int NPL>
@@ -1256,6 +1259,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
     }
     __syncthreads();
   }
+  float4 gv[2][4];                            // dLN of rows rr + 8 i, columns nt * 32 + 4 cq .. + 3
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -1264,23 +1268,93 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
       cs[rl * SP + col] = nt ? g1[r] : g0[r];
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rl = rr + 8 * i;
-      const long rg = m0 + wave * 32 + rl;
-      if (rg < a.M)
-        *reinterpret_cast<float4*>(a.dLN + rg * 64 + nt * 32 + cq * 4) = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+    for (int i = 0; i < 4; ++i) gv[nt][i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * SP + cq * 4]);
+  }
+  if (a.X == nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long rg = m0 + wave * 32 + rr + 8 * i;
+        if (rg < a.M) *reinterpret_cast<float4*>(a.dLN + rg * 64 + nt * 32 + cq * 4) = gv[nt][i];
+      }
+    return;
+  }
+  // LayerNorm backward on the rows in registers: a row's 64 channels sit in the 8 lanes cq = 0..7 of one rr group
+  float ag[2][4] = {}, ab[2][4] = {};
+  float4 gm[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) gm[nt] = *reinterpret_cast<const float4*>(a.gamma + nt * 32 + cq * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long rg = m0 + wave * 32 + rr + 8 * i;
+    const bool ok = rg < a.M;
+    float mean = 0.f, rstd = 0.f;
+    if (ok) { const float2 mr = *reinterpret_cast<const float2*>(a.stats + 2 * rg); mean = mr.x; rstd = mr.y; }
+    float xh[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float4 xv = ok ? *reinterpret_cast<const float4*>(a.X + rg * 64 + nt * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float dv[4] = {gv[nt][i].x, gv[nt][i].y, gv[nt][i].z, gv[nt][i].w};
+      const float gl[4] = {gm[nt].x, gm[nt].y, gm[nt].z, gm[nt].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[nt][j] = (xs[j] - mean) * rstd;
+        dxh[nt][j] = dv[j] * gl[j];
+        s1 += dxh[nt][j]; s2 += dxh[nt][j] * xh[nt][j];
+        if (ok) { ag[nt][j] += dv[j] * xh[nt][j]; ab[nt][j] += dv[j]; }
+      }
     }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
+    if (ok) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const long off = rg * 64 + nt * 32 + cq * 4;
+        const float4 r1 = *reinterpret_cast<const float4*>(a.dY + off);
+        float o4[4] = {r1.x, r1.y, r1.z, r1.w};
+        if (a.dR2) { const float4 r2 = *reinterpret_cast<const float4*>(a.dR2 + off); o4[0] += r2.x; o4[1] += r2.y; o4[2] += r2.z; o4[3] += r2.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
+        *reinterpret_cast<float4*>(a.dX + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
+    }
+  }
+  // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
+  float* redg = reinterpret_cast<float*>(Wa);         // [4 waves][64 channels][2]; the weight planes are free now
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sg = ag[nt][j], sb = ab[nt][j];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
+      if (rr == 0) { redg[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sg; redg[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sb; }
+    }
+  __syncthreads();
+  if (tid < 64) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sg += redg[(w * 64 + tid) * 2]; sb += redg[(w * 64 + tid) * 2 + 1]; }
+    atomicAdd(&a.dgamma[tid], sg);
+    atomicAdd(&a.dbeta[tid], sb);
   }
 }
 
 extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN,
-                               long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision, void* stream) {
-  SE_REQUIRE(dY && H && W2T && W1T && dZ && dLN, "ff_bwd_dgrad: null operand");
+                               long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision,
+                               const float* X, const float* stats, const float* gamma, const float* dR2, float* dX,
+                               float* dgamma, float* dbeta, void* stream) {
+  SE_REQUIRE(dY && H && W2T && W1T && dZ, "ff_bwd_dgrad: null operand");
+  SE_REQUIRE(X ? (stats && gamma && dX && dgamma && dbeta) : dLN != nullptr,
+             "ff_bwd_dgrad: either dLN, or all of X / stats / gamma / dX / dgamma / dbeta (fused LayerNorm backward)");
   SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_bwd_dgrad: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
   SE_REQUIRE(precision == 1 || precision == 2, "ff_bwd_dgrad: precision must be 1 (bf16x3) or 2 (bf16x6)");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_bwd_dgrad: drop_p=%f out of range", drop_p);
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_bwd_dgrad: dropout index exceeds 32 bits");
-  FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o};
+  FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, X, stats, gamma, dR2, dX, dgamma, dbeta};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL(ff_bwd_kernel<3>, grid, block, 0, as_stream(stream), a);

@@ -141,15 +141,19 @@ def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_
     return Y, H
 
 
-def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precision=None):
-    """fused dgrad chain of the feed-forward module (ff_bwd_kernel): returns (dZ [M, hid], dLN [M, 64])."""
+def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precision=None, ln=None):
+    """fused dgrad chain of the feed-forward module (ff_bwd_kernel): returns (dZ [M, hid], dLN [M, 64]); with
+    ln = (x, rowstats, gamma, dR2 or None, dgamma, dbeta) the LayerNorm backward is applied in the same kernel and the
+    second result is dX = dy + dR2 + LNbwd(dLN)."""
     L.check_cuda(dy, H, W2T_scaled, W1T)
     M, hid = H.shape
     dZ = torch.empty(M, hid, device=dy.device, dtype=torch.float32)
-    dLN = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
+    out = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
     prec = LINEAR_PRECISION if precision is None else precision
-    L.call('se_ff_bwd_dgrad', L.ptr(dy), L.ptr(H), L.ptr(W2T_scaled), L.ptr(W1T), L.ptr(dZ), L.ptr(dLN), C.c_long(M),
-           C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF), C.c_int(prec),
+    x, st, g, dR2, dg, db = ln if ln is not None else (None,) * 6
+    L.call('se_ff_bwd_dgrad', L.ptr(dy), L.ptr(H), L.ptr(W2T_scaled), L.ptr(W1T), L.ptr(dZ), L.ptr(None if ln else out),
+           C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF),
+           C.c_int(prec), L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dR2), L.ptr(out if ln else None), L.ptr(dg), L.ptr(db),
            L.stream(), _key=f'ff_bwd_dgrad_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid,
-           _bytes=4.0 * M * (128 + 2 * hid))
-    return dZ, dLN
+           _bytes=4.0 * M * (128 + 2 * hid + (128 if ln else 0)))
+    return dZ, out

@@ -267,7 +267,9 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     fused = GM.LINEAR_PRECISION in (1, 2) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0
     # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z);  dh = dz @ W1
     if fused:
-        dz, dh = GM.ff_bwd_dgrad(dy, z, _T(W2) * 0.5, _T(W1), drop, seed_h, seed_o)
+        # ... and the LayerNorm backward on the rows still in registers: dx = dy (+ dR2) + LNbwd(dz @ W1)
+        dz, dx = GM.ff_bwd_dgrad(dy, z, _T(W2) * 0.5, _T(W1), drop, seed_h, seed_o,
+                                 ln=(x, st, P[f'{p}.fn.norm.weight'], dR2, G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias']))
     else:
         dz = torch.empty(M, 256, device=x.device, dtype=torch.float32)
         GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_DROP if dr else L.PRO_NONE,
@@ -284,9 +286,10 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     # dW1 = dz^T LN(x);  db1 = sum dz
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, G[f'{p}.fn.fn.net.0.weight'],
                       G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
-    if not fused:
-        dh = torch.empty(M, 64, device=x.device, dtype=torch.float32)
-        GM.gemm_tap(GM.linear_desc(M, 256, 64), dz, _T(W1), dh)
+    if fused:
+        return dx
+    dh = torch.empty(M, 64, device=x.device, dtype=torch.float32)
+    GM.gemm_tap(GM.linear_desc(M, 256, 64), dz, _T(W1), dh)
     return O.layernorm_bwd(x, st, P[f'{p}.fn.norm.weight'], dh, G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'],
                            dR=dy, dR2=dR2)
 
