@@ -1829,6 +1829,210 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-bf16 triple-tap weight gradient (precision 1 / 2): wgrad3_kernel's tile sharing (one dY tile + one halo A tile
+// per step feed the taps df = -1, 0, +1) with wgrad_bf16_kernel's transposed bf16 staging.  The contraction index (row m)
+// is the contiguous LDS axis, so the +-1 row shift of a tap is an unaligned 8-element window: the fragment is assembled
+// from the aligned 16-B chunk plus one neighbouring dword with four v_alignbit.  Rows are laid out at position m + 8
+// (chunks 1..8; the two halo rows sit at positions 7 and 72).  Frequency-edge rows are cleared in the shifted fragment
+// by a dword mask; with Fo > 66 (host-checked) a 66-row tile holds at most one edge row of each kind, whose position
+// is a per-step scalar.  One split + one LDS store per element serves 72 MFMAs per wave and step instead of 24.
+template <int NPL>
+__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
+  constexpr int MR = 64;
+  constexpr int PLY = (9 * 64 + 4) * 8;       // Yt plane: [64 n][64 m],  cell(r, ch) = 9 r + (r >> 4) + ch
+  constexpr int PLX = (10 * 64 + 8) * 8;      // Xt plane: [64 c][80 positions], cell(r, ch) = 10 r + (r >> 3) + ch
+  __shared__ __attribute__((aligned(16))) __bf16 Yt[NPL * PLY];
+  __shared__ __attribute__((aligned(16))) __bf16 Xt[NPL * PLX];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64, nnb = (d.N + 63) / 64, ngrp = d.ntap / 3;
+  const WorkId wk_ = decode_work(ngrp * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int gi = tc / ncb, cb = tc - gi * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, rg = tid >> 4;
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  int dfs[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) dfs[s3] = d.df[3 * gi + s3];
+  const int ishift = d.dt[3 * gi] * d.Fo;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s3][r] = 0.f;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int n_ld = nb * 64 + q * 4, c_ld = cb * 64 + q * 4;
+  const bool nok = n_ld < d.N, cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+
+  float4 ry[4], rx[4], rh;
+  long eb[5];
+  int ip[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const long mg = mbeg + (i < 4 ? rg * 4 + i : ((tid >> 4) & 1) * (MR - 1));
+    const long bq = mg / Mb;
+    eb[i] = bq * Mb;
+    ip[i] = (int)(mg - eb[i]);
+  }
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long mg = mbase + rg * 4 + i;
+      const bool ok = mg < mend;
+      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int inb = ip[i] + ishift;
+      const bool v = ok && cok && inb >= 0 && inb < Mb;
+      rx[i] = v ? *reinterpret_cast<const float4*>(Ag + (eb[i] + inb) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 32) {
+      const int hsel = tid >> 4;
+      const long mg = hsel ? mbase + MR - 1 : mbase;
+      const int inb = ip[4] + ishift;
+      const int nbp = hsel ? inb + 1 : inb - 1;
+      const bool v = mg < mend && cok && inb >= 0 && inb < Mb && nbp >= 0 && nbp < Mb;
+      rh = v ? *reinterpret_cast<const float4*>(Ag + (eb[4] + nbp) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      ip[i] += MR;
+      if (ip[i] >= Mb) { ip[i] -= Mb; eb[i] += Mb; }
+    }
+  };
+  // 4 x 4 register transpose + split + 8-B store per column; poff = position of tile row 0 inside the LDS row
+  auto stage_t = [&](const float4 (&v)[4], __bf16* T, int pln, bool halo_layout) {
+    const float x[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      __bf16* dst = halo_layout ? T + (10 * r + (r >> 3)) * 8 + 8 + 4 * rg : T + (9 * r + (r >> 4)) * 8 + 4 * rg;
+      float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h[i] = (__bf16)e[i]; e[i] -= (float)h[i]; }
+        *reinterpret_cast<bf16x4*>(dst + pl * pln) = h;
+      }
+    }
+  };
+  int fbase = (int)((mbeg % Mb) % d.Fo);      // frequency index of the step's first row (wave-uniform)
+  if (mbeg < mend) load_tiles(mbeg);
+  const int ra_ = wn * 32 + (lane & 31), rb_ = wc * 32 + (lane & 31), kg = lane >> 5;
+  const __bf16* yfrag = Yt + (9 * ra_ + (ra_ >> 4)) * 8 + 8 * kg;
+  const __bf16* xrow = Xt + (10 * rb_ + (rb_ >> 3)) * 8;
+  for (long mb = mbeg; mb < mend; mb += MR) {
+    stage_t(rx, Xt, PLX, true);
+    stage_t(ry, Yt, PLY, false);
+    if (tid < 32) {                            // halo rows: positions 7 and 72
+      const int ph = (tid >> 4) ? 72 : 7;
+      const float hv[4] = {rh.x, rh.y, rh.z, rh.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        float e = hv[j];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { __bf16 h = (__bf16)e; e -= (float)h; Xt[pl * PLX + (10 * r + (r >> 3)) * 8 + ph] = h; }
+      }
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bsum.x += ry[i].x; bsum.y += ry[i].y; bsum.z += ry[i].z; bsum.w += ry[i].w; }
+    }
+    // positions (in the 80-slot LDS row) of the frequency-edge rows of this tile, -100 when there is none
+    const int r0f = fbase == 0 ? 0 : d.Fo - fbase;                  // tile row with frequency 0
+    const int pL = r0f <= 64 ? 8 + r0f : (r0f == d.Fo - 1 ? 7 : -100);
+    const int r1f = d.Fo - 1 - fbase;                                // tile row with frequency Fo - 1
+    const int pR = r1f <= 64 ? 8 + r1f : (r1f == d.Fo - 1 ? 7 : -100);
+    fbase += MR % d.Fo;
+    if (fbase >= d.Fo) fbase -= d.Fo;
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int jc = 2 * ks + kg + 1;
+      bf16x8 af[NPL];
+      unsigned cen[NPL][4], prv[NPL], nxt[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        af[pl] = *reinterpret_cast<const bf16x8*>(yfrag + pl * PLY + 16 * ks);
+        const __bf16* xp = xrow + pl * PLX + 8 * jc;
+        const uint4 cv = *reinterpret_cast<const uint4*>(xp);
+        cen[pl][0] = cv.x; cen[pl][1] = cv.y; cen[pl][2] = cv.z; cen[pl][3] = cv.w;
+        prv[pl] = *reinterpret_cast<const unsigned*>(xp - 2);
+        nxt[pl] = *reinterpret_cast<const unsigned*>(xp + 8);
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int df = dfs[s3];
+        bf16x8 bf[NPL];
+        if (df == 0) {
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) { uint4 u = make_uint4(cen[pl][0], cen[pl][1], cen[pl][2], cen[pl][3]); bf[pl] = *reinterpret_cast<bf16x8*>(&u); }
+        } else {
+          // element e of the shifted window is an edge row -> cleared
+          const int e = df > 0 ? pL - (8 * jc + 1) : pR - (8 * jc - 1);
+          unsigned mk[4];
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) mk[dd] = e == 2 * dd ? 0xFFFF0000u : (e == 2 * dd + 1 ? 0x0000FFFFu : 0xFFFFFFFFu);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            unsigned o[4];
+            if (df > 0) {
+              o[0] = __builtin_amdgcn_alignbit(cen[pl][1], cen[pl][0], 16); o[1] = __builtin_amdgcn_alignbit(cen[pl][2], cen[pl][1], 16);
+              o[2] = __builtin_amdgcn_alignbit(cen[pl][3], cen[pl][2], 16); o[3] = __builtin_amdgcn_alignbit(nxt[pl], cen[pl][3], 16);
+            } else {
+              o[0] = __builtin_amdgcn_alignbit(cen[pl][0], prv[pl], 16); o[1] = __builtin_amdgcn_alignbit(cen[pl][1], cen[pl][0], 16);
+              o[2] = __builtin_amdgcn_alignbit(cen[pl][2], cen[pl][1], 16); o[3] = __builtin_amdgcn_alignbit(cen[pl][3], cen[pl][2], 16);
+            }
+            uint4 u = make_uint4(o[0] & mk[0], o[1] & mk[1], o[2] & mk[2], o[3] & mk[3]);
+            bf[pl] = *reinterpret_cast<bf16x8*>(&u);
+          }
+        }
+#pragma unroll
+        for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa)
+            acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf[ord - qa], acc[s3], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int tap = 3 * gi + s3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[s3][r]);
+    }
+  }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(Yt);
+    *reinterpret_cast<float4*>(&red[rg * 64 + 4 * q]) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_ += red[r * 64 + tid];
+      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], s_);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void repack_kernel(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt,
                               long si, int rev, int accumulate) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1999,7 +2203,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
   WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc, chunks};
   dim3 grid((unsigned)((long)d->ntap * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8))), block(256);
   hipStream_t s = as_stream(stream);
-  if (d->precision == 0 && d->prologue == SE_PRO_NONE && !(d->epilogue & SE_EPI_DROP) && !d->up && d->st == 1 && d->sf == 1 &&
+  if (d->prologue == SE_PRO_NONE && !(d->epilogue & SE_EPI_DROP) && !d->up && d->st == 1 && d->sf == 1 &&
       d->Ti == d->To && d->Fi == d->Fo && d->ntap >= 3 && d->ntap % 3 == 0 && d->Fo >= 2 && d->To * d->Fo >= 64 &&
       getenv("SE_GEMM_NO_CONV3") == nullptr) {
     bool triples = true;
@@ -2011,13 +2215,17 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       }
       if (seen != 7) triples = false;
     }
-    if (triples) {
+    if (triples && (d->precision == 0 || d->Fo > 66)) {
       dim3 g3((unsigned)((long)(d->ntap / 3) * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8)));
-      hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
+      if (d->precision == 1) hipLaunchKernelGGL(wgrad3_bf16_kernel<2>, g3, block, 0, s, g);
+      else if (d->precision == 2) hipLaunchKernelGGL(wgrad3_bf16_kernel<3>, g3, block, 0, s, g);
+      else hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
       return se_check_launch("se_gemm_tap_wgrad(conv3)");
     }
   }
-  if (d->precision == 1 || d->precision == 2) {
+  // generic (non-triple) shapes: the six-product split kernel is VALU-bound by its own splits and measured slower than
+  // the fp32-MFMA kernel it is numerically equivalent to (77 vs 83 TFLOP/s) -> precision 2 runs the fp32 kernel there
+  if (d->precision == 1 || (d->precision == 2 && getenv("SE_WGRAD_FORCE_X6") != nullptr)) {
 #define LAUNCHWB(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 2>), grid, block, 0, s, g); \
                            else hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 3>), grid, block, 0, s, g); } while (0)
     switch (d->prologue) {

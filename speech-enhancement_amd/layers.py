@@ -24,15 +24,15 @@ CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_CONV_P
 
 
 # weight-gradient GEMMs of the same convolutions (contraction over pixels; same operand splits, transposed staging).
-# Default f32: measured on the dense-layer shapes the six-product kernel is VALU-bound by its own splits (77 TF vs 83
-# for fp32 MFMA); the three-product one reaches 116 TF and stays opt-in like the forward's.
-WGRAD_PRECISION = [{'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_WGRAD_PRECISION', 'f32')]]
+# 'bf16x6' routes the triple-tap layers with Fo > 66 to wgrad3_bf16_kernel (108 vs 94 TFLOP/s for the fp32 triple kernel);
+# every other shape runs the fp32-MFMA kernels under it (the generic six-product kernel is slower than fp32 MFMA).
+WGRAD_PRECISION = [{'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_WGRAD_PRECISION', 'bf16x6')]]
 
 
 def set_conv_precision(name, wgrad=None):
     global CONV_PRECISION
     CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[name]
-    WGRAD_PRECISION[0] = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[wgrad or ('bf16x3' if name == 'bf16x3' else 'f32')]
+    WGRAD_PRECISION[0] = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[wgrad or name]
 
 
 class DPHooks:
