@@ -33,8 +33,9 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
 
 # Arithmetic of the token-wise K = 64 -> N >= 128 layers (FF in-projection, qkv, pointwise-GLU): 'bf16x6' (default) routes
 # them to the row-panel kernel (exact three-way bf16 split, six MFMAs per product, fp32-equivalent); 'f32' keeps the
-# per-column-block fp32-MFMA kernel; 'bf16x3' is the opt-in two-way split.  Everything else (K > 64, N = 64, epilogues
-# that read a second operand, weight gradients) measured faster on the fp32-MFMA kernels and stays there.
+# per-column-block fp32-MFMA kernel; 'bf16x3' is the opt-in two-way split.  The prologue-free K >= 128 input gradients use
+# the generic split kernel; everything else (prologue GEMMs with K > 64, N = 64 with K = 64, accumulating epilogues, weight
+# gradients) measured faster on the fp32-MFMA kernels and stays there.
 LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'bf16x6')]
 WGRAD_LINEAR_PRECISION = 0
 
@@ -43,7 +44,8 @@ def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
     """plain row GEMM: M rows, one tap."""
     if 'precision' not in kw:
         second_operand = kw.get('epilogue', 0) & L.EPI_ACCUM
-        kw['precision'] = LINEAR_PRECISION if (C_in == 64 and N >= 128 and not second_operand) else 0
+        wide_k = C_in >= 128 and kw.get('prologue', L.PRO_NONE) == L.PRO_NONE      # K >= 128 -> 64 input gradients: 146 vs 181 us
+        kw['precision'] = LINEAR_PRECISION if ((C_in == 64 and N >= 128 and not second_operand) or wide_k) else 0
     return make_desc(1, 1, M, 1, M, [(0, 0)], C_in, lda or C_in, N, ldc or N, **kw)
 
 
@@ -52,7 +54,10 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     M = d.B * d.To * d.Fo
     L.call('se_gemm_tap', C.byref(d), L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Y), L.ptr(R), L.ptr(AUX),
            L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream(),
-           _key=(f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>'
+           _key=(f'conv3_bf16x{3 if d.precision == 1 else 6}'
+                 if d.precision in (1, 2) and d.C >= 32 and d.prologue == 0 and d.ntap >= 3 and d.ntap % 3 == 0 and not d.up
+                 and d.st == 1 and d.sf == 1 and d.Ti == d.To and d.Fi == d.Fo and not d.epilogue & (L.EPI_GLU | L.EPI_DROP) else
+                 f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>'
                  if d.precision in (1, 2) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1
                  and not d.epilogue & (L.EPI_ACCUM | L.EPI_STATS | L.EPI_SHUFFLE2) else
                  f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else

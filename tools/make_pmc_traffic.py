@@ -33,7 +33,7 @@ def fam(name):
         return f'gemm_tap_bf16x{3 if m.group(2) == "2" else 6}_kernel<{m.group(1)}>'
     m = re.match(r'conv3_bf16_kernel<(\d)>', n)
     if m:
-        return f'gemm_tap_bf16x{3 if m.group(1) == "2" else 6}_kernel<0>'
+        return f'conv3_bf16x{3 if m.group(1) == "2" else 6}'
     m = re.match(r'gemm_k64_panel_kernel<(\d), (\d), (true|false)>', n)
     if m:
         return f'gemm_k64_panel_bf16x{3 if m.group(2) == "2" else 6}<{m.group(1)}>'
@@ -43,8 +43,11 @@ def fam(name):
     m = re.match(r'wgrad_kernel<(\d)>', n)
     if m:
         return f'wgrad_kernel<{m.group(1)}>'
-    if n.startswith('wgrad3_kernel'):
+    if n.startswith('wgrad3_kernel') or n.startswith('wgrad3_bf16_kernel'):
         return 'wgrad_kernel<0>'
+    m = re.match(r'ff_(fwd|bwd)_kernel<(\d)>', n)
+    if m:
+        return f'ff_{m.group(1)}{"_dgrad" if m.group(1) == "bwd" else ""}_bf16x{3 if m.group(2) == "2" else 6}'
     if n.startswith('attn_bwd2_kernel'):
         return n + ' (+delta)'
     return n
