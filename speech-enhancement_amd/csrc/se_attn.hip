@@ -688,12 +688,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd2_kernel(AttnBwdArgs a, const
         for (int r = 0; r < 4; ++r) { dU[slot * TILE + (4 * g + r) * TS + c] = 0.f; }
       };
       int hi = 0;
+      // ONE barrier per step: between two barriers all waves are in the same step, where they own distinct key tiles
+      // and distinct offset tiles (see above).  The last low offset tile of a run (16 (qt - kt - 1)) is consumed after
+      // the NEXT barrier: there it can only meet offset tiles 16 (qt' - kt') of step t + 1, and
+      // qt - (t + 2w) - 1 == qt' - (t + 1 + 2w') forces w == w' (same wave, program order).
+      bool pend = false;
+      int pendD = 0;
       for (int t = 0; t < nkt; ++t) {
         int kt = t + sw;
         if (kt >= nkt) kt -= nkt;
         if (nwact == 1) kt = t;
         const int j0 = kt * 16, D0 = i0 - j0;
         __syncthreads();
+        if (pend) { consume(pendD, hi); pend = false; }
         if (active) {
           if (t == 0 || kt == 0) {           // start of a monotone run of key tiles: prime the window
 #pragma unroll
@@ -751,10 +758,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd2_kernel(AttnBwdArgs a, const
           }
           consume(D0, hi);
           hi = lo;
+          if (kt == nkt - 1 || t == nkt - 1) { pend = true; pendD = D0 - 16; }   // end of a run: the last low tile
         }
-        __syncthreads();
-        if (active && (kt == nkt - 1 || t == nkt - 1)) consume(D0 - 16, hi);   // end of a run: the last low tile
       }
+      __syncthreads();
+      if (pend) consume(pendD, hi);
       if (qok) *reinterpret_cast<float4*>(a.dQKV + qtok * 192 + head * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
     }
     __syncthreads();
