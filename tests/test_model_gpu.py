@@ -301,3 +301,22 @@ def test_scp_discriminator_step_matches_reference(S, golden):
     upd_ref = golden[k].astype(np.float64) - src.double().numpy()
     upd = ds['layers.17.weight_orig'].double().cpu().numpy() - src.double().numpy()
     assert rms(upd, upd_ref) < 2e-2 * np.sqrt(np.mean(upd_ref ** 2)) + 1e-9
+
+
+def test_graphed_inference_matches_eager(S):
+    """the HIP-graph replay of the batch-1 enhancement pipeline returns exactly what the eager predict() returns"""
+    import types
+    from speech_enhancement_amd import inference as INF
+    torch.manual_seed(0)
+    g = S.TSCNet(64, 201)
+    g.apply(S.kaiming_init)
+    g.cuda().eval()
+    cfg = types.SimpleNamespace(N_FFT=400, HOP_SAMPLES=100)
+    rng = np.random.RandomState(0)
+    enh = INF.GraphedEnhancer(g, cfg, 4850)
+    for seed in (1, 2):
+        x = (0.1 * np.random.RandomState(seed).randn(4850)).astype(np.float32)
+        ref = INF.predict(g, cfg, x)
+        out = enh(x)
+        assert out.shape == ref.shape and np.isfinite(out).all()
+        assert np.abs(out - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
