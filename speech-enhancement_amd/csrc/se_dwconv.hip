@@ -120,17 +120,20 @@ struct DwWgradArgs {
 
 // weight gradient, same thread layout (512 threads, 2 channels per lane, 8 slots x 8 positions): 31 float2
 // accumulators per lane, persistent over tiles, one flush per workgroup.
-__global__ __launch_bounds__(512) void dwconv_wgrad_kernel(DwWgradArgs a) {
+__global__ __launch_bounds__(512, 2) void dwconv_wgrad_kernel(DwWgradArgs a) {
   __shared__ __attribute__((aligned(16))) float xs[DW_ROWS * DW_C];
   __shared__ __attribute__((aligned(16))) float ys[DW_TILE * DW_C];
   const int tid = threadIdx.x, cl = tid & 63, ps = tid >> 6;
   const int n = a.g.n;
   const int tiles = (n + DW_TILE - 1) / DW_TILE;
   const long nitems = (long)a.g.nseq * tiles;
-  float2 acc[DW_K];
+  // explicit 2-wide vectors: v_pk_fma_f32 does both channels of a lane in one instruction (the scalar float2 form
+  // compiled to separate multiplies, packed adds and ~2 register moves per pair: 4.7x the VALU instructions)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[DW_K];
 #pragma unroll
-  for (int k = 0; k < DW_K; ++k) acc[k] = make_float2(0.f, 0.f);
-  float2 bacc = make_float2(0.f, 0.f);
+  for (int k = 0; k < DW_K; ++k) acc[k] = (f32x2){0.f, 0.f};
+  f32x2 bacc = {0.f, 0.f};
   constexpr int NPX = (DW_ROWS * 32 + 511) / 512, NPY = DW_TILE * 32 / 512;     // 6, 4
   float4 prx[NPX], pry[NPY];
   auto fetch = [&](long it) {
@@ -151,9 +154,11 @@ __global__ __launch_bounds__(512) void dwconv_wgrad_kernel(DwWgradArgs a) {
       pry[k] = (p < n) ? *reinterpret_cast<const float4*>(Gb + (long)p * rs + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  // no cross-tile register prefetch: without its 40 VGPRs the kernel fits 4 waves per SIMD, i.e. TWO of these
+  // 512-thread workgroups per CU (2 x 79 KB of LDS), and the other workgroup's compute covers this one's loads
   long it = blockIdx.x;
-  if (it < nitems) fetch(it);
   for (; it < nitems; it += gridDim.x) {
+    fetch(it);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < NPX; ++k) {
@@ -166,20 +171,19 @@ __global__ __launch_bounds__(512) void dwconv_wgrad_kernel(DwWgradArgs a) {
       *reinterpret_cast<float4*>(&ys[(i >> 5) * DW_C + (i & 31) * 4]) = pry[k];
     }
     __syncthreads();
-    if (it + gridDim.x < nitems) fetch(it + gridDim.x);
-    float2 dy[8];
+    f32x2 dy[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
-      dy[o] = *reinterpret_cast<const float2*>(&ys[(ps * 8 + o) * DW_C + cl * 2]);
-      bacc.x += dy[o].x; bacc.y += dy[o].y;
+      dy[o] = *reinterpret_cast<const f32x2*>(&ys[(ps * 8 + o) * DW_C + cl * 2]);
+      bacc += dy[o];
     }
 #pragma unroll
     for (int i = 0; i < 8 + DW_K - 1; ++i) {
-      float2 x = *reinterpret_cast<const float2*>(&xs[(ps * 8 + i) * DW_C + cl * 2]);
+      const f32x2 x = *reinterpret_cast<const f32x2*>(&xs[(ps * 8 + i) * DW_C + cl * 2]);
 #pragma unroll
       for (int o = 0; o < 8; ++o) {
         const int k = i - o;
-        if (k >= 0 && k < DW_K) { acc[k].x += dy[o].x * x.x; acc[k].y += dy[o].y * x.y; }
+        if (k >= 0 && k < DW_K) acc[k] = __builtin_elementwise_fma(dy[o], x, acc[k]);
       }
     }
   }
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(512) void dwconv_wgrad_kernel(DwWgradArgs a) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       const int k = k0 + kk;
-      float2 v = k < DW_K ? acc[k < DW_K ? k : 0] : bacc;      // slot k == 31 carries the bias gradient
-      *reinterpret_cast<float2*>(&red[((ps * 8 + kk) * DW_C) + cl * 2]) = v;
+      const f32x2 v = k < DW_K ? acc[k < DW_K ? k : 0] : bacc;      // slot k == 31 carries the bias gradient
+      *reinterpret_cast<f32x2*>(&red[((ps * 8 + kk) * DW_C) + cl * 2]) = v;
     }
     __syncthreads();
     for (int i = tid; i < 8 * DW_C; i += 512) {
