@@ -18,7 +18,10 @@ labels = {'est': q, 'clean': torch.full_like(q, 0.97), 'noisy': q * 0.5}
 w = (0.1, 0.9, 0.2, 0.05)
 for _ in range(2): TR.gan_step(G, D, og, od, clean, noisy, 'cmgan', w, labels=labels)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
     TR.gan_step(G, D, og, od, clean, noisy, 'cmgan', w, labels=labels)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=60))
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::')]
+rows.sort(key=lambda e: -e.count)
+for e in rows[:60]:
+    print(f'{e.key:28s} n={e.count:4d} cuda={e.device_time_total/1e3:7.3f} ms  {str(e.input_shapes)[:110]}')
