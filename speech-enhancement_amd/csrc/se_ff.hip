@@ -1,0 +1,460 @@
+// Fused feed-forward kernels of the Conformer blocks (forward; input-gradient chain + LayerNorm backward).
+#include "se_gemm_dev.h"
+
+// ---------------------------------------------------------------------------------------------
+// Fused feed-forward forward:  Y = X + alpha * Drop_o( W2 Drop_h( Swish( W1 LN(X) + b1 ) ) + b2 ),  H = W1 LN(X) + b1 kept
+// for the backward (conformer.py:53-71, Scale(0.5, PreNorm(FeedForward))).  Same skeleton as the K = 64 row-panel
+// kernel: every wave keeps the split LN(X) fragments of its 32 rows in registers and sweeps the hidden units in blocks
+// of 64; the block of H it has just produced is written out, activated, re-split and fed -- through a wave-private LDS
+// transpose -- straight back as the A operand of the second GEMM, whose 32 x 64 result stays in registers across the
+// sweep.  H is written once and never re-read in the forward (unfused: + one 4 M hid-byte read and a second kernel).
+struct FfArgs {
+  const float* X; const float* rowstats; const float* gamma; const float* beta;
+  const float* W1; const float* b1; const float* W2; const float* b2;
+  float* H; float* Y; long M; int hid; float drop_p; unsigned seed_h, seed_o; float alpha;
+};
+
+template <int NPL>
+__global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 workgroups per CU: VGPR + AGPR <= 256
+  constexpr int SB = 72, PB = 64 * SB, SP = 36;
+  __shared__ __attribute__((aligned(16))) __bf16 W1p[NPL * PB];
+  __shared__ __attribute__((aligned(16))) __bf16 W2p[NPL * PB];
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * SP];    // wave-private 32 x 32 transposes
+  __shared__ __attribute__((aligned(16))) float b1s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* cs = patch + wave * 32 * SP;
+  const long m0 = (long)blockIdx.x * 128;
+  const long row = m0 + wave * 32 + (lane & 31);
+  const int kg = lane >> 5;
+  const bool rok = row < a.M;
+  const unsigned thr = drop_thr(a.drop_p);
+  const float inv_keep = drop_inv_keep(a.drop_p);
+  const bool dr = a.drop_p > 0.f;
+
+  bf16x8 af1[4][NPL];
+  {
+    const float* __restrict__ xp = a.X + row * 64 + 8 * kg;
+    float mean = 0.f, rstd = 0.f;
+    if (rok) { float2 mr = *reinterpret_cast<const float2*>(a.rowstats + 2 * row); mean = mr.x; rstd = mr.y; }
+    float4 v[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v[ks][0] = rok ? *reinterpret_cast<const float4*>(xp + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[ks][1] = rok ? *reinterpret_cast<const float4*>(xp + 16 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * ks + 8 * kg + 4 * h;
+        const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c), bt = *reinterpret_cast<const float4*>(a.beta + c);
+        const float4 w = v[ks][h];
+        x[4 * h] = rok ? (w.x - mean) * rstd * gm.x + bt.x : 0.f;
+        x[4 * h + 1] = rok ? (w.y - mean) * rstd * gm.y + bt.y : 0.f;
+        x[4 * h + 2] = rok ? (w.z - mean) * rstd * gm.z + bt.z : 0.f;
+        x[4 * h + 3] = rok ? (w.w - mean) * rstd * gm.w + bt.w : 0.f;
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+        af1[ks][pl] = hh;
+      }
+    }
+  }
+  const int kq = tid & 15, r0 = tid >> 4;
+  const int nb = a.hid / 64;
+  float4 rw1[4], rw2[4];
+  auto load_w = [&](int jb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = r0 + 16 * i;
+      rw1[i] = *reinterpret_cast<const float4*>(a.W1 + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
+      rw2[i] = *reinterpret_cast<const float4*>(a.W2 + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
+    }
+  };
+  load_w(0);
+  f32x16 y0, y1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { y0[r] = 0.f; y1[r] = 0.f; }
+  const int frag = (lane & 31) * SB + 8 * kg;
+  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  for (int jb = 0; jb < nb; ++jb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      split_store<NPL>(rw1[i], &W1p[(r0 + 16 * i) * SB + kq * 4], PB);
+      split_store<NPL>(rw2[i], &W2p[(r0 + 16 * i) * SB + kq * 4], PB);
+    }
+    if (tid < 64) b1s[tid] = a.b1[jb * 64 + tid];
+    __syncthreads();
+    if (jb + 1 < nb) load_w(jb + 1);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 bf0[NPL], bf1[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf0[pl] = *reinterpret_cast<const bf16x8*>(&W1p[pl * PB + frag + 16 * ks]);
+        bf1[pl] = *reinterpret_cast<const bf16x8*>(&W1p[pl * PB + 32 * SB + frag + 16 * ks]);
+      }
+#pragma unroll
+      for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+        }
+    }
+    const float bb0 = b1s[col], bb1 = b1s[32 + col];
+    // per 32-column half of the block: transpose through the wave's patch, write H, re-split, second GEMM
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+        cs[rl * SP + col] = nt ? acc1[r] + bb1 : acc0[r] + bb0;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = rr + 8 * i;
+        const long rg = m0 + wave * 32 + rl;
+        if (rg < a.M)
+          *reinterpret_cast<float4*>(a.H + rg * a.hid + jb * 64 + nt * 32 + cq * 4) =
+              *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int ks = 2 * nt + k2;
+        float x[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int kl = 16 * k2 + 8 * kg + 4 * h;                 // column inside this half
+          const float4 pv = *reinterpret_cast<const float4*>(&cs[(lane & 31) * SP + kl]);
+          float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (dr) sc = drop_scale4(a.seed_h, (unsigned)(row * a.hid + jb * 64 + nt * 32 + kl), thr, inv_keep);
+          x[4 * h] = swishf_(pv.x) * sc.x; x[4 * h + 1] = swishf_(pv.y) * sc.y;
+          x[4 * h + 2] = swishf_(pv.z) * sc.z; x[4 * h + 3] = swishf_(pv.w) * sc.w;
+        }
+        bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          bf16x8 hh;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+          af2[pl] = hh;
+          bf0[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + frag + 16 * ks]);
+          bf1[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + 32 * SB + frag + 16 * ks]);
+        }
+#pragma unroll
+        for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa) {
+            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf0[ord - qa], y0, 0, 0, 0);
+            y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf1[ord - qa], y1, 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  // Y = X + alpha * Drop_o(acc + b2)
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      cs[rl * SP + col] = nt ? y1[r] : y0[r];
+    }
+    const int n = nt * 32 + cq * 4;
+    const float4 b2v = *reinterpret_cast<const float4*>(a.b2 + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = rr + 8 * i;
+      const long rg = m0 + wave * 32 + rl;
+      if (rg >= a.M) continue;
+      float4 v = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+      v.x += b2v.x; v.y += b2v.y; v.z += b2v.z; v.w += b2v.w;
+      if (dr) {
+        const float4 d4 = drop_scale4(a.seed_o, (unsigned)(rg * 64 + n), thr, inv_keep);
+        v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
+      }
+      const float4 xr = *reinterpret_cast<const float4*>(a.X + rg * 64 + n);
+      *reinterpret_cast<float4*>(a.Y + rg * 64 + n) =
+          make_float4(xr.x + a.alpha * v.x, xr.y + a.alpha * v.y, xr.z + a.alpha * v.z, xr.w + a.alpha * v.w);
+    }
+  }
+}
+
+// Fused feed-forward input-gradient chain (the two dgrad GEMMs of the same module):
+//   dZ  = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H))      [M, hid]   (W2s = alpha * W2, passed transposed)
+//   dLN = dZ W1                                               [M, 64]    (input of the LayerNorm backward)
+// dZ is written once (the weight-gradient GEMM reads it) and fed from registers / the wave's LDS patch into the second
+// GEMM; unfused it was written, re-read by a second kernel, and H and dY each cost one more pass.
+struct FfBwdArgs {
+  const float* dY; const float* H; const float* W2T; const float* W1T;
+  float* dZ; float* dLN; long M; int hid; float drop_p; unsigned seed_h, seed_o;
+  // optional fused LayerNorm backward (X != nullptr): dX = dY + dR2 + LNbwd(dLN) is written instead of dLN, and the
+  // gamma / beta gradients are accumulated (one atomic per channel per workgroup)
+  const float* X; const float* stats; const float* gamma; const float* dR2; float* dX; float* dgamma; float* dbeta;
+};
+
+template <int NPL>
+__global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
+  constexpr int SB = 72, PB = 64 * SB, SP = 36;
+  __shared__ __attribute__((aligned(16))) __bf16 Wa[NPL * PB];         // W2T block: rows = hidden units, k = channel
+  __shared__ __attribute__((aligned(16))) __bf16 Wb[NPL * PB];         // W1T block: rows = channel, k = hidden units
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * SP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* cs = patch + wave * 32 * SP;
+  const long m0 = (long)blockIdx.x * 128;
+  const long row = m0 + wave * 32 + (lane & 31);
+  const int kg = lane >> 5;
+  const bool rok = row < a.M;
+  const unsigned thr = drop_thr(a.drop_p);
+  const float inv_keep = drop_inv_keep(a.drop_p);
+  const bool dr = a.drop_p > 0.f;
+
+  bf16x8 af1[4][NPL];
+  {
+    const float* __restrict__ yp = a.dY + row * 64 + 8 * kg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * ks + 8 * kg + 4 * h;
+        float4 w = rok ? *reinterpret_cast<const float4*>(yp + 16 * ks + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dr && rok) {
+          const float4 d4 = drop_scale4(a.seed_o, (unsigned)(row * 64 + c), thr, inv_keep);
+          w.x *= d4.x; w.y *= d4.y; w.z *= d4.z; w.w *= d4.w;
+        }
+        x[4 * h] = w.x; x[4 * h + 1] = w.y; x[4 * h + 2] = w.z; x[4 * h + 3] = w.w;
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x8 hh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+        af1[ks][pl] = hh;
+      }
+    }
+  }
+  const int kq = tid & 15, r0 = tid >> 4;
+  const int nb = a.hid / 64;
+  f32x16 g0, g1;                              // dLN accumulators (32 rows x 64 channels)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+  const int frag = (lane & 31) * SB + 8 * kg;
+  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  for (int jb = 0; jb < nb; ++jb) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = r0 + 16 * i;
+      const float4 wa = *reinterpret_cast<const float4*>(a.W2T + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
+      const float4 wb = *reinterpret_cast<const float4*>(a.W1T + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
+      split_store<NPL>(wa, &Wa[j * SB + kq * 4], PB);
+      split_store<NPL>(wb, &Wb[j * SB + kq * 4], PB);
+    }
+    // pre-activations of this block for the Swish gradient: issued before the MFMAs, consumed in the epilogue
+    float4 hp[8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long rg = m0 + wave * 32 + rr + 8 * i;
+        hp[nt * 4 + i] = rg < a.M ? *reinterpret_cast<const float4*>(a.H + rg * a.hid + jb * 64 + nt * 32 + cq * 4)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    __syncthreads();
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 bf0[NPL], bf1[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wa[pl * PB + frag + 16 * ks]);
+        bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wa[pl * PB + 32 * SB + frag + 16 * ks]);
+      }
+#pragma unroll
+      for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+        cs[rl * SP + col] = nt ? acc1[r] : acc0[r];
+      }
+      // dZ in the row-major lane layout: coalesced H / dZ accesses; the result goes back into the patch in place
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = rr + 8 * i;
+        const long rg = m0 + wave * 32 + rl;
+        float4 v = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+        const float4 hz = hp[nt * 4 + i];
+        if (dr) {
+          const float4 d4 = drop_scale4(a.seed_h, (unsigned)(rg * a.hid + jb * 64 + nt * 32 + cq * 4), thr, inv_keep);
+          v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
+        }
+        v.x *= swish_gradf_(hz.x); v.y *= swish_gradf_(hz.y); v.z *= swish_gradf_(hz.z); v.w *= swish_gradf_(hz.w);
+        if (rg >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        else *reinterpret_cast<float4*>(a.dZ + rg * a.hid + jb * 64 + nt * 32 + cq * 4) = v;
+        *reinterpret_cast<float4*>(&cs[rl * SP + cq * 4]) = v;
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const int ks = 2 * nt + k2;
+        float x[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float4 pv = *reinterpret_cast<const float4*>(&cs[(lane & 31) * SP + 16 * k2 + 8 * kg + 4 * h]);
+          x[4 * h] = pv.x; x[4 * h + 1] = pv.y; x[4 * h + 2] = pv.z; x[4 * h + 3] = pv.w;
+        }
+        bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          bf16x8 hh;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
+          af2[pl] = hh;
+          bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + frag + 16 * ks]);
+          bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + 32 * SB + frag + 16 * ks]);
+        }
+#pragma unroll
+        for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa) {
+            g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf0[ord - qa], g0, 0, 0, 0);
+            g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf1[ord - qa], g1, 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+  }
+  float4 gv[2][4];                            // dLN of rows rr + 8 i, columns nt * 32 + 4 cq .. + 3
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+      cs[rl * SP + col] = nt ? g1[r] : g0[r];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gv[nt][i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * SP + cq * 4]);
+  }
+  if (a.X == nullptr) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long rg = m0 + wave * 32 + rr + 8 * i;
+        if (rg < a.M) *reinterpret_cast<float4*>(a.dLN + rg * 64 + nt * 32 + cq * 4) = gv[nt][i];
+      }
+    return;
+  }
+  // LayerNorm backward on the rows in registers: a row's 64 channels sit in the 8 lanes cq = 0..7 of one rr group
+  float ag[2][4] = {}, ab[2][4] = {};
+  float4 gm[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) gm[nt] = *reinterpret_cast<const float4*>(a.gamma + nt * 32 + cq * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long rg = m0 + wave * 32 + rr + 8 * i;
+    const bool ok = rg < a.M;
+    float mean = 0.f, rstd = 0.f;
+    if (ok) { const float2 mr = *reinterpret_cast<const float2*>(a.stats + 2 * rg); mean = mr.x; rstd = mr.y; }
+    float xh[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float4 xv = ok ? *reinterpret_cast<const float4*>(a.X + rg * 64 + nt * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float dv[4] = {gv[nt][i].x, gv[nt][i].y, gv[nt][i].z, gv[nt][i].w};
+      const float gl[4] = {gm[nt].x, gm[nt].y, gm[nt].z, gm[nt].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[nt][j] = (xs[j] - mean) * rstd;
+        dxh[nt][j] = dv[j] * gl[j];
+        s1 += dxh[nt][j]; s2 += dxh[nt][j] * xh[nt][j];
+        if (ok) { ag[nt][j] += dv[j] * xh[nt][j]; ab[nt][j] += dv[j]; }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
+    if (ok) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const long off = rg * 64 + nt * 32 + cq * 4;
+        const float4 r1 = *reinterpret_cast<const float4*>(a.dY + off);
+        float o4[4] = {r1.x, r1.y, r1.z, r1.w};
+        if (a.dR2) { const float4 r2 = *reinterpret_cast<const float4*>(a.dR2 + off); o4[0] += r2.x; o4[1] += r2.y; o4[2] += r2.z; o4[3] += r2.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
+        *reinterpret_cast<float4*>(a.dX + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
+    }
+  }
+  // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
+  float* redg = reinterpret_cast<float*>(Wa);         // [4 waves][64 channels][2]; the weight planes are free now
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sg = ag[nt][j], sb = ab[nt][j];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
+      if (rr == 0) { redg[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sg; redg[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sb; }
+    }
+  __syncthreads();
+  if (tid < 64) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sg += redg[(w * 64 + tid) * 2]; sb += redg[(w * 64 + tid) * 2 + 1]; }
+    atomicAdd(&a.dgamma[tid], sg);
+    atomicAdd(&a.dbeta[tid], sb);
+  }
+}
+
+extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN,
+                               long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision,
+                               const float* X, const float* stats, const float* gamma, const float* dR2, float* dX,
+                               float* dgamma, float* dbeta, void* stream) {
+  SE_REQUIRE(dY && H && W2T && W1T && dZ, "ff_bwd_dgrad: null operand");
+  SE_REQUIRE(X ? (stats && gamma && dX && dgamma && dbeta) : dLN != nullptr,
+             "ff_bwd_dgrad: either dLN, or all of X / stats / gamma / dX / dgamma / dbeta (fused LayerNorm backward)");
+  SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_bwd_dgrad: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
+  SE_REQUIRE(precision == 1 || precision == 2, "ff_bwd_dgrad: precision must be 1 (bf16x3) or 2 (bf16x6)");
+  SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_bwd_dgrad: drop_p=%f out of range", drop_p);
+  SE_REQUIRE(M * (long)hid < 4294967296L, "ff_bwd_dgrad: dropout index exceeds 32 bits");
+  FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, X, stats, gamma, dR2, dX, dgamma, dbeta};
+  dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(ff_bwd_kernel<3>, grid, block, 0, as_stream(stream), a);
+  return se_check_launch("se_ff_bwd_dgrad");
+}
+
+extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
+                         const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid,
+                         float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
+  SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && H && Y, "ff_fwd: null operand");
+  SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_fwd: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
+  SE_REQUIRE(precision == 1 || precision == 2, "ff_fwd: precision must be 1 (bf16x3) or 2 (bf16x6)");
+  SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_fwd: drop_p=%f out of range", drop_p);
+  SE_REQUIRE(M * (long)hid < 4294967296L, "ff_fwd: dropout index exceeds 32 bits");
+  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha};
+  dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(ff_fwd_kernel<3>, grid, block, 0, as_stream(stream), a);
+  return se_check_launch("se_ff_fwd");
+}
+

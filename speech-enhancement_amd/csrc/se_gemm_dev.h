@@ -1,0 +1,399 @@
+// Device-side building blocks shared by the tap-GEMM translation units (se_gemm.hip, se_ff.hip, se_wgrad.hip):
+// descriptor decoding, XCD-aware work placement, prologues, the counter-based dropout hash, the vectorised epilogues,
+// the bf16 operand split.  Everything is static / inline: each TU gets its own copy.
+#pragma once
+#include "se_common.h"
+#include <stdlib.h>
+
+struct GemmArgs {
+  se_gemm_desc d;
+  const float* A; const float* W; const float* bias; float* Y; const float* R; float* AUX;
+  const float* rowstats; const float* ps; const float* pb; double* stats;
+  int ncb;      // column blocks per row tile
+  int tiles;    // row tiles per batch entry
+  int nouter;   // B * tiles
+  int contig;   // 1: every XCD sweeps a contiguous range of row tiles (tap convolutions: the dt-shifted rows of a
+                //    tile are the dt = 0 rows of a tile the same L2 has just seen); 0: round-robin
+};
+
+// Workgroups are dispatched round-robin over the 8 XCDs, each with a private L2.  The `ninner` siblings of one
+// `outer` work item (column blocks sharing an A tile; (tap, channel, n) blocks sharing a row chunk) are decoded so
+// that they sit on the same XCD and next to each other in dispatch order: the shared operand is fetched into that
+// L2 once instead of once per sibling from the fabric.  The launch pads `nouter` to a multiple of 8.
+struct WorkId { int inner, outer; };
+static __device__ __forceinline__ WorkId decode_work(int ninner, int nouter, int contig) {
+  const unsigned w = blockIdx.x, xcd = w & 7u, slot = w >> 3;
+  const unsigned inner = slot % (unsigned)ninner, ol = slot / (unsigned)ninner;
+  const unsigned per = ((unsigned)nouter + 7u) >> 3;
+  return {(int)inner, (int)(contig ? xcd * per + ol : ol * 8u + xcd)};
+}
+
+// source pixel (index inside batch entry b's grid) of output pixel (t, f) for one tap; -1 when outside
+static __device__ __forceinline__ int src_pixel_in(const se_gemm_desc& d, int t, int f, int tap) {
+  int ti, fi;
+  if (!d.up) {
+    ti = t * d.st + d.dt[tap];
+    fi = f * d.sf + d.df[tap];
+    if (ti < 0 || ti >= d.Ti || fi < 0 || fi >= d.Fi) return -1;
+  } else {
+    int tt = t + d.dt[tap], ff = f + d.df[tap];
+    if (tt < 0 || ff < 0 || (tt % d.st) != 0 || (ff % d.sf) != 0) return -1;
+    ti = tt / d.st; fi = tt >= 0 ? ff / d.sf : 0;
+    if (ti >= d.Ti || fi >= d.Fi) return -1;
+  }
+  return ti * d.Fi + fi;
+}
+static __device__ __forceinline__ long src_pixel(const se_gemm_desc& d, int b, int t, int f, int tap) {
+  int ti, fi;
+  if (!d.up) {
+    ti = t * d.st + d.dt[tap];
+    fi = f * d.sf + d.df[tap];
+    if (ti < 0 || ti >= d.Ti || fi < 0 || fi >= d.Fi) return -1;
+  } else {
+    int tt = t + d.dt[tap], ff = f + d.df[tap];
+    if (tt < 0 || ff < 0 || (tt % d.st) != 0 || (ff % d.sf) != 0) return -1;
+    ti = tt / d.st; fi = ff / d.sf;
+    if (ti >= d.Ti || fi >= d.Fi) return -1;
+  }
+  return ((long)b * d.Ti + ti) * d.Fi + fi;
+}
+
+// Counter-based dropout mask.  Elements are hashed in aligned groups of 4 (every user processes float4s): one murmur3
+// finalizer of (seed, idx >> 2) plus one multiply-xorshift step give 64 bits = four 16-bit fields, element j of the
+// group is kept iff field_j >= thr16 = round(p * 65536); survivors are scaled by 65536 / (65536 - thr16), the exact
+// inverse of the realised keep probability.  (The per-element 32-bit hash this replaces cost 3 quarter-rate integer
+// multiplies per element -- more issue slots than the Swish it was fused with.)  The same (seed, index) pair is
+// re-evaluated in the backward kernels, so no mask is ever stored.
+static __device__ __forceinline__ void drop_fields(unsigned seed, unsigned grp, unsigned (&f)[4]) {
+  unsigned x = grp * 0x9E3779B1u ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  unsigned y = x * 0x9E3779B1u + 0x7F4A7C15u;
+  y ^= y >> 15;
+  f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
+}
+// scales of the 4 elements idx .. idx + 3 (idx a multiple of 4)
+static __device__ __forceinline__ float4 drop_scale4(unsigned seed, unsigned idx, unsigned thr, float inv_keep) {
+  unsigned f[4];
+  drop_fields(seed, idx >> 2, f);
+  return make_float4(f[0] >= thr ? inv_keep : 0.f, f[1] >= thr ? inv_keep : 0.f, f[2] >= thr ? inv_keep : 0.f,
+                     f[3] >= thr ? inv_keep : 0.f);
+}
+static __device__ __forceinline__ float drop_scale(unsigned seed, unsigned idx, unsigned thr, float inv_keep) {
+  unsigned f[4];
+  drop_fields(seed, idx >> 2, f);
+  const unsigned j = idx & 3u;
+  const unsigned fj = j == 0 ? f[0] : (j == 1 ? f[1] : (j == 2 ? f[2] : f[3]));
+  return fj >= thr ? inv_keep : 0.f;
+}
+static __device__ __forceinline__ unsigned drop_thr(float p) { return (unsigned)(p * 65536.0f + 0.5f); }
+static __device__ __forceinline__ float drop_inv_keep(float p) { return 65536.0f / (65536.0f - (float)drop_thr(p)); }
+
+// ps4 / pb4: the per-channel scale / shift of this float4's 4 channels (LN gamma / beta, BN-affine), fetched with the
+// tile as two 16-B loads -- per-element scalar loads here cost 8 VMEM instructions per float4 of A.
+template <int PRO>
+static __device__ __forceinline__ float4 apply_pro(float4 v, int c, int C, float mean, float rstd,
+                                                   float4 ps4, float4 pb4, long pix, unsigned seed,
+                                                   unsigned thr, float inv_keep) {
+  if (PRO == SE_PRO_NONE) return v;
+  float x[4] = {v.x, v.y, v.z, v.w};
+  const float ps[4] = {ps4.x, ps4.y, ps4.z, ps4.w}, pb[4] = {pb4.x, pb4.y, pb4.z, pb4.w};
+  float dsc[4] = {1.f, 1.f, 1.f, 1.f};
+  if (PRO == SE_PRO_SWISH_DROP || PRO == SE_PRO_DROP) {      // c and C are multiples of 4: one aligned group
+    const float4 d4 = drop_scale4(seed, (unsigned)(pix * C + c), thr, inv_keep);
+    dsc[0] = d4.x; dsc[1] = d4.y; dsc[2] = d4.z; dsc[3] = d4.w;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int cc = c + j;
+    if (cc < C) {
+      if (PRO == SE_PRO_LN) x[j] = (x[j] - mean) * rstd * ps[j] + pb[j];
+      else if (PRO == SE_PRO_SWISH) x[j] = swishf_(x[j]);
+      else if (PRO == SE_PRO_AFFINE_SWISH) x[j] = swishf_(x[j] * ps[j] + pb[j]);
+      else if (PRO == SE_PRO_SWISH_DROP) x[j] = swishf_(x[j]) * dsc[j];
+      else if (PRO == SE_PRO_DROP) x[j] = x[j] * dsc[j];
+    } else {
+      x[j] = 0.f;
+    }
+  }
+  return make_float4(x[0], x[1], x[2], x[3]);
+}
+template <int PRO>
+static __device__ __forceinline__ void load_pro_vec(const float* ps, const float* pb, int c, bool ok, float4& ps4, float4& pb4) {
+  if (PRO == SE_PRO_LN || PRO == SE_PRO_AFFINE_SWISH) {
+    ps4 = ok ? *reinterpret_cast<const float4*>(ps + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    pb4 = ok ? *reinterpret_cast<const float4*>(pb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// Vectorised epilogue (bias / dropout / swish-gradient / residual / accumulate / plain store): each 32x32 accumulator
+// is transposed through a wave-private LDS patch so that every lane then owns 4 consecutive output columns: the
+// AUX / R reads and the Y writes are 16-byte accesses (8 lanes = one 128-B row segment) and there are 4 of them per
+// lane and tile instead of 16 four-byte ones.  cs: the wave's [32][cs_ld] patch (reuses the A staging tile).
+template <bool HASPRE = false>
+static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
+                                                         int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
+                                                         float inv_keep, float* red, const float* bias_s,
+                                                         const float4 (&pre)[8] = {}) {   // pre[nt*4+i]: AUX / R values fetched early
+  const se_gemm_desc& d = g.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Mb = d.To * d.Fo, ep = d.epilogue;
+  const long ptile = (long)b * Mb + m0;
+  float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
+  const float* __restrict__ Xb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
+  const float* __restrict__ Rb = g.R ? g.R + ptile * d.ldr + d.r_off : nullptr;
+  const unsigned pdrop = (unsigned)ptile;
+  const int col = lane & 31, half = lane >> 5;
+  const int cq = lane & 7, rr = lane >> 3;          // read-back role: float4 column, row within an 8-row pass
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const f32x16& acc = nt ? acc1 : acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc[r];
+    const int n = by * 64 + nt * 32 + cq * 4;        // first of this lane's 4 output columns
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), qsum = ssum;
+    if (n < d.N) {                                   // N % 4 == 0 (host-checked)
+      const float4 bias4 = *reinterpret_cast<const float4*>(bias_s + nt * 32 + cq * 4);   // staged before the K loop
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + rr + 8 * i;
+        if (m0 + row >= Mb) continue;
+        float4 v = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
+        v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+        if (ep & SE_EPI_STATS) {
+          ssum.x += v.x; ssum.y += v.y; ssum.z += v.z; ssum.w += v.w;
+          qsum.x += v.x * v.x; qsum.y += v.y * v.y; qsum.z += v.z * v.z; qsum.w += v.w * v.w;
+        }
+        if (ep & SE_EPI_DROP) {
+          const unsigned pe = (pdrop + (unsigned)row) * (unsigned)d.N + (unsigned)n;
+          const float4 d4 = drop_scale4(d.epi_seed, pe, thr, inv_keep);       // pe is a multiple of 4 (N % 4 == 0, n % 4 == 0)
+          v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
+        }
+        if (ep & SE_EPI_SWISH_GRAD) {
+          float4 z = HASPRE ? pre[nt * 4 + i] : *reinterpret_cast<const float4*>(Xb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n));
+          v.x *= swish_gradf_(z.x); v.y *= swish_gradf_(z.y); v.z *= swish_gradf_(z.z); v.w *= swish_gradf_(z.w);
+        }
+        if (ep & SE_EPI_RESID) {
+          float4 rv = HASPRE ? pre[nt * 4 + i] : *reinterpret_cast<const float4*>(Rb + ((unsigned)row * (unsigned)d.ldr + (unsigned)n));
+          v.x = rv.x + d.alpha * v.x; v.y = rv.y + d.alpha * v.y; v.z = rv.z + d.alpha * v.z; v.w = rv.w + d.alpha * v.w;
+        }
+        float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
+        if (ep & SE_EPI_ACCUM) { float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *yp = v;
+      }
+    }
+    if (ep & SE_EPI_STATS) {      // fold the 8 row-lanes that share this column group, park per-wave partials in LDS
+      float sv[8] = {ssum.x, ssum.y, ssum.z, ssum.w, qsum.x, qsum.y, qsum.z, qsum.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { sv[k] += __shfl_xor(sv[k], 8, 64); sv[k] += __shfl_xor(sv[k], 16, 64); sv[k] += __shfl_xor(sv[k], 32, 64); }
+      if (rr == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sv[j]; red[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sv[4 + j]; }
+      }
+    }
+  }
+  if (ep & SE_EPI_STATS) {
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+      float s_ = 0.f, q_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s_ += red[(w * 64 + tid) * 2]; q_ += red[(w * 64 + tid) * 2 + 1]; }
+      int nn = by * 64 + tid;
+      if (nn < d.N) {
+        atomicAdd(&g.stats[((long)b * d.N + nn) * 2], (double)s_);
+        atomicAdd(&g.stats[((long)b * d.N + nn) * 2 + 1], (double)q_);
+      }
+    }
+  }
+}
+// the vector epilogue's bias operands go to LDS before the K loop (its barriers order the hand-off): a global load
+// at the tail of the workgroup would expose one full memory latency per tile
+static __device__ __forceinline__ void stage_bias(const GemmArgs& g, int by, float* bias_s) {
+  if (threadIdx.x < 64) {
+    const int n = by * 64 + threadIdx.x;
+    bias_s[threadIdx.x] = ((g.d.epilogue & SE_EPI_BIAS) && n < g.d.N) ? g.bias[n] : 0.f;
+  }
+}
+// GLU flavour of the vectorised epilogue: accumulator 0 = value columns, accumulator 1 = gate columns of the same 32
+// outputs.  The gate tile is transposed first and parked in registers, then the value tile; Y = a * sigmoid(g) and
+// the pre-GLU Z (both halves) leave as float4 stores.
+static __device__ __forceinline__ void gemm_epilogue_glu_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
+                                                             int m0, int by, int b, float* cs, int cs_ld) {
+  const se_gemm_desc& d = g.d;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Mb = d.To * d.Fo, No = d.N / 2;
+  const long ptile = (long)b * Mb + m0;
+  float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
+  float* __restrict__ Zb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
+  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  const int n = by * 32 + cq * 4;                  // value column; gate column = No + n
+  float4 gate[4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc1[r];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gate[i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc0[r];
+  if (n >= No) return;
+  float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+  if (d.epilogue & SE_EPI_BIAS) { ba = *reinterpret_cast<const float4*>(g.bias + n); bg = *reinterpret_cast<const float4*>(g.bias + No + n); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 32 + rr + 8 * i;
+    if (m0 + row >= Mb) continue;
+    float4 a = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
+    float4 gt = gate[i];
+    a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
+    gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
+    if (Zb) {
+      *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n)) = a;
+      *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)(No + n))) = gt;
+    }
+    *reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n)) =
+        make_float4(a.x * sigmoidf_(gt.x), a.y * sigmoidf_(gt.y), a.z * sigmoidf_(gt.z), a.w * sigmoidf_(gt.w));
+  }
+}
+static __device__ __forceinline__ bool epilogue_glu_vec_ok(const se_gemm_desc& d) {
+  return (d.epilogue & SE_EPI_GLU) && !(d.epilogue & (SE_EPI_STATS | SE_EPI_SHUFFLE2 | SE_EPI_DROP | SE_EPI_RESID | SE_EPI_ACCUM |
+                                                      SE_EPI_SWISH_GRAD | 256)) &&
+         (d.N & 7) == 0 && (d.ldc & 3) == 0 && (d.c_off & 3) == 0 && (d.ldx & 3) == 0 && (d.x_off & 3) == 0;
+}
+static __device__ __forceinline__ bool epilogue_vec_ok(const se_gemm_desc& d) {
+  return !(d.epilogue & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | 256)) && (d.N & 3) == 0 && (d.ldc & 3) == 0 &&
+         (d.c_off & 3) == 0 && (d.ldx & 3) == 0 && (d.x_off & 3) == 0 && (d.ldr & 3) == 0 && (d.r_off & 3) == 0;
+}
+
+// epilogue shared by the fp32 and the split-bf16 kernels: acc0 / acc1 = the wave's two 32x32 accumulators
+static __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1, int m0,
+                                                     int by, int b, float* red, unsigned thr, float inv_keep) {
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Mb = d.To * d.Fo;
+  const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
+  // ------------------------------ epilogue ------------------------------
+  const int ep = d.epilogue;
+  const int col = lane & 31, half = lane >> 5;
+  int n0, n1;           // original output-channel index of the two accumulators' column
+  bool nok0, nok1;
+  if (glu) {
+    n0 = by * 32 + col; n1 = d.N / 2 + n0;
+    nok0 = nok1 = n0 < d.N / 2;
+  } else {
+    n0 = by * 64 + col; n1 = n0 + 32;
+    nok0 = n0 < d.N; nok1 = n1 < d.N;
+  }
+  float bias0 = 0.f, bias1 = 0.f;
+  if (ep & SE_EPI_BIAS) {
+    if (nok0) bias0 = g.bias[n0];
+    if (nok1) bias1 = g.bias[n1];
+  }
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  const int No = d.N / 2;   // SHUFFLE2 / GLU output channels
+  // wave-uniform tile bases; lane offsets are 32-bit (a 128-row tile spans < 2^31 elements)
+  const long ptile = (long)b * Mb + m0;
+  float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
+  float* __restrict__ Xb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
+  const float* __restrict__ Rb = g.R ? g.R + ptile * d.ldr + d.r_off : nullptr;
+  const unsigned pdrop = (unsigned)ptile;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int m = m0 + row;
+    if (m >= Mb) continue;
+    float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+    if (ep & SE_EPI_STATS) { if (nok0) { s0 += v0; q0 += v0 * v0; } if (nok1) { s1 += v1; q1 += v1 * v1; } }
+    const unsigned yo = (unsigned)row * (unsigned)d.ldc;
+    if (glu) {
+      if (nok0) {
+        if (Xb) { const unsigned xo = (unsigned)row * (unsigned)d.ldx; Xb[xo + n0] = v0; Xb[xo + n1] = v1; }
+        Yb[yo + n0] = v0 * sigmoidf_(v1);
+      }
+      continue;
+    }
+    if (ep & SE_EPI_DROP) {       // dropout of the (bias-added) result, or of the hidden activation whose
+                                   // gradient this is (with SWISH_GRAD): mask index = output element
+      const unsigned pe = (pdrop + (unsigned)row) * (unsigned)d.N;
+      v0 *= drop_scale(d.epi_seed, pe + n0, thr, inv_keep);
+      v1 *= drop_scale(d.epi_seed, pe + n1, thr, inv_keep);
+    }
+    if (ep & SE_EPI_SWISH_GRAD) {
+      const unsigned xo = (unsigned)row * (unsigned)d.ldx;
+      if (nok0) v0 *= swish_gradf_(Xb[xo + n0]);
+      if (nok1) v1 *= swish_gradf_(Xb[xo + n1]);
+    }
+    if (ep & SE_EPI_RESID) {
+      const unsigned ro = (unsigned)row * (unsigned)d.ldr;
+      if (nok0) v0 = Rb[ro + n0] + d.alpha * v0;
+      if (nok1) v1 = Rb[ro + n1] + d.alpha * v1;
+    }
+    if (ep & SE_EPI_SHUFFLE2) {
+      int t = m / d.Fo, f = m - t * d.Fo;
+      float* __restrict__ Ys = g.Y + ((long)b * d.To * 2 * d.Fo) * d.ldc + d.c_off;
+      if (nok0) { unsigned po = (unsigned)(t * 2 * d.Fo + 2 * f + (n0 >= No));
+                  Ys[po * (unsigned)d.ldc + (n0 >= No ? n0 - No : n0)] = v0; }
+      if (nok1) { unsigned po = (unsigned)(t * 2 * d.Fo + 2 * f + (n1 >= No));
+                  Ys[po * (unsigned)d.ldc + (n1 >= No ? n1 - No : n1)] = v1; }
+      continue;
+    }
+    if (ep & 256) { if (v0 == 12345.678f && v1 == 0.1234f) Yb[yo + n0] = v0; continue; }      // ablation: no stores
+    if (ep & SE_EPI_ACCUM) { if (nok0) Yb[yo + n0] += v0; if (nok1) Yb[yo + n1] += v1; }
+    else { if (nok0) Yb[yo + n0] = v0; if (nok1) Yb[yo + n1] = v1; }
+  }
+  if (ep & SE_EPI_STATS) {
+    // rows live in registers (16 per lane) and in the two lane halves: fold halves, then waves via LDS
+    s0 += __shfl_xor(s0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+    s1 += __shfl_xor(s1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+    if (half == 0) {
+      red[(wave * 64 + col) * 2] = s0; red[(wave * 64 + col) * 2 + 1] = q0;
+      red[(wave * 64 + 32 + col) * 2] = s1; red[(wave * 64 + 32 + col) * 2 + 1] = q1;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s += red[(w * 64 + tid) * 2]; q += red[(w * 64 + tid) * 2 + 1]; }
+      int n = by * 64 + tid;
+      if (n < d.N) {
+        int ns = (ep & SE_EPI_SHUFFLE2) ? (n >= No ? n - No : n) : n;
+        int Ns = (ep & SE_EPI_SHUFFLE2) ? No : d.N;
+        atomicAdd(&g.stats[((long)b * Ns + ns) * 2], (double)s);
+        atomicAdd(&g.stats[((long)b * Ns + ns) * 2 + 1], (double)q);
+      }
+    }
+  }
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// NPL = 2: x = hi + lo (16 mantissa bits), products hh + hl + lh;  NPL = 3: x = hi + mid + lo (all 24 bits of an fp32:
+// the split is exact), products hh + hm + mh + hl + lh + mm, dropped terms <= 2^-24 relative -> fp32-equivalent.
+template <int NPL>
+static __device__ __forceinline__ void split_store(float4 v, __bf16* p, int plane_stride) {
+  float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    bf16x4 h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = (__bf16)x[j]; x[j] -= (float)h[j]; }
+    *reinterpret_cast<bf16x4*>(p + q * plane_stride) = h;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+static int check_desc(const se_gemm_desc* d) {
+  SE_REQUIRE(d->ntap >= 1 && d->ntap <= SE_MAX_TAPS, "gemm: ntap %d out of range", d->ntap);
+  SE_REQUIRE(d->C > 0 && (d->C % 4) == 0, "gemm: C=%d must be a positive multiple of 4", d->C);
+  SE_REQUIRE((d->lda % 4) == 0 && (d->a_off % 4) == 0, "gemm: lda/a_off must be multiples of 4");
+  SE_REQUIRE((d->ldw % 4) == 0 && d->ldw >= d->ntap * d->C, "gemm: ldw=%d too small / unaligned", d->ldw);
+  SE_REQUIRE(d->B > 0 && d->To > 0 && d->Fo > 0 && d->Ti > 0 && d->Fi > 0, "gemm: empty grid");
+  SE_REQUIRE(d->st >= 1 && d->sf >= 1, "gemm: bad strides");
+  SE_REQUIRE(d->N > 0, "gemm: N=%d", d->N);
+  if (d->prologue == SE_PRO_LN) SE_REQUIRE(d->ntap == 1, "gemm: LN prologue needs ntap==1");
+  SE_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f out of range", d->drop_p);
+  if (d->prologue == SE_PRO_SWISH_DROP || d->prologue == SE_PRO_DROP || (d->epilogue & SE_EPI_DROP))
+    SE_REQUIRE((long)d->B * d->Ti * d->Fi * (d->C > d->N ? d->C : d->N) < 4294967296L, "gemm: dropout index exceeds 32 bits");
+  return 0;
+}
+

@@ -1,0 +1,724 @@
+// Weight-gradient kernels of the tap-GEMM family (fp32 MFMA and split-bf16, generic and triple-tap).
+#include "se_gemm_dev.h"
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient:  dW[n][tap*C + c] += sum_m dY[m][n] * pro(A[src(m,tap)][c])
+// grid: (row chunks, ntap * ceil(C/64), ceil(N/64)); 4 waves = 2x2 tiles of 32(n) x 32(c).
+struct WgradArgs {
+  se_gemm_desc d;
+  const float* A; const float* dY; float* dW; float* dbias;
+  const float* rowstats; const float* ps; const float* pb;
+  long rows_per_chunk;
+  int nchunks;
+};
+
+template <int PRO>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
+  constexpr int SY = 68;            // 64 + 4 pad (float4-aligned rows)
+  constexpr int MR = 64;            // rows staged per step (32 MFMAs per wave between barriers)
+  __shared__ __attribute__((aligned(16))) float Ys[MR * SY];
+  __shared__ __attribute__((aligned(16))) float Xs[MR * SY];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64;
+  // siblings = the (tap, channel block, n block) workgroups of one row chunk: same XCD, adjacent in dispatch order,
+  // so the dY / A rows they share come out of that XCD's L2
+  const int nnb = (d.N + 63) / 64;
+  const WorkId wk_ = decode_work(d.ntap * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int tap = tc / ncb, cb = tc - tap * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, r0 = tid >> 4;    // float4 column / tile row (4 passes of 16 rows)
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  const bool lin = d.ntap == 1 && !d.up && d.st == 1 && d.sf == 1 && d.dt[0] == 0 && d.df[0] == 0 &&
+                   d.Ti == d.To && d.Fi == d.Fo;
+  const int TiFi = d.Ti * d.Fi;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+
+  const int n_ld = nb * 64 + q * 4;        // dY column of this thread's float4
+  const int c_ld = cb * 64 + q * 4;        // A channel of this thread's float4
+  const bool nok = n_ld < d.N;             // N multiple of 4 (checked on host)
+  const bool cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+
+  float4 ry[4], rx[4];
+  float mean[4] = {}, rstd[4] = {};
+  bool xok[4];
+  unsigned xpix[4];
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
+  const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
+  // (batch entry, t, f) of this thread's 4 rows, advanced by MR rows per step with adds and compares: the two
+  // divisions per row and step they replace (one of them 64-bit) cost more VALU issue slots than the step's MFMAs
+  int cb_[4], ct_[4], cf_[4];
+  const int adv_t = MR / d.Fo, adv_f = MR - adv_t * d.Fo;
+  if (!lin) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long mg = mbeg + r0 + i * 16;
+      cb_[i] = (int)(mg / Mb);
+      int m = (int)(mg - (long)cb_[i] * Mb);
+      ct_[i] = m / d.Fo;
+      cf_[i] = m - ct_[i] * d.Fo;
+    }
+  }
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long mg = mbase + r0 + i * 16;
+      bool ok = mg < mend;
+      long p = -1;
+      if (lin) { if (ok && cok) p = mg; }
+      else {
+        if (ok && cok) {
+          int pin = src_pixel_in(d, ct_[i], cf_[i], tap);
+          p = pin >= 0 ? (long)cb_[i] * TiFi + pin : -1;
+        }
+        cf_[i] += adv_f; ct_[i] += adv_t;
+        if (cf_[i] >= d.Fo) { cf_[i] -= d.Fo; ct_[i] += 1; }
+        while (ct_[i] >= d.To) { ct_[i] -= d.To; cb_[i] += 1; }
+      }
+      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy_drop && ok && nok) {
+        unsigned base = (unsigned)(mg * d.N + n_ld);
+        const float4 d4 = drop_scale4(d.epi_seed, base, thr, inv_keep);
+        ry[i].x *= d4.x; ry[i].y *= d4.y; ry[i].z *= d4.z; ry[i].w *= d4.w;
+      }
+      xok[i] = p >= 0;
+      xpix[i] = (unsigned)p;
+      rx[i] = xok[i] ? *reinterpret_cast<const float4*>(Ag + p * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO == SE_PRO_LN) {
+        float2 mr = xok[i] ? *reinterpret_cast<const float2*>(g.rowstats + 2 * p) : make_float2(0.f, 0.f);
+        mean[i] = mr.x;
+        rstd[i] = mr.y;
+      }
+    }
+  };
+
+  float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
+  load_pro_vec<PRO>(g.ps, g.pb, c_ld, cok, ps4, pb4);      // this thread's 4 channels never change
+  if (mbeg < mend) load_tiles(mbeg);
+  for (long mb = mbeg; mb < mend; mb += MR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = rx[i];
+      if (PRO != SE_PRO_NONE && xok[i])
+        v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], ps4, pb4, xpix[i], d.pro_seed, thr, inv_keep);
+      *reinterpret_cast<float4*>(&Xs[(r0 + i * 16) * SY + q * 4]) = v;
+      *reinterpret_cast<float4*>(&Ys[(r0 + i * 16) * SY + q * 4]) = ry[i];
+    }
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+    // MFMA step s pairs tile rows {s, s + 32}: lane half h supplies row s + 32 h
+    const float* yp = &Ys[(lane >> 5) * 32 * SY + wn * 32 + (lane & 31)];
+    const float* xp = &Xs[(lane >> 5) * 32 * SY + wc * 32 + (lane & 31)];
+#pragma unroll
+    for (int s = 0; s < 32; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yp[s * SY], xp[s * SY], acc, 0, 0, 0);
+    if (do_bias && tid < 64) {
+#pragma unroll
+      for (int r = 0; r < MR; ++r) bsum += Ys[r * SY + tid];
+    }
+    __syncthreads();
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[r]);
+  }
+  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], bsum);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the unit-stride convolutions whose taps come in frequency triples (see conv3_bf16_kernel): one
+// workgroup owns (row chunk, dt, channel block, n block) and accumulates the THREE taps df = -1, 0, +1 at once from one
+// dY tile and one 66-row halo tile of A (flattened pixels m - 1 .. m + 64 of the dt-shifted rows): a third of the
+// loads and LDS stores per MFMA of wgrad_kernel.  Rows whose frequency neighbour is padding are masked through a
+// per-row multiplier table (mask[df][row], built at staging time).  fp32 MFMA.
+__global__ __launch_bounds__(256) void wgrad3_kernel(WgradArgs g) {
+  constexpr int SY = 68, MR = 64, HR = MR + 2;
+  __shared__ __attribute__((aligned(16))) float Ys[MR * SY];
+  __shared__ __attribute__((aligned(16))) float Xs[HR * SY];
+  __shared__ float msk[2][MR];               // [0]: df = -1 allowed, [1]: df = +1 allowed
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64, nnb = (d.N + 63) / 64, ngrp = d.ntap / 3;
+  const WorkId wk_ = decode_work(ngrp * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int gi = tc / ncb, cb = tc - gi * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, r0 = tid >> 4;
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  // accumulator slot s <-> tap 3 gi + s; its frequency offset
+  int dfs[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) dfs[s3] = d.df[3 * gi + s3];
+  const long shift = (long)d.dt[3 * gi] * d.Fo;           // flattened pixel shift of this triple's rows
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s3][r] = 0.f;
+  float bsum = 0.f;
+  const int n_ld = nb * 64 + q * 4, c_ld = cb * 64 + q * 4;
+  const bool nok = n_ld < d.N, cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+
+  float4 ry[4], rx[4], rh;
+  // (entry base row, in-entry pixel) of this thread's 4 tile rows and of its halo row, advanced by MR per step with
+  // adds and compares (MR <= Mb is host-checked)
+  long eb[5];
+  int ip[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const long mg = mbeg + (i < 4 ? r0 + i * 16 : ((tid >> 4) & 1) * (MR - 1));
+    const long bq = mg / Mb;
+    eb[i] = bq * Mb;
+    ip[i] = (int)(mg - eb[i]);
+  }
+  const int ishift = (int)shift;
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long mg = mbase + r0 + i * 16;
+      const bool ok = mg < mend;
+      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int inb = ip[i] + ishift;
+      const bool v = ok && cok && inb >= 0 && inb < Mb;
+      rx[i] = v ? *reinterpret_cast<const float4*>(Ag + (eb[i] + inb) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 32) {                            // halo rows: source pixel of (first row) - 1 and of (last row) + 1
+      const int hsel = tid >> 4;
+      const long mg = hsel ? mbase + MR - 1 : mbase;
+      const int inb = ip[4] + ishift;
+      // out-of-entry / out-of-range neighbours are only ever read under a frequency-edge mask or for rows >= mend
+      const int nbp = hsel ? inb + 1 : inb - 1;
+      const bool v = mg < mend && cok && inb >= 0 && inb < Mb && nbp >= 0 && nbp < Mb;
+      rh = v ? *reinterpret_cast<const float4*>(Ag + (eb[4] + nbp) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      ip[i] += MR;
+      if (ip[i] >= Mb) { ip[i] -= Mb; eb[i] += Mb; }
+    }
+  };
+  int fm = (tid < MR) ? (int)(((mbeg + tid) % Mb) % d.Fo) : 0;      // frequency index of row mb + tid (mask builder)
+  const int fadv = MR % d.Fo;
+
+  if (mbeg < mend) load_tiles(mbeg);
+  for (long mb = mbeg; mb < mend; mb += MR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4*>(&Xs[(1 + r0 + i * 16) * SY + q * 4]) = rx[i];
+      *reinterpret_cast<float4*>(&Ys[(r0 + i * 16) * SY + q * 4]) = ry[i];
+    }
+    if (tid < 32) *reinterpret_cast<float4*>(&Xs[((tid >> 4) * (HR - 1)) * SY + q * 4]) = rh;
+    if (tid < MR) {                            // frequency-edge masks of the 64 rows of this step
+      msk[0][tid] = fm == 0 ? 0.f : 1.f;
+      msk[1][tid] = fm == d.Fo - 1 ? 0.f : 1.f;
+      fm += fadv;                              // Mb is a multiple of Fo, so entry boundaries do not disturb f
+      if (fm >= d.Fo) fm -= d.Fo;
+    }
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+    const int hrow = (lane >> 5) * 32;
+    const float* yp = &Ys[hrow * SY + wn * 32 + (lane & 31)];
+    const float* xp = &Xs[(1 + hrow) * SY + wc * 32 + (lane & 31)];
+    // tap order inside the loop: the three accumulator chains are independent, so consecutive MFMAs never wait on
+    // each other's result; row s of A serves df = -1 at output row s + 1, df = 0 at s, df = +1 at s - 1
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float yv = yp[s * SY];
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int df = dfs[s3];
+        float xv = xp[(s + df) * SY];
+        if (df != 0) xv *= (df < 0 ? msk[0] : msk[1])[hrow + s];
+        acc[s3] = __builtin_amdgcn_mfma_f32_32x32x2f32(yv, xv, acc[s3], 0, 0, 0);
+      }
+    }
+    if (do_bias && tid < 64) {
+#pragma unroll
+      for (int r = 0; r < MR; ++r) bsum += Ys[r * SY + tid];
+    }
+    __syncthreads();
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int tap = 3 * gi + s3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[s3][r]);
+    }
+  }
+  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], bsum);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 weight gradient (precision 1 / 2, same operand splits as gemm_tap_bf16x3_kernel).  The contraction index
+// of dW = dY^T X is the ROW index m, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane: both tiles are
+// therefore staged TRANSPOSED in LDS ([column][m], m contiguous).  Every thread owns a 4 (rows) x 4 (columns) block:
+// four 16-B global loads (one per row, 16 lanes = one 256-B row segment), a register transpose, and per column one
+// 8-B store of 4 consecutive m per plane.  LDS rows are laid out in 16-B cells, cell(r, ch) = 9 r + (r >> 4) + ch:
+// the 16-lane groups of both the fragment reads (16 consecutive rows, same ch) and the transposed stores (rows 4 l + j)
+// then touch 16 distinct bank groups -- conflict-free (searched exhaustively; plain padding gives 4-way write conflicts).
+template <int PRO, int NPL>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
+  constexpr int MR = 64;
+  constexpr int PLN = (9 * 64 + 4) * 8;          // bf16 elements of one [64 columns][64 m] plane
+  __shared__ __attribute__((aligned(16))) __bf16 Yt[NPL * PLN];
+  __shared__ __attribute__((aligned(16))) __bf16 Xt[NPL * PLN];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64;
+  const int nnb = (d.N + 63) / 64;
+  const WorkId wk_ = decode_work(d.ntap * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int tap = tc / ncb, cb = tc - tap * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, rg = tid >> 4;        // float4 column / group of 4 consecutive tile rows
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  const bool lin = d.ntap == 1 && !d.up && d.st == 1 && d.sf == 1 && d.dt[0] == 0 && d.df[0] == 0 &&
+                   d.Ti == d.To && d.Fi == d.Fo;
+  const int TiFi = d.Ti * d.Fi;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int n_ld = nb * 64 + q * 4, c_ld = cb * 64 + q * 4;
+  const bool nok = n_ld < d.N, cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+
+  // two register sets: the loads of step s + 2 are in flight while steps s and s + 1 run (one step of MFMAs is shorter
+  // than a memory round trip and only 2 workgroups fit per CU, so a single-step prefetch left the latency exposed)
+  struct Regs { float4 ry[4], rx[4]; float mean[4], rstd[4]; bool xok[4]; unsigned xpix[4]; };
+  Regs R0, R1;
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
+  const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
+  int cb_[4], ct_[4], cf_[4];
+  const int adv_t = MR / d.Fo, adv_f = MR - adv_t * d.Fo;
+  if (!lin) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long mg = mbeg + rg * 4 + i;
+      cb_[i] = (int)(mg / Mb);
+      int m = (int)(mg - (long)cb_[i] * Mb);
+      ct_[i] = m / d.Fo;
+      cf_[i] = m - ct_[i] * d.Fo;
+    }
+  }
+  auto load_tiles = [&](long mbase, Regs& R) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      long mg = mbase + rg * 4 + i;
+      bool ok = mg < mend;
+      long p = -1;
+      if (lin) { if (ok && cok) p = mg; }
+      else {
+        if (ok && cok) {
+          int pin = src_pixel_in(d, ct_[i], cf_[i], tap);
+          p = pin >= 0 ? (long)cb_[i] * TiFi + pin : -1;
+        }
+        cf_[i] += adv_f; ct_[i] += adv_t;
+        if (cf_[i] >= d.Fo) { cf_[i] -= d.Fo; ct_[i] += 1; }
+        while (ct_[i] >= d.To) { ct_[i] -= d.To; cb_[i] += 1; }
+      }
+      R.ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy_drop && ok && nok) {
+        unsigned base = (unsigned)(mg * d.N + n_ld);
+        const float4 d4 = drop_scale4(d.epi_seed, base, thr, inv_keep);
+        R.ry[i].x *= d4.x; R.ry[i].y *= d4.y; R.ry[i].z *= d4.z; R.ry[i].w *= d4.w;
+      }
+      R.xok[i] = p >= 0;
+      R.xpix[i] = (unsigned)p;
+      R.rx[i] = R.xok[i] ? *reinterpret_cast<const float4*>(Ag + p * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO == SE_PRO_LN) {
+        float2 mr = R.xok[i] ? *reinterpret_cast<const float2*>(g.rowstats + 2 * p) : make_float2(0.f, 0.f);
+        R.mean[i] = mr.x;
+        R.rstd[i] = mr.y;
+      }
+    }
+  };
+  // register transpose + split + store of one thread block: v[i] = row 4 rg + i, columns 4 q .. 4 q + 3
+  auto stage_t = [&](const float4 (&v)[4], __bf16* T) {
+    const float x[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      __bf16* dst = T + (9 * r + (r >> 4)) * 8 + 4 * rg;
+      float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h[i] = (__bf16)e[i]; e[i] -= (float)h[i]; }
+        *reinterpret_cast<bf16x4*>(dst + pl * PLN) = h;
+      }
+    }
+  };
+
+  float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
+  load_pro_vec<PRO>(g.ps, g.pb, c_ld, cok, ps4, pb4);
+  if (mbeg < mend) load_tiles(mbeg, R0);
+  if (mbeg + MR < mend) load_tiles(mbeg + MR, R1); else R1 = R0;
+  const int ra_ = wn * 32 + (lane & 31), rb_ = wc * 32 + (lane & 31);
+  const __bf16* yfrag = Yt + (9 * ra_ + (ra_ >> 4)) * 8 + 8 * (lane >> 5);
+  const __bf16* xfrag = Xt + (9 * rb_ + (rb_ >> 4)) * 8 + 8 * (lane >> 5);
+  auto step = [&](long mb, Regs& R) {
+    if (PRO != SE_PRO_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (R.xok[i]) R.rx[i] = apply_pro<PRO>(R.rx[i], c_ld, d.C, R.mean[i], R.rstd[i], ps4, pb4, R.xpix[i], d.pro_seed, thr, inv_keep);
+    }
+    stage_t(R.rx, Xt);
+    stage_t(R.ry, Yt);
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bsum.x += R.ry[i].x; bsum.y += R.ry[i].y; bsum.z += R.ry[i].z; bsum.w += R.ry[i].w; }
+    }
+    __syncthreads();
+    if (mb + 2 * MR < mend) load_tiles(mb + 2 * MR, R);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[NPL], bf[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        af[pl] = *reinterpret_cast<const bf16x8*>(yfrag + pl * PLN + 16 * ks);
+        bf[pl] = *reinterpret_cast<const bf16x8*>(xfrag + pl * PLN + 16 * ks);
+      }
+#pragma unroll
+      for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+        for (int qa = 0; qa <= ord; ++qa)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf[ord - qa], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (long mb = mbeg; mb < mend; mb += 2 * MR) {
+    step(mb, R0);
+    if (mb + MR < mend) step(mb + MR, R1);
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[r]);
+  }
+  if (do_bias) {       // column sums of dY: fold the 16 row groups through LDS (the tiles are free now)
+    float* red = reinterpret_cast<float*>(Yt);
+    *reinterpret_cast<float4*>(&red[rg * 64 + 4 * q]) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_ += red[r * 64 + tid];
+      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], s_);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split-bf16 triple-tap weight gradient (precision 1 / 2): wgrad3_kernel's tile sharing (one dY tile + one halo A tile
+// per step feed the taps df = -1, 0, +1) with wgrad_bf16_kernel's transposed bf16 staging.  The contraction index (row m)
+// is the contiguous LDS axis, so the +-1 row shift of a tap is an unaligned 8-element window: the fragment is assembled
+// from the aligned 16-B chunk plus one neighbouring dword with four v_alignbit.  Rows are laid out at position m + 8
+// (chunks 1..8; the two halo rows sit at positions 7 and 72).  Frequency-edge rows are cleared in the shifted fragment
+// by a dword mask; with Fo > 66 (host-checked) a 66-row tile holds at most one edge row of each kind, whose position
+// is a per-step scalar.  One split + one LDS store per element serves 72 MFMAs per wave and step instead of 24.
+template <int NPL>
+__global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
+  constexpr int MR = 64;
+  constexpr int PLY = (9 * 64 + 4) * 8;       // Yt plane: [64 n][64 m],  cell(r, ch) = 9 r + (r >> 4) + ch
+  constexpr int PLX = (10 * 64 + 8) * 8;      // Xt plane: [64 c][80 positions], cell(r, ch) = 10 r + (r >> 3) + ch
+  __shared__ __attribute__((aligned(16))) __bf16 Yt[NPL * PLY];
+  __shared__ __attribute__((aligned(16))) __bf16 Xt[NPL * PLX];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 63) / 64, nnb = (d.N + 63) / 64, ngrp = d.ntap / 3;
+  const WorkId wk_ = decode_work(ngrp * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int gi = tc / ncb, cb = tc - gi * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, rg = tid >> 4;
+  const int wn = wave >> 1, wc = wave & 1;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  int dfs[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) dfs[s3] = d.df[3 * gi + s3];
+  const int ishift = d.dt[3 * gi] * d.Fo;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s3][r] = 0.f;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int n_ld = nb * 64 + q * 4, c_ld = cb * 64 + q * 4;
+  const bool nok = n_ld < d.N, cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+
+  float4 ry[4], rx[4], rh;
+  long eb[5];
+  int ip[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const long mg = mbeg + (i < 4 ? rg * 4 + i : ((tid >> 4) & 1) * (MR - 1));
+    const long bq = mg / Mb;
+    eb[i] = bq * Mb;
+    ip[i] = (int)(mg - eb[i]);
+  }
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long mg = mbase + rg * 4 + i;
+      const bool ok = mg < mend;
+      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int inb = ip[i] + ishift;
+      const bool v = ok && cok && inb >= 0 && inb < Mb;
+      rx[i] = v ? *reinterpret_cast<const float4*>(Ag + (eb[i] + inb) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 32) {
+      const int hsel = tid >> 4;
+      const long mg = hsel ? mbase + MR - 1 : mbase;
+      const int inb = ip[4] + ishift;
+      const int nbp = hsel ? inb + 1 : inb - 1;
+      const bool v = mg < mend && cok && inb >= 0 && inb < Mb && nbp >= 0 && nbp < Mb;
+      rh = v ? *reinterpret_cast<const float4*>(Ag + (eb[4] + nbp) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      ip[i] += MR;
+      if (ip[i] >= Mb) { ip[i] -= Mb; eb[i] += Mb; }
+    }
+  };
+  // 4 x 4 register transpose + split + 8-B store per column; poff = position of tile row 0 inside the LDS row
+  auto stage_t = [&](const float4 (&v)[4], __bf16* T, int pln, bool halo_layout) {
+    const float x[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      __bf16* dst = halo_layout ? T + (10 * r + (r >> 3)) * 8 + 8 + 4 * rg : T + (9 * r + (r >> 4)) * 8 + 4 * rg;
+      float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        bf16x4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h[i] = (__bf16)e[i]; e[i] -= (float)h[i]; }
+        *reinterpret_cast<bf16x4*>(dst + pl * pln) = h;
+      }
+    }
+  };
+  int fbase = (int)((mbeg % Mb) % d.Fo);      // frequency index of the step's first row (wave-uniform)
+  if (mbeg < mend) load_tiles(mbeg);
+  const int ra_ = wn * 32 + (lane & 31), rb_ = wc * 32 + (lane & 31), kg = lane >> 5;
+  const __bf16* yfrag = Yt + (9 * ra_ + (ra_ >> 4)) * 8 + 8 * kg;
+  const __bf16* xrow = Xt + (10 * rb_ + (rb_ >> 3)) * 8;
+  for (long mb = mbeg; mb < mend; mb += MR) {
+    stage_t(rx, Xt, PLX, true);
+    stage_t(ry, Yt, PLY, false);
+    if (tid < 32) {                            // halo rows: positions 7 and 72
+      const int ph = (tid >> 4) ? 72 : 7;
+      const float hv[4] = {rh.x, rh.y, rh.z, rh.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        float e = hv[j];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) { __bf16 h = (__bf16)e; e -= (float)h; Xt[pl * PLX + (10 * r + (r >> 3)) * 8 + ph] = h; }
+      }
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bsum.x += ry[i].x; bsum.y += ry[i].y; bsum.z += ry[i].z; bsum.w += ry[i].w; }
+    }
+    // positions (in the 80-slot LDS row) of the frequency-edge rows of this tile, -100 when there is none
+    const int r0f = fbase == 0 ? 0 : d.Fo - fbase;                  // tile row with frequency 0
+    const int pL = r0f <= 64 ? 8 + r0f : (r0f == d.Fo - 1 ? 7 : -100);
+    const int r1f = d.Fo - 1 - fbase;                                // tile row with frequency Fo - 1
+    const int pR = r1f <= 64 ? 8 + r1f : (r1f == d.Fo - 1 ? 7 : -100);
+    fbase += MR % d.Fo;
+    if (fbase >= d.Fo) fbase -= d.Fo;
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int jc = 2 * ks + kg + 1;
+      bf16x8 af[NPL];
+      unsigned cen[NPL][4], prv[NPL], nxt[NPL];
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        af[pl] = *reinterpret_cast<const bf16x8*>(yfrag + pl * PLY + 16 * ks);
+        const __bf16* xp = xrow + pl * PLX + 8 * jc;
+        const uint4 cv = *reinterpret_cast<const uint4*>(xp);
+        cen[pl][0] = cv.x; cen[pl][1] = cv.y; cen[pl][2] = cv.z; cen[pl][3] = cv.w;
+        prv[pl] = *reinterpret_cast<const unsigned*>(xp - 2);
+        nxt[pl] = *reinterpret_cast<const unsigned*>(xp + 8);
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int df = dfs[s3];
+        bf16x8 bf[NPL];
+        if (df == 0) {
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) { uint4 u = make_uint4(cen[pl][0], cen[pl][1], cen[pl][2], cen[pl][3]); bf[pl] = *reinterpret_cast<bf16x8*>(&u); }
+        } else {
+          // element e of the shifted window is an edge row -> cleared
+          const int e = df > 0 ? pL - (8 * jc + 1) : pR - (8 * jc - 1);
+          unsigned mk[4];
+#pragma unroll
+          for (int dd = 0; dd < 4; ++dd) mk[dd] = e == 2 * dd ? 0xFFFF0000u : (e == 2 * dd + 1 ? 0x0000FFFFu : 0xFFFFFFFFu);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            unsigned o[4];
+            if (df > 0) {
+              o[0] = __builtin_amdgcn_alignbit(cen[pl][1], cen[pl][0], 16); o[1] = __builtin_amdgcn_alignbit(cen[pl][2], cen[pl][1], 16);
+              o[2] = __builtin_amdgcn_alignbit(cen[pl][3], cen[pl][2], 16); o[3] = __builtin_amdgcn_alignbit(nxt[pl], cen[pl][3], 16);
+            } else {
+              o[0] = __builtin_amdgcn_alignbit(cen[pl][0], prv[pl], 16); o[1] = __builtin_amdgcn_alignbit(cen[pl][1], cen[pl][0], 16);
+              o[2] = __builtin_amdgcn_alignbit(cen[pl][2], cen[pl][1], 16); o[3] = __builtin_amdgcn_alignbit(cen[pl][3], cen[pl][2], 16);
+            }
+            uint4 u = make_uint4(o[0] & mk[0], o[1] & mk[1], o[2] & mk[2], o[3] & mk[3]);
+            bf[pl] = *reinterpret_cast<bf16x8*>(&u);
+          }
+        }
+#pragma unroll
+        for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa)
+            acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf[ord - qa], acc[s3], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 64 + wc * 32 + col;
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int tap = 3 * gi + s3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[s3][r]);
+    }
+  }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(Yt);
+    *reinterpret_cast<float4*>(&red[rg * 64 + 4 * q]) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_ += red[r * 64 + tid];
+      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], s_);
+    }
+  }
+}
+
+extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW,
+                                 float* dbias, const float* rowstats, const float* pro_scale,
+                                 const float* pro_shift, int chunks, void* stream) {
+  if (int e = check_desc(d)) return e;
+  SE_REQUIRE(A && dY && dW, "wgrad: null operand");
+  SE_REQUIRE((d->N % 4) == 0 && (d->ldc % 4) == 0 && (d->c_off % 4) == 0, "wgrad: N/ldc/c_off must be multiples of 4");
+  if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "wgrad: LN prologue operands");
+  if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "wgrad: affine prologue operands");
+  const long Mtot = (long)d->B * d->To * d->Fo;
+  if (chunks < 1) chunks = 1;
+  long rpc = (Mtot + chunks - 1) / chunks;
+  rpc = ((rpc + 63) / 64) * 64;
+  chunks = (int)((Mtot + rpc - 1) / rpc);
+  WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc, chunks};
+  dim3 grid((unsigned)((long)d->ntap * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8))), block(256);
+  hipStream_t s = as_stream(stream);
+  if (d->prologue == SE_PRO_NONE && !(d->epilogue & SE_EPI_DROP) && !d->up && d->st == 1 && d->sf == 1 &&
+      d->Ti == d->To && d->Fi == d->Fo && d->ntap >= 3 && d->ntap % 3 == 0 && d->Fo >= 2 && d->To * d->Fo >= 64 &&
+      getenv("SE_GEMM_NO_CONV3") == nullptr) {
+    bool triples = true;
+    for (int t3 = 0; t3 < d->ntap && triples; t3 += 3) {
+      int seen = 0;
+      for (int j = 0; j < 3; ++j) {
+        if (d->dt[t3 + j] != d->dt[t3] || d->df[t3 + j] < -1 || d->df[t3 + j] > 1) triples = false;
+        else seen |= 1 << (d->df[t3 + j] + 1);
+      }
+      if (seen != 7) triples = false;
+    }
+    if (triples && (d->precision == 0 || d->Fo > 66)) {
+      dim3 g3((unsigned)((long)(d->ntap / 3) * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8)));
+      if (d->precision == 1) hipLaunchKernelGGL(wgrad3_bf16_kernel<2>, g3, block, 0, s, g);
+      else if (d->precision == 2) hipLaunchKernelGGL(wgrad3_bf16_kernel<3>, g3, block, 0, s, g);
+      else hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
+      return se_check_launch("se_gemm_tap_wgrad(conv3)");
+    }
+  }
+  // generic (non-triple) shapes: the six-product split kernel is VALU-bound by its own splits and measured slower than
+  // the fp32-MFMA kernel it is numerically equivalent to (77 vs 83 TFLOP/s) -> precision 2 runs the fp32 kernel there
+  if (d->precision == 1 || (d->precision == 2 && getenv("SE_WGRAD_FORCE_X6") != nullptr)) {
+#define LAUNCHWB(PRO) do { if (d->precision == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 2>), grid, block, 0, s, g); \
+                           else hipLaunchKernelGGL((wgrad_bf16_kernel<PRO, 3>), grid, block, 0, s, g); } while (0)
+    switch (d->prologue) {
+      case SE_PRO_NONE: LAUNCHWB(SE_PRO_NONE); break;
+      case SE_PRO_LN: LAUNCHWB(SE_PRO_LN); break;
+      case SE_PRO_SWISH: LAUNCHWB(SE_PRO_SWISH); break;
+      case SE_PRO_AFFINE_SWISH: LAUNCHWB(SE_PRO_AFFINE_SWISH); break;
+      case SE_PRO_SWISH_DROP: LAUNCHWB(SE_PRO_SWISH_DROP); break;
+      case SE_PRO_DROP: LAUNCHWB(SE_PRO_DROP); break;
+      default: return se_fail("wgrad: unknown prologue %d", d->prologue);
+    }
+#undef LAUNCHWB
+    return se_check_launch("se_gemm_tap_wgrad(bf16)");
+  }
+  switch (d->prologue) {
+    case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_NONE>), grid, block, 0, s, g); break;
+    case SE_PRO_LN: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_LN>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_SWISH>), grid, block, 0, s, g); break;
+    case SE_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_AFFINE_SWISH>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH_DROP: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_SWISH_DROP>), grid, block, 0, s, g); break;
+    case SE_PRO_DROP: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_DROP>), grid, block, 0, s, g); break;
+    default: return se_fail("wgrad: unknown prologue %d", d->prologue);
+  }
+  return se_check_launch("se_gemm_tap_wgrad");
+}
+
