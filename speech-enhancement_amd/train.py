@@ -27,6 +27,63 @@ def set_pesq_provider(fn):
     _PESQ_PROVIDER = fn
 
 
+class PesqSideChannel:
+    """Runs the PESQ provider off the critical path.  The reference calls batch_pesq between the
+    generator and the discriminator step (core/function.py:283-287): a device-to-host copy that waits for the whole
+    generator backward, then ~100 ms of CPU work with the GPU idle.  Here the enhanced audio is copied to pinned host
+    memory on a side stream as soon as the iSTFT has produced it, a worker thread waits for that copy only and calls
+    the provider while the GPU runs the generator backward, its optimizer step and the discriminator forwards; the
+    main thread blocks on the result only where the loss needs it (L_E).  Same labels, same arithmetic order."""
+
+    def __init__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=1)
+        self.stream = None
+        self.host = {}
+
+    def _pinned(self, key, like):
+        buf = self.host.get(key)
+        if buf is None or buf.shape != like.shape:
+            buf = torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
+            self.host[key] = buf
+        return buf
+
+    def submit(self, clean_dev, est_dev, extra=None):
+        """clean_dev / est_dev: [B, L] device tensors that are complete on the current stream.  Returns a future of
+        (q_est, q_extra...) CPU tensors; `extra` = optional dict name -> [B, L] device tensor scored against clean."""
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        names = ['clean', 'est'] + sorted(extra or {})
+        tensors = [clean_dev, est_dev] + [extra[k] for k in sorted(extra or {})]
+        with torch.cuda.stream(self.stream):
+            host = []
+            for n, t in zip(names, tensors):
+                t = t.detach()
+                t.record_stream(self.stream)
+                h = self._pinned(n, t)
+                h.copy_(t, non_blocking=True)
+                host.append(h)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+
+        def work():
+            ev.synchronize()
+            clean_list = list(host[0].numpy())
+            return [pesq_labels(clean_list, list(h.numpy())) for h in host[1:]]
+        return self.pool.submit(work)
+
+
+_SIDE = None
+
+
+def pesq_side_channel():
+    global _SIDE
+    if _SIDE is None:
+        _SIDE = PesqSideChannel()
+    return _SIDE
+
+
 def pesq_labels(clean_list, noisy_list):
     if _PESQ_PROVIDER is not None:
         return _PESQ_PROVIDER(clean_list, noisy_list)
@@ -127,6 +184,13 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
     clean_n = clean_pad[:, h:h + Ls]
     est = model.forward_planes(noisy_pl)
     est_audio = FE.istft_planes(est, n_fft, hop, 'pow')
+    label_future = None
+    if labels is None and gan_on:          # PESQ labels: start the host side now, collect it at the discriminator loss
+        length = est_audio.size(-1)
+        extra = None
+        if arch in ('scp', 'sc'):
+            extra = {'clean_self': clean_n[:, :length], 'noisy': noisy_pad[:, h:h + Ls][:, :length]}
+        label_future = pesq_side_channel().submit(clean_n[:, :length], est_audio, extra)
     if arch in ('scp', 'cp'):
         est_p = FE.stft_planes_grad(est_audio, n_fft, hop, comp_type)
         with torch.no_grad():
@@ -171,21 +235,20 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
         out['loss_d'] = torch.zeros((), device=clean.device)
         return out
     est_d = est.detach()
-    if labels is None:
-        length = est_audio.size(-1)
-        est_list = list(est_audio.detach().cpu().numpy())
-        clean_list = list(clean_n.cpu().numpy()[:, :length])
     d_gx = discriminator.forward_planes(clean_pl, est_d)
-    q_est = labels['est'] if labels is not None else pesq_labels(clean_list, est_list)
     d_yy = discriminator.forward_planes(clean_pl, clean_pl)
+    d_xy = discriminator.forward_planes(clean_pl, noisy_pl) if arch in ('scp', 'sc') else None
+    if labels is None:                     # all discriminator forwards are queued: only now wait for the CPU side
+        got = [q.to(clean.device, non_blocking=True) for q in label_future.result()]      # [est, clean_self, noisy]
+        labels = {'est': got[0]}
+        if len(got) == 3:
+            labels.update(clean=got[1], noisy=got[2])
+    q_est = labels['est']
     L_E = _mse(d_gx.flatten(), q_est)
     if arch in ('scp', 'sc'):
-        q_clean = labels['clean'] if labels is not None else pesq_labels(clean_list, clean_list)
+        q_clean = labels['clean']
         L_C = _mse(d_yy.flatten(), q_clean)
-        d_xy = discriminator.forward_planes(clean_pl, noisy_pl)
-        if labels is None:
-            noisy_list = list(noisy_pad[:, h:h + Ls].cpu().numpy()[:, :length])
-        q_noisy = labels['noisy'] if labels is not None else pesq_labels(clean_list, noisy_list)
+        q_noisy = labels['noisy']
         L_N = _mse(d_xy.flatten(), q_noisy)
         loss_d, wE, wN = _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hooks)
         out.update(L_N=L_N.detach(), w_E=wE, w_N=wN)

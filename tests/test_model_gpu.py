@@ -320,3 +320,59 @@ def test_graphed_inference_matches_eager(S):
         out = enh(x)
         assert out.shape == ref.shape and np.isfinite(out).all()
         assert np.abs(out - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize('arch', ['cmgan', 'scp'])
+def test_pesq_side_channel_matches_supplied_labels(S, arch):
+    """labels=None routes the PESQ provider through the asynchronous side channel (pinned D2H on a side stream + worker
+    thread): same losses as supplying the provider's labels directly, and the provider's latency is hidden behind the
+    generator backward."""
+    import time
+    import types
+    from speech_enhancement_amd import train as TR, optim as OP
+    calls = []
+
+    def provider(clean_list, deg_list):          # deterministic stand-in for pesq: a function of the audio only
+        calls.append(len(clean_list))
+        time.sleep(0.05)
+        q = [float(np.tanh(np.mean(np.abs(np.asarray(c) - np.asarray(dg))) * 5.0)) for c, dg in zip(clean_list, deg_list)]
+        return torch.tensor(q, dtype=torch.float32).cuda()
+    TR.set_pesq_provider(provider)
+    try:
+        torch.manual_seed(0)
+        B, Ls = 4, 3200
+        clean = 0.1 * torch.randn(B, Ls, device='cuda')
+        noisy = clean + 0.05 * torch.randn(B, Ls, device='cuda')
+        w = (0.1, 0.9, 0.2, 0.05) if arch == 'cmgan' else (0.3, 0.7, 0.2, 0.05)
+        outs = []
+        for use_side in (True, False):
+            torch.manual_seed(1)
+            g, d = S.TSCNet(64, 201), S.Discriminator(16)
+            g.apply(S.kaiming_init); d.apply(S.kaiming_init)
+            g.cuda().train(); d.cuda().train()
+            g.set_dropout(0.0, 0.0)
+            for m in d.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+            oa = types.SimpleNamespace(optimizer='sgd', lr=1e-3, weight_decay=0.0, momentum=0.9, max_norm=0.0)
+            og, od = OP.build_optimizer(oa, g), OP.build_optimizer(oa, d)
+            labels = None
+            if not use_side:                      # what the side channel must have produced, computed synchronously
+                with torch.no_grad():
+                    from speech_enhancement_amd import frontend as FE, ops as O
+                    c = O.clip_scale(noisy.contiguous())
+                    npl, npad = FE.stft_planes(noisy, 400, 100, 'pow', scale=c)
+                    cpl, cpad = FE.stft_planes(clean, 400, 100, 'pow', scale=c)
+                    est_audio = FE.istft_planes(g.forward_planes(npl), 400, 100, 'pow')
+                    Lh = est_audio.size(-1)
+                    cn = list(cpad[:, 200:200 + Ls][:, :Lh].cpu().numpy())
+                    labels = {'est': provider(cn, list(est_audio.cpu().numpy())), 'clean': provider(cn, cn),
+                              'noisy': provider(cn, list(npad[:, 200:200 + Ls][:, :Lh].cpu().numpy()))}
+                g.load_state_dict(g.state_dict())
+            out = TR.gan_step(g, d, og, od, clean, noisy, arch, w, labels=labels)
+            outs.append({k: float(v) for k, v in out.items()})
+        for k in outs[0]:
+            assert abs(outs[0][k] - outs[1][k]) <= 2e-5 * max(1.0, abs(outs[1][k])), (k, outs[0][k], outs[1][k])
+        assert calls[0] == B
+    finally:
+        TR.set_pesq_provider(None)
