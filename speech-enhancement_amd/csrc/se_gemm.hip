@@ -338,8 +338,11 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
   const float inv_keep = 1.f;
 
   float4 ra[4], rh, rb[2];
-  auto load_a = [&](int grp_it) {             // halo tile of (chunk, triple) number grp_it
-    const int chunk = grp_it / ngrp, gi = grp_it - chunk * ngrp;
+  // (chunk, triple) / (chunk, tap) of the tile being prefetched, advanced by increments (no divisions in the loop)
+  int a_chunk = 0, a_gi = 0, b_chunk = 0, b_tap = 0;
+  auto load_a = [&]() {                        // halo tile of (a_chunk, a_gi); then advance
+    const int chunk = a_chunk, gi = a_gi;
+    if (++a_gi == ngrp) { a_gi = 0; ++a_chunk; }
     const int c = chunk * BK + kq * 4;
     const bool cok = c < d.C;
     const int q0 = m0 - 1 + d.dt[3 * gi] * d.Fo;          // flattened source pixel of halo row 0
@@ -355,8 +358,9 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto load_b = [&](int it) {
-    const int chunk = it / d.ntap, tap = it - chunk * d.ntap;
+  auto load_b = [&]() {                        // weight tile of (b_chunk, b_tap); then advance
+    const int chunk = b_chunk, tap = b_tap;
+    if (++b_tap == d.ntap) { b_tap = 0; ++b_chunk; }
     const int c = chunk * BK + kq * 4;
     const bool cok = c < d.C;
     const unsigned wk = (unsigned)(tap * d.C + c);
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   const bool vec_ep = epilogue_vec_ok(d);
   if (vec_ep) stage_bias(g, by, bias_s);
-  load_a(0);
-  load_b(0);
+  load_a();
+  load_b();
   const int frag = (lane & 31) * SA + 8 * (lane >> 5);
   int it = 0, gi = 0;
   for (int gq = 0; gq < nchunk * ngrp; ++gq, gi = (gi + 1 == ngrp ? 0 : gi + 1)) {
@@ -384,8 +388,8 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
       __syncthreads();
-      if (it + 1 < NI) load_b(it + 1);
-      if (s3 == 0 && gq + 1 < nchunk * ngrp) load_a(gq + 1);
+      if (it + 1 < NI) load_b();
+      if (s3 == 0 && gq + 1 < nchunk * ngrp) load_a();
       const int df = d.df[3 * gi + s3];
       const bool kill = (df < 0 && edgeL) || (df > 0 && edgeR);
 #pragma unroll
