@@ -7,7 +7,8 @@
  * Conventions (all functions):
  *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer owned by the caller;
  *   - stream-ordered on `stream` (a hipStream_t passed as void*), no allocation, no host sync;
- *   - return 0 on success, negative on error (se_last_error() gives the text); never throws;
+ *   - return 0 on success, negative on error (se_last_error() gives the text of the calling THREAD's last error:
+ *     the buffer is thread-local, the entry points keep no other state and are re-entrant); never throws;
  *   - feature maps are channels-last fp32: X[b][t][f][c], pixel stride `ld` floats.
  */
 #ifndef SE_HIP_H
@@ -65,6 +66,15 @@ typedef struct {
 
 int se_version(void);
 const char* se_last_error(void);
+
+/* Workspace sizes (bytes) of the entry points that take a caller-owned workspace; pure host functions, no GPU call.
+ *   se_attn_bwd               : Dl     = float  [ntok][4]
+ *   se_norm_prelu_bwd         : red    = double [per_batch ? B : 1][C][3]
+ *   se_lars_step / lamb_step  : norms  = double [nseg][2]
+ */
+size_t se_attn_bwd_workspace_bytes(long ntok);
+size_t se_norm_prelu_bwd_workspace_bytes(int B, int C, int per_batch);
+size_t se_segnorm_workspace_bytes(int nseg);
 
 /* forward / input-gradient tap GEMM.  rowstats: [M][2] (mean, rstd) for SE_PRO_LN;
  * pro_scale/pro_shift: per-channel (LN gamma/beta or BN scale/shift); stats: double [B][N][2]. */
@@ -202,6 +212,20 @@ int se_adamw(float* p, const float* g, float* m, float* v, long n, float lr, flo
              float wd, int step, void* stream);
 int se_sgd_nesterov(float* p, const float* g, float* buf, long n, float lr, float momentum, int first, void* stream);
 int se_dot(const float* a, const float* b, double* out, long n, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (core/function.py:275-276, 311-312) on a flat gradient buffer: g *= min(1, max_norm /
+ * (sqrt(sums[0] + .. + sums[nsum-1]) + 1e-6)); sums = device partial sums of squares (se_dot(g, g) per buffer). */
+int se_grad_clip(float* g, long n, const double* sums, int nsum, float max_norm, void* stream);
+/* LARS.step (core/optimizer.py:71-113) on one flat parameter group.  seg_off[nseg+1]: element offsets of the
+ * parameter tensors inside the flat buffer; max_seg: the largest tensor; norms: workspace double [nseg][2]
+ * (se_segnorm_workspace_bytes(nseg)).  adapt = 1 for the ndim > 1 group (weight decay + trust ratio), 0 for the 1-D group. */
+int se_lars_step(float* p, const float* g, float* mu, const long* seg_off, int nseg, long max_seg, double* norms,
+                 int adapt, float lr, float wd, float momentum, float trust_coef, void* stream);
+/* Lamb.step (core/optimizer.py:176-238) on one flat parameter group: gsum[nsum] = partial sums of squares of ALL the
+ * model's gradients (global-norm clip, :186-199; nsum == 0 disables it); bc1 / bc2 = bias corrections
+ * (1 when off); beta3 = 1 - b1 with grad_averaging else 1; adapt = (wd != 0 || always_adapt). */
+int se_lamb_step(float* p, const float* g, float* m, float* v, const long* seg_off, int nseg, long max_seg,
+                 double* norms, const double* gsum, int nsum, float max_grad_norm, int adapt, int trust_clip, float lr,
+                 float wd, float b1, float b2, float beta3, float eps, float bc1, float bc2, void* stream);
 int se_axpbypcz(const float* a, const float* b, const float* c, float* y, float alpha, float beta, float gamma,
                 long n, void* stream);
 

@@ -409,13 +409,43 @@ def no_decay(name: str, p: Tensor) -> bool:
     return p.dim() == 1 or name.endswith('.bias')
 
 
+def _clip_grads(grads, max_norm: float):
+    """torch.nn.utils.clip_grad_norm_ (norm_type 2): scale by max_norm / (total + 1e-6), clamped to 1."""
+    if max_norm == 0.0:
+        return grads
+    total = torch.sqrt(sum((g.detach() ** 2).sum() for g in grads if g is not None))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return [None if g is None else g * coef for g in grads]
+
+
+def validate_step(sd_g: SD, sd_d: SD, clean: Tensor, noisy: Tensor, q_est: Tensor, arch: str = 'cmgan',
+                  weights=(0.1, 0.9, 0.2, 0.05), gan_on: bool = True, comp: str = 'pow'):
+    """One validate_gan iteration (core/function.py:362-430), eval mode, no grad: generator loss as in
+    training (consistency-preserving terms for scp / cp, GAN term behind the --gen-first gate),
+    discriminator loss always MSE(D(y,y), 1) + MSE(D(y,G(x)), Q)."""
+    with torch.no_grad():
+        cn, nn_, _ = normalize_pair(clean, noisy)
+        r = generator_losses(sd_g, sd_d, cn, nn_, arch, False, None, None, comp)
+        loss = weights[0] * r['loss_ri'] + weights[1] * r['loss_mag'] + weights[2] * r['time_loss']
+        if gan_on:
+            loss = loss + weights[3] * r['gan']
+        d_gx = discriminator_forward(sd_d, r['clean_mag'], r['est_mag'], False)
+        d_yy = discriminator_forward(sd_d, r['clean_mag'], r['clean_mag'], False)
+        loss_d = _mse(d_yy.flatten(), torch.ones_like(q_est)) + _mse(d_gx.flatten(), q_est)
+    return float(loss), float(loss_d), {k: float(r[k]) for k in ('loss_ri', 'loss_mag', 'time_loss', 'gan')}
+
+
 def train_step(sd_g: SD, sd_d: SD, clean: Tensor, noisy: Tensor, q_est: Tensor,
                arch: str = 'cmgan', weights=(0.1, 0.9, 0.2, 0.05), lr: float = 5e-4,
                wd: float = 0.01, opt_state: Optional[dict] = None,
                q_clean: Optional[Tensor] = None, q_noisy: Optional[Tensor] = None,
-               optimizer: str = 'adamw', momentum: float = 0.9):
+               optimizer: str = 'adamw', momentum: float = 0.9, gan_on: bool = True,
+               max_norm: float = 0.0):
     """One train_gan iteration (core/function.py:206-317), AdamW or nesterov-SGD, dropout off,
-    PESQ labels q_* supplied as inputs.  Returns (losses, new_sd_g, new_sd_d, opt_state)."""
+    PESQ labels q_* supplied as inputs.  gan_on=False is the --gen-first gate before
+    0.3 * epochs (:260-272, :280-315: no GAN term, no discriminator update); max_norm != 0 is
+    clip_grad_norm_ on each model's gradients (:275-276, :311-312).
+    Returns (losses, new_sd_g, new_sd_d, opt_state)."""
     G = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v)
          for k, v in sd_g.items()}
     D = {k: (v.clone().requires_grad_(True)
@@ -426,9 +456,30 @@ def train_step(sd_g: SD, sd_d: SD, clean: Tensor, noisy: Tensor, q_est: Tensor,
     clean_n, noisy_n, _ = normalize_pair(clean, noisy)
     bn_out, sn1 = {}, {}
     r = generator_losses(G, D, clean_n, noisy_n, arch, True, bn_out, sn1)
-    loss_g = weights[0] * r['loss_ri'] + weights[1] * r['loss_mag'] + \
-        weights[2] * r['time_loss'] + weights[3] * r['gan']
-    grads_g = torch.autograd.grad(loss_g, [G[k] for k in gp])
+    loss_g = weights[0] * r['loss_ri'] + weights[1] * r['loss_mag'] + weights[2] * r['time_loss']
+    if gan_on:
+        loss_g = loss_g + weights[3] * r['gan']
+    grads_g = torch.autograd.grad(loss_g, [G[k] for k in gp], allow_unused=not gan_on)
+    grads_g = _clip_grads(grads_g, max_norm)
+    if not gan_on:
+        # generator_losses evaluated the discriminator (an oracle convenience); the reference
+        # does not call it behind the gate, so its spectral-norm state is not advanced
+        out = dict(loss_ri=r['loss_ri'], loss_mag=r['loss_mag'], time_loss=r['time_loss'],
+                   gan=torch.zeros(()), loss_g=loss_g, loss_d=torch.zeros(()))
+        st = opt_state or {'step': 0, 'g': {}, 'd': {}}
+        st['step'] += 1
+        new_g = {k: v.detach() for k, v in G.items()}
+        new_g.update({k: v.detach() for k, v in bn_out.items()})
+        for k, g in zip(gp, grads_g):
+            if optimizer == 'sgd':
+                new_g[k], st['g'][k] = sgd_nesterov_update(new_g[k], g.detach(), st['g'].get(k), lr, momentum)
+            else:
+                m, v = st['g'].get(k, (torch.zeros_like(g), torch.zeros_like(g)))
+                new_g[k], m, v = adamw_update(new_g[k], g.detach(), m, v, st['step'], lr,
+                                              0.0 if no_decay(k, new_g[k]) else wd)
+                st['g'][k] = (m, v)
+        return ({k: float(v.detach()) for k, v in out.items()}, new_g,
+                {k: v.detach() for k, v in sd_d.items()}, st, dict(zip(gp, grads_g)), {})
     D.update(sn1)
     est_mag = r['est_mag'].detach()
     clean_mag = r['clean_mag'].detach()
@@ -471,6 +522,7 @@ def train_step(sd_g: SD, sd_d: SD, clean: Tensor, noisy: Tensor, q_est: Tensor,
         grads_d = torch.autograd.grad(loss_d, params_d, allow_unused=True)
         grads_d = [g if g is not None else torch.zeros_like(p) for g, p in zip(grads_d, params_d)]
         out.update(L_C=L_C)
+    grads_d = _clip_grads(grads_d, max_norm)
     out['loss_d'] = loss_d
     st = opt_state or {'step': 0, 'g': {}, 'd': {}}
     st['step'] += 1

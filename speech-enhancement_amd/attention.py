@@ -32,7 +32,7 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
     L.check_cuda(qkv, E, O, dO, lse, dE)
     ntok = qkv.shape[0]
     dqkv = torch.empty(ntok, 192, device=qkv.device, dtype=torch.float32)
-    dl = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32)
+    dl = torch.empty(L.lib().se_attn_bwd_workspace_bytes(C.c_long(ntok)) // 4, device=qkv.device, dtype=torch.float32)
     nseq, n, inner, os_, is_, ps = geom
     et_ld = (E.shape[0] + 3) // 4 * 4
     Et = torch.zeros(16, et_ld, device=E.device, dtype=torch.float32)      # transposed table (weight-sized plumbing)

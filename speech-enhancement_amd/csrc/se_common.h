@@ -7,7 +7,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-extern char g_se_err[512];
+extern thread_local char g_se_err[512];
 int se_fail(const char* fmt, ...);
 int se_check_launch(const char* what);
 

@@ -332,6 +332,109 @@ __global__ void axpbypcz_kernel(const float* a, const float* b, const float* c, 
   y[idx] = alpha * a[idx] + beta * b[idx] + gamma * c[idx];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Global-norm gradient clipping on a flat buffer (torch.nn.utils.clip_grad_norm_, core/function.py:275-276, 311-312):
+// g *= min(1, max_norm / (sqrt(sum of the nsum partial sums of squares) + 1e-6)).  The sums are device scalars produced
+// by se_dot(g, g) on each flat buffer of the model -> no host round trip.
+__global__ void grad_clip_kernel(float* __restrict__ g, long n, const double* __restrict__ sums, int nsum, float max_norm) {
+  long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (idx >= n) return;
+  double tot = 0.0;
+  for (int i = 0; i < nsum; ++i) tot += sums[i];
+  float coef = fminf(1.0f, max_norm / ((float)sqrt(tot) + 1e-6f));
+  if (idx + 4 <= n) {
+    float4 v = *reinterpret_cast<float4*>(g + idx);
+    v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+    *reinterpret_cast<float4*>(g + idx) = v;
+  } else {
+    for (long i = idx; i < n; ++i) g[i] *= coef;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LARS / Lamb of core/optimizer.py:63-238 on the flat buffers.  Both need one pair of norms PER PARAMETER TENSOR
+// (trust ratio): the flat buffer is described by seg_off[nseg + 1] (element offsets of the tensors, in order); the grid is
+// (chunks of SEG_CHUNK elements, nseg) and a workgroup whose chunk lies beyond its tensor exits at once (1.8 M elements
+// in 335 tensors: the largest has 73 728 elements = 72 chunks).  Phase 1 accumulates norms[seg] = (sum p^2, sum u^2) in
+// fp64 (one atomic pair per workgroup), phase 2 applies the update.
+#define SEG_CHUNK 1024
+// mode 0 (LARS, :71-113): u = g + wd * p                       (only called for the ndim > 1 group)
+// mode 1 (Lamb, :176-238): m, v updated in place; u = (m / bc1) / (sqrt(v) / sqrt(bc2) + eps) + wd * p, with
+//         g divided by clip = max(1, ||g||_global / max_grad_norm) (gsum: nsum partial sums of squares; nsum == 0: no clip)
+__global__ __launch_bounds__(256) void seg_norms_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v,
+                                                        const long* __restrict__ seg_off, double* __restrict__ norms,
+                                                        int mode, float wd, float b1, float b2, float beta3, float eps,
+                                                        float bc1, float rbc2, const double* __restrict__ gsum, int nsum,
+                                                        float max_gn) {
+  const int seg = blockIdx.y;
+  const long lo = seg_off[seg], hi = seg_off[seg + 1];
+  const long base = lo + (long)blockIdx.x * SEG_CHUNK;
+  if (base >= hi) return;
+  float rclip = 1.0f;
+  if (mode == 1 && nsum > 0) {      // max_grad_norm == 0 zeroes every gradient, exactly like the reference's g / (gn / 0)
+    double tot = 0.0;
+    for (int i = 0; i < nsum; ++i) tot += gsum[i];
+    float gn = (float)sqrt(tot);
+    rclip = gn > max_gn ? max_gn / gn : 1.0f;
+  }
+  double sp = 0.0, su = 0.0;
+  for (long i = base + threadIdx.x; i < hi && i < base + SEG_CHUNK; i += 256) {
+    float pi = p[i], gi = g[i], u;
+    if (mode == 0) {
+      u = gi + wd * pi;
+    } else {
+      gi *= rclip;
+      float mi = b1 * m[i] + beta3 * gi;
+      float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      u = (mi / bc1) / (sqrtf(vi) * rbc2 + eps) + wd * pi;
+    }
+    sp += (double)pi * pi;
+    su += (double)u * u;
+  }
+  __shared__ double part[8];
+  sp = wave_sum_d(sp); su = wave_sum_d(su);
+  if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sp; part[4 + (threadIdx.x >> 6)] = su; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(norms + 2 * seg, part[0] + part[1] + part[2] + part[3]);
+    atomicAdd(norms + 2 * seg + 1, part[4] + part[5] + part[6] + part[7]);
+  }
+}
+// mode 0 LARS: q = trust * ||p|| / ||u|| (1 where either norm is 0); mu = momentum * mu + u * q; p -= lr * mu   (m == mu)
+//        `adapt` = 0: the 1-D group -- u = g, q = 1 (no weight decay, no trust ratio, :93-103)
+// mode 1 Lamb: trust = ||p|| / ||u|| (1 where either norm is 0; min(.,1) if trust_clip) when adapt, else 1; p -= lr * trust * u
+__global__ __launch_bounds__(256) void seg_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, const float* __restrict__ v,
+                                                        const long* __restrict__ seg_off, const double* __restrict__ norms,
+                                                        int mode, int adapt, float lr, float wd, float momentum,
+                                                        float trust_coef, float eps, float bc1, float rbc2, int trust_clip) {
+  const int seg = blockIdx.y;
+  const long lo = seg_off[seg], hi = seg_off[seg + 1];
+  const long base = lo + (long)blockIdx.x * SEG_CHUNK;
+  if (base >= hi) return;
+  float q = 1.0f;
+  if (adapt) {
+    float pn = (float)sqrt(norms[2 * seg]), un = (float)sqrt(norms[2 * seg + 1]);
+    if (pn > 0.f && un > 0.f) q = (mode == 0 ? trust_coef : 1.0f) * pn / un;
+    if (mode == 1 && trust_clip) q = fminf(q, 1.0f);
+  }
+  for (long i = base + threadIdx.x; i < hi && i < base + SEG_CHUNK; i += 256) {
+    float pi = p[i];
+    if (mode == 0) {
+      float u = adapt ? (g[i] + wd * pi) * q : g[i];
+      float mu = momentum * m[i] + u;
+      m[i] = mu;
+      p[i] = pi - lr * mu;
+    } else {
+      float u = (m[i] / bc1) / (sqrtf(v[i]) * rbc2 + eps) + wd * pi;
+      p[i] = pi - lr * q * u;
+    }
+  }
+}
+
 // =============================================================================================
 #define EW_LAUNCH(kernel, n, s, ...) hipLaunchKernelGGL(kernel, dim3(cdiv((n), 256)), dim3(256), 0, as_stream(s), __VA_ARGS__)
 
@@ -466,4 +569,46 @@ extern "C" int se_axpbypcz(const float* a, const float* b, const float* c, float
   SE_REQUIRE(a && b && c && y && n > 0, "axpbypcz: bad arguments");
   EW_LAUNCH(axpbypcz_kernel, n, stream, a, b, c, y, alpha, beta, gamma, n);
   return se_check_launch("se_axpbypcz");
+}
+
+extern "C" int se_grad_clip(float* g, long n, const double* sums, int nsum, float max_norm, void* stream) {
+  SE_REQUIRE(g && sums && n > 0 && nsum > 0 && max_norm > 0.f, "grad_clip: bad arguments");
+  SE_REQUIRE(((uintptr_t)g & 15) == 0, "grad_clip: the gradient buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(grad_clip_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, as_stream(stream), g, n, sums, nsum, max_norm);
+  return se_check_launch("se_grad_clip");
+}
+static int seg_grid(long max_seg, int nseg, dim3* grid) {
+  if (nseg <= 0 || nseg > 65535 || max_seg <= 0) return -1;
+  *grid = dim3(cdiv(max_seg, SEG_CHUNK), nseg);
+  return 0;
+}
+extern "C" int se_lars_step(float* p, const float* g, float* mu, const long* seg_off, int nseg, long max_seg,
+                            double* norms, int adapt, float lr, float wd, float momentum, float trust_coef, void* stream) {
+  SE_REQUIRE(p && g && mu && seg_off && norms, "lars_step: bad arguments");
+  dim3 grid;
+  SE_REQUIRE(seg_grid(max_seg, nseg, &grid) == 0, "lars_step: bad segment table (nseg=%d, max_seg=%ld)", nseg, max_seg);
+  if (adapt) {
+    if (hipMemsetAsync(norms, 0, sizeof(double) * 2 * nseg, as_stream(stream)) != hipSuccess) return se_fail("segment-norm workspace memset failed");
+    hipLaunchKernelGGL(seg_norms_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)p, g, (float*)nullptr,
+                       (float*)nullptr, seg_off, norms, 0, wd, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, (const double*)nullptr, 0, 0.f);
+  }
+  hipLaunchKernelGGL(seg_apply_kernel, grid, dim3(256), 0, as_stream(stream), p, g, mu, (const float*)nullptr, seg_off,
+                     (const double*)norms, 0, adapt, lr, wd, momentum, trust_coef, 0.f, 1.f, 1.f, 0);
+  return se_check_launch("se_lars_step");
+}
+extern "C" int se_lamb_step(float* p, const float* g, float* m, float* v, const long* seg_off, int nseg, long max_seg,
+                            double* norms, const double* gsum, int nsum, float max_grad_norm, int adapt, int trust_clip,
+                            float lr, float wd, float b1, float b2, float beta3, float eps, float bc1, float bc2,
+                            void* stream) {
+  SE_REQUIRE(p && g && m && v && seg_off && norms && bc1 > 0.f && bc2 > 0.f, "lamb_step: bad arguments");
+  SE_REQUIRE(nsum == 0 || gsum, "lamb_step: nsum > 0 needs the gradient sums");
+  dim3 grid;
+  SE_REQUIRE(seg_grid(max_seg, nseg, &grid) == 0, "lamb_step: bad segment table (nseg=%d, max_seg=%ld)", nseg, max_seg);
+  float rbc2 = 1.0f / sqrtf(bc2);
+  if (hipMemsetAsync(norms, 0, sizeof(double) * 2 * nseg, as_stream(stream)) != hipSuccess) return se_fail("segment-norm workspace memset failed");
+  hipLaunchKernelGGL(seg_norms_kernel, grid, dim3(256), 0, as_stream(stream), (const float*)p, g, m, v, seg_off, norms, 1, wd,
+                     b1, b2, beta3, eps, bc1, rbc2, gsum, nsum, max_grad_norm);
+  hipLaunchKernelGGL(seg_apply_kernel, grid, dim3(256), 0, as_stream(stream), p, g, m, (const float*)v, seg_off,
+                     (const double*)norms, 1, adapt, lr, wd, 0.f, 0.f, eps, bc1, rbc2, trust_clip);
+  return se_check_launch("se_lamb_step");
 }

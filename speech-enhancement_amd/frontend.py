@@ -171,21 +171,39 @@ def planes_to_spec(planes):
     return torch.complex(planes[..., 1], planes[..., 2]).transpose(1, 2)
 
 
+def _check_window(window, n_fft):
+    """The kernels fold the periodic Hamming window (torch.hamming_window(n_fft), the only window the reference ever
+    passes: core/function.py:668) into the DFT matrices.  Any other window would be silently wrong -> refuse it."""
+    if window is None:
+        return
+    key = ('wchk', n_fft, window.data_ptr(), window._version, str(window.device))
+    if _CACHE.get('wchk_last') == key:
+        return
+    if window.numel() != n_fft or \
+            not torch.allclose(window.detach().double().cpu(), hamming(n_fft, 'cpu'), rtol=0.0, atol=1e-6):
+        raise L.SeHipError(f'the HIP STFT/iSTFT path is built for the periodic Hamming window hamming_window({n_fft}) '
+                           f'(core/function.py:668); got a different window')
+    _CACHE['wchk_last'] = key
+
+
 def compressed_stft(signal, n_fft, hop_length, window=None, comp_type='pow'):
-    """core/function.py:685-693.  `window` is accepted for signature parity; the kernel path uses the periodic
-    Hamming window the reference always passes (core/function.py:668)."""
+    """core/function.py:685-693.  `window` must be None or the periodic Hamming window (checked)."""
+    _check_window(window, n_fft)
     planes, _ = stft_planes(signal, n_fft, hop_length, comp_type)
     return planes_to_spec(planes)
 
 
 def uncompressed_istft(spec, n_fft, hop_length, window=None, comp_type='pow'):
-    """core/function.py:695-703."""
+    """core/function.py:695-703.  `window` must be None or the periodic Hamming window (checked)."""
+    _check_window(window, n_fft)
     return istft_planes(spec_to_planes(spec), n_fft, hop_length, comp_type)
 
 
 def normalize_batch(batch, args=None):
-    """core/function.py:647-659 (device placement is the caller's business here)."""
+    """core/function.py:647-659: moves the pair to args.gpu when given, scales both signals by c = sqrt(L / sum noisy^2)."""
     clean, noisy = batch['audio'], batch['noisy']
+    if getattr(args, 'gpu', None) is not None:
+        clean, noisy = clean.cuda(args.gpu, non_blocking=True), noisy.cuda(args.gpu, non_blocking=True)
     c = O.clip_scale(noisy.contiguous())
     return clean * c[:, None], noisy * c[:, None]
 

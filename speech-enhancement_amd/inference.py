@@ -13,11 +13,12 @@ from .generator import TSCNet
 
 
 def load_model(model_path, config, device=torch.device('cuda')):
-    """inference_gan.py:60-72: TSCNet(64, N_FFT//2+1), checkpoint['gen_state_dict'] with the 7-char 'module.' prefix
-    stripped unconditionally (checkpoints are saved from DDP), eval()."""
+    """inference_gan.py:60-72: TSCNet(64, N_FFT//2+1), checkpoint['gen_state_dict'], eval().  The reference strips
+    7 characters from every key because its checkpoints always come from DDP ('module.' prefix, main_gan.py:142);
+    here the prefix is stripped only where present, so single-GPU checkpoints of this package load as well."""
     model = TSCNet(num_channel=64, num_features=config.N_FFT // 2 + 1).to(device)
     checkpoint = torch.load(model_path, map_location=device)
-    sd = OrderedDict((k[7:], v) for k, v in checkpoint['gen_state_dict'].items())
+    sd = OrderedDict((k[7:] if k.startswith('module.') else k, v) for k, v in checkpoint['gen_state_dict'].items())
     model.load_state_dict(sd)
     model.eval()
     return model

@@ -78,7 +78,7 @@ def norm_prelu_bwd(x, ldx, x_off, mr, g, beta, slope, dy, ldy, y_off, dx, lddx, 
                    per_batch=True, act=0, allreduce=None, count=None):
     """allreduce: optional callable applied to the fp64 reduction buffer between the two phases
     (SyncBatchNorm backward); count: elements per statistic (defaults to the local count)."""
-    red = _new((B if per_batch else 1), C_, 3, like=x, dtype=f64)
+    red = _new(L.lib().se_norm_prelu_bwd_workspace_bytes(_i(B), _i(C_), _i(int(per_batch))) // 8, like=x, dtype=f64)
     if count is None:
         count = float(P if per_batch else P * B)
     args = lambda phase: (L.ptr(x), _i(ldx), _i(x_off), L.ptr(mr), L.ptr(g), L.ptr(beta), L.ptr(slope),

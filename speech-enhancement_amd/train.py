@@ -67,10 +67,17 @@ class PesqSideChannel:
             ev = torch.cuda.Event()
             ev.record(self.stream)
 
+        dev = est_dev.device
+
         def work():
-            ev.synchronize()
-            clean_list = list(host[0].numpy())
-            return [pesq_labels(clean_list, list(h.numpy())) for h in host[1:]]
+            # the current device is thread-local and a new thread starts on device 0: pin the worker to the caller's
+            # device so a provider that honours the "current device" contract never opens a context on GPU 0 from
+            # rank k > 0; results are handed back as CPU tensors and uploaded by the main thread on its own stream
+            with torch.cuda.device(dev):
+                ev.synchronize()
+                clean_list = list(host[0].numpy())
+                return [torch.as_tensor(pesq_labels(clean_list, list(h.numpy()), device='cpu')).float().cpu()
+                        for h in host[1:]]
         return self.pool.submit(work)
 
 
@@ -84,7 +91,9 @@ def pesq_side_channel():
     return _SIDE
 
 
-def pesq_labels(clean_list, noisy_list):
+def pesq_labels(clean_list, noisy_list, device=None):
+    """models/discriminator.py:25-32 (`batch_pesq`): (pesq - 1) / 3.5 per clip, -1 on a PESQ exception.  `device`:
+    where the label tensor should live (the reference hard-codes 'cuda'; default = the current CUDA device)."""
     if _PESQ_PROVIDER is not None:
         return _PESQ_PROVIDER(clean_list, noisy_list)
     try:
@@ -100,7 +109,8 @@ def pesq_labels(clean_list, noisy_list):
         except Exception:
             return -1
     s = np.array(Parallel(n_jobs=-1)(delayed(one)(c, n) for c, n in zip(clean_list, noisy_list)))
-    return torch.FloatTensor((s - 1) / 3.5).to('cuda')
+    q = torch.FloatTensor((s - 1) / 3.5)
+    return q.to(device if device is not None else torch.device('cuda', torch.cuda.current_device()))
 
 
 class DataParallelHooks(LY.DPHooks):
@@ -169,30 +179,62 @@ def self_correcting_weights(CE, CN, EN, EE, NN):
     return 1.0, wE, wN
 
 
-def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch, loss_weights, n_fft=400, hop=100,
-             comp_type='pow', max_norm=0.0, gan_on=True, labels=None, hooks=None):
-    """One iteration of the train_gan loop body (core/function.py:216-315).  `labels`: dict with 'est'
-    (and 'clean', 'noisy' for scp/sc) giving the PESQ targets directly; if None the PESQ provider is called on the
-    audio like the reference does.  Returns a dict of python-float-convertible loss tensors (no host sync here)."""
+class LabelCache:
+    """the reference recomputes Q_y_y = PESQ(clean, clean) and Q_x_y = PESQ(clean, noisy)
+    every step of the scp / sc recipes (core/function.py:292-301) although neither depends on the generator -- two of
+    the three PESQ batches per step are constants of the crop.  Labels are cached per utterance under a caller-supplied
+    key (`batch['keys']`: one hashable per clip that identifies file AND crop, e.g. (index, crop_start)); only the
+    missing clips of a batch go to the provider.  Without keys nothing is cached (the crop is unknown)."""
+
+    def __init__(self, max_items=1 << 20):
+        self.q = {}
+        self.max_items = max_items
+        self.hits = self.misses = 0
+
+    def lookup(self, keys, kind):
+        """-> (values list with None for misses, indices of the misses)"""
+        vals = [self.q.get((kind, k)) for k in keys]
+        miss = [i for i, v in enumerate(vals) if v is None]
+        self.hits += len(keys) - len(miss)
+        self.misses += len(miss)
+        return vals, miss
+
+    def store(self, keys, kind, values):
+        if len(self.q) + len(keys) > self.max_items:
+            self.q.clear()
+        for k, v in zip(keys, values):
+            self.q[(kind, k)] = float(v)
+
+
+_LABEL_CACHE = LabelCache()
+
+
+def label_cache():
+    return _LABEL_CACHE
+
+
+def generator_pass(model, discriminator, clean, noisy, arch, loss_weights, n_fft=400, hop=100, comp_type='pow',
+                   gan_on=True, grad=True, after_istft=None):
+    """The shared front half of train_gan and validate_gan (core/function.py:216-272 == :362-413): normalise, 2 STFT,
+    generator, iSTFT, the cmgan or consistency-preserving (scp / cp) spectral + time losses, and the GAN term unless the
+    `--gen-first` gate is closed.  grad=False (validation): nothing is recorded for backward.  `after_istft(r)` is
+    called as soon as the enhanced audio exists (PESQ side channel).  Returns a dict of tensors."""
     B, Ls = clean.shape
-    out = {}
-    optimizer.zero_grad()
+    r = {}
     c = O.clip_scale(noisy.contiguous())
     noisy_pl, noisy_pad = FE.stft_planes(noisy, n_fft, hop, 'pow', scale=c)
     clean_pl, clean_pad = FE.stft_planes(clean, n_fft, hop, 'pow', scale=c)
     h = n_fft // 2
-    clean_n = clean_pad[:, h:h + Ls]
+    clean_n, noisy_n = clean_pad[:, h:h + Ls], noisy_pad[:, h:h + Ls]
     est = model.forward_planes(noisy_pl)
     est_audio = FE.istft_planes(est, n_fft, hop, 'pow')
-    label_future = None
-    if labels is None and gan_on:          # PESQ labels: start the host side now, collect it at the discriminator loss
-        length = est_audio.size(-1)
-        extra = None
-        if arch in ('scp', 'sc'):
-            extra = {'clean_self': clean_n[:, :length], 'noisy': noisy_pad[:, h:h + Ls][:, :length]}
-        label_future = pesq_side_channel().submit(clean_n[:, :length], est_audio, extra)
+    r.update(noisy_pl=noisy_pl, clean_pl=clean_pl, clean_n=clean_n, noisy_n=noisy_n, est=est, est_audio=est_audio)
+    if after_istft is not None:
+        after_istft(r)
     if arch in ('scp', 'cp'):
-        est_p = FE.stft_planes_grad(est_audio, n_fft, hop, comp_type)
+        # enhanced-audio pipeline: re-STFT with args.comp_type; clean* pipeline: iSTFT -> STFT of the clean spectrum
+        est_p = FE.stft_planes_grad(est_audio, n_fft, hop, comp_type) if grad else \
+            FE.stft_planes(est_audio, n_fft, hop, comp_type)[0]
         with torch.no_grad():
             clean_audio_p = FE.istft_planes(clean_pl, n_fft, hop, 'pow')
             clean_p, _ = FE.stft_planes(clean_audio_p, n_fft, hop, comp_type)
@@ -209,6 +251,51 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
     else:
         gen_gan = torch.zeros((), device=clean.device)
         loss = w[0] * loss_ri + w[1] * loss_mag + w[2] * time_loss
+    r.update(loss_mag=loss_mag, loss_ri=loss_ri, time_loss=time_loss, gan=gen_gan, loss=loss, ones=ones)
+    return r
+
+
+def clip_grad_norm(optimizer, params, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (core/function.py:275-276, 311-312) on the flat gradient buffers when the
+    optimizer has them (one fused sum-of-squares + one scale launch per buffer, no host sync)."""
+    if hasattr(optimizer, 'clip_grad_norm'):
+        return optimizer.clip_grad_norm(max_norm)
+    return torch.nn.utils.clip_grad_norm_(params, max_norm)
+
+
+def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch, loss_weights, n_fft=400, hop=100,
+             comp_type='pow', max_norm=0.0, gan_on=True, labels=None, hooks=None, keys=None):
+    """One iteration of the train_gan loop body (core/function.py:216-315).  `labels`: dict with 'est'
+    (and 'clean', 'noisy' for scp/sc) giving the PESQ targets directly; if None the PESQ provider is called on the
+    audio like the reference does (asynchronously, see PesqSideChannel); `keys`: optional per-clip crop keys for the
+    crop-constant label cache (LabelCache).  Returns a dict of python-float-convertible loss tensors (no host sync)."""
+    B, Ls = clean.shape
+    out = {}
+    optimizer.zero_grad()
+    pending = {}
+
+    def submit_labels(r):
+        # PESQ labels: start the host side now, collect it at the discriminator loss
+        if labels is not None or not gan_on:
+            return
+        est_audio = r['est_audio']
+        length = est_audio.size(-1)
+        extra, cached = None, {}
+        if arch in ('scp', 'sc'):
+            extra = {'clean_self': r['clean_n'][:, :length], 'noisy': r['noisy_n'][:, :length]}
+            if keys is not None:          # crop-constant labels: only when the whole batch hits (one provider call less)
+                for name, kind in (('clean_self', 'clean'), ('noisy', 'noisy')):
+                    vals, miss = _LABEL_CACHE.lookup(keys, kind)
+                    if not miss:
+                        cached[kind] = torch.tensor(vals, dtype=torch.float32)
+                        del extra[name]
+        pending['future'] = pesq_side_channel().submit(r['clean_n'][:, :length], est_audio, extra or None)
+        pending['names'] = ['est'] + [{'clean_self': 'clean', 'noisy': 'noisy'}[k] for k in sorted(extra or {})]
+        pending['cached'] = cached
+
+    r = generator_pass(model, discriminator, clean, noisy, arch, loss_weights, n_fft, hop, comp_type, gan_on, True,
+                       submit_labels)
+    est, clean_pl, noisy_pl, ones, loss = r['est'], r['clean_pl'], r['noisy_pl'], r['ones'], r['loss']
     loss.backward()
     # Data parallel: the generator-gradient all-reduce (7.3 MB over xGMI) is launched asynchronously and only waited
     # for after the discriminator step has been issued -- the discriminator step reads est.detach() and no generator
@@ -220,13 +307,13 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
         if g_works is not None:
             hooks.finish_average(g_works)
         if max_norm != 0.0:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+            clip_grad_norm(optimizer, model.parameters(), max_norm)
         optimizer.step()
 
     if hooks is None:
         finish_generator_step()
-    out.update(loss_ri=loss_ri.detach(), loss_mag=loss_mag.detach(), time_loss=time_loss.detach(),
-               gan=gen_gan.detach(), loss_g=loss.detach())
+    out.update(loss_ri=r['loss_ri'].detach(), loss_mag=r['loss_mag'].detach(), time_loss=r['time_loss'].detach(),
+               gan=r['gan'].detach(), loss_g=loss.detach())
 
     optimizer_disc.zero_grad()
     if not gan_on:
@@ -239,10 +326,13 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
     d_yy = discriminator.forward_planes(clean_pl, clean_pl)
     d_xy = discriminator.forward_planes(clean_pl, noisy_pl) if arch in ('scp', 'sc') else None
     if labels is None:                     # all discriminator forwards are queued: only now wait for the CPU side
-        got = [q.to(clean.device, non_blocking=True) for q in label_future.result()]      # [est, clean_self, noisy]
-        labels = {'est': got[0]}
-        if len(got) == 3:
-            labels.update(clean=got[1], noisy=got[2])
+        got = dict(zip(pending['names'], pending['future'].result()))
+        if keys is not None:
+            for kind in ('clean', 'noisy'):
+                if kind in got:
+                    _LABEL_CACHE.store(keys, kind, got[kind].tolist())
+        got.update(pending['cached'])
+        labels = {k: v.to(clean.device, non_blocking=True) for k, v in got.items()}
     q_est = labels['est']
     L_E = _mse(d_gx.flatten(), q_est)
     if arch in ('scp', 'sc'):
@@ -259,7 +349,7 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
         if hooks is not None:
             hooks.average_grads(optimizer_disc)
     if max_norm != 0.0:
-        torch.nn.utils.clip_grad_norm_(discriminator.parameters(), max_norm)
+        clip_grad_norm(optimizer_disc, discriminator.parameters(), max_norm)
     optimizer_disc.step()
     if hooks is not None:
         finish_generator_step()
@@ -280,9 +370,10 @@ def _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hook
         gs = torch.autograd.grad(L_, params, retain_graph=True, allow_unused=True)
         flats.append(torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]))
     if hooks is not None:
-        for f in flats:
-            hooks.allreduce(f)
-            f.mul_(1.0 / hooks.world)
+        cat = torch.cat(flats)             # one 2.18 MB all-reduce instead of three
+        hooks.allreduce(cat)
+        cat.mul_(1.0 / hooks.world)
+        flats = list(cat.split(flats[0].numel()))
     C, E, N = flats
     dots = torch.zeros(5, device=C.device, dtype=torch.float64)
     for i, (a, b) in enumerate(((E, E), (N, N), (C, E), (C, N), (E, N))):
@@ -298,6 +389,13 @@ def _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hook
     return (wC * L_C + wE * L_E + wN * L_N), wE, wN
 
 
+def _to_gpu(batch, args):
+    clean, noisy = batch['audio'], batch['noisy']
+    if getattr(args, 'gpu', None) is not None:
+        clean, noisy = clean.cuda(args.gpu, non_blocking=True), noisy.cuda(args.gpu, non_blocking=True)
+    return clean, noisy
+
+
 def train_gan(train_loader, model, discriminator, criterion, optimizer, optimizer_disc, logger, epoch, args, config):
     """core/function.py:182-343: same signature and return values (avg generator / discriminator loss)."""
     if getattr(args, 'debug', False):
@@ -311,13 +409,11 @@ def train_gan(train_loader, model, discriminator, criterion, optimizer, optimize
     for idx, batch in enumerate(train_loader):
         data_time.update(time.time() - end)
         adjust_learning_rate([optimizer, optimizer_disc], epoch + idx / iters, config)
-        clean, noisy = batch['audio'], batch['noisy']
-        if getattr(args, 'gpu', None) is not None:
-            clean, noisy = clean.cuda(args.gpu, non_blocking=True), noisy.cuda(args.gpu, non_blocking=True)
+        clean, noisy = _to_gpu(batch, args)
         gan_on = epoch >= int(args.epochs * 0.3) or not args.gen_first
         out = gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, args.arch, config.LOSS_WEIGHTS,
                        config.N_FFT, config.HOP_SAMPLES, args.comp_type, args.max_norm, gan_on,
-                       labels=batch.get('labels'), hooks=hooks)
+                       labels=batch.get('labels'), hooks=hooks, keys=batch.get('keys'))
         torch.cuda.synchronize()
         gen_losses.update(out['loss_g'].item(), clean.size(0))
         disc_losses.update(out['loss_d'].item(), clean.size(0))
@@ -336,36 +432,30 @@ def train_gan(train_loader, model, discriminator, criterion, optimizer, optimize
 
 @torch.no_grad()
 def validate_gan(valid_loader, model, discriminator, criterion, logger, epoch, args, config):
-    """core/function.py:346-451: no backward, always L_C(ones) + L_E."""
+    """core/function.py:346-451: the generator loss follows the training recipe -- consistency-preserving losses for
+    scp / cp (:373-397), GAN term gated by --gen-first before 0.3 * epochs (:401-413); the discriminator loss is
+    always L_C(ones) + L_E ("unable to compute validation self-correcting loss", :427-428).  No backward."""
     model.eval()
     discriminator.eval()
     gen_losses, disc_losses = AverageMeter(), AverageMeter()
-    w = config.LOSS_WEIGHTS
+    arch = getattr(args, 'arch', 'cmgan')
+    gan_on = epoch >= int(getattr(args, 'epochs', 0) * 0.3) or not getattr(args, 'gen_first', False)
     for batch in valid_loader:
-        clean, noisy = batch['audio'], batch['noisy']
-        if getattr(args, 'gpu', None) is not None:
-            clean, noisy = clean.cuda(args.gpu, non_blocking=True), noisy.cuda(args.gpu, non_blocking=True)
-        B, Ls = clean.shape
-        c = O.clip_scale(noisy.contiguous())
-        noisy_pl, _ = FE.stft_planes(noisy, config.N_FFT, config.HOP_SAMPLES, 'pow', scale=c)
-        clean_pl, clean_pad = FE.stft_planes(clean, config.N_FFT, config.HOP_SAMPLES, 'pow', scale=c)
-        h = config.N_FFT // 2
-        clean_n = clean_pad[:, h:h + Ls]
-        est = model.forward_planes(noisy_pl)
-        est_audio = FE.istft_planes(est, config.N_FFT, config.HOP_SAMPLES, 'pow')
-        loss_mag, loss_ri = LS.spec_losses(est, clean_pl)
-        time_loss = LS.l1_time_loss(est_audio, clean_n)
-        ones = torch.ones(B, device=clean.device)
-        d_gx = discriminator.forward_planes(clean_pl, est)
-        gan = _mse(d_gx.flatten(), ones)
-        loss = w[0] * loss_ri + w[1] * loss_mag + w[2] * time_loss + w[3] * gan
+        clean, noisy = _to_gpu(batch, args)
+        B = clean.shape[0]
+        r = generator_pass(model, discriminator, clean, noisy, arch, config.LOSS_WEIGHTS, config.N_FFT,
+                           config.HOP_SAMPLES, getattr(args, 'comp_type', 'pow'), gan_on, grad=False)
+        est_audio, clean_n, clean_pl = r['est_audio'], r['clean_n'], r['clean_pl']
         labels = batch.get('labels')
+        d_gx = discriminator.forward_planes(clean_pl, r['est'])
         if labels is not None:
             q = labels['est']
         else:
-            q = pesq_labels(list(clean_n.cpu().numpy()), list(est_audio.cpu().numpy()))
+            length = est_audio.size(-1)
+            q = pesq_labels(list(clean_n[:, :length].cpu().numpy()), list(est_audio.cpu().numpy()),
+                            device=clean.device).to(clean.device)
         d_yy = discriminator.forward_planes(clean_pl, clean_pl)
-        loss_d = _mse(d_yy.flatten(), ones) + _mse(d_gx.flatten(), q)
-        gen_losses.update(loss.item(), B)
+        loss_d = _mse(d_yy.flatten(), r['ones']) + _mse(d_gx.flatten(), q)
+        gen_losses.update(r['loss'].item(), B)
         disc_losses.update(loss_d.item(), B)
     return gen_losses.avg, disc_losses.avg

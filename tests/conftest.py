@@ -17,3 +17,21 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_v1.npz'))
+
+
+@pytest.fixture(scope='session')
+def golden2():
+    """round-2 vectors (tests/golden/make_golden_v2.py): validate_gan, --gen-first, --max-norm, front-end API,
+    one FULL-SIZE (T=321) reference train_gan step"""
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_v2.npz'))
+
+
+def full_size_signals(seed, B=2, L=32000):
+    """the inputs of the full-size golden step, regenerated from the seed (numpy legacy RandomState is bit-stable)"""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(seed)
+    clean = (0.1 * rs.randn(B, L)).astype(np.float32)
+    noisy = (clean + 0.05 * rs.randn(B, L)).astype(np.float32)
+    return torch.from_numpy(clean), torch.from_numpy(noisy)

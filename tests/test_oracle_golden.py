@@ -257,3 +257,86 @@ def test_full_size_forward(golden, gsd):
     assert rms(mag, golden['full_est_mag']) < 1e-4
     audio = O.uncompressed_istft(torch.complex(er, ei).squeeze(1).permute(0, 2, 1))
     assert rms(audio, golden['full_est_audio']) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# round 2: validate_gan, --gen-first, --max-norm and the full-size step (tests/golden/make_golden_v2.py)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('arch,weights,dt,gen_first', [('cmgan', W_CM, 'f32', False), ('cmgan', W_CM, 'f64', False),
+                                                       ('scp', W_SCP, 'f64', False), ('scp', W_SCP, 'f64', True),
+                                                       ('cmgan', W_CM, 'f64', True)])
+def test_validate_step(golden, golden2, gsd, dsd, arch, weights, dt, gen_first):
+    """the reference's own validate_gan (core/function.py:346-451) vs the oracle: consistency-preserving losses for
+    scp, GAN term gated by --gen-first (epoch 10 of 100)"""
+    tdt = torch.float64 if dt == 'f64' else torch.float32
+    cast = lambda sd: {k: (v.to(tdt) if v.is_floating_point() else v) for k, v in sd.items()}
+    vg, vd, terms = O.validate_step(cast(gsd), cast(dsd), t(golden['fe_clean']).to(tdt), t(golden['fe_noisy']).to(tdt),
+                                    t(golden['q_est']).to(tdt), arch, weights, gan_on=not gen_first)
+    tag = f'val_{arch}_{dt}' + ('_genfirst' if gen_first else '')
+    ref = golden2[tag]
+    tol = 1e-9 if dt == 'f64' else 2e-5
+    assert abs(vg - ref[0]) < tol * abs(ref[0]) and abs(vd - ref[1]) < (1e-9 if dt == 'f64' else 5e-4) * abs(ref[1]) + 1e-12
+    mse = golden2[tag + '_mse_calls']          # mag, real, imag, [GAN], L_C, L_E
+    assert abs(terms['loss_mag'] - mse[0]) < tol * mse[0]
+    assert abs(terms['loss_ri'] - (mse[1] + mse[2])) < tol * (mse[1] + mse[2])
+    assert len(mse) == (5 if gen_first else 6)
+    if not gen_first:
+        # fp32: the discriminator's sigmoid head amplifies rounding
+        assert abs(terms['gan'] - mse[3]) < (1e-9 if dt == 'f64' else 5e-4) * mse[3] + 1e-12
+
+
+def test_gen_first_and_clipped_steps(golden, golden2, gsd, dsd):
+    """train_gan behind the --gen-first gate (generator-only step, discriminator untouched) and with --max-norm 0.5"""
+    cast = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    lr = O.lr_at(10.0, 0.01, 100)
+    args = (t(golden['fe_clean']).double(), t(golden['fe_noisy']).double(), t(golden['q_est']).double(), 'cmgan', W_CM)
+    out, ng, nd, *_ = O.train_step(cast(gsd), cast(dsd), *args, lr=lr, optimizer='sgd', gan_on=False)
+    assert abs(out['loss_g'] - golden2['step_genfirst_losses'][0]) < 1e-9 and golden2['step_genfirst_losses'][1] == 0
+    assert len(golden2['step_genfirst_mse_calls']) == 3
+    np.testing.assert_allclose([float(ng[k].double().norm()) for k in gsd], golden2['step_genfirst_g_norm'], rtol=1e-8)
+    np.testing.assert_allclose([float(nd[k].double().norm()) for k in dsd], golden2['step_genfirst_d_norm'], rtol=1e-12)
+    out, ng, nd, *_ = O.train_step(cast(gsd), cast(dsd), *args, lr=lr, optimizer='sgd', max_norm=0.5)
+    np.testing.assert_allclose([float(ng[k].double().norm()) for k in gsd], golden2['step_clip_g_norm'], rtol=1e-8)
+    np.testing.assert_allclose([float(nd[k].double().norm()) for k in dsd], golden2['step_clip_d_norm'], rtol=1e-8)
+    for k, new in (('g:mask_decoder.final_conv.weight', ng), ('d:layers.17.weight_orig', nd)):
+        name = k.split(':', 1)[1]
+        assert rms(new[name], golden2['step_clip_' + k]) < 1e-9
+
+
+def test_frontend_api_vectors(golden, golden2):
+    """power_compress / power_uncompress incl. angle(0)=0, batch_stft tuple"""
+    z = torch.complex(t(golden2['pc_in'][..., 0]), t(golden2['pc_in'][..., 1]))
+    for comp in ('pow', 'log', 'norm', 'none'):
+        re, im = O._compress(z.real, z.imag, comp)
+        assert rms(torch.stack([re, im], -1), golden2[f'pc_{comp}']) < 1e-6
+        re, im = O._uncompress(z.real, z.imag, comp)
+        ref = golden2[f'pu_{comp}']
+        assert rms(torch.stack([re, im], -1), ref) < 2e-6 * float(np.abs(ref).max())
+    cn, nn_, _ = O.normalize_pair(t(golden['fe_clean']), t(golden['fe_noisy']))
+    assert rms(cn, golden2['bs_clean']) < 1e-6 and rms(nn_, golden2['bs_noisy']) < 1e-6
+    assert rms(torch.view_as_real(O.compressed_stft(cn)), golden2['bs_clean_spec']) < 1e-5
+    assert rms(O.hamming_periodic(), golden2['bs_window']) < 1e-7
+
+
+def test_full_size_train_step_fp32(golden2, gsd, dsd):
+    """ONE FULL-SIZE step (B=2, L=32000, T=321 -- the benchmark geometry) of the reference's train_gan in fp64 vs the
+    oracle in fp32: every loss term and every post-step parameter norm (nesterov-SGD is linear in the gradient)."""
+    from conftest import full_size_signals
+    clean, noisy = full_size_signals(int(golden2['full_step_seed'][0]))
+    lr = O.lr_at(10.0, 0.01, 100)
+    out, ng, nd, _, gg, gd = O.train_step(dict(gsd), dict(dsd), clean, noisy, torch.tensor([0.35, 0.62]), 'cmgan', W_CM,
+                                          lr=lr, optimizer='sgd')
+    mse = golden2['full_step_mse_calls']
+    for a, b in ((out['loss_mag'], mse[0]), (out['loss_ri'], mse[1] + mse[2]), (out['gan'], mse[3]), (out['L_E'], mse[4]),
+                 (out['L_C'], mse[5]), (out['loss_g'], golden2['full_step_losses'][0])):
+        assert abs(a - b) < 1e-4 * abs(b) + 1e-7, (a, b)
+    np.testing.assert_allclose([float(ng[k].double().norm()) for k in gsd], golden2['full_step_g_norm'], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose([float(nd[k].double().norm()) for k in dsd], golden2['full_step_d_norm'], rtol=2e-4, atol=1e-6)
+    # first nesterov step: update = -lr (1 + momentum) g, so the stored fp64 updates pin the GRADIENTS themselves
+    # (several updates are below the fp32 resolution of their weights and could not be compared as weight differences)
+    for k in golden2.files:
+        if k.startswith('full_step_gupd:') or k.startswith('full_step_dupd:'):
+            name = k.split(':', 1)[1]
+            g = (gg if 'gupd' in k else gd)[name].double().numpy()
+            ref = golden2[k].astype(np.float64) / (-lr * 1.9)
+            assert rms(g, ref) < 2e-2 * np.sqrt(np.mean(ref ** 2)) + 1e-12, k
