@@ -375,7 +375,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     if train:
         O.norm_prelu_bwd(h, 128, 0, mr, g_bn, b_bn, None, dact, 128, 0, dh, 128, 0, G[f'{p}.conv.net.5.weight'],
                          G[f'{p}.conv.net.5.bias'], None, 1, M, 128, per_batch=False, act=1,
-                         allreduce=(dp.allreduce if dp.world > 1 else None), count=count)
+                         allreduce=(dp.allreduce if dp.world > 1 or getattr(dp, 'force_sync', False) else None), count=count)
     else:
         raise L.SeHipError('conformer_bwd in eval mode is not supported (BatchNorm uses running statistics)')
     Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)

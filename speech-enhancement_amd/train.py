@@ -114,14 +114,24 @@ def pesq_labels(clean_list, noisy_list, device=None):
 
 
 class DataParallelHooks(LY.DPHooks):
-    """RCCL hooks: SyncBatchNorm statistic all-reduce + flat gradient all-reduce (average)."""
+    """RCCL hooks: SyncBatchNorm statistic all-reduce + flat gradient all-reduce (average).
+
+    Backend "nccl" (== RCCL over xGMI) reduces the device buffers in place.  Backend "gloo" is the test transport
+    (several ranks sharing ONE GPU, which RCCL refuses): device tensors are staged through the host around the
+    collective, so exactly the same step logic runs in both cases."""
 
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.stage_host = dist.get_backend(group) == 'gloo'
 
     def allreduce(self, t):
-        dist.all_reduce(t, group=self.group)
+        if self.stage_host and t.is_cuda:
+            h = t.cpu()
+            dist.all_reduce(h, group=self.group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, group=self.group)
         return t
 
     def average_grads(self, optimizer):
@@ -129,11 +139,14 @@ class DataParallelHooks(LY.DPHooks):
 
     def start_average(self, optimizer):
         """launch the all-reduce of the flat gradient buffers asynchronously (RCCL runs on its own stream)"""
+        if self.stage_host:
+            return [(self.allreduce(g), None) for g in optimizer.flat_grads()]
         return [(g, dist.all_reduce(g, group=self.group, async_op=True)) for g in optimizer.flat_grads()]
 
     def finish_average(self, works):
         for g, w in works:
-            w.wait()
+            if w is not None:
+                w.wait()
             g.mul_(1.0 / self.world)
 
 
@@ -142,7 +155,12 @@ def attach_data_parallel(model, discriminator, group=None):
     hooks = DataParallelHooks(group)
     for m in (model, discriminator):
         for t in list(m.parameters()) + list(m.buffers()):
-            dist.broadcast(t.data, 0, group=group)
+            if hooks.stage_host and t.is_cuda:
+                h = t.data.cpu()
+                dist.broadcast(h, 0, group=group)
+                t.data.copy_(h)
+            else:
+                dist.broadcast(t.data, 0, group=group)
     model.dp = hooks
     return hooks
 

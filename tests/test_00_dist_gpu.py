@@ -1,0 +1,73 @@
+"""Multi-rank acceptance property (main_gan.py:133-171): an N-rank step equals the 1-rank step at
+the same global batch -- losses, every post-step parameter norm, BatchNorm running statistics (SyncBatchNorm with
+count = M * world), selected updates and, for scp, the self-correcting weights w_E / w_N (gradients averaged over ranks
+BEFORE the dot products).  Real HIP kernels on every rank.
+
+With >= 2 GPUs the ranks use RCCL ("nccl"), one GPU each; on a single-GPU box both ranks share GPU 0 and the hooks
+stage their collectives through the host over gloo (RCCL refuses two ranks on one device) -- the step logic is the same.
+
+This file sorts first on purpose: the ranks are CHILD processes and the pytest process must not have initialised the
+GPU when it starts them (torch.cuda.device_count() does not)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', 'dist_worker.py')
+
+
+def _port():
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def _run(world, arch, backend, out, timeout=900):
+    port = _port()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), arch, backend, out], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors='replace')[-3000:])
+    assert all(p.returncode == 0 for p in procs), '\n----\n'.join(logs)
+    return np.load(out)
+
+
+@pytest.mark.parametrize('arch', ['cmgan', 'scp'])
+def test_two_ranks_equal_one_rank_at_equal_global_batch(tmp_path, arch):
+    backend = 'nccl' if torch.cuda.device_count() >= 2 else 'gloo'
+    one = _run(1, arch, backend, str(tmp_path / 'one.npz'))
+    two = _run(2, arch, backend, str(tmp_path / 'two.npz'))
+    # losses (fp32 reduction order differs between a batch-4 and two batch-2 evaluations)
+    for n, a, b in zip(one['loss_names'], one['losses'], two['losses']):
+        assert abs(a - b) < 2e-5 * abs(a) + 1e-7, (str(n), a, b)
+    # SyncBatchNorm: running statistics are those of the GLOBAL batch on every rank
+    np.testing.assert_allclose(two['bn_rm'], one['bn_rm'], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(two['bn_rv'], one['bn_rv'], rtol=1e-5, atol=1e-7)
+    rel = lambda k: float(np.abs(two[k] - one[k]).max() / (np.abs(one[k]).max() + 1e-30))
+    diffs = {k: rel(k) for k in ('g_norm', 'd_norm', 'g_w', 'g_q', 'd_w')}
+    print(arch, backend, 'two-rank vs one-rank max relative differences:', diffs)
+    # the discriminator is well conditioned in both recipes
+    assert diffs['d_norm'] < 2e-6 and diffs['d_w'] < 2e-6, diffs
+    if arch == 'scp':
+        # the consistency-preserving generator gradient is ill-conditioned in fp32 (two fp32
+        # evaluation orders of the reference itself differ by up to 26 % in single gradient tensors): the step moves the
+        # weights by ~1e-3 relative, so the norms can only be compared to that order
+        assert diffs['g_norm'] < 1e-3, diffs
+        assert np.allclose(two['w'], one['w'], rtol=1e-4, atol=1e-6), (two['w'], one['w'])
+    else:
+        assert diffs['g_norm'] < 2e-6 and diffs['g_w'] < 2e-6 and diffs['g_q'] < 2e-6, diffs

@@ -593,3 +593,50 @@ def test_flat_clip_and_state_dict_interop(S):
                 o1.load_state_dict(sd2)
         for (n, p1), p2 in zip(d1.named_parameters(), d2.parameters()):
             assert rms(p1, p2) < 2e-6 * max(1.0, float(p2.abs().max())), (kind, n)
+
+
+def test_world1_hooks_equal_plain_step(S):
+    """the data-parallel code paths on ONE rank (process group of size 1): deferred generator step behind the
+    discriminator step, SyncBatchNorm exchange with count = M * world, averaged scp gradients -- with world == 1 every
+    collective is the identity, so the result must equal the hook-free step bit for bit"""
+    import os
+    import socket
+    import types
+    import torch.distributed as dist
+    from speech_enhancement_amd import train as TR, optim, layers as LY
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        torch.manual_seed(3)
+        clean = 0.1 * torch.randn(2, 1600, device='cuda')
+        noisy = clean + 0.05 * torch.randn(2, 1600, device='cuda')
+        labels = {'est': torch.tensor([0.4, 0.6], device='cuda'), 'clean': torch.tensor([0.95, 0.97], device='cuda'),
+                  'noisy': torch.tensor([0.3, 0.2], device='cuda')}
+        res = []
+        for use_hooks in (False, True):
+            g, d = load_g(S), load_d(S)
+            args = types.SimpleNamespace(optimizer='sgd', lr=0.01, weight_decay=0.01, momentum=0.9, max_norm=0.0)
+            og, od = optim.build_optimizer(args, g), optim.build_optimizer(args, d, lr=0.02)
+            hooks = None
+            if use_hooks:
+                hooks = TR.attach_data_parallel(g, d)
+                assert hooks.world == 1 and hooks.stage_host
+                hooks.force_sync = True              # take the two-phase SyncBatchNorm backward although world == 1
+                calls = []
+                orig = hooks.allreduce
+                hooks.allreduce = lambda t_: (calls.append(t_.numel()), orig(t_))[1]
+                g.dp = hooks
+            out = TR.gan_step(g, d, og, od, clean, noisy, 'scp', (0.3, 0.7, 0.2, 0.05), labels=labels, hooks=hooks)
+            res.append(({k: float(v) for k, v in out.items()},
+                        torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())]).clone()))
+            if use_hooks:
+                assert len(calls) >= 8 + 8 + 1, calls      # 8 BN forward + 8 BN backward exchanges, the scp gradient triple
+        for k in res[0][0]:
+            assert res[0][0][k] == res[1][0][k], k
+        # weight gradients use fp32 atomics (run-to-run order): compare to atomics noise, not bitwise
+        assert float((res[0][1] - res[1][1]).abs().max()) < 1e-6
+    finally:
+        dist.destroy_process_group()
