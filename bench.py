@@ -60,7 +60,7 @@ def cpu_baseline(budget_s=90.0):
     spec = Or.compressed_stft(nn_)
     sweep = {}
     t_start = time.time()
-    for th in sorted({min(ncpu, v) for v in (8, 16, 32, 64, ncpu)}):
+    for th in sorted({min(ncpu, v) for v in (8, 16, 32, 64)}):      # beyond 64 threads torch-CPU oversubscribes (256: 60x slower)
         torch.set_num_threads(th)
         with torch.no_grad():
             Or.tscnet_forward(gsd, spec, False)              # warm (allocator, thread pool)

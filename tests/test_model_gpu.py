@@ -598,7 +598,7 @@ def test_flat_clip_and_state_dict_interop(S):
 def test_world1_hooks_equal_plain_step(S):
     """the data-parallel code paths on ONE rank (process group of size 1): deferred generator step behind the
     discriminator step, SyncBatchNorm exchange with count = M * world, averaged scp gradients -- with world == 1 every
-    collective is the identity, so the result must equal the hook-free step bit for bit"""
+    collective is the identity, so the result must equal the hook-free step (to the fp32-atomics noise of the weight gradients)"""
     import os
     import socket
     import types
@@ -634,8 +634,8 @@ def test_world1_hooks_equal_plain_step(S):
                         torch.cat([p.detach().flatten() for p in list(g.parameters()) + list(d.parameters())]).clone()))
             if use_hooks:
                 assert len(calls) >= 8 + 8 + 1, calls      # 8 BN forward + 8 BN backward exchanges, the scp gradient triple
-        for k in res[0][0]:
-            assert res[0][0][k] == res[1][0][k], k
+        for k in res[0][0]:          # weight-gradient atomics make the gradient dot products differ in the last digits
+            assert abs(res[0][0][k] - res[1][0][k]) <= 1e-6 * abs(res[0][0][k]), k
         # weight gradients use fp32 atomics (run-to-run order): compare to atomics noise, not bitwise
         assert float((res[0][1] - res[1][1]).abs().max()) < 1e-6
     finally:
