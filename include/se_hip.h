@@ -68,11 +68,11 @@ int se_version(void);
 const char* se_last_error(void);
 
 /* Workspace sizes (bytes) of the entry points that take a caller-owned workspace; pure host functions, no GPU call.
- *   se_attn_bwd               : Dl     = float  [ntok][4]
+ *   se_attn_bwd               : ws     = row constants [ntok][4] + split / transposed copies of E + per-wave dE tiles
  *   se_norm_prelu_bwd         : red    = double [per_batch ? B : 1][C][3]
  *   se_lars_step / lamb_step  : norms  = double [nseg][2]
  */
-size_t se_attn_bwd_workspace_bytes(long ntok);
+size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n);
 size_t se_norm_prelu_bwd_workspace_bytes(int B, int C, int per_batch);
 size_t se_segnorm_workspace_bytes(int nseg);
 
@@ -160,12 +160,14 @@ int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const
  * [tokens][4].  token(s,p) = (s/inner)*outer_stride + (s%inner)*inner_stride + p*pos_stride. */
 int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq, int n, int inner,
                 long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
-/* backward: dQKV [tokens][192] written, dE accumulated (atomics; caller zeroes); Dl = workspace [tokens][4];
- * Et (optional) = E transposed, [16][et_ld] with et_ld % 4 == 0: enables the single-pass LDS-staged kernel */
+/* backward: dQKV [tokens][192] written, dE accumulated (caller zeroes); ws = workspace of
+ * se_attn_bwd_workspace_bytes(ntok, maxpos, nseq, n) bytes, 16-byte aligned (softmax row constants, bf16-split and
+ * transposed copies of E, per-wave dE tiles).  Sequences whose padded length fits the offset table (16 * ceil(n / 16) <= maxpos, the
+ * training shapes) run the decoupled split-bf16 kernel; longer ones the streaming fp32 kernels. */
 int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
-                float* Dl, float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
-                long inner_stride, long pos_stride, long ntok, int maxpos, float scale, const float* Et,
-                int et_ld, void* stream);
+                float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
+                long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws, size_t ws_bytes,
+                void* stream);
 
 /* ---- depthwise conv k=31 along the sequence axis (csrc/se_dwconv.hip) -------------------------- */
 /* DepthWiseConv1d forward (models/conformer.py:40-48,166) on [tokens][128] (+ fp64 BatchNorm statistics

@@ -32,15 +32,15 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
     L.check_cuda(qkv, E, O, dO, lse, dE)
     ntok = qkv.shape[0]
     dqkv = torch.empty(ntok, 192, device=qkv.device, dtype=torch.float32)
-    dl = torch.empty(L.lib().se_attn_bwd_workspace_bytes(C.c_long(ntok)) // 4, device=qkv.device, dtype=torch.float32)
     nseq, n, inner, os_, is_, ps = geom
-    et_ld = (E.shape[0] + 3) // 4 * 4
-    Et = torch.zeros(16, et_ld, device=E.device, dtype=torch.float32)      # transposed table (weight-sized plumbing)
-    Et[:, :E.shape[0]] = E.t()
-    L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dl), L.ptr(dqkv), L.ptr(dE),
+    nbytes = L.lib().se_attn_bwd_workspace_bytes(C.c_long(ntok), C.c_int(maxpos), C.c_int(nseq), C.c_int(n))
+    ws = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
+    npad = (n + 15) // 16 * 16
+    v3 = maxpos % 4 == 0 and npad + 128 <= maxpos and n <= 384
+    key = ('attn_bwd3_kernel (+delta, tables)' if v3 else
+           'attn_bwd2_kernel (+delta)' if n <= 336 and maxpos >= 352 else 'attn_bwd_dkv + attn_bwd_dq (+delta)')
+    L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dqkv), L.ptr(dE),
            C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
-           C.c_int(maxpos), C.c_float(scale), L.ptr(Et), C.c_int(et_ld), L.stream(), _key=('attn_bwd2_kernel<112, 4, true> (+delta)' if n <= 112 and maxpos >= 352 else
-                 'attn_bwd2_kernel<336, 8, false> (+delta)' if n <= 336 and maxpos >= 352 else
-                 'attn_bwd_dkv + attn_bwd_dq (+delta)'),
-           _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
+           C.c_int(maxpos), C.c_float(scale), L.ptr(ws), C.c_size_t(nbytes), L.stream(),
+           _key=key + (' n>128' if n > 128 else ' n<=128'), _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
     return dqkv

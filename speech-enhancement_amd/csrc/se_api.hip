@@ -23,7 +23,6 @@ extern "C" int se_version(void) { return 1; }
 extern "C" const char* se_last_error(void) { return g_se_err; }
 
 // workspace sizes of the entry points that take a caller-owned workspace (include/se_hip.h)
-extern "C" size_t se_attn_bwd_workspace_bytes(long ntok) { return ntok > 0 ? (size_t)ntok * 4 * sizeof(float) : 0; }
 extern "C" size_t se_norm_prelu_bwd_workspace_bytes(int B, int C, int per_batch) {
   return (B > 0 && C > 0) ? (size_t)(per_batch ? B : 1) * C * 3 * sizeof(double) : 0;
 }

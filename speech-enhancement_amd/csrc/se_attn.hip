@@ -786,6 +786,418 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd2_kernel(AttnBwdArgs a, const
   }
 }
 
+
+// =====================================================================================================================
+// v3 backward: decoupled waves, key-stationary, split-bf16 MFMA.
+//
+// Why: the v2 kernel keeps dK / dV / dE in LDS accumulators shared by the waves of a workgroup; LDS float atomics run at one
+// lane per ~3 cycles on gfx950 (ds_add_f32: 192 cycles per wave-instruction, tools/micro/lds_atomic_bench.hip), so v2 uses
+// plain read-modify-writes under a lock-step schedule with one barrier per 16x16 tile pair -- all waves of a CU sit in the
+// same phase (MFMA, then LDS, then VALU) and nothing overlaps: 0.24 of the fp32-MFMA peak.
+//
+// Here ONE WAVE owns a work item (sequence, head, group of KT3 = 7 key tiles = 112 keys) and there is no barrier and no shared
+// accumulator in the main loop:
+//   * dK^T / dV^T of its 7 key tiles stay in registers (key loop unrolled: static indices) and are stored once;
+//   * the wave sweeps the query tiles; dQ^T of a query tile is summed over the wave's 7 key tiles in registers and then
+//     either stored (one key group covers the sequence: n <= 112) or added to global memory with fp32 atomics (3 adds per
+//     element for n = 321: 0.4 GB of atomic bytes per launch, overlapped with compute, well under the chip's 1.3 TB/s);
+//   * the relative-position terms use a per-query-tile OFFSET STRIP in wave-private LDS: U[q][delta] = q . E[delta] for the
+//     8 offset tiles the 7 key tiles touch is written once per query tile, every step reads its skewed 16x16 window and
+//     overwrites it IN PLACE with dS (each (q, delta) cell belongs to exactly one key), and the finished strip W = skew(dS)
+//     feeds  dQ^T += E^T W^T  and  dE^T += Q^T W  tile by tile;
+//   * dE accumulators live in a REGISTER WINDOW of 8 offset tiles that slides with the query tile (v_mov rotation); the
+//     tile leaving the window is flushed with global atomics into one of NREP replicas of the table (summed at the end).
+// Every product is an exact 3-way bf16 split evaluated with THREE v_mfma_f32_16x16x32_bf16: the contraction length is 16, so
+// the two halves of K = 32 carry two different split pairs (k slot (g, j): j < 4 -> first pair, j >= 4 -> second pair, index
+// 4g + (j & 3)):  [a_hi|a_mid].[b_lo|b_mid] + [a_hi|a_lo].[b_mid|b_hi] + [a_hi|a_mid].[b_hi|b_hi]  = the six products of the
+// fp32-equivalent split (dropped terms <= 2^-24 relative) at 48 instead of 128 matrix-pipe cycles per 16x16x16 product.
+// K is staged once per item, pre-split, in wave-private LDS: its row fragments are ds_read_b64, its column fragments (for
+// dQ^T += K^T dS^T) come from the same image through ds_read_b64_tr_b16.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+// mid / hi / lo bf16 planes of 4 fp32 values, packed two per dword (element j in half j & 1 of a plane's word j >> 1), kept
+// as ONE register run {m0 m1 h0 h1 l0 l1 - -}: the two 4-dword windows [m|h] (words 0..3) and [h|l] (words 2..5) are the
+// K = 32 operands of the three MFMAs below for an A operand AND for a B operand, so no operand is ever re-assembled with moves
+struct S3 { u32x8 v; };
+static __device__ __forceinline__ bf16x8 win_mh(const S3& s) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(s.v, s.v, 0, 1, 2, 3)); }
+static __device__ __forceinline__ bf16x8 win_hl(const S3& s) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(s.v, s.v, 2, 3, 4, 5)); }
+static __device__ __forceinline__ void set_m(S3& s, u32x2 p) { s.v[0] = p[0]; s.v[1] = p[1]; }
+static __device__ __forceinline__ void set_h(S3& s, u32x2 p) { s.v[2] = p[0]; s.v[3] = p[1]; }
+static __device__ __forceinline__ void set_l(S3& s, u32x2 p) { s.v[4] = p[0]; s.v[5] = p[1]; }
+static __device__ __forceinline__ u32x2 get_m(const S3& s) { return (u32x2){s.v[0], s.v[1]}; }
+static __device__ __forceinline__ u32x2 get_h(const S3& s) { return (u32x2){s.v[2], s.v[3]}; }
+static __device__ __forceinline__ u32x2 get_l(const S3& s) { return (u32x2){s.v[4], s.v[5]}; }
+
+static __device__ __forceinline__ unsigned pk_bf16(float a, float b) {        // one v_cvt_pk_bf16_f32 (RNE)
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+static __device__ __forceinline__ float bf_lo(unsigned w) { return __builtin_bit_cast(float, w << 16); }
+static __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// exact 3-way split x = hi + mid + lo (8 + 8 + 8 mantissa bits): 18 VALU instructions for 4 values
+static __device__ __forceinline__ S3 split3(float x0, float x1, float x2, float x3) {
+  S3 s;
+  s.v[6] = 0; s.v[7] = 0;
+  s.v[2] = pk_bf16(x0, x1); s.v[3] = pk_bf16(x2, x3);
+  x0 -= bf_lo(s.v[2]); x1 -= bf_hi(s.v[2]); x2 -= bf_lo(s.v[3]); x3 -= bf_hi(s.v[3]);
+  s.v[0] = pk_bf16(x0, x1); s.v[1] = pk_bf16(x2, x3);
+  x0 -= bf_lo(s.v[0]); x1 -= bf_hi(s.v[0]); x2 -= bf_lo(s.v[1]); x3 -= bf_hi(s.v[1]);
+  s.v[4] = pk_bf16(x0, x1); s.v[5] = pk_bf16(x2, x3);
+  return s;
+}
+static __device__ __forceinline__ S3 split3(const float4& v) { return split3(v.x, v.y, v.z, v.w); }
+static __device__ __forceinline__ S3 split3(const f32x4& v) { return split3(v[0], v[1], v[2], v[3]); }
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+// acc += A . B over the 16-long contraction whose index 4*kgroup + j (j = 0..3) the lane holds in a / b:
+// [m|h].[h|l] + [h|l].[m|h] + [m|h].[m|h] = mh + hl + hm + lh + mm + hh, the six products of the fp32-equivalent split
+static __device__ __forceinline__ f32x4 prod3(const S3& a, const S3& b, f32x4 acc) {
+  acc = MFMA_BF(win_mh(a), win_hl(b), acc);
+  acc = MFMA_BF(win_hl(a), win_mh(b), acc);
+  acc = MFMA_BF(win_mh(a), win_mh(b), acc);
+  return acc;
+}
+// two independent products interleaved (their accumulator chains hide each other's MFMA latency)
+static __device__ __forceinline__ void prod3x2(const S3& a1, const S3& b1, f32x4& c1, const S3& a2, const S3& b2, f32x4& c2) {
+  c1 = MFMA_BF(win_mh(a1), win_hl(b1), c1);
+  c2 = MFMA_BF(win_mh(a2), win_hl(b2), c2);
+  c1 = MFMA_BF(win_hl(a1), win_mh(b1), c1);
+  c2 = MFMA_BF(win_hl(a2), win_mh(b2), c2);
+  c1 = MFMA_BF(win_mh(a1), win_mh(b1), c1);
+  c2 = MFMA_BF(win_mh(a2), win_mh(b2), c2);
+}
+static __device__ __forceinline__ u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
+static __device__ __forceinline__ void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
+// hardware-transposed LDS read (ds_read_b64_tr_b16): within each 16-lane group, lane 4q + p supplies the address of row q,
+// columns 4p..4p+3 of a 4 x 16 block of 16-bit elements; lane i receives column i of the 4 rows.  EXEC must be full.
+static __device__ __forceinline__ u32x2 tr8(const unsigned char* lds_ptr) {
+  return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(lds_ptr)));
+}
+
+constexpr int NREP3 = 1;   // (unused by the scratch-based dE reduction; kept for the workspace layout)
+
+// split tables of the relative-position embedding: Es[3][R][16] (row fragments), Ets[3][16][ET] (column fragments)
+__global__ void attn_split_tables_kernel(const float* __restrict__ E, __bf16* __restrict__ Es, __bf16* __restrict__ Ets,
+                                         int R, int ET) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * 16) return;
+  int row = idx >> 4, d = idx & 15;
+  float x = E[idx];
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    __bf16 h = (__bf16)x;
+    x -= (float)h;
+    Es[((long)pl * R + row) * 16 + d] = h;
+    Ets[((long)pl * 16 + d) * ET + row] = h;
+  }
+}
+// fp32 transposed table Et[16][ld] of the v2 kernel
+__global__ void attn_transpose_table_kernel(const float* __restrict__ E, float* __restrict__ Et, int R, int ld) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * 16) return;
+  Et[(long)(idx & 15) * ld + (idx >> 4)] = E[idx];
+}
+
+struct AttnBwd3Args {
+  AttnGeom g;
+  const float* QKV; const float* dO; const float* LSE; const float* Dl;
+  float* dQKV;
+  const __bf16* Es; const __bf16* Ets;
+  float* dEs;                        // per-wave dE tiles: [wave item][nqt + KT][16 offsets][16 d]
+  int R, ET, maxpos;
+  float scale;
+  int dbg;                           // timing ablations (profiling builds only; 0 in production)
+};
+
+// key tiles of wave w when the 4 waves of a workgroup share one (sequence, head)
+static __device__ __host__ __forceinline__ void group_split(int nkt, int w, int& kt0, int& cnt) {
+  const int b = nkt >> 2, r = nkt & 3;
+  cnt = b + (w < r ? 1 : 0);
+  kt0 = w * b + (w < r ? w : r);
+}
+
+template <int KT>
+struct Lds3 {
+  static constexpr int NU = KT + 1;
+  static constexpr int SW = NU * 16 + (KT == 7 ? 0 : 4);      // strip row stride (floats)
+  static constexpr int KIMG = 3 * KT * 16 * 32;               // bytes: [3 planes][KT*16 keys][16 d] bf16
+  static constexpr int DIMG = 3 * 16 * 32;                    // bytes: [3 planes][16][16] bf16 (one tile, split)
+  static constexpr int STRIP = 16 * SW * 4;
+  static constexpr int WAVE = KIMG + DIMG + STRIP;
+};
+
+// raw query-side operands of one query tile (prefetched one tile ahead)
+struct QSide { float4 q4, do4; float qcf[4], docf[4], lse[4], dl[4]; };
+
+// One wave: key tiles kt0 .. kt0 + nk_w - 1 of one (sequence, head), all query tiles.
+//   NK    : key tiles the register arrays and the unrolled loops are built for;
+//   EXACT : nk_w == NK, the unrolled key loop has no branches (one basic block per query tile: the compiler overlaps the LDS /
+//           global latencies of step s + 1 with the arithmetic of step s);  otherwise NK = KT and steps s >= nk_w are skipped;
+//   GROUP : the 4 waves of the workgroup share the (sequence, head): dQ tiles are summed through LDS (one barrier per query
+//           tile) and stored once -- deterministic, no atomics.
+template <int KT, int NK, bool EXACT, bool GROUP>
+static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, unsigned char* smem3, const int wave, const int lane,
+                                                      const long item, const int kt0, const int nk_w) {
+  using L3 = Lds3<KT>;
+  constexpr int NU = NK + 1, SW = L3::SW;
+  const int c = lane & 15, g = lane >> 4;
+  const int n = a.g.n, nkt = (n + 15) >> 4, nqt = nkt;
+  unsigned char* wl = smem3 + (size_t)wave * L3::WAVE;
+  unsigned char* Kimg = wl;
+  unsigned char* Dimg = wl + L3::KIMG;
+  float* strip = reinterpret_cast<float*>(wl + L3::KIMG + L3::DIMG);
+  float* dqs = reinterpret_cast<float*>(smem3 + (size_t)4 * L3::WAVE);      // GROUP: [2 parities][4 waves][256]
+  const int head = (int)(item & 3), seq = (int)(item >> 2);
+  const long base = seq_base(a.g, seq);
+  const int ps = (int)a.g.pos_stride;
+  const float* qb = a.QKV + base * 192 + head * 16;             // + pos * ps * 192 (+64: K, +128: V)
+  const float* dob = a.dO + base * 64 + head * 16;
+  const float* lseb = a.LSE + base * 4 + head;
+  const float* dlb = a.Dl + base * 4 + head;
+  float* dqb = a.dQKV + base * 192 + head * 16;
+  const float l2e = 1.4426950408889634f, sc2 = a.scale * l2e;
+  const long witem = GROUP ? item * 4 + wave : item;
+  float* dEs = a.dEs + witem * (long)(nqt + KT) * 256;
+  const int trrow = c >> 2, trcol = c & 3;                      // transposed-read address roles of this lane
+  const __bf16 *Es0 = a.Es, *Es1 = a.Es + (long)a.R * 16, *Es2 = a.Es + (long)a.R * 32;
+  const __bf16 *Et0 = a.Ets, *Et1 = a.Ets + (long)a.ET * 16, *Et2 = a.Ets + (long)a.ET * 32;
+
+  // ---- stage this wave's keys: K pre-split into the LDS image (row fragments b64, column fragments tr_b16) ----
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    const int key = (kt0 + s) * 16 + c;
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((EXACT || s < nk_w) && key < n) k4 = *reinterpret_cast<const float4*>(qb + (unsigned)(key * ps * 192 + 64 + 4 * g));
+    const S3 ks = split3(k4);
+    st8(Kimg + ((0 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_h(ks));
+    st8(Kimg + ((1 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_m(ks));
+    st8(Kimg + ((2 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_l(ks));
+  }
+  f32x4 dk[NK], dv[NK], de[NU];
+#pragma unroll
+  for (int s = 0; s < NK; ++s) { dk[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) de[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // one finished offset tile of the dE window goes to this wave's slot (Dtile + kt0 + KT) of the scratch table:
+  // v[r] = dE[delta = 16 Dtile + c][d = 4g + r]; tiles no (query, key) pair can reach are neither stored nor reduced
+  auto flush = [&](const f32x4& v, int Dtile) {
+    if (Dtile < -nkt || Dtile > nkt || (a.dbg & 1)) return;
+    *reinterpret_cast<float4*>(dEs + (Dtile + kt0 + KT) * 256 + c * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+  };
+  auto load_qside = [&](int qt, QSide& o) {
+    const int q0 = qt * 16;
+    int qc = q0 + c; if (qc > n - 1) qc = n - 1;
+    o.q4 = *reinterpret_cast<const float4*>(qb + (unsigned)(qc * ps * 192 + 4 * g));        // Q[q = c][4g..]
+    o.do4 = *reinterpret_cast<const float4*>(dob + (unsigned)(qc * ps * 64 + 4 * g));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int qr = q0 + 4 * g + j;
+      if (qr > n - 1) qr = n - 1;
+      o.qcf[j] = qb[(unsigned)(qr * ps * 192 + c)];          // Q[q = 4g + j][d = c]   (column fragment: contraction over queries)
+      o.docf[j] = dob[(unsigned)(qr * ps * 64 + c)];
+      o.lse[j] = lseb[(unsigned)(qr * ps * 4)];
+      o.dl[j] = dlb[(unsigned)(qr * ps * 4)];
+    }
+  };
+  QSide nxt;
+  load_qside(0, nxt);
+
+  for (int qt = 0; qt < nqt; ++qt) {
+    // ---- query-side operands of this tile (prefetched during the previous tile; split once, used by all key tiles) ----
+    const int q0 = qt * 16;
+    const QSide cur = nxt;
+    if (qt + 1 < nqt) load_qside(qt + 1, nxt);
+    float nlse2[4], dl4s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // C-layout rows are queries 4g + r: p = exp2((s + u) * scale * log2e - lse * log2e); rows beyond n get -inf -> p = 0
+      nlse2[j] = (q0 + 4 * g + j < n) ? -cur.lse[j] * l2e : -__builtin_inff();
+      dl4s[j] = cur.dl[j] * a.scale;
+    }
+    const S3 qrow = split3(cur.q4);
+    const S3 dorow = split3(cur.do4.x * a.scale, cur.do4.y * a.scale, cur.do4.z * a.scale, cur.do4.w * a.scale);   // dP pre-scaled
+    const S3 qcol = split3(cur.qcf[0], cur.qcf[1], cur.qcf[2], cur.qcf[3]);
+    const S3 docol = split3(cur.docf[0], cur.docf[1], cur.docf[2], cur.docf[3]);
+
+    // ---- offset strip: U[q][delta] for the NU tiles Dtile = qt - kt0 - u, strip columns 16 (NK - u) + (delta & 15) ----
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int row = 16 * (qt - kt0 - u) + c + a.maxpos;          // in range by the launch conditions
+      S3 es;
+      es.v[6] = 0; es.v[7] = 0;
+      if (a.dbg & 8) es = qrow; else {
+        const unsigned eo = (unsigned)(row * 16 + 4 * g);
+        set_h(es, ld8(Es0 + eo)); set_m(es, ld8(Es1 + eo)); set_l(es, ld8(Es2 + eo));
+      }
+      const f32x4 uu = prod3(qrow, es, (f32x4){0.f, 0.f, 0.f, 0.f});   // C[q = 4g + r][delta_local = c]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) strip[(4 * g + r) * SW + 16 * (NK - u) + c] = uu[r];
+    }
+    f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                 // dQ^T[d = 4g + r][q = c]
+
+    // ---- the wave's key tiles ----
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+      if (EXACT || s < nk_w) {                                       // wave-uniform
+        const int j0 = (kt0 + s) * 16;
+        const bool kv = j0 + c < n;
+        S3 krow;
+        krow.v[6] = 0; krow.v[7] = 0;
+        set_h(krow, ld8(Kimg + ((0 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
+        set_m(krow, ld8(Kimg + ((1 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
+        set_l(krow, ld8(Kimg + ((2 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
+        int kj = j0 + c; if (kj > n - 1) kj = n - 1;
+        const S3 vrow = (a.dbg & 4) ? krow : split3(*reinterpret_cast<const float4*>(qb + (unsigned)(kj * ps * 192 + 128 + 4 * g)));
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        prod3x2(qrow, krow, s4, dorow, vrow, dp);                    // S[q = 4g + r][key = c], scale * dP[q][key]
+        f32x4 pp, ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* cell = &strip[(4 * g + r) * SW + 16 * (NK - s) + (4 * g + r) - c];    // the cell of offset q - key
+          float p = __builtin_amdgcn_exp2f(fmaf(s4[r] + *cell, sc2, nlse2[r]));
+          p = kv ? p : 0.f;
+          pp[r] = p;
+          ds[r] = p * (dp[r] - dl4s[r]);
+          *cell = ds[r];                                             // W = skew(dS) replaces U in place
+        }
+        // contraction over the query rows 4g + r: the accumulator registers ARE the B operands
+        const S3 pps = split3(pp), dss = split3(ds);
+        // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+        prod3x2(docol, pps, dv[s], qcol, dss, dk[s]);
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: both operands through hardware-transposed reads -- A from the K row
+        // image, B from the split dS tile stored [key][q] (each lane writes 4 consecutive queries of its key: 8 bytes)
+        st8(Dimg + (0 * 16 + c) * 32 + g * 8, get_h(dss));
+        st8(Dimg + (1 * 16 + c) * 32 + g * 8, get_m(dss));
+        st8(Dimg + (2 * 16 + c) * 32 + g * 8, get_l(dss));
+        S3 kcol, dst;
+        kcol.v[6] = 0; kcol.v[7] = 0; dst.v[6] = 0; dst.v[7] = 0;
+        set_h(kcol, tr8(Kimg + ((0 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
+        set_m(kcol, tr8(Kimg + ((1 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
+        set_l(kcol, tr8(Kimg + ((2 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
+        set_h(dst, tr8(Dimg + (0 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+        set_m(dst, tr8(Dimg + (1 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+        set_l(dst, tr8(Dimg + (2 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+        dq = prod3(kcol, dst, dq);
+      }
+    }
+
+    // ---- consume the strip: dQ^T += E^T W^T, dE^T += Q^T W, one offset tile at a time ----
+    const int lim = 16 * nk_w;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      // a cell (q_local a, delta_local dl) of tile u belongs to key_rel = 16 u + a - dl (relative to the wave's first key);
+      // cells whose key the wave does not own still hold U values: mask them
+      float4 w4 = *reinterpret_cast<const float4*>(&strip[c * SW + 16 * (NK - u) + 4 * g]);     // W[a = c][dl = 4g + j]
+      if (!EXACT || u == 0 || u == NU - 1) {
+        const int kr = 16 * u + c - 4 * g;
+        if ((unsigned)kr >= (unsigned)lim) w4.x = 0.f;
+        if ((unsigned)(kr - 1) >= (unsigned)lim) w4.y = 0.f;
+        if ((unsigned)(kr - 2) >= (unsigned)lim) w4.z = 0.f;
+        if ((unsigned)(kr - 3) >= (unsigned)lim) w4.w = 0.f;
+      }
+      const S3 ws = split3(w4);
+      st8(Dimg + (0 * 16 + c) * 32 + g * 8, get_h(ws));             // image [a][dl]
+      st8(Dimg + (1 * 16 + c) * 32 + g * 8, get_m(ws));
+      st8(Dimg + (2 * 16 + c) * 32 + g * 8, get_l(ws));
+      S3 ec, wt;                                                     // E[Dt + 4g + j][d = c]
+      ec.v[6] = 0; ec.v[7] = 0; wt.v[6] = 0; wt.v[7] = 0;
+      if (a.dbg & 8) ec = qcol; else {
+        const unsigned eo = (unsigned)(c * a.ET + 16 * (qt - kt0 - u) + a.maxpos + 4 * g);
+        set_h(ec, ld8(Et0 + eo)); set_m(ec, ld8(Et1 + eo)); set_l(ec, ld8(Et2 + eo));
+      }
+      set_h(wt, tr8(Dimg + (0 * 16 + 4 * g + trrow) * 32 + trcol * 8));   // W[a = 4g + j][dl = c]
+      set_m(wt, tr8(Dimg + (1 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+      set_l(wt, tr8(Dimg + (2 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+      // dQ^T[d][q] += E^T[d][dl] W^T[dl][q];  dE^T[d][dl] += Q^T[d][q] W[q][dl]
+      prod3x2(ec, ws, dq, qcol, wt, de[u]);
+    }
+
+    // ---- dQ of this query tile ----
+    if (GROUP) {
+      float* slot = dqs + ((qt & 1) * 4) * 256;
+      *reinterpret_cast<float4*>(slot + wave * 256 + c * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+      __syncthreads();
+      if (wave == (qt & 3) && q0 + c < n) {
+        float4 t0 = *reinterpret_cast<const float4*>(slot + 0 * 256 + c * 16 + 4 * g);
+        const float4 t1 = *reinterpret_cast<const float4*>(slot + 1 * 256 + c * 16 + 4 * g);
+        const float4 t2 = *reinterpret_cast<const float4*>(slot + 2 * 256 + c * 16 + 4 * g);
+        const float4 t3 = *reinterpret_cast<const float4*>(slot + 3 * 256 + c * 16 + 4 * g);
+        t0.x += t1.x + (t2.x + t3.x); t0.y += t1.y + (t2.y + t3.y); t0.z += t1.z + (t2.z + t3.z); t0.w += t1.w + (t2.w + t3.w);
+        *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = t0;
+      }
+    } else if (q0 + c < n) {
+      *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    }
+    // ---- slide the dE window: tile qt - kt0 - NK is complete ----
+    flush(de[NU - 1], qt - kt0 - NK);
+#pragma unroll
+    for (int u = NU - 1; u > 0; --u) de[u] = de[u - 1];
+    de[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // after the last rotation slot u holds tile nqt - kt0 - u
+#pragma unroll
+  for (int u = 1; u < NU; ++u) flush(de[u], nqt - kt0 - u);
+  // ---- dK, dV of the wave's keys: C layout [d = 4g + r][key = c] ----
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    const int key = (kt0 + s) * 16 + c;
+    if ((EXACT || s < nk_w) && key < n) {
+      float* p = dqb + (unsigned)(key * ps * 192 + 4 * g);
+      *reinterpret_cast<float4*>(p + 64) = make_float4(dk[s][0], dk[s][1], dk[s][2], dk[s][3]);
+      *reinterpret_cast<float4*>(p + 128) = make_float4(dv[s][0], dv[s][1], dv[s][2], dv[s][3]);
+    }
+  }
+}
+
+template <int KT, bool GROUP>
+__global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkt = (a.g.n + 15) >> 4;
+  if (GROUP) {
+    int kt0, cnt;
+    group_split(nkt, wave, kt0, cnt);
+    // every wave runs nqt barriers whichever branch it takes (s_barrier counts arrivals, not program counters)
+    if (cnt == KT) attn_bwd3_body<KT, KT, true, true>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
+    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
+    else attn_bwd3_body<KT, KT, false, true>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
+  } else {
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)a.g.nseq * 4) return;                     // whole wave leaves: EXEC stays full for the others
+    if (nkt == KT) attn_bwd3_body<KT, KT, true, false>(a, smem3, wave, lane, item, 0, nkt);
+    else attn_bwd3_body<KT, KT, false, false>(a, smem3, wave, lane, item, 0, nkt);
+  }
+}
+
+// dE[delta][d] += sum over the wave items of their finished tiles.  grid = (offset tile, chunk of 64 wave items)
+template <int KT, bool GROUP>
+__global__ __launch_bounds__(256) void attn_de_reduce3_kernel(const float* __restrict__ dEs, float* __restrict__ dE, long nwitems,
+                                                              int nkt, int maxpos, int R) {
+  const int Dtile = (int)blockIdx.x - nkt;                       // -nkt .. nkt
+  const long w0 = (long)blockIdx.y * 64;
+  const int nslot = nkt + KT;
+  // a wave with key tiles [kt0, kt0 + cnt) stores the tiles -kt0 - cnt .. nqt - kt0 - 1 in slot (tile + kt0 + KT)
+  int kt0s[4] = {0, 0, 0, 0}, cnts[4] = {nkt, nkt, nkt, nkt};
+  if (GROUP) { for (int w = 0; w < 4; ++w) group_split(nkt, w, kt0s[w], cnts[w]); }
+  float s = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) {
+    const long w = w0 + i;
+    const int kt0 = kt0s[i & 3], cnt = cnts[i & 3];              // w0 is a multiple of 4
+    const int slot = Dtile + kt0 + KT;
+    if (w < nwitems && slot >= KT - cnt && slot < nslot) s += dEs[(w * nslot + slot) * 256 + threadIdx.x];
+  }
+  const int row = 16 * Dtile + (threadIdx.x >> 4) + maxpos;
+  if (row >= 0 && row < R) atomicAdd(&dE[(long)row * 16 + (threadIdx.x & 15)], s);
+}
+
 static int check_geom(const AttnGeom& g) {
   SE_REQUIRE(g.nseq > 0 && g.n > 0 && g.inner > 0, "attention: bad geometry");
   return 0;
@@ -825,17 +1237,92 @@ extern "C" int se_attn_fwd(const float* QKV, const float* E, float* O, float* LS
   return se_check_launch("se_attn_fwd");
 }
 
+// workspace of se_attn_bwd: Dl [ntok][4] | Es [3][R][16] bf16 | Ets [3][16][ET] bf16 | per-wave dE tiles
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+struct AttnWs { size_t dl, es, ets, des, total; int R, ET; };
+// the v3 kernel runs when the padded sequence fits the offset table and one of its two shapes: returns KT (7: one wave per
+// (sequence, head), n <= 112; 6: four waves per (sequence, head), n <= 384) or 0
+static int attn_v3_shape(int n, int maxpos) {
+  const int nkt = (n + 15) / 16;
+  if ((maxpos % 4) != 0 || 16 * nkt + 16 * 8 > maxpos) return 0;
+  if (nkt <= 7) return 7;
+  if ((nkt + 3) / 4 <= 6) return 6;
+  return 0;
+}
+static AttnWs attn_ws(long ntok, int maxpos, int nseq, int n) {
+  AttnWs w;
+  w.R = 2 * maxpos + 1;
+  w.ET = (w.R + 3 + 16) / 4 * 4;
+  w.dl = 0;
+  w.es = al256((size_t)ntok * 4 * sizeof(float));
+  w.ets = w.es + al256((size_t)3 * w.R * 16 * 2);
+  w.des = w.ets + al256((size_t)3 * 16 * w.ET * 2);
+  const int kt = attn_v3_shape(n, maxpos), nkt = (n + 15) / 16;
+  const size_t witems = (size_t)nseq * 4 * (kt == 6 ? 4 : 1);
+  w.total = w.des + (kt ? al256(witems * (size_t)(nkt + kt) * 256 * sizeof(float)) : 0);
+  return w;
+}
+extern "C" size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n) {
+  return (ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0) ? attn_ws(ntok, maxpos, nseq, n).total : 0;
+}
+
+template <int KT, bool GROUP>
+static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float* dE) {
+  using L3 = Lds3<KT>;
+  const size_t sh = (size_t)4 * L3::WAVE + (GROUP ? 2 * 4 * 256 * sizeof(float) : 0);
+  static bool raised = false;
+  if (!raised) {
+    SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd3_kernel<KT, GROUP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit to %zu", sh);
+    raised = true;
+  }
+  const long items = (long)b.g.nseq * 4;
+  const int nkt = (b.g.n + 15) / 16;
+  hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
+  hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 64)), dim3(256), 0, s, b.dEs, dE,
+                     nwitems, nkt, b.maxpos, b.R);
+  return 0;
+}
+
 extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
-                           float* Dl, float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
-                           long inner_stride, long pos_stride, long ntok, int maxpos, float scale, const float* Et,
-                           int et_ld, void* stream) {
+                           float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
+                           long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws,
+                           size_t ws_bytes, void* stream) {
+  SE_REQUIRE(QKV && E && O && dO && LSE && dQKV && dE && ws, "attn_bwd: null operand");
+  SE_REQUIRE(ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0, "attn_bwd: bad sizes");
+  const AttnWs w = attn_ws(ntok, maxpos, nseq, n);
+  SE_REQUIRE(ws_bytes >= w.total, "attn_bwd: workspace of %zu bytes, need %zu (se_attn_bwd_workspace_bytes)", ws_bytes, w.total);
+  SE_REQUIRE(((uintptr_t)ws & 15) == 0, "attn_bwd: workspace must be 16-byte aligned");
+  float* Dl = reinterpret_cast<float*>((char*)ws + w.dl);
   AttnBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, dO, LSE, Dl, dQKV, dE, maxpos, scale, 0};
-  if (const char* e = getenv("SE_ATTN_DBG")) a.dbg = atoi(e);
   if (int e = check_geom(a.g)) return e;
-  SE_REQUIRE(QKV && E && O && dO && LSE && Dl && dQKV && dE, "attn_bwd: null operand");
   hipStream_t s = as_stream(stream);
   hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
-  if (Et && (et_ld % 4) == 0 && et_ld >= 2 * maxpos + 1 && n <= 336 && maxpos >= 352) {
+  int kt3 = attn_v3_shape(n, maxpos);
+  if (const char* e = getenv("SE_ATTN_BWD")) { if (atoi(e) == 2) kt3 = 0; }
+  if (kt3 && pos_stride * 192 * (long)(16 * ((n + 15) / 16)) < 2147483647L) {
+    // decoupled split-bf16 kernel: one wave per (sequence, head[, key group]); no offset clamp can be active
+    __bf16* Es = reinterpret_cast<__bf16*>((char*)ws + w.es);
+    __bf16* Ets = reinterpret_cast<__bf16*>((char*)ws + w.ets);
+    SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.des - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
+    hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
+    AttnBwd3Args b{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, dO, LSE, Dl, dQKV, Es, Ets,
+                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0};
+    if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
+    const long items = (long)nseq * 4;
+    if (int e = (kt3 == 7 ? launch_bwd3<7, false>(b, items, s, dE) : launch_bwd3<6, true>(b, items * 4, s, dE))) return e;
+    return se_check_launch("se_attn_bwd");
+  }
+  // transposed table for the v2 kernel (fp32): built in the Ets region of the workspace
+  float* Et = nullptr;
+  const int et_ld = (2 * maxpos + 1 + 3) / 4 * 4;
+  if (n <= 336 && maxpos >= 352 && (size_t)16 * et_ld * sizeof(float) <= w.total - w.es) {
+    Et = reinterpret_cast<float*>((char*)ws + w.es);
+    SE_REQUIRE(hipMemsetAsync(Et, 0, (size_t)16 * et_ld * sizeof(float), s) == hipSuccess, "attn_bwd: memset failed");
+    hipLaunchKernelGGL(attn_transpose_table_kernel, dim3(cdiv((long)(2 * maxpos + 1) * 16, 256)), dim3(256), 0, s, E, Et,
+                       2 * maxpos + 1, et_ld);
+  }
+  if (Et) {
     // single-pass staged kernel (no clamp aliasing possible: |i-j| < 352 <= maxpos)
     const long items2 = (long)nseq * 4;
     if (n <= 112) {
