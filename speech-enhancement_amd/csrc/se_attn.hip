@@ -882,7 +882,8 @@ static __device__ __forceinline__ u32x2 tr8(const unsigned char* lds_ptr) {
 
 constexpr int NREP3 = 1;   // (unused by the scratch-based dE reduction; kept for the workspace layout)
 
-// split tables of the relative-position embedding: Es[3][R][16] (row fragments), Ets[3][16][ET] (column fragments)
+// split tables of the relative-position embedding: Es[3][R][16] (row fragments), Ets[3][ET/16 tiles][16 d][16 offsets]
+// (column fragments; tile-major so that one offset tile is 512 contiguous bytes per plane: 4 cache lines instead of 16)
 __global__ void attn_split_tables_kernel(const float* __restrict__ E, __bf16* __restrict__ Es, __bf16* __restrict__ Ets,
                                          int R, int ET) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -894,7 +895,7 @@ __global__ void attn_split_tables_kernel(const float* __restrict__ E, __bf16* __
     __bf16 h = (__bf16)x;
     x -= (float)h;
     Es[((long)pl * R + row) * 16 + d] = h;
-    Ets[((long)pl * 16 + d) * ET + row] = h;
+    Ets[(long)pl * ET * 16 + ((long)(row >> 4) * 16 + d) * 16 + (row & 15)] = h;      // [plane][tile][d][16 offsets]
   }
 }
 // fp32 transposed table Et[16][ld] of the v2 kernel
@@ -912,7 +913,7 @@ struct AttnBwd3Args {
   float* dEs;                        // per-wave dE tiles: [wave item][nqt + KT][16 offsets][16 d]
   int R, ET, maxpos;
   float scale;
-  int dbg;                           // timing ablations (profiling builds only; 0 in production)
+  int dbg;                           // timing ablations: SE_ATTN_DBG bits 1 no dE flush, 4 V := K, 8 E := Q (0 in production)
 };
 
 // key tiles of wave w when the 4 waves of a workgroup share one (sequence, head)
@@ -1041,6 +1042,11 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
       for (int r = 0; r < 4; ++r) strip[(4 * g + r) * SW + 16 * (NK - u) + c] = uu[r];
     }
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                 // dQ^T[d = 4g + r][q = c]
+    auto load_v = [&](int s_) {
+      int kj = (kt0 + s_) * 16 + c; if (kj > n - 1) kj = n - 1;
+      return *reinterpret_cast<const float4*>(qb + (unsigned)(kj * ps * 192 + 128 + 4 * g));
+    };
+    float4 vnext = load_v(0);
 
     // ---- the wave's key tiles ----
 #pragma unroll
@@ -1053,8 +1059,11 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
         set_h(krow, ld8(Kimg + ((0 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
         set_m(krow, ld8(Kimg + ((1 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
         set_l(krow, ld8(Kimg + ((2 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
-        int kj = j0 + c; if (kj > n - 1) kj = n - 1;
-        const S3 vrow = (a.dbg & 4) ? krow : split3(*reinterpret_cast<const float4*>(qb + (unsigned)(kj * ps * 192 + 128 + 4 * g)));
+        const float4 vcur = vnext;
+        if (s + 1 < NK) vnext = load_v(s + 1);                       // one step ahead
+        // (the run-time ablation switches double as scheduling fences: without these branch points the scheduler hoists
+        // whole steps' loads, spills, and the kernel runs 8 % slower)
+        const S3 vrow = (a.dbg & 4) ? krow : split3(vcur);
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
         prod3x2(qrow, krow, s4, dorow, vrow, dp);                    // S[q = 4g + r][key = c], scale * dP[q][key]
         f32x4 pp, ds;
@@ -1109,7 +1118,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
       S3 ec, wt;                                                     // E[Dt + 4g + j][d = c]
       ec.v[6] = 0; ec.v[7] = 0; wt.v[6] = 0; wt.v[7] = 0;
       if (a.dbg & 8) ec = qcol; else {
-        const unsigned eo = (unsigned)(c * a.ET + 16 * (qt - kt0 - u) + a.maxpos + 4 * g);
+        const unsigned eo = (unsigned)(((qt - kt0 - u) * 16 + a.maxpos + c) * 16 + 4 * g);   // tile (qt-kt0-u) + maxpos/16, row d = c
         set_h(ec, ld8(Et0 + eo)); set_m(ec, ld8(Et1 + eo)); set_l(ec, ld8(Et2 + eo));
       }
       set_h(wt, tr8(Dimg + (0 * 16 + 4 * g + trrow) * 32 + trcol * 8));   // W[a = 4g + j][dl = c]
@@ -1244,7 +1253,7 @@ struct AttnWs { size_t dl, es, ets, des, total; int R, ET; };
 // (sequence, head), n <= 112; 6: four waves per (sequence, head), n <= 384) or 0
 static int attn_v3_shape(int n, int maxpos) {
   const int nkt = (n + 15) / 16;
-  if ((maxpos % 4) != 0 || 16 * nkt + 16 * 8 > maxpos) return 0;
+  if ((maxpos % 16) != 0 || 16 * nkt + 16 * 8 > maxpos) return 0;
   if (nkt <= 7) return 7;
   if ((nkt + 3) / 4 <= 6) return 6;
   return 0;
@@ -1252,7 +1261,7 @@ static int attn_v3_shape(int n, int maxpos) {
 static AttnWs attn_ws(long ntok, int maxpos, int nseq, int n) {
   AttnWs w;
   w.R = 2 * maxpos + 1;
-  w.ET = (w.R + 3 + 16) / 4 * 4;
+  w.ET = (w.R + 16 + 15) / 16 * 16;
   w.dl = 0;
   w.es = al256((size_t)ntok * 4 * sizeof(float));
   w.ets = w.es + al256((size_t)3 * w.R * 16 * 2);
