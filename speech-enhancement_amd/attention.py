@@ -37,7 +37,7 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
     ws = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
     npad = (n + 15) // 16 * 16
     v3 = maxpos % 16 == 0 and npad + 128 <= maxpos and n <= 384
-    key = ('attn_bwd3_kernel (+delta, tables)' if v3 else
+    key = ('attn_bwd3_bf16x6 (+delta, tables, dE reduce)' if v3 else
            'attn_bwd2_kernel (+delta)' if n <= 336 and maxpos >= 352 else 'attn_bwd_dkv + attn_bwd_dq (+delta)')
     L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dqkv), L.ptr(dE),
            C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),

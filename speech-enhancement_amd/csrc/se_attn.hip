@@ -1185,26 +1185,39 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
   }
 }
 
-// dE[delta][d] += sum over the wave items of their finished tiles.  grid = (offset tile, chunk of 64 wave items)
+// dE[delta][d] += sum over the wave items of their finished tiles.  grid = (offset tile, chunk of 256 wave items); a
+// workgroup streams 256 x 1 KB with 16-byte loads (4 items in flight per 64-lane group), sums through LDS, 1 KB of atomics.
 template <int KT, bool GROUP>
 __global__ __launch_bounds__(256) void attn_de_reduce3_kernel(const float* __restrict__ dEs, float* __restrict__ dE, long nwitems,
                                                               int nkt, int maxpos, int R) {
+  __shared__ float4 part[4][64];
   const int Dtile = (int)blockIdx.x - nkt;                       // -nkt .. nkt
-  const long w0 = (long)blockIdx.y * 64;
-  const int nslot = nkt + KT;
+  const long w0 = (long)blockIdx.y * 256;
+  const int nslot = nkt + KT, t = threadIdx.x & 63, sub = threadIdx.x >> 6;
   // a wave with key tiles [kt0, kt0 + cnt) stores the tiles -kt0 - cnt .. nqt - kt0 - 1 in slot (tile + kt0 + KT)
   int kt0s[4] = {0, 0, 0, 0}, cnts[4] = {nkt, nkt, nkt, nkt};
   if (GROUP) { for (int w = 0; w < 4; ++w) group_split(nkt, w, kt0s[w], cnts[w]); }
-  float s = 0.f;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-  for (int i = 0; i < 64; ++i) {
+  for (int i = sub; i < 256; i += 4) {                            // w0 and the stride are multiples of 4: wave role = sub
     const long w = w0 + i;
-    const int kt0 = kt0s[i & 3], cnt = cnts[i & 3];              // w0 is a multiple of 4
-    const int slot = Dtile + kt0 + KT;
-    if (w < nwitems && slot >= KT - cnt && slot < nslot) s += dEs[(w * nslot + slot) * 256 + threadIdx.x];
+    const int slot = Dtile + kt0s[sub] + KT;
+    if (w < nwitems && slot >= KT - cnts[sub] && slot < nslot) {
+      const float4 v = *reinterpret_cast<const float4*>(dEs + (w * nslot + slot) * 256 + t * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  const int row = 16 * Dtile + (threadIdx.x >> 4) + maxpos;
-  if (row >= 0 && row < R) atomicAdd(&dE[(long)row * 16 + (threadIdx.x & 15)], s);
+  part[sub][t] = s;
+  __syncthreads();
+  if (sub == 0) {
+    const float4 b = part[1][t], c4 = part[2][t], d = part[3][t];
+    s.x += b.x + (c4.x + d.x); s.y += b.y + (c4.y + d.y); s.z += b.z + (c4.z + d.z); s.w += b.w + (c4.w + d.w);
+    const int row = 16 * Dtile + (t >> 2) + maxpos;              // element index in the tile = 4 t .. 4 t + 3 = [delta_l][d]
+    if (row >= 0 && row < R) {
+      float* p = &dE[(long)row * 16 + (t & 3) * 4];
+      atomicAdd(p, s.x); atomicAdd(p + 1, s.y); atomicAdd(p + 2, s.z); atomicAdd(p + 3, s.w);
+    }
+  }
 }
 
 static int check_geom(const AttnGeom& g) {
@@ -1288,7 +1301,7 @@ static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float
   const long items = (long)b.g.nseq * 4;
   const int nkt = (b.g.n + 15) / 16;
   hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
-  hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 64)), dim3(256), 0, s, b.dEs, dE,
+  hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 256)), dim3(256), 0, s, b.dEs, dE,
                      nwitems, nkt, b.maxpos, b.R);
   return 0;
 }
