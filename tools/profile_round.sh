@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel-trace stats of the default bench + separate PMC passes (SQ counters in two sets,
+# FETCH_SIZE, WRITE_SIZE -- never combined with each other or with other traces).  usage: tools/profile_round.sh r02b
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+B="python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS -d $OUT/sq1 -o p -- $B > $OUT/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq2 -o p -- $B > $OUT/sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p -- $B > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p -- $B > $OUT/write.log 2>&1
+python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench.err
+ls -R $OUT | head -40
