@@ -186,10 +186,11 @@ def main():
     roof = None
     if dom is not None:
         k, v = dom
-        traffic = None
+        traffic = mfma_busy = None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tpath):      # PMC passes are separate rocprofv3 runs; per launch, bytes
-            traffic = json.load(open(tpath)).get('kernels', {}).get(k, {}).get('traffic_bytes_per_launch')
+        if os.path.exists(tpath):      # PMC passes are separate rocprofv3 runs (tools/profile_round.sh); per launch
+            ent = json.load(open(tpath)).get('kernels', {}).get(k, {})
+            traffic, mfma_busy = ent.get('traffic_bytes_per_launch'), ent.get('mfma_busy_pct')
         if k.startswith('gemm_k64_panel') or k.startswith('dwconv'):
             ach = v['bytes'] / (v['ms'] * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'kernel': k, 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
@@ -207,7 +208,7 @@ def main():
                 peak = PEAK_F32_MFMA_TFLOPS
                 note = 'algorithmic fp32 FLOPs; peak = dense fp32 MFMA (v_mfma_f32_*)'
             roof = {'bound': 'mfma', 'kernel': k, 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4), 'traffic': traffic, 'note': note}
+                    'frac': round(ach / peak, 4), 'traffic': traffic, 'mfma_busy_pct_pmc': mfma_busy, 'note': note}
         roof.update({'launches_per_step': v['launches'] // a.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
                      'share_of_step_time': round(v['ms'] / (dt * 1e3), 3),
                      'families': {kk: {'ms_per_step': round(vv['ms'] / a.steps, 3),

@@ -13,4 +13,9 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o p -- $B > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o p -- $B > $OUT/write.log 2>&1
 python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench_line.json 2> $OUT/bench.err
-ls -R $OUT | head -40
+
+# keep only the summaries (gpurun copies back at most 64 MiB)
+python3 $R/tools/pmc_summary.py $OUT/pmc_summary.json $OUT/sq1/p_results.db $OUT/sq2/p_results.db $OUT/fetch/p_results.db $OUT/write/p_results.db > $OUT/pmc_summary.txt 2>&1
+cp $OUT/trace/*/t_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || cp $OUT/trace/t_kernel_stats.csv $OUT/kernel_stats.csv
+rm -rf $OUT/trace $OUT/sq1 $OUT/sq2 $OUT/fetch $OUT/write
+ls -la $OUT
