@@ -44,46 +44,64 @@ def predict(model, config, noisy_signal, device=torch.device('cuda')):
 
 
 class GraphedEnhancer:
-    """predict() for a stream of equal-length utterances with the whole device-side pipeline (clip scale, STFT,
-    generator, iSTFT, de-normalisation) captured once into a HIP graph and replayed per utterance.
+    """predict() with the whole device-side pipeline (STFT, generator, iSTFT, de-normalisation) captured into HIP graphs,
+    one graph per LENGTH BUCKET = number of STFT frames (all lengths that pad to the same multiple of the hop share a
+    graph; the reference's wrap-padding to the hop multiple (inference_gan.py:84-87) is done on the host copy, the
+    clip scale c of the UNPADDED signal by one eager launch in front of the replay, so results equal predict() exactly).
 
     Batch-1 inference is launch-bound: ~1500 kernel launches cost ~20 ms of host time for ~10 ms of GPU work, a replayed
     graph removes the host side.  All kernels are launched on torch's current stream, which is the capture stream
-    inside `torch.cuda.graph`; the dynamic-LDS attributes are raised by the eager warm-up run before the capture."""
+    inside `torch.cuda.graph`; the dynamic-LDS attributes are raised by the eager warm-up run before the capture.
+    `max_graphs` bounds the cache (least recently used bucket is dropped)."""
 
-    def __init__(self, model, config, length, device=torch.device('cuda')):
-        self.model, self.config, self.length, self.device = model, config, int(length), device
-        hop = config.HOP_SAMPLES
-        self.padding_len = int(np.ceil(self.length / hop)) * hop - self.length
-        self.static_in = torch.zeros(1, self.length, device=device, dtype=torch.float32)
-        self.static_out = None
+    def __init__(self, model, config, length=None, device=torch.device('cuda'), max_graphs=8):
+        self.model, self.config, self.device, self.max_graphs = model, config, device, max_graphs
+        self.buckets = OrderedDict()          # frames -> dict(graph, static_in, c, out)
+        if length is not None:
+            self._bucket(int(np.ceil(int(length) / config.HOP_SAMPLES)))
+
+    def _pipeline(self, b):
+        cfg = self.config
+        planes, _ = FE.stft_planes(b['static_in'], cfg.N_FFT, cfg.HOP_SAMPLES, 'pow', scale=b['c'])
+        est = self.model.forward_planes(planes)
+        return FE.istft_planes(est, cfg.N_FFT, cfg.HOP_SAMPLES, 'pow') / b['c'][:, None]
+
+    def _bucket(self, frames):
+        b = self.buckets.get(frames)
+        if b is not None:
+            self.buckets.move_to_end(frames)
+            return b
+        hop = self.config.HOP_SAMPLES
+        b = {'static_in': torch.zeros(1, frames * hop, device=self.device, dtype=torch.float32),
+             'c': torch.ones(1, device=self.device, dtype=torch.float32)}
+        b['static_in'].normal_(0.0, 0.1)             # warm-up on non-degenerate data
         with torch.no_grad():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._device_pipeline()
+                    self._pipeline(b)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.static_out = self._device_pipeline()
+            b['graph'] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(b['graph']):
+                b['out'] = self._pipeline(b)
         torch.cuda.synchronize()
-
-    def _device_pipeline(self):
-        cfg = self.config
-        noisy = self.static_in
-        c = O.clip_scale(noisy)
-        noisy = torch.cat([noisy, noisy[:, :self.padding_len]], dim=-1)
-        planes, _ = FE.stft_planes(noisy, cfg.N_FFT, cfg.HOP_SAMPLES, 'pow', scale=c)
-        est = self.model.forward_planes(planes)
-        return FE.istft_planes(est, cfg.N_FFT, cfg.HOP_SAMPLES, 'pow') / c[:, None]
+        self.buckets[frames] = b
+        while len(self.buckets) > self.max_graphs:
+            self.buckets.popitem(last=False)
+        return b
 
     @torch.no_grad()
     def __call__(self, noisy_signal):
-        x = torch.as_tensor(np.asarray(noisy_signal), dtype=torch.float32).reshape(1, -1)
-        if x.shape[1] != self.length:
-            raise ValueError(f'GraphedEnhancer was captured for {self.length} samples, got {x.shape[1]}')
-        self.static_in.copy_(x, non_blocking=True)
-        self.graph.replay()
-        return torch.flatten(self.static_out)[:self.length].cpu().numpy()
+        x = np.asarray(noisy_signal, dtype=np.float32).reshape(-1)
+        length, hop = x.shape[0], self.config.HOP_SAMPLES
+        frames = int(np.ceil(length / hop))
+        b = self._bucket(frames)
+        pad = frames * hop - length
+        xp = np.concatenate([x, x[:pad]]) if pad else x        # the reference's wrap-pad (head of the signal)
+        b['static_in'].copy_(torch.from_numpy(xp).reshape(1, -1), non_blocking=True)
+        # c = sqrt(L / sum x^2) over the UNPADDED signal: one eager launch writing the scalar the graph reads
+        b['c'].copy_(O.clip_scale(b['static_in'][:, :length].contiguous() if pad else b['static_in']))
+        b['graph'].replay()
+        return torch.flatten(b['out'])[:length].cpu().numpy()

@@ -281,12 +281,21 @@ def clip_grad_norm(optimizer, params, max_norm):
     return torch.nn.utils.clip_grad_norm_(params, max_norm)
 
 
+class _StaleState:
+    """what the one-step-stale discriminator update of step t needs from step t - 1"""
+    __slots__ = ('clean_pl', 'noisy_pl', 'est_d', 'pending', 'ones', 'keys')
+
+
 def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch, loss_weights, n_fft=400, hop=100,
-             comp_type='pow', max_norm=0.0, gan_on=True, labels=None, hooks=None, keys=None):
+             comp_type='pow', max_norm=0.0, gan_on=True, labels=None, hooks=None, keys=None, stale_labels=False):
     """One iteration of the train_gan loop body (core/function.py:216-315).  `labels`: dict with 'est'
     (and 'clean', 'noisy' for scp/sc) giving the PESQ targets directly; if None the PESQ provider is called on the
     audio like the reference does (asynchronously, see PesqSideChannel); `keys`: optional per-clip crop keys for the
-    crop-constant label cache (LabelCache).  Returns a dict of python-float-convertible loss tensors (no host sync)."""
+    crop-constant label cache (LabelCache).  `stale_labels=True` (opt-in, NOT the reference's
+    schedule): the discriminator update of this call uses the batch, the enhanced spectrum and the PESQ labels of the
+    PREVIOUS call (kept on `discriminator._stale`), so the label latency is hidden behind a whole step instead of the
+    generator backward; the first call then makes no discriminator update.
+    Returns a dict of python-float-convertible loss tensors (no host sync)."""
     B, Ls = clean.shape
     out = {}
     optimizer.zero_grad()
@@ -340,6 +349,19 @@ def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arch
         out['loss_d'] = torch.zeros((), device=clean.device)
         return out
     est_d = est.detach()
+    if stale_labels and labels is None:
+        cur = _StaleState()
+        cur.clean_pl, cur.noisy_pl, cur.est_d, cur.pending, cur.ones = clean_pl, noisy_pl, est_d, dict(pending), ones
+        cur.keys = keys
+        prev = getattr(discriminator, '_stale', None)
+        discriminator._stale = cur
+        if prev is None or prev.ones.shape != ones.shape:
+            if hooks is not None:
+                finish_generator_step()
+            out['loss_d'] = torch.zeros((), device=clean.device)
+            return out
+        clean_pl, noisy_pl, est_d, pending, ones = prev.clean_pl, prev.noisy_pl, prev.est_d, prev.pending, prev.ones
+        keys = prev.keys
     d_gx = discriminator.forward_planes(clean_pl, est_d)
     d_yy = discriminator.forward_planes(clean_pl, clean_pl)
     d_xy = discriminator.forward_planes(clean_pl, noisy_pl) if arch in ('scp', 'sc') else None
