@@ -70,6 +70,7 @@ const char* se_last_error(void);
 /* Workspace sizes (bytes) of the entry points that take a caller-owned workspace; pure host functions, no GPU call.
  *   se_attn_bwd               : ws     = row constants [ntok][4] + split / transposed copies of E + per-wave dE tiles
  *   se_norm_prelu_bwd         : red    = double [per_batch ? B : 1][C][3]
+ *   se_dwconv31_wgrad         : ws     = float  [512 workgroups][32][128]
  *   se_lars_step / lamb_step  : norms  = double [nseg][2]
  */
 size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n);
@@ -174,8 +175,11 @@ int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* d
  * [128][2] when stats != NULL); flip=1 with bias=NULL is the input gradient. */
 int se_dwconv31(const float* X, const float* W, const float* bias, float* Y, double* stats, int flip,
                 int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, void* stream);
+/* weight / bias gradient (accumulated into dW [128][31], dbias [128]); ws = workspace of
+ * se_dwconv31_wgrad_workspace_bytes() bytes (per-workgroup partial sums, reduced in a fixed order: deterministic) */
+size_t se_dwconv31_wgrad_workspace_bytes(void);
 int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, float* dbias, int nseq, int n, int inner,
-                      long outer_stride, long inner_stride, long pos_stride, void* stream);
+                      long outer_stride, long inner_stride, long pos_stride, float* ws, void* stream);
 
 /* ---- front-end glue, output assembly, losses, optimizers (csrc/se_elem.hip) --------------------- */
 /* normalize_batch (core/function.py:647-659): c[b] = sqrt(L / sum x^2) */

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(512) void dwconv_kernel(DwArgs a) {
 struct DwWgradArgs {
   SeqGeom g;
   const float* X; const float* dY; float* dW; float* dbias;
+  float* part;      // workspace [workgroups][32 taps (31 + bias)][128 channels]: per-workgroup partial sums
 };
 
 // weight gradient, same thread layout (512 threads, 2 channels per lane, 8 slots x 8 positions): 31 float2
@@ -187,8 +188,11 @@ __global__ __launch_bounds__(512, 2) void dwconv_wgrad_kernel(DwWgradArgs a) {
       }
     }
   }
-  // reduce the 8 position slots through LDS, 8 taps at a time, then one atomic per (channel, tap) per workgroup
+  // reduce the 8 position slots through LDS, 8 taps at a time; the workgroup's 32 x 128 partial sums go to its own row of
+  // the workspace with plain stores (512 workgroups hammering the same 4 096 addresses with atomics ran at the contended
+  // atomic rate: ~90 us of a 300 us launch) and a second tiny kernel adds the rows up in a fixed order
   float* red = xs;     // [8 slots][8 taps][128]
+  float* prow = a.part + (long)blockIdx.x * 32 * DW_C;
 #pragma unroll
   for (int k0 = 0; k0 < 32; k0 += 8) {
     __syncthreads();
@@ -204,11 +208,21 @@ __global__ __launch_bounds__(512, 2) void dwconv_wgrad_kernel(DwWgradArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl) t += red[(sl * 8 + kk) * DW_C + ch];
-      int k = k0 + kk;
-      if (k < DW_K) atomicAdd(&a.dW[ch * DW_K + k], t);
-      else if (a.dbias) atomicAdd(&a.dbias[ch], t);
+      prow[(k0 + kk) * DW_C + ch] = t;
     }
   }
+}
+
+// dW[ch][k] += sum over workgroups of part[wg][k][ch] (k == 31: dbias); one thread per (k, ch), fixed summation order
+__global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, int nwg, float* __restrict__ dW,
+                                           float* __restrict__ dbias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;       // k * 128 + ch
+  if (i >= 32 * DW_C) return;
+  float t = 0.f;
+  for (int w = 0; w < nwg; ++w) t += part[(long)w * 32 * DW_C + i];
+  const int k = i >> 7, ch = i & 127;
+  if (k < DW_K) dW[ch * DW_K + k] += t;
+  else if (dbias) dbias[ch] += t;
 }
 
 extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, float* Y, double* stats, int flip,
@@ -222,12 +236,17 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
   return se_check_launch("se_dwconv31");
 }
 
+extern "C" size_t se_dwconv31_wgrad_workspace_bytes(void) { return (size_t)512 * 32 * DW_C * sizeof(float); }
+
 extern "C" int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, float* dbias, int nseq, int n,
-                                 int inner, long outer_stride, long inner_stride, long pos_stride, void* stream) {
-  SE_REQUIRE(X && dY && dW && nseq > 0 && n > 0 && inner > 0, "dwconv31_wgrad: bad arguments");
-  DwWgradArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, dY, dW, dbias};
+                                 int inner, long outer_stride, long inner_stride, long pos_stride, float* ws,
+                                 void* stream) {
+  SE_REQUIRE(X && dY && dW && ws && nseq > 0 && n > 0 && inner > 0, "dwconv31_wgrad: bad arguments");
+  DwWgradArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, dY, dW, dbias, ws};
   long nitems = (long)nseq * cdiv(n, DW_TILE);
   int nblk = nitems < 512 ? (int)nitems : 512;
   hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(32 * DW_C / 256), dim3(256), 0, as_stream(stream), (const float*)ws, nblk,
+                     dW, dbias);
   return se_check_launch("se_dwconv31_wgrad");
 }

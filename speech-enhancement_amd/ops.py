@@ -105,8 +105,9 @@ def dwconv31(x, w, bias, geom, stats=None, flip=False):
 
 def dwconv31_wgrad(x, dy, dw, dbias, geom):
     nseq, n, inner, os_, is_, ps = geom
+    ws = _new(L.lib().se_dwconv31_wgrad_workspace_bytes() // 4, like=x)
     L.call('se_dwconv31_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(dbias), _i(nseq), _i(n), _i(inner), _l(os_),
-           _l(is_), _l(ps), L.stream())
+           _l(is_), _l(ps), L.ptr(ws), L.stream())
 
 
 # ---------------------------------------------------------------- front-end glue
