@@ -820,11 +820,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 // mid / hi / lo bf16 planes of 4 fp32 values, packed two per dword (element j in half j & 1 of a plane's word j >> 1), kept
-// as ONE register run {m0 m1 h0 h1 l0 l1 - -}: the two 4-dword windows [m|h] (words 0..3) and [h|l] (words 2..5) are the
+// as ONE 192-bit register run {m0 m1 h0 h1 l0 l1}: the two 4-dword windows [m|h] (words 0..3) and [h|l] (words 2..5) are the
 // K = 32 operands of the three MFMAs below for an A operand AND for a B operand, so no operand is ever re-assembled with moves
-struct S3 { u32x8 v; };
+struct S3 { u32x6 v; };
 static __device__ __forceinline__ bf16x8 win_mh(const S3& s) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(s.v, s.v, 0, 1, 2, 3)); }
 static __device__ __forceinline__ bf16x8 win_hl(const S3& s) { return __builtin_bit_cast(bf16x8, __builtin_shufflevector(s.v, s.v, 2, 3, 4, 5)); }
 static __device__ __forceinline__ void set_m(S3& s, u32x2 p) { s.v[0] = p[0]; s.v[1] = p[1]; }
@@ -843,7 +843,6 @@ static __device__ __forceinline__ float bf_hi(unsigned w) { return __builtin_bit
 // exact 3-way split x = hi + mid + lo (8 + 8 + 8 mantissa bits): 18 VALU instructions for 4 values
 static __device__ __forceinline__ S3 split3(float x0, float x1, float x2, float x3) {
   S3 s;
-  s.v[6] = 0; s.v[7] = 0;
   s.v[2] = pk_bf16(x0, x1); s.v[3] = pk_bf16(x2, x3);
   x0 -= bf_lo(s.v[2]); x1 -= bf_hi(s.v[2]); x2 -= bf_lo(s.v[3]); x3 -= bf_hi(s.v[3]);
   s.v[0] = pk_bf16(x0, x1); s.v[1] = pk_bf16(x2, x3);
@@ -1028,18 +1027,29 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
     const S3 docol = split3(cur.docf[0], cur.docf[1], cur.docf[2], cur.docf[3]);
 
     // ---- offset strip: U[q][delta] for the NU tiles Dtile = qt - kt0 - u, strip columns 16 (NK - u) + (delta & 15) ----
+    // the E row fragments are requested in batches of EB tiles before their products: one L2 round trip per batch, not per tile
+    constexpr int EB = 4;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int row = 16 * (qt - kt0 - u) + c + a.maxpos;          // in range by the launch conditions
-      S3 es;
-      es.v[6] = 0; es.v[7] = 0;
-      if (a.dbg & 8) es = qrow; else {
-        const unsigned eo = (unsigned)(row * 16 + 4 * g);
-        set_h(es, ld8(Es0 + eo)); set_m(es, ld8(Es1 + eo)); set_l(es, ld8(Es2 + eo));
+    for (int u0 = 0; u0 < NU; u0 += EB) {
+      S3 es[EB];
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const int u = u0 + e;
+        if (u < NU) {
+          const int row = 16 * (qt - kt0 - u) + c + a.maxpos;      // in range by the launch conditions
+          const unsigned eo = (unsigned)(row * 16 + 4 * g);
+          set_h(es[e], ld8(Es0 + eo)); set_m(es[e], ld8(Es1 + eo)); set_l(es[e], ld8(Es2 + eo));
+        }
       }
-      const f32x4 uu = prod3(qrow, es, (f32x4){0.f, 0.f, 0.f, 0.f});   // C[q = 4g + r][delta_local = c]
 #pragma unroll
-      for (int r = 0; r < 4; ++r) strip[(4 * g + r) * SW + 16 * (NK - u) + c] = uu[r];
+      for (int e = 0; e < EB; ++e) {
+        const int u = u0 + e;
+        if (u < NU) {
+          const f32x4 uu = prod3(qrow, es[e], (f32x4){0.f, 0.f, 0.f, 0.f});   // C[q = 4g + r][delta_local = c]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) strip[(4 * g + r) * SW + 16 * (NK - u) + c] = uu[r];
+        }
+      }
     }
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                 // dQ^T[d = 4g + r][q = c]
     auto load_v = [&](int s_) {
@@ -1055,7 +1065,6 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
         const int j0 = (kt0 + s) * 16;
         const bool kv = j0 + c < n;
         S3 krow;
-        krow.v[6] = 0; krow.v[7] = 0;
         set_h(krow, ld8(Kimg + ((0 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
         set_m(krow, ld8(Kimg + ((1 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
         set_l(krow, ld8(Kimg + ((2 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
@@ -1086,7 +1095,6 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
         st8(Dimg + (1 * 16 + c) * 32 + g * 8, get_m(dss));
         st8(Dimg + (2 * 16 + c) * 32 + g * 8, get_l(dss));
         S3 kcol, dst;
-        kcol.v[6] = 0; kcol.v[7] = 0; dst.v[6] = 0; dst.v[7] = 0;
         set_h(kcol, tr8(Kimg + ((0 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
         set_m(kcol, tr8(Kimg + ((1 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
         set_l(kcol, tr8(Kimg + ((2 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
@@ -1100,32 +1108,43 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
     // ---- consume the strip: dQ^T += E^T W^T, dE^T += Q^T W, one offset tile at a time ----
     const int lim = 16 * nk_w;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      // a cell (q_local a, delta_local dl) of tile u belongs to key_rel = 16 u + a - dl (relative to the wave's first key);
-      // cells whose key the wave does not own still hold U values: mask them
-      float4 w4 = *reinterpret_cast<const float4*>(&strip[c * SW + 16 * (NK - u) + 4 * g]);     // W[a = c][dl = 4g + j]
-      if (!EXACT || u == 0 || u == NU - 1) {
-        const int kr = 16 * u + c - 4 * g;
-        if ((unsigned)kr >= (unsigned)lim) w4.x = 0.f;
-        if ((unsigned)(kr - 1) >= (unsigned)lim) w4.y = 0.f;
-        if ((unsigned)(kr - 2) >= (unsigned)lim) w4.z = 0.f;
-        if ((unsigned)(kr - 3) >= (unsigned)lim) w4.w = 0.f;
+    for (int u0 = 0; u0 < NU; u0 += EB) {
+      S3 ecs[EB];                                                    // E[Dt + 4g + j][d = c], a batch of tiles requested up front
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const int u = u0 + e;
+        if (u < NU) {
+          const unsigned eo = (unsigned)(((qt - kt0 - u) * 16 + a.maxpos + c) * 16 + 4 * g);   // tile (qt-kt0-u) + maxpos/16, row d = c
+          set_h(ecs[e], ld8(Et0 + eo)); set_m(ecs[e], ld8(Et1 + eo)); set_l(ecs[e], ld8(Et2 + eo));
+        }
       }
-      const S3 ws = split3(w4);
-      st8(Dimg + (0 * 16 + c) * 32 + g * 8, get_h(ws));             // image [a][dl]
-      st8(Dimg + (1 * 16 + c) * 32 + g * 8, get_m(ws));
-      st8(Dimg + (2 * 16 + c) * 32 + g * 8, get_l(ws));
-      S3 ec, wt;                                                     // E[Dt + 4g + j][d = c]
-      ec.v[6] = 0; ec.v[7] = 0; wt.v[6] = 0; wt.v[7] = 0;
-      if (a.dbg & 8) ec = qcol; else {
-        const unsigned eo = (unsigned)(((qt - kt0 - u) * 16 + a.maxpos + c) * 16 + 4 * g);   // tile (qt-kt0-u) + maxpos/16, row d = c
-        set_h(ec, ld8(Et0 + eo)); set_m(ec, ld8(Et1 + eo)); set_l(ec, ld8(Et2 + eo));
+#pragma unroll
+      for (int e = 0; e < EB; ++e) {
+        const int u = u0 + e;
+        if (u < NU) {
+          // a cell (q_local a, delta_local dl) of tile u belongs to key_rel = 16 u + a - dl (relative to the wave's first
+          // key); cells whose key the wave does not own still hold U values: mask them
+          float4 w4 = *reinterpret_cast<const float4*>(&strip[c * SW + 16 * (NK - u) + 4 * g]);     // W[a = c][dl = 4g + j]
+          if (!EXACT || u == 0 || u == NU - 1) {
+            const int kr = 16 * u + c - 4 * g;
+            if ((unsigned)kr >= (unsigned)lim) w4.x = 0.f;
+            if ((unsigned)(kr - 1) >= (unsigned)lim) w4.y = 0.f;
+            if ((unsigned)(kr - 2) >= (unsigned)lim) w4.z = 0.f;
+            if ((unsigned)(kr - 3) >= (unsigned)lim) w4.w = 0.f;
+          }
+          const S3 ws = split3(w4);
+          st8(Dimg + (0 * 16 + c) * 32 + g * 8, get_h(ws));             // image [a][dl]
+          st8(Dimg + (1 * 16 + c) * 32 + g * 8, get_m(ws));
+          st8(Dimg + (2 * 16 + c) * 32 + g * 8, get_l(ws));
+          S3 wt;
+          set_h(wt, tr8(Dimg + (0 * 16 + 4 * g + trrow) * 32 + trcol * 8));   // W[a = 4g + j][dl = c]
+          set_m(wt, tr8(Dimg + (1 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+          set_l(wt, tr8(Dimg + (2 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+          // dQ^T[d][q] += E^T[d][dl] W^T[dl][q];  dE^T[d][dl] += Q^T[d][q] W[q][dl]
+          prod3x2(ecs[e], ws, dq, qcol, wt, de[u]);
+          if (a.dbg & 16) __builtin_amdgcn_s_sleep(1);               // (branch point: see the note at the V operand)
+        }
       }
-      set_h(wt, tr8(Dimg + (0 * 16 + 4 * g + trrow) * 32 + trcol * 8));   // W[a = 4g + j][dl = c]
-      set_m(wt, tr8(Dimg + (1 * 16 + 4 * g + trrow) * 32 + trcol * 8));
-      set_l(wt, tr8(Dimg + (2 * 16 + 4 * g + trrow) * 32 + trcol * 8));
-      // dQ^T[d][q] += E^T[d][dl] W^T[dl][q];  dE^T[d][dl] += Q^T[d][q] W[q][dl]
-      prod3x2(ec, ws, dq, qcol, wt, de[u]);
     }
 
     // ---- dQ of this query tile ----

@@ -61,9 +61,14 @@ __global__ __launch_bounds__(512) void dwconv_kernel(DwArgs a) {
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  long it = blockIdx.x;
-  if (it < nitems) fetch(it);
-  for (; it < nitems; it += gridDim.x) {
+  // XCD-aware item order: workgroups b and b + 8 share an XCD (round-robin dispatch), so XCD x walks its own contiguous
+  // eighth of the (sequence, tile) items with its gridDim / 8 workgroups side by side -- consecutive tiles of a sequence are
+  // in flight on the same XCD at the same time and their 30 shared halo rows are served by that XCD's L2 instead of HBM
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
+  const long Q = (nitems + 7) >> 3, ibase = (long)xcd * Q, iend = ibase + Q < nitems ? ibase + Q : nitems;
+  long it = ibase + slot;
+  if (it < iend) fetch(it);
+  for (; it < iend; it += S) {
     const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * DW_TILE;
     const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
     float* __restrict__ Yb = a.Y + base * DW_C;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(512) void dwconv_kernel(DwArgs a) {
       if (i < DW_ROWS * 32) *reinterpret_cast<float4*>(&xs[(i >> 5) * DW_C + (i & 31) * 4]) = pre[k];
     }
     __syncthreads();
-    if (it + gridDim.x < nitems) fetch(it + gridDim.x);
+    if (it + S < iend) fetch(it + S);
     float2 acc[8];
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = bv;
@@ -231,7 +236,7 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
   SE_REQUIRE(X && W && Y && nseq > 0 && n > 0 && inner > 0, "dwconv31: bad arguments");
   DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, W, bias, Y, stats, flip};
   long nitems = (long)nseq * cdiv(n, DW_TILE);
-  int nblk = nitems < 768 ? (int)nitems : 768;          // persistent: 3 workgroups (48 KB LDS each) per CU
+  int nblk = nitems < 768 ? (int)((nitems + 7) / 8 * 8) : 768;          // persistent: 3 workgroups (48 KB LDS each) per CU; multiple of 8
   hipLaunchKernelGGL(dwconv_kernel, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31");
 }
