@@ -23,7 +23,7 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True):
     nseq, n, inner, os_, is_, ps = geom
     L.call('se_attn_fwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner),
            C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos), C.c_float(scale), L.stream(),
-           _key=('attn_fwd2_kernel' if (n + 15) // 16 * 16 <= 1200 else 'attn_fwd_kernel'), _flops=nseq * 4 * 3 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 256)
+           _key=('attn_fwd3_bf16x6' if (n + 15) // 16 * 16 <= 1200 else 'attn_fwd_kernel'), _flops=nseq * 4 * 3 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 256)
     return O, lse
 
 

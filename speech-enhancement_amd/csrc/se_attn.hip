@@ -1239,6 +1239,134 @@ __global__ __launch_bounds__(256) void attn_de_reduce3_kernel(const float* __res
   }
 }
 
+// =====================================================================================================================
+// v3 forward: the fwd2 structure (one workgroup per (sequence, head), 32- or 16-query blocks dealt to the waves, online
+// softmax, sliding rel-pos window skewed through wave-private LDS) on the packed split-bf16 products of the v3 backward:
+//   S^T  = K  . Q^T : K row fragments read from global memory one key tile ahead and split on the fly (shared by the TQ query
+//                     tiles of the block); Q^T split once per block
+//   U    = Ew . Q^T : E row fragments likewise (one new offset tile per step serves both query tiles, rotated in registers)
+//   O^T += V^T . P^T: V is staged ONCE per workgroup, pre-split, in LDS and its column fragments (contraction over keys) come
+//                     through ds_read_b64_tr_b16; P^T's accumulator registers are the B operand after one split
+// 48 instead of 128 matrix-pipe cycles per 16x16x16 product; only V lives in LDS (32 KB at n = 321): two 8-wave workgroups per CU.
+// =====================================================================================================================
+template <int TQ>
+__global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
+  unsigned char* Vimg = smem_f3;                               // [3 planes][NP keys][16 d] bf16
+  float* Ubase = reinterpret_cast<float*>(smem_f3 + (size_t)3 * NP * 32);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NT = blockDim.x, NW = NT >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n = a.g.n;
+  const int head = blockIdx.x & 3, seq = blockIdx.x >> 2;
+  const long base = seq_base(a.g, seq);
+  const int ps = (int)a.g.pos_stride;
+  const float* qb = a.QKV + base * 192 + head * 16;
+  for (int i = tid; i < NP * 4; i += NT) {
+    const int j = i >> 2, q = i & 3;
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < n) v4 = *reinterpret_cast<const float4*>(qb + (unsigned)(j * ps * 192 + 128 + 4 * q));
+    const S3 vs = split3(v4);
+    st8(Vimg + ((0 * NP + j) * 16 + 4 * q) * 2, get_h(vs));
+    st8(Vimg + ((1 * NP + j) * 16 + 4 * q) * 2, get_m(vs));
+    st8(Vimg + ((2 * NP + j) * 16 + 4 * q) * 2, get_l(vs));
+  }
+  __syncthreads();
+  float* Ul = Ubase + wave * (TQ * 512);      // [tile t][slot][256]
+  const float l2e = 1.4426950408889634f * a.scale;
+  const int qblocks = (n + 16 * TQ - 1) / (16 * TQ), nkt = (n + 15) / 16;
+  const int trrow = c >> 2, trcol = c & 3;
+  auto e_row = [&](int D) {                   // E[clamp(D + c)][4g..4g+3]: the A operand rows are offsets
+    int d = D + c;
+    d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
+    return *reinterpret_cast<const float4*>(a.E + (unsigned)((d + a.maxpos) * 16 + 4 * g));
+  };
+  auto k_row = [&](int j0) {                  // K[j0 + c][4g..4g+3]
+    int kj = j0 + c; if (kj > n - 1) kj = n - 1;
+    return *reinterpret_cast<const float4*>(qb + (unsigned)(kj * ps * 192 + 64 + 4 * g));
+  };
+  for (int qbk = wave; qbk < qblocks; qbk += NW) {
+    const int i0 = qbk * 16 * TQ;
+    S3 qf[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+      int qi = i0 + 16 * t + c; if (qi > n - 1) qi = n - 1;
+      qf[t] = split3(*reinterpret_cast<const float4*>(qb + (unsigned)(qi * ps * 192 + 4 * g)));
+    }
+    f32x4 o[TQ];
+    float m[TQ], l[TQ];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) { m[t] = -1e30f; l[t] = 0.f; o[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    auto u_tile = [&](const S3& es, int t, int slot) {
+      const f32x4 u = prod3(es, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ul[(t * 2 + slot) * 256 + (4 * g + r) * 16 + c] = u[r];
+    };
+    // offset tiles: query tile t at key tile j0 needs offsets [D, D + 15] (hi) and [D - 16, D - 1] (lo), D = i0 + 16 t - j0.
+    // hi of step kt is lo of step kt - 1, and tile t's lo is tile t - 1's ... tile (t, D - 16) == tile (t - 1, D) shifted:
+    // E fragments depend only on the offset base, so one new fragment per step serves all TQ tiles (rotated in registers)
+    S3 ef[TQ + 1];                             // ef[t + 1] = E rows at base i0 + 16 t - j0 (hi of tile t), ef[0]: lo of tile 0
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) { ef[t + 1] = split3(e_row(i0 + 16 * t)); u_tile(ef[t + 1], t, 0); }
+    float4 enext = e_row(i0 - 16), knext = k_row(0);
+    int hi = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+      const int j0 = kt * 16, lo = hi ^ 1;
+      ef[0] = split3(enext);
+      const S3 kf = split3(knext);
+      if (kt + 1 < nkt) { enext = e_row(i0 - j0 - 32); knext = k_row(j0 + 16); }      // one step ahead
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) u_tile(ef[t], t, lo);          // lo tile of query tile t: offsets base i0 + 16 (t - 1) - j0
+      S3 vcol;                                                     // V[j0 + 4g + j][d = c]: transposed read of the row image
+      set_h(vcol, tr8(Vimg + ((0 * NP + j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
+      set_m(vcol, tr8(Vimg + ((1 * NP + j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
+      set_l(vcol, tr8(Vimg + ((2 * NP + j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
+#pragma unroll
+      for (int t = 0; t < TQ; ++t) {
+        const f32x4 s4 = prod3(kf, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});      // S^T[key 4g + r][query c]
+        float sc[4], tmax = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int dl = c - (4 * g + r);
+          const float u = dl >= 0 ? Ul[(t * 2 + hi) * 256 + dl * 16 + c] : Ul[(t * 2 + lo) * 256 + (16 + dl) * 16 + c];
+          sc[r] = (j0 + 4 * g + r < n) ? (s4[r] + u) * l2e : -1e30f;
+          tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m[t], tmax);
+        const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
+        m[t] = mn;
+        f32x4 p;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mn); psum += p[r]; }
+        l[t] = l[t] * corr + psum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][r] *= corr;
+        o[t] = prod3(vcol, split3(p), o[t]);                        // O^T[d 4g + r][query c] += V^T[d][key] P^T[key][query]
+      }
+      // slide the offset window: next step's hi fragments are this step's lo fragments
+#pragma unroll
+      for (int t = TQ; t > 0; --t) ef[t] = ef[t - 1];
+      hi = lo;
+    }
+#pragma unroll
+    for (int t = 0; t < TQ; ++t) {
+      float lt = l[t];
+      lt += __shfl_xor(lt, 16, 64);
+      lt += __shfl_xor(lt, 32, 64);
+      const int qi = i0 + 16 * t + c;
+      if (qi < n) {
+        const long tok = base + (long)qi * ps;
+        const float inv = 1.0f / lt;
+        *reinterpret_cast<float4*>(a.O + tok * 64 + head * 16 + 4 * g) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+        if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt)) * 0.6931471805599453f;
+      }
+    }
+  }
+}
+
 static int check_geom(const AttnGeom& g) {
   SE_REQUIRE(g.nseq > 0 && g.n > 0 && g.inner > 0, "attention: bad geometry");
   return 0;
@@ -1260,6 +1388,28 @@ extern "C" int se_attn_fwd(const float* QKV, const float* E, float* O, float* LS
   int nw = qb32 <= 4 ? 4 : 8, tq = qb32 <= 4 ? 1 : 2;
   if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v == 4 || v == 6 || v == 8) nw = v; }
   if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq = v; }
+  int use3 = pos_stride * 192 * (long)NP < 2147483647L;
+  if (const char* e = getenv("SE_ATTN_FWD")) { if (atoi(e) == 2) use3 = 0; }
+  if (use3) {
+    // split-bf16 kernel; measured at B = 16 (ms): n = 321: 8 waves x 2 tiles 0.92, 7 x 2 0.95, 8 x 1 0.94, 4 x 2 0.97, 6 x 2 1.10
+    // (fwd2: 1.07); n = 101: 4 x 1 0.342, 8 x 2 0.352, 4 x 2 0.367 (fwd2: 0.355)
+    int nw3 = qb32 <= 4 ? 4 : 8, tq3 = qb32 <= 4 ? 1 : 2;
+    if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v >= 1 && v <= 8) nw3 = v; }
+    if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq3 = v; }
+    const size_t sh3 = (size_t)3 * NP * 32 + (size_t)512 * tq3 * nw3 * sizeof(float);
+    if (sh3 <= 160 * 1024) {
+      static size_t raised3[3] = {0, 0, 0};
+      if (sh3 > 64 * 1024 && sh3 > raised3[tq3]) {
+        const void* fn = tq3 == 1 ? (const void*)attn_fwd3_kernel<1> : (const void*)attn_fwd3_kernel<2>;
+        SE_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3) == hipSuccess,
+                   "attn_fwd: cannot raise the dynamic LDS limit to %zu", sh3);
+        raised3[tq3] = sh3;
+      }
+      if (tq3 == 1) hipLaunchKernelGGL(attn_fwd3_kernel<1>, dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
+      else hipLaunchKernelGGL(attn_fwd3_kernel<2>, dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
+      return se_check_launch("se_attn_fwd");
+    }
+  }
   const size_t sh = ((size_t)NP * 16 + 16 * (size_t)(NP + 4) + 512 * (size_t)tq * nw) * sizeof(float);
   if (sh <= 160 * 1024) {       // K / V of one (sequence, head) fit in LDS: staged kernel
     static size_t raised[3] = {0, 0, 0};
