@@ -194,6 +194,17 @@ int se_compress_planes_bwd(const float* R, int ldr, const float* dP, float* dR, 
 int se_uncompress_rows(const float* P, float* A, int lda, long rows, int F, int comp, float post_scale, void* stream);
 int se_uncompress_rows_bwd(const float* P, const float* dA, int lda, float* dP, long rows, int F, int comp,
                            float post_scale, void* stream);
+/* Fused front-end for n_fft = 400, hop = 100 (csrc/se_front.hip), one launch each:
+ *   se_stft_fused : x [B, L] (* c[b] if c != NULL) -> planes [B, L/100 + 1, 201, 4] = compressed (|z|, Re, Im, 0); replaces
+ *                   torch.stft (center / reflect, periodic Hamming) + power_compress (core/function.py:685-693, 625-634).
+ *                   Wf = [400][416]: column 2f = w[k] cos(2 pi f k / 400), 2f + 1 = -w[k] sin(.)
+ *   se_istft_fused: planes -> y [B, 100 (T - 1)]; replaces power_uncompress + torch.istft (core/function.py:695-703, 636-645).
+ *                   Wi = [404][416]: row 2f = c_f w[n] cos(2 pi f n / 400) / 400, row 2f + 1 = -c_f w[n] sin(.) / 400;
+ *                   env = window envelope [100 (T - 1) + 400] */
+int se_stft_fused(const float* x, const float* c, const float* Wf, float* P, int B, int L, int n_fft, int hop, int comp,
+                  float pre_scale, void* stream);
+int se_istft_fused(const float* P, const float* Wi, const float* env, float* y, int B, int T, int n_fft, int hop, int comp,
+                   float post_scale, void* stream);
 /* overlap-add / envelope division / trim of torch.istft (core/function.py:701-702) and its transpose */
 int se_ola(const float* Fr, const float* env, float* y, int B, int T, int n_fft, int hop, int trim, int L, void* stream);
 int se_ola_bwd(const float* dy, const float* env, float* dFr, int B, int T, int n_fft, int hop, void* stream);

@@ -5,6 +5,7 @@ the A operand with a row stride of one hop (frames overlap in memory, nothing is
 matrix is the weight.  iSTFT = un-compress -> GEMM with the windowed inverse-DFT matrix -> overlap-add.
 Internal layout: "planes" [B, T, F, 4] = (|z|, Re z, Im z, 0), channels-last like every other feature map.
 """
+import ctypes as _C
 import math
 
 import torch
@@ -14,6 +15,7 @@ from . import gemm as GM
 from . import ops as O
 
 _CACHE = {}
+_ci, _cf = _C.c_int, _C.c_float
 
 
 def hamming(n_fft, device):
@@ -62,23 +64,51 @@ def envelope(n_fft, hop, T, device):
     return _CACHE[key]
 
 
-def stft_planes(x, n_fft=400, hop=100, comp='pow', scale=None):
+def fused_matrices(device):
+    """interleaved DFT matrices of the fused kernels (csrc/se_front.hip): Wf [400][416] (column 2f = Re, 2f + 1 = Im of bin f),
+    Wi [404][416] (row 2f / 2f + 1 = Re / Im coefficient of bin f)"""
+    key = ('fused', str(device))
+    if key not in _CACHE:
+        Wf, Wi, _ = dft_matrices(400, 100, device)           # Wf [402][400] rows re|im ; Wi [400][404] cols re|im
+        Fq = 201
+        Wfi = torch.zeros(400, 416, device=device, dtype=torch.float32)
+        Wfi[:, 0:2 * Fq:2] = Wf[:Fq].t()
+        Wfi[:, 1:2 * Fq:2] = Wf[Fq:2 * Fq].t()
+        Wii = torch.zeros(404, 416, device=device, dtype=torch.float32)
+        Wii[0:2 * Fq:2, :400] = Wi[:, :Fq].t()
+        Wii[1:2 * Fq:2, :400] = Wi[:, Fq:2 * Fq].t()
+        _CACHE[key] = (Wfi.contiguous(), Wii.contiguous())
+    return _CACHE[key]
+
+
+def stft_planes(x, n_fft=400, hop=100, comp='pow', scale=None, padded=True):
     """x [B, L] (L a multiple of hop) -> planes [B, T, F, 4].  scale: optional per-clip factor c[b] applied
-    while padding (fuses normalize_batch, core/function.py:647-659)."""
+    while padding (fuses normalize_batch, core/function.py:647-659).  Returns (planes, xp): xp = the scaled reflect-padded
+    signal [B, L + n_fft] (its middle is the normalised clip the losses use) or None with padded=False.
+    n_fft = 400 / hop = 100 (the reference's only analysis) runs the ONE-launch fused kernel (normalise + reflect-pad + frame +
+    windowed DFT + compression); other sizes the pad -> tap-GEMM -> compress sequence."""
     L.check_cuda(x)
     B, Ls = x.shape
     if Ls % hop != 0 or n_fft % hop != 0 or hop % 4 != 0:
         raise L.SeHipError(f'stft: need L % hop == 0, n_fft % hop == 0, hop % 4 == 0 (L={Ls}, hop={hop})')
     T = Ls // hop + 1
     Fq = n_fft // 2 + 1
-    xp = O.reflect_pad_scale(x.contiguous(), scale, n_fft // 2)          # [B, L + n_fft]
+    x = x.contiguous()
+    pre = n_fft ** -0.5 if comp == 'norm' else 1.0
+    if n_fft == 400 and hop == 100 and Ls > 200:
+        Wfi, _ = fused_matrices(x.device)
+        P = torch.empty(B, T, Fq, 4, device=x.device, dtype=torch.float32)
+        L.call('se_stft_fused', L.ptr(x), L.ptr(scale), L.ptr(Wfi), L.ptr(P), _ci(B), _ci(Ls), _ci(n_fft), _ci(hop),
+               _ci(O.COMP[comp]), _cf(pre), L.stream(), _key='stft_fused', _flops=2.0 * B * T * 400 * 402,
+               _bytes=4.0 * B * (Ls + T * Fq * 4))
+        return P, (O.reflect_pad_scale(x, scale, n_fft // 2) if padded else None)
+    xp = O.reflect_pad_scale(x, scale, n_fft // 2)          # [B, L + n_fft]
     Wf, _, _ = dft_matrices(n_fft, hop, x.device)
     ldr = _ceil4(2 * Fq)
     R = torch.empty(B * T, ldr, device=x.device, dtype=torch.float32)
     rows_per_b = (Ls + n_fft) // hop                                      # "pixels" of stride hop per clip
     d = GM.make_desc(B, 1, T, 1, rows_per_b, [(0, 0)], n_fft, hop, 2 * Fq, ldr, ldw=n_fft)
     GM.gemm_tap(d, xp, Wf, R)
-    pre = n_fft ** -0.5 if comp == 'norm' else 1.0
     return O.compress_planes(R, ldr, B * T, Fq, comp, pre).view(B, T, Fq, 4), xp
 
 
@@ -131,11 +161,19 @@ class _ISTFTFn(torch.autograd.Function):
         _, Wi, _ = dft_matrices(n_fft, hop, planes.device)
         lda = Wi.shape[1]
         post = n_fft ** 0.5 if comp == 'norm' else 1.0
-        Au = O.uncompress_rows(planes, B * T, Fq, lda, comp, post)
-        frames = torch.empty(B * T, n_fft, device=planes.device, dtype=torch.float32)
-        GM.gemm_tap(GM.linear_desc(B * T, lda, n_fft), Au, Wi, frames)
         env = envelope(n_fft, hop, T, planes.device)
-        y = O.ola(frames, env, B, T, n_fft, hop)
+        planes = planes.contiguous()
+        if n_fft == 400 and hop == 100 and T > 1:       # one launch: un-compress + inverse DFT + overlap-add + envelope + trim
+            _, Wii = fused_matrices(planes.device)
+            y = torch.empty(B, hop * (T - 1), device=planes.device, dtype=torch.float32)
+            L.call('se_istft_fused', L.ptr(planes), L.ptr(Wii), L.ptr(env), L.ptr(y), _ci(B), _ci(T), _ci(n_fft), _ci(hop),
+                   _ci(O.COMP[comp]), _cf(post), L.stream(), _key='istft_fused', _flops=2.0 * B * T * 402 * 400,
+                   _bytes=4.0 * B * (T * Fq * 4 + hop * (T - 1)))
+        else:
+            Au = O.uncompress_rows(planes, B * T, Fq, lda, comp, post)
+            frames = torch.empty(B * T, n_fft, device=planes.device, dtype=torch.float32)
+            GM.gemm_tap(GM.linear_desc(B * T, lda, n_fft), Au, Wi, frames)
+            y = O.ola(frames, env, B, T, n_fft, hop)
         ctx.save_for_backward(planes)
         ctx.cfg = (n_fft, hop, comp, lda, post)
         return y

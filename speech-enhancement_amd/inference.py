@@ -35,7 +35,7 @@ def predict(model, config, noisy_signal, device=torch.device('cuda')):
     frame_num = int(np.ceil(length / hop))
     padding_len = frame_num * hop - length
     noisy = torch.cat([noisy, noisy[:, :padding_len]], dim=-1)
-    planes, _ = FE.stft_planes(noisy, n_fft, hop, 'pow', scale=c)
+    planes, _ = FE.stft_planes(noisy, n_fft, hop, 'pow', scale=c, padded=False)
     est = model.forward_planes(planes)
     est_audio = FE.istft_planes(est, n_fft, hop, 'pow') / c[:, None]
     est_audio = torch.flatten(est_audio)[:length].cpu().numpy()
@@ -62,7 +62,7 @@ class GraphedEnhancer:
 
     def _pipeline(self, b):
         cfg = self.config
-        planes, _ = FE.stft_planes(b['static_in'], cfg.N_FFT, cfg.HOP_SAMPLES, 'pow', scale=b['c'])
+        planes, _ = FE.stft_planes(b['static_in'], cfg.N_FFT, cfg.HOP_SAMPLES, 'pow', scale=b['c'], padded=False)
         est = self.model.forward_planes(planes)
         return FE.istft_planes(est, cfg.N_FFT, cfg.HOP_SAMPLES, 'pow') / b['c'][:, None]
 
