@@ -71,6 +71,7 @@ const char* se_last_error(void);
  *   se_attn_bwd               : ws     = row constants [ntok][4] + split / transposed copies of E + per-wave dE tiles
  *   se_norm_prelu_bwd         : red    = double [per_batch ? B : 1][C][3]
  *   se_dwconv31_wgrad         : ws     = float  [512 workgroups][32][128]
+ *   se_disc_tail_fwd / _bwd   : ws     = float  [B][324]
  *   se_lars_step / lamb_step  : norms  = double [nseg][2]
  */
 size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n);
@@ -245,6 +246,23 @@ int se_lamb_step(float* p, const float* g, float* m, float* v, const long* seg_o
                  float wd, float b1, float b2, float beta3, float eps, float bc1, float bc2, void* stream);
 int se_axpbypcz(const float* a, const float* b, const float* c, float* y, float alpha, float beta, float gamma,
                 long n, void* stream);
+
+/* ---- metric-discriminator tail + spectral normalisation (models/discriminator.py:39-57; csrc/se_elem.hip) ---- */
+/* torch.nn.utils.spectral_norm on a [h, w] weight matrix: one power iteration (train != 0: u [h], v [w] updated in place),
+ * sigma = u . (W v) written to sigma[0], Wn = W / sigma.  Backward: dW += (dWn - <dWn, Wn> u v^T) / sigma. */
+int se_spectral_norm(const float* W, float* u, float* v, float* Wn, float* sigma, int h, int w, int train, float eps,
+                     void* stream);
+int se_spectral_norm_bwd(const float* dWn, const float* Wn, const float* u, const float* v, const float* sigma, float* dW,
+                         int h, int w, void* stream);
+/* AdaptiveMaxPool2d(1) over the P positions of A [B, P, 128] -> Linear(128, 64) -> dropout mask [B, 64] (NULL: none; entries
+ * 0 or 1 / (1 - p)) -> PReLU(64) -> Linear(64, 1) -> beta * sigmoid(slope * z): out [B].  ws = workspace of
+ * se_disc_tail_workspace_bytes(B) bytes, kept for the backward (dA must be zero-initialised; parameter gradients accumulate). */
+size_t se_disc_tail_workspace_bytes(int B);
+int se_disc_tail_fwd(const float* A, int B, int P, const float* W1, const float* b1, const float* mask, const float* slope1,
+                     const float* W2, const float* b2, const float* sslope, float beta, float* out, float* ws, void* stream);
+int se_disc_tail_bwd(const float* dout, const float* ws, int B, int P, const float* W1, const float* mask, const float* slope1,
+                     const float* W2, const float* sslope, float beta, float* dA, float* dW1, float* db1, float* dslope1,
+                     float* dW2, float* db2, float* dsslope, void* stream);
 
 #ifdef __cplusplus
 }

@@ -612,3 +612,184 @@ extern "C" int se_lamb_step(float* p, const float* g, float* m, float* v, const 
                      (const double*)norms, 1, adapt, lr, wd, 0.f, 0.f, eps, bc1, rbc2, trust_clip);
   return se_check_launch("se_lamb_step");
 }
+
+// =============================================================================================
+// Metric-discriminator tail and spectral normalisation as kernels (models/discriminator.py:39-57): the D step then has no
+// vendor-BLAS launch.  All operands are weight- or [B, 128]-sized: one workgroup each, latency-sized work.
+//
+// spectral_norm (torch.nn.utils.spectral_norm, one power iteration in training mode, eps 1e-12):
+//   v = normalize(W^T u), u = normalize(W v)   (train only; u, v updated in place)
+//   sigma = u . (W v);  Wn = W / sigma
+__global__ __launch_bounds__(256) void spectral_norm_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v,
+                                                            float* __restrict__ Wn, float* __restrict__ sigma_out, int h, int w,
+                                                            int train, float eps) {
+  extern __shared__ float sn[];           // v [w] | s = W v [h] | red [8]
+  float* vs = sn; float* ss = sn + w; float* red = ss + h;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  auto block_sum = [&](float x) {
+    x = wave_sum(x);
+    __syncthreads();
+    if (lane == 0) red[wv] = x;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  if (train) {
+    float nn = 0.f;
+    for (int j = tid; j < w; j += 256) {
+      float t = 0.f;
+      for (int i = 0; i < h; ++i) t += W[(long)i * w + j] * u[i];
+      vs[j] = t; nn += t * t;
+    }
+    const float nv = fmaxf(sqrtf(block_sum(nn)), eps);
+    for (int j = tid; j < w; j += 256) vs[j] /= nv;
+  } else {
+    for (int j = tid; j < w; j += 256) vs[j] = v[j];
+  }
+  __syncthreads();
+  float n2 = 0.f;
+  for (int i = wv; i < h; i += 4) {                 // one wave per row
+    float t = 0.f;
+    for (int j = lane; j < w; j += 64) t += W[(long)i * w + j] * vs[j];
+    t = wave_sum(t);
+    if (lane == 0) ss[i] = t;
+    if (lane == 0) n2 += t * t;
+  }
+  const float nu2 = block_sum(n2);
+  float sigma;
+  if (train) {
+    const float nu = fmaxf(sqrtf(nu2), eps);
+    sigma = nu2 / nu;                                // u . (W v) with u = s / nu
+    for (int i = tid; i < h; i += 256) u[i] = ss[i] / nu;
+    for (int j = tid; j < w; j += 256) v[j] = vs[j];
+  } else {
+    float d = 0.f;
+    for (int i = tid; i < h; i += 256) d += u[i] * ss[i];
+    sigma = block_sum(d);
+  }
+  const float inv = 1.0f / sigma;
+  for (long i = tid; i < (long)h * w; i += 256) Wn[i] = W[i] * inv;
+  if (tid == 0) sigma_out[0] = sigma;
+}
+// dW = (dWn - <dWn, Wn> u v^T) / sigma   (u, v are constants of the graph, as in torch's hook)
+__global__ __launch_bounds__(256) void spectral_norm_bwd_kernel(const float* __restrict__ dWn, const float* __restrict__ Wn,
+                                                                const float* __restrict__ u, const float* __restrict__ v,
+                                                                const float* __restrict__ sigma, float* __restrict__ dW, int h, int w) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  float d = 0.f;
+  for (long i = tid; i < (long)h * w; i += 256) d += dWn[i] * Wn[i];
+  d = wave_sum(d);
+  if ((tid & 63) == 0) red[tid >> 6] = d;
+  __syncthreads();
+  const float dot = red[0] + red[1] + red[2] + red[3], inv = 1.0f / sigma[0];
+  for (long i = tid; i < (long)h * w; i += 256) {
+    const int r = (int)(i / w), cc = (int)(i - (long)r * w);
+    dW[i] += (dWn[i] - dot * u[r] * v[cc]) * inv;
+  }
+}
+
+// tail: global max-pool over the P positions of a [B, P, 128] map -> Linear(128, 64) -> dropout mask -> PReLU(64) ->
+// Linear(64, 1) -> beta * sigmoid(slope * z).  One workgroup per batch element.  ws: float [B][SE_DISC_TAIL_WS] saved for the
+// backward: pooled [128] | argmax [128] (as float bits) | h1 (pre-mask, pre-PReLU) [64] | z [1]
+#define DT_C 128
+#define DT_H 64
+#define SE_DISC_TAIL_WS_ (DT_C + DT_C + DT_H + 4)
+__global__ __launch_bounds__(256) void disc_tail_fwd_kernel(const float* __restrict__ A, int P, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ mask,
+                                                            const float* __restrict__ slope1, const float* __restrict__ W2,
+                                                            const float* __restrict__ b2, const float* __restrict__ sslope, float beta,
+                                                            float* __restrict__ out, float* __restrict__ ws) {
+  __shared__ float pool[DT_C], h2[DT_H];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* w_ = ws + (long)b * SE_DISC_TAIL_WS_;
+  if (tid < DT_C) {
+    const float* a = A + (long)b * P * DT_C + tid;
+    float m = a[0]; int am = 0;
+    for (int p = 1; p < P; ++p) { float x = a[(long)p * DT_C]; if (x > m) { m = x; am = p; } }
+    pool[tid] = m; w_[tid] = m; w_[DT_C + tid] = __int_as_float(am);
+  }
+  __syncthreads();
+  if (tid < DT_H) {
+    float t = b1[tid];
+    for (int cc = 0; cc < DT_C; ++cc) t += W1[tid * DT_C + cc] * pool[cc];
+    w_[2 * DT_C + tid] = t;
+    if (mask) t *= mask[(long)b * DT_H + tid];
+    h2[tid] = t >= 0.f ? t : t * slope1[tid];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float t = W2[tid] * h2[tid];
+    t = wave_sum(t);
+    if (tid == 0) {
+      const float z = t + b2[0];
+      w_[2 * DT_C + DT_H] = z;
+      out[b] = beta / (1.0f + expf(-sslope[0] * z));
+    }
+  }
+}
+__global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ ws, int P,
+                                                            const float* __restrict__ W1, const float* __restrict__ mask,
+                                                            const float* __restrict__ slope1, const float* __restrict__ W2,
+                                                            const float* __restrict__ sslope, float beta, float* __restrict__ dA,
+                                                            float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dslope1,
+                                                            float* __restrict__ dW2, float* __restrict__ db2, float* __restrict__ dsslope) {
+  __shared__ float dh1[DT_H];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* w_ = ws + (long)b * SE_DISC_TAIL_WS_;
+  const float z = w_[2 * DT_C + DT_H], sl = sslope[0];
+  const float sg = 1.0f / (1.0f + expf(-sl * z));
+  const float go = dout[b] * beta * sg * (1.0f - sg);          // d out / d (slope * z)
+  const float dz = go * sl;
+  if (tid == 0) { if (dsslope) atomicAdd(dsslope, go * z); if (db2) atomicAdd(db2, dz); }
+  if (tid < DT_H) {
+    float t = w_[2 * DT_C + tid];
+    const float mk = mask ? mask[(long)b * DT_H + tid] : 1.0f;
+    const float tm = t * mk;
+    const float h2v = tm >= 0.f ? tm : tm * slope1[tid];
+    if (dW2) atomicAdd(&dW2[tid], dz * h2v);
+    const float dh2 = dz * W2[tid];
+    if (tm < 0.f && dslope1) atomicAdd(&dslope1[tid], dh2 * tm);
+    const float d1 = dh2 * (tm >= 0.f ? 1.0f : slope1[tid]) * mk;
+    dh1[tid] = d1;
+    if (db1) atomicAdd(&db1[tid], d1);
+  }
+  __syncthreads();
+  if (dW1) for (int i = tid; i < DT_H * DT_C; i += 256) atomicAdd(&dW1[i], dh1[i / DT_C] * w_[i % DT_C]);
+  if (dA && tid < DT_C) {
+    float t = 0.f;
+    for (int j = 0; j < DT_H; ++j) t += dh1[j] * W1[j * DT_C + tid];
+    const int am = __float_as_int(w_[DT_C + tid]);
+    dA[((long)b * P + am) * DT_C + tid] = t;               // dA is zero-initialised by the caller
+  }
+}
+
+extern "C" int se_spectral_norm(const float* W, float* u, float* v, float* Wn, float* sigma, int h, int w, int train, float eps,
+                                void* stream) {
+  SE_REQUIRE(W && u && v && Wn && sigma && h > 0 && w > 0 && h + w <= 8192, "spectral_norm: bad arguments");
+  hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(256), (size_t)(w + h + 8) * sizeof(float), as_stream(stream), W, u, v, Wn,
+                     sigma, h, w, train, eps);
+  return se_check_launch("se_spectral_norm");
+}
+extern "C" int se_spectral_norm_bwd(const float* dWn, const float* Wn, const float* u, const float* v, const float* sigma,
+                                    float* dW, int h, int w, void* stream) {
+  SE_REQUIRE(dWn && Wn && u && v && sigma && dW && h > 0 && w > 0, "spectral_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), dWn, Wn, u, v, sigma, dW, h, w);
+  return se_check_launch("se_spectral_norm_bwd");
+}
+extern "C" size_t se_disc_tail_workspace_bytes(int B) { return B > 0 ? (size_t)B * SE_DISC_TAIL_WS_ * sizeof(float) : 0; }
+extern "C" int se_disc_tail_fwd(const float* A, int B, int P, const float* W1, const float* b1, const float* mask,
+                                const float* slope1, const float* W2, const float* b2, const float* sslope, float beta, float* out,
+                                float* ws, void* stream) {
+  SE_REQUIRE(A && W1 && b1 && slope1 && W2 && b2 && sslope && out && ws && B > 0 && P > 0, "disc_tail_fwd: bad arguments");
+  hipLaunchKernelGGL(disc_tail_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), A, P, W1, b1, mask, slope1, W2, b2, sslope, beta,
+                     out, ws);
+  return se_check_launch("se_disc_tail_fwd");
+}
+extern "C" int se_disc_tail_bwd(const float* dout, const float* ws, int B, int P, const float* W1, const float* mask,
+                                const float* slope1, const float* W2, const float* sslope, float beta, float* dA, float* dW1,
+                                float* db1, float* dslope1, float* dW2, float* db2, float* dsslope, void* stream) {
+  SE_REQUIRE(dout && ws && W1 && slope1 && W2 && sslope && B > 0 && P > 0, "disc_tail_bwd: bad arguments");
+  hipLaunchKernelGGL(disc_tail_bwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), dout, ws, P, W1, mask, slope1, W2, sslope, beta,
+                     dA, dW1, db1, dslope1, dW2, db2, dsslope);
+  return se_check_launch("se_disc_tail_bwd");
+}

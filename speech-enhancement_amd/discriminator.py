@@ -1,12 +1,15 @@
 """Metric discriminator behind the reference's surface (models/discriminator.py:35-62).
 
 The four spectral-norm conv4x4/s2 + InstanceNorm + PReLU stages (all of the discriminator's FLOPs and bytes) run
-on the HIP tap-GEMM / norm kernels with a hand-written backward; the spectral-norm power iteration (weight-sized
-mat-vecs), the global max-pool over the final 12x20 map and the 128->64->1 head act on [B,128]-sized tensors and
-stay torch ops (launch-latency plumbing; listed as "next" in DESIGN.md).
+on the HIP tap-GEMM / norm kernels with a hand-written backward; the spectral-norm power iteration + weight scaling
+(se_spectral_norm) and the tail -- global max-pool over the final 12x20 map, Linear(128,64), Dropout, PReLU, Linear(64,1),
+learnable sigmoid (se_disc_tail_fwd / _bwd) -- are single-workgroup HIP kernels too: the discriminator step launches no
+vendor BLAS.
 The image is processed as [B, T, F, C] (channels-last, T x F transposed w.r.t. the reference's [B, C, F, T]); the
 4x4 taps are transposed accordingly, so no data is ever permuted.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -51,17 +54,66 @@ class _SNHolder(nn.Module):
         self.register_buffer('weight_v', F.normalize(torch.randn(wd), dim=0, eps=1e-12))
 
     def weight(self, train):
-        W = self.weight_orig
-        Wm = W.reshape(W.shape[0], -1)
-        if train:
-            with torch.no_grad():
-                v = F.normalize(Wm.t() @ self.weight_u, dim=0, eps=1e-12)
-                u = F.normalize(Wm @ v, dim=0, eps=1e-12)
-                self.weight_v.copy_(v)
-                self.weight_u.copy_(u)
-        u, v = self.weight_u.clone(), self.weight_v.clone()
-        sigma = torch.dot(u, Wm @ v)
-        return W / sigma
+        """W / sigma with one power iteration in training mode (torch.nn.utils.spectral_norm); u, v buffers updated in place"""
+        return _SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, bool(train))
+
+
+class _SpectralNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, u, v, train):
+        h, w = W.shape[0], W.numel() // W.shape[0]
+        Wc = W.detach().contiguous()
+        Wn = torch.empty_like(Wc)
+        sigma = torch.empty(1, device=W.device, dtype=torch.float32)
+        L.call('se_spectral_norm', L.ptr(Wc), L.ptr(u), L.ptr(v), L.ptr(Wn), L.ptr(sigma), C.c_int(h), C.c_int(w),
+               C.c_int(int(train)), C.c_float(1e-12), L.stream())
+        ctx.save_for_backward(Wn, u.clone(), v.clone(), sigma)      # the hook treats the (updated) u, v as constants
+        ctx.hw = (h, w)
+        return Wn
+
+    @staticmethod
+    def backward(ctx, dWn):
+        Wn, u, v, sigma = ctx.saved_tensors
+        h, w = ctx.hw
+        dW = torch.zeros_like(Wn)
+        L.call('se_spectral_norm_bwd', L.ptr(dWn.contiguous()), L.ptr(Wn), L.ptr(u), L.ptr(v), L.ptr(sigma), L.ptr(dW),
+               C.c_int(h), C.c_int(w), L.stream())
+        return dW, None, None, None
+
+
+class _DiscTailFn(torch.autograd.Function):
+    """a4 [B, To, Fo, 128] -> [B, 1]: max-pool, Linear(128,64), dropout mask, PReLU, Linear(64,1), beta * sigmoid(slope z)"""
+
+    @staticmethod
+    def forward(ctx, a4, W1, b1, mask, slope1, W2, b2, sslope, beta):
+        B = a4.shape[0]
+        P = a4.shape[1] * a4.shape[2]
+        a4 = a4.contiguous()
+        out = torch.empty(B, device=a4.device, dtype=torch.float32)
+        ws = torch.empty(L.lib().se_disc_tail_workspace_bytes(C.c_int(B)) // 4, device=a4.device, dtype=torch.float32)
+        args = [t.detach().contiguous() if t is not None else None for t in (W1, b1, mask, slope1, W2, b2, sslope)]
+        L.call('se_disc_tail_fwd', L.ptr(a4), C.c_int(B), C.c_int(P), L.ptr(args[0]), L.ptr(args[1]), L.ptr(args[2]),
+               L.ptr(args[3]), L.ptr(args[4]), L.ptr(args[5]), L.ptr(args[6]), C.c_float(beta), L.ptr(out), L.ptr(ws), L.stream())
+        ctx.save_for_backward(ws, *[a for a in args if a is not None])
+        ctx.has_mask, ctx.beta, ctx.shape = args[2] is not None, beta, a4.shape
+        return out.view(B, 1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        ws, *rest = ctx.saved_tensors
+        if ctx.has_mask:
+            W1, b1, mask, slope1, W2, b2, sslope = rest
+        else:
+            (W1, b1, slope1, W2, b2, sslope), mask = rest, None
+        B, To, Fo, _ = ctx.shape
+        need = ctx.needs_input_grad
+        dA = torch.zeros(ctx.shape, device=dout.device, dtype=torch.float32) if need[0] else None
+        g = lambda i, like: torch.zeros_like(like) if need[i] else None
+        dW1, db1, ds1, dW2, db2, dss = g(1, W1), g(2, b1), g(4, slope1), g(5, W2), g(6, b2), g(7, sslope)
+        L.call('se_disc_tail_bwd', L.ptr(dout.contiguous().view(-1)), L.ptr(ws), C.c_int(B), C.c_int(To * Fo), L.ptr(W1),
+               L.ptr(mask), L.ptr(slope1), L.ptr(W2), L.ptr(sslope), C.c_float(ctx.beta), L.ptr(dA), L.ptr(dW1), L.ptr(db1),
+               L.ptr(ds1), L.ptr(dW2), L.ptr(db2), L.ptr(dss), L.stream())
+        return dA, dW1, db1, None, ds1, dW2, db2, dss, None
 
 
 def _out(n):
@@ -154,12 +206,11 @@ class Discriminator(nn.Module):
         args = Ws + [dt(ly[i].weight) for i in (1, 4, 7, 10)] + [dt(ly[i].bias) for i in (1, 4, 7, 10)] + \
             [dt(ly[i].weight) for i in (2, 5, 8, 11)]
         a4 = _DConvStackFn.apply(xy, *args)
-        h = a4.amax(dim=(1, 2))
-        h = F.linear(h, dt(ly[14].weight(train)), dt(ly[14].bias))
-        h = ly[15](h)
-        h = F.prelu(h, dt(ly[16].weight))
-        h = F.linear(h, dt(ly[17].weight(train)), dt(ly[17].bias))
-        return self.layers[18].beta * torch.sigmoid(dt(ly[18].slope) * h)
+        B = a4.shape[0]
+        p = ly[15].p
+        mask = F.dropout(torch.ones(B, 64, device=a4.device), p, True) if (train and p > 0) else None   # nn.Dropout(0.3)
+        return _DiscTailFn.apply(a4, dt(ly[14].weight(train)), dt(ly[14].bias), mask, dt(ly[16].weight),
+                                 dt(ly[17].weight(train)), dt(ly[17].bias), dt(ly[18].slope), float(ly[18].beta))
 
     def forward(self, x, y):
         def planes(m):          # [B,1,F,T] -> [B,T,F,4]
