@@ -264,6 +264,26 @@ int se_disc_tail_bwd(const float* dout, const float* ws, int B, int P, const flo
                      const float* W2, const float* sslope, float beta, float* dA, float* dW1, float* db1, float* dslope1,
                      float* dW2, float* db2, float* dsslope, void* stream);
 
+/* ---- CDiffuSE denoiser glue (models/DiffuSE.py; csrc/se_diffuse.hip), channels-last [B, L, C] maps ---------------------- */
+/* SpectrogramUpsampler stage: ConvTranspose2d(1,1,[3,20], stride [1,10], padding [1,5]) + leaky_relu(0.4) on in [B][F][Tin];
+ * layout 0: out [B][F][10 Tin], layout 1: out [B][10 Tin][ldo] (channels-last, the conditioner GEMM operand) */
+int se_diff_upsample(const float* in, const float* w, const float* bias, float* out, int B, int F, int Tin, int layout, int ldo,
+                     void* stream);
+/* x = relu(w a + b) (input_projection, models/DiffuSE.py:150-151), y = x + d0[b or 0] (first diffusion_projection, :113-116) */
+int se_diff_input(const float* audio, const float* w, const float* bias, const float* d0, int dB, float* x, float* y, int B,
+                  long L, int C, void* stream);
+/* y = sigmoid(z[:C]) * tanh(z[C:]), z = R * scale + shift (GroupNorm of the dilated conv) + cond   (:117-122) */
+int se_diff_gate(const float* R, const float* ss, const float* cond, float* y, int B, long L, int C, void* stream);
+/* x <- (x + R2[:C]) / sqrt(2); ynext = x + d_next; skip (+)= GroupNorm(R2[C:])   (:124-127, 155-158) */
+int se_diff_mix(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip, int first,
+                int B, long L, int C, void* stream);
+/* nn.GroupNorm statistics -> ss [B][N][2] = (scale, shift) per (batch, channel) for channels [c_off, c_off + N) of the
+ * fp64 (sum, sumsq) table stats [B][Ntot][2] a GEMM epilogue produced (SE_EPI_STATS), groups of gsize channels */
+int se_group_finalize(const double* stats, int B, int Ntot, int c_off, int N, int gsize, double count_per_channel,
+                      const float* gamma, const float* beta, float* ss, float eps, void* stream);
+/* out[pos] = b + sum_c relu(h[pos][c]) w[c]   (:159-161) */
+int se_diff_out(const float* h, const float* w, const float* bias, float* out, long npos, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

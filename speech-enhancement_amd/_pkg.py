@@ -11,3 +11,5 @@ from .config import get_config  # noqa: F401
 from .inference import load_model, predict  # noqa: F401
 from .criterion import build_criterion  # noqa: F401
 from .frontend import disassemble_spectrogram, power_compress, power_uncompress  # noqa: F401
+from .diffuse import DiffuSE, inference_schedule  # noqa: F401
+from .diffuse import predict as predict_diffuse  # noqa: F401

@@ -114,7 +114,7 @@ extern "C" int se_stft_fused(const float* x, const float* c, const float* Wf, fl
                              int comp, float pre_scale, void* stream) {
   SE_REQUIRE(x && Wf && P && B > 0, "stft_fused: null operand");
   SE_REQUIRE(n_fft == FR_NFFT && hop == FR_HOP, "stft_fused: built for n_fft = 400, hop = 100 (got %d, %d)", n_fft, hop);
-  SE_REQUIRE(L > n_fft / 2 && (L % hop) == 0, "stft_fused: L = %d must be a multiple of the hop and exceed the reflect pad", L);
+  SE_REQUIRE(L > n_fft / 2, "stft_fused: L = %d must exceed the reflect pad", L);       // T = L / hop + 1 frames like torch.stft
   const int T = L / hop + 1;
   const size_t sh = (size_t)FR_TILE * FR_LDA * sizeof(float);
   hipLaunchKernelGGL(stft_fused_kernel, dim3(cdiv(T, FR_TILE), B), dim3(FR_NB * 64), sh, as_stream(stream), x, c, Wf, P, L, T, comp,

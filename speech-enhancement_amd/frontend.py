@@ -89,13 +89,14 @@ def stft_planes(x, n_fft=400, hop=100, comp='pow', scale=None, padded=True):
     windowed DFT + compression); other sizes the pad -> tap-GEMM -> compress sequence."""
     L.check_cuda(x)
     B, Ls = x.shape
-    if Ls % hop != 0 or n_fft % hop != 0 or hop % 4 != 0:
+    fused = n_fft == 400 and hop == 100 and Ls > 200
+    if (Ls % hop != 0 and not (fused and not padded)) or n_fft % hop != 0 or hop % 4 != 0:
         raise L.SeHipError(f'stft: need L % hop == 0, n_fft % hop == 0, hop % 4 == 0 (L={Ls}, hop={hop})')
     T = Ls // hop + 1
     Fq = n_fft // 2 + 1
     x = x.contiguous()
     pre = n_fft ** -0.5 if comp == 'norm' else 1.0
-    if n_fft == 400 and hop == 100 and Ls > 200:
+    if fused:
         Wfi, _ = fused_matrices(x.device)
         P = torch.empty(B, T, Fq, 4, device=x.device, dtype=torch.float32)
         L.call('se_stft_fused', L.ptr(x), L.ptr(scale), L.ptr(Wfi), L.ptr(P), _ci(B), _ci(Ls), _ci(n_fft), _ci(hop),

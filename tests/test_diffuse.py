@@ -1,0 +1,110 @@
+"""CDiffuSE (BASELINE config 5): oracle vs the reference's goldens (CPU), product vs goldens / oracle (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import formula
+from oracle import diffuse_oracle as DO
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NOISE_SCHEDULE = np.linspace(1e-4, 0.035, 50).tolist()
+FAST = [0.0001, 0.001, 0.01, 0.05, 0.2, 0.35]
+
+
+def rms(a, b):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+@pytest.fixture(scope='module')
+def gd():
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_diffuse.npz'))
+
+
+def diffuse_state():
+    """formula weights of the DiffuSE state_dict (names / shapes: tests/golden/diffuse_state_spec.json)"""
+    spec = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'diffuse_state_spec.json')))
+    sd = {}
+    for k, shape in spec:
+        base = 1.0 if (len(shape) == 1 and not k.endswith('.bias')) else 0.0        # GroupNorm weights are ones-initialised
+        t = formula.formula_tensor('diffuse.' + k, tuple(shape), 'float32', base)
+        if k == 'output_projection.weight':
+            t = formula.formula_tensor('diffuse.' + k, tuple(shape), 'float32', 0.0) * 0.5
+        sd[k] = t
+    return sd
+
+
+def test_oracle_forward_and_upsampler(gd):
+    sd = diffuse_state()
+    spec, audio = torch.from_numpy(gd['spec_mag']), torch.from_numpy(gd['audio'])
+    with torch.no_grad():
+        assert rms(DO.stft_mag(torch.from_numpy(gd['noisy'])), gd['spec_mag']) < 1e-6
+        assert rms(DO.upsample(sd, spec), gd['upsampled']) < 1e-6 * max(1.0, float(np.abs(gd['upsampled']).max()))
+        assert rms(DO.diffusion_embedding(sd, torch.tensor([12.375])), gd['embed_float']) < 1e-6
+        y = DO.forward(sd, audio, spec, torch.tensor([7, 31]))
+        assert rms(y, gd['fwd_int']) < 2e-5 * float(np.abs(gd['fwd_int']).max())
+        y = DO.forward(sd, audio, spec, torch.tensor([12.375]))
+        assert rms(y, gd['fwd_float']) < 2e-5 * float(np.abs(gd['fwd_float']).max())
+
+
+@pytest.mark.parametrize('tag', ['full', 'fast'])
+def test_oracle_schedule_and_sampler(gd, tag):
+    sched = DO.inference_schedule(NOISE_SCHEDULE, FAST if tag == 'fast' else None)
+    for k, v in sched.items():
+        np.testing.assert_allclose(v, gd[f'sched_{tag}_{k}'], rtol=1e-6 if k == 'T' else 1e-12, atol=1e-12, err_msg=k)
+    if tag == 'full':
+        return          # the 50-step trajectory is checked on the GPU only (CPU: 50 x 30-layer forwards)
+    with torch.no_grad():
+        y = DO.predict(diffuse_state(), gd['noisy'][0], sched, gd[f'predict_{tag}_noise'][:, 0])
+    assert rms(y, gd[f'predict_{tag}']) < 1e-4 * max(1e-3, float(np.abs(gd[f'predict_{tag}']).max()))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# GPU: the HIP path against the reference's goldens
+# ------------------------------------------------------------------------------------------------------------------
+def _model(S):
+    m = S.DiffuSE(10, 100, 201, NOISE_SCHEDULE, 64, 30)
+    sd = diffuse_state()
+    assert [k for k in m.state_dict()] == [k for k in sd]            # same names, same order as the reference module
+    m.load_state_dict(sd)
+    return m.cuda().eval()
+
+
+@pytest.mark.gpu
+def test_diffuse_forward_vs_reference(gd):
+    import speech_enhancement_amd as S
+    m = _model(S)
+    spec, audio = torch.from_numpy(gd['spec_mag']).cuda(), torch.from_numpy(gd['audio']).cuda()
+    cond = m.conditioner(spec)
+    # conditioner = conditioner_projection(upsampler(spec)): check layer 3 against the oracle built on the golden upsampling
+    sd = diffuse_state()
+    up = torch.from_numpy(gd['upsampled'])
+    ref3 = torch.nn.functional.conv1d(up, sd['residual_layers.3.conditioner_projection.weight'],
+                                      sd['residual_layers.3.conditioner_projection.bias']).transpose(1, 2)
+    assert rms(cond[3], ref3) < 2e-5 * float(ref3.abs().max())
+    y = m(audio, spec, torch.tensor([7, 31]))
+    assert y.shape == (2, 1, 900)
+    assert rms(y, gd['fwd_int']) < 5e-5 * float(np.abs(gd['fwd_int']).max())
+    y = m(audio, torch.complex(spec, torch.zeros_like(spec)), torch.tensor([12.375]))      # complex input: abs() (the fix)
+    assert rms(y, gd['fwd_float']) < 5e-5 * float(np.abs(gd['fwd_float']).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag', ['fast', 'full'])
+def test_diffuse_reverse_sampler_vs_reference(gd, tag):
+    """the reference's own predict() (6-step fast and full 50-step schedule, seeded noise draws) vs predict_diffuse"""
+    import types
+    import speech_enhancement_amd as S
+    m = _model(S)
+    cfg = types.SimpleNamespace(NOISE_SCHEDULE=NOISE_SCHEDULE, INFERENCE_NOISE_SCHEDULE=FAST, N_FFT=400, HOP_SAMPLES=100)
+    sched = S.inference_schedule(cfg, fast_sampling=(tag == 'fast'))
+    for mine, name in zip(sched, ('alpha', 'beta', 'alpha_cum', 'sigmas', 'T', 'c1', 'c2', 'c3', 'delta', 'delta_bar')):
+        np.testing.assert_allclose(np.asarray(mine, np.float64), gd[f'sched_{tag}_{name}'], rtol=1e-6, atol=1e-12, err_msg=name)
+    y = S.predict_diffuse(m, cfg, gd['noisy'][0], *sched, noises=gd[f'predict_{tag}_noise'])
+    ref = gd[f'predict_{tag}']
+    assert y.shape == ref.shape
+    assert rms(y, ref) < 2e-4 * max(1e-3, float(np.abs(ref).max())), (tag, rms(y, ref), float(np.abs(ref).max()))
