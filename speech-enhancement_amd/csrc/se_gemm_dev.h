@@ -392,6 +392,14 @@ static int check_desc(const se_gemm_desc* d) {
   SE_REQUIRE(d->N > 0, "gemm: N=%d", d->N);
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(d->ntap == 1, "gemm: LN prologue needs ntap==1");
   SE_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f out of range", d->drop_p);
+  // lane offsets are 32-bit element indices relative to a per-batch-entry base (64-bit): one batch entry of every operand
+  // must stay below 2^32 elements (B = 64 x [321, 201, 256] is 16.5 M elements per entry: fine; guarded, not assumed)
+  {
+    const long in_e = (long)d->Ti * d->Fi * d->lda, out_px = (long)d->To * d->Fo * ((d->epilogue & SE_EPI_SHUFFLE2) ? 2 : 1);
+    const long widest = d->ldc > d->ldr ? (d->ldc > d->ldx ? d->ldc : d->ldx) : (d->ldr > d->ldx ? d->ldr : d->ldx);
+    SE_REQUIRE(in_e < 4294967296L && out_px * widest < 4294967296L,
+               "gemm: a batch entry of an operand exceeds 2^32 elements (32-bit lane offsets): split the launch");
+  }
   if (d->prologue == SE_PRO_SWISH_DROP || d->prologue == SE_PRO_DROP || (d->epilogue & SE_EPI_DROP))
     SE_REQUIRE((long)d->B * d->Ti * d->Fi * (d->C > d->N ? d->C : d->N) < 4294967296L, "gemm: dropout index exceeds 32 bits");
   return 0;
