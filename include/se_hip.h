@@ -248,12 +248,14 @@ int se_axpbypcz(const float* a, const float* b, const float* c, float* y, float 
                 long n, void* stream);
 
 /* ---- metric-discriminator tail + spectral normalisation (models/discriminator.py:39-57; csrc/se_elem.hip) ---- */
-/* torch.nn.utils.spectral_norm on a [h, w] weight matrix: one power iteration (train != 0: u [h], v [w] updated in place),
- * sigma = u . (W v) written to sigma[0], Wn = W / sigma.  Backward: dW += (dWn - <dWn, Wn> u v^T) / sigma. */
-int se_spectral_norm(const float* W, float* u, float* v, float* Wn, float* sigma, int h, int w, int train, float eps,
-                     void* stream);
-int se_spectral_norm_bwd(const float* dWn, const float* Wn, const float* u, const float* v, const float* sigma, float* dW,
-                         int h, int w, void* stream);
+/* torch.nn.utils.spectral_norm on n <= 8 weight matrices [h_i, w_i] in ONE launch (host arrays of device pointers / sizes;
+ * the six spectral-norm layers of the discriminator): one power iteration each (train != 0: u_i [h_i], v_i [w_i] updated in
+ * place), sigma[i] = u_i . (W_i v_i), Wn_i = W_i / sigma[i].  Backward: dW_i += (dWn_i - <dWn_i, Wn_i> u_i v_i^T) / sigma[i];
+ * a NULL dWn[i] skips matrix i. */
+int se_spectral_norm(int n, const float* const* W, float* const* u, float* const* v, float* const* Wn, const int* h,
+                     const int* w, float* sigma, int train, float eps, void* stream);
+int se_spectral_norm_bwd(int n, const float* const* dWn, const float* const* Wn, const float* const* u,
+                         const float* const* v, const float* sigma, float* const* dW, const int* h, const int* w, void* stream);
 /* AdaptiveMaxPool2d(1) over the P positions of A [B, P, 128] -> Linear(128, 64) -> dropout mask [B, 64] (NULL: none; entries
  * 0 or 1 / (1 - p)) -> PReLU(64) -> Linear(64, 1) -> beta * sigmoid(slope * z): out [B].  ws = workspace of
  * se_disc_tail_workspace_bytes(B) bytes, kept for the backward (dA must be zero-initialised; parameter gradients accumulate). */

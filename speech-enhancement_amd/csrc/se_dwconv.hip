@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void dwconv_wgrad_kernel(DwWgradArgs a) {
   }
   // reduce the 8 position slots through LDS, 8 taps at a time; the workgroup's 32 x 128 partial sums go to its own row of
   // the workspace with plain stores (512 workgroups hammering the same 4 096 addresses with atomics ran at the contended
-  // atomic rate: ~90 us of a 300 us launch) and a second tiny kernel adds the rows up in a fixed order
+  // atomic rate: ~90 us of a 300 us launch) and a second tiny kernel adds the rows up (8 chunk sums per address)
   float* red = xs;     // [8 slots][8 taps][128]
   float* prow = a.part + (long)blockIdx.x * 32 * DW_C;
 #pragma unroll
@@ -218,16 +218,19 @@ __global__ __launch_bounds__(512, 2) void dwconv_wgrad_kernel(DwWgradArgs a) {
   }
 }
 
-// dW[ch][k] += sum over workgroups of part[wg][k][ch] (k == 31: dbias); one thread per (k, ch), fixed summation order
+// dW[ch][k] += sum over workgroups of part[wg][k][ch] (k == 31: dbias).  grid = (16 blocks of 256 (k, ch) pairs, 8 chunks of
+// workgroups): every thread adds up 64 rows, then one atomic per chunk (8 adds per address)
 __global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, int nwg, float* __restrict__ dW,
                                            float* __restrict__ dbias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;       // k * 128 + ch
-  if (i >= 32 * DW_C) return;
+  const int per = (nwg + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * per, w1 = w0 + per < nwg ? w0 + per : nwg;
+  if (i >= 32 * DW_C || w0 >= w1) return;
   float t = 0.f;
-  for (int w = 0; w < nwg; ++w) t += part[(long)w * 32 * DW_C + i];
+#pragma unroll 8
+  for (int w = w0; w < w1; ++w) t += part[(long)w * 32 * DW_C + i];
   const int k = i >> 7, ch = i & 127;
-  if (k < DW_K) dW[ch * DW_K + k] += t;
-  else if (dbias) dbias[ch] += t;
+  if (k < DW_K) atomicAdd(&dW[ch * DW_K + k], t);
+  else if (dbias) atomicAdd(&dbias[ch], t);
 }
 
 extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, float* Y, double* stats, int flip,
@@ -251,7 +254,7 @@ extern "C" int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, flo
   long nitems = (long)nseq * cdiv(n, DW_TILE);
   int nblk = nitems < 512 ? (int)nitems : 512;
   hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(512), 0, as_stream(stream), a);
-  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(32 * DW_C / 256), dim3(256), 0, as_stream(stream), (const float*)ws, nblk,
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(32 * DW_C / 256, 8), dim3(256), 0, as_stream(stream), (const float*)ws, nblk,
                      dW, dbias);
   return se_check_launch("se_dwconv31_wgrad");
 }

@@ -620,69 +620,81 @@ extern "C" int se_lamb_step(float* p, const float* g, float* m, float* v, const 
 // spectral_norm (torch.nn.utils.spectral_norm, one power iteration in training mode, eps 1e-12):
 //   v = normalize(W^T u), u = normalize(W v)   (train only; u, v updated in place)
 //   sigma = u . (W v);  Wn = W / sigma
-__global__ __launch_bounds__(256) void spectral_norm_kernel(const float* __restrict__ W, float* __restrict__ u, float* __restrict__ v,
-                                                            float* __restrict__ Wn, float* __restrict__ sigma_out, int h, int w,
-                                                            int train, float eps) {
-  extern __shared__ float sn[];           // v [w] | s = W v [h] | red [8]
+#define SN_MAX 8
+struct SnBatch { const float* W[SN_MAX]; float* u[SN_MAX]; float* v[SN_MAX]; float* Wn[SN_MAX]; int h[SN_MAX], w[SN_MAX]; float* sigma; };
+struct SnBwdBatch { const float* dWn[SN_MAX]; const float* Wn[SN_MAX]; const float* u[SN_MAX]; const float* v[SN_MAX];
+                    float* dW[SN_MAX]; int h[SN_MAX], w[SN_MAX]; const float* sigma; };
+// one workgroup (1024 threads) per weight matrix of the batch: the six spectral-norm layers of the discriminator in ONE launch
+__global__ __launch_bounds__(1024) void spectral_norm_kernel(SnBatch a, int train, float eps) {
+  extern __shared__ float sn[];           // v [w] | s = W v [h] | red [16]
+  const int li = blockIdx.x, h = a.h[li], w = a.w[li];
+  const float* __restrict__ W = a.W[li];
+  float* u = a.u[li]; float* v = a.v[li]; float* Wn = a.Wn[li];
   float* vs = sn; float* ss = sn + w; float* red = ss + h;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NT = 1024, NWV = 16;
   auto block_sum = [&](float x) {
     x = wave_sum(x);
     __syncthreads();
     if (lane == 0) red[wv] = x;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i];
+    return t;
   };
   if (train) {
     float nn = 0.f;
-    for (int j = tid; j < w; j += 256) {
+    for (int j = tid; j < w; j += NT) {
       float t = 0.f;
       for (int i = 0; i < h; ++i) t += W[(long)i * w + j] * u[i];
       vs[j] = t; nn += t * t;
     }
     const float nv = fmaxf(sqrtf(block_sum(nn)), eps);
-    for (int j = tid; j < w; j += 256) vs[j] /= nv;
+    for (int j = tid; j < w; j += NT) vs[j] /= nv;
   } else {
-    for (int j = tid; j < w; j += 256) vs[j] = v[j];
+    for (int j = tid; j < w; j += NT) vs[j] = v[j];
   }
   __syncthreads();
   float n2 = 0.f;
-  for (int i = wv; i < h; i += 4) {                 // one wave per row
+  for (int i = wv; i < h; i += NWV) {               // one wave per row
     float t = 0.f;
     for (int j = lane; j < w; j += 64) t += W[(long)i * w + j] * vs[j];
     t = wave_sum(t);
-    if (lane == 0) ss[i] = t;
-    if (lane == 0) n2 += t * t;
+    if (lane == 0) { ss[i] = t; n2 += t * t; }
   }
   const float nu2 = block_sum(n2);
   float sigma;
   if (train) {
     const float nu = fmaxf(sqrtf(nu2), eps);
     sigma = nu2 / nu;                                // u . (W v) with u = s / nu
-    for (int i = tid; i < h; i += 256) u[i] = ss[i] / nu;
-    for (int j = tid; j < w; j += 256) v[j] = vs[j];
+    for (int i = tid; i < h; i += NT) u[i] = ss[i] / nu;
+    for (int j = tid; j < w; j += NT) v[j] = vs[j];
   } else {
     float d = 0.f;
-    for (int i = tid; i < h; i += 256) d += u[i] * ss[i];
+    for (int i = tid; i < h; i += NT) d += u[i] * ss[i];
     sigma = block_sum(d);
   }
   const float inv = 1.0f / sigma;
-  for (long i = tid; i < (long)h * w; i += 256) Wn[i] = W[i] * inv;
-  if (tid == 0) sigma_out[0] = sigma;
+  for (long i = tid; i < (long)h * w; i += NT) Wn[i] = W[i] * inv;
+  if (tid == 0) a.sigma[li] = sigma;
 }
 // dW = (dWn - <dWn, Wn> u v^T) / sigma   (u, v are constants of the graph, as in torch's hook)
-__global__ __launch_bounds__(256) void spectral_norm_bwd_kernel(const float* __restrict__ dWn, const float* __restrict__ Wn,
-                                                                const float* __restrict__ u, const float* __restrict__ v,
-                                                                const float* __restrict__ sigma, float* __restrict__ dW, int h, int w) {
-  __shared__ float red[4];
-  const int tid = threadIdx.x;
+__global__ __launch_bounds__(1024) void spectral_norm_bwd_kernel(SnBwdBatch a) {
+  __shared__ float red[16];
+  const int li = blockIdx.x, h = a.h[li], w = a.w[li], tid = threadIdx.x;
+  const float* __restrict__ dWn = a.dWn[li]; const float* __restrict__ Wn = a.Wn[li];
+  if (!dWn) return;                                  // this layer needs no gradient
   float d = 0.f;
-  for (long i = tid; i < (long)h * w; i += 256) d += dWn[i] * Wn[i];
+  for (long i = tid; i < (long)h * w; i += 1024) d += dWn[i] * Wn[i];
   d = wave_sum(d);
   if ((tid & 63) == 0) red[tid >> 6] = d;
   __syncthreads();
-  const float dot = red[0] + red[1] + red[2] + red[3], inv = 1.0f / sigma[0];
-  for (long i = tid; i < (long)h * w; i += 256) {
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dot += red[i];
+  const float inv = 1.0f / a.sigma[li];
+  const float* u = a.u[li]; const float* v = a.v[li]; float* dW = a.dW[li];
+  for (long i = tid; i < (long)h * w; i += 1024) {
     const int r = (int)(i / w), cc = (int)(i - (long)r * w);
     dW[i] += (dWn[i] - dot * u[r] * v[cc]) * inv;
   }
@@ -763,17 +775,31 @@ __global__ __launch_bounds__(256) void disc_tail_bwd_kernel(const float* __restr
   }
 }
 
-extern "C" int se_spectral_norm(const float* W, float* u, float* v, float* Wn, float* sigma, int h, int w, int train, float eps,
-                                void* stream) {
-  SE_REQUIRE(W && u && v && Wn && sigma && h > 0 && w > 0 && h + w <= 8192, "spectral_norm: bad arguments");
-  hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(256), (size_t)(w + h + 8) * sizeof(float), as_stream(stream), W, u, v, Wn,
-                     sigma, h, w, train, eps);
+extern "C" int se_spectral_norm(int n, const float* const* W, float* const* u, float* const* v, float* const* Wn,
+                                const int* h, const int* w, float* sigma, int train, float eps, void* stream) {
+  SE_REQUIRE(n > 0 && n <= SN_MAX && W && u && v && Wn && h && w && sigma, "spectral_norm: bad arguments (at most %d matrices)", SN_MAX);
+  SnBatch a;
+  int maxhw = 0;
+  for (int i = 0; i < n; ++i) {
+    SE_REQUIRE(W[i] && u[i] && v[i] && Wn[i] && h[i] > 0 && w[i] > 0 && h[i] + w[i] <= 8192, "spectral_norm: bad matrix %d", i);
+    a.W[i] = W[i]; a.u[i] = u[i]; a.v[i] = v[i]; a.Wn[i] = Wn[i]; a.h[i] = h[i]; a.w[i] = w[i];
+    if (h[i] + w[i] > maxhw) maxhw = h[i] + w[i];
+  }
+  a.sigma = sigma;
+  hipLaunchKernelGGL(spectral_norm_kernel, dim3(n), dim3(1024), (size_t)(maxhw + 16) * sizeof(float), as_stream(stream), a, train, eps);
   return se_check_launch("se_spectral_norm");
 }
-extern "C" int se_spectral_norm_bwd(const float* dWn, const float* Wn, const float* u, const float* v, const float* sigma,
-                                    float* dW, int h, int w, void* stream) {
-  SE_REQUIRE(dWn && Wn && u && v && sigma && dW && h > 0 && w > 0, "spectral_norm_bwd: bad arguments");
-  hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), dWn, Wn, u, v, sigma, dW, h, w);
+extern "C" int se_spectral_norm_bwd(int n, const float* const* dWn, const float* const* Wn, const float* const* u,
+                                    const float* const* v, const float* sigma, float* const* dW, const int* h, const int* w,
+                                    void* stream) {
+  SE_REQUIRE(n > 0 && n <= SN_MAX && dWn && Wn && u && v && sigma && dW && h && w, "spectral_norm_bwd: bad arguments");
+  SnBwdBatch a;
+  for (int i = 0; i < n; ++i) {
+    SE_REQUIRE(!dWn[i] || (Wn[i] && u[i] && v[i] && dW[i] && h[i] > 0 && w[i] > 0), "spectral_norm_bwd: bad matrix %d", i);
+    a.dWn[i] = dWn[i]; a.Wn[i] = Wn[i]; a.u[i] = u[i]; a.v[i] = v[i]; a.dW[i] = dW[i]; a.h[i] = h[i]; a.w[i] = w[i];
+  }
+  a.sigma = sigma;
+  hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(n), dim3(1024), 0, as_stream(stream), a);
   return se_check_launch("se_spectral_norm_bwd");
 }
 extern "C" size_t se_disc_tail_workspace_bytes(int B) { return B > 0 ? (size_t)B * SE_DISC_TAIL_WS_ * sizeof(float) : 0; }

@@ -55,30 +55,51 @@ class _SNHolder(nn.Module):
 
     def weight(self, train):
         """W / sigma with one power iteration in training mode (torch.nn.utils.spectral_norm); u, v buffers updated in place"""
-        return _SpectralNormFn.apply(self.weight_orig, self.weight_u, self.weight_v, bool(train))
+        return spectral_weights([self], train)[0]
+
+
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
+
+
+def spectral_weights(holders, train, detach=False):
+    """the spectrally-normalised weights of several _SNHolder layers from ONE launch (se_spectral_norm)"""
+    Ws = [h.weight_orig.detach() if detach else h.weight_orig for h in holders]
+    uv = [t for h in holders for t in (h.weight_u, h.weight_v)]
+    return list(_SpectralNormFn.apply(bool(train), len(holders), *Ws, *uv))
 
 
 class _SpectralNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, W, u, v, train):
-        h, w = W.shape[0], W.numel() // W.shape[0]
-        Wc = W.detach().contiguous()
-        Wn = torch.empty_like(Wc)
-        sigma = torch.empty(1, device=W.device, dtype=torch.float32)
-        L.call('se_spectral_norm', L.ptr(Wc), L.ptr(u), L.ptr(v), L.ptr(Wn), L.ptr(sigma), C.c_int(h), C.c_int(w),
-               C.c_int(int(train)), C.c_float(1e-12), L.stream())
-        ctx.save_for_backward(Wn, u.clone(), v.clone(), sigma)      # the hook treats the (updated) u, v as constants
-        ctx.hw = (h, w)
-        return Wn
+    def forward(ctx, train, n, *ts):
+        Ws, uv = ts[:n], ts[n:]
+        us, vs = uv[0::2], uv[1::2]
+        hs = [W.shape[0] for W in Ws]
+        ws_ = [W.numel() // W.shape[0] for W in Ws]
+        Wc = [W.detach().contiguous() for W in Ws]
+        Wn = [torch.empty_like(W) for W in Wc]
+        sigma = torch.empty(n, device=Wc[0].device, dtype=torch.float32)
+        ha, wa = (C.c_int * n)(*hs), (C.c_int * n)(*ws_)
+        L.call('se_spectral_norm', C.c_int(n), _ptr_array(Wc), _ptr_array(us), _ptr_array(vs), _ptr_array(Wn), ha, wa,
+               L.ptr(sigma), C.c_int(int(train)), C.c_float(1e-12), L.stream())
+        # the hook treats the (updated) u, v as constants of the graph
+        ctx.save_for_backward(sigma, *Wn, *[u.clone() for u in us], *[v.clone() for v in vs])
+        ctx.n, ctx.hw = n, (hs, ws_)
+        return tuple(Wn)
 
     @staticmethod
-    def backward(ctx, dWn):
-        Wn, u, v, sigma = ctx.saved_tensors
-        h, w = ctx.hw
-        dW = torch.zeros_like(Wn)
-        L.call('se_spectral_norm_bwd', L.ptr(dWn.contiguous()), L.ptr(Wn), L.ptr(u), L.ptr(v), L.ptr(sigma), L.ptr(dW),
-               C.c_int(h), C.c_int(w), L.stream())
-        return dW, None, None, None
+    def backward(ctx, *dWn):
+        n = ctx.n
+        sigma, *rest = ctx.saved_tensors
+        Wn, us, vs = rest[:n], rest[n:2 * n], rest[2 * n:]
+        hs, ws_ = ctx.hw
+        need = ctx.needs_input_grad[2:2 + n]
+        dW = [torch.zeros_like(Wn[i]) if need[i] and dWn[i] is not None else None for i in range(n)]
+        if any(d is not None for d in dW):
+            dc = [dWn[i].contiguous() if dW[i] is not None else None for i in range(n)]
+            L.call('se_spectral_norm_bwd', C.c_int(n), _ptr_array(dc), _ptr_array(Wn), _ptr_array(us), _ptr_array(vs),
+                   L.ptr(sigma), _ptr_array(dW), (C.c_int * n)(*hs), (C.c_int * n)(*ws_), L.stream())
+        return (None, None) + tuple(dW) + (None,) * (2 * n)
 
 
 class _DiscTailFn(torch.autograd.Function):
@@ -202,15 +223,16 @@ class Discriminator(nn.Module):
         ly = self.layers
         train = self.training
         dt = (lambda t: t.detach()) if detach_params else (lambda t: t)
-        Ws = [dt(ly[i].weight(train)) for i in (0, 3, 6, 9)]
+        sn = spectral_weights([ly[i] for i in (0, 3, 6, 9, 14, 17)], train, detach=detach_params)   # all six layers, one launch
+        Ws = sn[:4]
         args = Ws + [dt(ly[i].weight) for i in (1, 4, 7, 10)] + [dt(ly[i].bias) for i in (1, 4, 7, 10)] + \
             [dt(ly[i].weight) for i in (2, 5, 8, 11)]
         a4 = _DConvStackFn.apply(xy, *args)
         B = a4.shape[0]
         p = ly[15].p
         mask = F.dropout(torch.ones(B, 64, device=a4.device), p, True) if (train and p > 0) else None   # nn.Dropout(0.3)
-        return _DiscTailFn.apply(a4, dt(ly[14].weight(train)), dt(ly[14].bias), mask, dt(ly[16].weight),
-                                 dt(ly[17].weight(train)), dt(ly[17].bias), dt(ly[18].slope), float(ly[18].beta))
+        return _DiscTailFn.apply(a4, sn[4], dt(ly[14].bias), mask, dt(ly[16].weight),
+                                 sn[5], dt(ly[17].bias), dt(ly[18].slope), float(ly[18].beta))
 
     def forward(self, x, y):
         def planes(m):          # [B,1,F,T] -> [B,T,F,4]

@@ -57,6 +57,10 @@ def fam(name):
         return 'attn_bwd3_bf16x6 (+delta, tables, dE reduce) n<=128'
     if n.startswith('attn_fwd2_kernel'):
         return 'attn_fwd2_kernel'
+    if n.startswith('attn_fwd3_kernel'):
+        return 'attn_fwd3_bf16x6'
+    if n.startswith('stft_fused_kernel') or n.startswith('istft_fused_kernel'):
+        return n.replace('_kernel', '')
     return None
 
 
