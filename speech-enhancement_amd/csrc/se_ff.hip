@@ -55,13 +55,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
         x[4 * h + 2] = rok ? (w.z - mean) * rstd * gm.z + bt.z : 0.f;
         x[4 * h + 3] = rok ? (w.w - mean) * rstd * gm.w + bt.w : 0.f;
       }
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        bf16x8 hh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
-        af1[ks][pl] = hh;
-      }
+      split_planes8<NPL>(x, af1[ks]);
     }
   }
   const int kq = tid & 15, r0 = tid >> 4;
@@ -140,12 +134,9 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
           x[4 * h + 2] = swishf_(pv.z) * sc.z; x[4 * h + 3] = swishf_(pv.w) * sc.w;
         }
         bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
+        split_planes8<NPL>(x, af2);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-          bf16x8 hh;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
-          af2[pl] = hh;
           bf0[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + frag + 16 * ks]);
           bf1[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + 32 * SB + frag + 16 * ks]);
         }
@@ -233,13 +224,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
         }
         x[4 * h] = w.x; x[4 * h + 1] = w.y; x[4 * h + 2] = w.z; x[4 * h + 3] = w.w;
       }
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        bf16x8 hh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
-        af1[ks][pl] = hh;
-      }
+      split_planes8<NPL>(x, af1[ks]);
     }
   }
   const int kq = tid & 15, r0 = tid >> 4;
@@ -321,12 +306,9 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
           x[4 * h] = pv.x; x[4 * h + 1] = pv.y; x[4 * h + 2] = pv.z; x[4 * h + 3] = pv.w;
         }
         bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
+        split_planes8<NPL>(x, af2);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
-          bf16x8 hh;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
-          af2[pl] = hh;
           bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + frag + 16 * ks]);
           bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + 32 * SB + frag + 16 * ks]);
         }

@@ -476,13 +476,7 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
         }
         x[4 * h] = w.x; x[4 * h + 1] = w.y; x[4 * h + 2] = w.z; x[4 * h + 3] = w.w;
       }
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        bf16x8 hh;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { hh[e] = (__bf16)x[e]; x[e] -= (float)hh[e]; }
-        af[ks][pl] = hh;
-      }
+      split_planes8<NPL>(x, af[ks]);
     }
   }
   // ---- W blocks: 64 rows x 64 k, 4 float4 per thread

@@ -375,6 +375,36 @@ static __device__ __forceinline__ unsigned pk_bf16_(float a, float b) {         
   f32x2_ v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
 }
+// Register-resident variants of the same packed split: x[] (8 or 4 floats) -> NPL planes of bf16x8 / bf16x4; x[] is consumed.
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+template <int NPL, typename V8>
+static __device__ __forceinline__ void split_planes8(float (&x)[8], V8 (&out)[NPL]) {
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    u32x4_ w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      w[i] = pk_bf16_(x[2 * i], x[2 * i + 1]);
+      if (q + 1 < NPL) {
+        x[2 * i] -= __builtin_bit_cast(float, w[i] << 16);
+        x[2 * i + 1] -= __builtin_bit_cast(float, w[i] & 0xffff0000u);
+      }
+    }
+    out[q] = __builtin_bit_cast(V8, w);
+  }
+}
+template <int NPL>
+static __device__ __forceinline__ void split_store4(float (&e)[4], __bf16* p, int plane_stride) {
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    const unsigned a = pk_bf16_(e[0], e[1]), b = pk_bf16_(e[2], e[3]);
+    *reinterpret_cast<u32x2_*>(p + q * plane_stride) = (u32x2_){a, b};
+    if (q + 1 < NPL) {
+      e[0] -= __builtin_bit_cast(float, a << 16); e[1] -= __builtin_bit_cast(float, a & 0xffff0000u);
+      e[2] -= __builtin_bit_cast(float, b << 16); e[3] -= __builtin_bit_cast(float, b & 0xffff0000u);
+    }
+  }
+}
 // Pairs are converted with one v_cvt_pk_bf16_f32, the residuals taken against the shifted / masked halves and subtracted with
 // v_pk_add_f32: 18 VALU instructions for the 3-way split of 4 values (the per-element form compiled to 31).  Same roundings.
 template <int NPL>

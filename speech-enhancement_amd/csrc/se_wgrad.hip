@@ -382,13 +382,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
       const int r = 4 * q + j;
       __bf16* dst = T + (9 * r + (r >> 4)) * 8 + 4 * rg;
       float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        bf16x4 h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { h[i] = (__bf16)e[i]; e[i] -= (float)h[i]; }
-        *reinterpret_cast<bf16x4*>(dst + pl * PLN) = h;
-      }
+      split_store4<NPL>(e, dst, PLN);
     }
   };
 
@@ -542,13 +536,7 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
       const int r = 4 * q + j;
       __bf16* dst = halo_layout ? T + (10 * r + (r >> 3)) * 8 + 8 + 4 * rg : T + (9 * r + (r >> 4)) * 8 + 4 * rg;
       float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
-#pragma unroll
-      for (int pl = 0; pl < NPL; ++pl) {
-        bf16x4 h;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { h[i] = (__bf16)e[i]; e[i] -= (float)h[i]; }
-        *reinterpret_cast<bf16x4*>(dst + pl * pln) = h;
-      }
+      split_store4<NPL>(e, dst, pln);
     }
   };
   int fbase = (int)((mbeg % Mb) % d.Fo);      // frequency index of the step's first row (wave-uniform)
