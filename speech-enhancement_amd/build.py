@@ -7,7 +7,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libse_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-munsafe-fp-atomics', '-fPIC', '-std=c++17', '-Wno-unused-result']
+# packed fp32 VALU ops (v_pk_add/mul/fma_f32) are disabled: measured on gfx950 (tools/micro/issue_bench.hip) they execute on the
+# matrix pipe -- each one stalls the MFMAs of every wave of the SIMD for ~6 cycles -- while two scalar fp32 ops overlap with them
+FLAGS = ['--offload-arch=gfx950', '-O3', '-munsafe-fp-atomics', '-fPIC', '-std=c++17', '-Wno-unused-result',
+         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
 def sources():

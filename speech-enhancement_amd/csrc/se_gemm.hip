@@ -340,33 +340,33 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
   float4 ra[4], rh, rb[2];
   // (chunk, triple) / (chunk, tap) of the tile being prefetched, advanced by increments (no divisions in the loop)
   int a_chunk = 0, a_gi = 0, b_chunk = 0, b_tap = 0;
+  // range-checked descriptors: output channels n >= N read as zeros; rows outside the batch entry and a channel chunk past C
+  // are sent out of range explicitly (byte offsets fit 32 bits: host-checked)
+  const __amdgpu_buffer_rsrc_t Ar = make_rsrc_(Ab, (unsigned)(((long)(Mb - 1) * d.lda + d.C) * 4));
+  const __amdgpu_buffer_rsrc_t Wr = make_rsrc_(Wb, (unsigned)((long)d.N * d.ldw * 4));
   auto load_a = [&]() {                        // halo tile of (a_chunk, a_gi); then advance
     const int chunk = a_chunk, gi = a_gi;
     if (++a_gi == ngrp) { a_gi = 0; ++a_chunk; }
     const int c = chunk * BK + kq * 4;
-    const bool cok = c < d.C;
     const int q0 = m0 - 1 + d.dt[3 * gi] * d.Fo;          // flattened source pixel of halo row 0
+    const unsigned cb = c < d.C ? (unsigned)c * 4u : BUF_OOB_;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = q0 + 1 + r0 + 32 * i;
-      ra[i] = (cok && q >= 0 && q < Mb) ? *reinterpret_cast<const float4*>(Ab + ((unsigned)q * (unsigned)d.lda + (unsigned)c))
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      ra[i] = buf_load4_(Ar, (unsigned)q < (unsigned)Mb ? (unsigned)q * (unsigned)d.lda * 4u + cb : BUF_OOB_);
     }
-    if (tid < 16) {                            // halo rows 0 and 129
+    {                                          // halo rows 0 and 129 (threads 0..15; the others fetch nothing)
       const int q = q0 + (tid >> 3) * (HR - 1);
-      rh = (cok && q >= 0 && q < Mb) ? *reinterpret_cast<const float4*>(Ab + ((unsigned)q * (unsigned)d.lda + (unsigned)c))
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+      rh = buf_load4_(Ar, (tid < 16 && (unsigned)q < (unsigned)Mb) ? (unsigned)q * (unsigned)d.lda * 4u + cb : BUF_OOB_);
     }
   };
   auto load_b = [&]() {                        // weight tile of (b_chunk, b_tap); then advance
     const int chunk = b_chunk, tap = b_tap;
     if (++b_tap == d.ntap) { b_tap = 0; ++b_chunk; }
     const int c = chunk * BK + kq * 4;
-    const bool cok = c < d.C;
-    const unsigned wk = (unsigned)(tap * d.C + c);
+    const unsigned wk = c < d.C ? (unsigned)(tap * d.C + c) * 4u : BUF_OOB_;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      rb[i] = (wok[i] && cok) ? *reinterpret_cast<const float4*>(Wb + (wrow[i] + wk)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 2; ++i) rb[i] = buf_load4_(Wr, wrow[i] * 4u + wk);
   };
 
   f32x16 acc0, acc1;
@@ -382,14 +382,19 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
     // stage the halo tile of this (chunk, triple); the previous iteration's trailing barrier freed Ap
 #pragma unroll
     for (int i = 0; i < 4; ++i) split_store<NPL>(ra[i], &Ap[(1 + r0 + 32 * i) * SA + kq * 4], PA);
+    // every lane consumes rh here (the lanes that do not store it too): a load still in flight on one path makes the
+    // compiler drain ALL loads before the register is reused
+    asm volatile("" :: "v"(rh.x), "v"(rh.y), "v"(rh.z), "v"(rh.w));
     if (tid < 16) split_store<NPL>(rh, &Ap[((tid >> 3) * (HR - 1)) * SA + kq * 4], PA);
-#pragma unroll 1
+    // the three taps are unrolled into straight-line code and every prefetch is issued unconditionally (past the last
+    // tile its offsets are out of range: zeros, no memory access), so the loads in flight are counted exactly
+#pragma unroll
     for (int s3 = 0; s3 < 3; ++s3, ++it) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
       __syncthreads();
-      if (it + 1 < NI) load_b();
-      if (s3 == 0 && gq + 1 < nchunk * ngrp) load_a();
+      load_b();
+      if (s3 == 0) load_a();
       const int df = d.df[3 * gi + s3];
       const bool kill = (df < 0 && edgeL) || (df > 0 && edgeR);
 #pragma unroll
@@ -632,6 +637,8 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   if ((d->precision == 1 || d->precision == 2) && d->C >= 32 && d->prologue == SE_PRO_NONE && !d->up && d->st == 1 && d->sf == 1 &&
       d->Ti == d->To && d->Fi == d->Fo && d->ntap >= 3 && d->ntap % 3 == 0 && !(ep & (SE_EPI_GLU | SE_EPI_DROP)) && d->Fo >= 2) {
     bool triples = getenv("SE_GEMM_NO_CONV3") == nullptr;
+    // the kernel addresses both operands with 32-bit BYTE offsets (range-checked buffer loads)
+    if ((long)d->To * d->Fo * d->lda * 4 >= (1L << 31) || (long)d->N * d->ldw * 4 >= (1L << 31)) triples = false;
     for (int t3 = 0; t3 < d->ntap && triples; t3 += 3) {
       int seen = 0;
       for (int j = 0; j < 3; ++j) {

@@ -7,7 +7,8 @@ skip = torch.randn(B, T, Fq, 256, device='cuda')
 w = torch.randn(64, Cin, 2, 3, device='cuda') * 0.02
 wp = GM.pack_conv_fwd(w)
 y = torch.empty(B, T, Fq, 64, device='cuda')
-d = GM.make_desc(B, T, Fq, T, Fq, LY.dense_taps(3), Cin, 256, 64, 64)
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+d = GM.make_desc(B, T, Fq, T, Fq, LY.dense_taps(3), Cin, 256, 64, 64, precision=prec)
 import time
 for _ in range(3):
     GM.gemm_tap(d, skip, wp, y)
@@ -17,4 +18,4 @@ for _ in range(5):
     GM.gemm_tap(d, skip, wp, y)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / 5
-print(f'conv Cin={Cin}: {dt*1e6:.0f} us, {2.0*B*T*Fq*64*6*Cin/dt/1e12:.1f} TF')
+print(f'conv Cin={Cin} precision={prec}: {dt*1e6:.0f} us, {2.0*B*T*Fq*64*6*Cin/dt/1e12:.1f} TF')
