@@ -211,8 +211,11 @@ def main():
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'mfma_busy_pct_pmc': mfma_busy, 'note': note}
         roof.update({'launches_per_step': v['launches'] // a.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
                      'share_of_step_time': round(v['ms'] / (dt * 1e3), 3),
-                     'families': {kk: {'ms_per_step': round(vv['ms'] / a.steps, 3),
-                                       'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)}
+                     'families': {kk: ({'ms_per_step': round(vv['ms'] / a.steps, 3),
+                                        'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)} if vv['flops'] > 0 else
+                                       {'ms_per_step': round(vv['ms'] / a.steps, 3),      # HBM-bound families: algorithmic bytes
+                                        'gbs': round(vv['bytes'] / (vv['ms'] * 1e-3) / 1e9, 1),
+                                        'frac_of_hbm_peak': round(vv['bytes'] / (vv['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)})
                                   for kk, vv in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}})
     res = {
         'metric': 'utterances/sec (2 s @16 kHz) CMGAN train step', 'value': round(world * B * a.steps / dt, 3),

@@ -9,8 +9,15 @@ LIB = os.path.join(HERE, 'libse_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # packed fp32 VALU ops (v_pk_add/mul/fma_f32) are disabled: measured on gfx950 (tools/micro/issue_bench.hip) they execute on the
 # matrix pipe -- each one stalls the MFMAs of every wave of the SIMD for ~6 cycles -- while two scalar fp32 ops overlap with them
-FLAGS = ['--offload-arch=gfx950', '-O3', '-munsafe-fp-atomics', '-fPIC', '-std=c++17', '-Wno-unused-result',
-         '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-munsafe-fp-atomics', '-fPIC', '-std=c++17', '-Wno-unused-result']
+NO_PACKED = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+# translation units without MFMAs whose inner loops are fp32 FMAs on channel pairs: v_pk_fma_f32 halves their VALU issue
+PACKED_OK = {'se_dwconv.hip'}
+FLAGS = BASE_FLAGS + NO_PACKED
+
+
+def flags_for(src):
+    return BASE_FLAGS if os.path.basename(src) in PACKED_OK else FLAGS
 
 
 def sources():
@@ -35,7 +42,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(HERE, 'build', os.path.basename(src) + '.o')
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + flags_for(src) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -17,19 +17,27 @@ static __device__ __forceinline__ long tok_of(const SeqGeom& g, int s, int p) {
   return (long)(s / g.inner) * g.outer_stride + (long)(s % g.inner) * g.inner_stride + (long)p * g.pos_stride;
 }
 
-constexpr int DW_C = 128, DW_K = 31, DW_TILE = 64, DW_ROWS = DW_TILE + DW_K - 1;   // 94
+constexpr int DW_C = 128, DW_K = 31;
 
 struct DwArgs {
   SeqGeom g;
   const float* X; const float* W; const float* bias; float* Y; double* stats; int flip;
 };
 
-// 512 threads: lane pair-channel cl = tid & 63 (2 channels), position slot ps = tid >> 6 (8 slots x 8 positions).
-// Two channels per lane (instead of four) keep the 31 taps + 8 accumulators + the next tile's prefetch registers
-// under ~100 VGPRs, so 3 workgroups (24 waves) stay resident per CU and the next tile's global loads are in flight
-// while the current tile is computed.
-__global__ __launch_bounds__(512) void dwconv_kernel(DwArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[DW_ROWS * DW_C];
+// 512 threads: lane pair-channel cl = tid & 63 (2 channels), position slot ps = tid >> 6 (8 slots x PPS positions).
+// A tile is 8 * PPS positions + 30 halo rows in LDS.  PPS is chosen per sequence length so that (a) a whole n = 101 sequence
+// is ONE tile (PPS = 13: no halo re-read at all, its 15 + 15 padding rows are zeros that are never fetched) and (b) n = 321 is
+// three tiles of 112 (PPS = 14: 142 rows read per 112 written instead of 94 per 64, and 336 computed positions for 321 instead
+// of 384).  More positions per slot also mean more FMAs per LDS read (PPS * 31 per PPS + 30 rows).  Two channels per lane keep
+// 31 taps + PPS accumulators at ~100 VGPRs: two 512-thread workgroups (2 x 72 KB of LDS) per CU, no cross-tile register
+// prefetch -- the other workgroup's compute covers this one's loads.  The FMAs are explicit 2-wide vectors (v_pk_fma_f32: both
+// channels of a lane in one instruction; this translation unit is built with packed fp32 ops enabled -- no MFMA here to stall).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int PPS>
+__global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
+  constexpr int TILE = 8 * PPS, ROWS = TILE + DW_K - 1;
+  __shared__ __attribute__((aligned(16))) float xs[ROWS * DW_C];
   const int tid = threadIdx.x, cl = tid & 63, ps = tid >> 6;
   const int n = a.g.n;
   for (int i = tid; i < DW_C * DW_K; i += 512) {
@@ -37,69 +45,88 @@ __global__ __launch_bounds__(512) void dwconv_kernel(DwArgs a) {
     xs[(a.flip ? DW_K - 1 - k : k) * DW_C + ch] = a.W[i];
   }
   __syncthreads();
-  float2 w[DW_K];
+  f32x2 w[DW_K];
 #pragma unroll
-  for (int k = 0; k < DW_K; ++k) w[k] = *reinterpret_cast<const float2*>(&xs[k * DW_C + cl * 2]);
-  float2 bv = make_float2(0.f, 0.f);
-  if (a.bias) bv = *reinterpret_cast<const float2*>(a.bias + cl * 2);
-  float s[2] = {0, 0}, q2[2] = {0, 0};
-  const int tiles = (n + DW_TILE - 1) / DW_TILE;
+  for (int k = 0; k < DW_K; ++k) w[k] = *reinterpret_cast<const f32x2*>(&xs[k * DW_C + cl * 2]);
+  f32x2 bv = {0.f, 0.f};
+  if (a.bias) bv = *reinterpret_cast<const f32x2*>(a.bias + cl * 2);
+  f32x2 s = {0.f, 0.f}, q2 = {0.f, 0.f};
+  const int tiles = (n + TILE - 1) / TILE;
   const long nitems = (long)a.g.nseq * tiles;
-  constexpr int NPRE = (DW_ROWS * 32 + 511) / 512;      // float4 per thread per tile (6)
-  float4 pre[NPRE];
-  auto fetch = [&](long it) {
-    const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * DW_TILE;
-    const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
-    const float* __restrict__ Xb = a.X + base * DW_C;
-    const long rs = a.g.pos_stride * DW_C;
-#pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-      int i = tid + k * 512;
-      int row = i >> 5, q = i & 31;
-      int p = p0 - 15 + row;
-      pre[k] = (row < DW_ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
+  constexpr int NLD = (ROWS * 32 + 511) / 512;      // float4 per thread per tile
   // XCD-aware item order: workgroups b and b + 8 share an XCD (round-robin dispatch), so XCD x walks its own contiguous
   // eighth of the (sequence, tile) items with its gridDim / 8 workgroups side by side -- consecutive tiles of a sequence are
   // in flight on the same XCD at the same time and their 30 shared halo rows are served by that XCD's L2 instead of HBM
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
   const long Q = (nitems + 7) >> 3, ibase = (long)xcd * Q, iend = ibase + Q < nitems ? ibase + Q : nitems;
-  long it = ibase + slot;
-  if (it < iend) fetch(it);
-  for (; it < iend; it += S) {
-    const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * DW_TILE;
+  for (long it = ibase + slot; it < iend; it += S) {
+    const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * TILE;
     const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
-    float* __restrict__ Yb = a.Y + base * DW_C;
+    const float* __restrict__ Xb = a.X + base * DW_C;
+    float* __restrict__ Yt = a.Y + base * DW_C + (long)p0 * (a.g.pos_stride * DW_C);
     const long rs = a.g.pos_stride * DW_C;
+    const unsigned rs32 = (unsigned)rs;
+    const float* __restrict__ Xt = Xb + (long)(p0 - 15) * rs;      // row 0 of the tile (never dereferenced outside [0, n))
+    float4 ld[NLD];
+    // wave-uniform base per 16-row step (SGPRs) + ONE 32-bit lane offset for all of them (rows of a tile span < 2^30 bytes:
+    // host-checked); per-load 64-bit lane addresses cost 2 VGPRs each and pushed the kernel over 128
+    const unsigned ld_off = (unsigned)(tid >> 5) * rs32 + (unsigned)(tid & 31) * 4u;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int row = (tid >> 5) + 16 * k, p = p0 - 15 + row;
+      const float* __restrict__ Xk = Xt + (long)(16 * k) * rs;
+      ld[k] = (row < ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xk + ld_off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     __syncthreads();                           // previous tile (or the tap table) fully consumed
 #pragma unroll
-    for (int k = 0; k < NPRE; ++k) {
-      int i = tid + k * 512;
-      if (i < DW_ROWS * 32) *reinterpret_cast<float4*>(&xs[(i >> 5) * DW_C + (i & 31) * 4]) = pre[k];
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * 512;
+      if (i < ROWS * 32) *reinterpret_cast<float4*>(&xs[(i >> 5) * DW_C + (i & 31) * 4]) = ld[k];
     }
     __syncthreads();
-    if (it + S < iend) fetch(it + S);
-    float2 acc[8];
+    f32x2 acc[PPS];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = bv;
+    for (int o = 0; o < PPS; ++o) acc[o] = bv;
+    // rows in groups of 4, the next group's LDS reads issued before this group's FMAs; the compiler barriers keep the
+    // fully unrolled loop from hoisting all PPS + 30 reads to the top (which cost 60 more VGPRs and a wave per SIMD)
+    constexpr int NR = PPS + DW_K - 1, NG = (NR + 3) / 4;
+    const float* xrow = &xs[(ps * PPS) * DW_C + cl * 2];
+    f32x2 xg[2][4];
 #pragma unroll
-    for (int i = 0; i < 8 + DW_K - 1; ++i) {
-      float2 x = *reinterpret_cast<const float2*>(&xs[(ps * 8 + i) * DW_C + cl * 2]);
+    for (int j = 0; j < 4; ++j) xg[0][j] = *reinterpret_cast<const f32x2*>(xrow + j * DW_C);
 #pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const int k = i - o;
-        if (k >= 0 && k < DW_K) { acc[o].x += x.x * w[k].x; acc[o].y += x.y * w[k].y; }
+    for (int g = 0; g < NG; ++g) {
+      asm volatile("" ::: "memory");
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((g + 1) * 4 + j < NR) xg[(g + 1) & 1][j] = *reinterpret_cast<const f32x2*>(xrow + ((g + 1) * 4 + j) * DW_C);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = g * 4 + j;
+        if (i < NR) {
+#pragma unroll
+          for (int o = 0; o < PPS; ++o) {
+            const int k = i - o;
+            if (k >= 0 && k < DW_K) acc[o] = __builtin_elementwise_fma(xg[g & 1][j], w[k], acc[o]);
+          }
+        }
       }
     }
+    // pin the accumulators here: otherwise the compiler sinks each output's 31 FMAs into its `p < n` branch below -- every
+    // row of the tile read into registers first (76 VGPRs), then one DEPENDENT chain of 31 FMAs per output
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      int p = p0 + ps * 8 + o;
+    for (int o = 0; o < PPS; ++o) asm volatile("" : "+v"(acc[o]));
+    const unsigned st_off = (unsigned)(ps * PPS) * rs32 + (unsigned)cl * 2u;
+#pragma unroll
+    for (int o = 0; o < PPS; ++o) {
+      const int p = p0 + ps * PPS + o;
       if (p < n) {
-        *reinterpret_cast<float2*>(Yb + (long)p * rs + cl * 2) = acc[o];
-        s[0] += acc[o].x; s[1] += acc[o].y;
-        q2[0] += acc[o].x * acc[o].x; q2[1] += acc[o].y * acc[o].y;
+        *reinterpret_cast<f32x2*>(Yt + (long)o * rs + st_off) = acc[o];
+        s += acc[o];
+        q2 = __builtin_elementwise_fma(acc[o], acc[o], q2);
       }
     }
   }
@@ -124,72 +151,85 @@ struct DwWgradArgs {
   float* part;      // workspace [workgroups][32 taps (31 + bias)][128 channels]: per-workgroup partial sums
 };
 
-// weight gradient, same thread layout (512 threads, 2 channels per lane, 8 slots x 8 positions): 31 float2
-// accumulators per lane, persistent over tiles, one flush per workgroup.
-__global__ __launch_bounds__(512, 2) void dwconv_wgrad_kernel(DwWgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[DW_ROWS * DW_C];
-  __shared__ __attribute__((aligned(16))) float ys[DW_TILE * DW_C];
+// weight gradient, same thread layout and tiling (512 threads, 2 channels per lane, 8 slots x PPS positions): 31 f32x2
+// accumulators per lane, persistent over tiles, one flush per workgroup.  Only X goes through LDS (halo rows shared by the
+// slots); every lane reads the dY values of its own PPS positions straight from global memory (8 B per lane, 512 B per
+// wave-instruction), so a workgroup needs 72 KB of LDS and two stay resident per CU.
+template <int PPS>
+__global__ __launch_bounds__(512, 4) void dwconv_wgrad_kernel(DwWgradArgs a) {
+  constexpr int TILE = 8 * PPS, ROWS = TILE + DW_K - 1;
+  __shared__ __attribute__((aligned(16))) float xs[ROWS * DW_C];
   const int tid = threadIdx.x, cl = tid & 63, ps = tid >> 6;
   const int n = a.g.n;
-  const int tiles = (n + DW_TILE - 1) / DW_TILE;
+  const int tiles = (n + TILE - 1) / TILE;
   const long nitems = (long)a.g.nseq * tiles;
-  // explicit 2-wide vectors: v_pk_fma_f32 does both channels of a lane in one instruction (the scalar float2 form
-  // compiled to separate multiplies, packed adds and ~2 register moves per pair: 4.7x the VALU instructions)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 acc[DW_K];
 #pragma unroll
   for (int k = 0; k < DW_K; ++k) acc[k] = (f32x2){0.f, 0.f};
   f32x2 bacc = {0.f, 0.f};
-  constexpr int NPX = (DW_ROWS * 32 + 511) / 512, NPY = DW_TILE * 32 / 512;     // 6, 4
-  float4 prx[NPX], pry[NPY];
-  auto fetch = [&](long it) {
-    const int seq = (int)(it / tiles), p0 = (int)(it % tiles) * DW_TILE;
+  constexpr int NLD = (ROWS * 32 + 511) / 512;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
+  const long Q = (nitems + 7) >> 3, ibase = (long)xcd * Q, iend = ibase + Q < nitems ? ibase + Q : nitems;
+  for (long it = ibase + slot; it < iend; it += S) {
+    const int seq = (int)(it / tiles), p0 = (int)(it % tiles) * TILE;
     const long base = (long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride;
     const float* __restrict__ Xb = a.X + base * DW_C;
-    const float* __restrict__ Gb = a.dY + base * DW_C;
+    const float* __restrict__ Gt = a.dY + base * DW_C + (long)p0 * (a.g.pos_stride * DW_C);
     const long rs = a.g.pos_stride * DW_C;
+    const unsigned rs32 = (unsigned)rs;
+    const float* __restrict__ Xt = Xb + (long)(p0 - 15) * rs;      // row 0 of the tile (never dereferenced outside [0, n))
+    float4 ld[NLD];
+    // wave-uniform base per 16-row step (SGPRs) + ONE 32-bit lane offset for all of them (rows of a tile span < 2^30 bytes:
+    // host-checked); per-load 64-bit lane addresses cost 2 VGPRs each and pushed the kernel over 128
+    const unsigned ld_off = (unsigned)(tid >> 5) * rs32 + (unsigned)(tid & 31) * 4u;
 #pragma unroll
-    for (int k = 0; k < NPX; ++k) {
-      int i = tid + k * 512, row = i >> 5, q = i & 31, p = p0 - 15 + row;
-      prx[k] = (row < DW_ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xb + (long)p * rs + q * 4)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < NPY; ++k) {
-      int i = tid + k * 512, row = i >> 5, q = i & 31, p = p0 + row;
-      pry[k] = (p < n) ? *reinterpret_cast<const float4*>(Gb + (long)p * rs + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  // no cross-tile register prefetch: without its 40 VGPRs the kernel fits 4 waves per SIMD, i.e. TWO of these
-  // 512-thread workgroups per CU (2 x 79 KB of LDS), and the other workgroup's compute covers this one's loads
-  long it = blockIdx.x;
-  for (; it < nitems; it += gridDim.x) {
-    fetch(it);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NPX; ++k) {
-      int i = tid + k * 512;
-      if (i < DW_ROWS * 32) *reinterpret_cast<float4*>(&xs[(i >> 5) * DW_C + (i & 31) * 4]) = prx[k];
-    }
-#pragma unroll
-    for (int k = 0; k < NPY; ++k) {
-      int i = tid + k * 512;
-      *reinterpret_cast<float4*>(&ys[(i >> 5) * DW_C + (i & 31) * 4]) = pry[k];
+    for (int k = 0; k < NLD; ++k) {
+      const int row = (tid >> 5) + 16 * k, p = p0 - 15 + row;
+      const float* __restrict__ Xk = Xt + (long)(16 * k) * rs;
+      ld[k] = (row < ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xk + ld_off) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
-    f32x2 dy[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) {
-      dy[o] = *reinterpret_cast<const f32x2*>(&ys[(ps * 8 + o) * DW_C + cl * 2]);
-      bacc += dy[o];
+    for (int k = 0; k < NLD; ++k) {
+      const int i = tid + k * 512;
+      if (i < ROWS * 32) *reinterpret_cast<float4*>(&xs[(i >> 5) * DW_C + (i & 31) * 4]) = ld[k];
     }
+    // dY after the staging registers are dead (31 accumulators + PPS dY values + the tile's loads would not fit 128 VGPRs)
+    asm volatile("" ::: "memory");
+    f32x2 dy[PPS];
+    const unsigned dy_off = (unsigned)(ps * PPS) * rs32 + (unsigned)cl * 2u;
 #pragma unroll
-    for (int i = 0; i < 8 + DW_K - 1; ++i) {
-      const f32x2 x = *reinterpret_cast<const f32x2*>(&xs[(ps * 8 + i) * DW_C + cl * 2]);
+    for (int o = 0; o < PPS; ++o) {
+      const int p = p0 + ps * PPS + o;
+      dy[o] = p < n ? *reinterpret_cast<const f32x2*>(Gt + (long)o * rs + dy_off) : (f32x2){0.f, 0.f};
+    }
+    __syncthreads();
 #pragma unroll
-      for (int o = 0; o < 8; ++o) {
-        const int k = i - o;
-        if (k >= 0 && k < DW_K) acc[k] = __builtin_elementwise_fma(dy[o], x, acc[k]);
+    for (int o = 0; o < PPS; ++o) bacc += dy[o];
+    constexpr int NR = PPS + DW_K - 1, NG = (NR + 3) / 4;
+    const float* xrow = &xs[(ps * PPS) * DW_C + cl * 2];
+    f32x2 xg[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xg[0][j] = *reinterpret_cast<const f32x2*>(xrow + j * DW_C);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      asm volatile("" ::: "memory");
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((g + 1) * 4 + j < NR) xg[(g + 1) & 1][j] = *reinterpret_cast<const f32x2*>(xrow + ((g + 1) * 4 + j) * DW_C);
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = g * 4 + j;
+        if (i < NR) {
+#pragma unroll
+          for (int o = 0; o < PPS; ++o) {
+            const int k = i - o;
+            if (k >= 0 && k < DW_K) acc[k] = __builtin_elementwise_fma(dy[o], xg[g & 1][j], acc[k]);
+          }
+        }
       }
     }
   }
@@ -218,16 +258,21 @@ __global__ __launch_bounds__(512, 2) void dwconv_wgrad_kernel(DwWgradArgs a) {
   }
 }
 
-// dW[ch][k] += sum over workgroups of part[wg][k][ch] (k == 31: dbias).  grid = (16 blocks of 256 (k, ch) pairs, 8 chunks of
-// workgroups): every thread adds up 64 rows, then one atomic per chunk (8 adds per address)
+// dW[ch][k] += sum over workgroups of part[wg][k][ch] (k == 31: dbias).  grid = (16 blocks of 256 (k, ch) pairs, 32 chunks of
+// workgroups)
 __global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, int nwg, float* __restrict__ dW,
                                            float* __restrict__ dbias) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;       // k * 128 + ch
   const int per = (nwg + gridDim.y - 1) / gridDim.y, w0 = blockIdx.y * per, w1 = w0 + per < nwg ? w0 + per : nwg;
   if (i >= 32 * DW_C || w0 >= w1) return;
+  // <= 16 partials per thread with all loads in flight at once, then one atomic per chunk (32 adds per address)
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = w0 + j < w1 ? part[(long)(w0 + j) * 32 * DW_C + i] : 0.f;
   float t = 0.f;
-#pragma unroll 8
-  for (int w = w0; w < w1; ++w) t += part[(long)w * 32 * DW_C + i];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) t += v[j];
+  for (int w = w0 + 16; w < w1; ++w) t += part[(long)w * 32 * DW_C + i];
   const int k = i >> 7, ch = i & 127;
   if (k < DW_K) atomicAdd(&dW[ch * DW_K + k], t);
   else if (dbias) atomicAdd(&dbias[ch], t);
@@ -237,10 +282,15 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
                            int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride,
                            void* stream) {
   SE_REQUIRE(X && W && Y && nseq > 0 && n > 0 && inner > 0, "dwconv31: bad arguments");
+  SE_REQUIRE(pos_stride > 0 && pos_stride * DW_C * 160L < (1L << 30), "dwconv31: position stride too large for 32-bit tile offsets");
   DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, W, bias, Y, stats, flip};
-  long nitems = (long)nseq * cdiv(n, DW_TILE);
-  int nblk = nitems < 768 ? (int)((nitems + 7) / 8 * 8) : 768;          // persistent: 3 workgroups (48 KB LDS each) per CU; multiple of 8
-  hipLaunchKernelGGL(dwconv_kernel, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  // tile = 8 slots x PPS positions: 64 (short sequences), 104 (n <= 104: the frequency axis, n = 101, is one tile), 112
+  const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
+  const long nitems = (long)nseq * cdiv(n, 8 * pps);
+  const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;    // persistent: 2 workgroups (<= 72 KB LDS each) per CU; multiple of 8
+  if (pps == 8) hipLaunchKernelGGL(dwconv_kernel<8>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (pps == 13) hipLaunchKernelGGL(dwconv_kernel<13>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(dwconv_kernel<14>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31");
 }
 
@@ -250,11 +300,15 @@ extern "C" int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, flo
                                  int inner, long outer_stride, long inner_stride, long pos_stride, float* ws,
                                  void* stream) {
   SE_REQUIRE(X && dY && dW && ws && nseq > 0 && n > 0 && inner > 0, "dwconv31_wgrad: bad arguments");
+  SE_REQUIRE(pos_stride > 0 && pos_stride * DW_C * 160L < (1L << 30), "dwconv31_wgrad: position stride too large for 32-bit tile offsets");
   DwWgradArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, dY, dW, dbias, ws};
-  long nitems = (long)nseq * cdiv(n, DW_TILE);
-  int nblk = nitems < 512 ? (int)nitems : 512;
-  hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3(nblk), dim3(512), 0, as_stream(stream), a);
-  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(32 * DW_C / 256, 8), dim3(256), 0, as_stream(stream), (const float*)ws, nblk,
+  const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
+  const long nitems = (long)nseq * cdiv(n, 8 * pps);
+  const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;      // <= 512 rows of the workspace; multiple of 8 (XCD split)
+  if (pps == 8) hipLaunchKernelGGL(dwconv_wgrad_kernel<8>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (pps == 13) hipLaunchKernelGGL(dwconv_wgrad_kernel<13>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL(dwconv_wgrad_kernel<14>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(32 * DW_C / 256, 32), dim3(256), 0, as_stream(stream), (const float*)ws, nblk,
                      dW, dbias);
   return se_check_launch("se_dwconv31_wgrad");
 }

@@ -99,7 +99,7 @@ def dwconv31(x, w, bias, geom, stats=None, flip=False):
     y = torch.empty_like(x)
     nseq, n, inner, os_, is_, ps = geom
     L.call('se_dwconv31', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(stats), _i(int(flip)), _i(nseq), _i(n),
-           _i(inner), _l(os_), _l(is_), _l(ps), L.stream())
+           _i(inner), _l(os_), _l(is_), _l(ps), L.stream(), _key='dwconv31 (fwd / dgrad)', _bytes=8.0 * x.numel())
     return y
 
 
@@ -107,7 +107,7 @@ def dwconv31_wgrad(x, dy, dw, dbias, geom):
     nseq, n, inner, os_, is_, ps = geom
     ws = _new(L.lib().se_dwconv31_wgrad_workspace_bytes() // 4, like=x)
     L.call('se_dwconv31_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(dbias), _i(nseq), _i(n), _i(inner), _l(os_),
-           _l(is_), _l(ps), L.ptr(ws), L.stream())
+           _l(is_), _l(ps), L.ptr(ws), L.stream(), _key='dwconv31_wgrad (+ reduce)', _bytes=8.0 * x.numel())
 
 
 # ---------------------------------------------------------------- front-end glue
