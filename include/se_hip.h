@@ -62,6 +62,10 @@ typedef struct {
   float drop_p;          /* dropout probability (0 = off), realised as round(p * 65536) / 65536; kept elements are scaled by the exact inverse keep probability */
   int precision;         /* 0: fp32 MFMA; 1: split-bf16 hi/lo (3 bf16 MFMAs per product, ~1.5e-5 relative);
                             2: split-bf16 hi/mid/lo (6 bf16 MFMAs, exact 24-bit split: fp32-equivalent, ~1e-7)   */
+  int w_planes;          /* 0: W is fp32 [N][ldw].  > 0 (se_gemm_tap, precision 2, C >= 32 only): W points to the weights
+                            PRE-SPLIT by se_weight_prep -- three bf16 planes (hi, mid, lo) of [N][ldw] elements each,
+                            w_planes elements apart (ldw, w_planes multiples of 8, 16-byte aligned); same results as the
+                            fp32 operand (the split is exact), without re-splitting the weights in every workgroup */
 } se_gemm_desc;
 
 int se_version(void);
@@ -87,7 +91,9 @@ int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W, const flo
 /* Fused feed-forward forward of a Conformer block (models/conformer.py:53-71,128-145: Scale(0.5, PreNorm(FeedForward))):
    Y = X + alpha * Drop_o(W2 Drop_h(Swish(W1 LN(X) + b1)) + b2), H = W1 LN(X) + b1 [M, hid] kept for the backward.
    X, Y: [M, 64]; rowstats: [M, 2] (mean, rstd) from se_row_stats; W1: [hid, 64]; W2: [64, hid]; hid % 64 == 0;
-   precision: 1 / 2 as in se_gemm_desc; dropout masks as in se_gemm_tap (prologue seed = seed_h on H, epilogue = seed_o). */
+   precision: 1 / 2 as in se_gemm_desc; dropout masks as in se_gemm_tap (prologue seed = seed_h on H, epilogue = seed_o).
+   precision | 16 (with 2): W1 and W2 point to weights PRE-SPLIT by se_weight_prep -- three bf16 planes of the same [rows][cols]
+   layout each, 64 * hid elements apart, 16-byte aligned (se_ff_bwd_dgrad: W2T and W1T likewise). */
 int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
               const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid, float drop_p,
               unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream);
@@ -109,6 +115,25 @@ int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const flo
 int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW, float* dbias,
                       const float* rowstats, const float* pro_scale, const float* pro_shift,
                       int chunks, void* stream);
+
+/* Weight preparation of a whole model in ONE launch (the per-step re-packing of every parameter the GEMMs read: tap order
+ * of nn.Conv2d weights, transposes for the input gradients, the newest-first slab order of DilatedDenseNet
+ * (models/generator.py:31), cat(to_q, to_kv), the 0.5 of Scale(0.5, .)), written as fp32 or as the exact three-way bf16 split
+ * (hi, mid, lo planes) the six-product kernels consume (se_gemm_desc.w_planes, se_ff_fwd precision | 16):
+ *   dst[o_off + o][c_off + t * Ni_dst + i] = scale * src[o' * so + t * stt + i' * si],   o < No, t < Nt, i < Ni
+ * (o', i' = o, i with the 64-slabs of i (rev 1) or o (rev 2) reversed).  `items_dev` is a DEVICE array built once by the caller
+ * (parameter and arena addresses are stable); max_elems = the largest No * Nt * Ni. */
+typedef struct {
+  const float* src;
+  void* dst;             /* fp32 matrix, or plane 0 of the three bf16 planes */
+  int No, Nt, Ni, Ni_dst;
+  long so, stt, si;
+  int rev;
+  int dst_ld, o_off, c_off;
+  float scale;
+  long plane_stride;     /* 0: fp32 destination; > 0: bf16 planes, this many elements apart */
+} se_wprep_item;
+int se_weight_prep(const se_wprep_item* items_dev, int nitems, long max_elems, void* stream);
 
 /* generic strided repack: dst[o][t][i] = src[o*so + i*si + t*stt] with optional reversal of the
  * 64-channel slabs of the o or i index (DilatedDenseNet concatenates newest-first,

@@ -14,7 +14,9 @@ struct FfArgs {
   float* H; float* Y; long M; int hid; float drop_p; unsigned seed_h, seed_o; float alpha;
 };
 
-template <int NPL>
+// WPL: W1 / W2 arrive pre-split (se_weight_prep: three bf16 planes each, 64 * hid elements apart): the weight blocks are
+// plain 16-B copies into LDS instead of 8 fp32 loads + 8 three-way splits (144 VALU instructions) per thread and block.
+template <int NPL, bool WPL = false>
 __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 workgroups per CU: VGPR + AGPR <= 256
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
   __shared__ __attribute__((aligned(16))) __bf16 W1p[NPL * PB];
@@ -61,12 +63,27 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
   const int kq = tid & 15, r0 = tid >> 4;
   const int nb = a.hid / 64;
   float4 rw1[4], rw2[4];
+  const int pr = tid >> 2, pc = tid & 3;       // pre-split weights: row, 16-B chunks pc and pc + 4 of a 64 x 64 bf16 block
+  const size_t wpl = (size_t)64 * (size_t)a.hid;
+  f32x4 rp1[NPL * 2], rp2[NPL * 2];           // (flat register arrays: a 2-D array behind the lambda went to scratch memory)
   auto load_w = [&](int jb) {
+    if (WPL) {
+      const __bf16* w1 = reinterpret_cast<const __bf16*>(a.W1) + ((unsigned)(jb * 64 + pr) * 64u + 8 * pc);
+      const __bf16* w2 = reinterpret_cast<const __bf16*>(a.W2) + ((unsigned)pr * (unsigned)a.hid + jb * 64 + 8 * pc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = r0 + 16 * i;
-      rw1[i] = *reinterpret_cast<const float4*>(a.W1 + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
-      rw2[i] = *reinterpret_cast<const float4*>(a.W2 + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          rp1[q * 2 + h] = *reinterpret_cast<const f32x4*>(w1 + q * wpl + 32 * h);
+          rp2[q * 2 + h] = *reinterpret_cast<const f32x4*>(w2 + q * wpl + 32 * h);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = r0 + 16 * i;
+        rw1[i] = *reinterpret_cast<const float4*>(a.W1 + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
+        rw2[i] = *reinterpret_cast<const float4*>(a.W2 + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
+      }
     }
   };
   load_w(0);
@@ -76,10 +93,20 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
   const int frag = (lane & 31) * SB + 8 * kg;
   const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
   for (int jb = 0; jb < nb; ++jb) {
+    if (WPL) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      split_store<NPL>(rw1[i], &W1p[(r0 + 16 * i) * SB + kq * 4], PB);
-      split_store<NPL>(rw2[i], &W2p[(r0 + 16 * i) * SB + kq * 4], PB);
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          *reinterpret_cast<f32x4*>(&W1p[q * PB + pr * SB + 8 * pc + 32 * h]) = rp1[q * 2 + h];
+          *reinterpret_cast<f32x4*>(&W2p[q * PB + pr * SB + 8 * pc + 32 * h]) = rp2[q * 2 + h];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        split_store<NPL>(rw1[i], &W1p[(r0 + 16 * i) * SB + kq * 4], PB);
+        split_store<NPL>(rw2[i], &W2p[(r0 + 16 * i) * SB + kq * 4], PB);
+      }
     }
     if (tid < 64) b1s[tid] = a.b1[jb * 64 + tid];
     __syncthreads();
@@ -192,7 +219,7 @@ struct FfBwdArgs {
   const float* X; const float* stats; const float* gamma; const float* dR2; float* dX; float* dgamma; float* dbeta;
 };
 
-template <int NPL>
+template <int NPL, bool WPL = false>
 __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
   __shared__ __attribute__((aligned(16))) __bf16 Wa[NPL * PB];         // W2T block: rows = hidden units, k = channel
@@ -235,13 +262,35 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
   const int frag = (lane & 31) * SB + 8 * kg;
   const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
   for (int jb = 0; jb < nb; ++jb) {
+    if (WPL) {       // pre-split planes (64 * hid elements apart): 16-B copies, no split
+      const int pr = tid >> 2, pc = tid & 3;
+      const size_t wpl = (size_t)64 * (size_t)a.hid;
+      const __bf16* wa = reinterpret_cast<const __bf16*>(a.W2T) + ((unsigned)(jb * 64 + pr) * 64u + 8 * pc);
+      const __bf16* wb = reinterpret_cast<const __bf16*>(a.W1T) + ((unsigned)pr * (unsigned)a.hid + jb * 64 + 8 * pc);
+      uint4 va[NPL][2], vb[NPL][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = r0 + 16 * i;
-      const float4 wa = *reinterpret_cast<const float4*>(a.W2T + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
-      const float4 wb = *reinterpret_cast<const float4*>(a.W1T + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
-      split_store<NPL>(wa, &Wa[j * SB + kq * 4], PB);
-      split_store<NPL>(wb, &Wb[j * SB + kq * 4], PB);
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          va[q][h] = *reinterpret_cast<const uint4*>(wa + q * wpl + 32 * h);
+          vb[q][h] = *reinterpret_cast<const uint4*>(wb + q * wpl + 32 * h);
+        }
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          *reinterpret_cast<uint4*>(&Wa[q * PB + pr * SB + 8 * pc + 32 * h]) = va[q][h];
+          *reinterpret_cast<uint4*>(&Wb[q * PB + pr * SB + 8 * pc + 32 * h]) = vb[q][h];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = r0 + 16 * i;
+        const float4 wa = *reinterpret_cast<const float4*>(a.W2T + (unsigned)(jb * 64 + j) * 64u + 4 * kq);
+        const float4 wb = *reinterpret_cast<const float4*>(a.W1T + (unsigned)j * (unsigned)a.hid + jb * 64 + 4 * kq);
+        split_store<NPL>(wa, &Wa[j * SB + kq * 4], PB);
+        split_store<NPL>(wb, &Wb[j * SB + kq * 4], PB);
+      }
     }
     // pre-activations of this block for the Swish gradient: issued before the MFMAs, consumed in the epilogue
     float4 hp[8];
@@ -415,12 +464,16 @@ extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T
   SE_REQUIRE(X ? (stats && gamma && dX && dgamma && dbeta) : dLN != nullptr,
              "ff_bwd_dgrad: either dLN, or all of X / stats / gamma / dX / dgamma / dbeta (fused LayerNorm backward)");
   SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_bwd_dgrad: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
+  const bool wpl = (precision & 16) != 0;
+  precision &= 15;
   SE_REQUIRE(precision == 1 || precision == 2, "ff_bwd_dgrad: precision must be 1 (bf16x3) or 2 (bf16x6)");
+  SE_REQUIRE(!wpl || (precision == 2 && (((size_t)W2T | (size_t)W1T) & 15) == 0), "ff_bwd_dgrad: pre-split weights need precision 2 and 16-byte alignment");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_bwd_dgrad: drop_p=%f out of range", drop_p);
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_bwd_dgrad: dropout index exceeds 32 bits");
   FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, X, stats, gamma, dR2, dX, dgamma, dbeta};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else if (wpl) hipLaunchKernelGGL((ff_bwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL(ff_bwd_kernel<3>, grid, block, 0, as_stream(stream), a);
   return se_check_launch("se_ff_bwd_dgrad");
 }
@@ -430,12 +483,16 @@ extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gam
                          float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
   SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && H && Y, "ff_fwd: null operand");
   SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_fwd: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
+  const bool wpl = (precision & 16) != 0;
+  precision &= 15;
   SE_REQUIRE(precision == 1 || precision == 2, "ff_fwd: precision must be 1 (bf16x3) or 2 (bf16x6)");
+  SE_REQUIRE(!wpl || (precision == 2 && (((size_t)W1 | (size_t)W2) & 15) == 0), "ff_fwd: pre-split weights need precision 2 and 16-byte alignment");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_fwd: drop_p=%f out of range", drop_p);
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_fwd: dropout index exceeds 32 bits");
   FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else if (wpl) hipLaunchKernelGGL((ff_fwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL(ff_fwd_kernel<3>, grid, block, 0, as_stream(stream), a);
   return se_check_launch("se_ff_fwd");
 }

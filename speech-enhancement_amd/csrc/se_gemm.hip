@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 // represented to 2^-16 relative, i.e. products carry ~1.5e-5 relative error (vs 6e-8 in fp32, 4e-3 in plain bf16)
 // -- inside the 1e-3 parity budget with two orders of magnitude to spare (measured in tests/test_gemm_gpu.py and
 // on the full model) -- while the three bf16 MFMAs cost 3/16 of the one fp32 MFMA they replace.
-template <int PRO, int NPL, bool LIN>
+template <int PRO, int NPL, bool LIN, bool WPL = false>
 __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 64, BK = 32, SA = 40;     // rows of 32 bf16 + 8 pad = 80 B: conflict-free b128 reads
   constexpr int KQ = BK / 4, RPP = 256 / KQ, NA = BM / RPP, NB = BN / RPP;
@@ -207,6 +207,16 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     else { n = by * 64 + j; wok[i] = n < d.N; }
     wrow[i] = (unsigned)n * (unsigned)d.ldw;
   }
+  const int pr = tid >> 2, pc = tid & 3;       // pre-split weights: (row, 16-B chunk) of the 64 x 32 bf16 tile
+  bool prow_ok;
+  unsigned prow_e;
+  {
+    int n;
+    if (glu) { n = (pr >> 5) * (d.N / 2) + by * 32 + (pr & 31); prow_ok = (by * 32 + (pr & 31)) < d.N / 2; }
+    else { n = by * 64 + pr; prow_ok = n < d.N; }
+    prow_e = (unsigned)n * (unsigned)d.ldw;
+  }
+  uint4 rbp[NPL];
   float ln_mean[NA] = {}, ln_rstd[NA] = {};
   if (PRO == SE_PRO_LN) {
     const float* __restrict__ rs = g.rowstats + (long)b * TiFi * 2;
@@ -245,9 +255,17 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
       ra[i] = aok[i] ? *reinterpret_cast<const float4*>(Ab + ((unsigned)p * (unsigned)d.lda + (unsigned)c))
                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (WPL) {       // pre-split planes: one 16-B chunk (8 k) of row tid >> 2 per plane
+      const int cp = c0 + pc * 8;
+      const __bf16* wp = reinterpret_cast<const __bf16*>(Wb) + (prow_e + (unsigned)(tap * d.C + cp));
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      rb[i] = (wok[i] && cok) ? *reinterpret_cast<const float4*>(Wb + (wrow[i] + wk)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int q = 0; q < NPL; ++q)
+        rbp[q] = (prow_ok && cp < d.C) ? *reinterpret_cast<const uint4*>(wp + (size_t)q * (size_t)d.w_planes) : make_uint4(0u, 0u, 0u, 0u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        rb[i] = (wok[i] && cok) ? *reinterpret_cast<const float4*>(Wb + (wrow[i] + wk)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   };
 
   f32x16 acc0, acc1;
@@ -266,9 +284,14 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
         v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], ps4, pb4, apix[i], d.pro_seed, thr, inv_keep);
       split_store<NPL>(v, &Ap[(r0 + i * RPP) * SA + kq * 4], PA);
     }
+    if (WPL) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      split_store<NPL>(rb[i], &Bp[(r0 + i * RPP) * SA + kq * 4], PB);
+      for (int q = 0; q < NPL; ++q) *reinterpret_cast<uint4*>(&Bp[q * PB + pr * SA + pc * 8]) = rbp[q];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        split_store<NPL>(rb[i], &Bp[(r0 + i * RPP) * SA + kq * 4], PB);
+    }
     __syncthreads();
     if (it + 1 < NI) load_tiles(it + 1);
 #pragma unroll
@@ -307,8 +330,10 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 // bf16 splits and LDS writes of the generic kernel (which is VALU-bound by exactly those).  The frequency padding
 // (f = 0 with df = -1, f = F - 1 with df = +1) wraps to the neighbouring time row in flattened order and is masked per
 // lane on the fragment instead.
-template <int NPL>
-__global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
+// WPL: the weights arrive pre-split (se_weight_prep: three bf16 planes [N][ldw]); the B tile is then a plain 16-B copy per
+// plane and thread instead of two fp32 loads + a 36-instruction split per tap step in every workgroup.
+template <int NPL, bool WPL = false>
+__global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
   constexpr int BM = 128, BN = 64, BK = 32, SA = 40, HR = BM + 2;
   constexpr int PA = HR * SA, PB = BN * SA;
   __shared__ __attribute__((aligned(16))) __bf16 Ap[NPL * PA];
@@ -360,13 +385,35 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
       rh = buf_load4_(Ar, (tid < 16 && (unsigned)q < (unsigned)Mb) ? (unsigned)q * (unsigned)d.lda * 4u + cb : BUF_OOB_);
     }
   };
+  // pre-split weights: thread -> (row tid >> 2, 16-B chunk tid & 3) of the 64 x 32 bf16 tile of every plane
+  const int pr = tid >> 2, pc = tid & 3;
+  const bool prow_ok = by * 64 + pr < d.N;
+  const unsigned prow_b = (unsigned)(by * 64 + pr) * (unsigned)d.ldw * 2u;
+  const __amdgpu_buffer_rsrc_t Wpr = make_rsrc_(Wb, WPL ? (unsigned)d.w_planes * 2u * (unsigned)NPL : 0u);
+  // WPL: two register slots.  vmcnt retires loads IN ORDER, so a weight tile requested after the (HBM-latency) halo tile of the
+  // next group cannot be waited for without waiting for that halo tile too: the second and third tap's tiles of a group are
+  // requested together, BEFORE the next group's halo tile, and the first tile of the next group after it (both are needed at
+  // the same moment).  With one tile per tap step the halo-tile latency was exposed at the second tap of every group.
+  f32x4 rbp[2][NPL];
+  auto load_bp = [&](int slot) {               // pre-split weight tile of (b_chunk, b_tap) -> slot; then advance
+    const int chunk = b_chunk, tap = b_tap;
+    if (++b_tap == d.ntap) { b_tap = 0; ++b_chunk; }
+    const int c = chunk * BK + pc * 8;
+    const bool ok = c < d.C && prow_ok;
+    const unsigned wk = prow_b + (unsigned)(tap * d.C + c) * 2u;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+      rbp[slot][q] = __builtin_bit_cast(f32x4, buf_load4_(Wpr, ok ? wk + (unsigned)q * (unsigned)d.w_planes * 2u : BUF_OOB_));
+  };
   auto load_b = [&]() {                        // weight tile of (b_chunk, b_tap); then advance
     const int chunk = b_chunk, tap = b_tap;
     if (++b_tap == d.ntap) { b_tap = 0; ++b_chunk; }
-    const int c = chunk * BK + kq * 4;
-    const unsigned wk = c < d.C ? (unsigned)(tap * d.C + c) * 4u : BUF_OOB_;
+    {
+      const int c = chunk * BK + kq * 4;
+      const unsigned wk = c < d.C ? (unsigned)(tap * d.C + c) * 4u : BUF_OOB_;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) rb[i] = buf_load4_(Wr, wrow[i] * 4u + wk);
+      for (int i = 0; i < 2; ++i) rb[i] = buf_load4_(Wr, wrow[i] * 4u + wk);
+    }
   };
 
   f32x16 acc0, acc1;
@@ -375,7 +422,7 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
   const bool vec_ep = epilogue_vec_ok(d);
   if (vec_ep) stage_bias(g, by, bias_s);
   load_a();
-  load_b();
+  if (WPL) load_bp(0); else load_b();
   const int frag = (lane & 31) * SA + 8 * (lane >> 5);
   int it = 0, gi = 0;
   for (int gq = 0; gq < nchunk * ngrp; ++gq, gi = (gi + 1 == ngrp ? 0 : gi + 1)) {
@@ -390,11 +437,21 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
     // tile its offsets are out of range: zeros, no memory access), so the loads in flight are counted exactly
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3, ++it) {
+      if (WPL) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
+        for (int q = 0; q < NPL; ++q) *reinterpret_cast<f32x4*>(&Bp[q * PB + pr * SA + pc * 8]) = rbp[s3 == 2 ? 1 : 0][q];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
+      }
       __syncthreads();
-      load_b();
-      if (s3 == 0) load_a();
+      if (WPL) {
+        if (s3 == 0) { load_bp(0); load_bp(1); load_a(); }      // taps 1, 2 of this group, then the next group's halo tile
+        else if (s3 == 1) load_bp(0);                            // tap 0 of the next group (slot 0 was stored above)
+      } else {
+        load_b();
+        if (s3 == 0) load_a();
+      }
       const int df = d.df[3 * gi + s3];
       const bool kill = (df < 0 && edgeL) || (df > 0 && edgeR);
 #pragma unroll
@@ -438,7 +495,7 @@ __global__ __launch_bounds__(256) void conv3_bf16_kernel(GemmArgs g) {
 // 64 MFMAs.  Here one workgroup owns 128 rows and sweeps ALL column blocks: each wave loads its 32 rows straight into
 // the MFMA A-fragment layout (lane = row, 8 consecutive k), applies the prologue and the bf16 split ONCE and keeps the
 // fragments in 16 * NPL VGPRs; only the 64 x 64 weight blocks stream through LDS (next block prefetched in registers).
-template <int PRO, int NPL, bool PRE2>
+template <int PRO, int NPL, bool PRE2, bool WPL = false>
 __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   constexpr int SB = 72, PB = 64 * SB;         // 64 + 8 bf16 per W row: 144-B stride, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
@@ -488,7 +545,22 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   const int kq = tid & 15, r0 = tid >> 4;
   const int ncb = g.ncb;
   float4 rb[4];
+  // pre-split weights: thread -> (row tid >> 2, 16-B chunks (tid & 3) and (tid & 3) + 4) of the 64 x 64 bf16 block of every plane
+  const int pr = tid >> 2, pc = tid & 3;
+  uint4 rbp[NPL][2];
   auto load_w = [&](int by) {
+    if (WPL) {
+      int n; bool ok;
+      if (glu) { n = (pr >> 5) * (d.N / 2) + by * 32 + (pr & 31); ok = (by * 32 + (pr & 31)) < d.N / 2; }
+      else { n = by * 64 + pr; ok = n < d.N; }
+      const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)n * (unsigned)d.ldw + 8 * pc);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          rbp[q][h] = ok ? *reinterpret_cast<const uint4*>(wp + (size_t)q * (size_t)d.w_planes + 32 * h) : make_uint4(0u, 0u, 0u, 0u);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = r0 + 16 * i;
@@ -503,8 +575,15 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   const int frag = (lane & 31) * SB + 8 * (lane >> 5);
   float* cs = patch + wave * 32 * 36;
   for (int by = 0; by < ncb; ++by) {
+    if (WPL) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 16 * i) * SB + kq * 4], PB);
+      for (int q = 0; q < NPL; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) *reinterpret_cast<uint4*>(&Bp[q * PB + pr * SB + 8 * pc + 32 * h]) = rbp[q][h];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 16 * i) * SB + kq * 4], PB);
+    }
     if (vec_ep) stage_bias(g, by, bias_s);
     __syncthreads();
     if (by + 1 < ncb) load_w(by + 1);
@@ -594,6 +673,12 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
   if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");
+  if (d->w_planes) {      // W = three bf16 planes (se_weight_prep): only the six-product split kernels read them
+    SE_REQUIRE(d->precision == 2 && d->C >= 32 && (d->C % 8) == 0 && (d->ldw % 8) == 0 && d->w_planes >= (long)d->N * d->ldw &&
+               (d->w_planes % 8) == 0 && ((size_t)W & 15) == 0,
+               "gemm: pre-split weights need precision 2, C >= 32, C, ldw and the plane stride multiples of 8, a 16-byte aligned W");
+    SE_REQUIRE((long)d->w_planes * 6 < (1L << 31), "gemm: pre-split weight planes exceed 2^31 bytes");
+  }
   GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats, 0, 0, 0, 0};
   const int Mb = d->To * d->Fo;
   const int ncols = (ep & SE_EPI_GLU) ? cdiv(d->N / 2, 32) : cdiv(d->N, 64);
@@ -618,6 +703,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       dim3 pgrid(g.tiles);
       const bool pre2 = (ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) != 0;
 #define LAUNCHP2(PRO, P2) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2>), pgrid, block, 0, s, g); \
+                          else if (d->w_planes) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3, P2, true>), pgrid, block, 0, s, g); \
                           else hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3, P2>), pgrid, block, 0, s, g); } while (0)
 #define LAUNCHP(PRO) do { if (pre2) LAUNCHP2(PRO, true); else LAUNCHP2(PRO, false); } while (0)
       switch (d->prologue) {
@@ -649,12 +735,14 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     }
     if (triples) {
       if (d->precision == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2>), grid, block, 0, s, g);
+      else if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<3, true>), grid, block, 0, s, g);
       else hipLaunchKernelGGL((conv3_bf16_kernel<3>), grid, block, 0, s, g);
       return se_check_launch("se_gemm_tap(conv3)");
     }
   }
   if ((d->precision == 1 || d->precision == 2) && d->C >= 32) {      // split-bf16 paths (BK = 32 only)
 #define LAUNCHB2(PRO, LIN_) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 2, LIN_>), grid, block, 0, s, g); \
+                          else if (d->w_planes) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 3, LIN_, true>), grid, block, 0, s, g); \
                           else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 3, LIN_>), grid, block, 0, s, g); } while (0)
 #define LAUNCHB(PRO) do { if (lin) LAUNCHB2(PRO, true); else LAUNCHB2(PRO, false); } while (0)
     switch (d->prologue) {
@@ -687,6 +775,44 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
 #undef LAUNCH_BK
 #undef LAUNCH
   return se_check_launch("se_gemm_tap");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight preparation of a whole model in ONE launch: every item re-packs one parameter tensor (tap order, transposition,
+// slab reversal, scaling, concatenation into a row / column range) into the [N][ld] matrix a GEMM reads, as fp32 or as the
+// exact three-way bf16 split (hi, mid, lo planes).  blockIdx.y = item, blockIdx.x = 256-element chunk.
+__global__ void weight_prep_kernel(const se_wprep_item* __restrict__ items, int nitems) {
+  const se_wprep_item it = items[blockIdx.y];
+  const long total = (long)it.No * it.Nt * it.Ni;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % it.Ni);
+    const int t = (int)((idx / it.Ni) % it.Nt);
+    const int o = (int)(idx / ((long)it.Ni * it.Nt));
+    int is = i, os = o;
+    if (it.rev == 1) { const int ns = it.Ni / 64; is = (ns - 1 - i / 64) * 64 + (i & 63); }
+    if (it.rev == 2) { const int ns = it.No / 64; os = (ns - 1 - o / 64) * 64 + (o & 63); }
+    float v = it.scale * it.src[os * it.so + is * it.si + t * it.stt];
+    const long at = (long)(it.o_off + o) * it.dst_ld + it.c_off + (long)t * it.Ni_dst + i;
+    if (it.plane_stride == 0) {
+      reinterpret_cast<float*>(it.dst)[at] = v;
+    } else {
+      __bf16* dp = reinterpret_cast<__bf16*>(it.dst) + at;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const __bf16 h = (__bf16)v;          // round to nearest even: the same split as split_store<3>
+        dp[(long)q * it.plane_stride] = h;
+        v -= (float)h;
+      }
+    }
+  }
+}
+
+extern "C" int se_weight_prep(const se_wprep_item* items_dev, int nitems, long max_elems, void* stream) {
+  SE_REQUIRE(items_dev && nitems > 0 && nitems <= 65535 && max_elems > 0, "weight_prep: bad arguments");
+  long nb = (max_elems + 255) / 256;
+  if (nb > 64) nb = 64;                       // grid-stride inside an item: most items are a few thousand elements
+  hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)nb, (unsigned)nitems), dim3(256), 0, as_stream(stream), items_dev, nitems);
+  return se_check_launch("se_weight_prep");
 }
 
 extern "C" int se_repack(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt, long si,

@@ -52,6 +52,10 @@ def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
 def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb=None, stats=None):
     L.check_cuda(A, W, Y, bias, R, AUX, rowstats, ps, pb, stats)
     M = d.B * d.To * d.Fo
+    if W.dtype == torch.bfloat16:        # weights pre-split by the step's WeightPlan: [3 planes][rows][ld] bf16
+        d.w_planes, d.ldw = W.stride(0), W.shape[2]
+    else:
+        d.w_planes = 0
     L.call('se_gemm_tap', C.byref(d), L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Y), L.ptr(R), L.ptr(AUX),
            L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream(),
            _key=(f'conv3_bf16x{3 if d.precision == 1 else 6}'
@@ -131,17 +135,20 @@ def unpack_conv_wgrad(dwp, dw, rev_slabs=False, accumulate=False):
                   accumulate=accumulate)
 
 
-def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None):
+def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None, hid=None):
     """fused Scale(alpha, PreNorm(FeedForward)) forward (csrc/se_gemm.hip: ff_fwd_kernel): returns (Y, H) with
     H = W1 LN(x) + b1 kept for the backward."""
     L.check_cuda(x, rowstats, gamma, beta, W1, b1, W2, b2)
-    M, hid = x.shape[0], W1.shape[0]
+    pl = W1.dtype == torch.bfloat16         # pre-split planes [3][hid][64] / [3][64][hid] (weights.WeightPlan)
+    if pl != (W2.dtype == torch.bfloat16):
+        raise L.SeHipError('ff_fwd: W1 and W2 must both be fp32 or both pre-split planes')
+    M, hid = x.shape[0], (hid or W1.shape[-2])
     H = torch.empty(M, hid, device=x.device, dtype=torch.float32)
     Y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     prec = LINEAR_PRECISION if precision is None else precision
     L.call('se_ff_fwd', L.ptr(x), L.ptr(rowstats), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
            L.ptr(H), L.ptr(Y), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF),
-           C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec), L.stream(),
+           C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec | (16 if pl else 0)), L.stream(),
            _key=f'ff_fwd_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid, _bytes=4.0 * M * (128 + hid))
     return Y, H
 
@@ -155,10 +162,13 @@ def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precisi
     dZ = torch.empty(M, hid, device=dy.device, dtype=torch.float32)
     out = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
     prec = LINEAR_PRECISION if precision is None else precision
+    pl = W2T_scaled.dtype == torch.bfloat16
+    if pl != (W1T.dtype == torch.bfloat16):
+        raise L.SeHipError('ff_bwd_dgrad: W2T and W1T must both be fp32 or both pre-split planes')
     x, st, g, dR2, dg, db = ln if ln is not None else (None,) * 6
     L.call('se_ff_bwd_dgrad', L.ptr(dy), L.ptr(H), L.ptr(W2T_scaled), L.ptr(W1T), L.ptr(dZ), L.ptr(None if ln else out),
            C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF),
-           C.c_int(prec), L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dR2), L.ptr(out if ln else None), L.ptr(dg), L.ptr(db),
+           C.c_int(prec | (16 if pl else 0)), L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dR2), L.ptr(out if ln else None), L.ptr(dg), L.ptr(db),
            L.stream(), _key=f'ff_bwd_dgrad_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid,
            _bytes=4.0 * M * (128 + 2 * hid + (128 if ln else 0)))
     return dZ, out

@@ -5,6 +5,8 @@ The nn.Module tree below only *holds* parameters and buffers under the reference
 checkpoints load with ``load_state_dict`` and ours load into the reference); none of the torch.nn forward
 methods is ever called -- ``TSCNet.forward`` runs ``_TSCNetFn``, whose forward/backward are hand-written.
 """
+import os as _os
+
 import torch
 import torch.nn as nn
 
@@ -82,6 +84,7 @@ class _TSCNetFn(torch.autograd.Function):
         P.update(model._buffer_dict())
         train = model.training
         with torch.no_grad():
+            P['__prep__'] = model._prepare_weights(P, xin.device)      # every re-packed / pre-split weight: one launch
             model._drop_calls += 1
             seed = (torch.initial_seed() * 2654435761 + model._drop_calls * 40503) & 0xFFFFFFFF
             est, c = LY.tscnet_fwd(P, xin.contiguous(), train=train, dp=model.dp,
@@ -144,6 +147,19 @@ class TSCNet(nn.Module):
         self._drop_calls = 0
         self.dp = LY.NO_DP
         self._pnames = [k for k, _ in self.named_parameters()]
+
+    def _prepare_weights(self, P, device):
+        """the step's prepared weights (weights.WeightPlan): built once per (device, parameter storage, precision setting),
+        refreshed from the current parameter values by one kernel launch."""
+        if _os.environ.get('SE_NO_WEIGHT_PLAN') == '1':      # A/B switch: round-1 path (per-use repacks, weights re-split per tile)
+            return None
+        key = (str(device), LY.CONV_PRECISION, LY.GM.LINEAR_PRECISION)
+        plan = self.__dict__.get('_wplan')
+        if plan is None or self.__dict__.get('_wplan_key') != key or plan.stale():
+            plan = LY.build_generator_plan(P, device)
+            self.__dict__['_wplan'], self.__dict__['_wplan_key'] = plan, key
+        plan.run()
+        return plan
 
     def set_dropout(self, ff=0.2, attn=0.2):
         """train-mode dropout probabilities (parity runs use 0, like the fixtures)."""

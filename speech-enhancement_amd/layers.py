@@ -88,7 +88,7 @@ def inorm_prelu_bwd(R, mr, g, b, slope, dy, ldy, y_off, dg, db, dslope):
 
 
 def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=1, rev=False, dx=None, lddx=None,
-             dx_off=0, accumulate=False, need_dx=True, w_for_dgrad=None):
+             dx_off=0, accumulate=False, need_dx=True, w_for_dgrad=None, wd=None):
     """gradients of a (non-shuffled) conv: weight/bias into dw/dbias (PyTorch layout, accumulated), input
     gradient into dx[..., dx_off:dx_off+C_in] (pixel stride lddx)."""
     N = dR.shape[-1]
@@ -99,9 +99,10 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     _unpack_w(dwp, dw, C_in, rev)
     if not need_dx:
         return None
-    wd = GM.pack_conv_dgrad(w_for_dgrad if w_for_dgrad is not None else w, rev_slabs=rev)   # [Cin][tap][N]
-    if wd.shape[0] != C_in:      # channel-padded input (Cin 3 -> 4 etc.)
-        wd = torch.cat([wd, wd.new_zeros(C_in - wd.shape[0], wd.shape[1])], 0)
+    if wd is None:               # no prepared [Cin][tap][N] matrix (weights.WeightPlan): build it now
+        wd = GM.pack_conv_dgrad(w_for_dgrad if w_for_dgrad is not None else w, rev_slabs=rev)
+        if wd.shape[0] != C_in:      # channel-padded input (Cin 3 -> 4 etc.)
+            wd = torch.cat([wd, wd.new_zeros(C_in - wd.shape[0], wd.shape[1])], 0)
     if dx is None:
         dx = torch.empty(B, Ti, Fi, C_in, device=dR.device, dtype=torch.float32)
         lddx = C_in
@@ -137,6 +138,66 @@ def pad_rows(w, n):
 
 
 # ------------------------------------------------------------------------------------------------
+# prepared weights: P['__prep__'] (weights.WeightPlan, refreshed by ONE launch per forward) holds every re-packed / transposed /
+# pre-split weight of the generator; without a plan (direct calls of these functions with a plain dict) the same matrices are
+# built on the fly, in fp32, by the round-1 helpers
+# ------------------------------------------------------------------------------------------------
+def _w(P, key, fallback):
+    plan = P.get('__prep__')
+    t = plan.out.get(key) if plan is not None else None
+    return t if t is not None else fallback()
+
+
+def build_generator_plan(P, device):
+    from .weights import WeightPlan
+    plan = WeightPlan(device)
+    cpl = CONV_PRECISION == 2            # six-product kernels read the exact hi/mid/lo planes; everything else fp32
+    lpl = GM.LINEAR_PRECISION == 2
+
+    def dense(p):
+        for i in range(4):
+            n = f'{p}.conv{i+1}.weight'
+            plan.conv_fwd((n, 'fwd'), P[n], rev=True, planes=cpl)
+            plan.conv_dgrad((n, 'dgrad'), P[n], rev=True, planes=cpl)
+
+    e = 'dense_encoder'
+    plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
+    dense(f'{e}.dilated_dense')
+    plan.conv_fwd((f'{e}.conv_2.0.weight', 'fwd'), P[f'{e}.conv_2.0.weight'], planes=cpl)
+    plan.conv_dgrad((f'{e}.conv_2.0.weight', 'dgrad'), P[f'{e}.conv_2.0.weight'], planes=cpl)
+    for dec, last in (('mask_decoder', 'conv_1'), ('complex_decoder', 'conv')):
+        dense(f'{dec}.dense_block')
+        n = f'{dec}.sub_pixel.conv.weight'
+        plan.conv_fwd((n, 'fwd'), P[n], planes=cpl)
+        plan.conv_dgrad((n, 'dgrad'), P[n], planes=cpl)
+        n = f'{dec}.{last}.weight'                                   # 64 -> 1 / 2 channels, rows padded to 4
+        plan.conv_fwd((n, 'fwd'), P[n], N_pad=4, planes=cpl)
+        plan.conv_dgrad((n, 'dgrad'), P[n], N_pad=4)                  # C = 4 < 32: fp32 kernel
+    for i in range(1, 5):
+        for ax in ('time', 'freq'):
+            p = f'TSCB_{i}.{ax}_conformer'
+            for ff in ('ff1', 'ff2'):
+                n1, n2 = f'{p}.{ff}.fn.fn.net.0.weight', f'{p}.{ff}.fn.fn.net.3.weight'
+                if lpl and P[n1].shape[1] == 64 and P[n2].shape[0] == 64 and P[n1].shape[0] % 64 == 0:
+                    plan.linear((n1, 'lin'), P[n1], planes=True)
+                    plan.linear((n2, 'lin'), P[n2], planes=True)
+                    plan.linear_T((n2, 'T0.5'), P[n2], planes=True, scale=0.5)
+                    plan.linear_T((n1, 'T'), P[n1], planes=True)
+            a = f'{p}.attn.fn'
+            plan.linear((a, 'qkv'), P[f'{a}.to_q.weight'], planes=lpl, rows=192)
+            plan.linear((a, 'qkv'), P[f'{a}.to_kv.weight'], planes=lpl, o_off=64)
+            plan.linear_T((a, 'qkvT'), P[f'{a}.to_q.weight'], planes=lpl, ld=192)
+            plan.linear_T((a, 'qkvT'), P[f'{a}.to_kv.weight'], planes=lpl, c_off=64)
+            plan.linear_T((f'{a}.to_out.weight', 'T'), P[f'{a}.to_out.weight'])
+            n = f'{p}.conv.net.2.weight'
+            plan.linear((n, 'lin'), P[n], planes=lpl)
+            plan.linear_T((n, 'T'), P[n], planes=lpl)
+            n = f'{p}.conv.net.7.weight'
+            plan.linear_T((n, 'T'), P[n], planes=lpl)
+    return plan
+
+
+# ------------------------------------------------------------------------------------------------
 # DilatedDenseNet (models/generator.py:6-32)
 # ------------------------------------------------------------------------------------------------
 def dense_taps(i):
@@ -150,7 +211,7 @@ def dense_block_fwd(P, p, skip, B, T, Fq):
     out = None
     for i in range(4):
         C_in = 64 * (i + 1)
-        wp = pack_w(P[f'{p}.conv{i+1}.weight'], rev=True)
+        wp = _w(P, (f'{p}.conv{i+1}.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv{i+1}.weight'], rev=True))
         R, stats = conv_fwd(skip, B, T, Fq, 256, 0, C_in, wp, P[f'{p}.conv{i+1}.bias'], dense_taps(i), 64)
         if i < 3:
             mr = inorm_prelu_fwd(R, stats, P[f'{p}.norm{i+1}.weight'], P[f'{p}.norm{i+1}.bias'],
@@ -179,7 +240,7 @@ def dense_block_bwd(P, G, p, ctx, dout, B, T, Fq):
                              G[f'{p}.norm{i+1}.bias'], G[f'{p}.prelu{i+1}.weight'])
         conv_bwd(skip, B, T, Fq, 256, 0, C_in, P[f'{p}.conv{i+1}.weight'], dense_taps(i), dR, T, Fq,
                  G[f'{p}.conv{i+1}.weight'], G[f'{p}.conv{i+1}.bias'], rev=True, dx=dskip, lddx=256, dx_off=0,
-                 accumulate=(i != 3))
+                 accumulate=(i != 3), wd=_w(P, (f'{p}.conv{i+1}.weight', 'dgrad'), lambda: None))
         ctx['R'][i] = None
     return dskip
 
@@ -195,7 +256,8 @@ TAPS_1x2 = [(0, 0), (0, 1)]
 def encoder_fwd(P, xin, B, T, Fq):
     p = 'dense_encoder'
     ctx = {'xin': xin}
-    R0, st0 = conv_fwd(xin, B, T, Fq, 4, 0, 4, pack_w(P[f'{p}.conv_1.0.weight'], C_pad=4),
+    R0, st0 = conv_fwd(xin, B, T, Fq, 4, 0, 4,
+                       _w(P, (f'{p}.conv_1.0.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv_1.0.weight'], C_pad=4)),
                        P[f'{p}.conv_1.0.bias'], TAPS_1x1, 64)
     skip = torch.empty(B, T, Fq, 256, device=xin.device, dtype=torch.float32)
     ctx['mr0'] = inorm_prelu_fwd(R0, st0, P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
@@ -203,8 +265,9 @@ def encoder_fwd(P, xin, B, T, Fq):
     ctx['R0'] = R0
     a2, ctx['dense'] = dense_block_fwd(P, f'{p}.dilated_dense', skip, B, T, Fq)
     Fo = (Fq + 2 - 3) // 2 + 1
-    R5, st5 = conv_fwd(a2, B, T, Fq, 64, 0, 64, pack_w(P[f'{p}.conv_2.0.weight']), P[f'{p}.conv_2.0.bias'],
-                       TAPS_1x3, 64, To=T, Fo=Fo, sf=2)
+    R5, st5 = conv_fwd(a2, B, T, Fq, 64, 0, 64,
+                       _w(P, (f'{p}.conv_2.0.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv_2.0.weight'])),
+                       P[f'{p}.conv_2.0.bias'], TAPS_1x3, 64, To=T, Fo=Fo, sf=2)
     out = torch.empty(B, T, Fo, 64, device=xin.device, dtype=torch.float32)
     ctx['mr5'] = inorm_prelu_fwd(R5, st5, P[f'{p}.conv_2.1.weight'], P[f'{p}.conv_2.1.bias'],
                                  P[f'{p}.conv_2.2.weight'], out, 64, 0)
@@ -219,7 +282,8 @@ def encoder_bwd(P, G, ctx, dout, B, T, Fq):
                           P[f'{p}.conv_2.2.weight'], dout, 64, 0, G[f'{p}.conv_2.1.weight'],
                           G[f'{p}.conv_2.1.bias'], G[f'{p}.conv_2.2.weight'])
     da2 = conv_bwd(ctx['a2'], B, T, Fq, 64, 0, 64, P[f'{p}.conv_2.0.weight'], TAPS_1x3, dR5, T, Fo,
-                   G[f'{p}.conv_2.0.weight'], G[f'{p}.conv_2.0.bias'], sf=2)
+                   G[f'{p}.conv_2.0.weight'], G[f'{p}.conv_2.0.bias'], sf=2,
+                   wd=_w(P, (f'{p}.conv_2.0.weight', 'dgrad'), lambda: None))
     dskip = dense_block_bwd(P, G, f'{p}.dilated_dense', ctx['dense'], da2, B, T, Fq)
     dR0 = inorm_prelu_bwd(ctx['R0'], ctx['mr0'], P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
                           P[f'{p}.conv_1.2.weight'], dskip, 256, 0, G[f'{p}.conv_1.1.weight'],
@@ -244,8 +308,10 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0):
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
     if GM.LINEAR_PRECISION in (1, 2) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0:
         # one fused kernel: the hidden activations are written once (for the backward) and never re-read here
-        y, z = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1, P[f'{p}.fn.fn.net.0.bias'], W2,
-                         P[f'{p}.fn.fn.net.3.bias'], drop, seed_h, seed_o, 0.5)
+        y, z = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
+                         _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1), P[f'{p}.fn.fn.net.0.bias'],
+                         _w(P, (f'{p}.fn.fn.net.3.weight', 'lin'), lambda: W2), P[f'{p}.fn.fn.net.3.bias'], drop, seed_h,
+                         seed_o, 0.5, hid=W1.shape[0])
         return y, (x, st, z, drop, seed_h, seed_o)
     z = torch.empty(M, 256, device=x.device, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, epilogue=L.EPI_BIAS), x, P[f'{p}.fn.fn.net.0.weight'], z,
@@ -268,7 +334,8 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z);  dh = dz @ W1
     if fused:
         # ... and the LayerNorm backward on the rows still in registers: dx = dy (+ dR2) + LNbwd(dz @ W1)
-        dz, dx = GM.ff_bwd_dgrad(dy, z, _T(W2) * 0.5, _T(W1), drop, seed_h, seed_o,
+        dz, dx = GM.ff_bwd_dgrad(dy, z, _w(P, (f'{p}.fn.fn.net.3.weight', 'T0.5'), lambda: _T(W2) * 0.5),
+                                 _w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: _T(W1)), drop, seed_h, seed_o,
                                  ln=(x, st, P[f'{p}.fn.norm.weight'], dR2, G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias']))
     else:
         dz = torch.empty(M, 256, device=x.device, dtype=torch.float32)
@@ -305,7 +372,8 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     y1, ctx['ff1'] = _ff_fwd(P, f'{p}.ff1', x, M, pf, site_seed(seed, 0), site_seed(seed, 1))
     # attention
     st2 = O.row_stats(y1, M)
-    Wqkv = torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0).contiguous()
+    Wqkv = _w(P, (f'{p}.attn.fn', 'qkv'),
+              lambda: torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0).contiguous())
     qkv = torch.empty(M, 192, device=x.device, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, Wqkv, qkv, rowstats=st2,
                 ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
@@ -322,7 +390,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     st3 = O.row_stats(y2, M)
     u = torch.empty(M, 128, device=x.device, dtype=torch.float32)
     zc = torch.empty(M, 256, device=x.device, dtype=torch.float32)
-    Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
+    Wpw1 = _w(P, (f'{p}.conv.net.2.weight', 'lin'), lambda: P[f'{p}.conv.net.2.weight'].view(256, 64))
     GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=256), y2,
                 Wpw1, u, bias=P[f'{p}.conv.net.2.bias'], AUX=zc, rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                 pb=P[f'{p}.conv.net.0.bias'])
@@ -367,7 +435,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     y2, st3, zc, u, h, mr, sc, sh, count = ctx['conv']
     Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
     dact = torch.empty(M, 128, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 128), dy3, _T(Wpw2), dact)
+    GM.gemm_tap(GM.linear_desc(M, 64, 128), dy3, _w(P, (f'{p}.conv.net.7.weight', 'T'), lambda: _T(Wpw2)), dact)
     GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH), h, dy3,
                       G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
     dh = torch.empty(M, 128, device=dev, dtype=torch.float32)
@@ -384,7 +452,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     dzc = O.glu_bwd(zc, du, M, 128)
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
     dl3 = torch.empty(M, 64, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 256, 64), dzc, _T(Wpw1), dl3)
+    GM.gemm_tap(GM.linear_desc(M, 256, 64), dzc, _w(P, (f'{p}.conv.net.2.weight', 'T'), lambda: _T(Wpw1)), dl3)
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), y2, dzc, G[f'{p}.conv.net.2.weight'].view(256, 64),
                       G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                       pb=P[f'{p}.conv.net.0.bias'])
@@ -397,13 +465,13 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     Wo = P[f'{p}.attn.fn.to_out.weight']
     do = torch.empty(M, 64, device=dev, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa),
-                dy2, _T(Wo), do)
+                dy2, _w(P, (f'{p}.attn.fn.to_out.weight', 'T'), lambda: _T(Wo)), do)
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa), o, dy2,
                       G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25)
     dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, _T(Wqkv), dl2)
+    GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv)), dl2)
     dWqkv = torch.zeros(192, 64, device=dev, dtype=torch.float32)
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, dqkv, dWqkv, None, rowstats=st2,
                       ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
@@ -432,11 +500,12 @@ def mask_decoder_fwd(P, x, B, T, Fq):
     p = 'mask_decoder'
     ctx = {}
     d4, ctx['dense'] = _decoder_head_fwd(P, p, x, B, T, Fq)
-    S, _ = conv_fwd(d4, B, T, Fq, 64, 0, 64, pack_w(P[f'{p}.sub_pixel.conv.weight']), P[f'{p}.sub_pixel.conv.bias'],
-                    TAPS_1x3, 128, shuffle2=True, want_stats=False)                       # [B,T,2Fq,64]
+    S, _ = conv_fwd(d4, B, T, Fq, 64, 0, 64,
+                    _w(P, (f'{p}.sub_pixel.conv.weight', 'fwd'), lambda: pack_w(P[f'{p}.sub_pixel.conv.weight'])),
+                    P[f'{p}.sub_pixel.conv.bias'], TAPS_1x3, 128, shuffle2=True, want_stats=False)          # [B,T,2Fq,64]
     F2 = 2 * Fq
     Fo = F2 - 1
-    w1 = pack_w(pad_rows(P[f'{p}.conv_1.weight'], 4))
+    w1 = _w(P, (f'{p}.conv_1.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv_1.weight'], 4)))
     b1 = pad_rows(P[f'{p}.conv_1.bias'], 4)
     r, st = conv_fwd(S, B, T, F2, 64, 0, 64, w1, b1, TAPS_1x2, 4, To=T, Fo=Fo)            # [B,T,Fo,4], channel 0
     g4, be4, a4 = pad_rows(P[f'{p}.norm.weight'], 4), pad_rows(P[f'{p}.norm.bias'], 4), pad_rows(P[f'{p}.prelu.weight'], 4)
@@ -467,7 +536,8 @@ def mask_decoder_bwd(P, G, ctx, dmask, B, T, Fq):
     G[f'{p}.prelu.weight'] += da4[:1]
     dw1 = torch.zeros(4, 64, 1, 2, device=dev)
     dbias1 = torch.zeros(4, device=dev)
-    dS = conv_bwd(ctx['S'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv_1.weight'], 4), TAPS_1x2, dr, T, Fo, dw1, dbias1)
+    dS = conv_bwd(ctx['S'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv_1.weight'], 4), TAPS_1x2, dr, T, Fo, dw1, dbias1,
+                  wd=_w(P, (f'{p}.conv_1.weight', 'dgrad'), lambda: None))
     G[f'{p}.conv_1.weight'] += dw1[:1]
     G[f'{p}.conv_1.bias'] += dbias1[:1]
     dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq)
@@ -481,20 +551,22 @@ def _subpixel_bwd(P, G, p, x, dS, B, T, Fq):
     dconv = dS.view(B, T, Fq, 128)                      # [.., f, (r, c)] : memory order is already (f, r, c)
     w = P[f'{p}.conv.weight']
     dw = G[f'{p}.conv.weight']
-    return conv_bwd(x, B, T, Fq, 64, 0, 64, w, TAPS_1x3, dconv, T, Fq, dw, G[f'{p}.conv.bias'])
+    return conv_bwd(x, B, T, Fq, 64, 0, 64, w, TAPS_1x3, dconv, T, Fq, dw, G[f'{p}.conv.bias'],
+                    wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None))
 
 
 def complex_decoder_fwd(P, x, B, T, Fq):
     p = 'complex_decoder'
     ctx = {}
     d4, ctx['dense'] = _decoder_head_fwd(P, p, x, B, T, Fq)
-    S, st = conv_fwd(d4, B, T, Fq, 64, 0, 64, pack_w(P[f'{p}.sub_pixel.conv.weight']), P[f'{p}.sub_pixel.conv.bias'],
-                     TAPS_1x3, 128, shuffle2=True, want_stats=True)
+    S, st = conv_fwd(d4, B, T, Fq, 64, 0, 64,
+                     _w(P, (f'{p}.sub_pixel.conv.weight', 'fwd'), lambda: pack_w(P[f'{p}.sub_pixel.conv.weight'])),
+                     P[f'{p}.sub_pixel.conv.bias'], TAPS_1x3, 128, shuffle2=True, want_stats=True)
     F2 = 2 * Fq
     Fo = F2 - 1
     a = torch.empty_like(S)
     mr = inorm_prelu_fwd(S, st, P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], a, 64, 0)
-    wc = pack_w(pad_rows(P[f'{p}.conv.weight'], 4))
+    wc = _w(P, (f'{p}.conv.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv.weight'], 4)))
     bc = pad_rows(P[f'{p}.conv.bias'], 4)
     cplx, _ = conv_fwd(a, B, T, F2, 64, 0, 64, wc, bc, TAPS_1x2, 4, To=T, Fo=Fo, want_stats=False)
     ctx.update(d4=d4, S=S, mr=mr, a=a, Fo=Fo)
@@ -507,7 +579,8 @@ def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
     dev = dcplx.device
     dwc = torch.zeros(4, 64, 1, 2, device=dev)
     dbc = torch.zeros(4, device=dev)
-    da = conv_bwd(ctx['a'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv.weight'], 4), TAPS_1x2, dcplx, T, Fo, dwc, dbc)
+    da = conv_bwd(ctx['a'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv.weight'], 4), TAPS_1x2, dcplx, T, Fo, dwc, dbc,
+                  wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None))
     G[f'{p}.conv.weight'] += dwc[:2]
     G[f'{p}.conv.bias'] += dbc[:2]
     dS = inorm_prelu_bwd(ctx['S'], ctx['mr'], P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], da,

@@ -1,0 +1,94 @@
+"""Per-step weight preparation in ONE launch (csrc/se_gemm.hip: weight_prep_kernel).
+
+Every GEMM of the generator reads its weight as an [N][ld] matrix in a layout PyTorch does not store: conv weights tap-major
+with the DilatedDenseNet slab order undone (models/generator.py:31), transposes for the input gradients, cat(to_q, to_kv),
+Scale(0.5)'s factor folded in, and -- for the six-product split-bf16 kernels -- the exact hi / mid / lo bf16 planes.  Round 1
+did this with ~170 small launches per step (repack kernels, .t().contiguous(), cat, mul) and re-split every weight tile in
+every workgroup of every GEMM.  A WeightPlan records each prepared matrix once (parameter and arena addresses are stable),
+uploads the item table, and `run()` refreshes all of them with a single kernel launch per forward.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class WItem(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('No', C.c_int), ('Nt', C.c_int), ('Ni', C.c_int),
+                ('Ni_dst', C.c_int), ('so', C.c_long), ('stt', C.c_long), ('si', C.c_long), ('rev', C.c_int),
+                ('dst_ld', C.c_int), ('o_off', C.c_int), ('c_off', C.c_int), ('scale', C.c_float),
+                ('plane_stride', C.c_long)]
+
+
+class WeightPlan:
+    def __init__(self, device):
+        self.device = device
+        self.out = {}          # key -> prepared tensor: fp32 [rows, ld] or bf16 planes [3, rows, ld]
+        self._items = []
+        self._srcs = []        # keeps the source tensors alive / lets `stale()` detect re-allocated parameters
+        self._table = None
+        self._max = 1
+
+    def add(self, key, src, No, Nt, Ni, so, stt, si, rev=0, scale=1.0, planes=False, rows=None, ld=None, o_off=0, c_off=0,
+            Ni_dst=None):
+        """dst[o_off + o][c_off + t * Ni_dst + i] = scale * src[o' * so + t * stt + i' * si]; the first `add` of a key
+        allocates its (zero-filled, so padding stays zero) destination of `rows` x `ld`."""
+        if not src.is_cuda or src.dtype != torch.float32 or not src.is_contiguous():
+            raise L.SeHipError(f'weight plan: {key}: parameters must be contiguous fp32 CUDA tensors')
+        Ni_dst = Ni_dst or Ni
+        if key not in self.out:
+            rows = rows or (o_off + No)
+            ld = ld or (c_off + Nt * Ni_dst)
+            if planes:
+                if ld % 8:
+                    raise L.SeHipError(f'weight plan: {key}: plane rows must be multiples of 8 elements (ld={ld})')
+                self.out[key] = torch.zeros(3, rows, ld, device=self.device, dtype=torch.bfloat16)
+            else:
+                self.out[key] = torch.zeros(rows, ld, device=self.device, dtype=torch.float32)
+        dst = self.out[key]
+        is_pl = dst.dtype == torch.bfloat16
+        drows, dld = dst.shape[-2], dst.shape[-1]
+        if o_off + No > drows or c_off + (Nt - 1) * Ni_dst + Ni > dld:
+            raise L.SeHipError(f'weight plan: {key}: item exceeds its destination')
+        self._items.append(WItem(src.data_ptr(), dst.data_ptr(), No, Nt, Ni, Ni_dst, so, stt, si, rev, dld, o_off, c_off,
+                                 float(scale), drows * dld if is_pl else 0))
+        self._srcs.append((src, src.data_ptr()))
+        self._max = max(self._max, No * Nt * Ni)
+        self._table = None
+        return dst
+
+    def stale(self):
+        """True when a source parameter has been re-allocated since the plan was built (.to(), .data = ...)."""
+        return any(t.data_ptr() != p for t, p in self._srcs)
+
+    def run(self):
+        if not self._items:
+            return
+        if self._table is None:
+            arr = (WItem * len(self._items))(*self._items)
+            self._table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        L.call('se_weight_prep', L.ptr(self._table), C.c_int(len(self._items)), C.c_long(self._max), L.stream())
+
+    # ---- recipes -------------------------------------------------------------------------------------------------
+    def conv_fwd(self, key, w, rev=False, C_pad=None, N_pad=None, planes=False):
+        """PyTorch conv weight [N, Cin, kh, kw] -> [N (N_pad)][tap][Cin (C_pad)]."""
+        N, Cin, kh, kw = w.shape
+        Cd = C_pad or Cin
+        return self.add(key, w, N, kh * kw, Cin, Cin * kh * kw, 1, kh * kw, rev=1 if rev else 0, planes=planes,
+                        rows=N_pad or N, ld=kh * kw * Cd, Ni_dst=Cd)
+
+    def conv_dgrad(self, key, w, rev=False, C_pad=None, N_pad=None, planes=False):
+        """[N, Cin, kh, kw] -> [Cin (C_pad)][tap][N (N_pad)] (the caller negates the taps)."""
+        N, Cin, kh, kw = w.shape
+        Nd = N_pad or N
+        return self.add(key, w, Cin, kh * kw, N, kh * kw, 1, Cin * kh * kw, rev=2 if rev else 0, planes=planes,
+                        rows=C_pad or Cin, ld=kh * kw * Nd, Ni_dst=Nd)
+
+    def linear(self, key, w, planes=False, scale=1.0, o_off=0, rows=None):
+        N, K = w.shape[0], w.numel() // w.shape[0]
+        return self.add(key, w, N, 1, K, K, 1, 1, planes=planes, scale=scale, o_off=o_off, rows=rows, ld=K)
+
+    def linear_T(self, key, w, planes=False, scale=1.0, c_off=0, ld=None):
+        N, K = w.shape[0], w.numel() // w.shape[0]
+        return self.add(key, w, K, 1, N, 1, 1, K, planes=planes, scale=scale, c_off=c_off, ld=ld or N, rows=K)

@@ -6,6 +6,11 @@ Cin = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 skip = torch.randn(B, T, Fq, 256, device='cuda')
 w = torch.randn(64, Cin, 2, 3, device='cuda') * 0.02
 wp = GM.pack_conv_fwd(w)
+if len(sys.argv) > 3 and sys.argv[3] == 'planes':      # pre-split weights (weights.WeightPlan)
+    from speech_enhancement_amd.weights import WeightPlan
+    plan = WeightPlan(torch.device('cuda'))
+    wp = plan.conv_fwd('w', w, planes=True)
+    plan.run()
 y = torch.empty(B, T, Fq, 64, device='cuda')
 prec = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 d = GM.make_desc(B, T, Fq, T, Fq, LY.dense_taps(3), Cin, 256, 64, 64, precision=prec)
