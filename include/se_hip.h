@@ -109,8 +109,9 @@ int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const flo
                     const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
                     void* stream);
 
-/* weight gradient: dW[n][tap*C + c] += sum_m dY[m][n] * pro(A[src(m,tap)][c]);  dW must be zeroed by
- * the caller (fp32 atomics across row chunks).  If dbias != NULL also dbias[n] += sum_m dY[m][n].
+/* weight gradient: dW[n][tap*C + c] += alpha * sum_m dY[m][n] * pro(A[src(m,tap)][c]) (alpha = d->alpha: the factor of a
+ * Scale(0.5, .) wrapper goes straight into the gradient buffer);  dW must be initialised by the caller (fp32 atomics across
+ * row chunks).  If dbias != NULL also dbias[n] += alpha * sum_m dY[m][n].
  * Replaces the weight-gradient kernels of the same ATen ops as se_gemm_tap. */
 int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW, float* dbias,
                       const float* rowstats, const float* pro_scale, const float* pro_shift,

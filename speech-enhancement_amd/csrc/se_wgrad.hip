@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[r]);
+    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], d.alpha * acc[r]);
   }
-  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], bsum);
+  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], d.alpha * bsum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,10 +272,10 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[s3][r]);
+      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], d.alpha * acc[s3][r]);
     }
   }
-  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], bsum);
+  if (do_bias && tid < 64 && nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], d.alpha * bsum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[r]);
+    if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], d.alpha * acc[r]);
   }
   if (do_bias) {       // column sums of dY: fold the 16 row groups through LDS (the tiles are free now)
     float* red = reinterpret_cast<float*>(Yt);
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
       float s_ = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_ += red[r * 64 + tid];
-      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], s_);
+      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], d.alpha * s_);
     }
   }
 }
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], acc[s3][r]);
+      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], d.alpha * acc[s3][r]);
     }
   }
   if (do_bias) {
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
       float s_ = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s_ += red[r * 64 + tid];
-      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], s_);
+      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], d.alpha * s_);
     }
   }
 }

@@ -156,7 +156,7 @@ class _DConvStackFn(torch.autograd.Function):
             wp = LY.pack_w(Ws[i].contiguous(), C_pad=Cin)
             d = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2, epilogue=L.EPI_STATS)
             R = torch.empty(B, To, Fo, N, device=x.device, dtype=torch.float32)
-            stats = torch.zeros(B, N, 2, device=x.device, dtype=torch.float64)
+            stats = LY.O.zeros(B, N, 2, device=x.device, dtype=torch.float64)
             LY.GM.gemm_tap(d, x, wp, R, stats=stats)
             a = torch.empty_like(R)
             mr = LY.inorm_prelu_fwd(R, stats, gs[i], bs[i], sl[i], a, N, 0)
@@ -181,7 +181,7 @@ class _DConvStackFn(torch.autograd.Function):
             need_dx = i > 0 or ctx.needs_input_grad[0]
             if ctx.needs_input_grad[1 + i]:
                 fd = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2)
-                dwp = torch.zeros(N, 16 * Cin, device=dR.device, dtype=torch.float32)
+                dwp = LY.O.zeros(N, 16 * Cin, device=dR.device)
                 LY.GM.gemm_tap_wgrad(fd, x, dR, dwp, None)
                 LY._unpack_w(dwp, dW[i], Cin, False)
             if need_dx:

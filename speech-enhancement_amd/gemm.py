@@ -70,8 +70,11 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     return Y
 
 
-def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, chunks=None, explicit_precision=False):
+def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, chunks=None, explicit_precision=False,
+                   scale=1.0):
+    """dW (+ dbias) += scale * gradient: accumulates straight into the caller's (gradient) buffers."""
     L.check_cuda(A, dY, dW, dbias, rowstats, ps, pb)
+    d.alpha = scale
     if chunks is None:
         M = d.B * d.To * d.Fo
         nblk = d.ntap * ((d.C + 63) // 64) * ((d.N + 63) // 64)

@@ -64,7 +64,7 @@ def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None
     d = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, No, a_off=a_off, sf=sf, epilogue=ep,
                      precision=CONV_PRECISION)
     R = torch.empty(B, To, Fo * (2 if shuffle2 else 1), No, device=x.device, dtype=torch.float32)
-    stats = torch.zeros(B, No, 2, device=x.device, dtype=torch.float64) if want_stats else None
+    stats = O.zeros(B, No, 2, device=x.device, dtype=torch.float64) if want_stats else None
     GM.gemm_tap(d, x, wp, R, bias=bias, stats=stats)
     return R, stats
 
@@ -94,7 +94,7 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     N = dR.shape[-1]
     ntap = len(taps)
     fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf, precision=WGRAD_PRECISION[0])
-    dwp = torch.zeros(N, ntap * C_in, device=dR.device, dtype=torch.float32)
+    dwp = O.zeros(N, ntap * C_in, device=dR.device)
     GM.gemm_tap_wgrad(fd, x, dR, dwp, dbias)
     _unpack_w(dwp, dw, C_in, rev)
     if not need_dx:
@@ -343,13 +343,9 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
                                    epilogue=L.EPI_SWISH_GRAD | (L.EPI_DROP if dr else 0), ldx=256, pro_seed=seed_o,
                                    epi_seed=seed_h, drop_p=drop), dy, _T(W2) * 0.5, dz, AUX=z)
     # dW2 = 0.5 * (mask_o * dy)^T (mask_h * swish(z));  db2 = 0.5 * sum mask_o * dy
-    dW2 = torch.zeros(64, 256, device=x.device, dtype=torch.float32)
-    db2 = torch.zeros(64, device=x.device, dtype=torch.float32)
     GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH,
                                      epilogue=L.EPI_DROP if dr else 0, pro_seed=seed_h, epi_seed=seed_o, drop_p=drop),
-                      z, dy, dW2, db2)
-    G[f'{p}.fn.fn.net.3.weight'].add_(dW2, alpha=0.5)
-    G[f'{p}.fn.fn.net.3.bias'].add_(db2, alpha=0.5)
+                      z, dy, G[f'{p}.fn.fn.net.3.weight'], G[f'{p}.fn.fn.net.3.bias'], scale=0.5)
     # dW1 = dz^T LN(x);  db1 = sum dz
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, G[f'{p}.fn.fn.net.0.weight'],
                       G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
@@ -398,7 +394,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     g_bn, b_bn = P[f'{p}.conv.net.5.weight'], P[f'{p}.conv.net.5.bias']
     count = float(M * dp.world)
     if train:
-        bnstats = torch.zeros(1, 128, 2, device=x.device, dtype=torch.float64)
+        bnstats = O.zeros(1, 128, 2, device=x.device, dtype=torch.float64)
         h = O.dwconv31(u, Wdw, P[f'{p}.conv.net.4.conv.bias'], geom, stats=bnstats)
         dp.allreduce(bnstats)
         rm = buffers[f'{p}.conv.net.5.running_mean'] if buffers is not None else None
@@ -472,11 +468,17 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25)
     dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv)), dl2)
-    dWqkv = torch.zeros(192, 64, device=dev, dtype=torch.float32)
+    gq, gkv = G[f'{p}.attn.fn.to_q.weight'], G[f'{p}.attn.fn.to_kv.weight']
+    # to_q / to_kv are neighbours in the flat gradient buffer of the optimizers: the [192, 64] gradient of the fused projection
+    # then accumulates in place; otherwise through a scratch matrix
+    adjacent = gq.is_contiguous() and gkv.is_contiguous() and gq.data_ptr() + gq.numel() * 4 == gkv.data_ptr()
+    dWqkv = torch.as_strided(gq, (192, 64), (64, 1)) if adjacent and gq.untyped_storage().nbytes() - gq.storage_offset() * 4 >= 192 * 64 * 4 \
+        else O.zeros(192, 64, device=dev)
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, dqkv, dWqkv, None, rowstats=st2,
                       ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
-    G[f'{p}.attn.fn.to_q.weight'] += dWqkv[:64]
-    G[f'{p}.attn.fn.to_kv.weight'] += dWqkv[64:]
+    if dWqkv.data_ptr() != gq.data_ptr():
+        gq += dWqkv[:64]
+        gkv += dWqkv[64:]
     dy1 = O.layernorm_bwd(y1, st2, P[f'{p}.attn.norm.weight'], dl2, G[f'{p}.attn.norm.weight'],
                           G[f'{p}.attn.norm.bias'], dR=dy2)
     ctx['attn'] = None
@@ -523,19 +525,19 @@ def mask_decoder_bwd(P, G, ctx, dmask, B, T, Fq):
     dev = dmask.device
     n = B * T * Fo
     duact = torch.empty(B, T, Fo, 4, device=dev, dtype=torch.float32)
-    dwb = torch.zeros(2, device=dev, dtype=torch.float64)
+    dwb = O.zeros(2, device=dev, dtype=torch.float64)
     O.mask_tail_bwd(ctx['uact'], 4, ctx['wb'], P[f'{p}.prelu_out.weight'], dmask, duact, dwb,
                     G[f'{p}.prelu_out.weight'], n, Fo)
     G[f'{p}.final_conv.weight'] += dwb[0].float().view(1, 1, 1, 1)
     G[f'{p}.final_conv.bias'] += dwb[1].float().view(1)
     g4, be4, a4 = ctx['pads']
-    dg4, db4, da4 = (torch.zeros(4, device=dev) for _ in range(3))
+    dg4, db4, da4 = (O.zeros(4, device=dev) for _ in range(3))
     dr = inorm_prelu_bwd(ctx['r'], ctx['mr'], g4, be4, a4, duact, 4, 0, dg4, db4, da4)
     G[f'{p}.norm.weight'] += dg4[:1]
     G[f'{p}.norm.bias'] += db4[:1]
     G[f'{p}.prelu.weight'] += da4[:1]
-    dw1 = torch.zeros(4, 64, 1, 2, device=dev)
-    dbias1 = torch.zeros(4, device=dev)
+    dw1 = O.zeros(4, 64, 1, 2, device=dev)
+    dbias1 = O.zeros(4, device=dev)
     dS = conv_bwd(ctx['S'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv_1.weight'], 4), TAPS_1x2, dr, T, Fo, dw1, dbias1,
                   wd=_w(P, (f'{p}.conv_1.weight', 'dgrad'), lambda: None))
     G[f'{p}.conv_1.weight'] += dw1[:1]
@@ -577,8 +579,8 @@ def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
     p = 'complex_decoder'
     Fo, F2 = ctx['Fo'], 2 * Fq
     dev = dcplx.device
-    dwc = torch.zeros(4, 64, 1, 2, device=dev)
-    dbc = torch.zeros(4, device=dev)
+    dwc = O.zeros(4, 64, 1, 2, device=dev)
+    dbc = O.zeros(4, device=dev)
     da = conv_bwd(ctx['a'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv.weight'], 4), TAPS_1x2, dcplx, T, Fo, dwc, dbc,
                   wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None))
     G[f'{p}.conv.weight'] += dwc[:2]

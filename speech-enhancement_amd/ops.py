@@ -1,6 +1,7 @@
 """Thin Python launchers for the non-GEMM kernels of libse_hip.so (csrc/se_norms.hip, se_dwconv.hip,
 se_elem.hip).  Every function takes/returns CUDA tensors and raises SeHipError on failure."""
 import ctypes as C
+import os as _os
 
 import torch
 
@@ -15,8 +16,54 @@ def _new(*shape, like, dtype=f32):
     return torch.empty(*shape, device=like.device, dtype=dtype)
 
 
+class ZeroArena:
+    """Step-scoped zero-initialised scratch.  A train step needs ~250 small zero-filled buffers (statistics accumulators,
+    packed weight-gradient tiles, atomically accumulated sums): one fill launch each.  Inside `with ARENA.step(device)` they
+    are carved out of one buffer that a single fill clears at the start of the step; outside a step (tests, inference) every
+    request is a plain torch.zeros.  A buffer handed out here must not outlive the step."""
+
+    def __init__(self):
+        self.buf, self.off, self.high, self.active, self.missed = None, 0, 0, False, 0
+
+    def begin(self, device, min_bytes=16 << 20):
+        if _os.environ.get('SE_NO_ZERO_ARENA') == '1':     # A/B switch: one torch.zeros per request
+            return
+        need = max(min_bytes, 2 * (self.high + self.missed))
+        if self.buf is None or self.buf.device != device or self.buf.numel() < need:
+            self.buf = torch.zeros(need, device=device, dtype=torch.uint8)
+        else:
+            self.buf[:max(self.high, 256)].zero_()          # ONE fill for everything handed out last step
+        self.off, self.missed, self.active = 0, 0, True
+
+    def end(self):
+        self.high = max(self.high, self.off)
+        self.active = False
+
+    def take(self, shape, dtype, device):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        nbytes = n * torch.empty((), dtype=dtype).element_size()
+        if not self.active or self.buf.device != device or nbytes == 0:
+            return torch.zeros(*shape, device=device, dtype=dtype)
+        start = (self.off + 255) & ~255
+        if start + nbytes > self.buf.numel():
+            self.missed += nbytes + 256                      # grown at the next begin()
+            return torch.zeros(*shape, device=device, dtype=dtype)
+        self.off = start + nbytes
+        return self.buf[start:start + nbytes].view(dtype).view(*shape)
+
+
+ARENA = ZeroArena()
+
+
+def zeros(*shape, device, dtype=f32):
+    """zero-filled scratch that does not outlive the current train step (see ZeroArena)."""
+    return ARENA.take(shape, dtype, torch.device(device) if not isinstance(device, torch.device) else device)
+
+
 def _zeros(*shape, like, dtype=f32):
-    return torch.zeros(*shape, device=like.device, dtype=dtype)
+    return ARENA.take(shape, dtype, like.device)
 
 
 # ---------------------------------------------------------------- LayerNorm(64)
