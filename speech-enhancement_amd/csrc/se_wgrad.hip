@@ -645,6 +645,140 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-GEMM (nn.Linear / 1x1 conv) weight gradient with the WHOLE [N x C] gradient in one workgroup (N, C <= 256, N * C <= 16 K:
+// every token-wise layer of the Conformer).  wgrad_kernel gives each 64 x 64 block of dW its own workgroup, so the 4 sibling
+// workgroups of a 256 x 64 gradient each re-load the shared operand's rows and re-apply its prologue (LayerNorm, BatchNorm-affine
+// + Swish, Swish + dropout hash), and a wave issues two LDS reads per MFMA for its 32 x 32 tile.  Here a wave owns
+// (TN * 32) x (TC * 32) outputs (four 32 x 32 accumulators for the 256 x 64 / 64 x 256 shapes: one LDS read per MFMA), the 4
+// waves tile [N x C] as WN x (4 / WN), every row of both operands is loaded, prologued and staged exactly once per launch, and a
+// step is 32 rows = 64 MFMAs per wave between barriers.  fp32 MFMA (32x32x2), fp32 atomics across row chunks.
+template <int PRO, int WN, int TN, int TC>
+__global__ __launch_bounds__(256, 3) void wgrad_lin_kernel(WgradArgs g) {
+  constexpr int WC = 4 / WN, NT = WN * TN * 32, CT = WC * TC * 32, MR = 32;
+  constexpr int SYL = NT + 4, SXL = CT + 4;                    // LDS row strides (floats): 16-B aligned rows
+  constexpr int QY = NT / 4, RY = 256 / QY, NY = MR / RY;       // dY tile: float4 columns, rows per pass, passes
+  constexpr int QX = CT / 4, RX = 256 / QX, NX = MR / RX;
+  __shared__ __attribute__((aligned(16))) float Ys[MR * SYL];
+  __shared__ __attribute__((aligned(16))) float Xs[MR * SXL];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave / WC, wc = wave - wn * WC;
+  const long Mtot = (long)d.To * d.Fo;                           // row GEMM: B == 1 (host-checked)
+  const long mbeg = (long)blockIdx.x * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int qy = tid % QY, ry0 = tid / QY, qx = tid % QX, rx0 = tid / QX;
+  const int n_ld = qy * 4, c_ld = qx * 4;
+  const bool nok = n_ld < d.N, cok = c_ld < d.C;
+  const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
+  const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
+  const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
+
+  f32x16 acc[TN][TC];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TC; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;
+  float4 ry[NY], rx[NX];
+  float mean[NX] = {}, rstd[NX] = {};
+  bool xok[NX];
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const long mg = mbase + ry0 + i * RY;
+      const bool ok = mg < mend && nok;
+      ry[i] = ok ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dy_drop && ok) {
+        const float4 d4 = drop_scale4(d.epi_seed, (unsigned)(mg * d.N + n_ld), thr, inv_keep);
+        ry[i].x *= d4.x; ry[i].y *= d4.y; ry[i].z *= d4.z; ry[i].w *= d4.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const long mg = mbase + rx0 + i * RX;
+      xok[i] = mg < mend && cok;
+      rx[i] = xok[i] ? *reinterpret_cast<const float4*>(Ag + mg * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (PRO == SE_PRO_LN) {
+        const float2 mr = xok[i] ? *reinterpret_cast<const float2*>(g.rowstats + 2 * mg) : make_float2(0.f, 0.f);
+        mean[i] = mr.x;
+        rstd[i] = mr.y;
+      }
+    }
+  };
+  float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
+  load_pro_vec<PRO>(g.ps, g.pb, c_ld, cok, ps4, pb4);           // this thread's 4 channels never change
+  if (mbeg < mend) load_tiles(mbeg);
+  const int half = lane >> 5, l31 = lane & 31;
+  const float* yp = &Ys[half * 16 * SYL + wn * TN * 32 + l31];   // MFMA step s pairs tile rows {s, s + 16}
+  const float* xp = &Xs[half * 16 * SXL + wc * TC * 32 + l31];
+  const bool do_bias = g.dbias != nullptr;
+  for (long mb = mbeg; mb < mend; mb += MR) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      float4 v = rx[i];
+      if (PRO != SE_PRO_NONE && xok[i])
+        v = apply_pro<PRO>(v, c_ld, d.C, mean[i], rstd[i], ps4, pb4, (unsigned)(mb + rx0 + i * RX), d.pro_seed, thr, inv_keep);
+      *reinterpret_cast<float4*>(&Xs[(rx0 + i * RX) * SXL + qx * 4]) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NY; ++i) *reinterpret_cast<float4*>(&Ys[(ry0 + i * RY) * SYL + qy * 4]) = ry[i];
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+    if (wn * TN * 32 < d.N && wc * TC * 32 < d.C) {               // wave-uniform: a wave whose whole tile is padding idles
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        float av[TN], bv[TC];
+#pragma unroll
+        for (int a = 0; a < TN; ++a) av[a] = yp[s * SYL + a * 32];
+#pragma unroll
+        for (int b = 0; b < TC; ++b) bv[b] = xp[s * SXL + b * 32];
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (do_bias && tid < NT) {
+#pragma unroll
+      for (int r = 0; r < MR; ++r) bsum += Ys[r * SYL + tid];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TC; ++b) {
+      const int c = (wc * TC + b) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = (wn * TN + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + c], d.alpha * acc[a][b][r]);
+      }
+    }
+  if (do_bias && tid < NT && tid < d.N) atomicAdd(&g.dbias[tid], d.alpha * bsum);
+}
+
+template <int WN, int TN, int TC>
+static int launch_wgrad_lin(const se_gemm_desc* d, const WgradArgs& g, dim3 grid, hipStream_t s) {
+  const dim3 block(256);
+  switch (d->prologue) {
+    case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_lin_kernel<SE_PRO_NONE, WN, TN, TC>), grid, block, 0, s, g); break;
+    case SE_PRO_LN: hipLaunchKernelGGL((wgrad_lin_kernel<SE_PRO_LN, WN, TN, TC>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH: hipLaunchKernelGGL((wgrad_lin_kernel<SE_PRO_SWISH, WN, TN, TC>), grid, block, 0, s, g); break;
+    case SE_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wgrad_lin_kernel<SE_PRO_AFFINE_SWISH, WN, TN, TC>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH_DROP: hipLaunchKernelGGL((wgrad_lin_kernel<SE_PRO_SWISH_DROP, WN, TN, TC>), grid, block, 0, s, g); break;
+    case SE_PRO_DROP: hipLaunchKernelGGL((wgrad_lin_kernel<SE_PRO_DROP, WN, TN, TC>), grid, block, 0, s, g); break;
+    default: return se_fail("wgrad: unknown prologue %d", d->prologue);
+  }
+  return se_check_launch("se_gemm_tap_wgrad(lin)");
+}
+
 extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW,
                                  float* dbias, const float* rowstats, const float* pro_scale,
                                  const float* pro_shift, int chunks, void* stream) {
@@ -679,6 +813,27 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       else if (d->precision == 2) hipLaunchKernelGGL(wgrad3_bf16_kernel<3>, g3, block, 0, s, g);
       else hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
       return se_check_launch("se_gemm_tap_wgrad(conv3)");
+    }
+  }
+  // token-wise layers (row GEMM, fp32 MFMA, the whole gradient fits one workgroup): every operand row staged once per launch
+  const bool lin = d->ntap == 1 && d->B == 1 && !d->up && d->st == 1 && d->sf == 1 && d->dt[0] == 0 && d->df[0] == 0 &&
+                   d->Ti == d->To && d->Fi == d->Fo;
+  if (lin && (d->precision == 0 || d->precision == 2) && (d->C % 4) == 0 && (d->lda % 4) == 0 && (d->a_off % 4) == 0 &&
+      getenv("SE_WGRAD_NO_LIN") == nullptr) {
+    int shape = 0;                                               // 1: N <= 256, C <= 64; 2: N <= 64, C <= 256; 3: N <= 64, C <= 128
+    if (d->C <= 64 && d->N > 64 && d->N <= 256) shape = 1;
+    else if (d->N <= 64 && d->C > 128 && d->C <= 256) shape = 2;
+    else if (d->N <= 64 && d->C > 64 && d->C <= 128) shape = 3;
+    if (shape) {
+      // one resident round of 3 workgroups per CU (42 KB of LDS each), steps of 32 rows
+      long rl = (Mtot + 767) / 768;
+      rl = ((rl + 31) / 32) * 32;
+      const int nch = (int)((Mtot + rl - 1) / rl);
+      WgradArgs gl{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rl, nch};
+      const dim3 gg((unsigned)nch);
+      if (shape == 1) return launch_wgrad_lin<4, 2, 2>(d, gl, gg, s);
+      if (shape == 2) return launch_wgrad_lin<1, 2, 2>(d, gl, gg, s);
+      return launch_wgrad_lin<1, 2, 1>(d, gl, gg, s);
     }
   }
   // generic (non-triple) shapes: the six-product split kernel is VALU-bound by its own splits and measured slower than

@@ -361,3 +361,100 @@ def test_triple_tap_kernels_edge_shapes(G, B, T, Fq, dil, C):
             gemm.unpack_conv_wgrad(dwp, dw)
             assert relerr(dw, w64.grad) < tol, (prec, chunks, relerr(dw, w64.grad))
             assert relerr(db, dy.double().sum((0, 1, 2))) < 1e-5
+
+
+def test_weight_plan_matches_per_use_packing_and_planes_are_bit_identical(G):
+    """se_weight_prep (weights.WeightPlan): one launch reproduces the per-use repack / transpose / cat / scale helpers, and the
+    pre-split bf16 planes give BIT-IDENTICAL GEMM results to the fp32 weights (the 3-way split is exact and the kernels
+    evaluate the same six products): conv3 (dilated, skip stack), generic split kernel (strided), row-panel, fused
+    feed-forward forward and backward."""
+    gemm, L = G
+    from speech_enhancement_amd import layers as LY
+    from speech_enhancement_amd.weights import WeightPlan
+    dev = torch.device('cuda')
+    w = rnd(64, 192, 2, 3, seed=1, scale=0.05)              # DilatedDenseNet conv3 (newest-first slabs)
+    w2 = rnd(64, 64, 1, 3, seed=2, scale=0.1)               # strided (1, 3)
+    w1x2 = rnd(2, 64, 1, 2, seed=3, scale=0.1)              # 64 -> 2 channels, rows padded to 4
+    W1, W2 = rnd(256, 64, seed=4, scale=0.1), rnd(64, 256, seed=5, scale=0.05)
+    Wq, Wkv = rnd(64, 64, seed=6, scale=0.1), rnd(128, 64, seed=7, scale=0.1)
+    plan = WeightPlan(dev)
+    for planes in (False, True):
+        t = 'p' if planes else 'f'
+        plan.conv_fwd(('w', 'fwd', t), w, rev=True, planes=planes)
+        plan.conv_dgrad(('w', 'dgrad', t), w, rev=True, planes=planes)
+        plan.conv_fwd(('w2', 'fwd', t), w2, planes=planes)
+        plan.conv_fwd(('w1x2', 'fwd', t), w1x2, N_pad=4, planes=planes)
+        plan.linear(('W1', t), W1, planes=planes)
+        plan.linear(('W2', t), W2, planes=planes)
+        plan.linear_T(('W2', 'T0.5', t), W2, planes=planes, scale=0.5)
+        plan.linear_T(('W1', 'T', t), W1, planes=planes)
+        plan.linear(('qkv', t), Wq, planes=planes, rows=192)
+        plan.linear(('qkv', t), Wkv, planes=planes, o_off=64)
+        plan.linear_T(('qkvT', t), Wq, planes=planes, ld=192)
+        plan.linear_T(('qkvT', t), Wkv, planes=planes, c_off=64)
+    plan.conv_dgrad(('w1x2', 'dgrad'), w1x2, N_pad=4)
+    plan.run()
+    o = plan.out
+    # fp32 items == the per-use helpers
+    assert torch.equal(o[('w', 'fwd', 'f')], LY.pack_w(w, rev=True))
+    assert torch.equal(o[('w', 'dgrad', 'f')], gemm.pack_conv_dgrad(w, rev_slabs=True))
+    assert torch.equal(o[('w1x2', 'fwd', 'f')], LY.pack_w(LY.pad_rows(w1x2, 4)))
+    assert torch.equal(o[('w1x2', 'dgrad')], gemm.pack_conv_dgrad(LY.pad_rows(w1x2, 4)))
+    assert torch.equal(o[('W2', 'T0.5', 'f')], W2.t().contiguous() * 0.5)
+    assert torch.equal(o[('qkv', 'f')], torch.cat([Wq, Wkv], 0))
+    assert torch.equal(o[('qkvT', 'f')], torch.cat([Wq, Wkv], 0).t().contiguous())
+    # planes: hi + mid + lo == the fp32 value exactly
+    for key in (('w', 'fwd'), ('W2', 'T0.5'), ('qkvT',)):
+        pl = o[key + ('p',)].float()
+        assert torch.equal(pl[0] + pl[1] + pl[2], o[key + ('f',)])
+    # GEMMs: planes vs fp32 weights, bit-identical
+    B, T, Fq = 2, 5, 67
+    skip = rnd(B, T, Fq, 256, seed=10)
+    def run(W, d, A, N, **kw):
+        y = torch.empty(A.shape[:-1] + (N,), device='cuda')
+        gemm.gemm_tap(d, A, W, y, **kw)
+        return y
+    d = lambda: gemm.make_desc(B, T, Fq, T, Fq, LY.dense_taps(2), 192, 256, 64, 64, precision=2)
+    assert torch.equal(run(o[('w', 'fwd', 'p')], d(), skip, 64), run(o[('w', 'fwd', 'f')], d(), skip, 64))
+    Fo = (Fq + 2 - 3) // 2 + 1
+    a2 = rnd(B, T, Fq, 64, seed=11)
+    ds = lambda: gemm.make_desc(B, T, Fo, T, Fq, LY.TAPS_1x3, 64, 64, 64, 64, sf=2, precision=2)
+    ys = [torch.empty(B, T, Fo, 64, device='cuda') for _ in range(2)]
+    gemm.gemm_tap(ds(), a2, o[('w2', 'fwd', 'p')], ys[0])
+    gemm.gemm_tap(ds(), a2, o[('w2', 'fwd', 'f')], ys[1])
+    assert torch.equal(ys[0], ys[1])
+    M = 1000
+    x = rnd(M, 64, seed=12)
+    from speech_enhancement_amd import ops as O
+    st = O.row_stats(x, M)
+    gam, bet = rnd(64, seed=13) * 0.1 + 1, rnd(64, seed=14) * 0.1
+    dq = lambda: gemm.linear_desc(M, 64, 192, prologue=L.PRO_LN, precision=2)
+    assert torch.equal(run(o[('qkv', 'p')], dq(), x, 192, rowstats=st, ps=gam, pb=bet),
+                       run(o[('qkv', 'f')], dq(), x, 192, rowstats=st, ps=gam, pb=bet))
+    dqk = rnd(M, 192, seed=15)
+    dt = lambda: gemm.linear_desc(M, 192, 64, precision=2)
+    assert torch.equal(run(o[('qkvT', 'p')], dt(), dqk, 64), run(o[('qkvT', 'f')], dt(), dqk, 64))
+    b1, b2 = rnd(256, seed=16) * 0.1, rnd(64, seed=17) * 0.1
+    yp, hp = gemm.ff_fwd(x, st, gam, bet, o[('W1', 'p')], b1, o[('W2', 'p')], b2, 0.2, 11, 12, 0.5, precision=2, hid=256)
+    yf, hf = gemm.ff_fwd(x, st, gam, bet, o[('W1', 'f')], b1, o[('W2', 'f')], b2, 0.2, 11, 12, 0.5, precision=2)
+    assert torch.equal(yp, yf) and torch.equal(hp, hf)
+    dy = rnd(M, 64, seed=18)
+    zp, lp = gemm.ff_bwd_dgrad(dy, hf, o[('W2', 'T0.5', 'p')], o[('W1', 'T', 'p')], 0.2, 11, 12, precision=2)
+    zf, lf = gemm.ff_bwd_dgrad(dy, hf, o[('W2', 'T0.5', 'f')], o[('W1', 'T', 'f')], 0.2, 11, 12, precision=2)
+    assert torch.equal(zp, zf) and torch.equal(lp, lf)
+    # pre-split weights are refused where no six-product kernel would read them
+    with pytest.raises(L.SeHipError):
+        gemm.gemm_tap(gemm.linear_desc(M, 64, 192, prologue=L.PRO_LN, precision=0), x, o[('qkv', 'p')],
+                      torch.empty(M, 192, device='cuda'), rowstats=st, ps=gam, pb=bet)
+
+
+def test_wgrad_scale_accumulates_in_place(G):
+    """se_gemm_tap_wgrad adds alpha * gradient into the caller's buffer (Scale(0.5) feed-forward weight gradient)."""
+    gemm, L = G
+    M = 900
+    a, dy = rnd(M, 256, seed=1), rnd(M, 64, seed=2)
+    dw0, db0 = rnd(64, 256, seed=3), rnd(64, seed=4)
+    dw, db = dw0.clone(), db0.clone()
+    gemm.gemm_tap_wgrad(gemm.linear_desc(M, 256, 64), a, dy, dw, db, scale=0.5)
+    assert relerr(dw, dw0.double() + 0.5 * dy.double().T @ a.double()) < 2e-6
+    assert relerr(db, db0.double() + 0.5 * dy.double().sum(0)) < 2e-6

@@ -128,3 +128,24 @@ def test_glu_bwd_and_optimizers():
             else:
                 O.sgd_nesterov(q, g, m, 1e-2, 0.9, step == 1)
         assert relerr(q, p.data) < 1e-5, kind
+
+
+def test_zero_arena_hands_out_zeroed_disjoint_buffers():
+    """ops.ZeroArena: step-scoped zero-filled scratch (one fill per step); outside a step plain torch.zeros."""
+    from speech_enhancement_amd import ops as O
+    dev = torch.device('cuda')
+    assert not O.ARENA.active
+    plain = O.zeros(3, 5, device=dev)
+    assert plain.eq(0).all()
+    for _ in range(2):                       # second step re-clears what the first one dirtied
+        O.ARENA.begin(dev, min_bytes=1 << 16)
+        try:
+            a = O.zeros(7, 3, device=dev)
+            b = O.zeros(2, 5, 2, device=dev, dtype=torch.float64)
+            big = O.zeros(1 << 20, device=dev)             # does not fit the 64 KB arena: falls back, grown next step
+            assert a.eq(0).all() and b.eq(0).all() and big.eq(0).all() and b.data_ptr() % 256 == 0
+            assert a.data_ptr() + a.numel() * 4 <= b.data_ptr() or b.data_ptr() + b.numel() * 8 <= a.data_ptr()
+            a.fill_(3.0); b.fill_(5.0)
+        finally:
+            O.ARENA.end()
+    O.ARENA.__init__()
