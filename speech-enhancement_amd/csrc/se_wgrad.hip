@@ -820,10 +820,13 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
                    d->Ti == d->To && d->Fi == d->Fo;
   if (lin && (d->precision == 0 || d->precision == 2) && (d->C % 4) == 0 && (d->lda % 4) == 0 && (d->a_off % 4) == 0 &&
       getenv("SE_WGRAD_NO_LIN") == nullptr) {
+    // measured at M = 518 736 (tools/tools_lin_wgrad.py): [64 x 256] 254 vs 293 us, [256 x 64] 250 vs 257 us; [192 x 64] is slower here
+    // (a quarter of the workgroup idles: 234 vs 189 us) and [64 x 128] equal (118 vs 120 us) -> those stay on wgrad_kernel
     int shape = 0;                                               // 1: N <= 256, C <= 64; 2: N <= 64, C <= 256; 3: N <= 64, C <= 128
-    if (d->C <= 64 && d->N > 64 && d->N <= 256) shape = 1;
+    if (d->C <= 64 && d->N > 192 && d->N <= 256) shape = 1;
     else if (d->N <= 64 && d->C > 128 && d->C <= 256) shape = 2;
-    else if (d->N <= 64 && d->C > 64 && d->C <= 128) shape = 3;
+    else if (d->N <= 64 && d->C > 64 && d->C <= 128 && getenv("SE_WGRAD_LIN_ALL") != nullptr) shape = 3;
+    if (d->C <= 64 && d->N > 64 && d->N <= 192 && getenv("SE_WGRAD_LIN_ALL") != nullptr) shape = 1;
     if (shape) {
       // one resident round of 3 workgroups per CU (42 KB of LDS each), steps of 32 rows
       long rl = (Mtot + 767) / 768;
