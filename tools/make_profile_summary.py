@@ -31,24 +31,28 @@ def short(n):
 def fam(name):
     """KernelTimer family (bench.py roofline keys) of a kernel name, or None"""
     n = short(name)
-    m = re.match(r'gemm_tap_bf16x3_kernel<(\d), (\d), (true|false)>', n)
+    m = re.match(r'gemm_tap_bf16x3_kernel<(\d), (\d), (true|false)', n)
     if m:
         return f'gemm_tap_bf16x{3 if m.group(2) == "2" else 6}_kernel<{m.group(1)}>'
-    m = re.match(r'conv3_bf16_kernel<(\d)>', n)
+    m = re.match(r'conv3_bf16_kernel<(\d)', n)
     if m:
         return f'conv3_bf16x{3 if m.group(1) == "2" else 6}'
-    m = re.match(r'gemm_k64_panel_kernel<(\d), (\d), (true|false)>', n)
+    m = re.match(r'gemm_k64_panel_kernel<(\d), (\d), (true|false)', n)
     if m:
         return f'gemm_k64_panel_bf16x{3 if m.group(2) == "2" else 6}<{m.group(1)}>'
     m = re.match(r'gemm_tap_kernel<(\d+), (\d), (true|false)>', n)
     if m:
         return f'gemm_tap_kernel<{m.group(1)},{m.group(2)}>'
-    m = re.match(r'wgrad_kernel<(\d)>', n)
+    m = re.match(r'wgrad_kernel<(\d)>', n) or re.match(r'wgrad_lin_kernel<(\d)', n)
     if m:
         return f'wgrad_kernel<{m.group(1)}>'
+    if n.startswith('dwconv_kernel'):
+        return 'dwconv31 (fwd / dgrad)'
+    if n.startswith('dwconv_wgrad_kernel'):
+        return 'dwconv31_wgrad (+ reduce)'
     if n.startswith('wgrad3_kernel') or n.startswith('wgrad3_bf16_kernel'):
         return 'wgrad_kernel<0>'
-    m = re.match(r'ff_(fwd|bwd)_kernel<(\d)>', n)
+    m = re.match(r'ff_(fwd|bwd)_kernel<(\d)', n)
     if m:
         return f'ff_{m.group(1)}{"_dgrad" if m.group(1) == "bwd" else ""}_bf16x{3 if m.group(2) == "2" else 6}'
     if n.startswith('attn_bwd3_kernel<6'):
