@@ -109,6 +109,15 @@ int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const flo
                     const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
                     void* stream);
 
+/* Input-gradient GEMM of a projection that follows a LayerNorm(64), fused with that LayerNorm's backward
+ * (models/conformer.py:67,162: PreNorm -> to_q/to_kv, LayerNorm -> pointwise conv):
+ *   dX = dR + LNbwd(A W^T),  dgamma += sum_rows (A W^T) * xhat,  dbeta += sum_rows (A W^T)
+ * A [M, K] = gradient w.r.t. the projection's output, W [64, K] (or its pre-split planes, w_planes elements apart; 0 = fp32),
+ * X [M, 64] the LayerNorm input, stats [M, 2] its (mean, rstd), dR [M, 64] (may be NULL) the residual-path gradient.  The
+ * [M, 64] product never goes to memory (se_gemm_tap + se_layernorm_bwd: one write and one read of it, and one launch, more). */
+int se_gemm_ln_bwd(const float* A, const float* W, int w_planes, long M, int K, const float* X, const float* stats,
+                   const float* gamma, const float* dR, float* dX, float* dgamma, float* dbeta, void* stream);
+
 /* weight gradient: dW[n][tap*C + c] += alpha * sum_m dY[m][n] * pro(A[src(m,tap)][c]) (alpha = d->alpha: the factor of a
  * Scale(0.5, .) wrapper goes straight into the gradient buffer);  dW must be initialised by the caller (fp32 atomics across
  * row chunks).  If dbias != NULL also dbias[n] += alpha * sum_m dY[m][n].

@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     __syncthreads();
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;        // the staging planes are free now
+  if (LIN && PRO == SE_PRO_NONE && (d.epilogue & SE_EPI_LN_BWD_)) { gemm_epilogue_ln_bwd(g, acc0, acc1, m0, cs, 36, red); return; }
   if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
@@ -665,6 +666,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                            const float* pro_scale, const float* pro_shift, double* stats, void* stream) {
   if (int e = check_desc(d)) return e;
   const int ep = d->epilogue;
+  SE_REQUIRE(!(ep & SE_EPI_LN_BWD_), "gemm: unknown epilogue bit 1024 (use se_gemm_ln_bwd)");
   SE_REQUIRE(A && W && Y, "gemm: null operand");
   SE_REQUIRE(!(ep & SE_EPI_BIAS) || bias, "gemm: bias flag without bias");
   SE_REQUIRE(!(ep & SE_EPI_RESID) || R, "gemm: resid flag without R");
@@ -679,7 +681,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                "gemm: pre-split weights need precision 2, C >= 32, C, ldw and the plane stride multiples of 8, a 16-byte aligned W");
     SE_REQUIRE((long)d->w_planes * 6 < (1L << 31), "gemm: pre-split weight planes exceed 2^31 bytes");
   }
-  GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats, 0, 0, 0, 0};
+  GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats, nullptr, nullptr, 0, 0, 0, 0};
   const int Mb = d->To * d->Fo;
   const int ncols = (ep & SE_EPI_GLU) ? cdiv(d->N / 2, 32) : cdiv(d->N, 64);
   g.ncb = ncols;
@@ -775,6 +777,29 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
 #undef LAUNCH_BK
 #undef LAUNCH
   return se_check_launch("se_gemm_tap");
+}
+
+// dX = dR + LayerNorm-backward(A W^T): the input-gradient GEMM of a projection that follows a LayerNorm(64), fused with that
+// LayerNorm's backward (se_layernorm_bwd with dY = A W^T, which never goes to memory).  Split-bf16 row GEMM (six products).
+extern "C" int se_gemm_ln_bwd(const float* A, const float* W, int w_planes, long M, int K, const float* X, const float* stats,
+                              const float* gamma, const float* dR, float* dX, float* dgamma, float* dbeta, void* stream) {
+  SE_REQUIRE(A && W && X && stats && gamma && dX && dgamma && dbeta, "gemm_ln_bwd: null operand");
+  SE_REQUIRE(M > 0 && M < 2147483647L && K >= 32 && (K % 8) == 0, "gemm_ln_bwd: M=%ld K=%d (K must be a multiple of 8, >= 32)", M, K);
+  se_gemm_desc d{};
+  d.B = 1; d.To = 1; d.Fo = (int)M; d.Ti = 1; d.Fi = (int)M; d.st = 1; d.sf = 1; d.ntap = 1;
+  d.C = K; d.lda = K; d.N = 64; d.ldc = 64; d.ldw = K; d.ldr = 64; d.ldx = 64;
+  d.epilogue = SE_EPI_LN_BWD_; d.alpha = 1.f; d.precision = 2; d.w_planes = w_planes;
+  if (int e = check_desc(&d)) return e;
+  if (w_planes) SE_REQUIRE(w_planes >= 64 * K && (w_planes % 8) == 0 && ((size_t)W & 15) == 0, "gemm_ln_bwd: bad weight planes");
+  GemmArgs g{d, A, W, nullptr, dX, dR, const_cast<float*>(X), stats, gamma, nullptr, nullptr, dgamma, dbeta, 0, 0, 0, 0};
+  g.ncb = 1;
+  g.tiles = cdiv(M, 128);
+  g.nouter = g.tiles;
+  g.contig = 0;
+  dim3 grid((unsigned)(((long)g.nouter + 7) / 8 * 8)), block(256);
+  if (w_planes) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, true>), grid, block, 0, as_stream(stream), g);
+  else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, false>), grid, block, 0, as_stream(stream), g);
+  return se_check_launch("se_gemm_ln_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------

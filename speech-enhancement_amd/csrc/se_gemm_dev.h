@@ -9,6 +9,7 @@ struct GemmArgs {
   se_gemm_desc d;
   const float* A; const float* W; const float* bias; float* Y; const float* R; float* AUX;
   const float* rowstats; const float* ps; const float* pb; double* stats;
+  float* dgamma; float* dbeta;     // SE_EPI_LN_BWD_ (se_gemm_ln_bwd): LayerNorm parameter gradients
   int ncb;      // column blocks per row tile
   int tiles;    // row tiles per batch entry
   int nouter;   // B * tiles
@@ -214,6 +215,87 @@ static __device__ __forceinline__ void stage_bias(const GemmArgs& g, int by, flo
     bias_s[threadIdx.x] = ((g.d.epilogue & SE_EPI_BIAS) && n < g.d.N) ? g.bias[n] : 0.f;
   }
 }
+// LayerNorm-backward epilogue of a row GEMM with N == 64 (se_gemm_ln_bwd): the tile holds whole rows, so the product
+// dL = A W^T never goes to memory -- dX = dR + rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)), dxh = dL * gamma, is computed
+// on the accumulators (a row's 64 channels sit in the 8 lanes cq = 0..7 of one rr group after the wave-private transpose) and
+// the gamma / beta gradients are folded over the rows of the workgroup (one atomic per channel and workgroup).
+// Operands: X = g.AUX [M][64], (mean, rstd) = g.rowstats, gamma = g.ps, dR = g.R, dX = g.Y; red: [4 waves][64][2] floats.
+constexpr int SE_EPI_LN_BWD_ = 1024;        // internal epilogue flag (not part of the public mask)
+static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1, int m0,
+                                                            float* cs, int cs_ld, float* red) {
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Mb = d.To * d.Fo;
+  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  float4 gv[2][4];                            // dL of rows rr + 8 i, columns nt * 32 + 4 cq .. + 3
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const f32x16& acc = nt ? acc1 : acc0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc[r];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gv[nt][i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
+  }
+  float ag[2][4] = {}, ab[2][4] = {};
+  float4 gm[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) gm[nt] = *reinterpret_cast<const float4*>(g.ps + nt * 32 + cq * 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long rg = (long)m0 + wave * 32 + rr + 8 * i;
+    const bool ok = rg < Mb;
+    float mean = 0.f, rstd = 0.f;
+    if (ok) { const float2 mr = *reinterpret_cast<const float2*>(g.rowstats + 2 * rg); mean = mr.x; rstd = mr.y; }
+    float xh[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const float4 xv = ok ? *reinterpret_cast<const float4*>(g.AUX + rg * 64 + nt * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float dv[4] = {gv[nt][i].x, gv[nt][i].y, gv[nt][i].z, gv[nt][i].w};
+      const float gl[4] = {gm[nt].x, gm[nt].y, gm[nt].z, gm[nt].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[nt][j] = (xs[j] - mean) * rstd;
+        dxh[nt][j] = dv[j] * gl[j];
+        s1 += dxh[nt][j]; s2 += dxh[nt][j] * xh[nt][j];
+        if (ok) { ag[nt][j] += dv[j] * xh[nt][j]; ab[nt][j] += dv[j]; }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
+    if (ok) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const long off = rg * 64 + nt * 32 + cq * 4;
+        float o4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.R) { const float4 r1 = *reinterpret_cast<const float4*>(g.R + off); o4[0] = r1.x; o4[1] = r1.y; o4[2] = r1.z; o4[3] = r1.w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
+        *reinterpret_cast<float4*>(g.Y + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
+    }
+  }
+  // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float sg = ag[nt][j], sb = ab[nt][j];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
+      if (rr == 0) { red[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sg; red[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sb; }
+    }
+  __syncthreads();
+  if (tid < 64) {
+    float sg = 0.f, sb = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sg += red[(w * 64 + tid) * 2]; sb += red[(w * 64 + tid) * 2 + 1]; }
+    atomicAdd(&g.dgamma[tid], sg);
+    atomicAdd(&g.dbeta[tid], sb);
+  }
+}
+
 // GLU flavour of the vectorised epilogue: accumulator 0 = value columns, accumulator 1 = gate columns of the same 32
 // outputs.  The gate tile is transposed first and parked in registers, then the value tile; Y = a * sigmoid(g) and
 // the pre-GLU Z (both halves) leave as float4 stores.

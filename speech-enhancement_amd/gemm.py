@@ -102,6 +102,19 @@ def _wgrad_call(d, A, dY, dW, dbias, rowstats, ps, pb, chunks, Mt):
     return dW
 
 
+def gemm_ln_bwd(A, WT, x, stats, gamma, dR, dgamma, dbeta):
+    """dX = dR + LayerNorm-backward(A @ WT.T) (csrc/se_gemm.hip: se_gemm_ln_bwd): A [M, K], WT [64, K] fp32 or pre-split planes
+    [3, 64, K]; x [M, 64], stats [M, 2], dR [M, 64] or None; dgamma / dbeta [64] accumulated."""
+    L.check_cuda(A, WT, x, stats, gamma, dR, dgamma, dbeta)
+    M, K = A.shape
+    planes = WT.dtype == torch.bfloat16
+    dX = torch.empty(M, 64, device=A.device, dtype=torch.float32)
+    L.call('se_gemm_ln_bwd', L.ptr(A), L.ptr(WT), C.c_int(WT.stride(0) if planes else 0), C.c_long(M), C.c_int(K), L.ptr(x),
+           L.ptr(stats), L.ptr(gamma), L.ptr(dR), L.ptr(dX), L.ptr(dgamma), L.ptr(dbeta), L.stream(),
+           _key='gemm_tap_bf16x6_kernel<0>', _flops=2.0 * M * 64 * K, _bytes=4.0 * M * (K + 192))
+    return dX
+
+
 def repack(src, No, Nt, Ni, so, stt, si, rev=0, out=None, accumulate=False):
     """dst[o][t][i] = src[o*so + i*si + t*stt]."""
     if out is None:

@@ -29,6 +29,11 @@ CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_CONV_P
 WGRAD_PRECISION = [{'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_WGRAD_PRECISION', 'bf16x6')]]
 
 
+# input-gradient GEMM of the qkv / pointwise-GLU projections fused with the backward of the LayerNorm in front of them
+# (se_gemm_ln_bwd); SE_NO_LN_FUSE=1 keeps the two-kernel form for A/B runs
+FUSE_LN_BWD = _os.environ.get('SE_NO_LN_FUSE') != '1'
+
+
 def set_conv_precision(name, wgrad=None):
     global CONV_PRECISION
     CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[name]
@@ -447,15 +452,22 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
     dzc = O.glu_bwd(zc, du, M, 128)
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
-    dl3 = torch.empty(M, 64, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 256, 64), dzc, _w(P, (f'{p}.conv.net.2.weight', 'T'), lambda: _T(Wpw1)), dl3)
     GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), y2, dzc, G[f'{p}.conv.net.2.weight'].view(256, 64),
                       G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                       pb=P[f'{p}.conv.net.0.bias'])
-    dy2 = O.layernorm_bwd(y2, st3, P[f'{p}.conv.net.0.weight'], dl3, G[f'{p}.conv.net.0.weight'],
-                          G[f'{p}.conv.net.0.bias'], dR=dy3)
+    Wpw1T = _w(P, (f'{p}.conv.net.2.weight', 'T'), lambda: _T(Wpw1))
+    if FUSE_LN_BWD and GM.LINEAR_PRECISION == 2:
+        # input-gradient GEMM + the LayerNorm backward on its accumulators: the [M, 64] product never goes to memory
+        dy2 = GM.gemm_ln_bwd(dzc, Wpw1T, y2, st3, P[f'{p}.conv.net.0.weight'], dy3, G[f'{p}.conv.net.0.weight'],
+                             G[f'{p}.conv.net.0.bias'])
+    else:
+        dl3 = torch.empty(M, 64, device=dev, dtype=torch.float32)
+        GM.gemm_tap(GM.linear_desc(M, 256, 64), dzc, Wpw1T, dl3)
+        dy2 = O.layernorm_bwd(y2, st3, P[f'{p}.conv.net.0.weight'], dl3, G[f'{p}.conv.net.0.weight'],
+                              G[f'{p}.conv.net.0.bias'], dR=dy3)
+        del dl3
     ctx['conv'] = None
-    del dact, dh, du, dzc, dl3, dy3, dy4
+    del dact, dh, du, dzc, dy3, dy4
     # attention: y2 = y1 + o @ Wo^T + bo
     y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa = ctx['attn']
     Wo = P[f'{p}.attn.fn.to_out.weight']
@@ -466,8 +478,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
                       G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25)
-    dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv)), dl2)
+    WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv))
     gq, gkv = G[f'{p}.attn.fn.to_q.weight'], G[f'{p}.attn.fn.to_kv.weight']
     # to_q / to_kv are neighbours in the flat gradient buffer of the optimizers: the [192, 64] gradient of the fused projection
     # then accumulates in place; otherwise through a scratch matrix
@@ -479,10 +490,17 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     if dWqkv.data_ptr() != gq.data_ptr():
         gq += dWqkv[:64]
         gkv += dWqkv[64:]
-    dy1 = O.layernorm_bwd(y1, st2, P[f'{p}.attn.norm.weight'], dl2, G[f'{p}.attn.norm.weight'],
-                          G[f'{p}.attn.norm.bias'], dR=dy2)
+    if FUSE_LN_BWD and GM.LINEAR_PRECISION == 2:
+        dy1 = GM.gemm_ln_bwd(dqkv, WqkvT, y1, st2, P[f'{p}.attn.norm.weight'], dy2, G[f'{p}.attn.norm.weight'],
+                             G[f'{p}.attn.norm.bias'])
+    else:
+        dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
+        GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, WqkvT, dl2)
+        dy1 = O.layernorm_bwd(y1, st2, P[f'{p}.attn.norm.weight'], dl2, G[f'{p}.attn.norm.weight'],
+                              G[f'{p}.attn.norm.bias'], dR=dy2)
+        del dl2
     ctx['attn'] = None
-    del do, dqkv, dl2, dy2
+    del do, dqkv, dy2
     # ff1, plus the TSCB residual (out = LN(y4) + x)
     dx = _ff_bwd(P, G, f'{p}.ff1', ctx['ff1'], dy1, M, dR2=dout)
     ctx['ff1'] = None

@@ -487,3 +487,34 @@ def test_full_tile_linear_wgrad_equals_block_kernel(G, Cin, N, pro, monkeypatch)
     if pro == 'ln':
         a = torch.nn.functional.layer_norm(x.double(), (Cin,), g.double(), b.double(), 1e-5)
         assert relerr(out['full'][0], dy.double().T @ a) < 5e-6 and relerr(out['full'][1], dy.double().sum(0)) < 5e-6
+
+
+@pytest.mark.parametrize('K,planes', [(192, True), (256, True), (192, False)])
+def test_gemm_ln_bwd_equals_gemm_then_layernorm_bwd(G, K, planes):
+    """se_gemm_ln_bwd (input-gradient GEMM + LayerNorm backward on the accumulators) against se_gemm_tap + se_layernorm_bwd and
+    against fp64 autograd of  y = LayerNorm(x) @ W.T  (dX incl. the residual path, dgamma, dbeta); ragged M."""
+    gemm, L = G
+    from speech_enhancement_amd import ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    M = 128 * 7 + 45
+    x, dy, dR = rnd(M, 64, seed=1) * 1.5 + 0.3, rnd(M, K, seed=2), rnd(M, 64, seed=3)
+    W = rnd(K, 64, seed=4, scale=0.1)                       # the projection's weight [K out, 64 in]
+    gam, bet = rnd(64, seed=5) * 0.2 + 1.0, rnd(64, seed=6) * 0.1
+    st = O.row_stats(x, M)
+    plan = WeightPlan(torch.device('cuda'))
+    WT = plan.linear_T('wt', W, planes=planes)              # [64][K]
+    plan.run()
+    dg, db = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    dX = gemm.gemm_ln_bwd(dy, WT, x, st, gam, dR, dg, db)
+    # two-kernel form
+    dl = torch.empty(M, 64, device='cuda')
+    gemm.gemm_tap(gemm.linear_desc(M, K, 64, precision=2), dy, WT, dl)
+    dg2, db2 = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    dX2 = O.layernorm_bwd(x, st, gam, dl, dg2, db2, dR=dR)
+    assert relerr(dX, dX2) < 2e-6 and relerr(dg, dg2) < 1e-5 and relerr(db, db2) < 1e-5
+    # fp64 autograd
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(x64, (64,), g64, b64, 1e-5) @ W.double().T
+    y.backward(dy.double())
+    assert relerr(dX, x64.grad + dR.double()) < 5e-6 and relerr(dg, g64.grad) < 1e-5 and relerr(db, b64.grad) < 1e-5
