@@ -829,7 +829,10 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
     if (d->C <= 64 && d->N > 64 && d->N <= 192 && getenv("SE_WGRAD_LIN_ALL") != nullptr) shape = 1;
     if (shape) {
       // one resident round of 3 workgroups per CU (42 KB of LDS each), steps of 32 rows
+      // (at least 8 steps per workgroup: every workgroup ends with N * C atomics, which dominated at small M -- 81 us of
+      // atomics for 3 steps of work at batch 2)
       long rl = (Mtot + 767) / 768;
+      if (rl < 256) rl = 256;
       rl = ((rl + 31) / 32) * 32;
       const int nch = (int)((Mtot + rl - 1) / rl);
       WgradArgs gl{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rl, nch};
