@@ -203,7 +203,9 @@ def main():
                 peak = PEAK_BF16_MFMA_TFLOPS / parts
                 note = (f'algorithmic (fp32-equivalent) FLOPs; the kernel evaluates every product as {parts} bf16 MFMAs '
                         f'(exact hi/mid/lo operand split, fp32 accumulate), so its peak is the dense bf16 MFMA peak / '
-                        f'{parts} = {round(peak, 1)} TFLOP/s; executed bf16 MFMA rate = {round(ach * parts, 1)} TFLOP/s')
+                        f'{parts} = {round(peak, 1)} TFLOP/s; executed bf16 MFMA rate = {round(ach * parts, 1)} TFLOP/s.  '
+                        f'The peak is quoted at the spec clock: under this load on random operands the chip holds a lower one '
+                        f'(the same launch runs 25 % faster on all-zero activations, DESIGN.md section 7)')
             else:
                 peak = PEAK_F32_MFMA_TFLOPS
                 note = 'algorithmic fp32 FLOPs; peak = dense fp32 MFMA (v_mfma_f32_*)'
