@@ -7,6 +7,7 @@ backend "nccl" == RCCL over xGMI) + the SyncBatchNorm statistic exchanges inside
 PESQ labels are third-party CPU arithmetic (PyPI `pesq`, not available offline): they come from a pluggable
 provider (`set_pesq_provider`); parity / bench runs supply them as inputs.
 """
+import os
 import time
 
 import torch
@@ -197,6 +198,18 @@ def self_correcting_weights(CE, CN, EN, EE, NN):
     return 1.0, wE, wN
 
 
+_D_OVERLAP = os.environ.get('SE_NO_D_OVERLAP') != '1'
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """one side stream per device for the discriminator step (see _gan_step)"""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)     # (a high-priority stream measured no different: 99.1 vs 99.1 ms)
+    return _SIDE_STREAMS[key]
+
+
 class LabelCache:
     """the reference recomputes Q_y_y = PESQ(clean, clean) and Q_x_y = PESQ(clean, noisy)
     every step of the scp / sc recipes (core/function.py:292-301) although neither depends on the generator -- two of
@@ -286,6 +299,43 @@ class _StaleState:
     __slots__ = ('clean_pl', 'noisy_pl', 'est_d', 'pending', 'ones', 'keys')
 
 
+def _discriminator_update(discriminator, optimizer_disc, est_d, clean_pl, noisy_pl, ones, arch, labels, pending, keys, hooks,
+                          max_norm, out):
+    """the discriminator half of the train_gan loop body (core/function.py:286-315) on the current stream: forwards on
+    (clean, est.detach()), (clean, clean) (and (clean, noisy) for scp / sc), metric losses (self-correcting weights for scp / sc),
+    backward, clipping, optimizer step; fills L_C / L_E / loss_d (and L_N / w_E / w_N) of `out`."""
+    d_gx = discriminator.forward_planes(clean_pl, est_d)
+    d_yy = discriminator.forward_planes(clean_pl, clean_pl)
+    d_xy = discriminator.forward_planes(clean_pl, noisy_pl) if arch in ('scp', 'sc') else None
+    if labels is None:                     # all discriminator forwards are queued: only now wait for the CPU side
+        got = dict(zip(pending['names'], pending['future'].result()))
+        if keys is not None:
+            for kind in ('clean', 'noisy'):
+                if kind in got:
+                    _LABEL_CACHE.store(keys, kind, got[kind].tolist())
+        got.update(pending['cached'])
+        labels = {k: v.to(clean_pl.device, non_blocking=True) for k, v in got.items()}
+    q_est = labels['est']
+    L_E = _mse(d_gx.flatten(), q_est)
+    if arch in ('scp', 'sc'):
+        q_clean = labels['clean']
+        L_C = _mse(d_yy.flatten(), q_clean)
+        q_noisy = labels['noisy']
+        L_N = _mse(d_xy.flatten(), q_noisy)
+        loss_d, wE, wN = _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hooks)
+        out.update(L_N=L_N.detach(), w_E=wE, w_N=wN)
+    else:
+        L_C = _mse(d_yy.flatten(), ones)
+        loss_d = L_C + L_E
+        loss_d.backward()
+        if hooks is not None:
+            hooks.average_grads(optimizer_disc)
+    if max_norm != 0.0:
+        clip_grad_norm(optimizer_disc, discriminator.parameters(), max_norm)
+    optimizer_disc.step()
+    out.update(L_C=L_C.detach(), L_E=L_E.detach(), loss_d=loss_d.detach())
+
+
 def gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, *args, **kwargs):
     """`_gan_step` inside the step's zero-filled scratch arena (ops.ZeroArena: one fill launch instead of ~250)."""
     O.ARENA.begin(clean.device)
@@ -332,7 +382,23 @@ def _gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arc
     r = generator_pass(model, discriminator, clean, noisy, arch, loss_weights, n_fft, hop, comp_type, gan_on, True,
                        submit_labels)
     est, clean_pl, noisy_pl, ones, loss = r['est'], r['clean_pl'], r['noisy_pl'], r['ones'], r['loss']
-    loss.backward()
+    # The discriminator step (2-3 forwards, backward, optimizer: ~150 launches of latency-bound kernels on a few workgroups each,
+    # 6-7 ms when run alone) reads est.detach() and the discriminator's own parameters only.  It is issued on a SIDE STREAM and runs
+    # concurrently with the generator backward (55 ms of large kernels), whose gaps and tails it fills.  For that the backward is
+    # taken in two stages: loss -> est first (loss kernels, iSTFT / re-STFT backward and the input gradient THROUGH the
+    # discriminator, which must read the discriminator's PReLU / InstanceNorm parameters before the side stream updates them),
+    # an event, then est -> generator parameters.  Same dataflow, same results; SE_NO_D_OVERLAP=1 restores the serial order.
+    overlap = _D_OVERLAP and gan_on and not stale_labels and est.is_cuda and est.requires_grad
+    main = side = ev = None
+    if overlap:
+        main, side = torch.cuda.current_stream(est.device), _side_stream(est.device)
+        dest, = torch.autograd.grad(loss, est)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        est.backward(dest)          # enqueued BEFORE the discriminator step: the host is never blocked (PESQ wait) ahead of it
+        del dest
+    else:
+        loss.backward()
     # Data parallel: the generator-gradient all-reduce (7.3 MB over xGMI) is launched asynchronously and only waited
     # for after the discriminator step has been issued -- the discriminator step reads est.detach() and no generator
     # parameter, so deferring optimizer.step() past it changes no result and hides the collective behind the three
@@ -351,6 +417,16 @@ def _gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arc
     out.update(loss_ri=r['loss_ri'].detach(), loss_mag=r['loss_mag'].detach(), time_loss=r['time_loss'].detach(),
                gan=r['gan'].detach(), loss_g=loss.detach())
 
+    if overlap:
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            optimizer_disc.zero_grad()          # on the side stream too: ordered before the backward that accumulates into it
+            _discriminator_update(discriminator, optimizer_disc, est.detach(), clean_pl, noisy_pl, ones, arch, labels, pending, keys,
+                                  hooks, max_norm, out)
+        main.wait_stream(side)      # the next generator forward reads the updated discriminator; scratch is recycled per step
+        if hooks is not None:
+            finish_generator_step()
+        return out
     optimizer_disc.zero_grad()
     if not gan_on:
         if hooks is not None:
@@ -371,38 +447,10 @@ def _gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arc
             return out
         clean_pl, noisy_pl, est_d, pending, ones = prev.clean_pl, prev.noisy_pl, prev.est_d, prev.pending, prev.ones
         keys = prev.keys
-    d_gx = discriminator.forward_planes(clean_pl, est_d)
-    d_yy = discriminator.forward_planes(clean_pl, clean_pl)
-    d_xy = discriminator.forward_planes(clean_pl, noisy_pl) if arch in ('scp', 'sc') else None
-    if labels is None:                     # all discriminator forwards are queued: only now wait for the CPU side
-        got = dict(zip(pending['names'], pending['future'].result()))
-        if keys is not None:
-            for kind in ('clean', 'noisy'):
-                if kind in got:
-                    _LABEL_CACHE.store(keys, kind, got[kind].tolist())
-        got.update(pending['cached'])
-        labels = {k: v.to(clean.device, non_blocking=True) for k, v in got.items()}
-    q_est = labels['est']
-    L_E = _mse(d_gx.flatten(), q_est)
-    if arch in ('scp', 'sc'):
-        q_clean = labels['clean']
-        L_C = _mse(d_yy.flatten(), q_clean)
-        q_noisy = labels['noisy']
-        L_N = _mse(d_xy.flatten(), q_noisy)
-        loss_d, wE, wN = _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hooks)
-        out.update(L_N=L_N.detach(), w_E=wE, w_N=wN)
-    else:
-        L_C = _mse(d_yy.flatten(), ones)
-        loss_d = L_C + L_E
-        loss_d.backward()
-        if hooks is not None:
-            hooks.average_grads(optimizer_disc)
-    if max_norm != 0.0:
-        clip_grad_norm(optimizer_disc, discriminator.parameters(), max_norm)
-    optimizer_disc.step()
+    _discriminator_update(discriminator, optimizer_disc, est_d, clean_pl, noisy_pl, ones, arch, labels, pending, keys, hooks,
+                          max_norm, out)
     if hooks is not None:
         finish_generator_step()
-    out.update(L_C=L_C.detach(), L_E=L_E.detach(), loss_d=loss_d.detach())
     return out
 
 
