@@ -70,6 +70,61 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     return Y
 
 
+class _LeafStream:
+    """Weight gradients are leaves of the backward graph: nothing downstream reads them before the optimizer step.  Inside the
+    generator backward they are issued on a second HIP stream, behind an event recorded when their operands are ready, and run
+    concurrently with the input-gradient chain on the main stream (joined before the optimizer step).  Operands the side stream
+    reads are registered with the caching allocator (record_stream) so that the main stream cannot recycle them early."""
+    enabled = __import__('os').environ.get('SE_NO_WGRAD_STREAM') != '1'
+    active = False
+    streams = {}
+
+    @classmethod
+    def side(cls, device):
+        k = torch.device(device).index
+        if k not in cls.streams:
+            cls.streams[k] = torch.cuda.Stream(device=device)
+        return cls.streams[k]
+
+
+class leaf_stream:
+    """`with leaf_stream(*operands):` -- the launches inside go to the leaf stream when the generator backward has enabled it."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        if not (_LeafStream.active and self.tensors and self.tensors[0].is_cuda):
+            return self
+        dev = self.tensors[0].device
+        main, side = torch.cuda.current_stream(dev), _LeafStream.side(dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        for t in self.tensors:
+            t.record_stream(side)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def leaf_begin():
+    _LeafStream.active = _LeafStream.enabled
+
+
+def leaf_join(device):
+    """the main stream waits for every weight gradient issued so far (before the optimizer step / gradient all-reduce)"""
+    if _LeafStream.active:
+        torch.cuda.current_stream(device).wait_stream(_LeafStream.side(device))
+    _LeafStream.active = False
+
+
 def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, chunks=None, explicit_precision=False,
                    scale=1.0):
     """dW (+ dbias) += scale * gradient: accumulates straight into the caller's (gradient) buffers."""

@@ -102,7 +102,11 @@ class _TSCNetFn(torch.autograd.Function):
         direct = all(P[k].grad is not None and P[k].grad.is_contiguous() for k in model._pnames)
         with torch.no_grad():
             G = {k: (P[k].grad if direct else torch.zeros_like(P[k])) for k in model._pnames}
-            LY.tscnet_bwd(P, G, ctx.c, dest.contiguous(), dp=model.dp)
+            LY.GM.leaf_begin()                       # weight gradients on their own stream (gemm.leaf_stream)
+            try:
+                LY.tscnet_bwd(P, G, ctx.c, dest.contiguous(), dp=model.dp)
+            finally:
+                LY.GM.leaf_join(dest.device)
         ctx.c = None
         if direct:
             return (None, None) + (None,) * len(model._pnames)

@@ -99,9 +99,10 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     N = dR.shape[-1]
     ntap = len(taps)
     fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf, precision=WGRAD_PRECISION[0])
-    dwp = O.zeros(N, ntap * C_in, device=dR.device)
-    GM.gemm_tap_wgrad(fd, x, dR, dwp, dbias)
-    _unpack_w(dwp, dw, C_in, rev)
+    with GM.leaf_stream(x, dR):
+        dwp = O.zeros(N, ntap * C_in, device=dR.device)
+        GM.gemm_tap_wgrad(fd, x, dR, dwp, dbias)
+        _unpack_w(dwp, dw, C_in, rev)
     if not need_dx:
         return None
     if wd is None:               # no prepared [Cin][tap][N] matrix (weights.WeightPlan): build it now
@@ -348,12 +349,13 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
                                    epilogue=L.EPI_SWISH_GRAD | (L.EPI_DROP if dr else 0), ldx=256, pro_seed=seed_o,
                                    epi_seed=seed_h, drop_p=drop), dy, _T(W2) * 0.5, dz, AUX=z)
     # dW2 = 0.5 * (mask_o * dy)^T (mask_h * swish(z));  db2 = 0.5 * sum mask_o * dy
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH,
-                                     epilogue=L.EPI_DROP if dr else 0, pro_seed=seed_h, epi_seed=seed_o, drop_p=drop),
-                      z, dy, G[f'{p}.fn.fn.net.3.weight'], G[f'{p}.fn.fn.net.3.bias'], scale=0.5)
-    # dW1 = dz^T LN(x);  db1 = sum dz
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, G[f'{p}.fn.fn.net.0.weight'],
-                      G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
+    with GM.leaf_stream(z, dy, x, dz, st):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH,
+                                         epilogue=L.EPI_DROP if dr else 0, pro_seed=seed_h, epi_seed=seed_o, drop_p=drop),
+                          z, dy, G[f'{p}.fn.fn.net.3.weight'], G[f'{p}.fn.fn.net.3.bias'], scale=0.5)
+        # dW1 = dz^T LN(x);  db1 = sum dz
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, G[f'{p}.fn.fn.net.0.weight'],
+                          G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
     if fused:
         return dx
     dh = torch.empty(M, 64, device=x.device, dtype=torch.float32)
@@ -437,8 +439,9 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
     dact = torch.empty(M, 128, device=dev, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 128), dy3, _w(P, (f'{p}.conv.net.7.weight', 'T'), lambda: _T(Wpw2)), dact)
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH), h, dy3,
-                      G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
+    with GM.leaf_stream(h, dy3, sc, sh):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH), h, dy3,
+                          G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
     dh = torch.empty(M, 128, device=dev, dtype=torch.float32)
     g_bn, b_bn = P[f'{p}.conv.net.5.weight'], P[f'{p}.conv.net.5.bias']
     if train:
@@ -449,12 +452,14 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
         raise L.SeHipError('conformer_bwd in eval mode is not supported (BatchNorm uses running statistics)')
     Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
     du = O.dwconv31(dh, Wdw, None, geom, flip=True)
-    O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
+    with GM.leaf_stream(u, dh):
+        O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
     dzc = O.glu_bwd(zc, du, M, 128)
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), y2, dzc, G[f'{p}.conv.net.2.weight'].view(256, 64),
-                      G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
-                      pb=P[f'{p}.conv.net.0.bias'])
+    with GM.leaf_stream(y2, dzc, st3):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), y2, dzc, G[f'{p}.conv.net.2.weight'].view(256, 64),
+                          G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
+                          pb=P[f'{p}.conv.net.0.bias'])
     Wpw1T = _w(P, (f'{p}.conv.net.2.weight', 'T'), lambda: _T(Wpw1))
     if FUSE_LN_BWD and GM.LINEAR_PRECISION == 2:
         # input-gradient GEMM + the LayerNorm backward on its accumulators: the [M, 64] product never goes to memory
@@ -474,8 +479,9 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     do = torch.empty(M, 64, device=dev, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa),
                 dy2, _w(P, (f'{p}.attn.fn.to_out.weight', 'T'), lambda: _T(Wo)), do)
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa), o, dy2,
-                      G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
+    with GM.leaf_stream(o, dy2):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa), o, dy2,
+                          G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25)
     WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv))
@@ -485,11 +491,12 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     adjacent = gq.is_contiguous() and gkv.is_contiguous() and gq.data_ptr() + gq.numel() * 4 == gkv.data_ptr()
     dWqkv = torch.as_strided(gq, (192, 64), (64, 1)) if adjacent and gq.untyped_storage().nbytes() - gq.storage_offset() * 4 >= 192 * 64 * 4 \
         else O.zeros(192, 64, device=dev)
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, dqkv, dWqkv, None, rowstats=st2,
-                      ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
-    if dWqkv.data_ptr() != gq.data_ptr():
-        gq += dWqkv[:64]
-        gkv += dWqkv[64:]
+    with GM.leaf_stream(y1, dqkv, st2):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, dqkv, dWqkv, None, rowstats=st2,
+                          ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
+        if dWqkv.data_ptr() != gq.data_ptr():
+            gq += dWqkv[:64]
+            gkv += dWqkv[64:]
     if FUSE_LN_BWD and GM.LINEAR_PRECISION == 2:
         dy1 = GM.gemm_ln_bwd(dqkv, WqkvT, y1, st2, P[f'{p}.attn.norm.weight'], dy2, G[f'{p}.attn.norm.weight'],
                              G[f'{p}.attn.norm.bias'])
@@ -558,8 +565,9 @@ def mask_decoder_bwd(P, G, ctx, dmask, B, T, Fq):
     dbias1 = O.zeros(4, device=dev)
     dS = conv_bwd(ctx['S'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv_1.weight'], 4), TAPS_1x2, dr, T, Fo, dw1, dbias1,
                   wd=_w(P, (f'{p}.conv_1.weight', 'dgrad'), lambda: None))
-    G[f'{p}.conv_1.weight'] += dw1[:1]
-    G[f'{p}.conv_1.bias'] += dbias1[:1]
+    with GM.leaf_stream(dw1, dbias1):            # dw1 / dbias1 are written on the weight-gradient stream (conv_bwd)
+        G[f'{p}.conv_1.weight'] += dw1[:1]
+        G[f'{p}.conv_1.bias'] += dbias1[:1]
     dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq)
     dskip = dense_block_bwd(P, G, f'{p}.dense_block', ctx['dense'], dd4, B, T, Fq)
     return dskip        # slab 0 = input gradient
@@ -601,8 +609,9 @@ def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
     dbc = O.zeros(4, device=dev)
     da = conv_bwd(ctx['a'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv.weight'], 4), TAPS_1x2, dcplx, T, Fo, dwc, dbc,
                   wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None))
-    G[f'{p}.conv.weight'] += dwc[:2]
-    G[f'{p}.conv.bias'] += dbc[:2]
+    with GM.leaf_stream(dwc, dbc):               # written on the weight-gradient stream (conv_bwd)
+        G[f'{p}.conv.weight'] += dwc[:2]
+        G[f'{p}.conv.bias'] += dbc[:2]
     dS = inorm_prelu_bwd(ctx['S'], ctx['mr'], P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], da,
                          64, 0, G[f'{p}.norm.weight'], G[f'{p}.norm.bias'], G[f'{p}.prelu.weight'])
     dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq)
