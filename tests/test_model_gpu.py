@@ -724,12 +724,14 @@ def test_world1_hooks_equal_plain_step(S):
 
 @pytest.mark.parametrize('arch', ['cmgan', 'scp'])
 def test_streams_do_not_change_the_step(S, arch):
-    """HIP-stream concurrency inside a step (weight gradients on a leaf stream during the generator backward, the discriminator
-    step on a side stream beside it) against the fully serial order: losses and EVERY parameter of both models after two SGD
-    steps, per tensor.  Weight gradients accumulate with fp32 atomics, so two SERIAL runs already differ in the last digits (more
-    for the ill-conditioned first layers): the noise floor is measured with a second serial run, and the run with streams has to
-    stay within a small multiple of it -- a gradient consumed before its stream had written it would be off by its whole
-    contribution."""
+    """HIP-stream concurrency inside a step (weight gradients on a leaf stream during the generator backward; + the two-stage
+    backward with the discriminator step on a side stream) against the fully serial order: losses and EVERY parameter of both
+    models after two SGD steps, per tensor, relative to the size of that tensor's update.  Weight gradients accumulate with fp32
+    atomics over ~100 row chunks whose partial sums cancel, so two serial runs already differ by up to a few 1e-4 of the update
+    (measured: tools/streams_diag.py; back-to-back runs much less, later ones more -- the order follows the clocks); the
+    two-stage backward additionally re-orders the sum of the contributions to d loss / d est (1e-7, amplified by the
+    ill-conditioned first layers).  A gradient consumed before its stream had written it would be off by its WHOLE contribution
+    (the padded 1- / 2-channel convolutions were, before their accumulate moved to the leaf stream)."""
     import types
     from speech_enhancement_amd import train as TR, optim, gemm as GM
     torch.manual_seed(5)
@@ -739,26 +741,33 @@ def test_streams_do_not_change_the_step(S, arch):
               'noisy': torch.tensor([0.3, 0.2, 0.25, 0.35], device='cuda')}
     w = (0.1, 0.9, 0.2, 0.05) if arch == 'cmgan' else (0.3, 0.7, 0.2, 0.05)
     saved = (GM._LeafStream.enabled, TR._D_OVERLAP)
-    res = []
+    res, init = [], None
     try:
-        for streams in (False, False, True):
-            GM._LeafStream.enabled, TR._D_OVERLAP = streams, streams
+        for leaf, dside in ((False, False), (True, False), (True, True)):
+            GM._LeafStream.enabled, TR._D_OVERLAP = leaf, dside
             g, d = load_g(S), load_d(S)
+            named = lambda: list(g.named_parameters()) + [('D.' + n, p) for n, p in d.named_parameters()]
+            if init is None:
+                init = {n: p.detach().clone() for n, p in named()}
             args = types.SimpleNamespace(optimizer='sgd', lr=0.01, weight_decay=0.01, momentum=0.9, max_norm=0.0)
             og, od = optim.build_optimizer(args, g), optim.build_optimizer(args, d, lr=0.02)
             outs = [TR.gan_step(g, d, og, od, clean, noisy, arch, w, labels=labels) for _ in range(2)]     # 2 steps: recycled scratch
             torch.cuda.synchronize()
-            res.append(([{k: float(v) for k, v in o.items()} for o in outs],
-                        {n: p.detach().clone() for n, p in list(g.named_parameters()) + [('D.' + n, p) for n, p in d.named_parameters()]}))
+            res.append(([{k: float(v) for k, v in o.items()} for o in outs], {n: p.detach().clone() for n, p in named()}))
     finally:
         GM._LeafStream.enabled, TR._D_OVERLAP = saved
-    for o0, o1 in zip(res[0][0], res[2][0]):
-        for k in o0:
-            assert abs(o0[k] - o1[k]) <= 1e-4 * abs(o0[k]) + 1e-7, (k, o0[k], o1[k])
+    for other in (1, 2):
+        for o0, o1 in zip(res[0][0], res[other][0]):
+            for k in o0:
+                assert abs(o0[k] - o1[k]) <= 1e-4 * abs(o0[k]) + 1e-7, (other, k, o0[k], o1[k])
     bad = []
     for n, p0 in res[0][1].items():
-        noise = float((p0 - res[1][1][n]).abs().max())
-        diff = float((p0 - res[2][1][n]).abs().max())
-        if diff > 5 * noise + 2e-7 * max(1.0, float(p0.abs().max())):
-            bad.append((n, diff, noise))
+        scale = max(1.0, float(p0.abs().max()))
+        upd = float((p0 - init[n]).abs().max())
+        d_leaf = float((p0 - res[1][1][n]).abs().max())
+        d_all = float((p0 - res[2][1][n]).abs().max())
+        if d_leaf > 2e-3 * upd + 5e-7 * scale:
+            bad.append(('leaf stream', n, d_leaf, upd))
+        if d_all > 1e-2 * upd + 1e-6 * scale:
+            bad.append(('all streams', n, d_all, upd))
     assert not bad, bad[:10]
