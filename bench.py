@@ -181,7 +181,30 @@ def main():
     bad = [k for k, v in out.items() if hasattr(v, 'item') and not torch.isfinite(v).all()]
     if bad:
         sys.exit(f'bench.py: non-finite loss terms after the timed steps: {bad}')
-    summ = _lib.TIMER.summary()
+    conc = _lib.TIMER.summary()          # timed region: weight-gradient and discriminator streams on -> launches overlap
+    # Per-kernel attribution: with the streams on a launch's elapsed time is not the kernel's own (kernels of three streams share
+    # the machine).  The roofline object is therefore measured on 2 extra steps in SERIAL stream order right after the timed
+    # region (same process, same buffers, HIP events per launch); `value` / `ms_per_step` above are the timed region's.
+    from speech_enhancement_amd import gemm as _GM
+    _saved = (_GM._LeafStream.enabled, TR._D_OVERLAP)
+    a_steps = a.steps
+    serial_steps = 2 if (world == 1 and not force_dp) else 0      # N > 1: the other ranks have left; attribution from the timed region
+    if serial_steps:
+        try:
+            _GM._LeafStream.enabled, TR._D_OVERLAP = False, False
+            step()
+            torch.cuda.synchronize()
+            _lib.TIMER.start()
+            for _ in range(serial_steps):
+                step()
+            torch.cuda.synchronize()
+            _lib.TIMER.stop()
+        finally:
+            _GM._LeafStream.enabled, TR._D_OVERLAP = _saved
+        summ = _lib.TIMER.summary()
+        a = argparse.Namespace(**{**vars(a), 'steps': serial_steps})  # per-step figures of the roofline object: serial pass
+    else:
+        summ = conc
     dom = max(summ.items(), key=lambda kv: kv[1]['ms']) if summ else None
     roof = None
     if dom is not None:
@@ -211,14 +234,21 @@ def main():
                 note = 'algorithmic fp32 FLOPs; peak = dense fp32 MFMA (v_mfma_f32_*)'
             roof = {'bound': 'mfma', 'kernel': k, 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'mfma_busy_pct_pmc': mfma_busy, 'note': note}
+        cv = conc.get(k)
         roof.update({'launches_per_step': v['launches'] // a.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
-                     'share_of_step_time': round(v['ms'] / (dt * 1e3), 3),
+                     'avg_launch_ms_in_timed_region': round(cv['ms'] / cv['launches'], 4) if cv else None,
+                     'measured_on': (f'{serial_steps} extra steps in serial stream order after the timed region (in the timed region '
+                                     f'the discriminator and weight-gradient streams overlap with this kernel: elapsed time per '
+                                     f'launch is then not the kernel\'s own)') if serial_steps else
+                                    'the timed region (launches of the three streams overlap: elapsed time per launch is not the kernel\'s own)',
+                     'share_of_step_time': round(v['ms'] / a.steps / (dt / a_steps * 1e3), 3),
                      'families': {kk: ({'ms_per_step': round(vv['ms'] / a.steps, 3),
                                         'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)} if vv['flops'] > 0 else
                                        {'ms_per_step': round(vv['ms'] / a.steps, 3),      # HBM-bound families: algorithmic bytes
                                         'gbs': round(vv['bytes'] / (vv['ms'] * 1e-3) / 1e9, 1),
                                         'frac_of_hbm_peak': round(vv['bytes'] / (vv['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)})
                                   for kk, vv in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}})
+    a = argparse.Namespace(**{**vars(a), 'steps': a_steps})
     res = {
         'metric': 'utterances/sec (2 s @16 kHz) CMGAN train step', 'value': round(world * B * a.steps / dt, 3),
         'unit': 'utterances/sec', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
