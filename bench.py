@@ -186,12 +186,12 @@ def main():
     # the machine).  The roofline object is therefore measured on 2 extra steps in SERIAL stream order right after the timed
     # region (same process, same buffers, HIP events per launch); `value` / `ms_per_step` above are the timed region's.
     from speech_enhancement_amd import gemm as _GM
-    _saved = (_GM._LeafStream.enabled, TR._D_OVERLAP)
+    _saved = (_GM._LeafStream.enabled, TR._D_OVERLAP, _GM.branch_stream.enabled)
     a_steps = a.steps
     serial_steps = 2 if (world == 1 and not force_dp) else 0      # N > 1: the other ranks have left; attribution from the timed region
     if serial_steps:
         try:
-            _GM._LeafStream.enabled, TR._D_OVERLAP = False, False
+            _GM._LeafStream.enabled, TR._D_OVERLAP, _GM.branch_stream.enabled = False, False, False
             step()
             torch.cuda.synchronize()
             _lib.TIMER.start()
@@ -200,7 +200,7 @@ def main():
             torch.cuda.synchronize()
             _lib.TIMER.stop()
         finally:
-            _GM._LeafStream.enabled, TR._D_OVERLAP = _saved
+            _GM._LeafStream.enabled, TR._D_OVERLAP, _GM.branch_stream.enabled = _saved
         summ = _lib.TIMER.summary()
         a = argparse.Namespace(**{**vars(a), 'steps': serial_steps})  # per-step figures of the roofline object: serial pass
     else:

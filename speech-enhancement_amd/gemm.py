@@ -114,6 +114,45 @@ class leaf_stream:
         return False
 
 
+class branch_stream:
+    """`with branch_stream(*inputs) as br: ...; br.join()` -- an independent branch of the graph (the complex decoder beside the
+    mask decoder) on a second stream: it waits for an event recorded on the current stream on entry (its inputs are ready),
+    `join()` makes the current stream wait for it.  Tensors it allocates belong to its stream's pool; they are only read by the
+    main stream after `join()`, and the branch stream re-uses a freed block only after its next entry event, i.e. after every
+    main-stream reader queued so far.  The inputs must stay referenced until `join()` (they do: locals of the caller).
+    SE_NO_BRANCH_STREAM=1: the branch runs inline."""
+    enabled = __import__('os').environ.get('SE_NO_BRANCH_STREAM') != '1'
+    streams = {}
+
+    def __init__(self, *tensors):
+        self.dev = tensors[0].device if tensors and tensors[0] is not None and tensors[0].is_cuda else None
+        self.ctx = self.side = self.main = None
+
+    def __enter__(self):
+        if not (branch_stream.enabled and self.dev is not None):
+            return self
+        k = self.dev.index
+        if k not in branch_stream.streams:
+            branch_stream.streams[k] = torch.cuda.Stream(device=self.dev)
+        self.main, self.side = torch.cuda.current_stream(self.dev), branch_stream.streams[k]
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+
+
 def leaf_begin():
     _LeafStream.active = _LeafStream.enabled
 

@@ -637,8 +637,11 @@ def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed
         tok, c2 = conformer_fwd(P, f'TSCB_{i}.freq_conformer', tok, B, T, Fp, 'freq', train, dp, buffers, drop,
                                 site_seed(seed, 101 + 2 * i))
         ctx['tscb'].append((c1, c2))
+    # the two decoders are independent branches (models/generator.py:154-156): the complex decoder runs on a second stream
+    with GM.branch_stream(tok) as br:
+        cplx, ctx['cplx'] = complex_decoder_fwd(P, tok, B, T, Fp)
     mask, ctx['mask'] = mask_decoder_fwd(P, tok, B, T, Fp)
-    cplx, ctx['cplx'] = complex_decoder_fwd(P, tok, B, T, Fp)
+    br.join()
     est = O.assemble(mask, 1, xin, cplx)
     ctx['est'] = est
     return est, ctx
@@ -652,10 +655,12 @@ def tscnet_bwd(P, G, ctx, dest, dp=NO_DP):
     dmask = torch.empty(B * T * Fq, device=dev, dtype=torch.float32)
     dcplx = torch.empty(B, T, Fq, 4, device=dev, dtype=torch.float32)
     O.assemble_bwd(ctx['est'], dest, ctx['xin'], dmask, 1, dcplx)
-    dsk_c = complex_decoder_bwd(P, G, ctx['cplx'], dcplx, B, T, Fp)
+    with GM.branch_stream(dcplx) as br:       # the decoder branches are independent in the backward too
+        dsk_c = complex_decoder_bwd(P, G, ctx['cplx'], dcplx, B, T, Fp)
     dsk_m = mask_decoder_bwd(P, G, ctx['mask'], dmask, B, T, Fp)
+    br.join()
     dtok = (dsk_c[..., :64] + dsk_m[..., :64]).reshape(B * T * Fp, 64)      # plumbing: sum of the two decoder branches
-    del dsk_c, dsk_m
+    del dsk_c, dsk_m, dcplx
     ctx['cplx'] = ctx['mask'] = None
     for i in (4, 3, 2, 1):
         c1, c2 = ctx['tscb'][i - 1]

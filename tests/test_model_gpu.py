@@ -740,11 +740,11 @@ def test_streams_do_not_change_the_step(S, arch):
     labels = {'est': torch.tensor([0.4, 0.6, 0.5, 0.7], device='cuda'), 'clean': torch.full((4,), 0.96, device='cuda'),
               'noisy': torch.tensor([0.3, 0.2, 0.25, 0.35], device='cuda')}
     w = (0.1, 0.9, 0.2, 0.05) if arch == 'cmgan' else (0.3, 0.7, 0.2, 0.05)
-    saved = (GM._LeafStream.enabled, TR._D_OVERLAP)
+    saved = (GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled)
     res, init = [], None
     try:
         for leaf, dside in ((False, False), (True, False), (True, True)):
-            GM._LeafStream.enabled, TR._D_OVERLAP = leaf, dside
+            GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled = leaf, dside, leaf      # decoder branch stream too
             g, d = load_g(S), load_d(S)
             named = lambda: list(g.named_parameters()) + [('D.' + n, p) for n, p in d.named_parameters()]
             if init is None:
@@ -755,7 +755,7 @@ def test_streams_do_not_change_the_step(S, arch):
             torch.cuda.synchronize()
             res.append(([{k: float(v) for k, v in o.items()} for o in outs], {n: p.detach().clone() for n, p in named()}))
     finally:
-        GM._LeafStream.enabled, TR._D_OVERLAP = saved
+        GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled = saved
     for other in (1, 2):
         for o0, o1 in zip(res[0][0], res[other][0]):
             for k in o0:
