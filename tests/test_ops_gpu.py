@@ -81,7 +81,11 @@ def test_batchnorm_swish_bwd_and_running_stats():
     assert relerr(dx, x64.grad) < 5e-5 and relerr(dg, g64.grad) < 5e-5 and relerr(db, b64.grad) < 5e-5
 
 
-@pytest.mark.parametrize('axis,B,T,Fq', [('time', 2, 70, 5), ('freq', 2, 3, 101), ('time', 1, 321, 2), ('freq', 1, 2, 17)])
+@pytest.mark.parametrize('axis,B,T,Fq', [('time', 2, 70, 5), ('freq', 2, 3, 101), ('time', 1, 321, 2), ('freq', 1, 2, 17),
+                                         # tile-size boundaries of the kernel: 64 | 65 (8 -> 13 positions per slot), 104 | 105
+                                         # (13 -> 14), 112 | 113 (one -> two tiles), and a long sequence (15 tiles)
+                                         ('freq', 1, 2, 64), ('freq', 1, 2, 65), ('freq', 2, 1, 104), ('freq', 1, 2, 105),
+                                         ('time', 1, 112, 3), ('time', 1, 113, 2), ('time', 1, 1601, 1)])
 def test_dwconv31(axis, B, T, Fq):
     from speech_enhancement_amd import ops as O, attention as A
     x = rnd(B, T, Fq, 128, seed=1)
