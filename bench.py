@@ -189,6 +189,8 @@ def main():
     _saved = (_GM._LeafStream.enabled, TR._D_OVERLAP, _GM.branch_stream.enabled)
     a_steps = a.steps
     serial_steps = 2 if (world == 1 and not force_dp) else 0      # N > 1: the other ranks have left; attribution from the timed region
+    if not any(_saved):
+        serial_steps = 0                                           # SE_NO_*_STREAM / SE_NO_D_OVERLAP: the timed region is serial already
     if serial_steps:
         try:
             _GM._LeafStream.enabled, TR._D_OVERLAP, _GM.branch_stream.enabled = False, False, False
@@ -240,7 +242,8 @@ def main():
                      'measured_on': (f'{serial_steps} extra steps in serial stream order after the timed region (in the timed region '
                                      f'the discriminator and weight-gradient streams overlap with this kernel: elapsed time per '
                                      f'launch is then not the kernel\'s own)') if serial_steps else
-                                    'the timed region (launches of the three streams overlap: elapsed time per launch is not the kernel\'s own)',
+                                    ('the timed region (serial stream order)' if not any(_saved) else
+                                     'the timed region (launches of the three streams overlap: elapsed time per launch is not the kernel\'s own)'),
                      'share_of_step_time': round(v['ms'] / a.steps / (dt / a_steps * 1e3), 3),
                      'families': {kk: ({'ms_per_step': round(vv['ms'] / a.steps, 3),
                                         'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)} if vv['flops'] > 0 else

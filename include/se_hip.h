@@ -197,6 +197,10 @@ int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const
  * [tokens][4].  token(s,p) = (s/inner)*outer_stride + (s%inner)*inner_stride + p*pos_stride. */
 int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq, int n, int inner,
                 long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
+/* the same with the embedding table also handed over PRE-SPLIT (se_weight_prep: three bf16 planes [2*maxpos+1][16], es_plane
+ * elements apart; Es may be NULL): the split-bf16 forward kernel then loads its E fragments instead of splitting them per key step */
+int se_attn_fwd_es(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
+                   int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
 /* backward: dQKV [tokens][192] written, dE accumulated (caller zeroes); ws = workspace of
  * se_attn_bwd_workspace_bytes(ntok, maxpos, nseq, n) bytes, 16-byte aligned (softmax row constants, bf16-split and
  * transposed copies of E, per-wave dE tiles).  Sequences whose padded length fits the offset table (16 * ceil(n / 16) <= maxpos, the

@@ -15,13 +15,15 @@ def seq_geometry(B, T, Fq, axis):
     return (B * T, Fq, 1, Fq, 0, 1)
 
 
-def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True):
-    L.check_cuda(qkv, E)
+def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None):
+    """Es: optional pre-split planes [3, 2*maxpos+1, 16] bf16 of E (weights.WeightPlan)"""
+    L.check_cuda(qkv, E, Es)
     ntok = qkv.shape[0]
     O = torch.empty(ntok, 64, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32) if need_lse else None
     nseq, n, inner, os_, is_, ps = geom
-    L.call('se_attn_fwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner),
+    L.call('se_attn_fwd_es', L.ptr(qkv), L.ptr(E), L.ptr(Es), C.c_long(Es.stride(0) if Es is not None else 0), L.ptr(O),
+           L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner),
            C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos), C.c_float(scale), L.stream(),
            _key=('attn_fwd3_bf16x6' if (n + 15) // 16 * 16 <= 1200 else 'attn_fwd_kernel'), _flops=nseq * 4 * 3 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 256)
     return O, lse

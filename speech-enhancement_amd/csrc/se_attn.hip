@@ -33,6 +33,8 @@ struct AttnArgs {
   float* LSE;        // [tokens][4]   log-sum-exp of the scaled logits (natural log)
   int maxpos;
   float scale;
+  const void* Es;    // optional: E pre-split into three bf16 planes [3][2*maxpos+1][16] (se_weight_prep), es_plane elements apart
+  long es_plane;
 };
 
 static __device__ __forceinline__ long tok_of(const AttnGeom& g, int s, int p) {
@@ -1276,10 +1278,17 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   const float l2e = 1.4426950408889634f * a.scale;
   const int qblocks = (n + 16 * TQ - 1) / (16 * TQ), nkt = (n + 15) / 16;
   const int trrow = c >> 2, trcol = c & 3;
-  auto e_row = [&](int D) {                   // E[clamp(D + c)][4g..4g+3]: the A operand rows are offsets
+  const __bf16* Esp = reinterpret_cast<const __bf16*>(a.Es);
+  auto e_row = [&](int D) -> S3 {             // E[clamp(D + c)][4g..4g+3], split: the A operand rows are offsets
     int d = D + c;
     d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
-    return *reinterpret_cast<const float4*>(a.E + (unsigned)((d + a.maxpos) * 16 + 4 * g));
+    const unsigned eo = (unsigned)((d + a.maxpos) * 16 + 4 * g);
+    if (Esp) {                                 // pre-split table: three 8-byte loads instead of a 16-byte load + an 18-instruction split
+      S3 r;
+      set_h(r, ld8(Esp + eo)); set_m(r, ld8(Esp + a.es_plane + eo)); set_l(r, ld8(Esp + 2 * a.es_plane + eo));
+      return r;
+    }
+    return split3(*reinterpret_cast<const float4*>(a.E + eo));
   };
   auto k_row = [&](int j0) {                  // K[j0 + c][4g..4g+3]
     int kj = j0 + c; if (kj > n - 1) kj = n - 1;
@@ -1307,12 +1316,13 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
     // E fragments depend only on the offset base, so one new fragment per step serves all TQ tiles (rotated in registers)
     S3 ef[TQ + 1];                             // ef[t + 1] = E rows at base i0 + 16 t - j0 (hi of tile t), ef[0]: lo of tile 0
 #pragma unroll
-    for (int t = 0; t < TQ; ++t) { ef[t + 1] = split3(e_row(i0 + 16 * t)); u_tile(ef[t + 1], t, 0); }
-    float4 enext = e_row(i0 - 16), knext = k_row(0);
+    for (int t = 0; t < TQ; ++t) { ef[t + 1] = e_row(i0 + 16 * t); u_tile(ef[t + 1], t, 0); }
+    S3 enext = e_row(i0 - 16);
+    float4 knext = k_row(0);
     int hi = 0;
     for (int kt = 0; kt < nkt; ++kt) {
       const int j0 = kt * 16, lo = hi ^ 1;
-      ef[0] = split3(enext);
+      ef[0] = enext;
       const S3 kf = split3(knext);
       if (kt + 1 < nkt) { enext = e_row(i0 - j0 - 32); knext = k_row(j0 + 16); }      // one step ahead
 #pragma unroll
@@ -1372,10 +1382,26 @@ static int check_geom(const AttnGeom& g) {
   return 0;
 }
 
+static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
+                         int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
+
 extern "C" int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq, int n, int inner,
                            long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale,
                            void* stream) {
-  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale};
+  return attn_fwd_impl(QKV, E, nullptr, 0, O, LSE, nseq, n, inner, outer_stride, inner_stride, pos_stride, maxpos, scale, stream);
+}
+
+extern "C" int se_attn_fwd_es(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq,
+                              int n, int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale,
+                              void* stream) {
+  SE_REQUIRE(Es == nullptr || (es_plane >= (long)(2 * maxpos + 1) * 16 && (es_plane % 4) == 0 && ((size_t)Es & 7) == 0),
+             "attn_fwd_es: the pre-split table needs planes of >= (2 maxpos + 1) * 16 elements, 8-byte aligned");
+  return attn_fwd_impl(QKV, E, Es, es_plane, O, LSE, nseq, n, inner, outer_stride, inner_stride, pos_stride, maxpos, scale, stream);
+}
+
+static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
+                         int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream) {
+  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale, Es, es_plane};
   if (int e = check_geom(a.g)) return e;
   SE_REQUIRE(QKV && E && O, "attn_fwd: null operand");
   const int NP = ((n + 15) / 16) * 16;

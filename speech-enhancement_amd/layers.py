@@ -195,6 +195,7 @@ def build_generator_plan(P, device):
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_q.weight'], planes=lpl, ld=192)
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_kv.weight'], planes=lpl, c_off=64)
             plan.linear_T((f'{a}.to_out.weight', 'T'), P[f'{a}.to_out.weight'])
+            plan.linear((f'{a}.rel_pos_emb.weight', 'es'), P[f'{a}.rel_pos_emb.weight'], planes=True)     # [3][2 maxpos + 1][16]
             n = f'{p}.conv.net.2.weight'
             plan.linear((n, 'lin'), P[n], planes=lpl)
             plan.linear_T((n, 'T'), P[n], planes=lpl)
@@ -382,7 +383,8 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
                 ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
     E = P[f'{p}.attn.fn.rel_pos_emb.weight']
     maxpos = (E.shape[0] - 1) // 2
-    o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25)
+    o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25,
+                        Es=_w(P, (f'{p}.attn.fn.rel_pos_emb.weight', 'es'), lambda: None))
     y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     sa = site_seed(seed, 2)
     GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if pa > 0 else 0), alpha=1.0,

@@ -20,7 +20,7 @@ import csv, json, os, re, shutil, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-steps_in_trace = 7
+steps_in_trace = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 
 
 def short(n):
