@@ -169,6 +169,12 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
     """dW (+ dbias) += scale * gradient: accumulates straight into the caller's (gradient) buffers."""
     L.check_cuda(A, dY, dW, dbias, rowstats, ps, pb)
     d.alpha = scale
+    if _LeafStream.active:          # safety net: whatever this launch reads is registered with the stream it runs on
+        cur = torch.cuda.current_stream(A.device)
+        if cur == _LeafStream.side(A.device):
+            for t in (A, dY, rowstats, ps, pb):
+                if t is not None:
+                    t.record_stream(cur)
     if chunks is None:
         M = d.B * d.To * d.Fo
         nblk = d.ntap * ((d.C + 63) // 64) * ((d.N + 63) // 64)
