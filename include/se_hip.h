@@ -35,8 +35,11 @@ enum {
   SE_EPI_STATS = 16,     /* per-(b, n) sum / sum-of-squares of the result (fp64 atomics) */
   SE_EPI_SWISH_GRAD = 32,/* Y = result * swish'(AUX[m][n])                              */
   SE_EPI_SHUFFLE2 = 64,  /* sub-pixel: channel r*No+c -> pixel 2f+r, channel c (N = 2*No) */
-  SE_EPI_DROP = 128      /* dropout on the (bias-added) result, mask = hash(epi_seed, m*N + n) (nn.Dropout after a
+  SE_EPI_DROP = 128,     /* dropout on the (bias-added) result, mask = hash(epi_seed, m*N + n) (nn.Dropout after a
                             Linear, conformer.py:94,141); in se_gemm_tap_wgrad: the same mask applied to dY      */
+  SE_EPI_ROWSTATS = 512  /* N == 64, row GEMM: AUX [M][2] receives (mean, rstd) over the 64 channels of every RESULT row,
+                            eps = 1e-5 -- the statistics of the nn.LayerNorm(64) that reads this output next
+                            (conformer.py:67,162), i.e. se_row_stats without its pass over the rows                  */
 };
 
 /* One "tap GEMM":  Y[m][n] = epi( sum_tap sum_c pro(A[src(m,tap)][a_off+c]) * W[n][tap*C+c] )
@@ -97,6 +100,11 @@ int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W, const flo
 int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
               const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid, float drop_p,
               unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream);
+/* the same, also writing (mean, rstd) (eps 1e-5) of every row of Y to out_stats [M][2] (may be NULL): the statistics of the
+   LayerNorm(64) that reads Y next */
+int se_ff_fwd_stats(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
+                    const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M, int hid,
+                    float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream);
 
 
 /* Fused input-gradient chain of the same feed-forward module (the backward of se_ff_fwd without the weight gradients):

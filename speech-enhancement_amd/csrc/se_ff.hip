@@ -12,6 +12,7 @@ struct FfArgs {
   const float* X; const float* rowstats; const float* gamma; const float* beta;
   const float* W1; const float* b1; const float* W2; const float* b2;
   float* H; float* Y; long M; int hid; float drop_p; unsigned seed_h, seed_o; float alpha;
+  float* out_stats;      // optional [M][2]: (mean, rstd) of the rows of Y (the next LayerNorm's statistics)
 };
 
 // WPL: W1 / W2 arrive pre-split (se_weight_prep: three bf16 planes each, 64 * hid elements apart): the weight blocks are
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
     __syncthreads();
   }
   // Y = X + alpha * Drop_o(acc + b2)
+  float4 kept[2][4];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -200,8 +202,29 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
         v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
       }
       const float4 xr = *reinterpret_cast<const float4*>(a.X + rg * 64 + n);
-      *reinterpret_cast<float4*>(a.Y + rg * 64 + n) =
-          make_float4(xr.x + a.alpha * v.x, xr.y + a.alpha * v.y, xr.z + a.alpha * v.z, xr.w + a.alpha * v.w);
+      const float4 yo = make_float4(xr.x + a.alpha * v.x, xr.y + a.alpha * v.y, xr.z + a.alpha * v.z, xr.w + a.alpha * v.w);
+      *reinterpret_cast<float4*>(a.Y + rg * 64 + n) = yo;
+      kept[nt][i] = yo;
+    }
+  }
+  if (a.out_stats) {      // (mean, rstd) of the rows of Y: a row's 64 channels sit in the 8 lanes cq = 0..7 of an rr group, two passes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long rg = m0 + wave * 32 + rr + 8 * i;
+      const bool ok = rg < a.M;
+      float sm = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) sm += ok ? (kept[nt][i].x + kept[nt][i].y) + (kept[nt][i].z + kept[nt][i].w) : 0.f;
+      sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+      const float mean = sm * (1.f / 64.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float a0 = kept[nt][i].x - mean, a1 = kept[nt][i].y - mean, a2 = kept[nt][i].z - mean, a3 = kept[nt][i].w - mean;
+        sq += ok ? (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3) : 0.f;
+      }
+      sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+      if (cq == 0 && ok) *reinterpret_cast<float2*>(a.out_stats + 2 * rg) = make_float2(mean, rsqrtf(sq * (1.f / 64.f) + 1e-5f));
     }
   }
 }
@@ -481,6 +504,13 @@ extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T
 extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
                          const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid,
                          float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
+  return se_ff_fwd_stats(X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, nullptr, M, hid, drop_p, seed_h, seed_o, alpha, precision,
+                         stream);
+}
+
+extern "C" int se_ff_fwd_stats(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
+                               const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M,
+                               int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
   SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && H && Y, "ff_fwd: null operand");
   SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_fwd: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
   const bool wpl = (precision & 16) != 0;
@@ -489,7 +519,7 @@ extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gam
   SE_REQUIRE(!wpl || (precision == 2 && (((size_t)W1 | (size_t)W2) & 15) == 0), "ff_fwd: pre-split weights need precision 2 and 16-byte alignment");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_fwd: drop_p=%f out of range", drop_p);
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_fwd: dropout index exceeds 32 bits");
-  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha};
+  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
   else if (wpl) hipLaunchKernelGGL((ff_fwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);

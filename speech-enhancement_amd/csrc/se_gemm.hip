@@ -672,6 +672,10 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   SE_REQUIRE(!(ep & SE_EPI_RESID) || R, "gemm: resid flag without R");
   SE_REQUIRE(!(ep & SE_EPI_SWISH_GRAD) || AUX, "gemm: swish-grad flag without AUX");
   SE_REQUIRE(!(ep & SE_EPI_STATS) || stats, "gemm: stats flag without buffer");
+  if (ep & SE_EPI_ROWSTATS)
+    SE_REQUIRE(AUX && d->N == 64 && d->C >= 32 && d->ntap == 1 && d->B == 1 && !(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | SE_EPI_SWISH_GRAD | SE_EPI_STATS)) &&
+               (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldr & 3) == 0 && (d->r_off & 3) == 0,
+               "gemm: SE_EPI_ROWSTATS needs a row GEMM with N == 64, AUX = [M][2] and a vector-epilogue layout");
   SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
   if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");

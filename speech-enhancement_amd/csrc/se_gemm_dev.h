@@ -145,6 +145,8 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
   const unsigned pdrop = (unsigned)ptile;
   const int col = lane & 31, half = lane >> 5;
   const int cq = lane & 7, rr = lane >> 3;          // read-back role: float4 column, row within an 8-row pass
+  const bool rowstats = (ep & SE_EPI_ROWSTATS) != 0;  // N == 64 (host-checked): the 8 lanes cq = 0..7 of an rr group hold a whole row
+  float4 kept[2][4];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const f32x16& acc = nt ? acc1 : acc0;
@@ -180,6 +182,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
         if (ep & SE_EPI_ACCUM) { float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *yp = v;
+        if (rowstats) kept[nt][i] = v;
       }
     }
     if (ep & SE_EPI_STATS) {      // fold the 8 row-lanes that share this column group, park per-wave partials in LDS
@@ -190,6 +193,28 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) { red[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sv[j]; red[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sv[4 + j]; }
       }
+    }
+  }
+  if (rowstats) {
+    // (mean, rstd) over the 64 channels of every RESULT row -- the statistics the next LayerNorm(64) needs (se_row_stats on Y):
+    // two passes over the values still in registers, exactly like row_stats64_kernel
+    float* __restrict__ So = g.AUX + 2 * ptile;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 32 + rr + 8 * i;
+      float sm = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) sm += (kept[nt][i].x + kept[nt][i].y) + (kept[nt][i].z + kept[nt][i].w);
+      sm += __shfl_xor(sm, 1, 64); sm += __shfl_xor(sm, 2, 64); sm += __shfl_xor(sm, 4, 64);
+      const float mean = sm * (1.f / 64.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float a0 = kept[nt][i].x - mean, a1 = kept[nt][i].y - mean, a2 = kept[nt][i].z - mean, a3 = kept[nt][i].w - mean;
+        sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+      sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
+      if (cq == 0 && m0 + row < Mb) *reinterpret_cast<float2*>(So + 2 * row) = make_float2(mean, rsqrtf(sq * (1.f / 64.f) + 1e-5f));
     }
   }
   if (ep & SE_EPI_STATS) {

@@ -251,7 +251,8 @@ def unpack_conv_wgrad(dwp, dw, rev_slabs=False, accumulate=False):
                   accumulate=accumulate)
 
 
-def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None, hid=None):
+def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None, hid=None,
+           out_stats=False):
     """fused Scale(alpha, PreNorm(FeedForward)) forward (csrc/se_gemm.hip: ff_fwd_kernel): returns (Y, H) with
     H = W1 LN(x) + b1 kept for the backward."""
     L.check_cuda(x, rowstats, gamma, beta, W1, b1, W2, b2)
@@ -262,10 +263,13 @@ def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_
     H = torch.empty(M, hid, device=x.device, dtype=torch.float32)
     Y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     prec = LINEAR_PRECISION if precision is None else precision
-    L.call('se_ff_fwd', L.ptr(x), L.ptr(rowstats), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
-           L.ptr(H), L.ptr(Y), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF),
+    ost = torch.empty(M, 2, device=x.device, dtype=torch.float32) if out_stats else None     # (mean, rstd) of the rows of Y
+    L.call('se_ff_fwd_stats', L.ptr(x), L.ptr(rowstats), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
+           L.ptr(H), L.ptr(Y), L.ptr(ost), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF),
            C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec | (16 if pl else 0)), L.stream(),
            _key=f'ff_fwd_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid, _bytes=4.0 * M * (128 + hid))
+    if out_stats:
+        return Y, H, ost
     return Y, H
 
 

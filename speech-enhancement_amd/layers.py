@@ -32,6 +32,8 @@ WGRAD_PRECISION = [{'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_WGRA
 # input-gradient GEMM of the qkv / pointwise-GLU projections fused with the backward of the LayerNorm in front of them
 # (se_gemm_ln_bwd); SE_NO_LN_FUSE=1 keeps the two-kernel form for A/B runs
 FUSE_LN_BWD = _os.environ.get('SE_NO_LN_FUSE') != '1'
+# LayerNorm row statistics emitted by the producer of the rows instead of a separate se_row_stats pass (SE_NO_ROWSTATS_FUSE=1: A/B)
+FUSE_ROWSTATS = _os.environ.get('SE_NO_ROWSTATS_FUSE') != '1'
 
 
 def set_conv_precision(name, wgrad=None):
@@ -308,17 +310,24 @@ def site_seed(base, idx):
     return (base * 0x9E3779B1 + (idx + 1) * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF
 
 
-def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0):
+def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0, st=None, want_out_stats=False):
     """x + 0.5 * Drop(W2 Drop(Swish(W1 LN(x)))) (Scale(0.5, PreNorm(FeedForward)), conformer.py:53-71,128-145).
-    The two dropout masks are counter-based (hash(seed, element)) and re-evaluated in the backward."""
-    st = O.row_stats(x, M)
+    The two dropout masks are counter-based (hash(seed, element)) and re-evaluated in the backward.
+    st: (mean, rstd) of the rows of x when the producer of x already emitted them (SE_EPI_ROWSTATS); want_out_stats: also
+    return the statistics of the output rows (for the LayerNorm that reads them next) -- None when not produced here."""
+    if st is None:
+        st = O.row_stats(x, M)
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
     if GM.LINEAR_PRECISION in (1, 2) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0:
         # one fused kernel: the hidden activations are written once (for the backward) and never re-read here
-        y, z = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
+        res = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
                          _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1), P[f'{p}.fn.fn.net.0.bias'],
                          _w(P, (f'{p}.fn.fn.net.3.weight', 'lin'), lambda: W2), P[f'{p}.fn.fn.net.3.bias'], drop, seed_h,
-                         seed_o, 0.5, hid=W1.shape[0])
+                         seed_o, 0.5, hid=W1.shape[0], out_stats=want_out_stats)
+        if want_out_stats:
+            y, z, ost = res
+            return y, (x, st, z, drop, seed_h, seed_o), ost
+        y, z = res
         return y, (x, st, z, drop, seed_h, seed_o)
     z = torch.empty(M, 256, device=x.device, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, epilogue=L.EPI_BIAS), x, P[f'{p}.fn.fn.net.0.weight'], z,
@@ -329,6 +338,8 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0):
                                epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if dr else 0), alpha=0.5, ldr=64,
                                pro_seed=seed_h, epi_seed=seed_o, drop_p=drop),
                 z, P[f'{p}.fn.fn.net.3.weight'], y, bias=P[f'{p}.fn.fn.net.3.bias'], R=x)
+    if want_out_stats:
+        return y, (x, st, z, drop, seed_h, seed_o), None
     return y, (x, st, z, drop, seed_h, seed_o)
 
 
@@ -373,9 +384,13 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     geom = A.seq_geometry(B, T, Fq, axis)
     ctx = {'geom': geom}
     pf, pa = (drop if train else (0.0, 0.0))
-    y1, ctx['ff1'] = _ff_fwd(P, f'{p}.ff1', x, M, pf, site_seed(seed, 0), site_seed(seed, 1))
+    # LayerNorm statistics of y1 / y2 / y3 come out of the kernels that produce those rows (se_ff_fwd_stats, SE_EPI_ROWSTATS):
+    # three of the four se_row_stats passes of a block (26 us each, on the serial forward path) disappear
+    r1 = _ff_fwd(P, f'{p}.ff1', x, M, pf, site_seed(seed, 0), site_seed(seed, 1), want_out_stats=FUSE_ROWSTATS)
+    y1, ctx['ff1'], st2 = r1[0], r1[1], (r1[2] if len(r1) > 2 else None)
     # attention
-    st2 = O.row_stats(y1, M)
+    if st2 is None:
+        st2 = O.row_stats(y1, M)
     Wqkv = _w(P, (f'{p}.attn.fn', 'qkv'),
               lambda: torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0).contiguous())
     qkv = torch.empty(M, 192, device=x.device, dtype=torch.float32)
@@ -387,12 +402,14 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
                         Es=_w(P, (f'{p}.attn.fn.rel_pos_emb.weight', 'es'), lambda: None))
     y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     sa = site_seed(seed, 2)
-    GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if pa > 0 else 0), alpha=1.0,
-                               ldr=64, epi_seed=sa, drop_p=pa), o,
-                P[f'{p}.attn.fn.to_out.weight'], y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1)
+    st3 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if pa > 0 else 0) |
+                               (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64, epi_seed=sa, drop_p=pa), o,
+                P[f'{p}.attn.fn.to_out.weight'], y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1, AUX=st3)
     ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa)
     # conv module
-    st3 = O.row_stats(y2, M)
+    if st3 is None:
+        st3 = O.row_stats(y2, M)
     u = torch.empty(M, 128, device=x.device, dtype=torch.float32)
     zc = torch.empty(M, 256, device=x.device, dtype=torch.float32)
     Wpw1 = _w(P, (f'{p}.conv.net.2.weight', 'lin'), lambda: P[f'{p}.conv.net.2.weight'].view(256, 64))
@@ -418,10 +435,12 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     sh = ss[0, :, 1].contiguous()
     y3 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
-    GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=1.0,
-                               ldr=64), h, Wpw2, y3, bias=P[f'{p}.conv.net.7.bias'], R=y2, ps=sc, pb=sh)
+    st4 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None
+    GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID |
+                               (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64), h, Wpw2, y3,
+                bias=P[f'{p}.conv.net.7.bias'], R=y2, ps=sc, pb=sh, AUX=st4)
     ctx['conv'] = (y2, st3, zc, u, h, mr, sc, sh, count)
-    y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M, pf, site_seed(seed, 3), site_seed(seed, 4))
+    y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M, pf, site_seed(seed, 3), site_seed(seed, 4), st=st4)
     out, st5 = O.layernorm_fwd(y4, P[f'{p}.post_norm.weight'], P[f'{p}.post_norm.bias'], R=x)
     ctx['post'] = (y4, st5)
     return out, ctx

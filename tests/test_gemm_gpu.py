@@ -518,3 +518,31 @@ def test_gemm_ln_bwd_equals_gemm_then_layernorm_bwd(G, K, planes):
     y = torch.nn.functional.layer_norm(x64, (64,), g64, b64, 1e-5) @ W.double().T
     y.backward(dy.double())
     assert relerr(dX, x64.grad + dR.double()) < 5e-6 and relerr(dg, g64.grad) < 1e-5 and relerr(db, b64.grad) < 1e-5
+
+
+def test_row_statistics_from_producer_epilogues(G):
+    """SE_EPI_ROWSTATS (row GEMM, N == 64) and se_ff_fwd_stats: (mean, rstd) of the RESULT rows equal se_row_stats on the
+    stored result (same two-pass arithmetic on the same fp32 values), incl. a ragged last tile, dropout and a prologue."""
+    gemm, L = G
+    from speech_enhancement_amd import ops as O
+    M = 128 * 5 + 77
+    for K, pro in ((64, L.PRO_NONE), (128, L.PRO_AFFINE_SWISH)):
+        x, w, b, r = rnd(M, K, seed=1), rnd(64, K, seed=2, scale=K ** -0.5), rnd(64, seed=3), rnd(M, 64, seed=4)
+        sc, sh = rnd(K, seed=5) * 0.1 + 1, rnd(K, seed=6) * 0.1
+        y, st = torch.empty(M, 64, device='cuda'), torch.full((M, 2), float('nan'), device='cuda')
+        d = gemm.linear_desc(M, K, 64, prologue=pro, epilogue=L.EPI_BIAS | L.EPI_RESID | L.EPI_DROP | L.EPI_ROWSTATS, alpha=1.0,
+                             ldr=64, epi_seed=17, drop_p=0.2)
+        gemm.gemm_tap(d, x, w, y, bias=b, R=r, AUX=st, ps=sc, pb=sh)
+        ref = O.row_stats(y, M)
+        assert torch.isfinite(st).all() and relerr(st, ref) < 1e-6
+    x = rnd(M, 64, seed=7)
+    st_in = O.row_stats(x, M)
+    g, be = rnd(64, seed=8) * 0.1 + 1, rnd(64, seed=9) * 0.1
+    W1, W2, b1, b2 = rnd(256, 64, seed=10, scale=0.1), rnd(64, 256, seed=11, scale=0.05), rnd(256, seed=12) * 0.1, rnd(64, seed=13) * 0.1
+    y, h, ost = gemm.ff_fwd(x, st_in, g, be, W1, b1, W2, b2, 0.2, 3, 4, 0.5, precision=2, out_stats=True)
+    y2, h2 = gemm.ff_fwd(x, st_in, g, be, W1, b1, W2, b2, 0.2, 3, 4, 0.5, precision=2)
+    assert torch.equal(y, y2) and torch.equal(h, h2)
+    assert relerr(ost, O.row_stats(y, M)) < 1e-6
+    with pytest.raises(L.SeHipError):          # only whole 64-channel rows have row statistics
+        gemm.gemm_tap(gemm.linear_desc(M, 64, 128, epilogue=L.EPI_ROWSTATS), x, rnd(128, 64, seed=14), torch.empty(M, 128, device='cuda'),
+                      AUX=torch.empty(M, 2, device='cuda'))
