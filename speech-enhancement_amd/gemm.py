@@ -74,10 +74,13 @@ class _LeafStream:
     """Weight gradients are leaves of the backward graph: nothing downstream reads them before the optimizer step.  Inside the
     generator backward they are issued on a second HIP stream, behind an event recorded when their operands are ready, and run
     concurrently with the input-gradient chain on the main stream (joined before the optimizer step).  Operands the side stream
-    reads are registered with the caching allocator (record_stream) so that the main stream cannot recycle them early."""
+    reads are kept referenced until the join, so that the main stream cannot recycle their memory early.  (record_stream would
+    do the same without extending lifetimes, but blocks freed with a pending cross-stream event are not reusable until the
+    lagging leaf stream has passed them: the caching allocator then reserved 150 GB for a 32 GB working set.)"""
     enabled = __import__('os').environ.get('SE_NO_WGRAD_STREAM') != '1'
     active = False
     streams = {}
+    keep = []
 
     @classmethod
     def side(cls, device):
@@ -102,8 +105,7 @@ class leaf_stream:
         ev = torch.cuda.Event()
         ev.record(main)
         side.wait_event(ev)
-        for t in self.tensors:
-            t.record_stream(side)
+        _LeafStream.keep.extend(self.tensors)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return self
@@ -161,6 +163,7 @@ def leaf_join(device):
     """the main stream waits for every weight gradient issued so far (before the optimizer step / gradient all-reduce)"""
     if _LeafStream.active:
         torch.cuda.current_stream(device).wait_stream(_LeafStream.side(device))
+    _LeafStream.keep.clear()        # after the join: their memory returns to the main stream's pool with no cross-stream event
     _LeafStream.active = False
 
 
@@ -169,12 +172,8 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
     """dW (+ dbias) += scale * gradient: accumulates straight into the caller's (gradient) buffers."""
     L.check_cuda(A, dY, dW, dbias, rowstats, ps, pb)
     d.alpha = scale
-    if _LeafStream.active:          # safety net: whatever this launch reads is registered with the stream it runs on
-        cur = torch.cuda.current_stream(A.device)
-        if cur == _LeafStream.side(A.device):
-            for t in (A, dY, rowstats, ps, pb):
-                if t is not None:
-                    t.record_stream(cur)
+    if _LeafStream.active and torch.cuda.current_stream(A.device) == _LeafStream.side(A.device):
+        _LeafStream.keep.extend(t for t in (A, dY, rowstats, ps, pb) if t is not None)      # safety net: kept until the join
     if chunks is None:
         M = d.B * d.To * d.Fo
         nblk = d.ntap * ((d.C + 63) // 64) * ((d.N + 63) // 64)
