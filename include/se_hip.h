@@ -218,6 +218,14 @@ int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* d
                 long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws, size_t ws_bytes,
                 void* stream);
 
+/* se_attn_bwd in two phases (same arguments): phase 1 = everything but the reduction of the per-wave dE tiles, phase 2 = that
+ * reduction alone (reads ws, accumulates dE) -- a leaf of the backward graph that the caller may issue on another stream behind
+ * phase 1; phase 3 = both = se_attn_bwd.  Sequence shapes without per-wave tiles do everything in phase 1. */
+int se_attn_bwd_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
+                      float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
+                      long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws, size_t ws_bytes,
+                      int phase, void* stream);
+
 /* ---- depthwise conv k=31 along the sequence axis (csrc/se_dwconv.hip) -------------------------- */
 /* DepthWiseConv1d forward (models/conformer.py:40-48,166) on [tokens][128] (+ fp64 BatchNorm statistics
  * [128][2] when stats != NULL); flip=1 with bias=NULL is the input gradient. */

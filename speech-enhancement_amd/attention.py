@@ -29,8 +29,9 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None):
     return O, lse
 
 
-def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
-    """returns dQKV [ntok,192]; accumulates into dE [2*maxpos+1, 16]."""
+def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None):
+    """returns dQKV [ntok,192]; accumulates into dE [2*maxpos+1, 16].  leaf: optional context-manager factory (gemm.leaf_stream):
+    the reduction of the per-wave dE tiles -- a leaf of the backward graph -- is then issued inside `leaf(ws, ...)`."""
     L.check_cuda(qkv, E, O, dO, lse, dE)
     ntok = qkv.shape[0]
     dqkv = torch.empty(ntok, 192, device=qkv.device, dtype=torch.float32)
@@ -41,8 +42,15 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25):
     v3 = maxpos % 16 == 0 and npad + 128 <= maxpos and n <= 384
     key = ('attn_bwd3_bf16x6 (+delta, tables, dE reduce)' if v3 else
            'attn_bwd2_kernel (+delta)' if n <= 336 and maxpos >= 352 else 'attn_bwd_dkv + attn_bwd_dq (+delta)')
-    L.call('se_attn_bwd', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dqkv), L.ptr(dE),
-           C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
-           C.c_int(maxpos), C.c_float(scale), L.ptr(ws), C.c_size_t(nbytes), L.stream(),
-           _key=key + (' n>128' if n > 128 else ' n<=128'), _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
+    def run(phase, **kw):
+        L.call('se_attn_bwd_phase', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dqkv), L.ptr(dE),
+               C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
+               C.c_int(maxpos), C.c_float(scale), L.ptr(ws), C.c_size_t(nbytes), C.c_int(phase), L.stream(), **kw)
+    tk = dict(_key=key + (' n>128' if n > 128 else ' n<=128'), _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
+    if leaf is None:
+        run(3, **tk)
+    else:
+        run(1, **tk)
+        with leaf(ws, dE):
+            run(2)
     return dqkv

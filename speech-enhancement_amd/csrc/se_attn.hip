@@ -1484,7 +1484,7 @@ extern "C" size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, i
 }
 
 template <int KT, bool GROUP>
-static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float* dE) {
+static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float* dE, int phase) {
   using L3 = Lds3<KT>;
   const size_t sh = (size_t)4 * L3::WAVE + (GROUP ? 2 * 4 * 256 * sizeof(float) : 0);
   static bool raised = false;
@@ -1495,16 +1495,36 @@ static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float
   }
   const long items = (long)b.g.nseq * 4;
   const int nkt = (b.g.n + 15) / 16;
-  hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
-  hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 256)), dim3(256), 0, s, b.dEs, dE,
-                     nwitems, nkt, b.maxpos, b.R);
+  if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
+  if (phase & 2) hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 256)), dim3(256), 0, s, b.dEs,
+                                    dE, nwitems, nkt, b.maxpos, b.R);
   return 0;
 }
+
+static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
+                         float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
+                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream);
 
 extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                            float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
                            long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws,
                            size_t ws_bytes, void* stream) {
+  return attn_bwd_impl(QKV, E, O, dO, LSE, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
+                       ws, ws_bytes, 3, stream);
+}
+
+extern "C" int se_attn_bwd_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
+                                 float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
+                                 long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws,
+                                 size_t ws_bytes, int phase, void* stream) {
+  SE_REQUIRE(phase == 1 || phase == 2 || phase == 3, "attn_bwd_phase: phase must be 1, 2 or 3");
+  return attn_bwd_impl(QKV, E, O, dO, LSE, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
+                       ws, ws_bytes, phase, stream);
+}
+
+static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
+                         float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
+                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream) {
   SE_REQUIRE(QKV && E && O && dO && LSE && dQKV && dE && ws, "attn_bwd: null operand");
   SE_REQUIRE(ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0, "attn_bwd: bad sizes");
   const AttnWs w = attn_ws(ntok, maxpos, nseq, n);
@@ -1514,20 +1534,26 @@ extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, con
   AttnBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, dO, LSE, Dl, dQKV, dE, maxpos, scale, 0};
   if (int e = check_geom(a.g)) return e;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
   int kt3 = attn_v3_shape(n, maxpos);
   if (const char* e = getenv("SE_ATTN_BWD")) { if (atoi(e) == 2) kt3 = 0; }
-  if (kt3 && pos_stride * 192 * (long)(16 * ((n + 15) / 16)) < 2147483647L) {
+  const bool v3 = kt3 && pos_stride * 192 * (long)(16 * ((n + 15) / 16)) < 2147483647L;
+  // phase 2 = the reduction of the per-wave dE tiles alone (a leaf of the backward graph: the caller may issue it on another
+  // stream once phase 1 has been queued); only the decoupled kernel has one -- the other kernels do everything in phase 1
+  if (!(phase & 1) && !v3) return 0;
+  if (phase & 1) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
+  if (v3) {
     // decoupled split-bf16 kernel: one wave per (sequence, head[, key group]); no offset clamp can be active
     __bf16* Es = reinterpret_cast<__bf16*>((char*)ws + w.es);
     __bf16* Ets = reinterpret_cast<__bf16*>((char*)ws + w.ets);
-    SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.des - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
-    hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
+    if (phase & 1) {
+      SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.des - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
+      hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
+    }
     AttnBwd3Args b{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, dO, LSE, Dl, dQKV, Es, Ets,
                    reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0};
     if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
     const long items = (long)nseq * 4;
-    if (int e = (kt3 == 7 ? launch_bwd3<7, false>(b, items, s, dE) : launch_bwd3<6, true>(b, items * 4, s, dE))) return e;
+    if (int e = (kt3 == 7 ? launch_bwd3<7, false>(b, items, s, dE, phase) : launch_bwd3<6, true>(b, items * 4, s, dE, phase))) return e;
     return se_check_launch("se_attn_bwd");
   }
   // transposed table for the v2 kernel (fp32): built in the Ets region of the workspace

@@ -504,7 +504,8 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa), o, dy2,
                           G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
-                      G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25)
+                      G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25,
+                      leaf=None if _os.environ.get('SE_ATTN_DE_MAIN') == '1' else GM.leaf_stream)
     WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv))
     gq, gkv = G[f'{p}.attn.fn.to_q.weight'], G[f'{p}.attn.fn.to_kv.weight']
     # to_q / to_kv are neighbours in the flat gradient buffer of the optimizers: the [192, 64] gradient of the fused projection
