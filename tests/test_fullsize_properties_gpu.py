@@ -1,0 +1,158 @@
+"""Benchmark-size (BASELINE configs[1]: B = 16, T = 321, F = 201 / 101) property checks of the large-grid paths: XCD-aware work
+decode over ~10^4 workgroups, 32-bit lane offsets on 1 GB operands, whole-round chunking, sequence-sized tiles.  The oracle cannot
+run these sizes in seconds, so every check is a size-independent property: two independently written kernels for the same op
+agree, a transform inverts, an op is linear / equivariant, or a random SAMPLE of the output matches fp64 torch."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+B, T, Fe, Fp = 16, 321, 201, 101
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    return torch.randn(*shape, generator=g, device='cuda') * scale
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_stft_istft_round_trip_and_linearity():
+    from speech_enhancement_amd import frontend as FE
+    x = rnd(B, 32000, seed=1, scale=0.1)
+    win = torch.hamming_window(400, device='cuda')
+    for comp in ('pow', 'log', 'norm'):
+        spec = FE.compressed_stft(x, 400, 100, win, comp_type=comp)
+        assert spec.shape == (B, 201, 321)
+        y = FE.uncompressed_istft(spec, 400, 100, win, comp_type=comp)
+        assert y.shape == x.shape and relerr(y, x) < 2e-5, comp
+    # the un-compressed transform is linear
+    a, b_ = rnd(B, 32000, seed=2), rnd(B, 32000, seed=3)
+    sa, sb = FE.compressed_stft(a, 400, 100, win, comp_type='none'), FE.compressed_stft(b_, 400, 100, win, comp_type='none')
+    sab = FE.compressed_stft(a + 0.5 * b_, 400, 100, win, comp_type='none')
+    assert relerr(torch.view_as_real(sab), torch.view_as_real(sa + 0.5 * sb)) < 2e-6
+
+
+@pytest.mark.parametrize('layer', [3, 1])
+def test_dense_conv_triple_tap_kernels_vs_generic_kernels(layer):
+    """conv3 / wgrad3 (halo-tile kernels) against the generic tap kernels on the encoder's dilated dense layer at B = 16"""
+    from speech_enhancement_amd import gemm as GM, layers as LY, _lib as L
+    C = 64 * (layer + 1)
+    skip = rnd(B, T, Fe, 256, seed=1)
+    w = rnd(64, C, 2, 3, seed=2, scale=(6 * C) ** -0.5)
+    wp = GM.pack_conv_fwd(w)
+    bias = rnd(64, seed=3)
+    taps = LY.dense_taps(layer)
+    outs, grads = [], []
+    dR = rnd(B, T, Fe, 64, seed=4)
+    for no3 in (False, True):
+        with env(**({'SE_GEMM_NO_CONV3': '1'} if no3 else {})):
+            y = torch.empty(B, T, Fe, 64, device='cuda')
+            st = torch.zeros(B, 64, 2, device='cuda', dtype=torch.float64)
+            d = GM.make_desc(B, T, Fe, T, Fe, taps, C, 256, 64, 64, epilogue=L.EPI_BIAS | L.EPI_STATS, precision=2)
+            GM.gemm_tap(d, skip, wp, y, bias=bias, stats=st)
+            dwp = torch.zeros(64, 6 * C, device='cuda')
+            GM.gemm_tap_wgrad(GM.make_desc(B, T, Fe, T, Fe, taps, C, 256, 64, 64, precision=2), skip, dR, dwp, None)
+            outs.append((y, st))
+            grads.append(dwp)
+    assert relerr(outs[0][0], outs[1][0]) < 2e-6 and relerr(outs[0][1], outs[1][1]) < 1e-9
+    assert relerr(grads[0], grads[1]) < 2e-5
+    # a random sample of output pixels against fp64 conv2d (padding: dil rows on top only, 1 column each side)
+    g = torch.Generator().manual_seed(5)
+    dil = 2 ** layer
+    xs = skip[..., :C].double()
+    for _ in range(8):
+        b, t, f = int(torch.randint(B, (1,), generator=g)), int(torch.randint(T, (1,), generator=g)), int(torch.randint(Fe, (1,), generator=g))
+        acc = bias.double().clone()
+        for i, dt in enumerate((-dil, 0)):
+            for j, df in enumerate((-1, 0, 1)):
+                tt, ff = t + dt, f + df
+                if 0 <= tt < T and 0 <= ff < Fe:
+                    acc += w[:, :, i, j].double() @ xs[b, tt, ff]
+        assert relerr(outs[0][0][b, t, f], acc) < 5e-6
+
+
+def test_linear_weight_gradient_kernels_agree_at_bench_size():
+    from speech_enhancement_amd import gemm as GM, ops as O, _lib as L
+    M = B * T * Fp
+    x, dz = rnd(M, 64, seed=1), rnd(M, 256, seed=2)
+    st = O.row_stats(x, M)
+    g, b_ = rnd(64, seed=3) * 0.1 + 1, rnd(64, seed=4) * 0.1
+    res = []
+    for blocks in (True, False):
+        with env(**({'SE_WGRAD_NO_LIN': '1'} if blocks else {})):
+            dw, db = torch.zeros(256, 64, device='cuda'), torch.zeros(256, device='cuda')
+            GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, dw, db, rowstats=st, ps=g, pb=b_)
+            res.append((dw, db))
+    assert relerr(res[0][0], res[1][0]) < 5e-6 and relerr(res[0][1], res[1][1]) < 5e-6
+    # linear in dY
+    dw2 = torch.zeros(256, 64, device='cuda')
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz * 0.5, dw2, None, rowstats=st, ps=g, pb=b_)
+    assert relerr(dw2 * 2, res[1][0]) < 5e-6
+
+
+@pytest.mark.parametrize('axis', ['time', 'freq'])
+def test_attention_kernels_agree_and_are_sequence_local(axis):
+    """decoupled split-bf16 backward vs the fp32 lock-step backward (two independent kernels) at B = 16; changing ONE sequence
+    changes only that sequence's outputs (no cross-sequence leakage through the strided token geometry)"""
+    from speech_enhancement_amd import attention as A
+    ntok = B * T * Fp
+    qkv, dO = rnd(ntok, 192, seed=1), rnd(ntok, 64, seed=2)
+    E = rnd(1025, 16, seed=3, scale=0.5)
+    geom = A.seq_geometry(B, T, Fp, axis)
+    o, lse = A.attn_fwd(qkv, E, geom)
+    res = []
+    for mode in ('3', '2'):
+        with env(SE_ATTN_BWD=mode):
+            dE = torch.zeros_like(E)
+            res.append((A.attn_bwd(qkv, E, o, dO, lse, geom, dE), dE))
+    scale = float(res[1][0].abs().max())
+    assert float((res[0][0] - res[1][0]).abs().max()) < 2e-5 * scale
+    assert float((res[0][1] - res[1][1]).abs().max()) < 5e-5 * float(res[1][1].abs().max())
+    # sequence locality: perturb the tokens of one sequence
+    tok = torch.arange(ntok, device='cuda').view(B, T, Fp)
+    sel = tok[3, :, 7] if axis == 'time' else tok[5, 11, :]
+    q2 = qkv.clone()
+    q2[sel] += 1.0
+    o2, _ = A.attn_fwd(q2, E, geom)
+    changed = (o2 - o).abs().amax(1) > 0
+    assert bool(changed[sel].all()) and int(changed.sum()) == sel.numel()
+
+
+def test_depthwise_conv_sampled_sequences_and_linearity():
+    from speech_enhancement_amd import ops as O, attention as A
+    x = rnd(B * T * Fp, 128, seed=1)
+    w, b_ = rnd(128, 31, seed=2, scale=0.2), rnd(128, seed=3)
+    for axis in ('time', 'freq'):
+        geom = A.seq_geometry(B, T, Fp, axis)
+        st = torch.zeros(1, 128, 2, device='cuda', dtype=torch.float64)
+        y = O.dwconv31(x, w, b_, geom, stats=st)
+        assert relerr(st[0, :, 0], y.double().sum(0)) < 1e-6 and relerr(st[0, :, 1], (y.double() ** 2).sum(0)) < 1e-6
+        xv, yv = x.view(B, T, Fp, 128), y.view(B, T, Fp, 128)
+        for (bi, oi) in ((0, 0), (7, 50), (15, 100 if axis == 'time' else 320)):
+            seq_x = xv[bi, :, oi] if axis == 'time' else xv[bi, oi]           # [n, 128]
+            seq_y = yv[bi, :, oi] if axis == 'time' else yv[bi, oi]
+            ref = F.conv1d(F.pad(seq_x.double().t().unsqueeze(0), (15, 15)), w.double().unsqueeze(1), b_.double(), groups=128)[0].t()
+            assert relerr(seq_y, ref) < 1e-5
+        y2 = O.dwconv31(x * 0.5, w, None, geom)
+        assert relerr(y2 * 2 + b_, y) < 2e-6
