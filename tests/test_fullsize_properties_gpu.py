@@ -156,3 +156,51 @@ def test_depthwise_conv_sampled_sequences_and_linearity():
             assert relerr(seq_y, ref) < 1e-5
         y2 = O.dwconv31(x * 0.5, w, None, geom)
         assert relerr(y2 * 2 + b_, y) < 2e-6
+
+
+def test_fused_feed_forward_vs_separate_gemms_at_bench_size():
+    """the fused feed-forward module (forward; input-gradient chain + LayerNorm backward; in-place scaled weight gradients) against
+    the same module evaluated with separate fp32-MFMA GEMMs + the standalone LayerNorm backward, M = 518 736 tokens, dropout 0.2
+    (the counter-based masks are functions of (seed, element): identical in both evaluations)"""
+    from speech_enhancement_amd import layers as LY, gemm as GM
+    M = B * T * Fp
+    p = 'ff'
+    P = {f'{p}.fn.norm.weight': rnd(64, seed=1) * 0.1 + 1, f'{p}.fn.norm.bias': rnd(64, seed=2) * 0.1,
+         f'{p}.fn.fn.net.0.weight': rnd(256, 64, seed=3, scale=0.125), f'{p}.fn.fn.net.0.bias': rnd(256, seed=4) * 0.1,
+         f'{p}.fn.fn.net.3.weight': rnd(64, 256, seed=5, scale=0.0625), f'{p}.fn.fn.net.3.bias': rnd(64, seed=6) * 0.1}
+    x, dy = rnd(M, 64, seed=7), rnd(M, 64, seed=8)
+    res = []
+    saved = GM.LINEAR_PRECISION
+    try:
+        for prec in (2, 0):                       # 2: fused split-bf16 kernels; 0: separate fp32-MFMA GEMMs
+            GM.LINEAR_PRECISION = prec
+            G = {k: torch.zeros_like(v) for k, v in P.items()}
+            y, saved_ctx = LY._ff_fwd(P, p, x, M, 0.2, 11, 12)
+            dx = LY._ff_bwd(P, G, p, saved_ctx, dy, M)
+            torch.cuda.synchronize()
+            res.append((y, dx, G))
+    finally:
+        GM.LINEAR_PRECISION = saved
+    assert relerr(res[0][0], res[1][0]) < 3e-6 and relerr(res[0][1], res[1][1]) < 5e-6
+    for k in P:
+        assert relerr(res[0][2][k], res[1][2][k]) < 2e-5, k
+
+
+def test_gemm_ln_bwd_vs_two_kernels_at_bench_size():
+    from speech_enhancement_amd import gemm as GM, ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    M = B * T * Fp
+    x, dqkv, dR = rnd(M, 64, seed=1), rnd(M, 192, seed=2), rnd(M, 64, seed=3)
+    W = rnd(192, 64, seed=4, scale=0.1)
+    gam = rnd(64, seed=5) * 0.1 + 1
+    st = O.row_stats(x, M)
+    plan = WeightPlan(torch.device('cuda'))
+    WT = plan.linear_T('wt', W, planes=True)
+    plan.run()
+    dg, db = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    dX = GM.gemm_ln_bwd(dqkv, WT, x, st, gam, dR, dg, db)
+    dl = torch.empty(M, 64, device='cuda')
+    GM.gemm_tap(GM.linear_desc(M, 192, 64, precision=2), dqkv, WT, dl)
+    dg2, db2 = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    dX2 = O.layernorm_bwd(x, st, gam, dl, dg2, db2, dR=dR)
+    assert relerr(dX, dX2) < 2e-6 and relerr(dg, dg2) < 2e-5 and relerr(db, db2) < 2e-5
