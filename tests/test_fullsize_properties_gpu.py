@@ -204,3 +204,69 @@ def test_gemm_ln_bwd_vs_two_kernels_at_bench_size():
     dg2, db2 = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
     dX2 = O.layernorm_bwd(x, st, gam, dl, dg2, db2, dR=dR)
     assert relerr(dX, dX2) < 2e-6 and relerr(dg, dg2) < 2e-5 and relerr(db, db2) < 2e-5
+
+
+def _models():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import formula
+    import speech_enhancement_amd as S
+    g, d = S.TSCNet(64, 201), S.Discriminator(16)
+    g.load_state_dict(formula.formula_state('generator'))
+    d.load_state_dict(formula.formula_state('discriminator'))
+    g.cuda().train().set_dropout(0.0, 0.0)
+    d.cuda().train()
+    for m in d.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return g, d
+
+
+def test_batch16_forward_equals_single_clips_in_eval_mode():
+    """eval mode (BatchNorm on running statistics): the clips of a batch are independent, so the batch-16 forward -- the grids the
+    bench launches -- must reproduce the batch-1 forward (pinned against the reference by test_full_size_enhanced_magnitude)"""
+    from speech_enhancement_amd import frontend as FE
+    g, _ = _models()
+    g.eval()
+    x = rnd(B, 32000, seed=1, scale=0.1)
+    with torch.no_grad():
+        pl, _ = FE.stft_planes(x, 400, 100, 'pow')
+        est = g.forward_planes(pl)
+        for i in (0, 9, 15):
+            one = g.forward_planes(pl[i:i + 1].contiguous())
+            assert float((est[i] - one[0]).abs().max()) < 2e-5 * float(one.abs().max()), i
+
+
+def test_streams_do_not_change_the_full_size_step():
+    """one cmgan train step at the bench configuration (batch 16, 2 s clips) with the three HIP streams on vs the serial order:
+    every parameter of both models relative to the size of its update (see test_model_gpu.test_streams_do_not_change_the_step)"""
+    import types
+    from speech_enhancement_amd import train as TR, optim, gemm as GM
+    clean = rnd(B, 32000, seed=1, scale=0.1)
+    noisy = clean + rnd(B, 32000, seed=2, scale=0.05)
+    labels = {'est': 0.2 + 0.7 * torch.rand(B, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3))}
+    saved = (GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled)
+    res, init = [], None
+    try:
+        for on in (False, True):
+            GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled = on, on, on
+            g, d = _models()
+            named = lambda: list(g.named_parameters()) + [('D.' + n, p) for n, p in d.named_parameters()]
+            if init is None:
+                init = {n: p.detach().clone() for n, p in named()}
+            a = types.SimpleNamespace(optimizer='sgd', lr=0.01, weight_decay=0.01, momentum=0.9, max_norm=0.0)
+            og, od = optim.build_optimizer(a, g), optim.build_optimizer(a, d, lr=0.02)
+            out = TR.gan_step(g, d, og, od, clean, noisy, 'cmgan', (0.1, 0.9, 0.2, 0.05), labels=labels)
+            torch.cuda.synchronize()
+            res.append(({k: float(v) for k, v in out.items()}, {n: p.detach().clone() for n, p in named()}))
+    finally:
+        GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled = saved
+    for k, v in res[0][0].items():
+        assert abs(v - res[1][0][k]) <= 1e-4 * abs(v) + 1e-7, (k, v, res[1][0][k])
+    bad = []
+    for n, p0 in res[0][1].items():
+        upd = float((p0 - init[n]).abs().max())
+        diff = float((p0 - res[1][1][n]).abs().max())
+        if diff > 1e-2 * upd + 1e-6 * max(1.0, float(p0.abs().max())):
+            bad.append((n, diff, upd))
+    assert not bad, bad[:10]
