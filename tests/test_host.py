@@ -194,3 +194,55 @@ def test_cli_surface(S, tmp_path):
                                        '--save', '--gpu', '0'])
     assert a.save and a.model_path == 'ck.pth.tar' and c.HOP_SAMPLES == 100
     assert S.build_criterion('l1').__class__.__name__ == 'L1Loss' and S.build_criterion('MSE').__class__.__name__ == 'MSELoss'
+
+
+def test_ctypes_struct_layouts_match_the_c_header(tmp_path):
+    """the two structs that cross the C ABI by value / by table (se_gemm_desc, se_wprep_item): size and field offsets of the
+    ctypes mirrors equal what the C compiler lays out for include/se_hip.h"""
+    import ctypes
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from speech_enhancement_amd import _lib as L
+    from speech_enhancement_amd.weights import WItem
+    src = tmp_path / 'layout.c'
+    fields_d = ['B', 'ntap', 'dt', 'df', 'C', 'N', 'ldw', 'prologue', 'alpha', 'ldx', 'pro_seed', 'drop_p', 'precision', 'w_planes']
+    fields_w = ['src', 'dst', 'No', 'Ni_dst', 'so', 'stt', 'si', 'rev', 'dst_ld', 'c_off', 'scale', 'plane_stride']
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "se_hip.h"\nint main(void) {\n'
+    prog += '  printf("%zu\\n", sizeof(se_gemm_desc));\n' + ''.join(f'  printf("%zu\\n", offsetof(se_gemm_desc, {f}));\n' for f in fields_d)
+    prog += '  printf("%zu\\n", sizeof(se_wprep_item));\n' + ''.join(f'  printf("%zu\\n", offsetof(se_wprep_item, {f}));\n' for f in fields_w)
+    prog += '  return 0;\n}\n'
+    src.write_text(prog)
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(L.GemmDesc)] + [getattr(L.GemmDesc, f).offset for f in fields_d] + \
+           [ctypes.sizeof(WItem)] + [getattr(WItem, f).offset for f in fields_w]
+    assert vals == want
+
+
+def test_zero_arena_bookkeeping_on_cpu():
+    """ops.ZeroArena hands out disjoint, aligned, zeroed views, falls back (and grows at the next step) when full, re-clears what
+    was dirtied -- the bookkeeping is device-independent"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from speech_enhancement_amd import ops as O
+    ar = O.ZeroArena()
+    dev = torch.device('cpu')
+    assert ar.take((3, 2), torch.float32, dev).eq(0).all() and not ar.active          # inactive: plain zeros
+    ar.begin(dev, min_bytes=4096)
+    a = ar.take((10, 3), torch.float32, dev)
+    b = ar.take((5,), torch.float64, dev)
+    big = ar.take((4096,), torch.float32, dev)                                         # does not fit: falls back
+    base = ar.buf.data_ptr()
+    assert (a.data_ptr() - base) % 256 == 0 and (b.data_ptr() - base) % 256 == 0 and b.data_ptr() >= a.data_ptr() + a.numel() * 4
+    assert big.eq(0).all() and ar.missed > 0
+    a.fill_(1.0); b.fill_(2.0)
+    ar.end()
+    ar.begin(dev, min_bytes=4096)                                                      # grown for the miss, cleared
+    assert ar.buf.numel() >= 2 * 4096 * 4
+    a2 = ar.take((10, 3), torch.float32, dev)
+    big2 = ar.take((4096,), torch.float32, dev)
+    assert a2.eq(0).all() and big2.eq(0).all() and ar.missed == 0
+    ar.end()
