@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 // represented to 2^-16 relative, i.e. products carry ~1.5e-5 relative error (vs 6e-8 in fp32, 4e-3 in plain bf16)
 // -- inside the 1e-3 parity budget with two orders of magnitude to spare (measured in tests/test_gemm_gpu.py and
 // on the full model) -- while the three bf16 MFMAs cost 3/16 of the one fp32 MFMA they replace.
-template <int PRO, int NPL, bool LIN, bool WPL = false>
+// LNB: the LayerNorm-backward epilogue of se_gemm_ln_bwd (its own instantiation: its operands are prefetched across the K loop,
+// 72 VGPRs the ordinary GEMMs must not pay)
+template <int PRO, int NPL, bool LIN, bool WPL = false, bool LNB = false>
 __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 64, BK = 32, SA = 40;     // rows of 32 bf16 + 8 pad = 80 B: conflict-free b128 reads
   constexpr int KQ = BK / 4, RPP = 256 / KQ, NA = BM / RPP, NB = BN / RPP;
@@ -274,6 +276,8 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   const bool vec_ep = epilogue_vec_ok(d);
   if (vec_ep) stage_bias(g, by, bias_s);
   load_tiles(0);
+  LnBwdPre lnpre;
+  if (LNB) ln_bwd_prefetch(g, m0, lnpre);
   // operand fragments: lane (r = lane & 31, h = lane >> 5) holds k = 16 ks + 8 h .. + 7 of row r (16 contiguous bytes)
   const int frag = (lane & 31) * SA + 8 * (lane >> 5);
   for (int it = 0; it < NI; ++it) {
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     __syncthreads();
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;        // the staging planes are free now
-  if (LIN && PRO == SE_PRO_NONE && (d.epilogue & SE_EPI_LN_BWD_)) { gemm_epilogue_ln_bwd(g, acc0, acc1, m0, cs, 36, red); return; }
+  if (LNB) { gemm_epilogue_ln_bwd(g, acc0, acc1, m0, cs, 36, red, lnpre); return; }
   if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
@@ -801,8 +805,8 @@ extern "C" int se_gemm_ln_bwd(const float* A, const float* W, int w_planes, long
   g.nouter = g.tiles;
   g.contig = 0;
   dim3 grid((unsigned)(((long)g.nouter + 7) / 8 * 8)), block(256);
-  if (w_planes) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, true>), grid, block, 0, as_stream(stream), g);
-  else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, false>), grid, block, 0, as_stream(stream), g);
+  if (w_planes) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, true, true>), grid, block, 0, as_stream(stream), g);
+  else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, false, true>), grid, block, 0, as_stream(stream), g);
   return se_check_launch("se_gemm_ln_bwd");
 }
 

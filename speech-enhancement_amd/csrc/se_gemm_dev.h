@@ -246,8 +246,27 @@ static __device__ __forceinline__ void stage_bias(const GemmArgs& g, int by, flo
 // the gamma / beta gradients are folded over the rows of the workgroup (one atomic per channel and workgroup).
 // Operands: X = g.AUX [M][64], (mean, rstd) = g.rowstats, gamma = g.ps, dR = g.R, dX = g.Y; red: [4 waves][64][2] floats.
 constexpr int SE_EPI_LN_BWD_ = 1024;        // internal epilogue flag (not part of the public mask)
+// operands of the LayerNorm-backward epilogue, requested BEFORE the K loop (a global load at the tail of a workgroup exposes one
+// full memory latency per tile: the first version of this epilogue waited 58 % of its wave cycles)
+struct LnBwdPre { float4 x[2][4]; float4 r[2][4]; float2 mr[4]; };
+static __device__ __forceinline__ void ln_bwd_prefetch(const GemmArgs& g, int m0, LnBwdPre& p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Mb = g.d.To * g.d.Fo, cq = lane & 7, rr = lane >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long rg = (long)m0 + wave * 32 + rr + 8 * i;
+    const bool ok = rg < Mb;
+    p.mr[i] = ok ? *reinterpret_cast<const float2*>(g.rowstats + 2 * rg) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const long off = rg * 64 + nt * 32 + cq * 4;
+      p.x[nt][i] = ok ? *reinterpret_cast<const float4*>(g.AUX + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      p.r[nt][i] = (ok && g.R) ? *reinterpret_cast<const float4*>(g.R + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
 static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1, int m0,
-                                                            float* cs, int cs_ld, float* red) {
+                                                            float* cs, int cs_ld, float* red, const LnBwdPre& pre) {
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Mb = d.To * d.Fo;
@@ -269,12 +288,11 @@ static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, c
   for (int i = 0; i < 4; ++i) {
     const long rg = (long)m0 + wave * 32 + rr + 8 * i;
     const bool ok = rg < Mb;
-    float mean = 0.f, rstd = 0.f;
-    if (ok) { const float2 mr = *reinterpret_cast<const float2*>(g.rowstats + 2 * rg); mean = mr.x; rstd = mr.y; }
+    const float mean = pre.mr[i].x, rstd = pre.mr[i].y;
     float xh[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const float4 xv = ok ? *reinterpret_cast<const float4*>(g.AUX + rg * 64 + nt * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 xv = pre.x[nt][i];
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
       const float dv[4] = {gv[nt][i].x, gv[nt][i].y, gv[nt][i].z, gv[nt][i].w};
       const float gl[4] = {gm[nt].x, gm[nt].y, gm[nt].z, gm[nt].w};
@@ -293,8 +311,8 @@ static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, c
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const long off = rg * 64 + nt * 32 + cq * 4;
-        float o4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (g.R) { const float4 r1 = *reinterpret_cast<const float4*>(g.R + off); o4[0] = r1.x; o4[1] = r1.y; o4[2] = r1.z; o4[3] = r1.w; }
+        const float4 r1 = pre.r[nt][i];
+        float o4[4] = {r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
         *reinterpret_cast<float4*>(g.Y + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
