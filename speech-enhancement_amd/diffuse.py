@@ -14,6 +14,7 @@ the 50 reverse steps: they are computed ONCE per utterance batch and kept in HBM
 of 2 s clips -- what 288 GB are for); a step then costs 7.6 instead of 56.7 GFLOP per clip."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -237,10 +238,11 @@ def inference_schedule(config, fast_sampling=False):
 
 @torch.no_grad()
 def predict(model, config, noisy_signal, alpha, beta, alpha_cum, sigmas, T, c1, c2, c3, delta, delta_bar,
-            device=torch.device('cuda'), noises=None):
+            device=torch.device('cuda'), noises=None, streams=None):
     """inference_diffuse.py:194-228: supportive reverse diffusion of one clip [L] or a batch [B, L] of equal-length clips.
     `noises` (optional, [steps - 1, B, 100 T]) replaces torch.randn_like for reproducible parity runs.
-    The conditioner projections are computed once and reused by every step."""
+    The conditioner projections are computed once and reused by every step.  `streams`: number of independent batch parts run
+    concurrently (default $SE_DIFFUSE_STREAMS or 1; parts hold at least 4 clips)."""
     noisy = torch.as_tensor(np.asarray(noisy_signal), dtype=torch.float32, device=device)
     single = noisy.dim() == 1
     if single:
@@ -250,18 +252,42 @@ def predict(model, config, noisy_signal, alpha, beta, alpha_cum, sigmas, T, c1, 
     Lp = config.HOP_SAMPLES * spec.shape[-1]
     noisy_audio = torch.zeros(noisy.shape[0], Lp, device=device)
     noisy_audio[:, :noisy.shape[1]] = noisy
-    audio = noisy_audio
     cond = model.conditioner(spec)
+    B = noisy.shape[0]
+    # Clips never interact (GroupNorm is per sample), so the batch can be cut into `streams` independent parts, each stepping
+    # through the whole reverse process on its own HIP stream.  Measured at batch 32 (tools/bench_diffuse.py): 17.65 / 17.61 /
+    # 16.9 utt/s for 1 / 2 / 3 parts -- every kernel here already fills the chip, so the default stays the serial order.
+    nparts = max(1, min(int(streams if streams is not None else os.environ.get('SE_DIFFUSE_STREAMS', '1')), B // 4 or 1))
+    cuts = [B * i // nparts for i in range(nparts + 1)]
+    parts = [slice(cuts[i], cuts[i + 1]) for i in range(nparts)]
+    main = torch.cuda.current_stream(device)
+    lanes = [main] if nparts == 1 else [torch.cuda.Stream(device) for _ in parts]
+    Tdev = torch.as_tensor(np.asarray(T, dtype=np.float32), device=device)
+    if noises is not None:
+        noises = torch.as_tensor(np.asarray(noises), dtype=torch.float32, device=device).reshape(-1, B, Lp)
+    state = []
+    for h, s in zip(parts, lanes):
+        s.wait_stream(main)
+        state.append({'audio': noisy_audio[h], 'noisy': noisy_audio[h], 'cond': [c[h] for c in cond]})
     gamma, k = [0.2], 0
     for n in range(len(alpha) - 1, -1, -1):
-        eps = model.denoise(audio, cond, torch.tensor([T[n]], device=device))
-        if n > 0:
-            audio = c1[n] * audio + c2[n] * noisy_audio - c3[n] * eps
-            noise = torch.randn_like(audio) if noises is None else torch.as_tensor(noises[k], device=device).reshape(audio.shape)
-            k += 1
-            audio = audio + delta_bar[n] ** 0.5 * noise
-        else:
-            audio = c1[n] * audio - c3[n] * eps
-            audio = (1 - gamma[n]) * audio + gamma[n] * noisy_audio
-            audio = torch.clamp(audio, -1.0, 1.0)
+        for h, s, stt in zip(parts, lanes, state):
+            with torch.cuda.stream(s):
+                audio = stt['audio']
+                eps = model.denoise(audio, stt['cond'], Tdev[n:n + 1])
+                if n > 0:
+                    audio = c1[n] * audio + c2[n] * stt['noisy'] - c3[n] * eps
+                    noise = torch.randn_like(audio) if noises is None else noises[k, h]
+                    audio = audio + delta_bar[n] ** 0.5 * noise
+                else:
+                    audio = c1[n] * audio - c3[n] * eps
+                    audio = (1 - gamma[n]) * audio + gamma[n] * stt['noisy']
+                    audio = torch.clamp(audio, -1.0, 1.0)
+                stt['audio'] = audio
+        k += 1
+    for s, stt in zip(lanes, state):
+        if s is not main:
+            main.wait_stream(s)
+            stt['audio'].record_stream(main)
+    audio = state[0]['audio'] if nparts == 1 else torch.cat([stt['audio'] for stt in state], 0)
     return (torch.flatten(audio) if single else audio).cpu().numpy()

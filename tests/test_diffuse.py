@@ -108,3 +108,25 @@ def test_diffuse_reverse_sampler_vs_reference(gd, tag):
     ref = gd[f'predict_{tag}']
     assert y.shape == ref.shape
     assert rms(y, ref) < 2e-4 * max(1e-3, float(np.abs(ref).max())), (tag, rms(y, ref), float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_diffuse_batch_parts_on_streams_match_serial(gd):
+    """predict_diffuse cuts a batch into independent parts on separate HIP streams; clips never interact, so the result must
+    equal the serial order (up to the fp64 atomics order of the GroupNorm sums) and clip 0 must still match the reference"""
+    import types
+    import speech_enhancement_amd as S
+    m = _model(S)
+    cfg = types.SimpleNamespace(NOISE_SCHEDULE=NOISE_SCHEDULE, INFERENCE_NOISE_SCHEDULE=FAST, N_FFT=400, HOP_SAMPLES=100)
+    sched = S.inference_schedule(cfg, fast_sampling=True)
+    rng = np.random.default_rng(5)
+    clip = gd['noisy'][0].reshape(-1)
+    nz0 = gd['predict_fast_noise'].reshape(len(FAST) - 1, 1, -1)
+    x = np.stack([clip] + [clip * s + 0.01 * rng.standard_normal(clip.shape).astype(np.float32) for s in np.linspace(0.3, 1.2, 8)])
+    nz = np.concatenate([nz0, rng.standard_normal((nz0.shape[0], 8, nz0.shape[2])).astype(np.float32)], 1)
+    y1 = S.predict_diffuse(m, cfg, x, *sched, noises=nz, streams=1)
+    y2 = S.predict_diffuse(m, cfg, x, *sched, noises=nz, streams=2)
+    assert y1.shape == y2.shape == (9, nz.shape[2])
+    assert np.abs(y1 - y2).max() < 1e-5 * max(1e-3, np.abs(y1).max())
+    ref = gd['predict_fast'].reshape(-1)
+    assert rms(y2[0], ref) < 2e-4 * max(1e-3, float(np.abs(ref).max()))

@@ -17,10 +17,13 @@ x = (0.1 * torch.randn(B, Ls)).numpy()
 sched = S.inference_schedule(cfg, fast_sampling=False)
 S.predict_diffuse(m, cfg, x[:2], *sched)            # warm-up (LDS attributes, caches)
 torch.cuda.synchronize()
-t0 = time.time()
-S.predict_diffuse(m, cfg, x, *sched)
-torch.cuda.synchronize()
-dt = time.time() - t0
+by_streams = {}
+for ns in (1, 2, 3, 2, 1):
+    t0 = time.time()
+    S.predict_diffuse(m, cfg, x, *sched, streams=ns)
+    torch.cuda.synchronize()
+    by_streams.setdefault(ns, []).append(round(B / (time.time() - t0), 2))
+dt = B / max(by_streams[1])
 # phases
 noisy = torch.from_numpy(x).cuda()
 from speech_enhancement_amd import frontend as FE
@@ -38,6 +41,6 @@ torch.cuda.synchronize(); ts = (time.time() - t0) / 5
 _lib.TIMER.stop()
 fam = {k: round(v['ms'] / 5, 3) for k, v in sorted(_lib.TIMER.summary().items(), key=lambda kv: -kv[1]['ms'])}
 print(json.dumps({'metric': 'utterances/sec CDiffuSE 50-step supportive reverse diffusion (2 s @16 kHz)', 'value': round(B / dt, 2),
-                  'batch': B, 'seconds_per_batch': round(dt, 3), 'conditioner_ms_once': round(tc * 1e3, 1),
+                  'batch': B, 'utt_per_s_by_streams': by_streams, 'seconds_per_batch': round(dt, 3), 'conditioner_ms_once': round(tc * 1e3, 1),
                   'step_ms': round(ts * 1e3, 2), 'conditioner_cache_GB': round(sum(c.numel() for c in cond) * 4 / 1e9, 2),
                   'gemm_families_ms_per_step': fam}))
