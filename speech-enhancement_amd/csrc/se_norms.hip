@@ -206,6 +206,8 @@ __global__ __launch_bounds__(256) void affine_prelu_kernel(const float* __restri
   }
 }
 
+constexpr int NB_U = 4;      // line pairs in flight per lane in the two norm-backward passes
+
 // backward pass 1 of  Y = prelu(xh*g + beta), xh = (X-mean)*rstd:
 // red[b][c][3] += (sum du, sum du*xh, sum dY*u*[u<0]),  du = dY * prelu'(u)
 __global__ __launch_bounds__(256) void norm_prelu_bwd_reduce_kernel(
@@ -223,18 +225,35 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_reduce_kernel(
     gg[j] = g[c]; bt[j] = beta[c]; sl[j] = slope ? slope[c] : 1.f;
   }
   float acc[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-  for (long p = (long)blockIdx.x * it.psub + it.sub; p < P; p += (long)gridDim.x * it.psub) {
-    long pix = (long)b * P + p;
-    float4 v = *reinterpret_cast<const float4*>(X + pix * ldx + x_off + it.q * 4);
-    float4 d = *reinterpret_cast<const float4*>(dY + pix * ldy + y_off + it.q * 4);
-    float x[4] = {v.x, v.y, v.z, v.w}, dy[4] = {d.x, d.y, d.z, d.w};
+  // each workgroup owns one contiguous run of pixels; NB_U independent (X, dY) line pairs are requested per lane before any
+  // of them is consumed (one pair in flight per lane left the memory pipe half empty: 3.0 TB/s)
+  const long step = (long)it.psub * NB_U;
+  const long chunk = ((P + gridDim.x - 1) / gridDim.x + step - 1) / step * step;
+  const long p_end = min(P, (long)(blockIdx.x + 1) * chunk);
+  const float* Xb = X + (long)b * P * ldx + x_off + it.q * 4;
+  const float* Db = dY + (long)b * P * ldy + y_off + it.q * 4;
+  for (long p0 = (long)blockIdx.x * chunk + it.sub; p0 < p_end; p0 += step) {
+    float4 v[NB_U], d[NB_U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float xh = (x[j] - mean[j]) * rstd[j];
-      float u = xh * gg[j] + bt[j];
-      float du = act ? dy[j] * swish_gradf_(u) : (u >= 0.f ? dy[j] : dy[j] * sl[j]);
-      acc[0][j] += du; acc[1][j] += du * xh;
-      acc[2][j] += (act || u >= 0.f) ? 0.f : dy[j] * u;
+    for (int k = 0; k < NB_U; ++k) {
+      long p = p0 + (long)k * it.psub;
+      bool ok = p < p_end;
+      long pc = ok ? p : p0;
+      v[k] = *reinterpret_cast<const float4*>(Xb + pc * ldx);
+      d[k] = *reinterpret_cast<const float4*>(Db + pc * ldy);
+      if (!ok) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NB_U; ++k) {
+      float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, dy[4] = {d[k].x, d[k].y, d[k].z, d[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float xh = (x[j] - mean[j]) * rstd[j];
+        float u = xh * gg[j] + bt[j];
+        float du = act ? dy[j] * swish_gradf_(u) : (u >= 0.f ? dy[j] : dy[j] * sl[j]);
+        acc[0][j] += du; acc[1][j] += du * xh;
+        acc[2][j] += (act || u >= 0.f) ? 0.f : dy[j] * u;
+      }
     }
   }
   block_reduce_atomic_d<3>(acc, it, C, red + (long)sb * C * 3);
@@ -258,19 +277,34 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
     m1[j] = (float)(red[((long)sb * C + c) * 3] / count);
     m2[j] = (float)(red[((long)sb * C + c) * 3 + 1] / count);
   }
-  for (long p = (long)blockIdx.x * it.psub + it.sub; p < P; p += (long)gridDim.x * it.psub) {
-    long pix = (long)b * P + p;
-    float4 v = *reinterpret_cast<const float4*>(X + pix * ldx + x_off + it.q * 4);
-    float4 d = *reinterpret_cast<const float4*>(dY + pix * ldy + y_off + it.q * 4);
-    float x[4] = {v.x, v.y, v.z, v.w}, dy[4] = {d.x, d.y, d.z, d.w}, o[4];
+  const long step = (long)it.psub * NB_U;
+  const long chunk = ((P + gridDim.x - 1) / gridDim.x + step - 1) / step * step;
+  const long p_end = min(P, (long)(blockIdx.x + 1) * chunk);
+  const float* Xb = X + (long)b * P * ldx + x_off + it.q * 4;
+  const float* Db = dY + (long)b * P * ldy + y_off + it.q * 4;
+  float* Ob = dX + (long)b * P * lddx + dx_off + it.q * 4;
+  for (long p0 = (long)blockIdx.x * chunk + it.sub; p0 < p_end; p0 += step) {
+    float4 v[NB_U], d[NB_U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float xh = (x[j] - mean[j]) * rstd[j];
-      float u = xh * gg[j] + bt[j];
-      float du = act ? dy[j] * swish_gradf_(u) : (u >= 0.f ? dy[j] : dy[j] * sl[j]);
-      o[j] = rstd[j] * gg[j] * (du - m1[j] - xh * m2[j]);
+    for (int k = 0; k < NB_U; ++k) {
+      long p = p0 + (long)k * it.psub;
+      long pc = p < p_end ? p : p0;
+      v[k] = *reinterpret_cast<const float4*>(Xb + pc * ldx);
+      d[k] = *reinterpret_cast<const float4*>(Db + pc * ldy);
     }
-    *reinterpret_cast<float4*>(dX + pix * lddx + dx_off + it.q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int k = 0; k < NB_U; ++k) {
+      long p = p0 + (long)k * it.psub;
+      float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, dy[4] = {d[k].x, d[k].y, d[k].z, d[k].w}, o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float xh = (x[j] - mean[j]) * rstd[j];
+        float u = xh * gg[j] + bt[j];
+        float du = act ? dy[j] * swish_gradf_(u) : (u >= 0.f ? dy[j] : dy[j] * sl[j]);
+        o[j] = rstd[j] * gg[j] * (du - m1[j] - xh * m2[j]);
+      }
+      if (p < p_end) *reinterpret_cast<float4*>(Ob + p * lddx) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -372,16 +406,20 @@ extern "C" int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float
   hipStream_t s = as_stream(stream);
   int nbs = per_batch ? B : 1;
   int psub = 256 / (C / 4);
-  long nb = (P + psub - 1) / psub;
+  long nb = (P + (long)psub * NB_U - 1) / ((long)psub * NB_U);
+  // ~2048 workgroups in total: each one pays a per-channel set-up (fp64 divisions) and, in pass 1, a block reduction + 3C fp64
+  // atomics -- with 8192 four-iteration workgroups that overhead held the passes at 3.8 / 4.35 TB/s
+  const long nb_cap = 2048 / B > 1 ? 2048 / B : 1;
+  if (nb > nb_cap) nb = nb_cap;
   if (phase & 1) {      // reduce (a data-parallel caller all-reduces `red` between the two phases: SyncBatchNorm)
     (void)hipMemsetAsync(red, 0, sizeof(double) * 3 * nbs * C, s);
-    hipLaunchKernelGGL(norm_prelu_bwd_reduce_kernel, dim3((int)(nb > 512 ? 512 : nb), B), dim3(256), 0, s, X, ldx,
+    hipLaunchKernelGGL(norm_prelu_bwd_reduce_kernel, dim3((int)(nb > (nb_cap + 3) / 4 ? (nb_cap + 3) / 4 : nb), B), dim3(256), 0, s, X, ldx,
                        x_off, mr, g, beta, slope, dY, ldy, y_off, red, P, C, per_batch, act);
   }
   if (phase & 4)        // parameter gradients from the LOCAL sums (before any cross-rank all-reduce)
     hipLaunchKernelGGL(norm_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, red, dg, dbeta, dslope, nbs, C);
   if (phase & 2) {
-    hipLaunchKernelGGL(norm_prelu_bwd_apply_kernel, dim3((int)(nb > 1024 ? 1024 : nb), B), dim3(256), 0, s, X, ldx,
+    hipLaunchKernelGGL(norm_prelu_bwd_apply_kernel, dim3((int)nb, B), dim3(256), 0, s, X, ldx,
                        x_off, mr, g, beta, slope, dY, ldy, y_off, red, dX, lddx, dx_off, P, C, per_batch, count, act);
   }
   return se_check_launch("se_norm_prelu_bwd");

@@ -766,7 +766,7 @@ def test_streams_do_not_change_the_step(S, arch):
         upd = float((p0 - init[n]).abs().max())
         d_leaf = float((p0 - res[1][1][n]).abs().max())
         d_all = float((p0 - res[2][1][n]).abs().max())
-        if d_leaf > 2e-3 * upd + 5e-7 * scale:
+        if d_leaf > 5e-3 * upd + 1e-6 * scale:       # a missed contribution is O(upd); order noise reached 3e-3 (prelu_out, 201 weights)
             bad.append(('leaf stream', n, d_leaf, upd))
         if d_all > 1e-2 * upd + 1e-6 * scale:
             bad.append(('all streams', n, d_all, upd))
