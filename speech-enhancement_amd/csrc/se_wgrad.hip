@@ -779,6 +779,192 @@ static int launch_wgrad_lin(const se_gemm_desc* d, const WgradArgs& g, dim3 grid
   return se_check_launch("se_gemm_tap_wgrad(lin)");
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same whole-gradient row GEMM on the bf16 matrix cores (exact hi / mid / lo split, six products: fp32-equivalent).
+// wgrad_lin_kernel's fp32 MFMA does 64 FLOP / clk / SIMD -- at [256 x 64] x 518 736 rows that alone is 125 us, as long as the
+// HBM time of the operands; six bf16 products cost 2.7x fewer matrix-pipe cycles.  The split-bf16 block kernel lost that
+// advantage to its own VALU work (every 64 x 64 block re-splits both operand tiles); here each operand element is split ONCE
+// per launch.  The contraction index is the row m, so the MFMA fragments need 8 consecutive rows of one column per lane:
+//   * wide operand (<= 256 columns): a lane loads the float4 of its 4 columns for the 8 rows of its wave's row octet (eight
+//     1-KB wave loads), transposes in registers, splits 8 values at a time (split_planes8) and writes one 16-B fragment cell
+//     per (plane, column);
+//   * narrow operand (<= 64 columns): a lane loads 2 consecutive rows x float4 and writes (row pair) dwords into the cells.
+// LDS image: [plane][row octet][column][8 rows] bf16 -- fragment reads and cell writes are both column-contiguous (conflict
+// free), 60 KB per workgroup, two workgroups per CU; global loads of the next 32 rows are in flight during the 48 MFMAs.
+// SH = 1: dY wide (N <= 256), X narrow (C <= 64): FF W1, pointwise-GLU conv.  SH = 2: X wide (C <= 256), dY narrow: FF W2.
+template <int PRO, int SH>
+__global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
+  constexpr int MR = 32, WIDE = 256, NARROW = 64;
+  constexpr int WPLN = 4 * WIDE * 8, NPLN = 4 * NARROW * 8;         // bf16 elements per plane
+  __shared__ __attribute__((aligned(16))) __bf16 Ws[3 * WPLN];
+  __shared__ __attribute__((aligned(16))) __bf16 Ns[3 * NPLN];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const long Mtot = (long)d.To * d.Fo;                               // row GEMM: B == 1 (host-checked)
+  const long mbeg = (long)blockIdx.x * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  constexpr bool XW = SH == 2;                                       // X is the wide operand
+  const int wcols = XW ? d.C : d.N, ncols = XW ? d.N : d.C;
+  const long ldw_ = XW ? d.lda : d.ldc, ldn_ = XW ? d.ldc : d.lda;
+  const int wq = lane * 4;                                           // wide: this lane's 4 columns, rows 8 * wave + i
+  const int nq = (tid & 15) * 4, nrp = tid >> 4;                     // narrow: 4 columns, rows 2 * nrp, 2 * nrp + 1
+  const bool wok = wq < wcols, nok = nq < ncols;
+  const float* __restrict__ Wg = (XW ? g.A + d.a_off : g.dY + d.c_off) + wq;
+  const float* __restrict__ Ng = (XW ? g.dY + d.c_off : g.A + d.a_off) + nq;
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
+  const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
+  const bool do_bias = g.dbias != nullptr;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 rw[8], rn[2];
+  float2 sw[8], sn[2];                                               // LayerNorm row statistics (PRO == SE_PRO_LN only)
+  float4 psw = make_float4(0.f, 0.f, 0.f, 0.f), pbw = psw, psn = psw, pbn = psw;
+  if (XW) load_pro_vec<PRO>(g.ps, g.pb, wq, wok, psw, pbw); else load_pro_vec<PRO>(g.ps, g.pb, nq, nok, psn, pbn);
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long mg = mbase + 8 * wave + i;
+      const bool ok = mg < mend && wok;
+      rw[i] = ok ? *reinterpret_cast<const float4*>(Wg + mg * ldw_) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (XW && PRO == SE_PRO_LN) sw[i] = mg < mend ? *reinterpret_cast<const float2*>(g.rowstats + 2 * mg) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long mg = mbase + 2 * nrp + i;
+      const bool ok = mg < mend && nok;
+      rn[i] = ok ? *reinterpret_cast<const float4*>(Ng + mg * ldn_) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!XW && PRO == SE_PRO_LN) sn[i] = mg < mend ? *reinterpret_cast<const float2*>(g.rowstats + 2 * mg) : make_float2(0.f, 0.f);
+    }
+  };
+  // operand transforms at staging time: the X prologue (the forward's LayerNorm / Swish / dropout, recomputed) and the dY mask
+  auto fix = [&](float4 v, bool is_x, int c0, bool ok, float2 st, float4 ps4, float4 pb4, long mg) -> float4 {
+    if (!(ok && mg < mend)) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (is_x) {
+      if (PRO != SE_PRO_NONE) v = apply_pro<PRO>(v, c0, d.C, st.x, st.y, ps4, pb4, mg, d.pro_seed, thr, inv_keep);
+    } else if (dy_drop) {
+      const float4 d4 = drop_scale4(d.epi_seed, (unsigned)(mg * d.N + c0), thr, inv_keep);
+      v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
+    }
+    return v;
+  };
+  if (mbeg < mend) load_tiles(mbeg);
+  // fragment bases: A = dY^T (rows n), B = X (columns c); this wave's 64 x 64 block of dW
+  const __bf16* abase = XW ? Ns + (half * NARROW + l31) * 8 : Ws + (half * WIDE + wave * 64 + l31) * 8;
+  const __bf16* bbase = XW ? Ws + (half * WIDE + wave * 64 + l31) * 8 : Ns + (half * NARROW + l31) * 8;
+  constexpr int APL = XW ? NPLN : WPLN, BPL = XW ? WPLN : NPLN, AOC = (XW ? NARROW : WIDE) * 8, BOC = (XW ? WIDE : NARROW) * 8;
+  const bool active = wave * 64 < wcols;                              // a wave whose whole block is padding idles
+  for (long mb = mbeg; mb < mend; mb += MR) {
+    {   // wide operand: 8 rows x 4 columns per lane -> 4 columns x 3 planes of 8-row cells
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        v[i] = fix(rw[i], XW, wq, wok, (XW && PRO == SE_PRO_LN) ? sw[i] : make_float2(0.f, 0.f), psw, pbw, mb + 8 * wave + i);
+        if (!XW && do_bias) { bsum.x += v[i].x; bsum.y += v[i].y; bsum.z += v[i].z; bsum.w += v[i].w; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = j == 0 ? v[i].x : (j == 1 ? v[i].y : (j == 2 ? v[i].z : v[i].w));
+        bf16x8 pl[3];
+        split_planes8<3, bf16x8>(x, pl);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(&Ws[q * WPLN + (wave * WIDE + wq + j) * 8]) = pl[q];
+      }
+    }
+    {   // narrow operand: 2 rows x 4 columns per lane -> (row pair) dwords
+      float4 v0 = fix(rn[0], !XW, nq, nok, (!XW && PRO == SE_PRO_LN) ? sn[0] : make_float2(0.f, 0.f), psn, pbn, mb + 2 * nrp);
+      float4 v1 = fix(rn[1], !XW, nq, nok, (!XW && PRO == SE_PRO_LN) ? sn[1] : make_float2(0.f, 0.f), psn, pbn, mb + 2 * nrp + 1);
+      if (XW && do_bias) { bsum.x += v0.x + v1.x; bsum.y += v0.y + v1.y; bsum.z += v0.z + v1.z; bsum.w += v0.w + v1.w; }
+      float a4[4] = {v0.x, v0.y, v0.z, v0.w}, b4[4] = {v1.x, v1.y, v1.z, v1.w};
+      unsigned* cell = reinterpret_cast<unsigned*>(&Ns[((nrp >> 2) * NARROW + nq) * 8 + 2 * (nrp & 3)]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned w = pk_bf16_(a4[j], b4[j]);
+          cell[(q * NPLN + j * 8) / 2] = w;
+          if (q < 2) { a4[j] -= __builtin_bit_cast(float, w << 16); b4[j] -= __builtin_bit_cast(float, w & 0xffff0000u); }
+        }
+    }
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+    if (active) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            af[t][q] = *reinterpret_cast<const bf16x8*>(abase + q * APL + 2 * s * AOC + t * 32 * 8);
+            bf[t][q] = *reinterpret_cast<const bf16x8*>(bbase + q * BPL + 2 * s * BOC + t * 32 * 8);
+          }
+#pragma unroll
+        for (int ord = 2; ord >= 0; --ord)
+#pragma unroll
+          for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][qa], bf[b][ord - qa], acc[a][b], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  const int wn = XW ? 0 : wave, wc = XW ? wave : 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int c = (wc * 2 + b) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = (wn * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + c], d.alpha * acc[a][b][r]);
+      }
+    }
+  if (do_bias) {          // column sums of dY, folded over the lanes that shared a column group
+    float* red = reinterpret_cast<float*>(Ws);
+    constexpr int NG = XW ? 16 : 4, NC = XW ? NARROW : WIDE;
+    const int grp = XW ? nrp : wave, c0 = XW ? nq : wq;
+    *reinterpret_cast<float4*>(&red[grp * NC + c0]) = bsum;
+    __syncthreads();
+    if (tid < NC && tid < d.N) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < NG; ++r) s_ += red[r * NC + tid];
+      atomicAdd(&g.dbias[tid], d.alpha * s_);
+    }
+  }
+}
+
+template <int SH>
+static int launch_wgrad_lin_bf16(const se_gemm_desc* d, const WgradArgs& g, dim3 grid, hipStream_t s) {
+  const dim3 block(256);
+  switch (d->prologue) {
+    case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_NONE, SH>), grid, block, 0, s, g); break;
+    case SE_PRO_LN: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_LN, SH>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_SWISH, SH>), grid, block, 0, s, g); break;
+    case SE_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_AFFINE_SWISH, SH>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH_DROP: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_SWISH_DROP, SH>), grid, block, 0, s, g); break;
+    case SE_PRO_DROP: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_DROP, SH>), grid, block, 0, s, g); break;
+    default: return se_fail("wgrad: unknown prologue %d", d->prologue);
+  }
+  return se_check_launch("se_gemm_tap_wgrad(lin bf16x6)");
+}
+
 extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW,
                                  float* dbias, const float* rowstats, const float* pro_scale,
                                  const float* pro_shift, int chunks, void* stream) {
@@ -827,6 +1013,15 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
     else if (d->N <= 64 && d->C > 128 && d->C <= 256) shape = 2;
     else if (d->N <= 64 && d->C > 64 && d->C <= 128 && getenv("SE_WGRAD_LIN_ALL") != nullptr) shape = 3;
     if (d->C <= 64 && d->N > 64 && d->N <= 192 && getenv("SE_WGRAD_LIN_ALL") != nullptr) shape = 1;
+    if (shape && shape <= 2 && d->precision == 2 && getenv("SE_WGRAD_LIN_F32") == nullptr) {
+      // split-bf16 form: one resident round of 2 workgroups per CU (60 KB of LDS each)
+      long rl = (Mtot + 511) / 512;
+      if (rl < 256) rl = 256;
+      rl = ((rl + 31) / 32) * 32;
+      const int nch = (int)((Mtot + rl - 1) / rl);
+      WgradArgs gl{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rl, nch};
+      return shape == 1 ? launch_wgrad_lin_bf16<1>(d, gl, dim3((unsigned)nch), s) : launch_wgrad_lin_bf16<2>(d, gl, dim3((unsigned)nch), s);
+    }
     if (shape) {
       // one resident round of 3 workgroups per CU (42 KB of LDS each), steps of 32 rows
       // (at least 8 steps per workgroup: every workgroup ends with N * C atomics, which dominated at small M -- 81 us of

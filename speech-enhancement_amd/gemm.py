@@ -37,7 +37,7 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
 # the generic split kernel; everything else (prologue GEMMs with K > 64, N = 64 with K = 64, accumulating epilogues, weight
 # gradients) measured faster on the fp32-MFMA kernels and stays there.
 LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'bf16x6')]
-WGRAD_LINEAR_PRECISION = 0
+WGRAD_LINEAR_PRECISION = {'f32': 0, 'bf16x6': 2}[__import__('os').environ.get('SE_WGRAD_LINEAR_PRECISION', 'bf16x6')]
 
 
 def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):

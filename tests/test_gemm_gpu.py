@@ -460,19 +460,23 @@ def test_wgrad_scale_accumulates_in_place(G):
     assert relerr(db, db0.double() + 0.5 * dy.double().sum(0)) < 2e-6
 
 
-@pytest.mark.parametrize('Cin,N,pro', [(64, 256, 'ln'), (256, 64, 'swish_drop'), (64, 192, 'ln'), (128, 64, 'affine_swish')])
-def test_full_tile_linear_wgrad_equals_block_kernel(G, Cin, N, pro, monkeypatch):
-    """wgrad_lin_kernel (the whole [N x C] gradient in one workgroup) against the per-block kernel and fp64 torch, incl. a ragged
-    last chunk, the dropout mask on dY and the bias gradient; SE_WGRAD_LIN_ALL routes every supported shape to it."""
+@pytest.mark.parametrize('Cin,N,pro,prec', [(64, 256, 'ln', 0), (256, 64, 'swish_drop', 0), (64, 192, 'ln', 0), (128, 64, 'affine_swish', 0),
+                                            (64, 256, 'ln', 2), (256, 64, 'swish_drop', 2), (64, 224, 'ln', 2), (200, 64, 'swish_drop', 2),
+                                            (256, 64, 'affine_swish', 2), (64, 256, 'none', 2)])
+def test_full_tile_linear_wgrad_equals_block_kernel(G, Cin, N, pro, prec, monkeypatch):
+    """wgrad_lin_kernel / wgrad_lin_bf16_kernel (the whole [N x C] gradient in one workgroup; prec 0: fp32 MFMA, prec 2: six
+    split-bf16 products) against the per-block kernel and fp64 torch, incl. a ragged last chunk, padded columns, the dropout
+    mask on dY and the bias gradient; SE_WGRAD_LIN_ALL routes every supported shape to the fp32 form."""
     gemm, L = G
     M = 5000 + 37
     x, dy = rnd(M, Cin, seed=1), rnd(M, N, seed=2)
     from speech_enhancement_amd import ops as O
     st = O.row_stats(x, M) if Cin == 64 else None
     g, b = rnd(Cin, seed=3) * 0.1 + 1, rnd(Cin, seed=4) * 0.1
-    code = {'ln': L.PRO_LN, 'swish_drop': L.PRO_SWISH_DROP, 'affine_swish': L.PRO_AFFINE_SWISH}[pro]
+    code = {'ln': L.PRO_LN, 'swish_drop': L.PRO_SWISH_DROP, 'affine_swish': L.PRO_AFFINE_SWISH, 'none': L.PRO_NONE}[pro]
     dp = 0.2 if pro == 'swish_drop' else 0.0
-    mk = lambda: gemm.linear_desc(M, Cin, N, prologue=code, epilogue=L.EPI_DROP if dp else 0, pro_seed=3, epi_seed=9, drop_p=dp)
+    mk = lambda: gemm.linear_desc(M, Cin, N, prologue=code, epilogue=L.EPI_DROP if dp else 0, pro_seed=3, epi_seed=9, drop_p=dp,
+                                  precision=prec)
     out = {}
     for mode in ('blocks', 'full'):
         if mode == 'blocks':
@@ -481,11 +485,11 @@ def test_full_tile_linear_wgrad_equals_block_kernel(G, Cin, N, pro, monkeypatch)
             monkeypatch.delenv('SE_WGRAD_NO_LIN')
             monkeypatch.setenv('SE_WGRAD_LIN_ALL', '1')
         dw, db = torch.zeros(N, Cin, device='cuda'), torch.zeros(N, device='cuda')
-        gemm.gemm_tap_wgrad(mk(), x, dy, dw, db, rowstats=st, ps=g, pb=b)
+        gemm.gemm_tap_wgrad(mk(), x, dy, dw, db, rowstats=st, ps=g, pb=b, explicit_precision=True)
         out[mode] = (dw, db)
     assert relerr(out['full'][0], out['blocks'][0]) < 5e-6 and relerr(out['full'][1], out['blocks'][1]) < 5e-6
-    if pro == 'ln':
-        a = torch.nn.functional.layer_norm(x.double(), (Cin,), g.double(), b.double(), 1e-5)
+    if pro in ('ln', 'none'):
+        a = torch.nn.functional.layer_norm(x.double(), (Cin,), g.double(), b.double(), 1e-5) if pro == 'ln' else x.double()
         assert relerr(out['full'][0], dy.double().T @ a) < 5e-6 and relerr(out['full'][1], dy.double().sum(0)) < 5e-6
 
 

@@ -14,13 +14,14 @@ for name, Cin, N, pro, epi in cases:
     g = torch.rand(Cin, device='cuda') + 0.5; b = torch.randn(Cin, device='cuda') * 0.1
     d = GM.linear_desc(M, Cin, N, prologue=pro, epilogue=epi, pro_seed=5, epi_seed=7, drop_p=0.2 if pro == L.PRO_SWISH_DROP else 0.0)
     res = {}
-    for mode in ('blocks', 'full'):
+    for mode in ('blocks', 'full', 'full-x6'):
         if mode == 'blocks':
             os.environ['SE_WGRAD_NO_LIN'] = '1'
         else:
             os.environ.pop('SE_WGRAD_NO_LIN', None)
+        d.precision = 2 if mode == 'full-x6' else 0
         dw = torch.zeros(N, Cin, device='cuda'); db = torch.zeros(N, device='cuda')
-        f = lambda: GM.gemm_tap_wgrad(d, x, dy, dw, db, rowstats=st, ps=g, pb=b)
+        f = lambda: GM.gemm_tap_wgrad(d, x, dy, dw, db, rowstats=st, ps=g, pb=b, explicit_precision=True)
         f(); torch.cuda.synchronize()
         res[mode] = (dw.clone(), db.clone())
         for _ in range(2): f()
@@ -28,6 +29,7 @@ for name, Cin, N, pro, epi in cases:
         for _ in range(10): f()
         torch.cuda.synchronize(); dt = (time.time() - t0) / 10
         print(f'{name:48s} {mode:7s} {dt*1e6:7.1f} us  {2.0*M*Cin*N/dt/1e12:6.1f} TF', flush=True)
-    e = float((res['full'][0] - res['blocks'][0]).abs().max() / res['blocks'][0].abs().max())
-    eb = float((res['full'][1] - res['blocks'][1]).abs().max() / res['blocks'][1].abs().max())
-    print(f'    max relative difference full vs blocks: dW {e:.2e}, dbias {eb:.2e}')
+    for m2 in ('full', 'full-x6'):
+        e = float((res[m2][0] - res['blocks'][0]).abs().max() / res['blocks'][0].abs().max())
+        eb = float((res[m2][1] - res['blocks'][1]).abs().max() / res['blocks'][1].abs().max())
+        print(f'    max relative difference {m2} vs blocks: dW {e:.2e}, dbias {eb:.2e}')
