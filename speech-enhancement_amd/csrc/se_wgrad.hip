@@ -789,8 +789,8 @@ static int launch_wgrad_lin(const se_gemm_desc* d, const WgradArgs& g, dim3 grid
 //     1-KB wave loads), transposes in registers, splits 8 values at a time (split_planes8) and writes one 16-B fragment cell
 //     per (plane, column);
 //   * narrow operand (<= 64 columns): a lane loads 2 consecutive rows x float4 and writes (row pair) dwords into the cells.
-// LDS image: [plane][row octet][column][8 rows] bf16 -- fragment reads and cell writes are both column-contiguous (conflict
-// free), 60 KB per workgroup, two workgroups per CU; global loads of the next 32 rows are in flight during the 48 MFMAs.
+// LDS image: [plane][row octet][column cell][8 rows] bf16 (wide operand: cells swizzled, see swz below -- fragment reads and
+// cell writes both conflict free), 60 KB per workgroup, two workgroups per CU; global loads of the next 32 rows are in flight during the 48 MFMAs.
 // SH = 1: dY wide (N <= 256), X narrow (C <= 64): FF W1, pointwise-GLU conv.  SH = 2: X wide (C <= 256), dY narrow: FF W2.
 template <int PRO, int SH>
 __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
@@ -859,8 +859,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
   };
   if (mbeg < mend) load_tiles(mbeg);
   // fragment bases: A = dY^T (rows n), B = X (columns c); this wave's 64 x 64 block of dW
-  const __bf16* abase = XW ? Ns + (half * NARROW + l31) * 8 : Ws + (half * WIDE + wave * 64 + l31) * 8;
-  const __bf16* bbase = XW ? Ws + (half * WIDE + wave * 64 + l31) * 8 : Ns + (half * NARROW + l31) * 8;
+  // wide image: column c sits in cell swz(c) = 64 (c & 3) + ((c >> 2) + 4 (c & 3)) mod 64 of its row octet -- the 64 lanes of a
+  // staging write (columns 4 lane + j) then cover 64 consecutive cells, and the 16 lanes of a fragment-read pass 16 distinct
+  // 16-B bank groups (column-major cells made every staging write a 4-way bank conflict: 0.68 conflict cycles per active one)
+  auto swz = [](int c) { return 64 * (c & 3) + (((c >> 2) + 4 * (c & 3)) & 63); };
+  const int wf0 = swz(wave * 64 + l31), wf1 = swz(wave * 64 + 32 + l31);
+  const __bf16* abase = XW ? Ns + (half * NARROW + l31) * 8 : Ws + (half * WIDE) * 8;
+  const __bf16* bbase = XW ? Ws + (half * WIDE) * 8 : Ns + (half * NARROW + l31) * 8;
+  const int aoff[2] = {XW ? 0 : wf0 * 8, XW ? 32 * 8 : wf1 * 8}, boff[2] = {XW ? wf0 * 8 : 0, XW ? wf1 * 8 : 32 * 8};
   constexpr int APL = XW ? NPLN : WPLN, BPL = XW ? WPLN : NPLN, AOC = (XW ? NARROW : WIDE) * 8, BOC = (XW ? WIDE : NARROW) * 8;
   const bool active = wave * 64 < wcols;                              // a wave whose whole block is padding idles
   for (long mb = mbeg; mb < mend; mb += MR) {
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
         bf16x8 pl[3];
         split_planes8<3, bf16x8>(x, pl);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(&Ws[q * WPLN + (wave * WIDE + wq + j) * 8]) = pl[q];
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(&Ws[q * WPLN + (wave * WIDE + 64 * j + ((lane + 4 * j) & 63)) * 8]) = pl[q];
       }
     }
     {   // narrow operand: 2 rows x 4 columns per lane -> (row pair) dwords
@@ -907,8 +913,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int q = 0; q < 3; ++q) {
-            af[t][q] = *reinterpret_cast<const bf16x8*>(abase + q * APL + 2 * s * AOC + t * 32 * 8);
-            bf[t][q] = *reinterpret_cast<const bf16x8*>(bbase + q * BPL + 2 * s * BOC + t * 32 * 8);
+            af[t][q] = *reinterpret_cast<const bf16x8*>(abase + q * APL + 2 * s * AOC + aoff[t]);
+            bf[t][q] = *reinterpret_cast<const bf16x8*>(bbase + q * BPL + 2 * s * BOC + boff[t]);
           }
 #pragma unroll
         for (int ord = 2; ord >= 0; --ord)

@@ -23,5 +23,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith('aten::')]
 rows.sort(key=lambda e: -e.count)
-for e in rows[:60]:
+rows = [e for e in rows if e.device_time_total > 0 and e.key not in ('aten::zeros_like', 'aten::zero_', 'aten::clone', 'aten::contiguous', 'aten::zeros')]
+print('launching aten ops per step:', sum(e.count for e in rows))
+for e in rows[:90]:
     print(f'{e.key:28s} n={e.count:4d} cuda={e.device_time_total/1e3:7.3f} ms  {str(e.input_shapes)[:110]}')
