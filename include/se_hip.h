@@ -188,11 +188,19 @@ int se_bn_eval_scale(const float* rm, const float* rv, const float* g, const flo
 /* Y[.., y_off+c] = prelu(X*scale + shift): the apply pass of InstanceNorm2d(affine)+PReLU */
 int se_affine_prelu(const float* X, int ldx, int x_off, const float* ss, const float* slope, float* Y,
                     int ldy, int y_off, int B, long P, int C, void* stream);
+/* se_norm_finalize (instance statistics, no running buffers) + se_affine_prelu in one launch: stats[B][C][2] (sum, sumsq) ->
+ * Y = prelu(xhat*g + beta) and mr[B][C][2] = (mean, rstd) for the backward pass (generator.py:21-22,40-47,101-104,120-121;
+ * discriminator.py:40-50) */
+int se_inorm_prelu_fwd(const float* X, int ldx, int x_off, const double* stats, const float* g, const float* beta,
+                       const float* slope, float* Y, int ldy, int y_off, float* mr, int B, long P, int C, double count,
+                       float eps, void* stream);
 /* backward of Y = act(xhat*g + beta), act = PReLU (act=0; slope NULL = identity) or Swish (act=1), for
  * instance (per_batch=1) or batch (per_batch=0; BatchNorm1d+Swish, conformer.py:167-168) statistics;
  * red: workspace double[nb][C][3]; dg/dbeta/dslope accumulate.  phase bits: 1 = reduction, 4 = parameter
- * gradients (from the local sums), 2 = apply (data-parallel SyncBatchNorm all-reduces `red` between 1|4 and 2); count = elements per
- * statistic (global count under SyncBatchNorm). */
+ * gradients (from the local sums), 2 = apply (data-parallel SyncBatchNorm all-reduces `red` between 1|4 and 2), 8 = the parameter
+ * gradients are taken inside the apply pass instead of their own launch (alternative to 4: only without an exchange between the
+ * passes), 16 = the caller hands `red` over zero-filled (no memset launch); count = elements per statistic (global count under
+ * SyncBatchNorm). */
 int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const float* g,
                       const float* beta, const float* slope, const float* dY, int ldy, int y_off,
                       double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,

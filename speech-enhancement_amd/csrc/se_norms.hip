@@ -206,7 +206,53 @@ __global__ __launch_bounds__(256) void affine_prelu_kernel(const float* __restri
   }
 }
 
-constexpr int NB_U = 4;      // line pairs in flight per lane in the two norm-backward passes
+constexpr int NB_U = 4;      // lines (line pairs) in flight per lane in the norm forward / backward passes
+
+// InstanceNorm(affine) + PReLU forward in ONE launch: every workgroup turns the (sum, sumsq) of its 4 channels per lane into
+// (scale, shift) itself (same fp64 arithmetic as norm_finalize_kernel), the first workgroup of a batch entry also stores
+// (mean, rstd) for the backward pass; ~2048 workgroups over contiguous pixel runs like the backward passes.
+__global__ __launch_bounds__(256) void inorm_prelu_fwd_kernel(
+    const float* __restrict__ X, int ldx, int x_off, const double* __restrict__ stats, const float* __restrict__ g,
+    const float* __restrict__ beta, const float* __restrict__ slope, float* __restrict__ Y, int ldy, int y_off,
+    float* __restrict__ mr, long P, int C, double count, float eps) {
+  ChanIter it(C);
+  const int b = blockIdx.y;
+  float sc[4], sh[4], sl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = it.q * 4 + j;
+    const long idx = (long)b * C + c;
+    const double mean = stats[2 * idx] / count;
+    double var = stats[2 * idx + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    sc[j] = rstd * g[c];
+    sh[j] = beta[c] - (float)mean * sc[j];
+    sl[j] = slope ? slope[c] : 1.f;
+    if (blockIdx.x == 0 && it.sub == 0) { mr[2 * idx] = (float)mean; mr[2 * idx + 1] = rstd; }
+  }
+  const long step = (long)it.psub * NB_U;
+  const long chunk = ((P + gridDim.x - 1) / gridDim.x + step - 1) / step * step;
+  const long p_end = min(P, (long)(blockIdx.x + 1) * chunk);
+  const float* Xb = X + (long)b * P * ldx + x_off + it.q * 4;
+  float* Yb = Y + (long)b * P * ldy + y_off + it.q * 4;
+  for (long p0 = (long)blockIdx.x * chunk + it.sub; p0 < p_end; p0 += step) {
+    float4 v[NB_U];
+#pragma unroll
+    for (int k = 0; k < NB_U; ++k) {
+      const long p = p0 + (long)k * it.psub;
+      v[k] = *reinterpret_cast<const float4*>(Xb + (p < p_end ? p : p0) * ldx);
+    }
+#pragma unroll
+    for (int k = 0; k < NB_U; ++k) {
+      const long p = p0 + (long)k * it.psub;
+      float u[4] = {v[k].x * sc[0] + sh[0], v[k].y * sc[1] + sh[1], v[k].z * sc[2] + sh[2], v[k].w * sc[3] + sh[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u[j] = u[j] >= 0.f ? u[j] : u[j] * sl[j];
+      if (p < p_end) *reinterpret_cast<float4*>(Yb + p * ldy) = make_float4(u[0], u[1], u[2], u[3]);
+    }
+  }
+}
 
 // backward pass 1 of  Y = prelu(xh*g + beta), xh = (X-mean)*rstd:
 // red[b][c][3] += (sum du, sum du*xh, sum dY*u*[u<0]),  du = dY * prelu'(u)
@@ -264,10 +310,18 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
     const float* __restrict__ X, int ldx, int x_off, const float* __restrict__ mr, const float* __restrict__ g,
     const float* __restrict__ beta, const float* __restrict__ slope, const float* __restrict__ dY, int ldy, int y_off,
     const double* __restrict__ red, float* __restrict__ dX, int lddx, int dx_off, long P, int C, int per_batch,
-    double count, int act) {
+    double count, int act, float* dg, float* dbeta, float* dslope, int nbs) {
   ChanIter it(C);
   const int b = blockIdx.y;
   const int sb = per_batch ? b : 0;
+  if (dg && blockIdx.x == 0 && b == 0 && threadIdx.x < C) {      // norm_param_grad_kernel's work, one launch less
+    const int c = threadIdx.x;
+    double s1 = 0, s2 = 0, s3 = 0;
+    for (int k = 0; k < nbs; ++k) { s1 += red[((long)k * C + c) * 3]; s2 += red[((long)k * C + c) * 3 + 1]; s3 += red[((long)k * C + c) * 3 + 2]; }
+    dg[c] += (float)s2;
+    dbeta[c] += (float)s1;
+    if (dslope) dslope[c] += (float)s3;
+  }
   float mean[4], rstd[4], gg[4], bt[4], sl[4], m1[4], m2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -394,6 +448,20 @@ extern "C" int se_affine_prelu(const float* X, int ldx, int x_off, const float* 
   return se_check_launch("se_affine_prelu");
 }
 
+extern "C" int se_inorm_prelu_fwd(const float* X, int ldx, int x_off, const double* stats, const float* g, const float* beta,
+                                  const float* slope, float* Y, int ldy, int y_off, float* mr, int B, long P, int C,
+                                  double count, float eps, void* stream) {
+  SE_REQUIRE(X && stats && g && beta && Y && mr && B > 0 && P > 0 && count > 0 && chan_ok(C), "inorm_prelu_fwd: bad arguments (C=%d)", C);
+  SE_REQUIRE((ldx % 4) == 0 && (x_off % 4) == 0 && (ldy % 4) == 0 && (y_off % 4) == 0, "inorm_prelu_fwd: alignment");
+  const int psub = 256 / (C / 4);
+  long nb = (P + (long)psub * NB_U - 1) / ((long)psub * NB_U);
+  const long nb_cap = 2048 / B > 1 ? 2048 / B : 1;
+  if (nb > nb_cap) nb = nb_cap;
+  hipLaunchKernelGGL(inorm_prelu_fwd_kernel, dim3((int)nb, B), dim3(256), 0, as_stream(stream), X, ldx, x_off, stats, g, beta,
+                     slope, Y, ldy, y_off, mr, P, C, count, eps);
+  return se_check_launch("se_inorm_prelu_fwd");
+}
+
 extern "C" int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const float* g,
                                  const float* beta, const float* slope, const float* dY, int ldy, int y_off,
                                  double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,
@@ -412,15 +480,18 @@ extern "C" int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float
   const long nb_cap = 2048 / B > 1 ? 2048 / B : 1;
   if (nb > nb_cap) nb = nb_cap;
   if (phase & 1) {      // reduce (a data-parallel caller all-reduces `red` between the two phases: SyncBatchNorm)
-    (void)hipMemsetAsync(red, 0, sizeof(double) * 3 * nbs * C, s);
+    if (!(phase & 16)) (void)hipMemsetAsync(red, 0, sizeof(double) * 3 * nbs * C, s);
     hipLaunchKernelGGL(norm_prelu_bwd_reduce_kernel, dim3((int)(nb > (nb_cap + 3) / 4 ? (nb_cap + 3) / 4 : nb), B), dim3(256), 0, s, X, ldx,
                        x_off, mr, g, beta, slope, dY, ldy, y_off, red, P, C, per_batch, act);
   }
+  SE_REQUIRE(!((phase & 4) && (phase & 8)), "norm_prelu_bwd: phase bits 4 and 8 are alternatives");
+  SE_REQUIRE(!(phase & 8) || (phase & 2), "norm_prelu_bwd: phase bit 8 rides on the apply pass (bit 2)");
   if (phase & 4)        // parameter gradients from the LOCAL sums (before any cross-rank all-reduce)
     hipLaunchKernelGGL(norm_param_grad_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, red, dg, dbeta, dslope, nbs, C);
   if (phase & 2) {
     hipLaunchKernelGGL(norm_prelu_bwd_apply_kernel, dim3((int)nb, B), dim3(256), 0, s, X, ldx,
-                       x_off, mr, g, beta, slope, dY, ldy, y_off, red, dX, lddx, dx_off, P, C, per_batch, count, act);
+                       x_off, mr, g, beta, slope, dY, ldy, y_off, red, dX, lddx, dx_off, P, C, per_batch, count, act,
+                       (phase & 8) ? dg : nullptr, dbeta, dslope, nbs);
   }
   return se_check_launch("se_norm_prelu_bwd");
 }

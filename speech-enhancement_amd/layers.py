@@ -80,9 +80,7 @@ def inorm_prelu_fwd(R, stats, g, b, slope, out, ldy, y_off):
     B = R.shape[0]
     C_ = R.shape[-1]
     P = R.numel() // (B * C_)
-    mr, ss = O.norm_finalize(stats, g, b, B, C_, float(P))
-    O.affine_prelu(R, C_, 0, ss, slope, out, ldy, y_off, B, P, C_)
-    return mr
+    return O.inorm_prelu_fwd(R, C_, 0, stats, g, b, slope, out, ldy, y_off, B, P, C_)
 
 
 def inorm_prelu_bwd(R, mr, g, b, slope, dy, ldy, y_off, dg, db, dslope):

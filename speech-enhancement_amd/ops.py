@@ -106,6 +106,14 @@ def norm_finalize(stats, g, beta, nb, C_, count, eps=1e-5, running_mean=None, ru
     return mr, ss
 
 
+def inorm_prelu_fwd(x, ldx, x_off, stats, g, beta, slope, y, ldy, y_off, B, P, C_, eps=1e-5):
+    """InstanceNorm(affine) + PReLU from the producer's (sum, sumsq): one launch; returns mr [B, C, 2] = (mean, rstd)"""
+    mr = _new(B, C_, 2, like=g)
+    L.call('se_inorm_prelu_fwd', L.ptr(x), _i(ldx), _i(x_off), L.ptr(stats), L.ptr(g), L.ptr(beta), L.ptr(slope), L.ptr(y),
+           _i(ldy), _i(y_off), L.ptr(mr), _i(B), _l(P), _i(C_), _d(float(P)), _f(eps), L.stream())
+    return mr
+
+
 def bn_eval_scale(rm, rv, g, beta, eps=1e-5):
     C_ = g.numel()
     ss = _new(1, C_, 2, like=g)
@@ -125,7 +133,7 @@ def norm_prelu_bwd(x, ldx, x_off, mr, g, beta, slope, dy, ldy, y_off, dx, lddx, 
                    per_batch=True, act=0, allreduce=None, count=None):
     """allreduce: optional callable applied to the fp64 reduction buffer between the two phases
     (SyncBatchNorm backward); count: elements per statistic (defaults to the local count)."""
-    red = _new(L.lib().se_norm_prelu_bwd_workspace_bytes(_i(B), _i(C_), _i(int(per_batch))) // 8, like=x, dtype=f64)
+    red = zeros(L.lib().se_norm_prelu_bwd_workspace_bytes(_i(B), _i(C_), _i(int(per_batch))) // 8, device=x.device, dtype=f64)
     if count is None:
         count = float(P if per_batch else P * B)
     args = lambda phase: (L.ptr(x), _i(ldx), _i(x_off), L.ptr(mr), L.ptr(g), L.ptr(beta), L.ptr(slope),
@@ -133,9 +141,9 @@ def norm_prelu_bwd(x, ldx, x_off, mr, g, beta, slope, dy, ldy, y_off, dx, lddx, 
                           L.ptr(dbeta), L.ptr(dslope), _i(B), _l(P), _i(C_), _i(int(per_batch)), _i(act),
                           _i(phase), _d(count), L.stream())
     if allreduce is None:
-        L.call('se_norm_prelu_bwd', *args(7))
+        L.call('se_norm_prelu_bwd', *args(1 | 2 | 8 | 16))      # two launches: reduce, apply (+ parameter gradients); red from the arena
     else:
-        L.call('se_norm_prelu_bwd', *args(5))
+        L.call('se_norm_prelu_bwd', *args(1 | 4 | 16))
         allreduce(red)
         L.call('se_norm_prelu_bwd', *args(2))
     return dx

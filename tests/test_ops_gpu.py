@@ -51,12 +51,24 @@ def test_instance_norm_prelu(C):
     xn = F.instance_norm(x64.permute(0, 3, 1, 2), weight=p64[0], bias=p64[1], eps=1e-5)
     ref = F.prelu(xn, p64[2]).permute(0, 2, 3, 1)
     assert relerr(y[..., C:], ref) < 1e-5 and float(y[..., :C].abs().max()) == 0.0
+    # the one-launch form (se_inorm_prelu_fwd: finalize + apply) gives the same bits and the same (mean, rstd)
+    y1 = torch.zeros(B, T, Fq, 2 * C, device='cuda')
+    mr1 = O.inorm_prelu_fwd(x, C, 0, stats, g, be, a, y1, 2 * C, C, B, P, C)
+    assert torch.equal(y1, y) and torch.equal(mr1, mr)
     ref.backward(dy[..., C:].double())
     dg, db, da = (torch.zeros(C, device='cuda') for _ in range(3))
     dx = torch.empty_like(x)
     O.norm_prelu_bwd(x, C, 0, mr, g, be, a, dy, 2 * C, C, dx, C, 0, dg, db, da, B, P, C, per_batch=True)
     assert relerr(dx, x64.grad) < 5e-5
     assert relerr(dg, p64[0].grad) < 5e-5 and relerr(db, p64[1].grad) < 5e-5 and relerr(da, p64[2].grad) < 5e-5
+    # the exchange form (reduce + local parameter gradients, [all-reduce], apply) against the fused two-launch form
+    dg2, db2, da2 = (torch.zeros(C, device='cuda') for _ in range(3))
+    dx2 = torch.empty_like(x)
+    seen = []
+    O.norm_prelu_bwd(x, C, 0, mr, g, be, a, dy, 2 * C, C, dx2, C, 0, dg2, db2, da2, B, P, C, per_batch=True,
+                     allreduce=lambda red: seen.append(tuple(red.shape)))
+    assert seen and relerr(dx2, dx) < 1e-6
+    assert relerr(dg2, dg) < 1e-6 and relerr(db2, db) < 1e-6 and relerr(da2, da) < 1e-6
 
 
 def test_batchnorm_swish_bwd_and_running_stats():
