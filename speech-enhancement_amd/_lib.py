@@ -66,10 +66,13 @@ class KernelTimer:
 
     def __init__(self):
         self.active = False
+        self.every = False
         self.records = []
 
-    def start(self):
+    def start(self, every_call=False):
+        """every_call: also time the launches without a roofline key, and keep the stream each one went to (tools/streams_timeline.py)"""
         self.records = []
+        self.every = every_call
         self.active = True
 
     def stop(self):
@@ -78,7 +81,7 @@ class KernelTimer:
     def summary(self):
         """key -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
         out = {}
-        for key, flops, nbytes, e0, e1 in self.records:
+        for key, flops, nbytes, e0, e1, _ in self.records:
             d = out.setdefault(key, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
             d['launches'] += 1
             d['ms'] += e0.elapsed_time(e1)
@@ -92,12 +95,12 @@ TIMER = KernelTimer()
 
 def call(name, *args, _key=None, _flops=0.0, _bytes=0.0):
     fn = getattr(lib(), name)
-    if TIMER.active and _key is not None:
+    if TIMER.active and (_key is not None or TIMER.every):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
         e1.record()
-        TIMER.records.append((_key, _flops, _bytes, e0, e1))
+        TIMER.records.append((_key or name, _flops, _bytes, e0, e1, torch.cuda.current_stream().cuda_stream))
     else:
         rc = fn(*args)
     if rc != 0:
