@@ -1,5 +1,8 @@
 #!/bin/bash
 # per-queue busy time, overlap and idle gaps of the last traced step of the default bench: tools/trace_timeline.sh <tag> [bench args]
+# NOTE: under rocprofv3 --kernel-trace all dispatches of this workload come out on ONE queue and strictly serialised (no two kernels
+# in flight), so this shows the SERIAL order only: kernel-boundary gaps (3.5 ms over 936 launches) and the main-queue top list.
+# For the concurrency of the real step use tools/streams_timeline.py (HIP events on each stream, no profiler attached).
 TAG=${1:-tl0}
 shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
