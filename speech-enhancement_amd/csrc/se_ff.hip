@@ -17,13 +17,18 @@ struct FfArgs {
 
 // WPL: W1 / W2 arrive pre-split (se_weight_prep: three bf16 planes each, 64 * hid elements apart): the weight blocks are
 // plain 16-B copies into LDS instead of 8 fp32 loads + 8 three-way splits (144 VALU instructions) per thread and block.
-template <int NPL, bool WPL = false>
+// NB: number of 64-wide hidden blocks when known at compile time (4 for the Conformer's hid = 256; 0 = run-time loop).  With NB
+// the sweep is straight-line code: at the head of a LOOP the wait-count pass has to merge the entry state (weight loads only)
+// with the back edge (weight loads, then the H stores) and falls back to vmcnt(0) -- every block then waits for the write
+// acknowledgements of the previous block's H stores.  Unrolled, the wait for the weights is vmcnt(#stores issued after them).
+template <int NPL, bool WPL = false, int NB = 0>
 __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 workgroups per CU: VGPR + AGPR <= 256
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
   __shared__ __attribute__((aligned(16))) __bf16 W1p[NPL * PB];
   __shared__ __attribute__((aligned(16))) __bf16 W2p[NPL * PB];
   __shared__ __attribute__((aligned(16))) float patch[4 * 32 * SP];    // wave-private 32 x 32 transposes
   __shared__ __attribute__((aligned(16))) float b1s[64];
+  __shared__ __attribute__((aligned(16))) float gbs[128];               // LayerNorm gamma | beta
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* cs = patch + wave * 32 * SP;
   const long m0 = (long)blockIdx.x * 128;
@@ -36,22 +41,28 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
 
   bf16x8 af1[4][NPL];
   {
-    const float* __restrict__ xp = a.X + row * 64 + 8 * kg;
-    float mean = 0.f, rstd = 0.f;
-    if (rok) { float2 mr = *reinterpret_cast<const float2*>(a.rowstats + 2 * row); mean = mr.x; rstd = mr.y; }
+    // every load of the prologue is unconditional (rows past M read row M - 1 and are zeroed by selects below): predicated
+    // loads compile to divergent branches with an s_waitcnt vmcnt(0) in each -- 8 dependent memory round trips per workgroup
+    const long rowl = rok ? row : a.M - 1;
+    const float* __restrict__ xp = a.X + rowl * 64 + 8 * kg;
+    const float2 mr = *reinterpret_cast<const float2*>(a.rowstats + 2 * rowl);
+    const float mean = mr.x, rstd = mr.y;
     float4 v[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      v[ks][0] = rok ? *reinterpret_cast<const float4*>(xp + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
-      v[ks][1] = rok ? *reinterpret_cast<const float4*>(xp + 16 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[ks][0] = *reinterpret_cast<const float4*>(xp + 16 * ks);
+      v[ks][1] = *reinterpret_cast<const float4*>(xp + 16 * ks + 4);
     }
+    // gamma / beta through LDS: fetched piecewise from global memory under register pressure they were 12 dependent L2 round trips
+    if (tid < 32) *reinterpret_cast<float4*>(&gbs[4 * tid]) = *reinterpret_cast<const float4*>((tid < 16 ? a.gamma : a.beta - 64) + 4 * tid);
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       float x[8];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int c = 16 * ks + 8 * kg + 4 * h;
-        const float4 gm = *reinterpret_cast<const float4*>(a.gamma + c), bt = *reinterpret_cast<const float4*>(a.beta + c);
+        const float4 gm = *reinterpret_cast<const float4*>(&gbs[c]), bt = *reinterpret_cast<const float4*>(&gbs[64 + c]);
         const float4 w = v[ks][h];
         x[4 * h] = rok ? (w.x - mean) * rstd * gm.x + bt.x : 0.f;
         x[4 * h + 1] = rok ? (w.y - mean) * rstd * gm.y + bt.y : 0.f;
@@ -62,12 +73,14 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
     }
   }
   const int kq = tid & 15, r0 = tid >> 4;
-  const int nb = a.hid / 64;
+  const int nb = NB > 0 ? NB : a.hid / 64;
   float4 rw1[4], rw2[4];
   const int pr = tid >> 2, pc = tid & 3;       // pre-split weights: row, 16-B chunks pc and pc + 4 of a 64 x 64 bf16 block
   const size_t wpl = (size_t)64 * (size_t)a.hid;
   f32x4 rp1[NPL * 2], rp2[NPL * 2];           // (flat register arrays: a 2-D array behind the lambda went to scratch memory)
+  float b1n = 0.f;                             // bias of the next hidden block, fetched with its weights (lanes 0..63)
   auto load_w = [&](int jb) {
+    b1n = a.b1[jb * 64 + (tid & 63)];
     if (WPL) {
       const __bf16* w1 = reinterpret_cast<const __bf16*>(a.W1) + ((unsigned)(jb * 64 + pr) * 64u + 8 * pc);
       const __bf16* w2 = reinterpret_cast<const __bf16*>(a.W2) + ((unsigned)pr * (unsigned)a.hid + jb * 64 + 8 * pc);
@@ -93,6 +106,14 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
   for (int r = 0; r < 16; ++r) { y0[r] = 0.f; y1[r] = 0.f; }
   const int frag = (lane & 31) * SB + 8 * kg;
   const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+  // H and Y leave through buffer stores whose descriptor covers the VALID rows of this workgroup's 128: a row past M is dropped
+  // by the range check instead of a branch.  With branches around the stores the compiler can not count them, and the wait
+  // for the next weight block (issued BEFORE them, so vmcnt(#stores) would do) became vmcnt(0): every hidden block waited for
+  // the write acknowledgements of the previous one.
+  const long rows_ok = a.M - m0 < 128 ? a.M - m0 : 128;
+  const __amdgpu_buffer_rsrc_t Hrs = make_rsrc_(a.H + m0 * a.hid, (unsigned)(rows_ok * a.hid * 4));
+  const __amdgpu_buffer_rsrc_t Yrs = make_rsrc_(a.Y + m0 * 64, (unsigned)(rows_ok * 64 * 4));
+#pragma unroll
   for (int jb = 0; jb < nb; ++jb) {
     if (WPL) {
 #pragma unroll
@@ -109,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
         split_store<NPL>(rw2[i], &W2p[(r0 + 16 * i) * SB + kq * 4], PB);
       }
     }
-    if (tid < 64) b1s[tid] = a.b1[jb * 64 + tid];
+    if (tid < 64) b1s[tid] = b1n;
     __syncthreads();
     if (jb + 1 < nb) load_w(jb + 1);
     f32x16 acc0, acc1;
@@ -143,10 +164,8 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rl = rr + 8 * i;
-        const long rg = m0 + wave * 32 + rl;
-        if (rg < a.M)
-          *reinterpret_cast<float4*>(a.H + rg * a.hid + jb * 64 + nt * 32 + cq * 4) =
-              *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
+        buf_store4_(Hrs, (unsigned)(((wave * 32 + rl) * a.hid + jb * 64 + nt * 32 + cq * 4) * 4),
+                    *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]));
       }
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
@@ -180,7 +199,14 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
     __syncthreads();
   }
   // Y = X + alpha * Drop_o(acc + b2)
-  float4 kept[2][4];
+  float4 kept[2][4];          // first the residual rows (all 8 loads in flight at once: they were 8 dependent round trips), then Y
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long rg_ = m0 + wave * 32 + rr + 8 * i;
+      kept[nt][i] = *reinterpret_cast<const float4*>(a.X + (rg_ < a.M ? rg_ : a.M - 1) * 64 + nt * 32 + cq * 4);
+    }
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -193,17 +219,17 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int rl = rr + 8 * i;
-      const long rg = m0 + wave * 32 + rl;
-      if (rg >= a.M) continue;
+      const long rg_ = m0 + wave * 32 + rl;
+      const long rg = rg_ < a.M ? rg_ : a.M - 1;        // clamped: the residual load below stays unconditional
       float4 v = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
       v.x += b2v.x; v.y += b2v.y; v.z += b2v.z; v.w += b2v.w;
       if (dr) {
         const float4 d4 = drop_scale4(a.seed_o, (unsigned)(rg * 64 + n), thr, inv_keep);
         v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
       }
-      const float4 xr = *reinterpret_cast<const float4*>(a.X + rg * 64 + n);
+      const float4 xr = kept[nt][i];
       const float4 yo = make_float4(xr.x + a.alpha * v.x, xr.y + a.alpha * v.y, xr.z + a.alpha * v.z, xr.w + a.alpha * v.w);
-      *reinterpret_cast<float4*>(a.Y + rg * 64 + n) = yo;
+      buf_store4_(Yrs, (unsigned)(((wave * 32 + rl) * 64 + n) * 4), yo);
       kept[nt][i] = yo;
     }
   }
@@ -242,7 +268,9 @@ struct FfBwdArgs {
   const float* X; const float* stats; const float* gamma; const float* dR2; float* dX; float* dgamma; float* dbeta;
 };
 
-template <int NPL, bool WPL = false>
+// NB as in ff_fwd_kernel (straight-line sweep: exact wait counts).  No predicated global access anywhere: rows past M are clamped
+// (loads) or dropped by the range check of a buffer descriptor (H loads, dZ / dX / dLN stores).
+template <int NPL, bool WPL = false, int NB = 0>
 __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
   __shared__ __attribute__((aligned(16))) __bf16 Wa[NPL * PB];         // W2T block: rows = hidden units, k = channel
@@ -260,50 +288,65 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
 
   bf16x8 af1[4][NPL];
   {
-    const float* __restrict__ yp = a.dY + row * 64 + 8 * kg;
+    const float* __restrict__ yp = a.dY + (rok ? row : a.M - 1) * 64 + 8 * kg;
+    float4 v[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v[ks][0] = *reinterpret_cast<const float4*>(yp + 16 * ks);
+      v[ks][1] = *reinterpret_cast<const float4*>(yp + 16 * ks + 4);
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       float x[8];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int c = 16 * ks + 8 * kg + 4 * h;
-        float4 w = rok ? *reinterpret_cast<const float4*>(yp + 16 * ks + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (dr && rok) {
+        float4 w = v[ks][h];
+        if (dr) {
           const float4 d4 = drop_scale4(a.seed_o, (unsigned)(row * 64 + c), thr, inv_keep);
           w.x *= d4.x; w.y *= d4.y; w.z *= d4.z; w.w *= d4.w;
         }
-        x[4 * h] = w.x; x[4 * h + 1] = w.y; x[4 * h + 2] = w.z; x[4 * h + 3] = w.w;
+        x[4 * h] = rok ? w.x : 0.f; x[4 * h + 1] = rok ? w.y : 0.f; x[4 * h + 2] = rok ? w.z : 0.f; x[4 * h + 3] = rok ? w.w : 0.f;
       }
       split_planes8<NPL>(x, af1[ks]);
     }
   }
   const int kq = tid & 15, r0 = tid >> 4;
-  const int nb = a.hid / 64;
+  const int nb = NB > 0 ? NB : a.hid / 64;
+  const long rows_ok = a.M - m0 < 128 ? a.M - m0 : 128;
+  const __amdgpu_buffer_rsrc_t Hrs = make_rsrc_(a.H + m0 * a.hid, (unsigned)(rows_ok * a.hid * 4));
+  const __amdgpu_buffer_rsrc_t Zrs = make_rsrc_(a.dZ + m0 * a.hid, (unsigned)(rows_ok * a.hid * 4));
+  // pre-split weight blocks: fetched into registers during the second GEMM of the previous block (where the H tile and the
+  // first GEMM's accumulators are dead), written to LDS at the top of their own block
+  const int pr = tid >> 2, pc = tid & 3;
+  const size_t wpl = (size_t)64 * (size_t)a.hid;
+  f32x4 va[NPL * 2], vb[NPL * 2];             // (ext-vector registers: an array of uint4 structs behind the lambda went to scratch memory)
+  auto load_w = [&](int jb) {
+    const __bf16* wa = reinterpret_cast<const __bf16*>(a.W2T) + ((unsigned)(jb * 64 + pr) * 64u + 8 * pc);
+    const __bf16* wb = reinterpret_cast<const __bf16*>(a.W1T) + ((unsigned)pr * (unsigned)a.hid + jb * 64 + 8 * pc);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        va[q * 2 + h] = *reinterpret_cast<const f32x4*>(wa + q * wpl + 32 * h);
+        vb[q * 2 + h] = *reinterpret_cast<const f32x4*>(wb + q * wpl + 32 * h);
+      }
+  };
+  if (WPL) load_w(0);
   f32x16 g0, g1;                              // dLN accumulators (32 rows x 64 channels)
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
   const int frag = (lane & 31) * SB + 8 * kg;
   const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+#pragma unroll
   for (int jb = 0; jb < nb; ++jb) {
     if (WPL) {       // pre-split planes (64 * hid elements apart): 16-B copies, no split
-      const int pr = tid >> 2, pc = tid & 3;
-      const size_t wpl = (size_t)64 * (size_t)a.hid;
-      const __bf16* wa = reinterpret_cast<const __bf16*>(a.W2T) + ((unsigned)(jb * 64 + pr) * 64u + 8 * pc);
-      const __bf16* wb = reinterpret_cast<const __bf16*>(a.W1T) + ((unsigned)pr * (unsigned)a.hid + jb * 64 + 8 * pc);
-      uint4 va[NPL][2], vb[NPL][2];
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          va[q][h] = *reinterpret_cast<const uint4*>(wa + q * wpl + 32 * h);
-          vb[q][h] = *reinterpret_cast<const uint4*>(wb + q * wpl + 32 * h);
-        }
-#pragma unroll
-      for (int q = 0; q < NPL; ++q)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          *reinterpret_cast<uint4*>(&Wa[q * PB + pr * SB + 8 * pc + 32 * h]) = va[q][h];
-          *reinterpret_cast<uint4*>(&Wb[q * PB + pr * SB + 8 * pc + 32 * h]) = vb[q][h];
+          *reinterpret_cast<f32x4*>(&Wa[q * PB + pr * SB + 8 * pc + 32 * h]) = va[q * 2 + h];
+          *reinterpret_cast<f32x4*>(&Wb[q * PB + pr * SB + 8 * pc + 32 * h]) = vb[q * 2 + h];
         }
     } else {
 #pragma unroll
@@ -321,9 +364,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long rg = m0 + wave * 32 + rr + 8 * i;
-        hp[nt * 4 + i] = rg < a.M ? *reinterpret_cast<const float4*>(a.H + rg * a.hid + jb * 64 + nt * 32 + cq * 4)
-                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        hp[nt * 4 + i] = buf_load4_(Hrs, (unsigned)(((wave * 32 + rr + 8 * i) * a.hid + jb * 64 + nt * 32 + cq * 4) * 4));
       }
     __syncthreads();
     f32x16 acc0, acc1;
@@ -365,9 +406,10 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
         }
         v.x *= swish_gradf_(hz.x); v.y *= swish_gradf_(hz.y); v.z *= swish_gradf_(hz.z); v.w *= swish_gradf_(hz.w);
         if (rg >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        else *reinterpret_cast<float4*>(a.dZ + rg * a.hid + jb * 64 + nt * 32 + cq * 4) = v;
+        buf_store4_(Zrs, (unsigned)(((wave * 32 + rl) * a.hid + jb * 64 + nt * 32 + cq * 4) * 4), v);
         *reinterpret_cast<float4*>(&cs[rl * SP + cq * 4]) = v;
       }
+      if (WPL && nt == 1 && jb + 1 < nb) load_w(jb + 1);
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
         const int ks = 2 * nt + k2;
@@ -411,8 +453,8 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long rg = m0 + wave * 32 + rr + 8 * i;
-        if (rg < a.M) *reinterpret_cast<float4*>(a.dLN + rg * 64 + nt * 32 + cq * 4) = gv[nt][i];
+        const __amdgpu_buffer_rsrc_t Lrs = make_rsrc_(a.dLN + m0 * 64, (unsigned)(rows_ok * 64 * 4));
+        buf_store4_(Lrs, (unsigned)(((wave * 32 + rr + 8 * i) * 64 + nt * 32 + cq * 4) * 4), gv[nt][i]);
       }
     return;
   }
@@ -421,16 +463,33 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
   float4 gm[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) gm[nt] = *reinterpret_cast<const float4*>(a.gamma + nt * 32 + cq * 4);
+  // every operand row of the LayerNorm backward is requested here, before any is used (behind `if (ok)` they were a dozen
+  // dependent round trips per workgroup)
+  float2 mrs[4];
+  float4 xvs[4][2], r1s[4][2], r2s[4][2];
+  const __amdgpu_buffer_rsrc_t Xrs = make_rsrc_(a.dX + m0 * 64, (unsigned)(rows_ok * 64 * 4));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long rg_ = m0 + wave * 32 + rr + 8 * i;
+    const long rgc = rg_ < a.M ? rg_ : a.M - 1;
+    mrs[i] = *reinterpret_cast<const float2*>(a.stats + 2 * rgc);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const long off = rgc * 64 + nt * 32 + cq * 4;
+      xvs[i][nt] = *reinterpret_cast<const float4*>(a.X + off);
+      r1s[i][nt] = *reinterpret_cast<const float4*>(a.dY + off);
+      r2s[i][nt] = a.dR2 ? *reinterpret_cast<const float4*>(a.dR2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long rg = m0 + wave * 32 + rr + 8 * i;
     const bool ok = rg < a.M;
-    float mean = 0.f, rstd = 0.f;
-    if (ok) { const float2 mr = *reinterpret_cast<const float2*>(a.stats + 2 * rg); mean = mr.x; rstd = mr.y; }
+    const float mean = mrs[i].x, rstd = mrs[i].y;
     float xh[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const float4 xv = ok ? *reinterpret_cast<const float4*>(a.X + rg * 64 + nt * 32 + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 xv = xvs[i][nt];
       const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
       const float dv[4] = {gv[nt][i].x, gv[nt][i].y, gv[nt][i].z, gv[nt][i].w};
       const float gl[4] = {gm[nt].x, gm[nt].y, gm[nt].z, gm[nt].w};
@@ -445,17 +504,13 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
     s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
-    if (ok) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        const long off = rg * 64 + nt * 32 + cq * 4;
-        const float4 r1 = *reinterpret_cast<const float4*>(a.dY + off);
-        float o4[4] = {r1.x, r1.y, r1.z, r1.w};
-        if (a.dR2) { const float4 r2 = *reinterpret_cast<const float4*>(a.dR2 + off); o4[0] += r2.x; o4[1] += r2.y; o4[2] += r2.z; o4[3] += r2.w; }
+    for (int nt = 0; nt < 2; ++nt) {
+      const float4 r1 = r1s[i][nt], r2 = r2s[i][nt];
+      float o4[4] = {r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
-        *reinterpret_cast<float4*>(a.dX + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
-      }
+      for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
+      buf_store4_(Xrs, (unsigned)(((wave * 32 + rr + 8 * i) * 64 + nt * 32 + cq * 4) * 4), make_float4(o4[0], o4[1], o4[2], o4[3]));
     }
   }
   // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
@@ -496,6 +551,7 @@ extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T
   FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, X, stats, gamma, dR2, dX, dgamma, dbeta};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else if (wpl && hid == 256) hipLaunchKernelGGL((ff_bwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);
   else if (wpl) hipLaunchKernelGGL((ff_bwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL(ff_bwd_kernel<3>, grid, block, 0, as_stream(stream), a);
   return se_check_launch("se_ff_bwd_dgrad");
@@ -522,6 +578,7 @@ extern "C" int se_ff_fwd_stats(const float* X, const float* rowstats, const floa
   FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  else if (wpl && hid == 256) hipLaunchKernelGGL((ff_fwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);
   else if (wpl) hipLaunchKernelGGL((ff_fwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL(ff_fwd_kernel<3>, grid, block, 0, as_stream(stream), a);
   return se_check_launch("se_ff_fwd");

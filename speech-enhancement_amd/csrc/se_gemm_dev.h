@@ -513,6 +513,10 @@ static __device__ __forceinline__ float4 buf_load4_(__amdgpu_buffer_rsrc_t r, un
   typedef unsigned u32x4b_ __attribute__((ext_vector_type(4)));
   return __builtin_bit_cast(float4, (u32x4b_)__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+static __device__ __forceinline__ void buf_store4_(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+  typedef unsigned u32x4b_ __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b_, v), r, byte_off, 0, 0);
+}
 constexpr unsigned BUF_OOB_ = 0xfffffff0u;      // a byte offset no descriptor of ours covers
 // Register-resident variants of the same packed split: x[] (8 or 4 floats) -> NPL planes of bf16x8 / bf16x4; x[] is consumed.
 typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
