@@ -971,11 +971,20 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
   const __bf16 *Et0 = a.Ets, *Et1 = a.Ets + (long)a.ET * 16, *Et2 = a.Ets + (long)a.ET * 32;
 
   // ---- stage this wave's keys: K pre-split into the LDS image (row fragments b64, column fragments tr_b16) ----
+  // all NK rows are requested before the first one is split (clamped key index, zeroed by a select): with the load behind
+  // `if (key < n)` every key tile was its own dependent HBM round trip (rows of a time-axis sequence are 77 KB apart)
+  float4 k4s[NK];
+#pragma unroll
+  for (int s = 0; s < NK; ++s) {
+    int key = (kt0 + s) * 16 + c;
+    if (key > n - 1) key = n - 1;
+    k4s[s] = *reinterpret_cast<const float4*>(qb + (unsigned)(key * ps * 192 + 64 + 4 * g));
+  }
 #pragma unroll
   for (int s = 0; s < NK; ++s) {
     const int key = (kt0 + s) * 16 + c;
-    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((EXACT || s < nk_w) && key < n) k4 = *reinterpret_cast<const float4*>(qb + (unsigned)(key * ps * 192 + 64 + 4 * g));
+    const bool kok = (EXACT || s < nk_w) && key < n;
+    const float4 k4 = make_float4(kok ? k4s[s].x : 0.f, kok ? k4s[s].y : 0.f, kok ? k4s[s].z : 0.f, kok ? k4s[s].w : 0.f);
     const S3 ks = split3(k4);
     st8(Kimg + ((0 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_h(ks));
     st8(Kimg + ((1 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_m(ks));
@@ -1264,14 +1273,27 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   const long base = seq_base(a.g, seq);
   const int ps = (int)a.g.pos_stride;
   const float* qb = a.QKV + base * 192 + head * 16;
-  for (int i = tid; i < NP * 4; i += NT) {
-    const int j = i >> 2, q = i & 3;
-    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j < n) v4 = *reinterpret_cast<const float4*>(qb + (unsigned)(j * ps * 192 + 128 + 4 * q));
-    const S3 vs = split3(v4);
-    st8(Vimg + ((0 * NP + j) * 16 + 4 * q) * 2, get_h(vs));
-    st8(Vimg + ((1 * NP + j) * 16 + 4 * q) * 2, get_m(vs));
-    st8(Vimg + ((2 * NP + j) * 16 + 4 * q) * 2, get_l(vs));
+  // V rows in batches of 4 per thread: requested together (clamped row, zeroed by a select), then split -- one load behind
+  // `if (j < n)` per loop iteration was one dependent HBM round trip per iteration
+  for (int i0 = tid; i0 < NP * 4; i0 += 4 * NT) {
+    float4 vv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int j = (i0 + e * NT) >> 2;
+      if (j > n - 1) j = n - 1;
+      vv[e] = *reinterpret_cast<const float4*>(qb + (unsigned)(j * ps * 192 + 128 + 4 * (tid & 3)));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = i0 + e * NT, j = i >> 2, q = i & 3;          // NT is a multiple of 4: q == tid & 3
+      if (i < NP * 4) {
+        const bool ok = j < n;
+        const S3 vs = split3(make_float4(ok ? vv[e].x : 0.f, ok ? vv[e].y : 0.f, ok ? vv[e].z : 0.f, ok ? vv[e].w : 0.f));
+        st8(Vimg + ((0 * NP + j) * 16 + 4 * q) * 2, get_h(vs));
+        st8(Vimg + ((1 * NP + j) * 16 + 4 * q) * 2, get_m(vs));
+        st8(Vimg + ((2 * NP + j) * 16 + 4 * q) * 2, get_l(vs));
+      }
+    }
   }
   __syncthreads();
   float* Ul = Ubase + wave * (TQ * 512);      // [tile t][slot][256]

@@ -520,14 +520,23 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   const bool rok = row < Mb;
   bf16x8 af[4][NPL];
   {
-    const float* __restrict__ ap = g.A + (long)row * d.lda + d.a_off + 8 * kg;
+    // no predicated loads: rows past the end read the last row and are zeroed by selects; the per-channel prologue operands
+    // (LayerNorm gamma / beta, BatchNorm scale / shift) go through LDS.  Behind `rok ? load : 0` the compiler emitted one
+    // divergent branch + s_waitcnt vmcnt(0) per load: ~10 dependent L2 round trips before a workgroup's first MFMA.
+    const long rowl = rok ? row : Mb - 1;
+    const float* __restrict__ ap = g.A + rowl * d.lda + d.a_off + 8 * kg;
     float mean = 0.f, rstd = 0.f;
-    if (PRO == SE_PRO_LN && rok) { float2 mr = *reinterpret_cast<const float2*>(g.rowstats + 2 * (long)row); mean = mr.x; rstd = mr.y; }
+    if (PRO == SE_PRO_LN) { const float2 mr = *reinterpret_cast<const float2*>(g.rowstats + 2 * rowl); mean = mr.x; rstd = mr.y; }
     float4 v[4][2];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      v[ks][0] = rok ? *reinterpret_cast<const float4*>(ap + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
-      v[ks][1] = rok ? *reinterpret_cast<const float4*>(ap + 16 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[ks][0] = *reinterpret_cast<const float4*>(ap + 16 * ks);
+      v[ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
+    }
+    float* pss = patch;                          // [ps 64 | pb 64], the patch is not in use yet
+    if (PRO == SE_PRO_LN || PRO == SE_PRO_AFFINE_SWISH) {
+      if (tid < 32) *reinterpret_cast<float4*>(&pss[4 * tid]) = *reinterpret_cast<const float4*>((tid < 16 ? g.ps : g.pb - 64) + 4 * tid);
+      __syncthreads();
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -536,12 +545,15 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
       for (int h = 0; h < 2; ++h) {
         const int c = 16 * ks + 8 * kg + 4 * h;
         float4 w = v[ks][h];
-        if (PRO != SE_PRO_NONE && rok) {
+        if (PRO != SE_PRO_NONE) {
           float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
-          load_pro_vec<PRO>(g.ps, g.pb, c, true, ps4, pb4);
+          if (PRO == SE_PRO_LN || PRO == SE_PRO_AFFINE_SWISH) {
+            ps4 = *reinterpret_cast<const float4*>(&pss[c]);
+            pb4 = *reinterpret_cast<const float4*>(&pss[64 + c]);
+          }
           w = apply_pro<PRO>(w, c, 64, mean, rstd, ps4, pb4, (unsigned)row, d.pro_seed, thr, inv_keep);
         }
-        x[4 * h] = w.x; x[4 * h + 1] = w.y; x[4 * h + 2] = w.z; x[4 * h + 3] = w.w;
+        x[4 * h] = rok ? w.x : 0.f; x[4 * h + 1] = rok ? w.y : 0.f; x[4 * h + 2] = rok ? w.z : 0.f; x[4 * h + 3] = rok ? w.w : 0.f;
       }
       split_planes8<NPL>(x, af[ks]);
     }
