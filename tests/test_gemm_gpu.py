@@ -550,3 +550,39 @@ def test_row_statistics_from_producer_epilogues(G):
     with pytest.raises(L.SeHipError):          # only whole 64-channel rows have row statistics
         gemm.gemm_tap(gemm.linear_desc(M, 64, 128, epilogue=L.EPI_ROWSTATS), x, rnd(128, 64, seed=14), torch.empty(M, 128, device='cuda'),
                       AUX=torch.empty(M, 2, device='cuda'))
+
+
+@pytest.mark.parametrize('hid,planes', [(256, True), (128, True), (256, False)])
+def test_ff_kernels_fused_layernorm_backward_and_hidden_sizes(G, hid, planes):
+    """ff_fwd / ff_bwd_dgrad at a ragged M: the straight-line hid = 256 instantiation (pre-split weights) and the run-time-loop
+    ones (hid = 128 planes, fp32 weights) give the same bits as each other where both exist, and the LayerNorm backward fused
+    into ff_bwd_dgrad (ln=...) equals ff_bwd_dgrad + se_layernorm_bwd, incl. the residual path and dgamma / dbeta."""
+    gemm, L = G
+    from speech_enhancement_amd import ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    M = 128 * 5 + 77
+    x, dy, dR2 = rnd(M, 64, seed=1) * 1.3 + 0.2, rnd(M, 64, seed=2), rnd(M, 64, seed=3)
+    W1, b1 = rnd(hid, 64, seed=4, scale=0.1), rnd(hid, seed=5) * 0.1
+    W2, b2 = rnd(64, hid, seed=6, scale=0.05), rnd(64, seed=7) * 0.1
+    gam, bet = rnd(64, seed=8) * 0.2 + 1.0, rnd(64, seed=9) * 0.1
+    st = O.row_stats(x, M)
+    plan = WeightPlan(torch.device('cuda'))
+    w = {}
+    for tag, pl in (('p', True), ('f', False)):
+        w[tag] = (plan.linear('w1' + tag, W1, planes=pl), plan.linear('w2' + tag, W2, planes=pl),
+                  plan.linear_T('w2t' + tag, W2, planes=pl, scale=0.5), plan.linear_T('w1t' + tag, W1, planes=pl))
+    plan.run()
+    tag = 'p' if planes else 'f'
+    y, h, ost = gemm.ff_fwd(x, st, gam, bet, w[tag][0], b1, w[tag][1], b2, 0.2, 11, 12, 0.5, precision=2, hid=hid, out_stats=True)
+    yf, hf = gemm.ff_fwd(x, st, gam, bet, w['f'][0], b1, w['f'][1], b2, 0.2, 11, 12, 0.5, precision=2)
+    assert torch.equal(y, yf) and torch.equal(h, hf)
+    assert relerr(ost, O.row_stats(y, M)) < 1e-5
+    z0, dln = gemm.ff_bwd_dgrad(dy, h, w[tag][2], w[tag][3], 0.2, 11, 12, precision=2)
+    zf, dlnf = gemm.ff_bwd_dgrad(dy, h, w['f'][2], w['f'][3], 0.2, 11, 12, precision=2)
+    assert torch.equal(z0, zf) and torch.equal(dln, dlnf)
+    dg0, db0 = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    dx0 = O.layernorm_bwd(x, st, gam, dln, dg0, db0, dR=dy, dR2=dR2)
+    dg1, db1 = torch.zeros(64, device='cuda'), torch.zeros(64, device='cuda')
+    z1, dx1 = gemm.ff_bwd_dgrad(dy, h, w[tag][2], w[tag][3], 0.2, 11, 12, precision=2, ln=(x, st, gam, dR2, dg1, db1))
+    assert torch.equal(z1, z0)
+    assert relerr(dx1, dx0) < 2e-6 and relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5
