@@ -1158,6 +1158,13 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
       }
     }
 
+    // The next tile's query-side operands were requested a whole tile ago: make them arrive HERE, before this tile's dQ / dE
+    // stores are issued.  Left to the first use at the top of the next tile, the wait comes right after those stores, and behind
+    // their (wave-uniform, but still control-flow) conditions the wait-count pass can only emit vmcnt(0): one exposed write
+    // acknowledgement per query tile.
+    asm volatile("" : "+v"(nxt.q4.x), "+v"(nxt.q4.y), "+v"(nxt.q4.z), "+v"(nxt.q4.w), "+v"(nxt.do4.x), "+v"(nxt.do4.y), "+v"(nxt.do4.z), "+v"(nxt.do4.w));
+    asm volatile("" : "+v"(nxt.qcf[0]), "+v"(nxt.qcf[1]), "+v"(nxt.qcf[2]), "+v"(nxt.qcf[3]), "+v"(nxt.docf[0]), "+v"(nxt.docf[1]), "+v"(nxt.docf[2]), "+v"(nxt.docf[3]));
+    asm volatile("" : "+v"(nxt.lse[0]), "+v"(nxt.lse[1]), "+v"(nxt.lse[2]), "+v"(nxt.lse[3]), "+v"(nxt.dl[0]), "+v"(nxt.dl[1]), "+v"(nxt.dl[2]), "+v"(nxt.dl[3]));
     // ---- dQ of this query tile ----
     if (GROUP) {
       float* slot = dqs + ((qt & 1) * 4) * 256;
