@@ -242,7 +242,7 @@ def predict(model, config, noisy_signal, alpha, beta, alpha_cum, sigmas, T, c1, 
     """inference_diffuse.py:194-228: supportive reverse diffusion of one clip [L] or a batch [B, L] of equal-length clips.
     `noises` (optional, [steps - 1, B, 100 T]) replaces torch.randn_like for reproducible parity runs.
     The conditioner projections are computed once and reused by every step.  `streams`: number of independent batch parts run
-    concurrently (default $SE_DIFFUSE_STREAMS or 1; parts hold at least 4 clips)."""
+    concurrently (default $SE_DIFFUSE_STREAMS or 2; parts hold at least 4 clips)."""
     noisy = torch.as_tensor(np.asarray(noisy_signal), dtype=torch.float32, device=device)
     single = noisy.dim() == 1
     if single:
@@ -255,9 +255,9 @@ def predict(model, config, noisy_signal, alpha, beta, alpha_cum, sigmas, T, c1, 
     cond = model.conditioner(spec)
     B = noisy.shape[0]
     # Clips never interact (GroupNorm is per sample), so the batch can be cut into `streams` independent parts, each stepping
-    # through the whole reverse process on its own HIP stream.  Measured at batch 32 (tools/bench_diffuse.py): 17.65 / 17.61 /
-    # 16.9 utt/s for 1 / 2 / 3 parts -- every kernel here already fills the chip, so the default stays the serial order.
-    nparts = max(1, min(int(streams if streams is not None else os.environ.get('SE_DIFFUSE_STREAMS', '1')), B // 4 or 1))
+    # through the whole reverse process on its own HIP stream.  Measured at batch 32 (tools/bench_diffuse.py) on two boxes:
+    # 17.65 / 17.61 / 16.9 and 16.6 / 18.0 / 17.0 utt/s for 1 / 2 / 3 parts -- two parts are never slower: the default.
+    nparts = max(1, min(int(streams if streams is not None else os.environ.get('SE_DIFFUSE_STREAMS', '2')), B // 4 or 1))
     cuts = [B * i // nparts for i in range(nparts + 1)]
     parts = [slice(cuts[i], cuts[i + 1]) for i in range(nparts)]
     main = torch.cuda.current_stream(device)

@@ -23,7 +23,7 @@ for ns in (1, 2, 3, 2, 1):
     S.predict_diffuse(m, cfg, x, *sched, streams=ns)
     torch.cuda.synchronize()
     by_streams.setdefault(ns, []).append(round(B / (time.time() - t0), 2))
-dt = B / max(by_streams[1])
+dt = B / max(by_streams[2])
 # phases
 noisy = torch.from_numpy(x).cuda()
 from speech_enhancement_amd import frontend as FE
