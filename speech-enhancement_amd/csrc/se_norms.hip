@@ -217,19 +217,29 @@ __global__ __launch_bounds__(256) void inorm_prelu_fwd_kernel(
     float* __restrict__ mr, long P, int C, double count, float eps) {
   ChanIter it(C);
   const int b = blockIdx.y;
-  float sc[4], sh[4], sl[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = it.q * 4 + j;
+  // one thread per channel does the fp64 arithmetic (two divisions, a square root, a reciprocal), the others pick the result up
+  // from LDS: done by every lane for its 4 channels it was 256 / (C / 4) times redundant and cost more than the finalize launch
+  __shared__ float scs[256], shs[256];
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
     const long idx = (long)b * C + c;
     const double mean = stats[2 * idx] / count;
     double var = stats[2 * idx + 1] / count - mean * mean;
     if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    sc[j] = rstd * g[c];
-    sh[j] = beta[c] - (float)mean * sc[j];
+    const float s_ = rstd * g[c];
+    scs[c] = s_;
+    shs[c] = beta[c] - (float)mean * s_;
+    if (blockIdx.x == 0) { mr[2 * idx] = (float)mean; mr[2 * idx + 1] = rstd; }
+  }
+  __syncthreads();
+  float sc[4], sh[4], sl[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = it.q * 4 + j;
+    sc[j] = scs[c];
+    sh[j] = shs[c];
     sl[j] = slope ? slope[c] : 1.f;
-    if (blockIdx.x == 0 && it.sub == 0) { mr[2 * idx] = (float)mean; mr[2 * idx + 1] = rstd; }
   }
   const long step = (long)it.psub * NB_U;
   const long chunk = ((P + gridDim.x - 1) / gridDim.x + step - 1) / step * step;
