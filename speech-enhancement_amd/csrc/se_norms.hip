@@ -332,14 +332,21 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
     dbeta[c] += (float)s1;
     if (dslope) dslope[c] += (float)s3;
   }
+  __shared__ float m1s[256], m2s[256];          // the two fp64 divisions once per channel, not once per lane and channel
+  if ((int)threadIdx.x < C) {
+    const int c = threadIdx.x;
+    m1s[c] = (float)(red[((long)sb * C + c) * 3] / count);
+    m2s[c] = (float)(red[((long)sb * C + c) * 3 + 1] / count);
+  }
+  __syncthreads();
   float mean[4], rstd[4], gg[4], bt[4], sl[4], m1[4], m2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int c = it.q * 4 + j;
     mean[j] = mr[((long)sb * C + c) * 2]; rstd[j] = mr[((long)sb * C + c) * 2 + 1];
     gg[j] = g[c]; bt[j] = beta[c]; sl[j] = slope ? slope[c] : 1.f;
-    m1[j] = (float)(red[((long)sb * C + c) * 3] / count);
-    m2[j] = (float)(red[((long)sb * C + c) * 3 + 1] / count);
+    m1[j] = m1s[c];
+    m2[j] = m2s[c];
   }
   const long step = (long)it.psub * NB_U;
   const long chunk = ((P + gridDim.x - 1) / gridDim.x + step - 1) / step * step;
