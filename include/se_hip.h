@@ -170,6 +170,10 @@ int se_row_stats(const float* X, float* stats, long M, int C, int ld, float eps,
  * generator.py:70,72).  stats (optional) receives (mean, rstd) per row. */
 int se_layernorm_fwd(const float* X, const float* g, const float* b, const float* R, float* Y,
                      float* stats, long M, int C, float eps, void* stream);
+/* the same, also emitting out_stats[M][2] = (mean, rstd) of the rows of Y (what se_row_stats(Y) would give): the statistics the
+ * next block's first LayerNorm needs (conformer.py:204 -> :67 of the following block) without another pass over Y; out_stats may be NULL */
+int se_layernorm_fwd_stats(const float* X, const float* g, const float* b, const float* R, float* Y, float* stats,
+                           float* out_stats, long M, int C, float eps, void* stream);
 /* dX = (dR) + (dR2) + LayerNorm backward of dY; dg += sum dY*xhat, db += sum dY (fp32 atomics; caller zeroes) */
 int se_layernorm_bwd(const float* X, const float* stats, const float* g, const float* dY,
                      const float* dR, const float* dR2, float* dX, float* dg, float* db, long M, int C,

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void row_stats64_kernel(const float* __restric
 __global__ __launch_bounds__(256) void layernorm64_fwd_kernel(const float* __restrict__ X, const float* __restrict__ g,
                                                               const float* __restrict__ b, const float* __restrict__ R,
                                                               float* __restrict__ Y, float* __restrict__ stats,
-                                                              long M, float eps) {
+                                                              long M, float eps, float* __restrict__ out_stats) {
   const int q = threadIdx.x & 15;
   const float4 gg = *reinterpret_cast<const float4*>(g + q * 4);
   const float4 bb = *reinterpret_cast<const float4*>(b + q * 4);
@@ -52,6 +52,12 @@ __global__ __launch_bounds__(256) void layernorm64_fwd_kernel(const float* __res
     }
     *reinterpret_cast<float4*>(Y + row * 64 + q * 4) = o;
     if (stats && q == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    if (out_stats) {      // (mean, rstd) of the RESULT row, exactly as row_stats64_kernel would compute them from Y: the next LayerNorm's
+      const float m2 = sum16(o.x + o.y + o.z + o.w) * (1.f / 64.f);
+      const float c0 = o.x - m2, c1 = o.y - m2, c2 = o.z - m2, c3 = o.w - m2;
+      const float v2 = sum16(c0 * c0 + c1 * c1 + c2 * c2 + c3 * c3) * (1.f / 64.f);
+      if (q == 0) { out_stats[2 * row] = m2; out_stats[2 * row + 1] = rsqrtf(v2 + eps); }
+    }
   }
 }
 
@@ -411,8 +417,17 @@ extern "C" int se_layernorm_fwd(const float* X, const float* g, const float* b, 
   SE_REQUIRE(X && g && b && Y && M > 0, "layernorm_fwd: bad arguments");
   SE_REQUIRE(C == 64, "layernorm_fwd: only C == 64 is built");
   hipLaunchKernelGGL(layernorm64_fwd_kernel, dim3(grid_for(M, 16)), dim3(256), 0, as_stream(stream), X, g, b, R, Y,
-                     stats, M, eps);
+                     stats, M, eps, (float*)nullptr);
   return se_check_launch("se_layernorm_fwd");
+}
+
+extern "C" int se_layernorm_fwd_stats(const float* X, const float* g, const float* b, const float* R, float* Y,
+                                      float* stats, float* out_stats, long M, int C, float eps, void* stream) {
+  SE_REQUIRE(X && g && b && Y && M > 0, "layernorm_fwd_stats: bad arguments");
+  SE_REQUIRE(C == 64, "layernorm_fwd_stats: only C == 64 is built");
+  hipLaunchKernelGGL(layernorm64_fwd_kernel, dim3(grid_for(M, 16)), dim3(256), 0, as_stream(stream), X, g, b, R, Y,
+                     stats, M, eps, out_stats);
+  return se_check_launch("se_layernorm_fwd_stats");
 }
 
 extern "C" int se_layernorm_bwd(const float* X, const float* stats, const float* g, const float* dY,

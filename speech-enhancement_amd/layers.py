@@ -374,7 +374,7 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
                            dR=dy, dR2=dR2)
 
 
-def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed=0):
+def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed=0, st_in=None):
     """x: [B*T*Fq, 64] tokens; returns LN(y4) + x (the TSCB adds the block input, generator.py:70,72).
     drop = (ff_dropout, attn_dropout) (generator.py:60-65: 0.2 / 0.2, conv dropout 0); seed: base of this
     block's five dropout streams."""
@@ -384,7 +384,8 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     pf, pa = (drop if train else (0.0, 0.0))
     # LayerNorm statistics of y1 / y2 / y3 come out of the kernels that produce those rows (se_ff_fwd_stats, SE_EPI_ROWSTATS):
     # three of the four se_row_stats passes of a block (26 us each, on the serial forward path) disappear
-    r1 = _ff_fwd(P, f'{p}.ff1', x, M, pf, site_seed(seed, 0), site_seed(seed, 1), want_out_stats=FUSE_ROWSTATS)
+    # (st_in: the statistics of the rows of x, emitted by the previous block's post_norm: the fourth pass disappears too)
+    r1 = _ff_fwd(P, f'{p}.ff1', x, M, pf, site_seed(seed, 0), site_seed(seed, 1), st=st_in, want_out_stats=FUSE_ROWSTATS)
     y1, ctx['ff1'], st2 = r1[0], r1[1], (r1[2] if len(r1) > 2 else None)
     # attention
     if st2 is None:
@@ -439,7 +440,10 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
                 bias=P[f'{p}.conv.net.7.bias'], R=y2, ps=sc, pb=sh, AUX=st4)
     ctx['conv'] = (y2, st3, zc, u, h, mr, sc, sh, count)
     y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M, pf, site_seed(seed, 3), site_seed(seed, 4), st=st4)
-    out, st5 = O.layernorm_fwd(y4, P[f'{p}.post_norm.weight'], P[f'{p}.post_norm.bias'], R=x)
+    if FUSE_ROWSTATS:
+        out, st5, ctx['out_stats'] = O.layernorm_fwd(y4, P[f'{p}.post_norm.weight'], P[f'{p}.post_norm.bias'], R=x, out_stats=True)
+    else:
+        out, st5 = O.layernorm_fwd(y4, P[f'{p}.post_norm.weight'], P[f'{p}.post_norm.bias'], R=x)
     ctx['post'] = (y4, st5)
     return out, ctx
 
@@ -651,11 +655,14 @@ def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed
     ctx['Fp'] = Fp
     tok = x.view(B * T * Fp, 64)
     ctx['tscb'] = []
+    st_tok = None                  # row statistics of `tok`, handed from one block's post_norm to the next block's first LayerNorm
     for i in range(1, 5):
         tok, c1 = conformer_fwd(P, f'TSCB_{i}.time_conformer', tok, B, T, Fp, 'time', train, dp, buffers, drop,
-                                site_seed(seed, 100 + 2 * i))
+                                site_seed(seed, 100 + 2 * i), st_in=st_tok)
+        st_tok = c1.pop('out_stats', None)
         tok, c2 = conformer_fwd(P, f'TSCB_{i}.freq_conformer', tok, B, T, Fp, 'freq', train, dp, buffers, drop,
-                                site_seed(seed, 101 + 2 * i))
+                                site_seed(seed, 101 + 2 * i), st_in=st_tok)
+        st_tok = c2.pop('out_stats', None)
         ctx['tscb'].append((c1, c2))
     # the two decoders are independent branches (models/generator.py:154-156): the complex decoder runs on a second stream
     with GM.branch_stream(tok) as br:

@@ -73,13 +73,15 @@ def row_stats(x, M, C_=64, ld=None, eps=1e-5):
     return st
 
 
-def layernorm_fwd(x, g, b, R=None, want_stats=True, eps=1e-5):
+def layernorm_fwd(x, g, b, R=None, want_stats=True, eps=1e-5, out_stats=False):
+    """out_stats: also return (mean, rstd) of the rows of the RESULT (the next LayerNorm's statistics)"""
     M = x.numel() // 64
     y = torch.empty_like(x)
     st = _new(M, 2, like=x) if want_stats else None
-    L.call('se_layernorm_fwd', L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(R), L.ptr(y), L.ptr(st), _l(M), _i(64), _f(eps),
-           L.stream())
-    return y, st
+    ost = _new(M, 2, like=x) if out_stats else None
+    L.call('se_layernorm_fwd_stats', L.ptr(x), L.ptr(g), L.ptr(b), L.ptr(R), L.ptr(y), L.ptr(st), L.ptr(ost), _l(M), _i(64),
+           _f(eps), L.stream())
+    return (y, st, ost) if out_stats else (y, st)
 
 
 def layernorm_bwd(x, st, g, dy, dg, db, dR=None, dR2=None):

@@ -165,3 +165,16 @@ def test_zero_arena_hands_out_zeroed_disjoint_buffers():
         finally:
             O.ARENA.end()
     O.ARENA.__init__()
+
+
+def test_layernorm_fwd_emits_the_statistics_of_its_result():
+    """se_layernorm_fwd_stats: (mean, rstd) of the rows of Y = LN(X) g + b + R come out of the same pass and equal se_row_stats(Y)"""
+    from speech_enhancement_amd import ops as O
+    M = 16 * 37 + 5
+    x, r = rnd(M, 64, seed=1) * 1.5 + 0.3, rnd(M, 64, seed=2)
+    g, b = rnd(64, seed=3) * 0.2 + 1, rnd(64, seed=4) * 0.1
+    y, st, ost = O.layernorm_fwd(x, g, b, R=r, out_stats=True)
+    y0, st0 = O.layernorm_fwd(x, g, b, R=r)
+    assert torch.equal(y, y0) and torch.equal(st, st0)
+    ref = O.row_stats(y, M)
+    assert relerr(ost, ref) < 1e-6
