@@ -6,7 +6,9 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libse_hip.so')
+# SE_HIP_LIB: an alternative build of the SAME library for A/B timing on one box (tools/micro/run_ab.sh) -- the in-tree file is
+# never overwritten by an experiment; unset = the product library
+LIB_PATH = os.environ.get('SE_HIP_LIB') or os.path.join(HERE, 'libse_hip.so')
 SE_MAX_TAPS = 16
 
 PRO_NONE, PRO_LN, PRO_SWISH, PRO_AFFINE_SWISH, PRO_SWISH_DROP, PRO_DROP = 0, 1, 2, 3, 4, 5

@@ -1516,12 +1516,8 @@ template <int KT, bool GROUP>
 static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float* dE, int phase) {
   using L3 = Lds3<KT>;
   const size_t sh = (size_t)4 * L3::WAVE + (GROUP ? 2 * 4 * 256 * sizeof(float) : 0);
-  static bool raised = false;
-  if (!raised) {
-    SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd3_kernel<KT, GROUP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit to %zu", sh);
-    raised = true;
-  }
+  static unsigned raised = 0;
+  SE_REQUIRE(se_raise_lds((const void*)attn_bwd3_kernel<KT, GROUP>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit to %zu", sh);
   const long items = (long)b.g.nseq * 4;
   const int nkt = (b.g.n + 15) / 16;
   if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
@@ -1599,24 +1595,16 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     const long items2 = (long)nseq * 4;
     if (n <= 112) {
       const size_t sh = (2 * 112 * 16 + 2 * 16 * 116 + 16 * 228 + 4 * 5 * 320) * sizeof(float);
-      static bool raised = false;
-      if (!raised) {
-        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<112, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
-        raised = true;
-      }
+      static unsigned raised = 0;
+  SE_REQUIRE(se_raise_lds((const void*)attn_bwd2_kernel<112, 4, true>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit");
       int nb = items2 < 512 ? (int)items2 : 512;
       int ipb = (int)((items2 + nb - 1) / nb);
       nb = (int)((items2 + ipb - 1) / ipb);
       hipLaunchKernelGGL((attn_bwd2_kernel<112, 4, true>), dim3(nb), dim3(256), sh, s, a, Et, et_ld, ipb);
     } else {
       const size_t sh = (336 * 16 + 2 * 16 * 340 + 16 * 676 + 8 * 5 * 320) * sizeof(float);
-      static bool raised = false;
-      if (!raised) {
-        SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd2_kernel<336, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
-        raised = true;
-      }
+      static unsigned raised = 0;
+  SE_REQUIRE(se_raise_lds((const void*)attn_bwd2_kernel<336, 8, false>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit");
       int nb = items2 < 256 ? (int)items2 : 256;
       int ipb = (int)((items2 + nb - 1) / nb);
       nb = (int)((items2 + ipb - 1) / ipb);

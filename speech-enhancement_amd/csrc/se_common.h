@@ -42,5 +42,17 @@ static __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// The dynamic-LDS limit is a per-DEVICE function attribute: remember it per (call site, device), not per process -- a process
+// that drives a second GPU would otherwise launch there with the default 64 KB limit and fail.  `done` = one bit per device
+// ordinal of the call site (devices >= 32 simply set the attribute every time; the call is idempotent and cheap).
+static inline bool se_raise_lds(const void* fn, size_t bytes, unsigned* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (dev >= 0 && dev < 32 && ((*done >> dev) & 1u)) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+  if (dev >= 0 && dev < 32) *done |= 1u << dev;
+  return true;
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

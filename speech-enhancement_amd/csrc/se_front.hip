@@ -127,12 +127,8 @@ extern "C" int se_istft_fused(const float* P, const float* Wi, const float* env,
   SE_REQUIRE(P && Wi && env && y && B > 0 && T > 1, "istft_fused: bad arguments");
   SE_REQUIRE(n_fft == FR_NFFT && hop == FR_HOP, "istft_fused: built for n_fft = 400, hop = 100 (got %d, %d)", n_fft, hop);
   const size_t sh = (size_t)FR_TILE * (FR_LDA2 + FR_LDA) * sizeof(float);
-  static bool raised = false;
-  if (!raised) {
-    SE_REQUIRE(hipFuncSetAttribute((const void*)istft_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) == hipSuccess,
-               "istft_fused: cannot raise the dynamic LDS limit");
-    raised = true;
-  }
+  static unsigned raised = 0;
+  SE_REQUIRE(se_raise_lds((const void*)istft_fused_kernel, sh, &raised), "istft_fused: cannot raise the dynamic LDS limit");
   const int hops = T - 1;                       // output hops: padded hops 2 .. T
   hipLaunchKernelGGL(istft_fused_kernel, dim3(cdiv(hops, FR_TILE - 3), B), dim3(FR_NB * 64), sh, as_stream(stream), P, Wi, env, y, T,
                      comp, post_scale);

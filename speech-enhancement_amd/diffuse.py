@@ -94,7 +94,8 @@ class DiffuSE(nn.Module):
 
     # ---- weight packing (once per weight version) ----------------------------------------------------------------
     def _pack(self):
-        ver = tuple(p._version for p in self.parameters())
+        # data_ptr and device too: model.to(device) / p.data = ... swap the storage without bumping _version
+        ver = tuple((p._version, p.data_ptr(), str(p.device)) for p in self.parameters())
         if self._packed is not None and self._packed['ver'] == ver:
             return self._packed
         Cc, nl = self.C, len(self.residual_layers)

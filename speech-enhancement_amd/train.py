@@ -41,6 +41,8 @@ class PesqSideChannel:
         self.pool = ThreadPoolExecutor(max_workers=1)
         self.stream = None
         self.host = {}
+        self.calls = 0
+        self.last_use = [None, None]          # the future that last read buffer set 0 / 1
 
     def _pinned(self, key, like):
         buf = self.host.get(key)
@@ -48,6 +50,21 @@ class PesqSideChannel:
             buf = torch.empty(like.shape, dtype=like.dtype, pin_memory=True)
             self.host[key] = buf
         return buf
+
+    def _claim_set(self):
+        """Pinned staging buffers are DOUBLE-BUFFERED: with stale_labels=True step t submits before step t - 1's future
+        has been read, and the provider (~100 ms) is slower than the generator forward (~30 ms) -- one buffer set would let
+        the new D2H copy overwrite the audio the worker is still scoring.  Set k is reused only after the future that last
+        read it has finished (a no-op in the default schedule, where every future is consumed within its step)."""
+        k = self.calls & 1
+        self.calls += 1
+        prev = self.last_use[k]
+        if prev is not None and not prev.done():
+            try:
+                prev.result()
+            except Exception:                 # the consumer of that future reports the provider error
+                pass
+        return k
 
     def submit(self, clean_dev, est_dev, extra=None):
         """clean_dev / est_dev: [B, L] device tensors that are complete on the current stream.  Returns a future of
@@ -57,12 +74,13 @@ class PesqSideChannel:
         self.stream.wait_stream(torch.cuda.current_stream())
         names = ['clean', 'est'] + sorted(extra or {})
         tensors = [clean_dev, est_dev] + [extra[k] for k in sorted(extra or {})]
+        bset = self._claim_set()
         with torch.cuda.stream(self.stream):
             host = []
             for n, t in zip(names, tensors):
                 t = t.detach()
                 t.record_stream(self.stream)
-                h = self._pinned(n, t)
+                h = self._pinned((bset, n), t)
                 h.copy_(t, non_blocking=True)
                 host.append(h)
             ev = torch.cuda.Event()
@@ -79,7 +97,9 @@ class PesqSideChannel:
                 clean_list = list(host[0].numpy())
                 return [torch.as_tensor(pesq_labels(clean_list, list(h.numpy()), device='cpu')).float().cpu()
                         for h in host[1:]]
-        return self.pool.submit(work)
+        fut = self.pool.submit(work)
+        self.last_use[bset] = fut
+        return fut
 
 
 _SIDE = None
@@ -125,30 +145,53 @@ class DataParallelHooks(LY.DPHooks):
         self.group = group
         self.world = dist.get_world_size(group)
         self.stage_host = dist.get_backend(group) == 'gloo'
+        # bench.py --gpus N: when a list, every exchange appends (kind, start event, end event) recorded on the stream the
+        # exchange is issued on ("comm" object of the bench line); None = off, nothing is recorded
+        self.comm_events = None
 
-    def allreduce(self, t):
+    def _mark(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def allreduce(self, t, kind='stats'):
+        """small blocking-in-stream all-reduce (SUM): SyncBatchNorm statistics (256 / 384 doubles), the scp gradient triple"""
+        e0 = self._mark() if (self.comm_events is not None and kind is not None and t.is_cuda) else None
         if self.stage_host and t.is_cuda:
             h = t.cpu()
             dist.all_reduce(h, group=self.group)
             t.copy_(h)
         else:
             dist.all_reduce(t, group=self.group)
+        if e0 is not None:
+            self.comm_events.append((kind, e0, self._mark()))
         return t
 
-    def average_grads(self, optimizer):
-        self.finish_average(self.start_average(optimizer))
+    def average_grads(self, optimizer, kind='grads_d'):
+        self.finish_average(self.start_average(optimizer, kind))
 
-    def start_average(self, optimizer):
+    def start_average(self, optimizer, kind='grads_g'):
         """launch the all-reduce of the flat gradient buffers asynchronously (RCCL runs on its own stream)"""
+        e0 = self._mark() if self.comm_events is not None else None
         if self.stage_host:
-            return [(self.allreduce(g), None) for g in optimizer.flat_grads()]
-        return [(g, dist.all_reduce(g, group=self.group, async_op=True)) for g in optimizer.flat_grads()]
+            works = [(self.allreduce(g, kind=None), None) for g in optimizer.flat_grads()]
+        else:
+            works = [(g, dist.all_reduce(g, group=self.group, async_op=True)) for g in optimizer.flat_grads()]
+        return works, kind, e0
 
-    def finish_average(self, works):
+    def finish_average(self, handle):
+        works, kind, e0 = handle
+        # `<kind>_exposed`: from the moment the consumer stream has nothing else left to do (everything issued before this
+        # point) until the reduced buffer is usable = the part of the collective that was NOT hidden behind other work
+        e_pre = self._mark() if e0 is not None else None
         for g, w in works:
             if w is not None:
                 w.wait()
             g.mul_(1.0 / self.world)
+        if e0 is not None:
+            e1 = self._mark()
+            self.comm_events.append((kind, e0, e1))
+            self.comm_events.append((kind + '_exposed', e_pre, e1))
 
 
 def attach_data_parallel(model, discriminator, group=None):
@@ -419,11 +462,15 @@ def _gan_step(model, discriminator, optimizer, optimizer_disc, clean, noisy, arc
 
     if overlap:
         side.wait_event(ev)
-        with torch.cuda.stream(side):
-            optimizer_disc.zero_grad()          # on the side stream too: ordered before the backward that accumulates into it
-            _discriminator_update(discriminator, optimizer_disc, est.detach(), clean_pl, noisy_pl, ones, arch, labels, pending, keys,
-                                  hooks, max_norm, out)
-        main.wait_stream(side)      # the next generator forward reads the updated discriminator; scratch is recycled per step
+        try:
+            with torch.cuda.stream(side):
+                optimizer_disc.zero_grad()      # on the side stream too: ordered before the backward that accumulates into it
+                _discriminator_update(discriminator, optimizer_disc, est.detach(), clean_pl, noisy_pl, ones, arch, labels, pending,
+                                      keys, hooks, max_norm, out)
+        finally:
+            # ALWAYS joined (also when the PESQ provider or a kernel launch raised): the caller's `finally` recycles the step's
+            # scratch arena on the main stream, which must not overtake work the side stream has already been given
+            main.wait_stream(side)  # the next generator forward reads the updated discriminator; scratch is recycled per step
         if hooks is not None:
             finish_generator_step()
         return out
@@ -468,7 +515,7 @@ def _self_correcting_backward(discriminator, optimizer_disc, L_C, L_E, L_N, hook
         flats.append(torch.cat([(g if g is not None else torch.zeros_like(p)).reshape(-1) for g, p in zip(gs, params)]))
     if hooks is not None:
         cat = torch.cat(flats)             # one 2.18 MB all-reduce instead of three
-        hooks.allreduce(cat)
+        hooks.allreduce(cat, kind='scp_grad_triple')
         cat.mul_(1.0 / hooks.world)
         flats = list(cat.split(flats[0].numel()))
     C, E, N = flats

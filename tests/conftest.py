@@ -27,6 +27,14 @@ def golden2():
     return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_v2.npz'))
 
 
+@pytest.fixture(scope='session')
+def golden3():
+    """round-3 vectors (tests/golden/make_golden_v3.py): gradient of the reference's compressed_stft on a well-conditioned
+    signal, the reference's train_gan for cp / sc / scp on that signal, the reference's predict on one 10 s clip"""
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_v3.npz'))
+
+
 def full_size_signals(seed, B=2, L=32000):
     """the inputs of the full-size golden step, regenerated from the seed (numpy legacy RandomState is bit-stable)"""
     import numpy as np

@@ -55,3 +55,28 @@ def formula_state(which: str):
     for name, shape, dtype, base in load_spec(which):
         sd[name] = formula_tensor(name, tuple(shape), dtype, base)
     return sd
+
+
+def cond_signals(B: int, L: int, seed: int):
+    """A WELL-CONDITIONED (clean, noisy) pair: each clean clip is 40 sinusoids (50 Hz .. 7.9 kHz at 16 kHz) plus broadband
+    noise, so no STFT bin is near zero and the |z|^0.3 backward of the consistency path is well conditioned."""
+    rs = np.random.RandomState(seed)
+    n = np.arange(L, dtype=np.float64)
+    clean = np.zeros((B, L))
+    for b in range(B):
+        f, ph, a = rs.uniform(50.0, 7900.0, 40), rs.uniform(0.0, 2 * np.pi, 40), rs.uniform(0.01, 0.04, 40)
+        clean[b] = (a[:, None] * np.sin(2 * np.pi * f[:, None] * n[None, :] / 16000.0 + ph[:, None])).sum(0)
+    clean = clean + 0.03 * rs.randn(B, L)
+    noisy = clean + 0.05 * rs.randn(B, L)
+    return torch.from_numpy(clean.astype(np.float32)), torch.from_numpy(noisy.astype(np.float32))
+
+
+def long_clip(L: int, seed: int) -> np.ndarray:
+    """one noisy utterance-like clip of L samples: slowly modulated harmonics + noise (BASELINE config 4 golden)."""
+    rs = np.random.RandomState(seed)
+    n = np.arange(L, dtype=np.float64) / 16000.0
+    f0 = 140.0 + 40.0 * np.sin(2 * np.pi * 0.3 * n)
+    ph = 2 * np.pi * np.cumsum(f0) / 16000.0
+    env = 0.5 * (1.0 + np.sin(2 * np.pi * 1.7 * n))
+    x = sum((0.08 / h) * np.sin(h * ph + 0.3 * h) for h in range(1, 13)) * env
+    return (x + 0.03 * rs.randn(L)).astype(np.float32)

@@ -32,17 +32,25 @@ def _run(world, arch, backend, out, timeout=900):
     port = _port()
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # every rank writes to its own log FILE: draining PIPEs one after another can dead-lock (rank 1 fills its 64 KB pipe with
+    # RCCL / HIP warnings while rank 0 waits for it in a collective and the parent waits for rank 0)
+    log_paths = [f'{out}.rank{r}.log' for r in range(world)]
+    files = [open(pth, 'wb') for pth in log_paths]
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), arch, backend, out], env=env,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
-    logs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        logs.append(o.decode(errors='replace')[-3000:])
+                              stdout=files[r], stderr=subprocess.STDOUT) for r in range(world)]
+    try:
+        import time
+        deadline = time.time() + timeout
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        for q in procs:
+            q.kill()
+        raise
+    finally:
+        for f in files:
+            f.close()
+    logs = [open(pth, 'rb').read().decode(errors='replace')[-3000:] for pth in log_paths]
     assert all(p.returncode == 0 for p in procs), '\n----\n'.join(logs)
     return np.load(out)
 

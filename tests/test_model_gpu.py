@@ -366,15 +366,30 @@ def test_ten_second_utterance_graphed_vs_eager_vs_oracle_prefix(S):
 
 def test_stale_label_option_hides_the_provider(S):
     """opt-in one-step-stale PESQ labels: the first call makes no discriminator update, the second
-    one updates the discriminator with the FIRST batch and its labels -- already finished, so nothing blocks"""
+    one updates the discriminator with the FIRST batch and its labels and does NOT wait for the provider call of its own
+    batch (ordering check: that call is held open until the second step has returned -- a step that waited for it would
+    hang on the gate, which then times out and fails the test).  Also the staging-buffer hazard of this schedule: the
+    provider call of batch 1 reads its host arrays only AFTER step 2 has submitted batch 2; it must still see batch 1
+    (double-buffered pinned buffers, train.PesqSideChannel._claim_set)."""
+    import threading
     import time
     import types
     from speech_enhancement_amd import train as TR, optim as OP
-    calls = []
+    calls, released, seen_late = [], [], []
+    gate = threading.Event()
+    side = TR.pesq_side_channel()
 
     def provider(clean_list, deg_list):
+        k = len(calls)
         calls.append(float(np.abs(np.asarray(clean_list[0])).sum()))          # fingerprint of the batch it was given
-        time.sleep(0.15)
+        if k == 0:
+            t_end = time.time() + 20.0
+            while side.calls < base_calls + 2 and time.time() < t_end:        # until step 2 has submitted batch 2 ...
+                time.sleep(0.005)
+            time.sleep(0.1)                                                   # ... and its D2H copies have landed
+            seen_late.append(float(np.abs(np.asarray(clean_list[0])).sum()))  # read the staging buffer LATE
+        else:
+            released.append(gate.wait(20.0))                                  # held open until step 2 has returned
         return torch.tensor([0.5] * len(clean_list), dtype=torch.float32)
     TR.set_pesq_provider(provider)
     try:
@@ -384,22 +399,24 @@ def test_stale_label_option_hides_the_provider(S):
         torch.manual_seed(0)
         b1 = 0.1 * torch.randn(2, 1600, device='cuda')
         b2 = 0.1 * torch.randn(2, 1600, device='cuda')
+        base_calls = side.calls
         d0 = torch.cat([p.detach().flatten() for p in d.parameters()]).clone()
         out1 = TR.gan_step(g, d, og, od, b1, b1 + 0.01, 'cmgan', (0.1, 0.9, 0.2, 0.05), stale_labels=True)
         assert float(out1['loss_d']) == 0.0
         assert torch.equal(d0, torch.cat([p.detach().flatten() for p in d.parameters()]))
-        torch.cuda.synchronize()
-        time.sleep(0.3)                                  # the worker finishes batch 1's labels in the background
-        t0 = time.time()
         out2 = TR.gan_step(g, d, og, od, b2, b2 + 0.01, 'cmgan', (0.1, 0.9, 0.2, 0.05), stale_labels=True)
         torch.cuda.synchronize()
-        dt = time.time() - t0
+        gate.set()                                       # step 2 is back: only now may batch 2's provider call finish
         assert float(out2['loss_d']) > 0.0 and not torch.equal(d0, torch.cat([p.detach().flatten() for p in d.parameters()]))
+        for f in side.last_use:
+            if f is not None:
+                f.result(timeout=30)
         assert len(calls) == 2 and calls[0] != calls[1]
-        assert dt < 0.14, dt                             # did not wait for the 150 ms provider call of batch 2
+        assert released == [True]                        # the gate was opened by the main thread, not by its timeout
+        assert seen_late == [calls[0]]                   # batch 1's staging buffer was not overwritten by batch 2's copy
     finally:
+        gate.set()
         TR.set_pesq_provider(None)
-        time.sleep(0.3)
 
 
 @pytest.mark.parametrize('arch', ['cmgan', 'scp'])

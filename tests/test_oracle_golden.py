@@ -340,3 +340,78 @@ def test_full_size_train_step_fp32(golden2, gsd, dsd):
             g = (gg if 'gupd' in k else gd)[name].double().numpy()
             ref = golden2[k].astype(np.float64) / (-lr * 1.9)
             assert rms(g, ref) < 2e-2 * np.sqrt(np.mean(ref ** 2)) + 1e-12, k
+
+
+# ---- round 3: consistency-path gradient, cp / sc / scp steps, 10 s inference (tests/golden/make_golden_v3.py) ----------
+@pytest.mark.parametrize('comp', ['pow', 'log', 'norm', 'none'])
+def test_compressed_stft_gradient(golden3, comp):
+    """the oracle's STFT + compression differentiates like the reference's (core/function.py:685-693, 625-634), fp64"""
+    x = t(golden3['stftbwd_x']).clone().requires_grad_(True)
+    T = x.shape[1] // 100 + 1
+    k = torch.arange(2 * 201 * T, dtype=torch.float64).view(2, 201, T)
+    wr, wi, wm = torch.cos(k * 0.013), torch.sin(k * 0.017), torch.cos(k * 0.0071 + 1.0)
+    s = O.compressed_stft(x, comp=comp)
+    ref = golden3[f'stftbwd_{comp}_spec']
+    assert rms(s.detach().real, ref[..., 0]) < 1e-12 and rms(s.detach().imag, ref[..., 1]) < 1e-12
+    (s.real * wr + s.imag * wi + s.abs() * wm).sum().backward()
+    dref = golden3[f'stftbwd_{comp}_dx']
+    assert rms(x.grad, dref) < 1e-11 * float(np.abs(dref).max())
+
+
+@pytest.mark.parametrize('arch,weights', [('cp', (0.1, 0.9, 0.2, 0.05)), ('sc', (0.1, 0.9, 0.2, 0.05)),
+                                          ('scp', (0.3, 0.7, 0.2, 0.05))])
+def test_conditioned_recipe_steps_fp64(golden3, gsd, dsd, arch, weights):
+    """one reference train_gan iteration for the cp / sc / scp recipes on the well-conditioned clip pair, fp64: every loss
+    term, every post-step parameter norm, six generator and two discriminator updates"""
+    tdt = torch.float64
+    lr = O.lr_at(10.0, 0.01, 100)
+    cast = lambda sd: {k: (v.to(tdt) if v.is_floating_point() else v) for k, v in sd.items()}
+    g0, d0 = cast(gsd), cast(dsd)
+    q = {'est': torch.tensor([0.35, 0.62]).to(tdt), 'clean': torch.tensor([0.97, 0.93]).to(tdt),
+         'noisy': torch.tensor([0.21, 0.44]).to(tdt)}           # fp32 label values, as the generating script passes them
+    clean, noisy = formula.cond_signals(2, 1600, 5)
+    assert np.array_equal(clean.numpy(), golden3['cond_clean']) and np.array_equal(noisy.numpy(), golden3['cond_noisy'])
+    out, ng, nd, *_ = O.train_step(g0, d0, clean.to(tdt), noisy.to(tdt), q['est'], arch, weights, lr=lr, wd=0.01,
+                                   q_clean=q['clean'], q_noisy=q['noisy'], optimizer='sgd')
+    pre = f'cstep_{arch}_f64_'
+    gl, dl = golden3[pre + 'losses']
+    assert abs(out['loss_g'] - gl) < 1e-9 * abs(gl) and abs(out['loss_d'] - dl) < 1e-8 * abs(dl)
+    mse = golden3[pre + 'mse_calls']
+    mine = [out['loss_mag'], None, None, out['gan'], out['L_E'], out['L_C']] + ([out['L_N']] if arch in ('scp', 'sc') else [])
+    assert len(mse) == len(mine)
+    for a, b in zip(mine, mse):
+        if a is not None:
+            assert abs(a - b) < 1e-9 * abs(b) + 1e-13
+    gnorm = np.array([float(ng[k].double().norm()) for k in gsd])
+    dnorm = np.array([float(nd[k].double().norm()) for k in dsd])
+    np.testing.assert_allclose(gnorm, golden3[pre + 'g_norm'], rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(dnorm, golden3[pre + 'd_norm'], rtol=1e-8, atol=1e-12)
+    for k in golden3.files:
+        if k.startswith(pre + 'gupd:') or k.startswith(pre + 'dupd:'):
+            name = k.split(':', 1)[1]
+            src, new = (g0, ng) if k.startswith(pre + 'gupd:') else (d0, nd)
+            upd = (new[name].double() - src[name].double()).numpy()
+            ref = golden3[k].astype(np.float64)
+            assert rms(upd, ref) < 1e-5 * np.sqrt(np.mean(ref ** 2)) + 1e-14, k
+
+
+def test_ten_second_predict_fp32(golden3, gsd):
+    """BASELINE config 4: the oracle's whole-utterance eval forward on the 10 s clip (T = 1601, clamp active) vs the
+    reference's predict (inference_gan.py:75-100), fp32"""
+    L, seed = (int(v) for v in golden3['long_seed'])
+    x = torch.from_numpy(formula.long_clip(L, seed))[None]
+    c = torch.sqrt(x.shape[-1] / torch.sum(x ** 2, -1))
+    xn = x * c[:, None]
+    pad = -L % 100
+    xn = torch.cat([xn, xn[:, :pad]], -1)
+    with torch.no_grad():
+        er, ei = O.tscnet_forward(gsd, O.compressed_stft(xn), False)
+        audio = (O.uncompressed_istft(torch.complex(er, ei).squeeze(1).permute(0, 2, 1)) / c[:, None]).flatten()[:L]
+    mag = torch.sqrt(er ** 2 + ei ** 2)[0, 0].double().numpy()            # [T, F]
+    bins = golden3['long_bins']
+    scale = float(golden3['long_f64_mag_rms'][0])
+    assert rms(mag[bins[:, 0], bins[:, 1]], golden3['long_f64_mag_bins']) < 2e-5 * scale
+    assert rms(mag.sum(0) / mag.shape[0], golden3['long_f64_mag_colsum'] / mag.shape[0]) < 2e-5 * scale
+    a = audio.double().numpy()
+    ref = golden3['long_f64_audio_samples']
+    assert rms(a[golden3['long_samples']], ref) < 1e-4 * float(np.abs(ref).max())

@@ -1,11 +1,11 @@
 #!/bin/bash
 # times tools_conv_one.py with each experimental build of libse_hip.so found in tools/micro/bin/ (see conv3_ablate.py)
-# usage: tools/micro/run_hacks.sh "<Cin> <precision> [planes]" ...
+# usage: tools/micro/run_hacks.sh "<Cin> <precision> [planes]" ...   (library selected through SE_HIP_LIB, nothing is overwritten)
 cd "$(dirname "$0")/../.."
-cp speech-enhancement_amd/libse_hip.so /tmp/libse_orig.so
-for lib in /tmp/libse_orig.so tools/micro/bin/libse_hack*.so; do
-  cp "$lib" speech-enhancement_amd/libse_hip.so
-  echo "== $lib"
-  for c in "$@"; do python tools/tools_conv_one.py $c; done
+for lib in "" tools/micro/bin/libse_hack*.so; do
+  [ -z "$lib" ] || [ -f "$lib" ] || continue
+  echo "== ${lib:-speech-enhancement_amd/libse_hip.so}"
+  for c in "$@"; do
+    if [ -z "$lib" ]; then python tools/tools_conv_one.py $c; else SE_HIP_LIB="$PWD/$lib" python tools/tools_conv_one.py $c; fi
+  done
 done
-cp /tmp/libse_orig.so speech-enhancement_amd/libse_hip.so
