@@ -64,11 +64,25 @@ typedef struct {
   unsigned pro_seed, epi_seed;   /* dropout streams of the prologue / epilogue masks             */
   float drop_p;          /* dropout probability (0 = off), realised as round(p * 65536) / 65536; kept elements are scaled by the exact inverse keep probability */
   int precision;         /* 0: fp32 MFMA; 1: split-bf16 hi/lo (3 bf16 MFMAs per product, ~1.5e-5 relative);
-                            2: split-bf16 hi/mid/lo (6 bf16 MFMAs, exact 24-bit split: fp32-equivalent, ~1e-7)   */
+                            2: split-bf16 hi/mid/lo (6 bf16 MFMAs, exact 24-bit split: fp32-equivalent, ~1e-7);
+                            3: SCALED split-fp16 hi/lo (3 fp16 MFMAs per product): each operand is multiplied by a power of
+                               two that brings its largest magnitude to [2^13, 2^14) (exact), then x = hi + lo with two 11-bit
+                               fp16 significands: 2^-24 relative representation error (the fp32 rounding unit) for every
+                               element within 2^17 of the operand's maximum and 2^-39 of that maximum below; products
+                               hi*hi + hi*lo + lo*hi are exact in the fp32 accumulator, the dropped lo*lo term is <= 2^-24
+                               relative: fp32-equivalent like 2, at half the MFMAs and two thirds of the LDS bytes          */
   int w_planes;          /* 0: W is fp32 [N][ldw].  > 0 (se_gemm_tap, precision 2, C >= 32 only): W points to the weights
                             PRE-SPLIT by se_weight_prep -- three bf16 planes (hi, mid, lo) of [N][ldw] elements each,
                             w_planes elements apart (ldw, w_planes multiples of 8, 16-byte aligned); same results as the
-                            fp32 operand (the split is exact), without re-splitting the weights in every workgroup */
+                            fp32 operand (the split is exact), without re-splitting the weights in every workgroup.
+                            precision 3: TWO fp16 planes (hi, lo) of the weights scaled by 2^sexp(*w_amax) (se_weight_prep,
+                            fmt 1) */
+  int a_sexp, w_sexp;    /* precision 3: log2 of the power-of-two operand scales used when the amax pointer below is NULL
+                            (e.g. a_sexp = 4 for InstanceNorm / LayerNorm outputs: |x| < 4096 representable)               */
+  const float* a_amax;   /* precision 3: device scalar >= max |A| (e.g. se_absmax, or a producer kernel's atomic maximum); the
+                            kernel derives the scale 2^(13 - floor(log2 amax)) from it.  NULL: a_sexp                     */
+  const float* w_amax;   /* the same for W; with pre-split fp16 planes it must be the scalar se_weight_prep scaled them by.
+                            se_gemm_tap_wgrad: a_* scale the activations A, w_* the second operand dY                     */
 } se_gemm_desc;
 
 int se_version(void);
@@ -149,7 +163,11 @@ typedef struct {
   int rev;
   int dst_ld, o_off, c_off;
   float scale;
-  long plane_stride;     /* 0: fp32 destination; > 0: bf16 planes, this many elements apart */
+  long plane_stride;     /* 0: fp32 destination; > 0: 16-bit planes, this many elements apart */
+  int fmt;               /* planes: 0 = three bf16 planes (exact hi / mid / lo); 1 = two fp16 planes (hi, lo) of
+                            scale * src * 2^sexp(*amax) (se_gemm_desc precision 3)                                  */
+  float* amax;           /* fmt 1: device scalar of the DESTINATION matrix (all items of one destination share it): must be
+                            zero on entry; se_weight_prep first reduces max |scale * src| into it, then splits         */
 } se_wprep_item;
 int se_weight_prep(const se_wprep_item* items_dev, int nitems, long max_elems, void* stream);
 
@@ -210,6 +228,14 @@ int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const
                       double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,
                       float* dslope, int B, long P, int C, int per_batch, int act, int phase, double count,
                       void* stream);
+/* the same; amax_out (may be NULL): device scalar, zero or a running maximum on entry, raised to max |dX| by the apply pass (one
+ * atomic per wave) -- the operand scale of the scaled split-fp16 kernels that read dX next (se_gemm_desc precision 3: a_amax of
+ * the conv input gradient, w_amax of the conv weight gradient) */
+int se_norm_prelu_bwd_amax(const float* X, int ldx, int x_off, const float* mr, const float* g,
+                           const float* beta, const float* slope, const float* dY, int ldy, int y_off,
+                           double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,
+                           float* dslope, int B, long P, int C, int per_batch, int act, int phase, double count,
+                           float* amax_out, void* stream);
 
 /* ---- fused relative-position attention (csrc/se_attn.hip) ----------------------------------- */
 /* Attention.forward without the projections (models/conformer.py:103-122): QKV [tokens][192] (q|k|v, head h =

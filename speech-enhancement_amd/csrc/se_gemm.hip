@@ -337,7 +337,9 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 // lane on the fragment instead.
 // WPL: the weights arrive pre-split (se_weight_prep: three bf16 planes [N][ldw]); the B tile is then a plain 16-B copy per
 // plane and thread instead of two fp32 loads + a 36-instruction split per tap step in every workgroup.
-template <int NPL, bool WPL = false>
+// F16 (precision 3): NPL = 2 planes of SCALED fp16 (hi, lo), three fp16 MFMAs per product (se_gemm_dev.h); the accumulators are
+// multiplied by 2^-(sexp_A + sexp_W) (exact) before the epilogue.
+template <int NPL, bool WPL = false, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
   constexpr int BM = 128, BN = 64, BK = 32, SA = 40, HR = BM + 2;
   constexpr int PA = HR * SA, PB = BN * SA;
@@ -366,6 +368,12 @@ __global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     //
   const int NI = nchunk * d.ntap;
   const unsigned thr = 0u;
   const float inv_keep = 1.f;
+  float sa = 1.f, sw = 1.f, unscale = 1.f;
+  if (F16) {
+    f16_clamp_mode_();
+    const int ea = operand_sexp_(d.a_amax, d.a_sexp), ew = operand_sexp_(d.w_amax, d.w_sexp);
+    sa = exp2i_(ea); sw = exp2i_(ew); unscale = exp2i_(-ea - ew);
+  }
 
   float4 ra[4], rh, rb[2];
   // (chunk, triple) / (chunk, tap) of the tile being prefetched, advanced by increments (no divisions in the loop)
@@ -433,11 +441,11 @@ __global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     //
   for (int gq = 0; gq < nchunk * ngrp; ++gq, gi = (gi + 1 == ngrp ? 0 : gi + 1)) {
     // stage the halo tile of this (chunk, triple); the previous iteration's trailing barrier freed Ap
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_store<NPL>(ra[i], &Ap[(1 + r0 + 32 * i) * SA + kq * 4], PA);
+    for (int i = 0; i < 4; ++i) split_store_x<NPL, F16>(ra[i], sa, &Ap[(1 + r0 + 32 * i) * SA + kq * 4], PA);
     // every lane consumes rh here (the lanes that do not store it too): a load still in flight on one path makes the
     // compiler drain ALL loads before the register is reused
     asm volatile("" :: "v"(rh.x), "v"(rh.y), "v"(rh.z), "v"(rh.w));
-    if (tid < 16) split_store<NPL>(rh, &Ap[((tid >> 3) * (HR - 1)) * SA + kq * 4], PA);
+    if (tid < 16) split_store_x<NPL, F16>(rh, sa, &Ap[((tid >> 3) * (HR - 1)) * SA + kq * 4], PA);
     // the three taps are unrolled into straight-line code and every prefetch is issued unconditionally (past the last
     // tile its offsets are out of range: zeros, no memory access), so the loads in flight are counted exactly
 #pragma unroll
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     //
         for (int q = 0; q < NPL; ++q) *reinterpret_cast<f32x4*>(&Bp[q * PB + pr * SA + pc * 8]) = rbp[s3 == 2 ? 1 : 0][q];
       } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
+        for (int i = 0; i < 2; ++i) split_store_x<NPL, F16>(rb[i], sw, &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
       }
       __syncthreads();
       if (WPL) {
@@ -481,12 +489,16 @@ __global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     //
 #pragma unroll
           for (int qa = 0; qa <= ord; ++qa) {
             const int qb = ord - qa;
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf0[qb], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf1[qb], acc1, 0, 0, 0);
+            acc0 = mfma32_<F16>(af[qa], bf0[qb], acc0);
+            acc1 = mfma32_<F16>(af[qa], bf1[qb], acc1);
           }
       }
       __syncthreads();
     }
+  }
+  if (F16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;
   if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
@@ -695,8 +707,12 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
   if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");
+  if (d->precision == 3)
+    SE_REQUIRE(d->C >= 32 && d->prologue == SE_PRO_NONE && !d->up && d->st == 1 && d->sf == 1 && d->Ti == d->To && d->Fi == d->Fo &&
+               d->ntap >= 3 && d->ntap % 3 == 0 && !(ep & (SE_EPI_GLU | SE_EPI_DROP)) && d->Fo >= 2 && (!d->w_planes || d->w_amax),
+               "gemm: precision 3 (scaled split-fp16) is built for the triple-tap convolutions; pre-split planes need w_amax");
   if (d->w_planes) {      // W = three bf16 planes (se_weight_prep): only the six-product split kernels read them
-    SE_REQUIRE(d->precision == 2 && d->C >= 32 && (d->C % 8) == 0 && (d->ldw % 8) == 0 && d->w_planes >= (long)d->N * d->ldw &&
+    SE_REQUIRE((d->precision == 2 || d->precision == 3) && d->C >= 32 && (d->C % 8) == 0 && (d->ldw % 8) == 0 && d->w_planes >= (long)d->N * d->ldw &&
                (d->w_planes % 8) == 0 && ((size_t)W & 15) == 0,
                "gemm: pre-split weights need precision 2, C >= 32, C, ldw and the plane stride multiples of 8, a 16-byte aligned W");
     SE_REQUIRE((long)d->w_planes * 6 < (1L << 31), "gemm: pre-split weight planes exceed 2^31 bytes");
@@ -742,7 +758,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       return se_check_launch("se_gemm_tap(k64 panel)");
     }
   }
-  if ((d->precision == 1 || d->precision == 2) && d->C >= 32 && d->prologue == SE_PRO_NONE && !d->up && d->st == 1 && d->sf == 1 &&
+  if ((d->precision >= 1 && d->precision <= 3) && d->C >= 32 && d->prologue == SE_PRO_NONE && !d->up && d->st == 1 && d->sf == 1 &&
       d->Ti == d->To && d->Fi == d->Fo && d->ntap >= 3 && d->ntap % 3 == 0 && !(ep & (SE_EPI_GLU | SE_EPI_DROP)) && d->Fo >= 2) {
     bool triples = getenv("SE_GEMM_NO_CONV3") == nullptr;
     // the kernel addresses both operands with 32-bit BYTE offsets (range-checked buffer loads)
@@ -756,7 +772,11 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       if (seen != 7) triples = false;
     }
     if (triples) {
-      if (d->precision == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2>), grid, block, 0, s, g);
+      if (d->precision == 3) {
+        if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((conv3_bf16_kernel<2, false, true>), grid, block, 0, s, g);
+      }
+      else if (d->precision == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2>), grid, block, 0, s, g);
       else if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<3, true>), grid, block, 0, s, g);
       else hipLaunchKernelGGL((conv3_bf16_kernel<3>), grid, block, 0, s, g);
       return se_check_launch("se_gemm_tap(conv3)");
@@ -840,6 +860,12 @@ __global__ void weight_prep_kernel(const se_wprep_item* __restrict__ items, int 
     const long at = (long)(it.o_off + o) * it.dst_ld + it.c_off + (long)t * it.Ni_dst + i;
     if (it.plane_stride == 0) {
       reinterpret_cast<float*>(it.dst)[at] = v;
+    } else if (it.fmt == 1) {                  // two scaled fp16 planes (precision 3)
+      const float y = v * exp2i_(f16_sexp_(*it.amax));
+      const _Float16 h = (_Float16)y, l = (_Float16)(y - (float)h);
+      unsigned short* dp = reinterpret_cast<unsigned short*>(it.dst) + at;
+      dp[0] = __builtin_bit_cast(unsigned short, h);
+      dp[it.plane_stride] = __builtin_bit_cast(unsigned short, l);
     } else {
       __bf16* dp = reinterpret_cast<__bf16*>(it.dst) + at;
 #pragma unroll
@@ -852,10 +878,27 @@ __global__ void weight_prep_kernel(const se_wprep_item* __restrict__ items, int 
   }
 }
 
+// max |scale * src| of every fmt-1 item into the amax scalar of its destination (non-negative floats order like their bit patterns)
+__global__ void weight_amax_kernel(const se_wprep_item* __restrict__ items, int nitems) {
+  const se_wprep_item it = items[blockIdx.y];
+  if (it.plane_stride == 0 || it.fmt != 1) return;
+  const long total = (long)it.No * it.Nt * it.Ni;
+  float m = 0.f;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % it.Ni);
+    const int t = (int)((idx / it.Ni) % it.Nt);
+    const int o = (int)(idx / ((long)it.Ni * it.Nt));
+    m = fmaxf(m, fabsf(it.scale * it.src[o * it.so + i * it.si + t * it.stt]));      // a maximum: the slab reversal is irrelevant
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(it.amax), __float_as_uint(m));
+}
+
 extern "C" int se_weight_prep(const se_wprep_item* items_dev, int nitems, long max_elems, void* stream) {
   SE_REQUIRE(items_dev && nitems > 0 && nitems <= 65535 && max_elems > 0, "weight_prep: bad arguments");
   long nb = (max_elems + 255) / 256;
   if (nb > 64) nb = 64;                       // grid-stride inside an item: most items are a few thousand elements
+  hipLaunchKernelGGL(weight_amax_kernel, dim3((unsigned)nb, (unsigned)nitems), dim3(256), 0, as_stream(stream), items_dev, nitems);
   hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)nb, (unsigned)nitems), dim3(256), 0, as_stream(stream), items_dev, nitems);
   return se_check_launch("se_weight_prep");
 }

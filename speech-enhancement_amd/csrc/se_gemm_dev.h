@@ -565,6 +565,70 @@ static __device__ __forceinline__ void split_store(float4 v, __bf16* p, int plan
 }
 
 
+// ---- precision 3: scaled split-fp16 (hi + lo, three products) --------------------------------------------------------------
+// y = x * 2^sexp (exact) with sexp chosen so that the operand's largest |y| lies in [2^13, 2^14); hi = fp16(y) (round to nearest
+// even, 11-bit significand), lo = fp16(y - hi): |lo| <= 2^-12 |y| and its own rounding error <= 2^-12 |lo|, so hi + lo
+// represents y to 2^-24 |y| (the fp32 rounding unit) wherever lo is a NORMAL fp16 (|y| >= 2^-3, i.e. within 2^17 of the
+// maximum); below that lo is subnormal with quantum 2^-24: absolute error <= 2^-25 = 2^-39 of the maximum.  hi*hi, hi*lo, lo*hi
+// are exact in fp32 (22-bit products); lo*lo (<= 2^-24 relative) is dropped.  FP16_OVFL clamps an out-of-range conversion to
+// +-65504 instead of producing inf (amax pointers make that unreachable; a static exponent is a promise by the caller).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ unsigned pk_f16_(float a, float b) {            // one v_cvt_pk_f16_f32 (round to nearest even)
+  f32x2_ v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_));
+}
+static __device__ __forceinline__ void f16_clamp_mode_() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+static __host__ __device__ __forceinline__ int f16_sexp_(float amax) {             // amax * 2^sexp in [2^13, 2^14)
+  unsigned u;
+  __builtin_memcpy(&u, &amax, 4);
+  const int e = (int)((u >> 23) & 0xffu) - 127;
+  const int sx = 13 - e;
+  return !(amax > 0.f) ? 0 : (sx < -60 ? -60 : (sx > 60 ? 60 : sx));
+}
+static __device__ __forceinline__ float exp2i_(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+static __device__ __forceinline__ int operand_sexp_(const float* amax, int sexp) {
+  return amax ? f16_sexp_(__builtin_nontemporal_load(amax)) : sexp;
+}
+static __device__ __forceinline__ void split_store_h(float4 v, float s, __bf16* p, int plane_stride) {
+  float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+  const unsigned a = pk_f16_(x0, x1), b = pk_f16_(x2, x3);
+  *reinterpret_cast<u32x2_*>(p) = (u32x2_){a, b};
+  const f16x2_ ah = __builtin_bit_cast(f16x2_, a), bh = __builtin_bit_cast(f16x2_, b);
+  x0 -= (float)ah[0]; x1 -= (float)ah[1]; x2 -= (float)bh[0]; x3 -= (float)bh[1];
+  *reinterpret_cast<u32x2_*>(p + plane_stride) = (u32x2_){pk_f16_(x0, x1), pk_f16_(x2, x3)};
+}
+template <typename V8>
+static __device__ __forceinline__ void split_planes8_h(float (&x)[8], float s, V8 (&out)[2]) {
+  u32x4_ h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float y0 = x[2 * i] * s, y1 = x[2 * i + 1] * s;
+    h[i] = pk_f16_(y0, y1);
+    const f16x2_ hh = __builtin_bit_cast(f16x2_, h[i]);
+    l[i] = pk_f16_(y0 - (float)hh[0], y1 - (float)hh[1]);
+  }
+  out[0] = __builtin_bit_cast(V8, h);
+  out[1] = __builtin_bit_cast(V8, l);
+}
+// one 32x32x16 / 16x16x32 MFMA on 16-bit fragments held as bf16x8 bit patterns: bf16 or (F16) fp16 arithmetic
+template <bool F16>
+static __device__ __forceinline__ f32x16 mfma32_(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+template <bool F16>
+static __device__ __forceinline__ f32x4 mfma16_(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// NPL-plane split of a float4 into LDS in either arithmetic (s: the fp16 operand scale, ignored for bf16)
+template <int NPL, bool F16>
+static __device__ __forceinline__ void split_store_x(float4 v, float s, __bf16* p, int plane_stride) {
+  if constexpr (F16) { static_assert(NPL == 2, "split-fp16 has two planes"); split_store_h(v, s, p, plane_stride); }
+  else split_store<NPL>(v, p, plane_stride);
+}
+
 // ---------------------------------------------------------------------------------------------
 static int check_desc(const se_gemm_desc* d) {
   SE_REQUIRE(d->ntap >= 1 && d->ntap <= SE_MAX_TAPS, "gemm: ntap %d out of range", d->ntap);

@@ -326,10 +326,11 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
     const float* __restrict__ X, int ldx, int x_off, const float* __restrict__ mr, const float* __restrict__ g,
     const float* __restrict__ beta, const float* __restrict__ slope, const float* __restrict__ dY, int ldy, int y_off,
     const double* __restrict__ red, float* __restrict__ dX, int lddx, int dx_off, long P, int C, int per_batch,
-    double count, int act, float* dg, float* dbeta, float* dslope, int nbs) {
+    double count, int act, float* dg, float* dbeta, float* dslope, int nbs, float* amax_out) {
   ChanIter it(C);
   const int b = blockIdx.y;
   const int sb = per_batch ? b : 0;
+  float amx = 0.f;                               // max |dX| written by this lane (amax_out: the consumer's fp16 operand scale)
   if (dg && blockIdx.x == 0 && b == 0 && threadIdx.x < C) {      // norm_param_grad_kernel's work, one launch less
     const int c = threadIdx.x;
     double s1 = 0, s2 = 0, s3 = 0;
@@ -380,8 +381,15 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
         float du = act ? dy[j] * swish_gradf_(u) : (u >= 0.f ? dy[j] : dy[j] * sl[j]);
         o[j] = rstd[j] * gg[j] * (du - m1[j] - xh * m2[j]);
       }
-      if (p < p_end) *reinterpret_cast<float4*>(Ob + p * lddx) = make_float4(o[0], o[1], o[2], o[3]);
+      if (p < p_end) {
+        *reinterpret_cast<float4*>(Ob + p * lddx) = make_float4(o[0], o[1], o[2], o[3]);
+        amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+      }
     }
+  }
+  if (amax_out) {                                // non-negative floats order like their bit patterns: one atomic per wave
+    amx = wave_max(amx);
+    if ((threadIdx.x & 63) == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amx));
   }
 }
 
@@ -499,6 +507,15 @@ extern "C" int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float
                                  double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,
                                  float* dslope, int B, long P, int C, int per_batch, int act, int phase, double count,
                                  void* stream) {
+  return se_norm_prelu_bwd_amax(X, ldx, x_off, mr, g, beta, slope, dY, ldy, y_off, red, dX, lddx, dx_off, dg, dbeta, dslope, B, P, C,
+                                per_batch, act, phase, count, nullptr, stream);
+}
+
+extern "C" int se_norm_prelu_bwd_amax(const float* X, int ldx, int x_off, const float* mr, const float* g,
+                                      const float* beta, const float* slope, const float* dY, int ldy, int y_off,
+                                      double* red, float* dX, int lddx, int dx_off, float* dg, float* dbeta,
+                                      float* dslope, int B, long P, int C, int per_batch, int act, int phase, double count,
+                                      float* amax_out, void* stream) {
   SE_REQUIRE(X && mr && g && beta && dY && red && dX && dg && dbeta && B > 0 && P > 0 && chan_ok(C),
              "norm_prelu_bwd: bad arguments (C=%d)", C);
   SE_REQUIRE((ldx % 4) == 0 && (x_off % 4) == 0 && (ldy % 4) == 0 && (y_off % 4) == 0 && (lddx % 4) == 0 &&
@@ -523,7 +540,7 @@ extern "C" int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float
   if (phase & 2) {
     hipLaunchKernelGGL(norm_prelu_bwd_apply_kernel, dim3((int)nb, B), dim3(256), 0, s, X, ldx,
                        x_off, mr, g, beta, slope, dY, ldy, y_off, red, dX, lddx, dx_off, P, C, per_batch, count, act,
-                       (phase & 8) ? dg : nullptr, dbeta, dslope, nbs);
+                       (phase & 8) ? dg : nullptr, dbeta, dslope, nbs, amax_out);
   }
   return se_check_launch("se_norm_prelu_bwd");
 }

@@ -455,7 +455,10 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
 // (chunks 1..8; the two halo rows sit at positions 7 and 72).  Frequency-edge rows are cleared in the shifted fragment
 // by a dword mask; with Fo > 66 (host-checked) a 66-row tile holds at most one edge row of each kind, whose position
 // is a per-step scalar.  One split + one LDS store per element serves 72 MFMAs per wave and step instead of 24.
-template <int NPL>
+// F16 (precision 3): two planes of scaled fp16 (se_gemm_dev.h), three fp16 MFMAs per product; the activations are scaled by
+// 2^sexp(a_amax | a_sexp), dY by 2^sexp(w_amax | w_sexp) -- the descriptor's second-operand scale -- and the sums are un-scaled
+// (exactly) where they are added to dW.
+template <int NPL, bool F16 = false>
 __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   constexpr int MR = 64;
   constexpr int PLY = (9 * 64 + 4) * 8;       // Yt plane: [64 n][64 m],  cell(r, ch) = 9 r + (r >> 4) + ch
@@ -481,6 +484,12 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
 #pragma unroll
   for (int s3 = 0; s3 < 3; ++s3) dfs[s3] = d.df[3 * gi + s3];
   const int ishift = d.dt[3 * gi] * d.Fo;
+  float sx = 1.f, sy = 1.f, unscale = 1.f;
+  if (F16) {
+    f16_clamp_mode_();
+    const int ex = operand_sexp_(d.a_amax, d.a_sexp), ey = operand_sexp_(d.w_amax, d.w_sexp);
+    sx = exp2i_(ex); sy = exp2i_(ey); unscale = exp2i_(-ex - ey);
+  }
 
   f32x16 acc[3];
 #pragma unroll
@@ -528,15 +537,19 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
     }
   };
   // 4 x 4 register transpose + split + 8-B store per column; poff = position of tile row 0 inside the LDS row
-  auto stage_t = [&](const float4 (&v)[4], __bf16* T, int pln, bool halo_layout) {
+  auto stage_t = [&](const float4 (&v)[4], __bf16* T, int pln, bool halo_layout, float sc) {
     const float x[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
                            {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * q + j;
       __bf16* dst = halo_layout ? T + (10 * r + (r >> 3)) * 8 + 8 + 4 * rg : T + (9 * r + (r >> 4)) * 8 + 4 * rg;
-      float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
-      split_store4<NPL>(e, dst, pln);
+      if constexpr (F16) {
+        split_store_h(make_float4(x[0][j], x[1][j], x[2][j], x[3][j]), sc, dst, pln);
+      } else {
+        float e[4] = {x[0][j], x[1][j], x[2][j], x[3][j]};
+        split_store4<NPL>(e, dst, pln);
+      }
     }
   };
   int fbase = (int)((mbeg % Mb) % d.Fo);      // frequency index of the step's first row (wave-uniform)
@@ -545,8 +558,8 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   const __bf16* yfrag = Yt + (9 * ra_ + (ra_ >> 4)) * 8 + 8 * kg;
   const __bf16* xrow = Xt + (10 * rb_ + (rb_ >> 3)) * 8;
   for (long mb = mbeg; mb < mend; mb += MR) {
-    stage_t(rx, Xt, PLX, true);
-    stage_t(ry, Yt, PLY, false);
+    stage_t(rx, Xt, PLX, true, sx);
+    stage_t(ry, Yt, PLY, false, sy);
     if (tid < 32) {                            // halo rows: positions 7 and 72
       const int ph = (tid >> 4) ? 72 : 7;
       const float hv[4] = {rh.x, rh.y, rh.z, rh.w};
@@ -554,8 +567,16 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * q + j;
         float e = hv[j];
+        if constexpr (F16) {
+          e *= sx;
+          const _Float16 h = (_Float16)e, l = (_Float16)(e - (float)h);
+          unsigned short* xt = reinterpret_cast<unsigned short*>(Xt);
+          xt[(10 * r + (r >> 3)) * 8 + ph] = __builtin_bit_cast(unsigned short, h);
+          xt[PLX + (10 * r + (r >> 3)) * 8 + ph] = __builtin_bit_cast(unsigned short, l);
+        } else {
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) { __bf16 h = (__bf16)e; e -= (float)h; Xt[pl * PLX + (10 * r + (r >> 3)) * 8 + ph] = h; }
+          for (int pl = 0; pl < NPL; ++pl) { __bf16 h = (__bf16)e; e -= (float)h; Xt[pl * PLX + (10 * r + (r >> 3)) * 8 + ph] = h; }
+        }
       }
     }
     if (do_bias) {
@@ -616,20 +637,21 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
         for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
           for (int qa = 0; qa <= ord; ++qa)
-            acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf[ord - qa], acc[s3], 0, 0, 0);
+            acc[s3] = mfma32_<F16>(af[qa], bf[ord - qa], acc[s3]);
       }
     }
     __syncthreads();
   }
   const int col = lane & 31, half = lane >> 5;
   const int c = cb * 64 + wc * 32 + col;
+  const float oscale = d.alpha * unscale;
 #pragma unroll
   for (int s3 = 0; s3 < 3; ++s3) {
     const int tap = 3 * gi + s3;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], d.alpha * acc[s3][r]);
+      if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], oscale * acc[s3][r]);
     }
   }
   if (do_bias) {
@@ -1001,12 +1023,15 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
     }
     if (triples && (d->precision == 0 || d->Fo > 66)) {
       dim3 g3((unsigned)((long)(d->ntap / 3) * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8)));
-      if (d->precision == 1) hipLaunchKernelGGL(wgrad3_bf16_kernel<2>, g3, block, 0, s, g);
+      if (d->precision == 3) hipLaunchKernelGGL((wgrad3_bf16_kernel<2, true>), g3, block, 0, s, g);
+      else if (d->precision == 1) hipLaunchKernelGGL(wgrad3_bf16_kernel<2>, g3, block, 0, s, g);
       else if (d->precision == 2) hipLaunchKernelGGL(wgrad3_bf16_kernel<3>, g3, block, 0, s, g);
       else hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
       return se_check_launch("se_gemm_tap_wgrad(conv3)");
     }
   }
+  se_gemm_desc dfb;
+  if (d->precision == 3) { dfb = *d; dfb.precision = 2; d = &dfb; }      // shapes without a scaled split-fp16 kernel: six-product / fp32 ones
   // token-wise layers (row GEMM, fp32 MFMA, the whole gradient fits one workgroup): every operand row staged once per launch
   const bool lin = d->ntap == 1 && d->B == 1 && !d->up && d->st == 1 && d->sf == 1 && d->dt[0] == 0 && d->df[0] == 0 &&
                    d->Ti == d->To && d->Fi == d->Fo;

@@ -14,7 +14,7 @@ def conv_taps(kh, kw, dil=(1, 1), pad=(0, 0)):
 
 def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=None, st=1, sf=1, up=0,
               prologue=L.PRO_NONE, epilogue=0, alpha=1.0, ldr=0, r_off=0, ldx=0, x_off=0, pro_seed=0, epi_seed=0,
-              drop_p=0.0, precision=0):
+              drop_p=0.0, precision=0, a_sexp=0, w_sexp=0, a_amax=None, w_amax=None):
     d = GemmDesc()
     d.B, d.To, d.Fo, d.Ti, d.Fi = B, To, Fo, Ti, Fi
     d.st, d.sf, d.up = st, sf, up
@@ -28,6 +28,10 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
     d.ldr, d.r_off, d.ldx, d.x_off = ldr, r_off, ldx, x_off
     d.pro_seed, d.epi_seed, d.drop_p = pro_seed & 0xFFFFFFFF, epi_seed & 0xFFFFFFFF, drop_p
     d.precision = precision
+    d.a_sexp, d.w_sexp = a_sexp, w_sexp
+    d.a_amax = a_amax.data_ptr() if a_amax is not None else None
+    d.w_amax = w_amax.data_ptr() if w_amax is not None else None
+    d._keep = (a_amax, w_amax)                # the descriptor holds raw pointers: keep the scalars alive with it
     return d
 
 
@@ -54,12 +58,15 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     M = d.B * d.To * d.Fo
     if W.dtype == torch.bfloat16:        # weights pre-split by the step's WeightPlan: [3 planes][rows][ld] bf16
         d.w_planes, d.ldw = W.stride(0), W.shape[2]
+    elif W.dtype == torch.float16:       # precision 3: [2 planes][rows][ld] scaled fp16 + the scalar they were scaled by
+        d.w_planes, d.ldw = W.stride(0), W.shape[2]
+        d.w_amax = W._se_amax.data_ptr()
     else:
         d.w_planes = 0
     L.call('se_gemm_tap', C.byref(d), L.ptr(A), L.ptr(W), L.ptr(bias), L.ptr(Y), L.ptr(R), L.ptr(AUX),
            L.ptr(rowstats), L.ptr(ps), L.ptr(pb), L.ptr(stats), L.stream(),
-           _key=(f'conv3_bf16x{3 if d.precision == 1 else 6}'
-                 if d.precision in (1, 2) and d.C >= 32 and d.prologue == 0 and d.ntap >= 3 and d.ntap % 3 == 0 and not d.up
+           _key=(('conv3_f16x3' if d.precision == 3 else f'conv3_bf16x{3 if d.precision == 1 else 6}')
+                 if d.precision in (1, 2, 3) and d.C >= 32 and d.prologue == 0 and d.ntap >= 3 and d.ntap % 3 == 0 and not d.up
                  and d.st == 1 and d.sf == 1 and d.Ti == d.To and d.Fi == d.Fo and not d.epilogue & (L.EPI_GLU | L.EPI_DROP) else
                  f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>'
                  if d.precision in (1, 2) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1

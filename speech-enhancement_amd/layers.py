@@ -20,13 +20,30 @@ EPS = 1e-5
 # fp32 accumulation: fp32-equivalent results (dropped terms <= 2^-24) at 16/6 of the fp32 MFMA rate; 'bf16x3' = two
 # parts / three MFMAs, ~1.5e-5 relative per product (meets the 1e-3 bar with less margin; opt-in).
 import os as _os
-CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_CONV_PRECISION', 'bf16x6')]
+EPS = 1e-5
+
+# Arithmetic of the MFMA-bound convolution GEMMs (dilated dense stacks, sub-pixel, strided convs): 'f32' = exact
+# fp32 MFMA; 'bf16x6' (default) = every fp32 operand split EXACTLY into three bf16 parts, six bf16 MFMAs per product,
+# fp32 accumulation: fp32-equivalent results (dropped terms <= 2^-24) at 16/6 of the fp32 MFMA rate; 'bf16x3' = two
+# parts / three MFMAs, ~1.5e-5 relative per product (meets the 1e-3 bar with less margin; opt-in); 'f16x3' = SCALED split-fp16
+# (se_gemm_desc precision 3): every operand times a power of two that brings its maximum to [2^13, 2^14), then hi + lo in fp16
+# (2 x 11 significand bits, 2^-24 relative), three fp16 MFMAs per product -- measured MORE accurate than both fp32-MFMA and
+# bf16x6 against fp64 (rms 4.4e-7 vs 6.9e-7 / 6.0e-7 at Cin = 256) at 1.44x - 1.74x the bf16x6 speed.  The triple-tap unit-stride
+# convolutions (90 % of the conv FLOPs) run it; the other conv shapes keep the six-product kernels under this setting.
+import os as _os
+_PREC = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2, 'f16x3': 3}
+CONV_PRECISION = _PREC[_os.environ.get('SE_CONV_PRECISION', 'f16x3')]
+# static operand exponent of NORMALISED activations under precision 3 (InstanceNorm / LayerNorm outputs after PReLU, the TSCB
+# token stream): |x| * 2^4 must stay below 65504, i.e. |x| < 4094 -- an InstanceNorm output is bounded by sqrt(T F - 1) |gamma| +
+# |beta| = 254 |gamma| + |beta|; out-of-range values would be clamped (FP16_OVFL), not turned into inf.  Gradients and weights
+# are scaled by their MEASURED maxima instead (amax scalars).
+ACT_SEXP = 4
 
 
 # weight-gradient GEMMs of the same convolutions (contraction over pixels; same operand splits, transposed staging).
 # 'bf16x6' routes the triple-tap layers with Fo > 66 to wgrad3_bf16_kernel (108 vs 94 TFLOP/s for the fp32 triple kernel);
 # every other shape runs the fp32-MFMA kernels under it (the generic six-product kernel is slower than fp32 MFMA).
-WGRAD_PRECISION = [{'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[_os.environ.get('SE_WGRAD_PRECISION', 'bf16x6')]]
+WGRAD_PRECISION = [_PREC[_os.environ.get('SE_WGRAD_PRECISION', 'f16x3')]]
 
 
 # input-gradient GEMM of the qkv / pointwise-GLU projections fused with the backward of the LayerNorm in front of them
@@ -38,8 +55,26 @@ FUSE_ROWSTATS = _os.environ.get('SE_NO_ROWSTATS_FUSE') != '1'
 
 def set_conv_precision(name, wgrad=None):
     global CONV_PRECISION
-    CONV_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[name]
-    WGRAD_PRECISION[0] = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[wgrad or name]
+    CONV_PRECISION = _PREC[name]
+    WGRAD_PRECISION[0] = _PREC[wgrad or name]
+
+
+def _conv3_shape(taps, sf, C_in, Fo=None):
+    """the triple-tap unit-stride shapes conv3_bf16_kernel / wgrad3_bf16_kernel cover (the only ones with a precision-3 kernel)"""
+    if sf != 1 or C_in < 32 or len(taps) % 3 or (Fo is not None and Fo < 2):
+        return False
+    for i in range(0, len(taps), 3):
+        if {t[0] for t in taps[i:i + 3]} != {taps[i][0]} or sorted(abs(t[1]) for t in taps[i:i + 3]) != [0, 1, 1] or \
+                {t[1] for t in taps[i:i + 3]} != {-1, 0, 1}:
+            return False
+    return True
+
+
+def _prec(p, taps, sf, C_in, Fo=None, have_scale=True):
+    """precision 3 only where a scaled split-fp16 kernel exists and the operand scales are known; six-product otherwise"""
+    if p != 3:
+        return p
+    return 3 if (have_scale and _conv3_shape(taps, sf, C_in, Fo)) else 2
 
 
 class DPHooks:
@@ -69,7 +104,8 @@ def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None
     ep = L.EPI_BIAS | (L.EPI_STATS if want_stats else 0) | (L.EPI_SHUFFLE2 if shuffle2 else 0)
     No = N // 2 if shuffle2 else N
     d = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, No, a_off=a_off, sf=sf, epilogue=ep,
-                     precision=CONV_PRECISION)
+                     precision=_prec(CONV_PRECISION, taps, sf, C_in, Fo, have_scale=wp.dtype != torch.bfloat16), a_sexp=ACT_SEXP,
+                     w_sexp=8)
     R = torch.empty(B, To, Fo * (2 if shuffle2 else 1), No, device=x.device, dtype=torch.float32)
     stats = O.zeros(B, No, 2, device=x.device, dtype=torch.float64) if want_stats else None
     GM.gemm_tap(d, x, wp, R, bias=bias, stats=stats)
@@ -88,7 +124,10 @@ def inorm_prelu_bwd(R, mr, g, b, slope, dy, ldy, y_off, dg, db, dslope):
     C_ = R.shape[-1]
     P = R.numel() // (B * C_)
     dR = torch.empty_like(R)
-    O.norm_prelu_bwd(R, C_, 0, mr, g, b, slope, dy, ldy, y_off, dR, C_, 0, dg, db, dslope, B, P, C_, per_batch=True)
+    # max |dR| for the scaled split-fp16 kernels that read dR next (conv input / weight gradient): one atomic per wave
+    amax = O.zeros(1, device=R.device) if 3 in (CONV_PRECISION, WGRAD_PRECISION[0]) else None
+    O.norm_prelu_bwd(R, C_, 0, mr, g, b, slope, dy, ldy, y_off, dR, C_, 0, dg, db, dslope, B, P, C_, per_batch=True, amax=amax)
+    dR._se_amax = amax
     return dR
 
 
@@ -98,8 +137,11 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     gradient into dx[..., dx_off:dx_off+C_in] (pixel stride lddx)."""
     N = dR.shape[-1]
     ntap = len(taps)
-    fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf, precision=WGRAD_PRECISION[0])
-    with GM.leaf_stream(x, dR):
+    amax = getattr(dR, '_se_amax', None)            # producer-measured max |dR| (inorm_prelu_bwd); None: no scaled-fp16 kernels here
+    fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf,
+                      precision=_prec(WGRAD_PRECISION[0], taps, sf, C_in, Fo, have_scale=amax is not None and Fo > 66),
+                      a_sexp=ACT_SEXP, w_amax=amax)
+    with GM.leaf_stream(x, dR, amax):
         dwp = O.zeros(N, ntap * C_in, device=dR.device)
         GM.gemm_tap_wgrad(fd, x, dR, dwp, dbias)
         _unpack_w(dwp, dw, C_in, rev)
@@ -112,8 +154,11 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     if dx is None:
         dx = torch.empty(B, Ti, Fi, C_in, device=dR.device, dtype=torch.float32)
         lddx = C_in
-    dd = GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in taps], N, N, C_in, lddx, c_off=dx_off, sf=sf,
-                      up=1 if sf != 1 else 0, epilogue=L.EPI_ACCUM if accumulate else 0, precision=CONV_PRECISION)
+    dtaps = [(-a, -c) for a, c in taps]
+    dd = GM.make_desc(B, Ti, Fi, To, Fo, dtaps, N, N, C_in, lddx, c_off=dx_off, sf=sf,
+                      up=1 if sf != 1 else 0, epilogue=L.EPI_ACCUM if accumulate else 0,
+                      precision=_prec(CONV_PRECISION, dtaps, sf, N, Fi, have_scale=amax is not None and wd.dtype != torch.bfloat16),
+                      a_amax=amax, w_sexp=8)
     GM.gemm_tap(dd, dR, wd, dx)
     return dx
 
@@ -157,14 +202,15 @@ def _w(P, key, fallback):
 def build_generator_plan(P, device):
     from .weights import WeightPlan
     plan = WeightPlan(device)
-    cpl = CONV_PRECISION == 2            # six-product kernels read the exact hi/mid/lo planes; everything else fp32
+    cpl = CONV_PRECISION in (2, 3)       # six-product kernels read the exact hi/mid/lo planes; everything else fp32
+    c3 = 'f16' if CONV_PRECISION == 3 else cpl      # triple-tap unit-stride convolutions under precision 3: scaled fp16 planes
     lpl = GM.LINEAR_PRECISION == 2
 
     def dense(p):
         for i in range(4):
             n = f'{p}.conv{i+1}.weight'
-            plan.conv_fwd((n, 'fwd'), P[n], rev=True, planes=cpl)
-            plan.conv_dgrad((n, 'dgrad'), P[n], rev=True, planes=cpl)
+            plan.conv_fwd((n, 'fwd'), P[n], rev=True, planes=c3)
+            plan.conv_dgrad((n, 'dgrad'), P[n], rev=True, planes=c3)
 
     e = 'dense_encoder'
     plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
@@ -174,8 +220,8 @@ def build_generator_plan(P, device):
     for dec, last in (('mask_decoder', 'conv_1'), ('complex_decoder', 'conv')):
         dense(f'{dec}.dense_block')
         n = f'{dec}.sub_pixel.conv.weight'
-        plan.conv_fwd((n, 'fwd'), P[n], planes=cpl)
-        plan.conv_dgrad((n, 'dgrad'), P[n], planes=cpl)
+        plan.conv_fwd((n, 'fwd'), P[n], planes=c3)
+        plan.conv_dgrad((n, 'dgrad'), P[n], planes=c3 if dec == 'complex_decoder' else cpl)      # mask decoder: dS has no measured amax
         n = f'{dec}.{last}.weight'                                   # 64 -> 1 / 2 channels, rows padded to 4
         plan.conv_fwd((n, 'fwd'), P[n], N_pad=4, planes=cpl)
         plan.conv_dgrad((n, 'dgrad'), P[n], N_pad=4)                  # C = 4 < 32: fp32 kernel

@@ -132,22 +132,23 @@ def affine_prelu(x, ldx, x_off, ss, slope, y, ldy, y_off, B, P, C_):
 
 
 def norm_prelu_bwd(x, ldx, x_off, mr, g, beta, slope, dy, ldy, y_off, dx, lddx, dx_off, dg, dbeta, dslope, B, P, C_,
-                   per_batch=True, act=0, allreduce=None, count=None):
+                   per_batch=True, act=0, allreduce=None, count=None, amax=None):
     """allreduce: optional callable applied to the fp64 reduction buffer between the two phases
-    (SyncBatchNorm backward); count: elements per statistic (defaults to the local count)."""
+    (SyncBatchNorm backward); count: elements per statistic (defaults to the local count); amax: optional zero-filled device
+    scalar raised to max |dx| (operand scale of the scaled split-fp16 GEMMs that read dx)."""
     red = zeros(L.lib().se_norm_prelu_bwd_workspace_bytes(_i(B), _i(C_), _i(int(per_batch))) // 8, device=x.device, dtype=f64)
     if count is None:
         count = float(P if per_batch else P * B)
     args = lambda phase: (L.ptr(x), _i(ldx), _i(x_off), L.ptr(mr), L.ptr(g), L.ptr(beta), L.ptr(slope),
                           L.ptr(dy), _i(ldy), _i(y_off), L.ptr(red), L.ptr(dx), _i(lddx), _i(dx_off), L.ptr(dg),
                           L.ptr(dbeta), L.ptr(dslope), _i(B), _l(P), _i(C_), _i(int(per_batch)), _i(act),
-                          _i(phase), _d(count), L.stream())
+                          _i(phase), _d(count), L.ptr(amax), L.stream())
     if allreduce is None:
-        L.call('se_norm_prelu_bwd', *args(1 | 2 | 8 | 16))      # two launches: reduce, apply (+ parameter gradients); red from the arena
+        L.call('se_norm_prelu_bwd_amax', *args(1 | 2 | 8 | 16))      # two launches: reduce, apply (+ parameter gradients); red from the arena
     else:
-        L.call('se_norm_prelu_bwd', *args(1 | 4 | 16))
+        L.call('se_norm_prelu_bwd_amax', *args(1 | 4 | 16))
         allreduce(red)
-        L.call('se_norm_prelu_bwd', *args(2))
+        L.call('se_norm_prelu_bwd_amax', *args(2))
     return dx
 
 

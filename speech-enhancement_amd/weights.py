@@ -18,17 +18,19 @@ class WItem(C.Structure):
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('No', C.c_int), ('Nt', C.c_int), ('Ni', C.c_int),
                 ('Ni_dst', C.c_int), ('so', C.c_long), ('stt', C.c_long), ('si', C.c_long), ('rev', C.c_int),
                 ('dst_ld', C.c_int), ('o_off', C.c_int), ('c_off', C.c_int), ('scale', C.c_float),
-                ('plane_stride', C.c_long)]
+                ('plane_stride', C.c_long), ('fmt', C.c_int), ('amax', C.c_void_p)]
 
 
 class WeightPlan:
     def __init__(self, device):
         self.device = device
-        self.out = {}          # key -> prepared tensor: fp32 [rows, ld] or bf16 planes [3, rows, ld]
+        self.out = {}          # key -> prepared tensor: fp32 [rows, ld], bf16 planes [3, rows, ld] or scaled fp16 planes [2, rows, ld]
         self._items = []
         self._srcs = []        # keeps the source tensors alive / lets `stale()` detect re-allocated parameters
         self._table = None
         self._max = 1
+        self._amax = None      # one fp32 scalar per fp16-plane destination (se_gemm_desc.w_amax); zeroed before every run
+        self._amax_slot = {}
 
     def add(self, key, src, No, Nt, Ni, so, stt, si, rev=0, scale=1.0, planes=False, rows=None, ld=None, o_off=0, c_off=0,
             Ni_dst=None):
@@ -43,16 +45,27 @@ class WeightPlan:
             if planes:
                 if ld % 8:
                     raise L.SeHipError(f'weight plan: {key}: plane rows must be multiples of 8 elements (ld={ld})')
-                self.out[key] = torch.zeros(3, rows, ld, device=self.device, dtype=torch.bfloat16)
+                if planes == 'f16':        # precision 3: two scaled fp16 planes + the amax scalar they were scaled by
+                    if self._amax is None:
+                        self._amax = torch.zeros(1024, device=self.device, dtype=torch.float32)
+                    if len(self._amax_slot) >= self._amax.numel():
+                        raise L.SeHipError('weight plan: more than 1024 fp16-plane matrices')
+                    self._amax_slot[key] = len(self._amax_slot)
+                    self.out[key] = torch.zeros(2, rows, ld, device=self.device, dtype=torch.float16)
+                    self.out[key]._se_amax = self._amax[self._amax_slot[key]:self._amax_slot[key] + 1]
+                else:
+                    self.out[key] = torch.zeros(3, rows, ld, device=self.device, dtype=torch.bfloat16)
             else:
                 self.out[key] = torch.zeros(rows, ld, device=self.device, dtype=torch.float32)
         dst = self.out[key]
-        is_pl = dst.dtype == torch.bfloat16
+        is_pl = dst.dtype in (torch.bfloat16, torch.float16)
+        f16 = dst.dtype == torch.float16
         drows, dld = dst.shape[-2], dst.shape[-1]
         if o_off + No > drows or c_off + (Nt - 1) * Ni_dst + Ni > dld:
             raise L.SeHipError(f'weight plan: {key}: item exceeds its destination')
         self._items.append(WItem(src.data_ptr(), dst.data_ptr(), No, Nt, Ni, Ni_dst, so, stt, si, rev, dld, o_off, c_off,
-                                 float(scale), drows * dld if is_pl else 0))
+                                 float(scale), drows * dld if is_pl else 0, 1 if f16 else 0,
+                                 dst._se_amax.data_ptr() if f16 else None))
         self._srcs.append((src, src.data_ptr()))
         self._max = max(self._max, No * Nt * Ni)
         self._table = None
@@ -68,6 +81,8 @@ class WeightPlan:
         if self._table is None:
             arr = (WItem * len(self._items))(*self._items)
             self._table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        if self._amax is not None:
+            self._amax.zero_()
         L.call('se_weight_prep', L.ptr(self._table), C.c_int(len(self._items)), C.c_long(self._max), L.stream())
 
     # ---- recipes -------------------------------------------------------------------------------------------------

@@ -74,8 +74,17 @@ def test_consistency_stft_backward_vs_reference(S, golden3, comp):
     (P[..., 1] * wr + P[..., 2] * wi + P[..., 0] * wm).sum().backward()
     dref = golden3[f'stftbwd_{comp}_dx']
     err = float(np.abs(x.grad.double().cpu().numpy() - dref).max())
-    print(comp, 'dx max err', err, 'of max', float(np.abs(dref).max()))
-    assert err < 2e-5 * float(np.abs(dref).max())
+    # the fp32 floor of this quantity: the same chain in torch-CPU fp32 (oracle) against the fp64 golden -- bins of 0.04 next to
+    # bins of 100 make the |z|^-0.7 factor of the 'pow' backward sensitive to the forward's fp32 rounding (measured on MI355X:
+    # pow 1.9e-5, log 6e-7, norm 3e-7, none 3e-7 of max |dx|)
+    from oracle import se_oracle as Or
+    xo = torch.from_numpy(golden3['stftbwd_x'].astype(np.float32)).requires_grad_(True)
+    so = Or.compressed_stft(xo, comp=comp)
+    wro, wio, wmo = (w.permute(0, 2, 1).cpu() for w in (wr, wi, wm))
+    (so.real * wro + so.imag * wio + so.abs() * wmo).sum().backward()
+    floor = float(np.abs(xo.grad.double().numpy() - dref).max())
+    print(comp, 'dx max err', err, 'of max', float(np.abs(dref).max()), '(torch-CPU fp32 floor:', floor, ')')
+    assert err < 2e-5 * float(np.abs(dref).max()) + 1.5 * floor
     # the same gradient through the product's non-fused forward twin on the oracle side is covered on CPU
     # (tests/test_oracle_golden.py::test_compressed_stft_gradient)
 

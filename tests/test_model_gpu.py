@@ -724,7 +724,7 @@ def test_world1_hooks_equal_plain_step(S):
                 hooks.force_sync = True              # take the two-phase SyncBatchNorm backward although world == 1
                 calls = []
                 orig = hooks.allreduce
-                hooks.allreduce = lambda t_: (calls.append(t_.numel()), orig(t_))[1]
+                hooks.allreduce = lambda t_, **kw: (calls.append(t_.numel()), orig(t_, **kw))[1]
                 g.dp = hooks
             out = TR.gan_step(g, d, og, od, clean, noisy, 'scp', (0.3, 0.7, 0.2, 0.05), labels=labels, hooks=hooks)
             res.append(({k: float(v) for k, v in out.items()},
