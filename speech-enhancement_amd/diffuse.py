@@ -172,7 +172,7 @@ class DiffuSE(nn.Module):
         for i, (lay, blk) in enumerate(zip(pk['layers'], self.residual_layers)):
             st = torch.zeros(B, 2 * Cc, 2, device=dev, dtype=torch.float64)
             d = GM.make_desc(B, 1, Lp, 1, Lp, lay['taps'], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
-                             precision=LY.CONV_PRECISION)
+                             precision=min(LY.CONV_PRECISION, 2))      # no scaled-fp16 kernel for these tap shapes
             GM.gemm_tap(d, y, lay['wd'], R, bias=lay['bd'], stats=st)
             gn = blk.dilated_conv[1]
             L.call('se_group_finalize', L.ptr(st), _i(B), _i(2 * Cc), _i(0), _i(2 * Cc), _i(16), _d(float(Lp)), L.ptr(gn.weight),
@@ -180,7 +180,7 @@ class DiffuSE(nn.Module):
             L.call('se_diff_gate', L.ptr(R), L.ptr(ss), L.ptr(cond[i]), L.ptr(y2), _i(B), _l(Lp), _i(Cc), L.stream())
             st2 = torch.zeros(B, 2 * Cc, 2, device=dev, dtype=torch.float64)
             d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
-                              precision=LY.CONV_PRECISION)
+                              precision=min(LY.CONV_PRECISION, 2))      # no scaled-fp16 kernel for these tap shapes
             GM.gemm_tap(d2, y2, lay['w2'], R2, bias=lay['b2'], stats=st2)
             gn2 = blk.output_projection[1]
             L.call('se_group_finalize', L.ptr(st2), _i(B), _i(2 * Cc), _i(Cc), _i(Cc), _i(16), _d(float(Lp)), L.ptr(gn2.weight),

@@ -57,8 +57,12 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     L.check_cuda(A, W, Y, bias, R, AUX, rowstats, ps, pb, stats)
     M = d.B * d.To * d.Fo
     if W.dtype == torch.bfloat16:        # weights pre-split by the step's WeightPlan: [3 planes][rows][ld] bf16
+        if d.precision != 2:
+            raise L.SeHipError('gemm_tap: bf16 weight planes need a precision-2 descriptor')
         d.w_planes, d.ldw = W.stride(0), W.shape[2]
     elif W.dtype == torch.float16:       # precision 3: [2 planes][rows][ld] scaled fp16 + the scalar they were scaled by
+        if d.precision != 3:
+            raise L.SeHipError('gemm_tap: scaled fp16 weight planes need a precision-3 descriptor (operand scales known)')
         d.w_planes, d.ldw = W.stride(0), W.shape[2]
         d.w_amax = W._se_amax.data_ptr()
     else:

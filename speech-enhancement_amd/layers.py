@@ -647,6 +647,7 @@ def _subpixel_bwd(P, G, p, x, dS, B, T, Fq):
     """SPConvTranspose2d backward: dS [B,T,2Fq,64] is the un-shuffled gradient; view it as [B,T,Fq,128] with
     channel r*64+c <- pixel 2f+r (the pixel shuffle is a pure re-indexing of the same memory)."""
     dconv = dS.view(B, T, Fq, 128)                      # [.., f, (r, c)] : memory order is already (f, r, c)
+    dconv._se_amax = getattr(dS, '_se_amax', None)      # the producer's max |dS| travels with the view
     w = P[f'{p}.conv.weight']
     dw = G[f'{p}.conv.weight']
     return conv_bwd(x, B, T, Fq, 64, 0, 64, w, TAPS_1x3, dconv, T, Fq, dw, G[f'{p}.conv.bias'],
