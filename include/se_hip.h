@@ -105,6 +105,19 @@ int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W, const flo
                 float* Y, const float* R, float* AUX, const float* rowstats,
                 const float* pro_scale, const float* pro_shift, double* stats, void* stream);
 
+/* operand scales of the token-wise scaled split-fp16 kernels (precision 3; see se_gemm_desc.precision).  amax pointers are device
+ * scalars: an input amax must be >= max |operand| (raised by the kernel that produced the operand, or by se_weight_prep for
+ * weight planes); output amax scalars must be zero (or a running maximum) on entry and are raised with one atomic per wave */
+typedef struct {
+  const float* in_amax;  /* first A operand when it is a gradient (se_ff_bwd_dgrad_f16: dY); NULL: 2^(13 - in_sexp) is assumed */
+  int in_sexp;           /* static exponent of a bounded first A operand (LayerNorm output: 6 -> |x| < 1023)                    */
+  int mid_sexp;          /* static exponent of the in-kernel second A operand of se_ff_fwd_f16 (Swish(H) * mask: 3 -> < 8191)  */
+  const float* wa_amax;  /* scalar of the first weight matrix's fp16 planes (W1 / W2T)                                       */
+  const float* wb_amax;  /* the same for the second one (W2 / W1T)                                                            */
+  float* out_amax;       /* se_ff_bwd_dgrad_f16: raised to max |dX|; may be NULL                                              */
+  float* mid_amax;       /* se_ff_bwd_dgrad_f16: raised to max |dZ|; may be NULL                                              */
+} se_f16_scales;
+
 /* Fused feed-forward forward of a Conformer block (models/conformer.py:53-71,128-145: Scale(0.5, PreNorm(FeedForward))):
    Y = X + alpha * Drop_o(W2 Drop_h(Swish(W1 LN(X) + b1)) + b2), H = W1 LN(X) + b1 [M, hid] kept for the backward.
    X, Y: [M, 64]; rowstats: [M, 2] (mean, rstd) from se_row_stats; W1: [hid, 64]; W2: [64, hid]; hid % 64 == 0;
@@ -121,6 +134,12 @@ int se_ff_fwd_stats(const float* X, const float* rowstats, const float* gamma, c
                     float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream);
 
 
+/* se_ff_fwd_stats with precision 3 (| 16: pre-split planes are mandatory): W1 / W2 = two scaled fp16 planes each (se_weight_prep
+   fmt 1), sc = their amax scalars + the static activation exponents; H may be NULL (not stored).  sc == NULL: precision 1 / 2 */
+int se_ff_fwd_f16(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
+                  const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M, int hid,
+                  float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, const se_f16_scales* sc, void* stream);
+
 /* Fused input-gradient chain of the same feed-forward module (the backward of se_ff_fwd without the weight gradients):
    dZ = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H)) [M, hid],  dLN = dZ W1 [M, 64].
    W2T = (alpha * W2)^T [hid, 64], W1T = W1^T [64, hid]; masks / seeds as in se_ff_fwd.
@@ -131,6 +150,12 @@ int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const flo
                     const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
                     void* stream);
 
+/* se_ff_bwd_dgrad with precision 3 (| 16): W2T / W1T = scaled fp16 planes, sc->in_amax = max |dY| (device scalar) */
+int se_ff_bwd_dgrad_f16(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN, long M,
+                        int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision, const float* X,
+                        const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
+                        const se_f16_scales* sc, void* stream);
+
 /* Input-gradient GEMM of a projection that follows a LayerNorm(64), fused with that LayerNorm's backward
  * (models/conformer.py:67,162: PreNorm -> to_q/to_kv, LayerNorm -> pointwise conv):
  *   dX = dR + LNbwd(A W^T),  dgamma += sum_rows (A W^T) * xhat,  dbeta += sum_rows (A W^T)
@@ -139,6 +164,12 @@ int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const flo
  * [M, 64] product never goes to memory (se_gemm_tap + se_layernorm_bwd: one write and one read of it, and one launch, more). */
 int se_gemm_ln_bwd(const float* A, const float* W, int w_planes, long M, int K, const float* X, const float* stats,
                    const float* gamma, const float* dR, float* dX, float* dgamma, float* dbeta, void* stream);
+
+/* the same with precision 3 (W = scaled fp16 planes, a_amax / w_amax = the operand scalars, see se_gemm_desc) and/or
+ * out_amax (may be NULL): raised to max |dX| */
+int se_gemm_ln_bwd_f16(const float* A, const float* W, int w_planes, long M, int K, const float* X, const float* stats,
+                       const float* gamma, const float* dR, float* dX, float* dgamma, float* dbeta, int precision,
+                       const float* a_amax, const float* w_amax, float* out_amax, void* stream);
 
 /* weight gradient: dW[n][tap*C + c] += alpha * sum_m dY[m][n] * pro(A[src(m,tap)][c]) (alpha = d->alpha: the factor of a
  * Scale(0.5, .) wrapper goes straight into the gradient buffer);  dW must be initialised by the caller (fp32 atomics across
@@ -196,6 +227,10 @@ int se_layernorm_fwd_stats(const float* X, const float* g, const float* b, const
 int se_layernorm_bwd(const float* X, const float* stats, const float* g, const float* dY,
                      const float* dR, const float* dR2, float* dX, float* dg, float* db, long M, int C,
                      void* stream);
+/* the same; amax_out (may be NULL): zero / running maximum on entry, raised to max |dX| (operand scale of the scaled split-fp16
+ * kernels that read dX next) */
+int se_layernorm_bwd_amax(const float* X, const float* stats, const float* g, const float* dY, const float* dR,
+                          const float* dR2, float* dX, float* dg, float* db, long M, int C, float* amax_out, void* stream);
 /* stats[b][c][2] += (sum, sumsq) over the P pixels of batch b (fp64 atomics; caller zeroes).  Feeds
  * nn.InstanceNorm2d (generator.py:21,40,46,101,120; discriminator.py:40-49) and nn.BatchNorm1d
  * (conformer.py:167) when the producer kernel did not already emit them. */
@@ -311,6 +346,7 @@ int se_mask_tail_bwd(const float* U, int ldu, const float* wb, const float* slop
                      double* dwb, float* dslope, long n, int F, void* stream);
 /* GLU backward (models/conformer.py:30-37) */
 int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, int H, void* stream);
+int se_glu_bwd_amax(const float* Z, const float* dU, float* dZ, long M, int H, float* amax_out, void* stream);   /* + max |dZ| */
 /* loss reductions of train_gan (core/function.py:251-258) and their gradient seeds (`up` = device scalars) */
 int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream);
 int se_spec_loss_bwd(const float* A, const float* Bp, float* dA, const float* up, float cmag, float cri, long n,

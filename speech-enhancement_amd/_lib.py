@@ -29,6 +29,12 @@ class GemmDesc(C.Structure):
                 ('w_amax', C.c_void_p)]
 
 
+class F16Scales(C.Structure):
+    """se_f16_scales (include/se_hip.h): operand scales of the token-wise scaled split-fp16 kernels (precision 3)"""
+    _fields_ = [('in_amax', C.c_void_p), ('in_sexp', C.c_int), ('mid_sexp', C.c_int), ('wa_amax', C.c_void_p),
+                ('wb_amax', C.c_void_p), ('out_amax', C.c_void_p), ('mid_amax', C.c_void_p)]
+
+
 class SeHipError(RuntimeError):
     pass
 

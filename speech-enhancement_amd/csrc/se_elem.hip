@@ -223,10 +223,11 @@ __global__ __launch_bounds__(256) void mask_tail_bwd_kernel(const float* __restr
 
 // GLU backward (models/conformer.py:30-37): Z = [a | g] (2H), dU (H) -> dZ
 __global__ void glu_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dU, float* __restrict__ dZ,
-                               long M, int H) {
+                               long M, int H, float* amax_out) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of H per thread
   int hq = H >> 2;
-  if (idx >= M * hq) return;
+  const bool live = idx < M * hq;
+  if (!live) idx = M * hq - 1;           // (no early return: the wave-wide maximum below needs every lane)
   long row = idx / hq;
   int q = (int)(idx - row * hq);
   float4 a = *reinterpret_cast<const float4*>(Z + row * 2 * H + q * 4);
@@ -239,8 +240,17 @@ __global__ void glu_bwd_kernel(const float* __restrict__ Z, const float* __restr
     da[j] = dv[j] * s;
     dg[j] = dv[j] * av[j] * s * (1.f - s);
   }
-  *reinterpret_cast<float4*>(dZ + row * 2 * H + q * 4) = make_float4(da[0], da[1], da[2], da[3]);
-  *reinterpret_cast<float4*>(dZ + row * 2 * H + H + q * 4) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+  if (live) {
+    *reinterpret_cast<float4*>(dZ + row * 2 * H + q * 4) = make_float4(da[0], da[1], da[2], da[3]);
+    *reinterpret_cast<float4*>(dZ + row * 2 * H + H + q * 4) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+  }
+  if (amax_out) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m = fmaxf(m, fmaxf(fabsf(da[j]), fabsf(dg[j])));
+    m = wave_max(live ? m : 0.f);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(m));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,8 +528,11 @@ extern "C" int se_mask_tail_bwd(const float* U, int ldu, const float* wb, const 
   return se_check_launch("se_mask_tail_bwd");
 }
 extern "C" int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, int H, void* stream) {
+  return se_glu_bwd_amax(Z, dU, dZ, M, H, nullptr, stream);
+}
+extern "C" int se_glu_bwd_amax(const float* Z, const float* dU, float* dZ, long M, int H, float* amax_out, void* stream) {
   SE_REQUIRE(Z && dU && dZ && M > 0 && H > 0 && (H % 4) == 0, "glu_bwd: bad arguments");
-  EW_LAUNCH(glu_bwd_kernel, M * (H / 4), stream, Z, dU, dZ, M, H);
+  EW_LAUNCH(glu_bwd_kernel, M * (H / 4), stream, Z, dU, dZ, M, H, amax_out);
   return se_check_launch("se_glu_bwd");
 }
 extern "C" int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream) {

@@ -13,6 +13,7 @@ struct FfArgs {
   const float* W1; const float* b1; const float* W2; const float* b2;
   float* H; float* Y; long M; int hid; float drop_p; unsigned seed_h, seed_o; float alpha;
   float* out_stats;      // optional [M][2]: (mean, rstd) of the rows of Y (the next LayerNorm's statistics)
+  se_f16_scales sc;      // F16 kernels only (precision 3)
 };
 
 // WPL: W1 / W2 arrive pre-split (se_weight_prep: three bf16 planes each, 64 * hid elements apart): the weight blocks are
@@ -21,8 +22,13 @@ struct FfArgs {
 // the sweep is straight-line code: at the head of a LOOP the wait-count pass has to merge the entry state (weight loads only)
 // with the back edge (weight loads, then the H stores) and falls back to vmcnt(0) -- every block then waits for the write
 // acknowledgements of the previous block's H stores.  Unrolled, the wait for the weights is vmcnt(#stores issued after them).
-template <int NPL, bool WPL = false, int NB = 0>
+// F16 (precision 3): scaled split-fp16, two planes, three MFMAs per product (se_gemm_dev.h); needs WPL (se_weight_prep fmt 1
+// planes and their amax scalars).  LN(X) is scaled by 2^in_sexp (a LayerNorm output is bounded by 7.94 |gamma| + |beta|), the
+// activated hidden block by 2^mid_sexp; H (when stored) and Y are un-scaled exactly.  H == nullptr: H is not stored (the
+// recomputing backward does not read it).
+template <int NPL, bool WPL = false, int NB = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 workgroups per CU: VGPR + AGPR <= 256
+  static_assert(!F16 || (WPL && NPL == 2), "the scaled split-fp16 kernels read pre-split fp16 planes");
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
   __shared__ __attribute__((aligned(16))) __bf16 W1p[NPL * PB];
   __shared__ __attribute__((aligned(16))) __bf16 W2p[NPL * PB];
@@ -38,6 +44,13 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
   const unsigned thr = drop_thr(a.drop_p);
   const float inv_keep = drop_inv_keep(a.drop_p);
   const bool dr = a.drop_p > 0.f;
+  float s_in = 1.f, s_mid = 1.f, u1 = 1.f, u2 = 1.f;
+  if (F16) {
+    f16_clamp_mode_();
+    const int e1 = operand_sexp_(a.sc.wa_amax, 0), e2 = operand_sexp_(a.sc.wb_amax, 0);
+    s_in = exp2i_(a.sc.in_sexp); s_mid = exp2i_(a.sc.mid_sexp);
+    u1 = exp2i_(-a.sc.in_sexp - e1); u2 = exp2i_(-a.sc.mid_sexp - e2);
+  }
 
   bf16x8 af1[4][NPL];
   {
@@ -69,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
         x[4 * h + 2] = rok ? (w.z - mean) * rstd * gm.z + bt.z : 0.f;
         x[4 * h + 3] = rok ? (w.w - mean) * rstd * gm.w + bt.w : 0.f;
       }
-      split_planes8<NPL>(x, af1[ks]);
+      if constexpr (F16) split_planes8_h(x, s_in, af1[ks]); else split_planes8<NPL>(x, af1[ks]);
     }
   }
   const int kq = tid & 15, r0 = tid >> 4;
@@ -148,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
       for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
         for (int qa = 0; qa <= ord; ++qa) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+          acc0 = mfma32_<F16>(af1[ks][qa], bf0[ord - qa], acc0);
+          acc1 = mfma32_<F16>(af1[ks][qa], bf1[ord - qa], acc1);
         }
     }
     const float bb0 = b1s[col], bb1 = b1s[32 + col];
@@ -159,13 +172,15 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-        cs[rl * SP + col] = nt ? acc1[r] + bb1 : acc0[r] + bb0;
+        cs[rl * SP + col] = F16 ? (nt ? acc1[r] * u1 + bb1 : acc0[r] * u1 + bb0) : (nt ? acc1[r] + bb1 : acc0[r] + bb0);
       }
+      if (a.H != nullptr) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rl = rr + 8 * i;
-        buf_store4_(Hrs, (unsigned)(((wave * 32 + rl) * a.hid + jb * 64 + nt * 32 + cq * 4) * 4),
-                    *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]));
+        for (int i = 0; i < 4; ++i) {
+          const int rl = rr + 8 * i;
+          buf_store4_(Hrs, (unsigned)(((wave * 32 + rl) * a.hid + jb * 64 + nt * 32 + cq * 4) * 4),
+                      *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]));
+        }
       }
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
           x[4 * h + 2] = swishf_(pv.z) * sc.z; x[4 * h + 3] = swishf_(pv.w) * sc.w;
         }
         bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
-        split_planes8<NPL>(x, af2);
+        if constexpr (F16) split_planes8_h(x, s_mid, af2); else split_planes8<NPL>(x, af2);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
           bf0[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + frag + 16 * ks]);
@@ -191,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
         for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
           for (int qa = 0; qa <= ord; ++qa) {
-            y0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf0[ord - qa], y0, 0, 0, 0);
-            y1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf1[ord - qa], y1, 0, 0, 0);
+            y0 = mfma32_<F16>(af2[qa], bf0[ord - qa], y0);
+            y1 = mfma32_<F16>(af2[qa], bf1[ord - qa], y1);
           }
       }
     }
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-      cs[rl * SP + col] = nt ? y1[r] : y0[r];
+      cs[rl * SP + col] = (nt ? y1[r] : y0[r]) * u2;
     }
     const int n = nt * 32 + cq * 4;
     const float4 b2v = *reinterpret_cast<const float4*>(a.b2 + n);
@@ -266,12 +281,18 @@ struct FfBwdArgs {
   // optional fused LayerNorm backward (X != nullptr): dX = dY + dR2 + LNbwd(dLN) is written instead of dLN, and the
   // gamma / beta gradients are accumulated (one atomic per channel per workgroup)
   const float* X; const float* stats; const float* gamma; const float* dR2; float* dX; float* dgamma; float* dbeta;
+  se_f16_scales sc;      // F16 kernels only (precision 3)
 };
 
 // NB as in ff_fwd_kernel (straight-line sweep: exact wait counts).  No predicated global access anywhere: rows past M are clamped
 // (loads) or dropped by the range check of a buffer descriptor (H loads, dZ / dX / dLN stores).
-template <int NPL, bool WPL = false, int NB = 0>
+// F16 (precision 3): dY is scaled by its measured maximum (sc.in_amax, raised by the kernel that produced dY); dZ, formed in
+// registers, by a BOUND of its maximum: |dZ| <= amax(dY) * inv_keep^2 * 64 amax(W2s) * 1.1 (64 terms, |Swish'| < 1.1) -- a few
+// binades loose, well inside the 17 binades of full precision below an operand's maximum.  The kernel raises sc.out_amax /
+// sc.mid_amax to max |dX| / max |dZ| (one atomic per wave) for the scaled kernels that read those tensors next.
+template <int NPL, bool WPL = false, int NB = 0, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
+  static_assert(!F16 || (WPL && NPL == 2), "the scaled split-fp16 kernels read pre-split fp16 planes");
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
   __shared__ __attribute__((aligned(16))) __bf16 Wa[NPL * PB];         // W2T block: rows = hidden units, k = channel
   __shared__ __attribute__((aligned(16))) __bf16 Wb[NPL * PB];         // W1T block: rows = channel, k = hidden units
@@ -285,6 +306,16 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
   const unsigned thr = drop_thr(a.drop_p);
   const float inv_keep = drop_inv_keep(a.drop_p);
   const bool dr = a.drop_p > 0.f;
+  float s_dy = 1.f, s_dz = 1.f, u1 = 1.f, u2 = 1.f, xmax = 0.f;
+  unsigned zmh = 0u;                           // packed fp16 pair: running max of |hi(dZ * s_dz)|
+  if (F16) {
+    f16_clamp_mode_();
+    const float dy_amax = a.sc.in_amax ? __builtin_nontemporal_load(a.sc.in_amax) : exp2i_(13 - a.sc.in_sexp);
+    const float wa_amax = __builtin_nontemporal_load(a.sc.wa_amax);
+    const int e_dy = f16_sexp_(dy_amax), e_wa = f16_sexp_(wa_amax), e_wb = operand_sexp_(a.sc.wb_amax, 0);
+    const int e_dz = f16_sexp_(dy_amax * inv_keep * inv_keep * 64.f * wa_amax * 1.1f);
+    s_dy = exp2i_(e_dy); s_dz = exp2i_(e_dz); u1 = exp2i_(-e_dy - e_wa); u2 = exp2i_(-e_dz - e_wb);
+  }
 
   bf16x8 af1[4][NPL];
   {
@@ -308,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
         }
         x[4 * h] = rok ? w.x : 0.f; x[4 * h + 1] = rok ? w.y : 0.f; x[4 * h + 2] = rok ? w.z : 0.f; x[4 * h + 3] = rok ? w.w : 0.f;
       }
-      split_planes8<NPL>(x, af1[ks]);
+      if constexpr (F16) split_planes8_h(x, s_dy, af1[ks]); else split_planes8<NPL>(x, af1[ks]);
     }
   }
   const int kq = tid & 15, r0 = tid >> 4;
@@ -382,8 +413,8 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
       for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
         for (int qa = 0; qa <= ord; ++qa) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+          acc0 = mfma32_<F16>(af1[ks][qa], bf0[ord - qa], acc0);
+          acc1 = mfma32_<F16>(af1[ks][qa], bf1[ord - qa], acc1);
         }
     }
 #pragma unroll
@@ -391,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-        cs[rl * SP + col] = nt ? acc1[r] : acc0[r];
+        cs[rl * SP + col] = (nt ? acc1[r] : acc0[r]) * u1;
       }
       // dZ in the row-major lane layout: coalesced H / dZ accesses; the result goes back into the patch in place
 #pragma unroll
@@ -420,7 +451,10 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
           x[4 * h] = pv.x; x[4 * h + 1] = pv.y; x[4 * h + 2] = pv.z; x[4 * h + 3] = pv.w;
         }
         bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
-        split_planes8<NPL>(x, af2);
+        if constexpr (F16) {
+          split_planes8_h(x, s_dz, af2);
+          zmh = pk_absmax_f16_(zmh, af2[0]);        // running max |hi plane| (packed fp16): max |dZ| to 2^-11 relative
+        } else split_planes8<NPL>(x, af2);
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
           bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + frag + 16 * ks]);
@@ -430,8 +464,8 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
         for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
           for (int qa = 0; qa <= ord; ++qa) {
-            g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf0[ord - qa], g0, 0, 0, 0);
-            g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2[qa], bf1[ord - qa], g1, 0, 0, 0);
+            g0 = mfma32_<F16>(af2[qa], bf0[ord - qa], g0);
+            g1 = mfma32_<F16>(af2[qa], bf1[ord - qa], g1);
           }
       }
     }
@@ -443,10 +477,16 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-      cs[rl * SP + col] = nt ? g1[r] : g0[r];
+      cs[rl * SP + col] = (nt ? g1[r] : g0[r]) * u2;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) gv[nt][i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * SP + cq * 4]);
+  }
+  if (F16 && a.sc.mid_amax) {
+    const f16x2_ zp = __builtin_bit_cast(f16x2_, zmh);
+    // (1 + 2^-10): hi is dZ rounded to 11 bits -- the recorded maximum must not be below the true one
+    const float zmax = wave_max(fmaxf((float)zp[0], (float)zp[1])) * (1.f + 0x1p-10f) / s_dz;
+    if (lane == 0 && zmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.sc.mid_amax), __float_as_uint(zmax));
   }
   if (a.X == nullptr) {
 #pragma unroll
@@ -511,7 +551,12 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
       buf_store4_(Xrs, (unsigned)(((wave * 32 + rr + 8 * i) * 64 + nt * 32 + cq * 4) * 4), make_float4(o4[0], o4[1], o4[2], o4[3]));
+      if (F16 && ok) xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
     }
+  }
+  if (F16 && a.sc.out_amax) {
+    xmax = wave_max(xmax);
+    if (lane == 0 && xmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.sc.out_amax), __float_as_uint(xmax));
   }
   // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
   float* redg = reinterpret_cast<float*>(Wa);         // [4 waves][64 channels][2]; the weight planes are free now
@@ -538,19 +583,30 @@ extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T
                                long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision,
                                const float* X, const float* stats, const float* gamma, const float* dR2, float* dX,
                                float* dgamma, float* dbeta, void* stream) {
+  return se_ff_bwd_dgrad_f16(dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, precision, X, stats, gamma, dR2, dX, dgamma,
+                             dbeta, nullptr, stream);
+}
+
+extern "C" int se_ff_bwd_dgrad_f16(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN,
+                                   long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision,
+                                   const float* X, const float* stats, const float* gamma, const float* dR2, float* dX,
+                                   float* dgamma, float* dbeta, const se_f16_scales* sc, void* stream) {
   SE_REQUIRE(dY && H && W2T && W1T && dZ, "ff_bwd_dgrad: null operand");
   SE_REQUIRE(X ? (stats && gamma && dX && dgamma && dbeta) : dLN != nullptr,
              "ff_bwd_dgrad: either dLN, or all of X / stats / gamma / dX / dgamma / dbeta (fused LayerNorm backward)");
   SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_bwd_dgrad: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
   const bool wpl = (precision & 16) != 0;
   precision &= 15;
-  SE_REQUIRE(precision == 1 || precision == 2, "ff_bwd_dgrad: precision must be 1 (bf16x3) or 2 (bf16x6)");
-  SE_REQUIRE(!wpl || (precision == 2 && (((size_t)W2T | (size_t)W1T) & 15) == 0), "ff_bwd_dgrad: pre-split weights need precision 2 and 16-byte alignment");
+  SE_REQUIRE(precision >= 1 && precision <= 3, "ff_bwd_dgrad: precision must be 1 (bf16x3), 2 (bf16x6) or 3 (scaled fp16x3)");
+  SE_REQUIRE(!wpl || (precision >= 2 && (((size_t)W2T | (size_t)W1T) & 15) == 0), "ff_bwd_dgrad: pre-split weights need precision 2 / 3 and 16-byte alignment");
+  SE_REQUIRE(precision != 3 || (wpl && sc && sc->wa_amax && sc->wb_amax && hid == 256),
+             "ff_bwd_dgrad: precision 3 needs pre-split fp16 planes with their amax scalars (sc) and hid == 256");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_bwd_dgrad: drop_p=%f out of range", drop_p);
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_bwd_dgrad: dropout index exceeds 32 bits");
-  FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, X, stats, gamma, dR2, dX, dgamma, dbeta};
+  FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, X, stats, gamma, dR2, dX, dgamma, dbeta, sc ? *sc : se_f16_scales{}};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
-  if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  if (precision == 3) hipLaunchKernelGGL((ff_bwd_kernel<2, true, 4, true>), grid, block, 0, as_stream(stream), a);
+  else if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
   else if (wpl && hid == 256) hipLaunchKernelGGL((ff_bwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);
   else if (wpl) hipLaunchKernelGGL((ff_bwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL(ff_bwd_kernel<3>, grid, block, 0, as_stream(stream), a);
@@ -567,17 +623,28 @@ extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gam
 extern "C" int se_ff_fwd_stats(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
                                const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M,
                                int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
-  SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && H && Y, "ff_fwd: null operand");
+  return se_ff_fwd_f16(X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, out_stats, M, hid, drop_p, seed_h, seed_o, alpha, precision,
+                       nullptr, stream);
+}
+
+extern "C" int se_ff_fwd_f16(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
+                             const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M,
+                             int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision,
+                             const se_f16_scales* sc, void* stream) {
+  SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && Y && (H || (precision & 15) == 3), "ff_fwd: null operand");
   SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_fwd: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
   const bool wpl = (precision & 16) != 0;
   precision &= 15;
-  SE_REQUIRE(precision == 1 || precision == 2, "ff_fwd: precision must be 1 (bf16x3) or 2 (bf16x6)");
-  SE_REQUIRE(!wpl || (precision == 2 && (((size_t)W1 | (size_t)W2) & 15) == 0), "ff_fwd: pre-split weights need precision 2 and 16-byte alignment");
+  SE_REQUIRE(precision >= 1 && precision <= 3, "ff_fwd: precision must be 1 (bf16x3), 2 (bf16x6) or 3 (scaled fp16x3)");
+  SE_REQUIRE(!wpl || (precision >= 2 && (((size_t)W1 | (size_t)W2) & 15) == 0), "ff_fwd: pre-split weights need precision 2 / 3 and 16-byte alignment");
+  SE_REQUIRE(precision != 3 || (wpl && sc && sc->wa_amax && sc->wb_amax && hid == 256),
+             "ff_fwd: precision 3 needs pre-split fp16 planes with their amax scalars (sc) and hid == 256");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_fwd: drop_p=%f out of range", drop_p);
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_fwd: dropout index exceeds 32 bits");
-  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats};
+  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats, sc ? *sc : se_f16_scales{}};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
-  if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
+  if (precision == 3) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true>), grid, block, 0, as_stream(stream), a);
+  else if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
   else if (wpl && hid == 256) hipLaunchKernelGGL((ff_fwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);
   else if (wpl) hipLaunchKernelGGL((ff_fwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
   else hipLaunchKernelGGL(ff_fwd_kernel<3>, grid, block, 0, as_stream(stream), a);

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 // on the full model) -- while the three bf16 MFMAs cost 3/16 of the one fp32 MFMA they replace.
 // LNB: the LayerNorm-backward epilogue of se_gemm_ln_bwd (its own instantiation: its operands are prefetched across the K loop,
 // 72 VGPRs the ordinary GEMMs must not pay)
-template <int PRO, int NPL, bool LIN, bool WPL = false, bool LNB = false>
+// F16 (precision 3): scaled split-fp16, NPL = 2 (se_gemm_dev.h); the accumulators are un-scaled before the epilogue.
+template <int PRO, int NPL, bool LIN, bool WPL = false, bool LNB = false, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 64, BK = 32, SA = 40;     // rows of 32 bf16 + 8 pad = 80 B: conflict-free b128 reads
   constexpr int KQ = BK / 4, RPP = 256 / KQ, NA = BM / RPP, NB = BN / RPP;
@@ -239,6 +240,12 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   float4 ps4 = make_float4(0.f, 0.f, 0.f, 0.f), pb4 = ps4;
   const unsigned thr = drop_thr(d.drop_p);
   const float inv_keep = drop_inv_keep(d.drop_p);
+  float sa = 1.f, sw = 1.f, unscale = 1.f;
+  if (F16) {
+    f16_clamp_mode_();
+    const int ea = operand_sexp_(d.a_amax, d.a_sexp), ew = operand_sexp_(d.w_amax, d.w_sexp);
+    sa = exp2i_(ea); sw = exp2i_(ew); unscale = exp2i_(-ea - ew);
+  }
 
   auto load_tiles = [&](int it) {
     int chunk = lin ? it : it / d.ntap;  // channel chunk outer, tap inner: the taps of one chunk re-touch the same
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
       float4 v = ra[i];
       if (PRO != SE_PRO_NONE && aok[i])
         v = apply_pro<PRO>(v, cur_c, d.C, ln_mean[i], ln_rstd[i], ps4, pb4, apix[i], d.pro_seed, thr, inv_keep);
-      split_store<NPL>(v, &Ap[(r0 + i * RPP) * SA + kq * 4], PA);
+      split_store_x<NPL, F16>(v, sa, &Ap[(r0 + i * RPP) * SA + kq * 4], PA);
     }
     if (WPL) {
 #pragma unroll
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
     } else {
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        split_store<NPL>(rb[i], &Bp[(r0 + i * RPP) * SA + kq * 4], PB);
+        split_store_x<NPL, F16>(rb[i], sw, &Bp[(r0 + i * RPP) * SA + kq * 4], PB);
     }
     __syncthreads();
     if (it + 1 < NI) load_tiles(it + 1);
@@ -314,11 +321,15 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int qa = 0; qa <= ord; ++qa) {
           const int qb = ord - qa;
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf0[qb], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[qa], bf1[qb], acc1, 0, 0, 0);
+          acc0 = mfma32_<F16>(af[qa], bf0[qb], acc0);
+          acc1 = mfma32_<F16>(af[qa], bf1[qb], acc1);
         }
     }
     __syncthreads();
+  }
+  if (F16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;        // the staging planes are free now
   if (LNB) { gemm_epilogue_ln_bwd(g, acc0, acc1, m0, cs, 36, red, lnpre); return; }
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     //
 // 64 MFMAs.  Here one workgroup owns 128 rows and sweeps ALL column blocks: each wave loads its 32 rows straight into
 // the MFMA A-fragment layout (lane = row, 8 consecutive k), applies the prologue and the bf16 split ONCE and keeps the
 // fragments in 16 * NPL VGPRs; only the 64 x 64 weight blocks stream through LDS (next block prefetched in registers).
-template <int PRO, int NPL, bool PRE2, bool WPL = false>
+template <int PRO, int NPL, bool PRE2, bool WPL = false, bool F16 = false>
 __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   constexpr int SB = 72, PB = 64 * SB;         // 64 + 8 bf16 per W row: 144-B stride, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
@@ -527,6 +538,12 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
   const unsigned thr = drop_thr(d.drop_p);
   const float inv_keep = drop_inv_keep(d.drop_p);
 
+  float sa = 1.f, unscale = 1.f;
+  if (F16) {      // scaled split-fp16 (precision 3): pre-split fp16 weight planes (WPL), A scaled by its measured / static maximum
+    f16_clamp_mode_();
+    const int ea = operand_sexp_(d.a_amax, d.a_sexp), ew = operand_sexp_(d.w_amax, d.w_sexp);
+    sa = exp2i_(ea); unscale = exp2i_(-ea - ew);
+  }
   // ---- A fragments: row = lane & 31 of this wave's 32 rows, k = 16 ks + 8 (lane >> 5) .. + 7
   const int row = m0 + wave * 32 + (lane & 31), kg = lane >> 5;
   const bool rok = row < Mb;
@@ -567,7 +584,7 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
         }
         x[4 * h] = rok ? w.x : 0.f; x[4 * h + 1] = rok ? w.y : 0.f; x[4 * h + 2] = rok ? w.z : 0.f; x[4 * h + 3] = rok ? w.w : 0.f;
       }
-      split_planes8<NPL>(x, af[ks]);
+      if constexpr (F16) split_planes8_h(x, sa, af[ks]); else split_planes8<NPL>(x, af[ks]);
     }
   }
   // ---- W blocks: 64 rows x 64 k, 4 float4 per thread
@@ -646,9 +663,13 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
       for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
         for (int qa = 0; qa <= ord; ++qa) {
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][qa], bf0[ord - qa], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][qa], bf1[ord - qa], acc1, 0, 0, 0);
+          acc0 = mfma32_<F16>(af[ks][qa], bf0[ord - qa], acc0);
+          acc1 = mfma32_<F16>(af[ks][qa], bf1[ord - qa], acc1);
         }
+    }
+    if (F16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
     }
     if (vec_ep) gemm_epilogue_vec<PRE2>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, red, bias_s, pre);
     else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, 0, cs, 36);
@@ -708,9 +729,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
   if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");
   if (d->precision == 3)
-    SE_REQUIRE(d->C >= 32 && d->prologue == SE_PRO_NONE && !d->up && d->st == 1 && d->sf == 1 && d->Ti == d->To && d->Fi == d->Fo &&
-               d->ntap >= 3 && d->ntap % 3 == 0 && !(ep & (SE_EPI_GLU | SE_EPI_DROP)) && d->Fo >= 2 && (!d->w_planes || d->w_amax),
-               "gemm: precision 3 (scaled split-fp16) is built for the triple-tap convolutions; pre-split planes need w_amax");
+    SE_REQUIRE(d->C >= 32 && (!d->w_planes || d->w_amax), "gemm: precision 3 (scaled split-fp16) needs C >= 32; pre-split planes need w_amax");
   if (d->w_planes) {      // W = three bf16 planes (se_weight_prep): only the six-product split kernels read them
     SE_REQUIRE((d->precision == 2 || d->precision == 3) && d->C >= 32 && (d->C % 8) == 0 && (d->ldw % 8) == 0 && d->w_planes >= (long)d->N * d->ldw &&
                (d->w_planes % 8) == 0 && ((size_t)W & 15) == 0,
@@ -736,11 +755,13 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                                                        SE_EPI_SWISH_GRAD | 256)) &&
                         (d->N & 7) == 0 && (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldx & 3) == 0 && (d->x_off & 3) == 0;
     static const bool no_panel = getenv("SE_GEMM_NO_PANEL") != nullptr;
-    if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && (d->precision == 1 || d->precision == 2) && (vec_ok || glu_ok) &&
+    if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && (d->precision >= 1 && d->precision <= 3) && (vec_ok || glu_ok) &&
         !(ep & SE_EPI_ACCUM) && !((ep & SE_EPI_SWISH_GRAD) && (ep & SE_EPI_RESID)) && !no_panel) {
       dim3 pgrid(g.tiles);
+      SE_REQUIRE(d->precision != 3 || d->w_planes, "gemm: the scaled split-fp16 row-panel kernel reads pre-split fp16 planes");
       const bool pre2 = (ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) != 0;
-#define LAUNCHP2(PRO, P2) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2>), pgrid, block, 0, s, g); \
+#define LAUNCHP2(PRO, P2) do { if (d->precision == 3) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2, true, true>), pgrid, block, 0, s, g); \
+                          else if (d->precision == 1) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2>), pgrid, block, 0, s, g); \
                           else if (d->w_planes) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3, P2, true>), pgrid, block, 0, s, g); \
                           else hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3, P2>), pgrid, block, 0, s, g); } while (0)
 #define LAUNCHP(PRO) do { if (pre2) LAUNCHP2(PRO, true); else LAUNCHP2(PRO, false); } while (0)
@@ -781,6 +802,13 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       else hipLaunchKernelGGL((conv3_bf16_kernel<3>), grid, block, 0, s, g);
       return se_check_launch("se_gemm_tap(conv3)");
     }
+  }
+  if (d->precision == 3) {        // scaled split-fp16, generic tap kernel: prologue-free shapes with pre-split planes
+    SE_REQUIRE(d->prologue == SE_PRO_NONE && d->w_planes, "gemm: precision 3 outside the triple-tap / K = 64 row-panel kernels needs "
+               "no prologue and pre-split fp16 planes");
+    if (lin) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 2, true, true, false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 2, false, true, false, true>), grid, block, 0, s, g);
+    return se_check_launch("se_gemm_tap(f16x3)");
   }
   if ((d->precision == 1 || d->precision == 2) && d->C >= 32) {      // split-bf16 paths (BK = 32 only)
 #define LAUNCHB2(PRO, LIN_) do { if (d->precision == 1) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<PRO, 2, LIN_>), grid, block, 0, s, g); \
@@ -823,12 +851,21 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
 // LayerNorm's backward (se_layernorm_bwd with dY = A W^T, which never goes to memory).  Split-bf16 row GEMM (six products).
 extern "C" int se_gemm_ln_bwd(const float* A, const float* W, int w_planes, long M, int K, const float* X, const float* stats,
                               const float* gamma, const float* dR, float* dX, float* dgamma, float* dbeta, void* stream) {
+  return se_gemm_ln_bwd_f16(A, W, w_planes, M, K, X, stats, gamma, dR, dX, dgamma, dbeta, 2, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int se_gemm_ln_bwd_f16(const float* A, const float* W, int w_planes, long M, int K, const float* X, const float* stats,
+                                  const float* gamma, const float* dR, float* dX, float* dgamma, float* dbeta, int precision,
+                                  const float* a_amax, const float* w_amax, float* out_amax, void* stream) {
   SE_REQUIRE(A && W && X && stats && gamma && dX && dgamma && dbeta, "gemm_ln_bwd: null operand");
+  SE_REQUIRE(precision == 2 || (precision == 3 && w_planes && a_amax && w_amax),
+             "gemm_ln_bwd: precision 2, or 3 with pre-split fp16 planes and the operand amax scalars");
   SE_REQUIRE(M > 0 && M < 2147483647L && K >= 32 && (K % 8) == 0, "gemm_ln_bwd: M=%ld K=%d (K must be a multiple of 8, >= 32)", M, K);
   se_gemm_desc d{};
   d.B = 1; d.To = 1; d.Fo = (int)M; d.Ti = 1; d.Fi = (int)M; d.st = 1; d.sf = 1; d.ntap = 1;
   d.C = K; d.lda = K; d.N = 64; d.ldc = 64; d.ldw = K; d.ldr = 64; d.ldx = 64;
-  d.epilogue = SE_EPI_LN_BWD_; d.alpha = 1.f; d.precision = 2; d.w_planes = w_planes;
+  d.epilogue = SE_EPI_LN_BWD_; d.alpha = 1.f; d.precision = precision; d.w_planes = w_planes;
+  d.a_amax = a_amax; d.w_amax = w_amax;
   if (int e = check_desc(&d)) return e;
   if (w_planes) SE_REQUIRE(w_planes >= 64 * K && (w_planes % 8) == 0 && ((size_t)W & 15) == 0, "gemm_ln_bwd: bad weight planes");
   GemmArgs g{d, A, W, nullptr, dX, dR, const_cast<float*>(X), stats, gamma, nullptr, nullptr, dgamma, dbeta, 0, 0, 0, 0};
@@ -837,7 +874,9 @@ extern "C" int se_gemm_ln_bwd(const float* A, const float* W, int w_planes, long
   g.nouter = g.tiles;
   g.contig = 0;
   dim3 grid((unsigned)(((long)g.nouter + 7) / 8 * 8)), block(256);
-  if (w_planes) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, true, true>), grid, block, 0, as_stream(stream), g);
+  g.amax_out = out_amax;
+  if (precision == 3) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 2, true, true, true, true>), grid, block, 0, as_stream(stream), g);
+  else if (w_planes) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, true, true>), grid, block, 0, as_stream(stream), g);
   else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 3, true, false, true>), grid, block, 0, as_stream(stream), g);
   return se_check_launch("se_gemm_ln_bwd");
 }

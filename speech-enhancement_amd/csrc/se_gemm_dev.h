@@ -15,6 +15,7 @@ struct GemmArgs {
   int nouter;   // B * tiles
   int contig;   // 1: every XCD sweeps a contiguous range of row tiles (tap convolutions: the dt-shifted rows of a
                 //    tile are the dt = 0 rows of a tile the same L2 has just seen); 0: round-robin
+  float* amax_out = nullptr;   // SE_EPI_LN_BWD_: raised to max |dX| (operand scale of the scaled split-fp16 kernels reading dX)
 };
 
 // Workgroups are dispatched round-robin over the 8 XCDs, each with a private L2.  The `ninner` siblings of one
@@ -280,7 +281,7 @@ static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, c
 #pragma unroll
     for (int i = 0; i < 4; ++i) gv[nt][i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * cs_ld + cq * 4]);
   }
-  float ag[2][4] = {}, ab[2][4] = {};
+  float ag[2][4] = {}, ab[2][4] = {}, xmax = 0.f;
   float4 gm[2];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) gm[nt] = *reinterpret_cast<const float4*>(g.ps + nt * 32 + cq * 4);
@@ -316,8 +317,13 @@ static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, c
 #pragma unroll
         for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
         *reinterpret_cast<float4*>(g.Y + off) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
       }
     }
+  }
+  if (g.amax_out) {
+    xmax = wave_max(xmax);
+    if (lane == 0 && xmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(g.amax_out), __float_as_uint(xmax));
   }
   // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
 #pragma unroll
@@ -610,6 +616,14 @@ static __device__ __forceinline__ void split_planes8_h(float (&x)[8], float s, V
   }
   out[0] = __builtin_bit_cast(V8, h);
   out[1] = __builtin_bit_cast(V8, l);
+}
+// running element-wise maximum of |x| over packed fp16 pairs: m (one pair) vs the 8 values of a fragment
+static __device__ __forceinline__ unsigned pk_absmax_f16_(unsigned m, const bf16x8& frag) {
+  const u32x4_ w = __builtin_bit_cast(u32x4_, frag);
+  f16x2_ r = __builtin_bit_cast(f16x2_, m);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r = __builtin_elementwise_max(r, __builtin_bit_cast(f16x2_, w[i] & 0x7fff7fffu));
+  return __builtin_bit_cast(unsigned, r);
 }
 // one 32x32x16 / 16x16x32 MFMA on 16-bit fragments held as bf16x8 bit patterns: bf16 or (F16) fp16 arithmetic
 template <bool F16>

@@ -67,8 +67,10 @@ __global__ __launch_bounds__(256) void layernorm64_bwd_kernel(const float* __res
                                                               const float* __restrict__ g, const float* __restrict__ dY,
                                                               const float* __restrict__ dR, const float* __restrict__ dR2,
                                                               float* __restrict__ dX,
-                                                              float* __restrict__ dg, float* __restrict__ db, long M) {
+                                                              float* __restrict__ dg, float* __restrict__ db, long M,
+                                                              float* amax_out) {
   __shared__ float red[16 * 64 * 2];
+  float amx = 0.f;
   const int q = threadIdx.x & 15, sub = threadIdx.x >> 4;
   const float4 gg = *reinterpret_cast<const float4*>(g + q * 4);
   float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
@@ -102,6 +104,11 @@ __global__ __launch_bounds__(256) void layernorm64_bwd_kernel(const float* __res
       o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
     }
     *reinterpret_cast<float4*>(dX + row * 64 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+  }
+  if (amax_out) {
+    amx = wave_max(amx);
+    if ((threadIdx.x & 63) == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amx));
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { red[(sub * 64 + q * 4 + j) * 2] = ag[j]; red[(sub * 64 + q * 4 + j) * 2 + 1] = ab[j]; }
@@ -441,12 +448,18 @@ extern "C" int se_layernorm_fwd_stats(const float* X, const float* g, const floa
 extern "C" int se_layernorm_bwd(const float* X, const float* stats, const float* g, const float* dY,
                                 const float* dR, const float* dR2, float* dX, float* dg, float* db, long M, int C,
                                 void* stream) {
+  return se_layernorm_bwd_amax(X, stats, g, dY, dR, dR2, dX, dg, db, M, C, nullptr, stream);
+}
+
+extern "C" int se_layernorm_bwd_amax(const float* X, const float* stats, const float* g, const float* dY,
+                                     const float* dR, const float* dR2, float* dX, float* dg, float* db, long M, int C,
+                                     float* amax_out, void* stream) {
   SE_REQUIRE(X && stats && g && dY && dX && dg && db && M > 0, "layernorm_bwd: bad arguments");
   SE_REQUIRE(C == 64, "layernorm_bwd: only C == 64 is built");
   long nb = (M + 15) / 16;
   if (nb > 1024) nb = 1024;
   hipLaunchKernelGGL(layernorm64_bwd_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), X, stats, g, dY, dR, dR2, dX,
-                     dg, db, M);
+                     dg, db, M, amax_out);
   return se_check_launch("se_layernorm_bwd");
 }
 

@@ -814,12 +814,14 @@ static int launch_wgrad_lin(const se_gemm_desc* d, const WgradArgs& g, dim3 grid
 // LDS image: [plane][row octet][column cell][8 rows] bf16 (wide operand: cells swizzled, see swz below -- fragment reads and
 // cell writes both conflict free), 60 KB per workgroup, two workgroups per CU; global loads of the next 32 rows are in flight during the 48 MFMAs.
 // SH = 1: dY wide (N <= 256), X narrow (C <= 64): FF W1, pointwise-GLU conv.  SH = 2: X wide (C <= 256), dY narrow: FF W2.
-template <int PRO, int SH>
+// F16 (precision 3): two planes of scaled fp16 instead of three of bf16 (se_gemm_dev.h), three MFMAs per product: X scaled by
+// 2^sexp(a_amax | a_sexp) after its prologue, dY by 2^sexp(w_amax | w_sexp); the sums are un-scaled where they are added to dW.
+template <int PRO, int SH, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
-  constexpr int MR = 32, WIDE = 256, NARROW = 64;
-  constexpr int WPLN = 4 * WIDE * 8, NPLN = 4 * NARROW * 8;         // bf16 elements per plane
-  __shared__ __attribute__((aligned(16))) __bf16 Ws[3 * WPLN];
-  __shared__ __attribute__((aligned(16))) __bf16 Ns[3 * NPLN];
+  constexpr int MR = 32, WIDE = 256, NARROW = 64, NP = F16 ? 2 : 3;
+  constexpr int WPLN = 4 * WIDE * 8, NPLN = 4 * NARROW * 8;         // 16-bit elements per plane
+  __shared__ __attribute__((aligned(16))) __bf16 Ws[NP * WPLN];
+  __shared__ __attribute__((aligned(16))) __bf16 Ns[NP * NPLN];
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -839,6 +841,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
   const float inv_keep = drop_inv_keep(d.drop_p);
   const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
   const bool do_bias = g.dbias != nullptr;
+  float s_wide = 1.f, s_narrow = 1.f, unscale = 1.f;
+  if (F16) {
+    f16_clamp_mode_();
+    const int ex = operand_sexp_(d.a_amax, d.a_sexp), ey = operand_sexp_(d.w_amax, d.w_sexp);
+    s_wide = exp2i_(SH == 2 ? ex : ey); s_narrow = exp2i_(SH == 2 ? ey : ex); unscale = exp2i_(-ex - ey);
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -904,10 +912,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
         float x[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) x[i] = j == 0 ? v[i].x : (j == 1 ? v[i].y : (j == 2 ? v[i].z : v[i].w));
-        bf16x8 pl[3];
-        split_planes8<3, bf16x8>(x, pl);
+        bf16x8 pl[NP];
+        if constexpr (F16) split_planes8_h(x, s_wide, pl); else split_planes8<3, bf16x8>(x, pl);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(&Ws[q * WPLN + (wave * WIDE + 64 * j + ((lane + 4 * j) & 63)) * 8]) = pl[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x8*>(&Ws[q * WPLN + (wave * WIDE + 64 * j + ((lane + 4 * j) & 63)) * 8]) = pl[q];
       }
     }
     {   // narrow operand: 2 rows x 4 columns per lane -> (row pair) dwords
@@ -916,37 +924,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
       if (XW && do_bias) { bsum.x += v0.x + v1.x; bsum.y += v0.y + v1.y; bsum.z += v0.z + v1.z; bsum.w += v0.w + v1.w; }
       float a4[4] = {v0.x, v0.y, v0.z, v0.w}, b4[4] = {v1.x, v1.y, v1.z, v1.w};
       unsigned* cell = reinterpret_cast<unsigned*>(&Ns[((nrp >> 2) * NARROW + nq) * 8 + 2 * (nrp & 3)]);
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
+      if constexpr (F16) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const unsigned w = pk_bf16_(a4[j], b4[j]);
-          cell[(q * NPLN + j * 8) / 2] = w;
-          if (q < 2) { a4[j] -= __builtin_bit_cast(float, w << 16); b4[j] -= __builtin_bit_cast(float, w & 0xffff0000u); }
+          const float ya = a4[j] * s_narrow, yb = b4[j] * s_narrow;
+          const unsigned w = pk_f16_(ya, yb);
+          const f16x2_ hh = __builtin_bit_cast(f16x2_, w);
+          cell[(j * 8) / 2] = w;
+          cell[(NPLN + j * 8) / 2] = pk_f16_(ya - (float)hh[0], yb - (float)hh[1]);
         }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const unsigned w = pk_bf16_(a4[j], b4[j]);
+            cell[(q * NPLN + j * 8) / 2] = w;
+            if (q < 2) { a4[j] -= __builtin_bit_cast(float, w << 16); b4[j] -= __builtin_bit_cast(float, w & 0xffff0000u); }
+          }
+      }
     }
     __syncthreads();
     if (mb + MR < mend) load_tiles(mb + MR);
     if (active) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 af[2][3], bf[2][3];
+        bf16x8 af[2][NP], bf[2][NP];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
+          for (int q = 0; q < NP; ++q) {
             af[t][q] = *reinterpret_cast<const bf16x8*>(abase + q * APL + 2 * s * AOC + aoff[t]);
             bf[t][q] = *reinterpret_cast<const bf16x8*>(bbase + q * BPL + 2 * s * BOC + boff[t]);
           }
 #pragma unroll
-        for (int ord = 2; ord >= 0; --ord)
+        for (int ord = NP - 1; ord >= 0; --ord)
 #pragma unroll
           for (int qa = 0; qa <= ord; ++qa)
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
               for (int b = 0; b < 2; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][qa], bf[b][ord - qa], acc[a][b], 0, 0, 0);
+                acc[a][b] = mfma32_<F16>(af[a][qa], bf[b][ord - qa], acc[a][b]);
       }
     }
     __syncthreads();
@@ -960,7 +979,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = (wn * 2 + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + c], d.alpha * acc[a][b][r]);
+        if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + c], d.alpha * unscale * acc[a][b][r]);
       }
     }
   if (do_bias) {          // column sums of dY, folded over the lanes that shared a column group
@@ -976,6 +995,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
       atomicAdd(&g.dbias[tid], d.alpha * s_);
     }
   }
+}
+
+template <int SH>
+static int launch_wgrad_lin_f16(const se_gemm_desc* d, const WgradArgs& g, dim3 grid, hipStream_t s) {
+  const dim3 block(256);
+  switch (d->prologue) {
+    case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_NONE, SH, true>), grid, block, 0, s, g); break;
+    case SE_PRO_LN: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_LN, SH, true>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_SWISH, SH, true>), grid, block, 0, s, g); break;
+    case SE_PRO_SWISH_DROP: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_SWISH_DROP, SH, true>), grid, block, 0, s, g); break;
+    default: return se_fail("wgrad: no scaled split-fp16 kernel for prologue %d", d->prologue);
+  }
+  return se_check_launch("se_gemm_tap_wgrad(lin f16x3)");
 }
 
 template <int SH>
@@ -1030,6 +1062,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       return se_check_launch("se_gemm_tap_wgrad(conv3)");
     }
   }
+  const bool want_f16 = d->precision == 3;
   se_gemm_desc dfb;
   if (d->precision == 3) { dfb = *d; dfb.precision = 2; d = &dfb; }      // shapes without a scaled split-fp16 kernel: six-product / fp32 ones
   // token-wise layers (row GEMM, fp32 MFMA, the whole gradient fits one workgroup): every operand row staged once per launch
@@ -1051,6 +1084,8 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       rl = ((rl + 31) / 32) * 32;
       const int nch = (int)((Mtot + rl - 1) / rl);
       WgradArgs gl{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rl, nch};
+      if (want_f16 && (d->prologue == SE_PRO_NONE || d->prologue == SE_PRO_LN || d->prologue == SE_PRO_SWISH || d->prologue == SE_PRO_SWISH_DROP))
+        return shape == 1 ? launch_wgrad_lin_f16<1>(d, gl, dim3((unsigned)nch), s) : launch_wgrad_lin_f16<2>(d, gl, dim3((unsigned)nch), s);
       return shape == 1 ? launch_wgrad_lin_bf16<1>(d, gl, dim3((unsigned)nch), s) : launch_wgrad_lin_bf16<2>(d, gl, dim3((unsigned)nch), s);
     }
     if (shape) {

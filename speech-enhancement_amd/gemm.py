@@ -40,8 +40,14 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
 # per-column-block fp32-MFMA kernel; 'bf16x3' is the opt-in two-way split.  The prologue-free K >= 128 input gradients use
 # the generic split kernel; everything else (prologue GEMMs with K > 64, N = 64 with K = 64, accumulating epilogues, weight
 # gradients) measured faster on the fp32-MFMA kernels and stays there.
-LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'bf16x6')]
-WGRAD_LINEAR_PRECISION = {'f32': 0, 'bf16x6': 2}[__import__('os').environ.get('SE_WGRAD_LINEAR_PRECISION', 'bf16x6')]
+# 'f16x3' (default since round 3) = the SCALED split-fp16 arithmetic of se_gemm_desc precision 3 wherever the operand scales are
+# known (pre-split fp16 weight planes from the step's WeightPlan; LayerNorm outputs with a static exponent; gradients with the
+# maximum their producer measured): fp32-equivalent like bf16x6 at half the MFMAs.  Calls without those scales (plain fp32
+# weights, e.g. direct layer calls in tests) run the six-product kernels.
+LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2, 'f16x3': 3}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'f16x3')]
+WGRAD_LINEAR_PRECISION = {'f32': 0, 'bf16x6': 2, 'f16x3': 3}[__import__('os').environ.get('SE_WGRAD_LINEAR_PRECISION', 'f16x3')]
+LN_SEXP = 6        # LayerNorm(64) outputs: |x| <= 7.94 |gamma| + |beta|; 2^6 keeps |x| < 1023 below the fp16 maximum
+HID_SEXP = 3       # Swish(H) * dropout mask (FF hidden activations): |x| < 8191
 
 
 def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
@@ -49,7 +55,7 @@ def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
     if 'precision' not in kw:
         second_operand = kw.get('epilogue', 0) & L.EPI_ACCUM
         wide_k = C_in >= 128 and kw.get('prologue', L.PRO_NONE) == L.PRO_NONE      # K >= 128 -> 64 input gradients: 146 vs 181 us
-        kw['precision'] = LINEAR_PRECISION if ((C_in == 64 and N >= 128 and not second_operand) or wide_k) else 0
+        kw['precision'] = min(LINEAR_PRECISION, 2) if ((C_in == 64 and N >= 128 and not second_operand) or wide_k) else 0
     return make_desc(1, 1, M, 1, M, [(0, 0)], C_in, lda or C_in, N, ldc or N, **kw)
 
 
@@ -63,6 +69,8 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
     elif W.dtype == torch.float16:       # precision 3: [2 planes][rows][ld] scaled fp16 + the scalar they were scaled by
         if d.precision != 3:
             raise L.SeHipError('gemm_tap: scaled fp16 weight planes need a precision-3 descriptor (operand scales known)')
+        if not d.a_amax and not d.a_sexp:
+            raise L.SeHipError('gemm_tap: precision 3 needs the scale of the A operand (a_amax or a static a_sexp)')
         d.w_planes, d.ldw = W.stride(0), W.shape[2]
         d.w_amax = W._se_amax.data_ptr()
     else:
@@ -72,9 +80,10 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
            _key=(('conv3_f16x3' if d.precision == 3 else f'conv3_bf16x{3 if d.precision == 1 else 6}')
                  if d.precision in (1, 2, 3) and d.C >= 32 and d.prologue == 0 and d.ntap >= 3 and d.ntap % 3 == 0 and not d.up
                  and d.st == 1 and d.sf == 1 and d.Ti == d.To and d.Fi == d.Fo and not d.epilogue & (L.EPI_GLU | L.EPI_DROP) else
-                 f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>'
-                 if d.precision in (1, 2) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1
+                 (f'gemm_k64_panel_f16x3<{d.prologue}>' if d.precision == 3 else f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>')
+                 if d.precision in (1, 2, 3) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1
                  and not d.epilogue & (L.EPI_ACCUM | L.EPI_STATS | L.EPI_SHUFFLE2) else
+                 'gemm_tap_f16x3_kernel<0>' if d.precision == 3 else
                  f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
                  f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>'), _flops=2.0 * M * d.N * d.ntap * d.C,
            _bytes=4.0 * M * (d.C + d.N))
@@ -197,7 +206,8 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
     lin = d.ntap == 1 and d.B == 1 and d.To == 1
     saved = d.precision
     if lin and not explicit_precision:
-        d.precision = WGRAD_LINEAR_PRECISION      # the forward descriptor's choice is about the forward kernel only
+        # the forward descriptor's choice is about the forward kernel only; precision 3 needs the dY scale (w_amax) too
+        d.precision = WGRAD_LINEAR_PRECISION if (WGRAD_LINEAR_PRECISION != 3 or d.w_amax) else 2
     try:
         _wgrad_call(d, A, dY, dW, dbias, rowstats, ps, pb, chunks, Mt)
     finally:
@@ -212,16 +222,24 @@ def _wgrad_call(d, A, dY, dW, dbias, rowstats, ps, pb, chunks, Mt):
     return dW
 
 
-def gemm_ln_bwd(A, WT, x, stats, gamma, dR, dgamma, dbeta):
+def gemm_ln_bwd(A, WT, x, stats, gamma, dR, dgamma, dbeta, out_amax=None):
     """dX = dR + LayerNorm-backward(A @ WT.T) (csrc/se_gemm.hip: se_gemm_ln_bwd): A [M, K], WT [64, K] fp32 or pre-split planes
-    [3, 64, K]; x [M, 64], stats [M, 2], dR [M, 64] or None; dgamma / dbeta [64] accumulated."""
+    [3, 64, K] bf16 / [2, 64, K] scaled fp16 (then A._se_amax = the measured max |A|); x [M, 64], stats [M, 2], dR [M, 64] or
+    None; dgamma / dbeta [64] accumulated; out_amax: optional zero-filled scalar raised to max |dX| (returned as dX._se_amax)."""
     L.check_cuda(A, WT, x, stats, gamma, dR, dgamma, dbeta)
     M, K = A.shape
-    planes = WT.dtype == torch.bfloat16
+    planes = WT.dtype in (torch.bfloat16, torch.float16)
+    f16 = WT.dtype == torch.float16
+    a_amax = getattr(A, '_se_amax', None)
+    if f16 and a_amax is None:
+        raise L.SeHipError('gemm_ln_bwd: scaled fp16 weight planes need the measured maximum of A (A._se_amax)')
     dX = torch.empty(M, 64, device=A.device, dtype=torch.float32)
-    L.call('se_gemm_ln_bwd', L.ptr(A), L.ptr(WT), C.c_int(WT.stride(0) if planes else 0), C.c_long(M), C.c_int(K), L.ptr(x),
-           L.ptr(stats), L.ptr(gamma), L.ptr(dR), L.ptr(dX), L.ptr(dgamma), L.ptr(dbeta), L.stream(),
-           _key='gemm_tap_bf16x6_kernel<0>', _flops=2.0 * M * 64 * K, _bytes=4.0 * M * (K + 192))
+    dX._se_amax = out_amax
+    L.call('se_gemm_ln_bwd_f16', L.ptr(A), L.ptr(WT), C.c_int(WT.stride(0) if planes else 0), C.c_long(M), C.c_int(K), L.ptr(x),
+           L.ptr(stats), L.ptr(gamma), L.ptr(dR), L.ptr(dX), L.ptr(dgamma), L.ptr(dbeta), C.c_int(3 if f16 else 2),
+           L.ptr(a_amax if f16 else None), L.ptr(WT._se_amax if f16 else None), L.ptr(out_amax), L.stream(),
+           _key='gemm_tap_f16x3_kernel<0>' if f16 else 'gemm_tap_bf16x6_kernel<0>', _flops=2.0 * M * 64 * K,
+           _bytes=4.0 * M * (K + 192))
     return dX
 
 
@@ -266,39 +284,52 @@ def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_
     """fused Scale(alpha, PreNorm(FeedForward)) forward (csrc/se_gemm.hip: ff_fwd_kernel): returns (Y, H) with
     H = W1 LN(x) + b1 kept for the backward."""
     L.check_cuda(x, rowstats, gamma, beta, W1, b1, W2, b2)
-    pl = W1.dtype == torch.bfloat16         # pre-split planes [3][hid][64] / [3][64][hid] (weights.WeightPlan)
-    if pl != (W2.dtype == torch.bfloat16):
-        raise L.SeHipError('ff_fwd: W1 and W2 must both be fp32 or both pre-split planes')
+    pl = W1.dtype in (torch.bfloat16, torch.float16)   # pre-split planes [3|2][hid][64] / [3|2][64][hid] (weights.WeightPlan)
+    if W1.dtype != W2.dtype:
+        raise L.SeHipError('ff_fwd: W1 and W2 must both be fp32 or both pre-split planes of one kind')
+    f16 = W1.dtype == torch.float16
     M, hid = x.shape[0], (hid or W1.shape[-2])
     H = torch.empty(M, hid, device=x.device, dtype=torch.float32)
     Y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
-    prec = LINEAR_PRECISION if precision is None else precision
+    prec = (3 if f16 else min(LINEAR_PRECISION, 2)) if precision is None else precision
     ost = torch.empty(M, 2, device=x.device, dtype=torch.float32) if out_stats else None     # (mean, rstd) of the rows of Y
-    L.call('se_ff_fwd_stats', L.ptr(x), L.ptr(rowstats), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
+    sc = L.F16Scales(None, LN_SEXP, HID_SEXP, W1._se_amax.data_ptr(), W2._se_amax.data_ptr(), None, None) if f16 else None
+    L.call('se_ff_fwd_f16', L.ptr(x), L.ptr(rowstats), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
            L.ptr(H), L.ptr(Y), L.ptr(ost), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF),
-           C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec | (16 if pl else 0)), L.stream(),
-           _key=f'ff_fwd_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid, _bytes=4.0 * M * (128 + hid))
+           C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec | (16 if pl else 0)), C.byref(sc) if f16 else None,
+           L.stream(), _key='ff_fwd_f16x3' if f16 else f'ff_fwd_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid,
+           _bytes=4.0 * M * (128 + hid))
     if out_stats:
         return Y, H, ost
     return Y, H
 
 
-def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precision=None, ln=None):
+def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precision=None, ln=None, amax_out=(None, None)):
     """fused dgrad chain of the feed-forward module (ff_bwd_kernel): returns (dZ [M, hid], dLN [M, 64]); with
     ln = (x, rowstats, gamma, dR2 or None, dgamma, dbeta) the LayerNorm backward is applied in the same kernel and the
-    second result is dX = dy + dR2 + LNbwd(dLN)."""
+    second result is dX = dy + dR2 + LNbwd(dLN).  amax_out = (zero-filled scalars for max |dX|, max |dZ|): required with scaled
+    fp16 weight planes (they travel with the results as ._se_amax)."""
     L.check_cuda(dy, H, W2T_scaled, W1T)
     M, hid = H.shape
     dZ = torch.empty(M, hid, device=dy.device, dtype=torch.float32)
     out = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
-    prec = LINEAR_PRECISION if precision is None else precision
-    pl = W2T_scaled.dtype == torch.bfloat16
-    if pl != (W1T.dtype == torch.bfloat16):
-        raise L.SeHipError('ff_bwd_dgrad: W2T and W1T must both be fp32 or both pre-split planes')
+    pl = W2T_scaled.dtype in (torch.bfloat16, torch.float16)
+    if W2T_scaled.dtype != W1T.dtype:
+        raise L.SeHipError('ff_bwd_dgrad: W2T and W1T must both be fp32 or both pre-split planes of one kind')
+    f16 = W1T.dtype == torch.float16
+    prec = (3 if f16 else min(LINEAR_PRECISION, 2)) if precision is None else precision
     x, st, g, dR2, dg, db = ln if ln is not None else (None,) * 6
-    L.call('se_ff_bwd_dgrad', L.ptr(dy), L.ptr(H), L.ptr(W2T_scaled), L.ptr(W1T), L.ptr(dZ), L.ptr(None if ln else out),
+    sc = None
+    if f16:        # dY scaled by its measured maximum (dy._se_amax, raised by the kernel that produced dy); max |dX| / |dZ| out
+        dy_amax = getattr(dy, '_se_amax', None)
+        if dy_amax is None:
+            raise L.SeHipError('ff_bwd_dgrad: scaled fp16 weight planes need the measured maximum of dy (dy._se_amax)')
+        out._se_amax, dZ._se_amax = amax_out
+        sc = L.F16Scales(dy_amax.data_ptr(), 0, 0, W2T_scaled._se_amax.data_ptr(), W1T._se_amax.data_ptr(),
+                         out._se_amax.data_ptr(), dZ._se_amax.data_ptr())
+    L.call('se_ff_bwd_dgrad_f16', L.ptr(dy), L.ptr(H), L.ptr(W2T_scaled), L.ptr(W1T), L.ptr(dZ), L.ptr(None if ln else out),
            C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF),
            C.c_int(prec | (16 if pl else 0)), L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dR2), L.ptr(out if ln else None), L.ptr(dg), L.ptr(db),
-           L.stream(), _key=f'ff_bwd_dgrad_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid,
-           _bytes=4.0 * M * (128 + 2 * hid + (128 if ln else 0)))
+           C.byref(sc) if f16 else None, L.stream(), _key='ff_bwd_dgrad_f16x3' if f16 else f'ff_bwd_dgrad_bf16x{3 if prec == 1 else 6}',
+           _flops=4.0 * M * 64 * hid, _bytes=4.0 * M * (128 + 2 * hid + (128 if ln else 0)))
     return dZ, out

@@ -77,6 +77,16 @@ def _prec(p, taps, sf, C_in, Fo=None, have_scale=True):
     return 3 if (have_scale and _conv3_shape(taps, sf, C_in, Fo)) else 2
 
 
+def _prec_w(p, W, taps, sf, C_in, Fo=None, have_scale=True):
+    """precision of a forward / input-gradient conv GEMM from the form its weight arrives in: scaled fp16 planes (the step's
+    WeightPlan chose precision 3 for this layer) -> 3, bf16 planes -> 2, plain fp32 -> `_prec`"""
+    if W.dtype == torch.float16:
+        return 3
+    if W.dtype == torch.bfloat16:
+        return 2
+    return _prec(p, taps, sf, C_in, Fo, have_scale)
+
+
 class DPHooks:
     """Data-parallel hooks: SyncBatchNorm statistic exchange (main_gan.py:154-155).  Single-GPU default: none."""
     world = 1
@@ -104,8 +114,7 @@ def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None
     ep = L.EPI_BIAS | (L.EPI_STATS if want_stats else 0) | (L.EPI_SHUFFLE2 if shuffle2 else 0)
     No = N // 2 if shuffle2 else N
     d = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, No, a_off=a_off, sf=sf, epilogue=ep,
-                     precision=_prec(CONV_PRECISION, taps, sf, C_in, Fo, have_scale=wp.dtype != torch.bfloat16), a_sexp=ACT_SEXP,
-                     w_sexp=8)
+                     precision=_prec_w(CONV_PRECISION, wp, taps, sf, C_in, Fo), a_sexp=ACT_SEXP, w_sexp=8)
     R = torch.empty(B, To, Fo * (2 if shuffle2 else 1), No, device=x.device, dtype=torch.float32)
     stats = O.zeros(B, No, 2, device=x.device, dtype=torch.float64) if want_stats else None
     GM.gemm_tap(d, x, wp, R, bias=bias, stats=stats)
@@ -157,8 +166,7 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     dtaps = [(-a, -c) for a, c in taps]
     dd = GM.make_desc(B, Ti, Fi, To, Fo, dtaps, N, N, C_in, lddx, c_off=dx_off, sf=sf,
                       up=1 if sf != 1 else 0, epilogue=L.EPI_ACCUM if accumulate else 0,
-                      precision=_prec(CONV_PRECISION, dtaps, sf, N, Fi, have_scale=amax is not None and wd.dtype != torch.bfloat16),
-                      a_amax=amax, w_sexp=8)
+                      precision=_prec_w(CONV_PRECISION, wd, dtaps, sf, N, Fi, have_scale=amax is not None), a_amax=amax, w_sexp=8)
     GM.gemm_tap(dd, dR, wd, dx)
     return dx
 
@@ -204,7 +212,8 @@ def build_generator_plan(P, device):
     plan = WeightPlan(device)
     cpl = CONV_PRECISION in (2, 3)       # six-product kernels read the exact hi/mid/lo planes; everything else fp32
     c3 = 'f16' if CONV_PRECISION == 3 else cpl      # triple-tap unit-stride convolutions under precision 3: scaled fp16 planes
-    lpl = GM.LINEAR_PRECISION == 2
+    lpl = GM.LINEAR_PRECISION in (2, 3)
+    l3 = 'f16' if GM.LINEAR_PRECISION == 3 else lpl      # token-wise GEMMs under precision 3: scaled fp16 planes
 
     def dense(p):
         for i in range(4):
@@ -215,8 +224,8 @@ def build_generator_plan(P, device):
     e = 'dense_encoder'
     plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
     dense(f'{e}.dilated_dense')
-    plan.conv_fwd((f'{e}.conv_2.0.weight', 'fwd'), P[f'{e}.conv_2.0.weight'], planes=cpl)
-    plan.conv_dgrad((f'{e}.conv_2.0.weight', 'dgrad'), P[f'{e}.conv_2.0.weight'], planes=cpl)
+    plan.conv_fwd((f'{e}.conv_2.0.weight', 'fwd'), P[f'{e}.conv_2.0.weight'], planes=c3)          # strided: generic split kernel
+    plan.conv_dgrad((f'{e}.conv_2.0.weight', 'dgrad'), P[f'{e}.conv_2.0.weight'], planes=c3)
     for dec, last in (('mask_decoder', 'conv_1'), ('complex_decoder', 'conv')):
         dense(f'{dec}.dense_block')
         n = f'{dec}.sub_pixel.conv.weight'
@@ -231,22 +240,25 @@ def build_generator_plan(P, device):
             for ff in ('ff1', 'ff2'):
                 n1, n2 = f'{p}.{ff}.fn.fn.net.0.weight', f'{p}.{ff}.fn.fn.net.3.weight'
                 if lpl and P[n1].shape[1] == 64 and P[n2].shape[0] == 64 and P[n1].shape[0] % 64 == 0:
-                    plan.linear((n1, 'lin'), P[n1], planes=True)
-                    plan.linear((n2, 'lin'), P[n2], planes=True)
-                    plan.linear_T((n2, 'T0.5'), P[n2], planes=True, scale=0.5)
-                    plan.linear_T((n1, 'T'), P[n1], planes=True)
+                    f3 = 'f16' if (l3 == 'f16' and P[n1].shape[0] == 256) else True       # the fp16 FF kernels are built for hid = 256
+                    plan.linear((n1, 'lin'), P[n1], planes=f3)
+                    plan.linear((n2, 'lin'), P[n2], planes=f3)
+                    plan.linear_T((n2, 'T0.5'), P[n2], planes=f3, scale=0.5)
+                    plan.linear_T((n1, 'T'), P[n1], planes=f3)
             a = f'{p}.attn.fn'
-            plan.linear((a, 'qkv'), P[f'{a}.to_q.weight'], planes=lpl, rows=192)
-            plan.linear((a, 'qkv'), P[f'{a}.to_kv.weight'], planes=lpl, o_off=64)
+            plan.linear((a, 'qkv'), P[f'{a}.to_q.weight'], planes=l3, rows=192)
+            plan.linear((a, 'qkv'), P[f'{a}.to_kv.weight'], planes=l3, o_off=64)
+            # the attention backward does not measure max |dqkv| (its 256-VGPR kernel has no room for it): the input-gradient
+            # GEMM of the qkv projection keeps the six-product kernel
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_q.weight'], planes=lpl, ld=192)
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_kv.weight'], planes=lpl, c_off=64)
             plan.linear_T((f'{a}.to_out.weight', 'T'), P[f'{a}.to_out.weight'])
             plan.linear((f'{a}.rel_pos_emb.weight', 'es'), P[f'{a}.rel_pos_emb.weight'], planes=True)     # [3][2 maxpos + 1][16]
             n = f'{p}.conv.net.2.weight'
-            plan.linear((n, 'lin'), P[n], planes=lpl)
-            plan.linear_T((n, 'T'), P[n], planes=lpl)
+            plan.linear((n, 'lin'), P[n], planes=l3)
+            plan.linear_T((n, 'T'), P[n], planes=l3)
             n = f'{p}.conv.net.7.weight'
-            plan.linear_T((n, 'T'), P[n], planes=lpl)
+            plan.linear_T((n, 'T'), P[n], planes=l3)
     return plan
 
 
@@ -354,6 +366,19 @@ def site_seed(base, idx):
     return (base * 0x9E3779B1 + (idx + 1) * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF
 
 
+def _lin3(W, **kw):
+    """precision / scale keywords of a token-wise GEMM whose weight W may be scaled fp16 planes (precision 3) -- then the A operand
+    needs its scale: a_sexp (static: LayerNorm prologue) or a_amax (measured maximum of a gradient)"""
+    if W.dtype == torch.float16:
+        return dict(precision=3, **kw)
+    return {}
+
+
+def _amax(dev):
+    """a zero-filled device scalar for a producer kernel to raise to max |output| (None when no scaled-fp16 kernel runs)"""
+    return O.zeros(1, device=dev) if 3 in (GM.LINEAR_PRECISION, GM.WGRAD_LINEAR_PRECISION, CONV_PRECISION, WGRAD_PRECISION[0]) else None
+
+
 def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0, st=None, want_out_stats=False):
     """x + 0.5 * Drop(W2 Drop(Swish(W1 LN(x)))) (Scale(0.5, PreNorm(FeedForward)), conformer.py:53-71,128-145).
     The two dropout masks are counter-based (hash(seed, element)) and re-evaluated in the backward.
@@ -362,7 +387,7 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0, st=None, want_out_stats=Fa
     if st is None:
         st = O.row_stats(x, M)
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
-    if GM.LINEAR_PRECISION in (1, 2) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0:
+    if GM.LINEAR_PRECISION in (1, 2, 3) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0:
         # one fused kernel: the hidden activations are written once (for the backward) and never re-read here
         res = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
                          _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1), P[f'{p}.fn.fn.net.0.bias'],
@@ -392,26 +417,30 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     x, st, z, drop, seed_h, seed_o = saved
     dr = drop > 0.0
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
-    fused = GM.LINEAR_PRECISION in (1, 2) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0
+    fused = GM.LINEAR_PRECISION in (1, 2, 3) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0
     # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z);  dh = dz @ W1
     if fused:
         # ... and the LayerNorm backward on the rows still in registers: dx = dy (+ dR2) + LNbwd(dz @ W1)
         dz, dx = GM.ff_bwd_dgrad(dy, z, _w(P, (f'{p}.fn.fn.net.3.weight', 'T0.5'), lambda: _T(W2) * 0.5),
                                  _w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: _T(W1)), drop, seed_h, seed_o,
-                                 ln=(x, st, P[f'{p}.fn.norm.weight'], dR2, G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias']))
+                                 ln=(x, st, P[f'{p}.fn.norm.weight'], dR2, G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias']),
+                                 amax_out=(_amax(dy.device), _amax(dy.device)))
     else:
         dz = torch.empty(M, 256, device=x.device, dtype=torch.float32)
         GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_DROP if dr else L.PRO_NONE,
                                    epilogue=L.EPI_SWISH_GRAD | (L.EPI_DROP if dr else 0), ldx=256, pro_seed=seed_o,
                                    epi_seed=seed_h, drop_p=drop), dy, _T(W2) * 0.5, dz, AUX=z)
     # dW2 = 0.5 * (mask_o * dy)^T (mask_h * swish(z));  db2 = 0.5 * sum mask_o * dy
-    with GM.leaf_stream(z, dy, x, dz, st):
+    dy_amax, dz_amax = getattr(dy, '_se_amax', None), getattr(dz, '_se_amax', None)
+    with GM.leaf_stream(z, dy, x, dz, st, dy_amax, dz_amax):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH,
-                                         epilogue=L.EPI_DROP if dr else 0, pro_seed=seed_h, epi_seed=seed_o, drop_p=drop),
+                                         epilogue=L.EPI_DROP if dr else 0, pro_seed=seed_h, epi_seed=seed_o, drop_p=drop,
+                                         a_sexp=GM.HID_SEXP, w_amax=dy_amax),
                           z, dy, G[f'{p}.fn.fn.net.3.weight'], G[f'{p}.fn.fn.net.3.bias'], scale=0.5)
         # dW1 = dz^T LN(x);  db1 = sum dz
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), x, dz, G[f'{p}.fn.fn.net.0.weight'],
-                          G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dz_amax), x, dz,
+                          G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'],
+                          pb=P[f'{p}.fn.norm.bias'])
     if fused:
         return dx
     dh = torch.empty(M, 64, device=x.device, dtype=torch.float32)
@@ -439,7 +468,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     Wqkv = _w(P, (f'{p}.attn.fn', 'qkv'),
               lambda: torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0).contiguous())
     qkv = torch.empty(M, 192, device=x.device, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, Wqkv, qkv, rowstats=st2,
+    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, **_lin3(Wqkv, a_sexp=GM.LN_SEXP)), y1, Wqkv, qkv, rowstats=st2,
                 ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
     E = P[f'{p}.attn.fn.rel_pos_emb.weight']
     maxpos = (E.shape[0] - 1) // 2
@@ -458,7 +487,8 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     u = torch.empty(M, 128, device=x.device, dtype=torch.float32)
     zc = torch.empty(M, 256, device=x.device, dtype=torch.float32)
     Wpw1 = _w(P, (f'{p}.conv.net.2.weight', 'lin'), lambda: P[f'{p}.conv.net.2.weight'].view(256, 64))
-    GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=256), y2,
+    GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=256,
+                               **_lin3(Wpw1, a_sexp=GM.LN_SEXP)), y2,
                 Wpw1, u, bias=P[f'{p}.conv.net.2.bias'], AUX=zc, rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                 pb=P[f'{p}.conv.net.0.bias'])
     Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
@@ -500,14 +530,15 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     dev = dout.device
     y4, st5 = ctx['post']
     dy4 = O.layernorm_bwd(y4, st5, P[f'{p}.post_norm.weight'], dout, G[f'{p}.post_norm.weight'],
-                          G[f'{p}.post_norm.bias'])
+                          G[f'{p}.post_norm.bias'], amax=_amax(dev))
     dy3 = _ff_bwd(P, G, f'{p}.ff2', ctx['ff2'], dy4, M)
     ctx['ff2'] = ctx['post'] = None
     # conv module: y3 = y2 + swish(bn(h)) @ Wpw2^T + b
     y2, st3, zc, u, h, mr, sc, sh, count = ctx['conv']
     Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
     dact = torch.empty(M, 128, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 128), dy3, _w(P, (f'{p}.conv.net.7.weight', 'T'), lambda: _T(Wpw2)), dact)
+    Wpw2T = _w(P, (f'{p}.conv.net.7.weight', 'T'), lambda: _T(Wpw2))
+    GM.gemm_tap(GM.linear_desc(M, 64, 128, **_lin3(Wpw2T, a_amax=getattr(dy3, '_se_amax', None))), dy3, Wpw2T, dact)
     with GM.leaf_stream(h, dy3, sc, sh):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH), h, dy3,
                           G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
@@ -523,20 +554,21 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     du = O.dwconv31(dh, Wdw, None, geom, flip=True)
     with GM.leaf_stream(u, dh):
         O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
-    dzc = O.glu_bwd(zc, du, M, 128)
+    dzc = O.glu_bwd(zc, du, M, 128, amax=_amax(dev))
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
-    with GM.leaf_stream(y2, dzc, st3):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN), y2, dzc, G[f'{p}.conv.net.2.weight'].view(256, 64),
+    with GM.leaf_stream(y2, dzc, st3, dzc._se_amax):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dzc._se_amax), y2, dzc,
+                          G[f'{p}.conv.net.2.weight'].view(256, 64),
                           G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                           pb=P[f'{p}.conv.net.0.bias'])
     Wpw1T = _w(P, (f'{p}.conv.net.2.weight', 'T'), lambda: _T(Wpw1))
-    if FUSE_LN_BWD and GM.LINEAR_PRECISION == 2:
+    if FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
         # input-gradient GEMM + the LayerNorm backward on its accumulators: the [M, 64] product never goes to memory
         dy2 = GM.gemm_ln_bwd(dzc, Wpw1T, y2, st3, P[f'{p}.conv.net.0.weight'], dy3, G[f'{p}.conv.net.0.weight'],
                              G[f'{p}.conv.net.0.bias'])
     else:
         dl3 = torch.empty(M, 64, device=dev, dtype=torch.float32)
-        GM.gemm_tap(GM.linear_desc(M, 256, 64), dzc, Wpw1T, dl3)
+        GM.gemm_tap(GM.linear_desc(M, 256, 64, **_lin3(Wpw1T, a_amax=dzc._se_amax)), dzc, Wpw1T, dl3)
         dy2 = O.layernorm_bwd(y2, st3, P[f'{p}.conv.net.0.weight'], dl3, G[f'{p}.conv.net.0.weight'],
                               G[f'{p}.conv.net.0.bias'], dR=dy3)
         del dl3
@@ -567,14 +599,15 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
         if dWqkv.data_ptr() != gq.data_ptr():
             gq += dWqkv[:64]
             gkv += dWqkv[64:]
-    if FUSE_LN_BWD and GM.LINEAR_PRECISION == 2:
+    if FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
+        # (six-product kernel: max |dqkv| is not measured; its OUTPUT dy1 feeds the scaled-fp16 feed-forward backward -> max |dy1|)
         dy1 = GM.gemm_ln_bwd(dqkv, WqkvT, y1, st2, P[f'{p}.attn.norm.weight'], dy2, G[f'{p}.attn.norm.weight'],
-                             G[f'{p}.attn.norm.bias'])
+                             G[f'{p}.attn.norm.bias'], out_amax=_amax(dev))
     else:
         dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
         GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, WqkvT, dl2)
         dy1 = O.layernorm_bwd(y1, st2, P[f'{p}.attn.norm.weight'], dl2, G[f'{p}.attn.norm.weight'],
-                              G[f'{p}.attn.norm.bias'], dR=dy2)
+                              G[f'{p}.attn.norm.bias'], dR=dy2, amax=_amax(dev))
         del dl2
     ctx['attn'] = None
     del do, dqkv, dy2

@@ -84,11 +84,13 @@ def layernorm_fwd(x, g, b, R=None, want_stats=True, eps=1e-5, out_stats=False):
     return (y, st, ost) if out_stats else (y, st)
 
 
-def layernorm_bwd(x, st, g, dy, dg, db, dR=None, dR2=None):
+def layernorm_bwd(x, st, g, dy, dg, db, dR=None, dR2=None, amax=None):
+    """amax: optional zero-filled device scalar raised to max |dx| (travels with the result as dx._se_amax)"""
     M = x.numel() // 64
     dx = torch.empty_like(x)
-    L.call('se_layernorm_bwd', L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dy), L.ptr(dR), L.ptr(dR2), L.ptr(dx), L.ptr(dg),
-           L.ptr(db), _l(M), _i(64), L.stream())
+    L.call('se_layernorm_bwd_amax', L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dy), L.ptr(dR), L.ptr(dR2), L.ptr(dx), L.ptr(dg),
+           L.ptr(db), _l(M), _i(64), L.ptr(amax), L.stream())
+    dx._se_amax = amax
     return dx
 
 
@@ -259,9 +261,11 @@ def mask_tail_bwd(U, ldu, wb, slope, dM, dU, dwb, dslope, n, F_):
            L.ptr(dslope), _l(n), _i(F_), L.stream())
 
 
-def glu_bwd(Z, dU, M, H):
+def glu_bwd(Z, dU, M, H, amax=None):
+    """amax: optional zero-filled device scalar raised to max |dZ| (travels with the result as dZ._se_amax)"""
     dZ = torch.empty_like(Z)
-    L.call('se_glu_bwd', L.ptr(Z), L.ptr(dU), L.ptr(dZ), _l(M), _i(H), L.stream())
+    L.call('se_glu_bwd_amax', L.ptr(Z), L.ptr(dU), L.ptr(dZ), _l(M), _i(H), L.ptr(amax), L.stream())
+    dZ._se_amax = amax
     return dZ
 
 
