@@ -54,5 +54,16 @@ static inline bool se_raise_lds(const void* fn, size_t bytes, unsigned* done) {
   return true;
 }
 
+// Raise the device scalar *p (a running maximum of non-negative floats, ordered like their bit patterns) to m; called by ONE lane
+// per wave with the wave's maximum.  The plain load first: tens of thousands of waves hammering one address with atomics are
+// serialised in the L2 (259 K atomics of a glu_bwd launch cost milliseconds); after the first few waves almost every wave sees
+// a stored maximum >= its own and issues nothing.  (A stale read only costs a redundant atomic.)
+static __device__ __forceinline__ void amax_raise_(float* p, float m) {
+  if (!(m > 0.f)) return;
+  const unsigned mb = __float_as_uint(m);
+  if (__hip_atomic_load(reinterpret_cast<unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= mb) return;
+  atomicMax(reinterpret_cast<unsigned*>(p), mb);
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -249,7 +249,7 @@ __global__ void glu_bwd_kernel(const float* __restrict__ Z, const float* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) m = fmaxf(m, fmaxf(fabsf(da[j]), fabsf(dg[j])));
     m = wave_max(live ? m : 0.f);
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(m));
+    if ((threadIdx.x & 63) == 0) amax_raise_(amax_out, m);
   }
 }
 

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
     const f16x2_ zp = __builtin_bit_cast(f16x2_, zmh);
     // (1 + 2^-10): hi is dZ rounded to 11 bits -- the recorded maximum must not be below the true one
     const float zmax = wave_max(fmaxf((float)zp[0], (float)zp[1])) * (1.f + 0x1p-10f) / s_dz;
-    if (lane == 0 && zmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.sc.mid_amax), __float_as_uint(zmax));
+    if (lane == 0) amax_raise_(a.sc.mid_amax, zmax);
   }
   if (a.X == nullptr) {
 #pragma unroll
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
   }
   if (F16 && a.sc.out_amax) {
     xmax = wave_max(xmax);
-    if (lane == 0 && xmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(a.sc.out_amax), __float_as_uint(xmax));
+    if (lane == 0) amax_raise_(a.sc.out_amax, xmax);
   }
   // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
   float* redg = reinterpret_cast<float*>(Wa);         // [4 waves][64 channels][2]; the weight planes are free now

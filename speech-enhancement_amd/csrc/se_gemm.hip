@@ -930,7 +930,7 @@ __global__ void weight_amax_kernel(const se_wprep_item* __restrict__ items, int 
     m = fmaxf(m, fabsf(it.scale * it.src[o * it.so + i * it.si + t * it.stt]));      // a maximum: the slab reversal is irrelevant
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned*>(it.amax), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) amax_raise_(it.amax, m);
 }
 
 extern "C" int se_weight_prep(const se_wprep_item* items_dev, int nitems, long max_elems, void* stream) {

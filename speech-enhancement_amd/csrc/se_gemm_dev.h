@@ -323,7 +323,7 @@ static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, c
   }
   if (g.amax_out) {
     xmax = wave_max(xmax);
-    if (lane == 0 && xmax > 0.f) atomicMax(reinterpret_cast<unsigned*>(g.amax_out), __float_as_uint(xmax));
+    if (lane == 0) amax_raise_(g.amax_out, xmax);
   }
   // gamma / beta gradients: fold the 8 row groups of the wave (lane bits 3..5), then the 4 waves through LDS
 #pragma unroll
@@ -606,16 +606,19 @@ static __device__ __forceinline__ void split_store_h(float4 v, float s, __bf16* 
 }
 template <typename V8>
 static __device__ __forceinline__ void split_planes8_h(float (&x)[8], float s, V8 (&out)[2]) {
-  u32x4_ h, l;
+  // (scalar words, assembled into the vectors at the end: with `u32x4_ h; h[i] = ...; bit_cast(h[i])` in the loop, hipcc 7.2
+  // selected v_fma_mix_f32 with the FIRST word as the fp16 source of all eight residuals -- tools/micro/f16chk.hip)
+  unsigned hw[4], lw[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const float y0 = x[2 * i] * s, y1 = x[2 * i + 1] * s;
-    h[i] = pk_f16_(y0, y1);
-    const f16x2_ hh = __builtin_bit_cast(f16x2_, h[i]);
-    l[i] = pk_f16_(y0 - (float)hh[0], y1 - (float)hh[1]);
+    const unsigned w = pk_f16_(y0, y1);
+    const f16x2_ hh = __builtin_bit_cast(f16x2_, w);
+    hw[i] = w;
+    lw[i] = pk_f16_(y0 - (float)hh[0], y1 - (float)hh[1]);
   }
-  out[0] = __builtin_bit_cast(V8, h);
-  out[1] = __builtin_bit_cast(V8, l);
+  out[0] = __builtin_bit_cast(V8, (u32x4_){hw[0], hw[1], hw[2], hw[3]});
+  out[1] = __builtin_bit_cast(V8, (u32x4_){lw[0], lw[1], lw[2], lw[3]});
 }
 // running element-wise maximum of |x| over packed fp16 pairs: m (one pair) vs the 8 values of a fragment
 static __device__ __forceinline__ unsigned pk_absmax_f16_(unsigned m, const bf16x8& frag) {

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void layernorm64_bwd_kernel(const float* __res
   }
   if (amax_out) {
     amx = wave_max(amx);
-    if ((threadIdx.x & 63) == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amx));
+    if ((threadIdx.x & 63) == 0) amax_raise_(amax_out, amx);
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { red[(sub * 64 + q * 4 + j) * 2] = ag[j]; red[(sub * 64 + q * 4 + j) * 2 + 1] = ab[j]; }
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
   }
   if (amax_out) {                                // non-negative floats order like their bit patterns: one atomic per wave
     amx = wave_max(amx);
-    if ((threadIdx.x & 63) == 0 && amx > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax_out), __float_as_uint(amx));
+    if ((threadIdx.x & 63) == 0) amax_raise_(amax_out, amx);
   }
 }
 
