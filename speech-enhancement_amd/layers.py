@@ -38,6 +38,7 @@ CONV_PRECISION = _PREC[_os.environ.get('SE_CONV_PRECISION', 'f16x3')]
 # |beta| = 254 |gamma| + |beta|; out-of-range values would be clamped (FP16_OVFL), not turned into inf.  Gradients and weights
 # are scaled by their MEASURED maxima instead (amax scalars).
 ACT_SEXP = 4
+ATTN_O_SEXP = 4    # attention outputs (convex combinations of the value rows): |o| < 4094
 
 
 # weight-gradient GEMMs of the same convolutions (contraction over pixels; same operand splits, transposed staging).
@@ -252,7 +253,9 @@ def build_generator_plan(P, device):
             # GEMM of the qkv projection keeps the six-product kernel
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_q.weight'], planes=lpl, ld=192)
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_kv.weight'], planes=lpl, c_off=64)
-            plan.linear_T((f'{a}.to_out.weight', 'T'), P[f'{a}.to_out.weight'])
+            plan.linear_T((f'{a}.to_out.weight', 'T'), P[f'{a}.to_out.weight'], planes='f16' if l3 == 'f16' else False)
+            if l3 == 'f16':
+                plan.linear((f'{a}.to_out.weight', 'lin'), P[f'{a}.to_out.weight'], planes='f16')
             plan.linear((f'{a}.rel_pos_emb.weight', 'es'), P[f'{a}.rel_pos_emb.weight'], planes=True)     # [3][2 maxpos + 1][16]
             n = f'{p}.conv.net.2.weight'
             plan.linear((n, 'lin'), P[n], planes=l3)
@@ -477,9 +480,12 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     sa = site_seed(seed, 2)
     st3 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None
+    # the attention output is a convex combination of value rows v = LN(y1) Wv: bounded like them -> static exponent ATTN_O_SEXP
+    Wo_ = _w(P, (f'{p}.attn.fn.to_out.weight', 'lin'), lambda: P[f'{p}.attn.fn.to_out.weight'])
     GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if pa > 0 else 0) |
-                               (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64, epi_seed=sa, drop_p=pa), o,
-                P[f'{p}.attn.fn.to_out.weight'], y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1, AUX=st3)
+                               (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64, epi_seed=sa, drop_p=pa,
+                               **_lin3(Wo_, a_sexp=ATTN_O_SEXP)), o,
+                Wo_, y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1, AUX=st3)
     ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa)
     # conv module
     if st3 is None:
@@ -565,12 +571,12 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     if FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
         # input-gradient GEMM + the LayerNorm backward on its accumulators: the [M, 64] product never goes to memory
         dy2 = GM.gemm_ln_bwd(dzc, Wpw1T, y2, st3, P[f'{p}.conv.net.0.weight'], dy3, G[f'{p}.conv.net.0.weight'],
-                             G[f'{p}.conv.net.0.bias'])
+                             G[f'{p}.conv.net.0.bias'], out_amax=_amax(dev))
     else:
         dl3 = torch.empty(M, 64, device=dev, dtype=torch.float32)
         GM.gemm_tap(GM.linear_desc(M, 256, 64, **_lin3(Wpw1T, a_amax=dzc._se_amax)), dzc, Wpw1T, dl3)
         dy2 = O.layernorm_bwd(y2, st3, P[f'{p}.conv.net.0.weight'], dl3, G[f'{p}.conv.net.0.weight'],
-                              G[f'{p}.conv.net.0.bias'], dR=dy3)
+                              G[f'{p}.conv.net.0.bias'], dR=dy3, amax=_amax(dev))
         del dl3
     ctx['conv'] = None
     del dact, dh, du, dzc, dy3, dy4
@@ -578,8 +584,9 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa = ctx['attn']
     Wo = P[f'{p}.attn.fn.to_out.weight']
     do = torch.empty(M, 64, device=dev, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa),
-                dy2, _w(P, (f'{p}.attn.fn.to_out.weight', 'T'), lambda: _T(Wo)), do)
+    WoT = _w(P, (f'{p}.attn.fn.to_out.weight', 'T'), lambda: _T(Wo))
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa,
+                               **_lin3(WoT, a_amax=getattr(dy2, '_se_amax', None))), dy2, WoT, do)
     with GM.leaf_stream(o, dy2):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa), o, dy2,
                           G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
