@@ -304,6 +304,11 @@ int se_attn_bwd_phase(const float* QKV, const float* E, const float* O, const fl
  * [128][2] when stats != NULL); flip=1 with bias=NULL is the input gradient. */
 int se_dwconv31(const float* X, const float* W, const float* bias, float* Y, double* stats, int flip,
                 int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, void* stream);
+/* input gradient of DepthWiseConv1d fused with the backward of the GLU in front of it (conformer.py:164-166 backwards):
+ * dU = flipped-tap depthwise conv of dH [tokens][128] (never written), dZ [tokens][256] = (dU sigmoid(g), dU a sigmoid(g)(1 - sigmoid(g)))
+ * with Z = (a | g) the pre-GLU activations; amax_out (may be NULL): raised to max |dZ| */
+int se_dwconv31_glu_bwd(const float* dH, const float* W, const float* Z, float* dZ, float* amax_out, int nseq, int n,
+                        int inner, long outer_stride, long inner_stride, long pos_stride, void* stream);
 /* weight / bias gradient (accumulated into dW [128][31], dbias [128]); ws = workspace of
  * se_dwconv31_wgrad_workspace_bytes() bytes (per-workgroup partial sums, reduced in a fixed order: deterministic) */
 size_t se_dwconv31_wgrad_workspace_bytes(void);

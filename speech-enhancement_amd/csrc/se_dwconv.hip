@@ -22,6 +22,9 @@ constexpr int DW_C = 128, DW_K = 31;
 struct DwArgs {
   SeqGeom g;
   const float* X; const float* W; const float* bias; float* Y; double* stats; int flip;
+  // GLU variant (input gradient of the conv module, conformer.py:164-166 backwards): Z = the pre-GLU activations [tokens][256]
+  // (a | gate), Y = dZ [tokens][256]; the depthwise input gradient dU never goes to memory
+  const float* Z; float* amax_out;
 };
 
 // 512 threads: lane pair-channel cl = tid & 63 (2 channels), position slot ps = tid >> 6 (8 slots x PPS positions).
@@ -34,7 +37,10 @@ struct DwArgs {
 // channels of a lane in one instruction; this translation unit is built with packed fp32 ops enabled -- no MFMA here to stall).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int PPS>
+// GLU: the epilogue applies the backward of GLU (a * sigmoid(gate)) to the result on its way out: dZ[:, c] = dU sigmoid(g),
+// dZ[:, 128 + c] = dU a sigmoid(g) (1 - sigmoid(g)) -- the stand-alone glu_bwd pass (read Z and dU, write dZ: 1.33 GB per block at
+// batch 16, 214 us x 8 per step) and the write + re-read of dU disappear; max |dZ| is raised for the scaled-fp16 consumers.
+template <int PPS, bool GLU = false>
 __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
   constexpr int TILE = 8 * PPS, ROWS = TILE + DW_K - 1;
   __shared__ __attribute__((aligned(16))) float xs[ROWS * DW_C];
@@ -51,6 +57,7 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
   f32x2 bv = {0.f, 0.f};
   if (a.bias) bv = *reinterpret_cast<const f32x2*>(a.bias + cl * 2);
   f32x2 s = {0.f, 0.f}, q2 = {0.f, 0.f};
+  float zmax = 0.f;
   const int tiles = (n + TILE - 1) / TILE;
   const long nitems = (long)a.g.nseq * tiles;
   constexpr int NLD = (ROWS * 32 + 511) / 512;      // float4 per thread per tile
@@ -120,15 +127,57 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
 #pragma unroll
     for (int o = 0; o < PPS; ++o) asm volatile("" : "+v"(acc[o]));
     const unsigned st_off = (unsigned)(ps * PPS) * rs32 + (unsigned)cl * 2u;
+    if constexpr (GLU) {
+      // rows of Z / dZ are 256 floats: twice the row stride of the conv operands; positions past n read row n - 1 (unconditional
+      // loads, in groups of GG positions: all loads of a group in flight before the first is used) and store nothing
+      const float* __restrict__ Zt = a.Z + 2 * (base * DW_C + (long)p0 * rs) + 2 * (long)(ps * PPS) * rs + cl * 2;
+      float* __restrict__ Dt = a.Y + 2 * (base * DW_C + (long)p0 * rs) + 2 * (long)(ps * PPS) * rs + cl * 2;
+      const int plast = n - 1 - (p0 + ps * PPS);            // last valid position offset of this slot (may be negative)
+      constexpr int GG = 2;
 #pragma unroll
-    for (int o = 0; o < PPS; ++o) {
-      const int p = p0 + ps * PPS + o;
-      if (p < n) {
-        *reinterpret_cast<f32x2*>(Yt + (long)o * rs + st_off) = acc[o];
-        s += acc[o];
-        q2 = __builtin_elementwise_fma(acc[o], acc[o], q2);
+      for (int o0 = 0; o0 < PPS; o0 += GG) {
+        f32x2 za[GG], zg[GG];
+#pragma unroll
+        for (int j = 0; j < GG; ++j) {
+          if (o0 + j < PPS) {
+            int oc = o0 + j; oc = oc > plast ? plast : oc; oc = oc < 0 ? 0 : oc;
+            const float* zp = (plast >= 0 ? Zt : a.Z) + 2 * (long)oc * rs;       // an all-padding slot reads a valid dummy row
+            za[j] = *reinterpret_cast<const f32x2*>(zp);
+            zg[j] = *reinterpret_cast<const f32x2*>(zp + DW_C);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < GG; ++j) {
+          const int o = o0 + j;
+          if (o < PPS && o <= plast) {
+            f32x2 da, dg;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const float sg = sigmoidf_(zg[j][e]);
+              da[e] = acc[o][e] * sg;
+              dg[e] = acc[o][e] * za[j][e] * sg * (1.f - sg);
+              zmax = fmaxf(zmax, fmaxf(fabsf(da[e]), fabsf(dg[e])));
+            }
+            *reinterpret_cast<f32x2*>(Dt + 2 * (long)o * rs) = da;
+            *reinterpret_cast<f32x2*>(Dt + 2 * (long)o * rs + DW_C) = dg;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < PPS; ++o) {
+        const int p = p0 + ps * PPS + o;
+        if (p < n) {
+          *reinterpret_cast<f32x2*>(Yt + (long)o * rs + st_off) = acc[o];
+          s += acc[o];
+          q2 = __builtin_elementwise_fma(acc[o], acc[o], q2);
+        }
       }
     }
+  }
+  if (GLU && a.amax_out) {
+    zmax = wave_max(zmax);
+    if ((tid & 63) == 0) amax_raise_(a.amax_out, zmax);
   }
   if (a.stats) {            // one fp64 atomic per (channel, moment) per workgroup
     __syncthreads();
@@ -283,7 +332,7 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
                            void* stream) {
   SE_REQUIRE(X && W && Y && nseq > 0 && n > 0 && inner > 0, "dwconv31: bad arguments");
   SE_REQUIRE(pos_stride > 0 && pos_stride * DW_C * 160L < (1L << 30), "dwconv31: position stride too large for 32-bit tile offsets");
-  DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, W, bias, Y, stats, flip};
+  DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, X, W, bias, Y, stats, flip, nullptr, nullptr};
   // tile = 8 slots x PPS positions: 64 (short sequences), 104 (n <= 104: the frequency axis, n = 101, is one tile), 112
   const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
   const long nitems = (long)nseq * cdiv(n, 8 * pps);
@@ -292,6 +341,20 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
   else if (pps == 13) hipLaunchKernelGGL(dwconv_kernel<13>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else hipLaunchKernelGGL(dwconv_kernel<14>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31");
+}
+
+extern "C" int se_dwconv31_glu_bwd(const float* dH, const float* W, const float* Z, float* dZ, float* amax_out, int nseq, int n,
+                                   int inner, long outer_stride, long inner_stride, long pos_stride, void* stream) {
+  SE_REQUIRE(dH && W && Z && dZ && nseq > 0 && n > 0 && inner > 0, "dwconv31_glu_bwd: bad arguments");
+  SE_REQUIRE(pos_stride > 0 && pos_stride * DW_C * 320L < (1L << 30), "dwconv31_glu_bwd: position stride too large for 32-bit tile offsets");
+  DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, dH, W, nullptr, dZ, nullptr, 1, Z, amax_out};
+  const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
+  const long nitems = (long)nseq * cdiv(n, 8 * pps);
+  const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;
+  if (pps == 8) hipLaunchKernelGGL((dwconv_kernel<8, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((dwconv_kernel<14, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  return se_check_launch("se_dwconv31_glu_bwd");
 }
 
 extern "C" size_t se_dwconv31_wgrad_workspace_bytes(void) { return (size_t)512 * 32 * DW_C * sizeof(float); }

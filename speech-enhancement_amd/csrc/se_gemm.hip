@@ -350,8 +350,8 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 // plane and thread instead of two fp32 loads + a 36-instruction split per tap step in every workgroup.
 // F16 (precision 3): NPL = 2 planes of SCALED fp16 (hi, lo), three fp16 MFMAs per product (se_gemm_dev.h); the accumulators are
 // multiplied by 2^-(sexp_A + sexp_W) (exact) before the epilogue.
-template <int NPL, bool WPL = false, bool F16 = false>
-__global__ __launch_bounds__(256, 3) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
+template <int NPL, bool WPL = false, bool F16 = false, int OCC = 3>
+__global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
   constexpr int BM = 128, BN = 64, BK = 32, SA = 40, HR = BM + 2;
   constexpr int PA = HR * SA, PB = BN * SA;
   __shared__ __attribute__((aligned(16))) __bf16 Ap[NPL * PA];
@@ -794,7 +794,11 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     }
     if (triples) {
       if (d->precision == 3) {
-        if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true>), grid, block, 0, s, g);
+        // two planes instead of three leave room for 4 waves per SIMD (115 VGPRs, 33 KB of LDS): 1.5 - 7 % (949 -> 934 us at
+        // Cin = 256, 226 -> 211 us at Cin = 64); SE_CONV3_OCC3=1 restores the 3-wave build for A/B runs
+        static const bool occ4 = getenv("SE_CONV3_OCC3") == nullptr;
+        if (d->w_planes && occ4) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 4>), grid, block, 0, s, g);
+        else if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((conv3_bf16_kernel<2, false, true>), grid, block, 0, s, g);
       }
       else if (d->precision == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2>), grid, block, 0, s, g);

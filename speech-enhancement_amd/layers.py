@@ -52,6 +52,8 @@ WGRAD_PRECISION = [_PREC[_os.environ.get('SE_WGRAD_PRECISION', 'f16x3')]]
 FUSE_LN_BWD = _os.environ.get('SE_NO_LN_FUSE') != '1'
 # LayerNorm row statistics emitted by the producer of the rows instead of a separate se_row_stats pass (SE_NO_ROWSTATS_FUSE=1: A/B)
 FUSE_ROWSTATS = _os.environ.get('SE_NO_ROWSTATS_FUSE') != '1'
+# GLU backward in the epilogue of the depthwise input-gradient kernel (se_dwconv31_glu_bwd); SE_NO_GLU_FUSE=1: two kernels (A/B)
+FUSE_GLU_BWD = _os.environ.get('SE_NO_GLU_FUSE') != '1'
 
 
 def set_conv_precision(name, wgrad=None):
@@ -557,10 +559,15 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     else:
         raise L.SeHipError('conformer_bwd in eval mode is not supported (BatchNorm uses running statistics)')
     Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
-    du = O.dwconv31(dh, Wdw, None, geom, flip=True)
+    if FUSE_GLU_BWD:       # depthwise input gradient + GLU backward in one kernel: dU (266 MB at batch 16) never goes to memory
+        dzc = O.dwconv31_glu_bwd(dh, Wdw, zc, geom, amax=_amax(dev))
+        du = None
+    else:
+        du = O.dwconv31(dh, Wdw, None, geom, flip=True)
     with GM.leaf_stream(u, dh):
         O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
-    dzc = O.glu_bwd(zc, du, M, 128, amax=_amax(dev))
+    if not FUSE_GLU_BWD:
+        dzc = O.glu_bwd(zc, du, M, 128, amax=_amax(dev))
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
     with GM.leaf_stream(y2, dzc, st3, dzc._se_amax):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dzc._se_amax), y2, dzc,

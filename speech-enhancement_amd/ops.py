@@ -163,6 +163,17 @@ def dwconv31(x, w, bias, geom, stats=None, flip=False):
     return y
 
 
+def dwconv31_glu_bwd(dh, w, z, geom, amax=None):
+    """dZ [M, 256] = GLU-backward(Z, depthwise-conv input gradient of dh): one kernel, dU never goes to memory"""
+    M = dh.shape[0]
+    dz = torch.empty(M, 256, device=dh.device, dtype=torch.float32)
+    nseq, n, inner, os_, is_, ps = geom
+    L.call('se_dwconv31_glu_bwd', L.ptr(dh), L.ptr(w), L.ptr(z), L.ptr(dz), L.ptr(amax), _i(nseq), _i(n), _i(inner), _l(os_),
+           _l(is_), _l(ps), L.stream(), _key='dwconv31 dgrad + glu_bwd', _bytes=4.0 * (dh.numel() + 2 * dz.numel()))
+    dz._se_amax = amax
+    return dz
+
+
 def dwconv31_wgrad(x, dy, dw, dbias, geom):
     nseq, n, inner, os_, is_, ps = geom
     ws = _new(L.lib().se_dwconv31_wgrad_workspace_bytes() // 4, like=x)

@@ -120,6 +120,18 @@ def test_dwconv31(axis, B, T, Fq):
     dw, db = torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda')
     O.dwconv31_wgrad(x.view(-1, 128), dy.view(-1, 128), dw, db, geom)
     assert relerr(dw, w64.grad.view(128, 31)) < 2e-5 and relerr(db, b64.grad) < 2e-5
+    # the input gradient fused with the backward of the GLU in front of the conv (se_dwconv31_glu_bwd): fp64 autograd of
+    # conv(GLU(z)) w.r.t. z, and the measured max |dZ|
+    z = rnd(B, T, Fq, 256, seed=5)
+    z64 = z.double().requires_grad_(True)
+    u64 = z64[..., :128] * torch.sigmoid(z64[..., 128:])
+    sq = u64.permute(0, 2, 3, 1) if axis == 'time' else u64.permute(0, 1, 3, 2)
+    rr = F.conv1d(F.pad(sq.reshape(-1, 128, sq.shape[-1]), (15, 15)), w.double(), None, groups=128).reshape(sq.shape)
+    (rr.permute(0, 3, 1, 2) if axis == 'time' else rr.permute(0, 1, 3, 2)).backward(dy.double())
+    amax = torch.zeros(1, device='cuda')
+    dz = O.dwconv31_glu_bwd(dy.view(-1, 128), w.view(128, 31), z.view(-1, 256), geom, amax=amax)
+    assert relerr(dz.view(B, T, Fq, 256), z64.grad) < 1e-5
+    assert abs(float(amax) - float(dz.abs().max())) <= 1e-6 * float(amax)
 
 
 def test_glu_bwd_and_optimizers():
