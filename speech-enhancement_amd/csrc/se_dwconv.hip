@@ -18,6 +18,17 @@ static __device__ __forceinline__ long tok_of(const SeqGeom& g, int s, int p) {
 }
 
 constexpr int DW_C = 128, DW_K = 31;
+// output rows are written once and read by the NEXT kernel (266 - 531 MB per launch: nothing of them survives in L2 / MALL)
+// -> non-temporal stores: 107 -> 103 us (time axis), 121 -> 111 us (frequency axis), input gradient 105 -> 96 / 116 -> 107 us
+#ifndef SE_DW_NO_NT
+#define DW_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define DW_STORE(p, v) (*(p) = (v))
+#endif
+// non-temporal LOADS of the tiles: slower in the convolution (103 -> 122 us: neighbouring tiles re-read 30 halo rows out of L2),
+// faster in the weight gradient (130 -> 123, 125 -> 118 us: its X tile is read by one workgroup only and dY streams past)
+#define DW_LOAD4(p) (*reinterpret_cast<const f32x4*>(p))
+#define DW_LOAD4_NT(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
 
 struct DwArgs {
   SeqGeom g;
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
     for (int k = 0; k < NLD; ++k) {
       const int row = (tid >> 5) + 16 * k, p = p0 - 15 + row;
       const float* __restrict__ Xk = Xt + (long)(16 * k) * rs;
-      ld[k] = (row < ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xk + ld_off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ld[k] = (row < ROWS && p >= 0 && p < n) ? __builtin_bit_cast(float4, DW_LOAD4(Xk + ld_off)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();                           // previous tile (or the tap table) fully consumed
 #pragma unroll
@@ -158,8 +169,8 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
               dg[e] = acc[o][e] * za[j][e] * sg * (1.f - sg);
               zmax = fmaxf(zmax, fmaxf(fabsf(da[e]), fabsf(dg[e])));
             }
-            *reinterpret_cast<f32x2*>(Dt + 2 * (long)o * rs) = da;
-            *reinterpret_cast<f32x2*>(Dt + 2 * (long)o * rs + DW_C) = dg;
+            DW_STORE(reinterpret_cast<f32x2*>(Dt + 2 * (long)o * rs), da);
+            DW_STORE(reinterpret_cast<f32x2*>(Dt + 2 * (long)o * rs + DW_C), dg);
           }
         }
       }
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
       for (int o = 0; o < PPS; ++o) {
         const int p = p0 + ps * PPS + o;
         if (p < n) {
-          *reinterpret_cast<f32x2*>(Yt + (long)o * rs + st_off) = acc[o];
+          DW_STORE(reinterpret_cast<f32x2*>(Yt + (long)o * rs + st_off), acc[o]);
           s += acc[o];
           q2 = __builtin_elementwise_fma(acc[o], acc[o], q2);
         }
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(512, 4) void dwconv_wgrad_kernel(DwWgradArgs a) {
     for (int k = 0; k < NLD; ++k) {
       const int row = (tid >> 5) + 16 * k, p = p0 - 15 + row;
       const float* __restrict__ Xk = Xt + (long)(16 * k) * rs;
-      ld[k] = (row < ROWS && p >= 0 && p < n) ? *reinterpret_cast<const float4*>(Xk + ld_off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ld[k] = (row < ROWS && p >= 0 && p < n) ? __builtin_bit_cast(float4, DW_LOAD4_NT(Xk + ld_off)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 #pragma unroll
