@@ -65,5 +65,16 @@ static __device__ __forceinline__ void amax_raise_(float* p, float m) {
   atomicMax(reinterpret_cast<unsigned*>(p), mb);
 }
 
+// 16-byte store of a feature-map element that is written once and read by a LATER kernel.  Non-temporal stores (SE_NT_STORE
+// builds) were measured on the normalisation / GLU kernels: no gain on the step (76.7 vs 76.3 - 76.7 ms, two A/B pairs), unlike the
+// depthwise conv where they win 4 - 9 % -- plain stores stay the default here.
+static __device__ __forceinline__ void st4_stream_(float* p, float4 v) {
+#ifdef SE_NT_STORE
+  __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v), reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

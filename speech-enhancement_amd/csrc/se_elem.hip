@@ -241,8 +241,8 @@ __global__ void glu_bwd_kernel(const float* __restrict__ Z, const float* __restr
     dg[j] = dv[j] * av[j] * s * (1.f - s);
   }
   if (live) {
-    *reinterpret_cast<float4*>(dZ + row * 2 * H + q * 4) = make_float4(da[0], da[1], da[2], da[3]);
-    *reinterpret_cast<float4*>(dZ + row * 2 * H + H + q * 4) = make_float4(dg[0], dg[1], dg[2], dg[3]);
+    st4_stream_(dZ + row * 2 * H + q * 4, make_float4(da[0], da[1], da[2], da[3]));
+    st4_stream_(dZ + row * 2 * H + H + q * 4, make_float4(dg[0], dg[1], dg[2], dg[3]));
   }
   if (amax_out) {
     float m = 0.f;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void layernorm64_fwd_kernel(const float* __res
       float4 r = *reinterpret_cast<const float4*>(R + row * 64 + q * 4);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    *reinterpret_cast<float4*>(Y + row * 64 + q * 4) = o;
+    st4_stream_(Y + row * 64 + q * 4, o);
     if (stats && q == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
     if (out_stats) {      // (mean, rstd) of the RESULT row, exactly as row_stats64_kernel would compute them from Y: the next LayerNorm's
       const float m2 = sum16(o.x + o.y + o.z + o.w) * (1.f / 64.f);
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void layernorm64_bwd_kernel(const float* __res
       float4 r = *reinterpret_cast<const float4*>(dR2 + row * 64 + q * 4);
       o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
     }
-    *reinterpret_cast<float4*>(dX + row * 64 + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    st4_stream_(dX + row * 64 + q * 4, make_float4(o[0], o[1], o[2], o[3]));
     amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
   }
   if (amax_out) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void affine_prelu_kernel(const float* __restri
     float u[4] = {v.x * sc[0] + sh[0], v.y * sc[1] + sh[1], v.z * sc[2] + sh[2], v.w * sc[3] + sh[3]};
 #pragma unroll
     for (int j = 0; j < 4; ++j) u[j] = u[j] >= 0.f ? u[j] : u[j] * sl[j];
-    *reinterpret_cast<float4*>(Y + pix * ldy + y_off + it.q * 4) = make_float4(u[0], u[1], u[2], u[3]);
+    st4_stream_(Y + pix * ldy + y_off + it.q * 4, make_float4(u[0], u[1], u[2], u[3]));
   }
 }
 
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void inorm_prelu_fwd_kernel(
       float u[4] = {v[k].x * sc[0] + sh[0], v[k].y * sc[1] + sh[1], v[k].z * sc[2] + sh[2], v[k].w * sc[3] + sh[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) u[j] = u[j] >= 0.f ? u[j] : u[j] * sl[j];
-      if (p < p_end) *reinterpret_cast<float4*>(Yb + p * ldy) = make_float4(u[0], u[1], u[2], u[3]);
+      if (p < p_end) st4_stream_(Yb + p * ldy, make_float4(u[0], u[1], u[2], u[3]));
     }
   }
 }
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
         o[j] = rstd[j] * gg[j] * (du - m1[j] - xh * m2[j]);
       }
       if (p < p_end) {
-        *reinterpret_cast<float4*>(Ob + p * lddx) = make_float4(o[0], o[1], o[2], o[3]);
+        st4_stream_(Ob + p * lddx, make_float4(o[0], o[1], o[2], o[3]));
         amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
       }
     }
