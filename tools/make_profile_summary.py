@@ -31,15 +31,32 @@ def short(n):
 def fam(name):
     """KernelTimer family (bench.py roofline keys) of a kernel name, or None"""
     n = short(name)
+    # the scaled split-fp16 instantiations (precision 3) carry a trailing `true` template argument (F16)
+    m = re.match(r'gemm_tap_bf16x3_kernel<(\d), (\d), (?:true|false), (?:true|false), (?:true|false), true>', n)
+    if m:
+        return 'gemm_tap_f16x3_kernel<0>'
     m = re.match(r'gemm_tap_bf16x3_kernel<(\d), (\d), (true|false)', n)
     if m:
         return f'gemm_tap_bf16x{3 if m.group(2) == "2" else 6}_kernel<{m.group(1)}>'
+    if re.match(r'conv3_bf16_kernel<2, (?:true|false), true', n):
+        return 'conv3_f16x3'
     m = re.match(r'conv3_bf16_kernel<(\d)', n)
     if m:
         return f'conv3_bf16x{3 if m.group(1) == "2" else 6}'
+    m = re.match(r'gemm_k64_panel_kernel<(\d), 2, (?:true|false), true, true>', n)
+    if m:
+        return f'gemm_k64_panel_f16x3<{m.group(1)}>'
     m = re.match(r'gemm_k64_panel_kernel<(\d), (\d), (true|false)', n)
     if m:
         return f'gemm_k64_panel_bf16x{3 if m.group(2) == "2" else 6}<{m.group(1)}>'
+    if re.match(r'dwconv_kernel<\d+, true>', n):
+        return 'dwconv31 dgrad + glu_bwd'
+    m = re.match(r'ff_(fwd|bwd)_kernel<2, true, \d, true>', n)
+    if m:
+        return f'ff_{m.group(1)}{"_dgrad" if m.group(1) == "bwd" else ""}_f16x3'
+    m = re.match(r'wgrad_lin_bf16_kernel<(\d)', n)
+    if m:
+        return f'wgrad_kernel<{m.group(1)}>'
     m = re.match(r'gemm_tap_kernel<(\d+), (\d), (true|false)>', n)
     if m:
         return f'gemm_tap_kernel<{m.group(1)},{m.group(2)}>'
