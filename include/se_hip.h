@@ -156,6 +156,24 @@ int se_ff_bwd_dgrad_f16(const float* dY, const float* H, const float* W2T, const
                         const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
                         const se_f16_scales* sc, void* stream);
 
+/* RECOMPUTING backward of the fused feed-forward module (scaled split-fp16 only; hid == 256): dX = dY + dR2 + LNbwd(dZ W1) with
+   dZ = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H)) and H = LN(X) W1^T + b1 RECOMPUTED from X -- no H is read and no dZ written
+   (se_ff_fwd_f16 with H = NULL stores none; se_ff_wgrad_rc recomputes both for the weight gradients).  W1 [hid][64], W2T = (alpha
+   W2)^T [hid][64], W1T [64][hid]: scaled fp16 planes (se_weight_prep fmt 1) with their amax scalars; dy_amax = max |dY| (device
+   scalar raised by the producer of dY); out_amax (may be NULL) is raised to max |dX|; ln_sexp = static exponent of LN(X). */
+int se_ff_bwd_rc(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta, const float* W1,
+                 const float* b1, const float* W2T, const float* W1T, long M, int hid, float drop_p, unsigned seed_h,
+                 unsigned seed_o, const float* dR2, float* dX, float* dgamma, float* dbeta, const float* dy_amax,
+                 const float* w1_amax, const float* w2t_amax, const float* w1t_amax, float* out_amax, int ln_sexp, void* stream);
+
+/* RECOMPUTING weight gradients of the same module (scaled split-fp16 only; hid == 256): dW1 [hid][64] += dZ^T LN(X), db1 += sum dZ,
+   dW2 [64][hid] += alpha (Drop_o dY)^T S, db2 (may be NULL) += alpha sum Drop_o dY, with S = Swish(H) Drop_h-mask, H and dZ as in
+   se_ff_bwd_rc, all recomputed from X and dY: nothing [M, hid]-sized is read.  W1, W2T = (alpha W2)^T: scaled fp16 planes. */
+int se_ff_wgrad_rc(const float* X, const float* stats, const float* gamma, const float* beta, const float* dY, const float* W1,
+                   const float* b1, const float* W2T, float* dW1, float* db1, float* dW2, float* db2, long M, int hid,
+                   float drop_p, unsigned seed_h, unsigned seed_o, float alpha, const float* dy_amax, const float* w1_amax,
+                   const float* w2t_amax, int ln_sexp, int hid_sexp, void* stream);
+
 /* Input-gradient GEMM of a projection that follows a LayerNorm(64), fused with that LayerNorm's backward
  * (models/conformer.py:67,162: PreNorm -> to_q/to_kv, LayerNorm -> pointwise conv):
  *   dX = dR + LNbwd(A W^T),  dgamma += sum_rows (A W^T) * xhat,  dbeta += sum_rows (A W^T)

@@ -279,8 +279,11 @@ def unpack_conv_wgrad(dwp, dw, rev_slabs=False, accumulate=False):
                   accumulate=accumulate)
 
 
+FF_RECOMPUTE = __import__('os').environ.get('SE_NO_FF_RECOMPUTE') != '1'      # scaled-fp16 feed-forward: H / dZ recomputed, not stored
+
+
 def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None, hid=None,
-           out_stats=False):
+           out_stats=False, store_h=True):
     """fused Scale(alpha, PreNorm(FeedForward)) forward (csrc/se_gemm.hip: ff_fwd_kernel): returns (Y, H) with
     H = W1 LN(x) + b1 kept for the backward."""
     L.check_cuda(x, rowstats, gamma, beta, W1, b1, W2, b2)
@@ -289,7 +292,8 @@ def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_
         raise L.SeHipError('ff_fwd: W1 and W2 must both be fp32 or both pre-split planes of one kind')
     f16 = W1.dtype == torch.float16
     M, hid = x.shape[0], (hid or W1.shape[-2])
-    H = torch.empty(M, hid, device=x.device, dtype=torch.float32)
+    # store_h=False (scaled fp16 planes only): H is not written -- the recomputing backward (ff_bwd_rc / ff_wgrad_rc) needs none
+    H = torch.empty(M, hid, device=x.device, dtype=torch.float32) if (store_h or not f16) else None
     Y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     prec = (3 if f16 else min(LINEAR_PRECISION, 2)) if precision is None else precision
     ost = torch.empty(M, 2, device=x.device, dtype=torch.float32) if out_stats else None     # (mean, rstd) of the rows of Y
@@ -298,10 +302,42 @@ def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_
            L.ptr(H), L.ptr(Y), L.ptr(ost), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF),
            C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec | (16 if pl else 0)), C.byref(sc) if f16 else None,
            L.stream(), _key='ff_fwd_f16x3' if f16 else f'ff_fwd_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid,
-           _bytes=4.0 * M * (128 + hid))
+           _bytes=4.0 * M * (128 + (hid if H is not None else 0)))
     if out_stats:
         return Y, H, ost
     return Y, H
+
+
+def ff_bwd_rc(dy, x, st, gamma, beta, W1, b1, W2T_scaled, W1T, drop_p, seed_h, seed_o, dR2, dgamma, dbeta, out_amax=None):
+    """RECOMPUTING backward of the fused feed-forward module (csrc/se_ff.hip: ff_bwd_rc_kernel; scaled fp16 planes only):
+    dx = dy + dR2 + LNbwd(dZ W1) with H and dZ recomputed from x -- no [M, hid] tensor is read or written."""
+    L.check_cuda(dy, x, st, W1, W2T_scaled, W1T)
+    dy_amax = getattr(dy, '_se_amax', None)
+    if dy_amax is None or W1.dtype != torch.float16:
+        raise L.SeHipError('ff_bwd_rc: needs scaled fp16 weight planes and the measured maximum of dy (dy._se_amax)')
+    M, hid = x.shape[0], W1.shape[-2]
+    dx = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
+    dx._se_amax = out_amax
+    L.call('se_ff_bwd_rc', L.ptr(dy), L.ptr(x), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2T_scaled),
+           L.ptr(W1T), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF),
+           L.ptr(dR2), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy_amax), L.ptr(W1._se_amax), L.ptr(W2T_scaled._se_amax),
+           L.ptr(W1T._se_amax), L.ptr(out_amax), C.c_int(LN_SEXP), L.stream(), _key='ff_bwd_rc_f16x3', _flops=6.0 * M * 64 * hid,
+           _bytes=4.0 * M * (64 * (4 if dR2 is not None else 3)))
+    return dx
+
+
+def ff_wgrad_rc(x, st, gamma, beta, dy, W1, b1, W2T_scaled, dW1, db1, dW2, db2, drop_p, seed_h, seed_o, alpha=0.5):
+    """RECOMPUTING weight gradients of the module (ff_wgrad_rc_kernel): dW1, db1, dW2, db2 accumulated from x and dy alone."""
+    L.check_cuda(x, st, dy, W1, W2T_scaled, dW1, db1, dW2, db2)
+    dy_amax = getattr(dy, '_se_amax', None)
+    if dy_amax is None or W1.dtype != torch.float16:
+        raise L.SeHipError('ff_wgrad_rc: needs scaled fp16 weight planes and the measured maximum of dy (dy._se_amax)')
+    M, hid = x.shape[0], W1.shape[-2]
+    L.call('se_ff_wgrad_rc', L.ptr(x), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(dy), L.ptr(W1), L.ptr(b1), L.ptr(W2T_scaled),
+           L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), C.c_long(M), C.c_int(hid), C.c_float(drop_p),
+           C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), L.ptr(dy_amax), L.ptr(W1._se_amax),
+           L.ptr(W2T_scaled._se_amax), C.c_int(LN_SEXP), C.c_int(HID_SEXP), L.stream(), _key='ff_wgrad_rc_f16x3',
+           _flops=8.0 * M * 64 * hid, _bytes=4.0 * M * 128)
 
 
 def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precision=None, ln=None, amax_out=(None, None)):

@@ -394,10 +394,14 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0, st=None, want_out_stats=Fa
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
     if GM.LINEAR_PRECISION in (1, 2, 3) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0:
         # one fused kernel: the hidden activations are written once (for the backward) and never re-read here
+        W1p = _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1)
+        # scaled fp16 planes: H is neither stored nor read again (recomputing backward, gemm.ff_bwd_rc / ff_wgrad_rc; inference
+        # never needed it)
+        rc = GM.FF_RECOMPUTE and W1p.dtype == torch.float16
         res = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
-                         _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1), P[f'{p}.fn.fn.net.0.bias'],
+                         W1p, P[f'{p}.fn.fn.net.0.bias'],
                          _w(P, (f'{p}.fn.fn.net.3.weight', 'lin'), lambda: W2), P[f'{p}.fn.fn.net.3.bias'], drop, seed_h,
-                         seed_o, 0.5, hid=W1.shape[0], out_stats=want_out_stats)
+                         seed_o, 0.5, hid=W1.shape[0], out_stats=want_out_stats, store_h=not rc)
         if want_out_stats:
             y, z, ost = res
             return y, (x, st, z, drop, seed_h, seed_o), ost
@@ -423,6 +427,19 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     dr = drop > 0.0
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
     fused = GM.LINEAR_PRECISION in (1, 2, 3) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0
+    if fused and z is None:
+        # recomputing path (scaled fp16): nothing [M, hid]-sized exists -- the input-gradient chain recomputes H from x; so do the
+        # weight gradients (one kernel for dW1, db1, dW2, db2 on the leaf stream, reading x and dy only)
+        W1p, W2Tp = _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: None), _w(P, (f'{p}.fn.fn.net.3.weight', 'T0.5'), lambda: None)
+        b1 = P[f'{p}.fn.fn.net.0.bias']
+        dx = GM.ff_bwd_rc(dy, x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1p, b1, W2Tp,
+                          _w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: None), drop, seed_h, seed_o, dR2,
+                          G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], out_amax=_amax(dy.device))
+        with GM.leaf_stream(dy, x, st, dy._se_amax):
+            GM.ff_wgrad_rc(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], dy, W1p, b1, W2Tp,
+                           G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], G[f'{p}.fn.fn.net.3.weight'],
+                           G[f'{p}.fn.fn.net.3.bias'], drop, seed_h, seed_o, 0.5)
+        return dx
     # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z);  dh = dz @ W1
     if fused:
         # ... and the LayerNorm backward on the rows still in registers: dx = dy (+ dR2) + LNbwd(dz @ W1)
