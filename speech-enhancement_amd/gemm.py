@@ -279,7 +279,12 @@ def unpack_conv_wgrad(dwp, dw, rev_slabs=False, accumulate=False):
                   accumulate=accumulate)
 
 
-FF_RECOMPUTE = __import__('os').environ.get('SE_NO_FF_RECOMPUTE') != '1'      # scaled-fp16 feed-forward: H / dZ recomputed, not stored
+# SE_FF_RECOMPUTE=1 (opt-in): the scaled-fp16 feed-forward module stores no H and writes no dZ -- backward and weight gradients
+# recompute them from X and dY (ff_bwd_rc / ff_wgrad_rc: 0.94 GB instead of 3.6 GB of HBM traffic per module at 518 736 rows,
+# 17 GB less saved state per step at batch 16).  Measured on MI355X it is NOT faster: forward 3.76 -> 3.14 ms per step, backward
+# 4.84 -> 4.75, but the fused recomputing weight gradient takes 8.6 ms against 5.2 ms for the two whole-gradient kernels it
+# replaces (twice their matrix work, VALU- and barrier-bound at one 8-wave workgroup per CU): 77.0 vs 76.3 ms per step.
+FF_RECOMPUTE = __import__('os').environ.get('SE_FF_RECOMPUTE') == '1'
 
 
 def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None, hid=None,

@@ -586,3 +586,56 @@ def test_ff_kernels_fused_layernorm_backward_and_hidden_sizes(G, hid, planes):
     z1, dx1 = gemm.ff_bwd_dgrad(dy, h, w[tag][2], w[tag][3], 0.2, 11, 12, precision=2, ln=(x, st, gam, dR2, dg1, db1))
     assert torch.equal(z1, z0)
     assert relerr(dx1, dx0) < 2e-6 and relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5
+
+
+def test_feed_forward_recompute_kernels():
+    """the recomputing feed-forward backward (ff_bwd_rc: no H read, no dZ written) and the recomputing weight gradients
+    (ff_wgrad_rc: dW1, db1, dW2, db2 from X and dY alone) of the scaled split-fp16 path (opt-in SE_FF_RECOMPUTE=1): dX must equal
+    the stored-H kernel's bit for bit (H is recomputed with the forward's own arithmetic), the weight gradients agree with the
+    fp32-MFMA whole-gradient kernels on the stored H / dZ and with fp64; with and without dropout (same counter-based masks)."""
+    from speech_enhancement_amd import gemm as GM, _lib as L, ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    M = 4096 + 37
+    x = torch.randn(M, 64, device=dev)
+    st = O.row_stats(x, M)
+    g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    W1, b1 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
+    W2, b2 = torch.randn(64, 256, device=dev) * 0.1, torch.randn(64, device=dev) * 0.1
+    p = WeightPlan(dev)
+    p.linear('w1', W1, planes='f16'); p.linear('w2', W2, planes='f16')
+    p.linear_T('w2t', W2, planes='f16', scale=0.5); p.linear_T('w1t', W1, planes='f16')
+    p.run()
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / r.double().abs().max())
+    for drop in (0.0, 0.2):
+        dy = torch.randn(M, 64, device=dev) * 1e-3
+        dy._se_amax = dy.abs().max().reshape(1).clone()
+        y, h = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, drop, 11, 12, 0.5, hid=256)
+        y2, h2 = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, drop, 11, 12, 0.5, hid=256, store_h=False)
+        assert h2 is None and torch.equal(y, y2)
+        dg0, db0, dg1, db1_ = (torch.zeros(64, device=dev) for _ in range(4))
+        dz, dx0 = GM.ff_bwd_dgrad(dy, h, p.out['w2t'], p.out['w1t'], drop, 11, 12, ln=(x, st, g, None, dg0, db0),
+                                  amax_out=(torch.zeros(1, device=dev), torch.zeros(1, device=dev)))
+        dx1 = GM.ff_bwd_rc(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], p.out['w1t'], drop, 11, 12, None, dg1, db1_,
+                           out_amax=torch.zeros(1, device=dev))
+        assert torch.equal(dx1, dx0)
+        assert rel(dg1, dg0) < 2e-6 and rel(db1_, db0) < 2e-6                      # fp32 atomics over workgroups: order noise only
+        assert abs(float(dx1._se_amax) - float(dx1.abs().max())) <= 1e-6 * float(dx1.abs().max())
+        dr = drop > 0
+        dW1a, db1a, dW2a, db2a = (torch.zeros(s, device=dev) for s in ((256, 64), (256,), (64, 256), (64,)))
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH, epilogue=L.EPI_DROP if dr else 0,
+                                         pro_seed=11, epi_seed=12, drop_p=drop, precision=0), h, dy, dW2a, db2a, scale=0.5,
+                          explicit_precision=True)
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, precision=0), x, dz, dW1a, db1a, rowstats=st, ps=g, pb=b,
+                          explicit_precision=True)
+        dW1b, db1b, dW2b, db2b = (torch.zeros(s, device=dev) for s in ((256, 64), (256,), (64, 256), (64,)))
+        GM.ff_wgrad_rc(x, st, g, b, dy, p.out['w1'], b1, p.out['w2t'], dW1b, db1b, dW2b, db2b, drop, 11, 12, 0.5)
+        for got, ref in ((dW1b, dW1a), (db1b, db1a), (dW2b, dW2a), (db2b, db2a)):
+            assert rel(got, ref) < 2e-6
+        if not dr:
+            xl = ((x.double() - st[:, :1].double()) * st[:, 1:].double()) * g.double() + b.double()
+            h64 = xl @ W1.double().t() + b1.double()
+            sg = torch.sigmoid(h64)
+            dz64 = (dy.double() @ (0.5 * W2.double())) * (sg * (1 + h64 * (1 - sg)))
+            assert rel(dW1b, dz64.t() @ xl) < 1e-6 and rel(dW2b, 0.5 * dy.double().t() @ (h64 * sg)) < 1e-6
