@@ -130,3 +130,28 @@ def test_diffuse_batch_parts_on_streams_match_serial(gd):
     assert np.abs(y1 - y2).max() < 1e-5 * max(1e-3, np.abs(y1).max())
     ref = gd['predict_fast'].reshape(-1)
     assert rms(y2[0], ref) < 2e-4 * max(1e-3, float(np.abs(ref).max()))
+
+
+@pytest.mark.gpu
+def test_diffuse_bench_size_parts_on_streams_match_serial():
+    """BASELINE config 5 at its benchmark size -- batch 32 x 2 s clips (15.8 GB conditioner cache), the 6-step fast schedule --:
+    the batch cut into 2 and 3 independent parts on separate HIP streams returns what the serial order returns (clips never
+    interact: GroupNorm is per sample), clip by clip, and permuting the clips permutes the outputs (no cross-clip leakage)."""
+    import types
+    import speech_enhancement_amd as S
+    m = _model(S)
+    cfg = types.SimpleNamespace(NOISE_SCHEDULE=NOISE_SCHEDULE, INFERENCE_NOISE_SCHEDULE=FAST, N_FFT=400, HOP_SAMPLES=100)
+    sched = S.inference_schedule(cfg, fast_sampling=True)
+    rng = np.random.default_rng(7)
+    B, Ls = 32, 32000
+    x = (0.1 * rng.standard_normal((B, Ls))).astype(np.float32) * np.linspace(0.3, 1.5, B, dtype=np.float32)[:, None]
+    nz = rng.standard_normal((len(FAST) - 1, B, Ls + 100)).astype(np.float32)
+    y1 = S.predict_diffuse(m, cfg, x, *sched, noises=nz, streams=1)           # noise draws: [steps - 1, B, 100 T], T = Ls / 100 + 1
+    assert y1.shape[0] == B and np.isfinite(y1).all()
+    scale = max(1e-3, float(np.abs(y1).max()))
+    for ns in (2, 3):
+        yn = S.predict_diffuse(m, cfg, x, *sched, noises=nz, streams=ns)
+        assert np.abs(yn - y1).max() < 1e-5 * scale, (ns, float(np.abs(yn - y1).max()))
+    perm = rng.permutation(B)
+    yp = S.predict_diffuse(m, cfg, x[perm], *sched, noises=nz[:, perm], streams=2)
+    assert np.abs(yp - y1[perm]).max() < 1e-5 * scale
