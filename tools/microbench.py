@@ -20,7 +20,7 @@ def cmd(fn):
 
 @cmd
 def attn_bench(argv):
-    sys.argv = ['attn_bench'] + list(argv)
+    __import__('sys').argv = ['attn_bench'] + list(argv)
     """micro-benchmark of the attention kernels at the bench shapes (B=16); SE_ATTN_BWD=2 selects the v2 backward."""
     import os, sys, time, torch
     from speech_enhancement_amd import attention as A
@@ -56,7 +56,7 @@ def attn_bench(argv):
 
 @cmd
 def attn_fwd_es(argv):
-    sys.argv = ['attn_fwd_es'] + list(argv)
+    __import__('sys').argv = ['attn_fwd_es'] + list(argv)
     """attention forward with the relative-position table split on the fly vs pre-split (se_attn_fwd_es), B = 16 shapes"""
     import os, sys, time, torch
     from speech_enhancement_amd import attention as A
@@ -82,7 +82,7 @@ def attn_fwd_es(argv):
 
 @cmd
 def attn_prof(argv):
-    sys.argv = ['attn_prof'] + list(argv)
+    __import__('sys').argv = ['attn_prof'] + list(argv)
     """one attention forward + backward per axis at the bench shapes (B=16), for rocprofv3 counter passes"""
     import os, sys, torch
     from speech_enhancement_amd import attention as A
@@ -101,7 +101,7 @@ def attn_prof(argv):
 
 @cmd
 def bw(argv):
-    sys.argv = ['bw'] + list(argv)
+    __import__('sys').argv = ['bw'] + list(argv)
     import torch, time
     M = 16 * 321 * 101
     for shape in ((M, 256), (M, 64)):
@@ -116,7 +116,7 @@ def bw(argv):
 
 @cmd
 def conv_one(argv):
-    sys.argv = ['conv_one'] + list(argv)
+    __import__('sys').argv = ['conv_one'] + list(argv)
     import os, sys, torch
     from speech_enhancement_amd import gemm as GM, _lib as L, layers as LY
     B, T, Fq = 16, 321, 201
@@ -151,7 +151,7 @@ def conv_one(argv):
 
 @cmd
 def cpu_overhead(argv):
-    sys.argv = ['cpu_overhead'] + list(argv)
+    __import__('sys').argv = ['cpu_overhead'] + list(argv)
     """host-side enqueue time of one train step vs its GPU time"""
     import os, sys, time, types, torch
     import speech_enhancement_amd as S
@@ -181,7 +181,7 @@ def cpu_overhead(argv):
 
 @cmd
 def dw_bench(argv):
-    sys.argv = ['dw_bench'] + list(argv)
+    __import__('sys').argv = ['dw_bench'] + list(argv)
     import os, sys, time, torch
     from speech_enhancement_amd import ops as O, attention as A
     B, T, Fq = 16, 321, 101
@@ -202,7 +202,7 @@ def dw_bench(argv):
 
 @cmd
 def ff_one(argv):
-    sys.argv = ['ff_one'] + list(argv)
+    __import__('sys').argv = ['ff_one'] + list(argv)
     """fused feed-forward forward / input-gradient kernels at the benchmark shape (M = 16 * 321 * 101 tokens, hidden 256, pre-split weights)"""
     import os, sys, time, torch
     from speech_enhancement_amd import gemm as GM, ops as O
@@ -232,7 +232,7 @@ def ff_one(argv):
 
 @cmd
 def gemm_bench(argv):
-    sys.argv = ['gemm_bench'] + list(argv)
+    __import__('sys').argv = ['gemm_bench'] + list(argv)
     """micro-benchmark of the tap-GEMM at the Conformer linear-layer shapes (M = 16*321*101 tokens)."""
     import os, sys, time, torch
     from speech_enhancement_amd import gemm as GM, _lib as L
@@ -289,7 +289,7 @@ def gemm_bench(argv):
 
 @cmd
 def gemm_one(argv):
-    sys.argv = ['gemm_one'] + list(argv)
+    __import__('sys').argv = ['gemm_one'] + list(argv)
     """one Conformer-shaped linear GEMM, for rocprofv3 --pmc runs: args C N [pro] [epi] [prec]"""
     import os, sys, torch
     from speech_enhancement_amd import gemm as GM, _lib as L
@@ -319,7 +319,7 @@ def gemm_one(argv):
 
 @cmd
 def infer_graph(argv):
-    sys.argv = ['infer_graph'] + list(argv)
+    __import__('sys').argv = ['infer_graph'] + list(argv)
     """eager vs HIP-graph batch-1 inference latency (2 s and 10 s clips)"""
     import os, sys, time, types, numpy as np, torch
     import speech_enhancement_amd as S
@@ -342,7 +342,7 @@ def infer_graph(argv):
 
 @cmd
 def k64_one(argv):
-    sys.argv = ['k64_one'] + list(argv)
+    __import__('sys').argv = ['k64_one'] + list(argv)
     """row-panel kernel (K = 64 -> N = 192 qkv / 256 pointwise-GLU, LayerNorm prologue, pre-split weights) at the benchmark size"""
     import os, sys, time, torch
     from speech_enhancement_amd import gemm as GM, ops as O, _lib as L
@@ -368,7 +368,7 @@ def k64_one(argv):
 
 @cmd
 def lin_wgrad(argv):
-    sys.argv = ['lin_wgrad'] + list(argv)
+    __import__('sys').argv = ['lin_wgrad'] + list(argv)
     """token-wise (row-GEMM) weight gradients of a Conformer block: full-tile kernel (wgrad_lin_kernel) vs the per-block kernel"""
     import os, sys, time, torch
     from speech_enhancement_amd import gemm as GM, _lib as L
@@ -406,7 +406,7 @@ def lin_wgrad(argv):
 
 @cmd
 def ln_bwd(argv):
-    sys.argv = ['ln_bwd'] + list(argv)
+    __import__('sys').argv = ['ln_bwd'] + list(argv)
     """se_gemm_ln_bwd (input-gradient GEMM + LayerNorm backward on the accumulators) vs the two-kernel form at bench size"""
     import os, sys, time, torch
     from speech_enhancement_amd import gemm as GM, ops as O
@@ -432,7 +432,7 @@ def ln_bwd(argv):
 
 @cmd
 def mem(argv):
-    sys.argv = ['mem'] + list(argv)
+    __import__('sys').argv = ['mem'] + list(argv)
     """peak / reserved device memory of the train step over a few steps (stream concurrency on unless SE_NO_* are set)"""
     import sys, os, types, torch
     import speech_enhancement_amd as S
@@ -454,7 +454,7 @@ def mem(argv):
 
 @cmd
 def norm_bwd(argv):
-    sys.argv = ['norm_bwd'] + list(argv)
+    __import__('sys').argv = ['norm_bwd'] + list(argv)
     """InstanceNorm+PReLU backward (se_norm_prelu_bwd) at the dense-block shapes: time per call and algorithmic GB/s."""
     import os, sys, time
     import torch
@@ -479,7 +479,7 @@ def norm_bwd(argv):
 
 @cmd
 def pesq_overlap(argv):
-    sys.argv = ['pesq_overlap'] + list(argv)
+    __import__('sys').argv = ['pesq_overlap'] + list(argv)
     """PESQ side channel: step time with a slow label provider (sleep) vs labels supplied"""
     import os, sys, time, types, torch
     import speech_enhancement_amd as S
@@ -506,7 +506,7 @@ def pesq_overlap(argv):
 
 @cmd
 def rowgemm_one(argv):
-    sys.argv = ['rowgemm_one'] + list(argv)
+    __import__('sys').argv = ['rowgemm_one'] + list(argv)
     """fp32-MFMA row GEMMs with a residual epilogue at the benchmark size: attention out-projection (64 -> 64, bias + dropout +
     residual + row statistics) and pointwise conv 2 (BatchNorm-affine + Swish prologue, 128 -> 64, bias + residual + row statistics)"""
     import os, sys, time, torch
@@ -535,7 +535,7 @@ def rowgemm_one(argv):
 
 @cmd
 def wgrad_one(argv):
-    sys.argv = ['wgrad_one'] + list(argv)
+    __import__('sys').argv = ['wgrad_one'] + list(argv)
     """micro-benchmark of the conv weight-gradient kernel (dense layer shape) and of the split-bf16 conv forward."""
     import os, sys, time, torch
     from speech_enhancement_amd import gemm as GM, _lib as L, layers as LY
@@ -568,7 +568,7 @@ def wgrad_one(argv):
 
 @cmd
 def aten_prof(argv):
-    sys.argv = ['aten_prof'] + list(argv)
+    __import__('sys').argv = ['aten_prof'] + list(argv)
     """count the aten ops (PyTorch glue) in one train step"""
     import os, sys, torch
     import speech_enhancement_amd as S
