@@ -350,9 +350,13 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 // plane and thread instead of two fp32 loads + a 36-instruction split per tap step in every workgroup.
 // F16 (precision 3): NPL = 2 planes of SCALED fp16 (hi, lo), three fp16 MFMAs per product (se_gemm_dev.h); the accumulators are
 // multiplied by 2^-(sexp_A + sexp_W) (exact) before the epilogue.
-template <int NPL, bool WPL = false, bool F16 = false, int OCC = 3>
+// MT = 2: 256-row tiles, every wave owns TWO 32-row blocks (rows wave * 32 and 128 + wave * 32): the B fragments of a tap are read
+// from LDS once and feed both -- 16 fragment reads per 24 MFMAs instead of 12 per 12 (at one read per MFMA the LDS pipe saturates
+// together with the matrix pipe: 48 KB of fragment reads per workgroup and tap = 384 cycles at 128 B/clk, and 48 MFMAs on 4 SIMDs
+// = 384 cycles).
+template <int NPL, bool WPL = false, bool F16 = false, int OCC = 3, int MT = 1>
 __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
-  constexpr int BM = 128, BN = 64, BK = 32, SA = 40, HR = BM + 2;
+  constexpr int BM = 128 * MT, BN = 64, BK = 32, SA = 40, HR = BM + 2;
   constexpr int PA = HR * SA, PB = BN * SA;
   __shared__ __attribute__((aligned(16))) __bf16 Ap[NPL * PA];
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
@@ -372,9 +376,13 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
   bool wok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) { int n = by * 64 + r0 + 32 * i; wok[i] = n < d.N; wrow[i] = (unsigned)n * (unsigned)d.ldw; }
-  // frequency-edge masks of this lane's output pixel (fragment row lane & 31 of the wave's 32 rows)
-  const int fpix = (m0 + wave * 32 + (lane & 31)) % d.Fo;
-  const bool edgeL = fpix == 0, edgeR = fpix == d.Fo - 1;
+  // frequency-edge masks of this lane's output pixel (fragment row lane & 31 of the wave's 32 rows), per row block
+  bool edgeL[MT], edgeR[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int fpix = (m0 + mt * 128 + wave * 32 + (lane & 31)) % d.Fo;
+    edgeL[mt] = fpix == 0; edgeR[mt] = fpix == d.Fo - 1;
+  }
   const int nchunk = (d.C + BK - 1) / BK, ngrp = d.ntap / 3;
   const int NI = nchunk * d.ntap;
   const unsigned thr = 0u;
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
     sa = exp2i_(ea); sw = exp2i_(ew); unscale = exp2i_(-ea - ew);
   }
 
-  float4 ra[4], rh, rb[2];
+  float4 ra[4 * MT], rh, rb[2];
   // (chunk, triple) / (chunk, tap) of the tile being prefetched, advanced by increments (no divisions in the loop)
   int a_chunk = 0, a_gi = 0, b_chunk = 0, b_tap = 0;
   // range-checked descriptors: output channels n >= N read as zeros; rows outside the batch entry and a channel chunk past C
@@ -400,7 +408,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
     const int q0 = m0 - 1 + d.dt[3 * gi] * d.Fo;          // flattened source pixel of halo row 0
     const unsigned cb = c < d.C ? (unsigned)c * 4u : BUF_OOB_;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4 * MT; ++i) {
       const int q = q0 + 1 + r0 + 32 * i;
       ra[i] = buf_load4_(Ar, (unsigned)q < (unsigned)Mb ? (unsigned)q * (unsigned)d.lda * 4u + cb : BUF_OOB_);
     }
@@ -440,9 +448,11 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
     }
   };
 
-  f32x16 acc0, acc1;
+  f32x16 acc[MT][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
   const bool vec_ep = epilogue_vec_ok(d);
   if (vec_ep) stage_bias(g, by, bias_s);
   load_a();
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
   for (int gq = 0; gq < nchunk * ngrp; ++gq, gi = (gi + 1 == ngrp ? 0 : gi + 1)) {
     // stage the halo tile of this (chunk, triple); the previous iteration's trailing barrier freed Ap
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_store_x<NPL, F16>(ra[i], sa, &Ap[(1 + r0 + 32 * i) * SA + kq * 4], PA);
+    for (int i = 0; i < 4 * MT; ++i) split_store_x<NPL, F16>(ra[i], sa, &Ap[(1 + r0 + 32 * i) * SA + kq * 4], PA);
     // every lane consumes rh here (the lanes that do not store it too): a load still in flight on one path makes the
     // compiler drain ALL loads before the register is reused
     asm volatile("" :: "v"(rh.x), "v"(rh.y), "v"(rh.z), "v"(rh.w));
@@ -477,43 +487,56 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
         if (s3 == 0) load_a();
       }
       const int df = d.df[3 * gi + s3];
-      const bool kill = (df < 0 && edgeL) || (df > 0 && edgeR);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const int ao = (wave * 32 + 1 + df) * SA + frag + 16 * ks, bo = frag + 16 * ks;
-        bf16x8 af[NPL], bf0[NPL], bf1[NPL];
+        const int bo = frag + 16 * ks;
+        bf16x8 bf0[NPL], bf1[NPL];
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
-          af[q] = *reinterpret_cast<const bf16x8*>(&Ap[q * PA + ao]);
           bf0[q] = *reinterpret_cast<const bf16x8*>(&Bp[q * PB + bo]);
           bf1[q] = *reinterpret_cast<const bf16x8*>(&Bp[q * PB + 32 * SA + bo]);
         }
-        if (df != 0) {
 #pragma unroll
-          for (int q = 0; q < NPL; ++q) {
-            f32x4 z = kill ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(&af[q]);
-            af[q] = *reinterpret_cast<bf16x8*>(&z);
+        for (int mt = 0; mt < MT; ++mt) {
+          const int ao = (mt * 128 + wave * 32 + 1 + df) * SA + frag + 16 * ks;
+          const bool kill = (df < 0 && edgeL[mt]) || (df > 0 && edgeR[mt]);
+          bf16x8 af[NPL];
+#pragma unroll
+          for (int q = 0; q < NPL; ++q) af[q] = *reinterpret_cast<const bf16x8*>(&Ap[q * PA + ao]);
+          if (df != 0) {
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+              f32x4 z = kill ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(&af[q]);
+              af[q] = *reinterpret_cast<bf16x8*>(&z);
+            }
           }
+#pragma unroll
+          for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+            for (int qa = 0; qa <= ord; ++qa) {
+              const int qb = ord - qa;
+              acc[mt][0] = mfma32_<F16>(af[qa], bf0[qb], acc[mt][0]);
+              acc[mt][1] = mfma32_<F16>(af[qa], bf1[qb], acc[mt][1]);
+            }
         }
-#pragma unroll
-        for (int ord = NPL - 1; ord >= 0; --ord)
-#pragma unroll
-          for (int qa = 0; qa <= ord; ++qa) {
-            const int qb = ord - qa;
-            acc0 = mfma32_<F16>(af[qa], bf0[qb], acc0);
-            acc1 = mfma32_<F16>(af[qa], bf1[qb], acc1);
-          }
       }
       __syncthreads();
     }
   }
   if (F16) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[mt][0][r] *= unscale; acc[mt][1][r] *= unscale; }
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;
-  if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
-  else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (mt) __syncthreads();                   // the statistics epilogue folds the waves through `red`: one row block at a time
+    if (m0 + mt * 128 >= Mb) break;            // (block-uniform) the second row block of the last tile may be empty
+    if (vec_ep) gemm_epilogue_vec(g, acc[mt][0], acc[mt][1], m0 + mt * 128, by, b, cs, 36, thr, inv_keep, red, bias_s);
+    else gemm_epilogue(g, acc[mt][0], acc[mt][1], m0 + mt * 128, by, b, red, thr, inv_keep);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -797,7 +820,16 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
         // two planes instead of three leave room for 4 waves per SIMD (115 VGPRs, 33 KB of LDS): 1.5 - 7 % (949 -> 934 us at
         // Cin = 256, 226 -> 211 us at Cin = 64); SE_CONV3_OCC3=1 restores the 3-wave build for A/B runs
         static const bool occ4 = getenv("SE_CONV3_OCC3") == nullptr;
-        if (d->w_planes && occ4) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 4>), grid, block, 0, s, g);
+        // 256-row tiles (two row blocks per wave, B fragments shared) pay on the deep layers only: Cin = 256: 959 -> 904 us,
+        // Cin = 64: 197 -> 211 us (tools/microbench.py conv_one); SE_CONV3_NO_MT2=1: always 128-row tiles
+        static const bool mt2 = getenv("SE_CONV3_NO_MT2") == nullptr;
+        if (d->w_planes && mt2 && d->C >= 192) {
+          g.tiles = cdiv(Mb, 256);
+          g.nouter = d->B * g.tiles;
+          dim3 grid2((unsigned)(ncols * (((long)g.nouter + 7) / 8 * 8)));
+          hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 2, 2>), grid2, block, 0, s, g);
+        }
+        else if (d->w_planes && occ4) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 4>), grid, block, 0, s, g);
         else if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((conv3_bf16_kernel<2, false, true>), grid, block, 0, s, g);
       }
