@@ -18,17 +18,18 @@ static __device__ __forceinline__ long tok_of(const SeqGeom& g, int s, int p) {
 }
 
 constexpr int DW_C = 128, DW_K = 31;
-// output rows are written once and read by the NEXT kernel (266 - 531 MB per launch: nothing of them survives in L2 / MALL)
-// -> non-temporal stores: 107 -> 103 us (time axis), 121 -> 111 us (frequency axis), input gradient 105 -> 96 / 116 -> 107 us
-#ifndef SE_DW_NO_NT
+// Non-temporal stores of the output rows (SE_DW_NT builds): faster in an isolated loop (107 -> 103 us on the time axis, 121 -> 111
+// us on the frequency axis, tools/microbench.py dw_bench) but SLOWER inside the step (rocprofv3, serial order: 126.5 -> 136.6 us,
+// fused input gradient 254 -> 274 us; profiles/r03a vs r03b): the consumer kernel starts right behind and finds part of a
+// normally-stored 266 MB result in the 256 MB MALL.  Plain stores stay.
+#ifdef SE_DW_NT
 #define DW_STORE(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define DW_STORE(p, v) (*(p) = (v))
 #endif
-// non-temporal LOADS of the tiles: slower in the convolution (103 -> 122 us: neighbouring tiles re-read 30 halo rows out of L2),
-// faster in the weight gradient (130 -> 123, 125 -> 118 us: its X tile is read by one workgroup only and dY streams past)
+// non-temporal LOADS of the tiles: slower in the convolution (103 -> 122 us: neighbouring tiles re-read 30 halo rows out of L2);
+// in the weight gradient 130 -> 123 us in isolation, not re-measured inside the step: plain loads there too
 #define DW_LOAD4(p) (*reinterpret_cast<const f32x4*>(p))
-#define DW_LOAD4_NT(p) __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p))
 
 struct DwArgs {
   SeqGeom g;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(512, 4) void dwconv_wgrad_kernel(DwWgradArgs a) {
     for (int k = 0; k < NLD; ++k) {
       const int row = (tid >> 5) + 16 * k, p = p0 - 15 + row;
       const float* __restrict__ Xk = Xt + (long)(16 * k) * rs;
-      ld[k] = (row < ROWS && p >= 0 && p < n) ? __builtin_bit_cast(float4, DW_LOAD4_NT(Xk + ld_off)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ld[k] = (row < ROWS && p >= 0 && p < n) ? __builtin_bit_cast(float4, DW_LOAD4(Xk + ld_off)) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 #pragma unroll
