@@ -370,6 +370,8 @@ int se_mask_tail_bwd(const float* U, int ldu, const float* wb, const float* slop
 /* GLU backward (models/conformer.py:30-37) */
 int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, int H, void* stream);
 int se_glu_bwd_amax(const float* Z, const float* dU, float* dZ, long M, int H, float* amax_out, void* stream);   /* + max |dZ| */
+/* MergeBlock gate of the TSC-diffusion hybrid (models/tsc_diffusion.py:34-35): Y [M][2C] (gate | filter) -> G [M][C] = sigmoid(gate) tanh(filter) */
+int se_gate_tanh(const float* Y, float* G, long M, int C, void* stream);
 /* loss reductions of train_gan (core/function.py:251-258) and their gradient seeds (`up` = device scalars) */
 int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream);
 int se_spec_loss_bwd(const float* A, const float* Bp, float* dA, const float* up, float cmag, float cri, long n,

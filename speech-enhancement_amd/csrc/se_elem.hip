@@ -254,6 +254,22 @@ __global__ void glu_bwd_kernel(const float* __restrict__ Z, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// MergeBlock gate of the TSC-diffusion hybrid (models/tsc_diffusion.py:34-35): Y [M, C] (gate | filter halves, ld 2C) ->
+// G [M, C] = sigmoid(gate) * tanh(filter)
+__global__ void gate_tanh_kernel(const float* __restrict__ Y, float* __restrict__ G, long M, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of C per thread
+  const int cq = C >> 2;
+  if (idx >= M * cq) return;
+  const long row = idx / cq;
+  const int q = (int)(idx - row * cq);
+  const float4 a = *reinterpret_cast<const float4*>(Y + row * 2 * C + q * 4);
+  const float4 f = *reinterpret_cast<const float4*>(Y + row * 2 * C + C + q * 4);
+  auto th = [](float x) { const float e = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x)); const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e); return x < 0.f ? -t : t; };
+  *reinterpret_cast<float4*>(G + row * C + q * 4) = make_float4(sigmoidf_(a.x) * th(f.x), sigmoidf_(a.y) * th(f.y),
+                                                                sigmoidf_(a.z) * th(f.z), sigmoidf_(a.w) * th(f.w));
+}
+
+// ---------------------------------------------------------------------------------------------
 // spectral losses on planes (mag, re, im, -): sums[0] += sum (mag-mag')^2, sums[1] += sum (re-re')^2 + (im-im')^2
 __global__ __launch_bounds__(256) void spec_loss_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
                                                         double* __restrict__ sums, long n) {
@@ -534,6 +550,11 @@ extern "C" int se_glu_bwd_amax(const float* Z, const float* dU, float* dZ, long 
   SE_REQUIRE(Z && dU && dZ && M > 0 && H > 0 && (H % 4) == 0, "glu_bwd: bad arguments");
   EW_LAUNCH(glu_bwd_kernel, M * (H / 4), stream, Z, dU, dZ, M, H, amax_out);
   return se_check_launch("se_glu_bwd");
+}
+extern "C" int se_gate_tanh(const float* Y, float* G, long M, int C, void* stream) {
+  SE_REQUIRE(Y && G && M > 0 && C > 0 && (C % 4) == 0, "gate_tanh: bad arguments");
+  EW_LAUNCH(gate_tanh_kernel, M * (C / 4), stream, Y, G, M, C);
+  return se_check_launch("se_gate_tanh");
 }
 extern "C" int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream) {
   SE_REQUIRE(A && Bp && sums && n > 0, "spec_loss: bad arguments");

@@ -224,11 +224,13 @@ def build_generator_plan(P, device):
             plan.conv_fwd((n, 'fwd'), P[n], rev=True, planes=c3)
             plan.conv_dgrad((n, 'dgrad'), P[n], rev=True, planes=c3)
 
-    e = 'dense_encoder'
-    plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
-    dense(f'{e}.dilated_dense')
-    plan.conv_fwd((f'{e}.conv_2.0.weight', 'fwd'), P[f'{e}.conv_2.0.weight'], planes=c3)          # strided: generic split kernel
-    plan.conv_dgrad((f'{e}.conv_2.0.weight', 'dgrad'), P[f'{e}.conv_2.0.weight'], planes=c3)
+    for e in ('dense_encoder', 'dense_encoder_noisy'):       # (the second one: TSC-diffusion hybrid, models/tsc_diffusion.py:47)
+        if f'{e}.conv_1.0.weight' not in P:
+            continue
+        plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
+        dense(f'{e}.dilated_dense')
+        plan.conv_fwd((f'{e}.conv_2.0.weight', 'fwd'), P[f'{e}.conv_2.0.weight'], planes=c3)          # strided: generic split kernel
+        plan.conv_dgrad((f'{e}.conv_2.0.weight', 'dgrad'), P[f'{e}.conv_2.0.weight'], planes=c3)
     for dec, last in (('mask_decoder', 'conv_1'), ('complex_decoder', 'conv')):
         dense(f'{dec}.dense_block')
         n = f'{dec}.sub_pixel.conv.weight'
@@ -323,8 +325,7 @@ TAPS_1x3 = [(0, -1), (0, 0), (0, 1)]
 TAPS_1x2 = [(0, 0), (0, 1)]
 
 
-def encoder_fwd(P, xin, B, T, Fq):
-    p = 'dense_encoder'
+def encoder_fwd(P, xin, B, T, Fq, p='dense_encoder'):
     ctx = {'xin': xin}
     R0, st0 = conv_fwd(xin, B, T, Fq, 4, 0, 4,
                        _w(P, (f'{p}.conv_1.0.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv_1.0.weight'], C_pad=4)),

@@ -280,6 +280,12 @@ def glu_bwd(Z, dU, M, H, amax=None):
     return dZ
 
 
+def gate_tanh(Y, M, C_):
+    G = torch.empty(M, C_, device=Y.device, dtype=torch.float32)
+    L.call('se_gate_tanh', L.ptr(Y), L.ptr(G), _l(M), _i(C_), L.stream())
+    return G
+
+
 def spec_loss(A, B_, sums):
     L.call('se_spec_loss', L.ptr(A), L.ptr(B_), L.ptr(sums), _l(A.numel() // 4), L.stream())
     return sums

@@ -80,3 +80,14 @@ def long_clip(L: int, seed: int) -> np.ndarray:
     env = 0.5 * (1.0 + np.sin(2 * np.pi * 1.7 * n))
     x = sum((0.08 / h) * np.sin(h * ph + 0.3 * h) for h in range(1, 13)) * env
     return (x + 0.03 * rs.randn(L)).astype(np.float32)
+
+
+def tsc_state():
+    """formula weights of the TSC-diffusion hybrid (models/tsc_diffusion.py TSCNet; names / shapes: tsc_state_spec.json)"""
+    from collections import OrderedDict
+    with open(os.path.join(HERE, 'tsc_state_spec.json')) as f:
+        spec = json.load(f)
+    sd = OrderedDict()
+    for name, shape, dtype, base in spec:
+        sd[name] = formula_tensor('tscd.' + name, tuple(shape), dtype, base)
+    return sd
