@@ -37,6 +37,8 @@ enum {
   SE_EPI_SHUFFLE2 = 64,  /* sub-pixel: channel r*No+c -> pixel 2f+r, channel c (N = 2*No) */
   SE_EPI_DROP = 128,     /* dropout on the (bias-added) result, mask = hash(epi_seed, m*N + n) (nn.Dropout after a
                             Linear, conformer.py:94,141); in se_gemm_tap_wgrad: the same mask applied to dY      */
+  SE_EPI_GLU_GATE = 2048,/* with SE_EPI_GLU: AUX receives only the gate half g [M][No] (ldx >= No) instead of the pre-GLU [a | g]:
+                            the GLU backward needs (u = a sigmoid(g), g) only -- d a = dU sigmoid(g), d g = dU u (1 - sigmoid(g)) */
   SE_EPI_ROWSTATS = 512  /* N == 64, row GEMM: AUX [M][2] receives (mean, rstd) over the 64 channels of every RESULT row,
                             eps = 1e-5 -- the statistics of the nn.LayerNorm(64) that reads this output next
                             (conformer.py:67,162), i.e. se_row_stats without its pass over the rows                  */
@@ -323,10 +325,11 @@ int se_attn_bwd_phase(const float* QKV, const float* E, const float* O, const fl
 int se_dwconv31(const float* X, const float* W, const float* bias, float* Y, double* stats, int flip,
                 int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, void* stream);
 /* input gradient of DepthWiseConv1d fused with the backward of the GLU in front of it (conformer.py:164-166 backwards):
- * dU = flipped-tap depthwise conv of dH [tokens][128] (never written), dZ [tokens][256] = (dU sigmoid(g), dU a sigmoid(g)(1 - sigmoid(g)))
- * with Z = (a | g) the pre-GLU activations; amax_out (may be NULL): raised to max |dZ| */
-int se_dwconv31_glu_bwd(const float* dH, const float* W, const float* Z, float* dZ, float* amax_out, int nseq, int n,
-                        int inner, long outer_stride, long inner_stride, long pos_stride, void* stream);
+ * dU = flipped-tap depthwise conv of dH [tokens][128] (never written), dZ [tokens][256] = (dU sigmoid(g), dU u (1 - sigmoid(g)))
+ * with U = a sigmoid(g) the forward GLU result and G = the gate half g of the pre-GLU activations, both [tokens][128] (a GEMM
+ * with SE_EPI_GLU | SE_EPI_GLU_GATE writes exactly these two); amax_out (may be NULL): raised to max |dZ| */
+int se_dwconv31_glu_bwd(const float* dH, const float* W, const float* U, const float* G, float* dZ, float* amax_out, int nseq,
+                        int n, int inner, long outer_stride, long inner_stride, long pos_stride, void* stream);
 /* weight / bias gradient (accumulated into dW [128][31], dbias [128]); ws = workspace of
  * se_dwconv31_wgrad_workspace_bytes() bytes (per-workgroup partial sums, reduced in a fixed order: deterministic) */
 size_t se_dwconv31_wgrad_workspace_bytes(void);
@@ -370,6 +373,8 @@ int se_mask_tail_bwd(const float* U, int ldu, const float* wb, const float* slop
 /* GLU backward (models/conformer.py:30-37) */
 int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, int H, void* stream);
 int se_glu_bwd_amax(const float* Z, const float* dU, float* dZ, long M, int H, float* amax_out, void* stream);   /* + max |dZ| */
+/* the same from the GLU result U = a sigmoid(g) [M][H] and the gate half G [M][H] (SE_EPI_GLU | SE_EPI_GLU_GATE keeps only these) */
+int se_glu_bwd_gate(const float* U, const float* G, const float* dU, float* dZ, long M, int H, float* amax_out, void* stream);
 /* MergeBlock gate of the TSC-diffusion hybrid (models/tsc_diffusion.py:34-35): Y [M][2C] (gate | filter) -> G [M][C] = sigmoid(gate) tanh(filter) */
 int se_gate_tanh(const float* Y, float* G, long M, int C, void* stream);
 /* loss reductions of train_gan (core/function.py:251-258) and their gradient seeds (`up` = device scalars) */

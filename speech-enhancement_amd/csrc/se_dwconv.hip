@@ -34,9 +34,10 @@ constexpr int DW_C = 128, DW_K = 31;
 struct DwArgs {
   SeqGeom g;
   const float* X; const float* W; const float* bias; float* Y; double* stats; int flip;
-  // GLU variant (input gradient of the conv module, conformer.py:164-166 backwards): Z = the pre-GLU activations [tokens][256]
-  // (a | gate), Y = dZ [tokens][256]; the depthwise input gradient dU never goes to memory
-  const float* Z; float* amax_out;
+  // GLU variant (input gradient of the conv module, conformer.py:164-166 backwards): U = the GLU result a sigmoid(g) (the conv's
+  // forward input) and Z = the gate half g, both [tokens][128] in the conv operands' layout; Y = dZ [tokens][256]; the depthwise
+  // input gradient dU never goes to memory
+  const float* Z; float* amax_out; const float* U;
 };
 
 // 512 threads: lane pair-channel cl = tid & 63 (2 channels), position slot ps = tid >> 6 (8 slots x PPS positions).
@@ -50,7 +51,8 @@ struct DwArgs {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // GLU: the epilogue applies the backward of GLU (a * sigmoid(gate)) to the result on its way out: dZ[:, c] = dU sigmoid(g),
-// dZ[:, 128 + c] = dU a sigmoid(g) (1 - sigmoid(g)) -- the stand-alone glu_bwd pass (read Z and dU, write dZ: 1.33 GB per block at
+// dZ[:, 128 + c] = dU a sigmoid(g) (1 - sigmoid(g)) = dU u (1 - sigmoid(g)) with u = a sigmoid(g) the forward GLU result (so the
+// pre-GLU value half a is never stored: 266 MB less written by the pw1 GEMM and read here, per block) -- the stand-alone glu_bwd pass (read Z and dU, write dZ: 1.33 GB per block at
 // batch 16, 214 us x 8 per step) and the write + re-read of dU disappear; max |dZ| is raised for the scaled-fp16 consumers.
 template <int PPS, bool GLU = false>
 __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
@@ -140,9 +142,11 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
     for (int o = 0; o < PPS; ++o) asm volatile("" : "+v"(acc[o]));
     const unsigned st_off = (unsigned)(ps * PPS) * rs32 + (unsigned)cl * 2u;
     if constexpr (GLU) {
-      // rows of Z / dZ are 256 floats: twice the row stride of the conv operands; positions past n read row n - 1 (unconditional
-      // loads, in groups of GG positions: all loads of a group in flight before the first is used) and store nothing
-      const float* __restrict__ Zt = a.Z + 2 * (base * DW_C + (long)p0 * rs) + 2 * (long)(ps * PPS) * rs + cl * 2;
+      // rows of dZ are 256 floats: twice the row stride of the conv operands (U, gate); positions past n read row n - 1
+      // (unconditional loads, in groups of GG positions: all loads of a group in flight before the first is used), store nothing
+      const long toff = base * DW_C + (long)p0 * rs + (long)(ps * PPS) * rs + cl * 2;
+      const float* __restrict__ Ut = a.U + toff;
+      const float* __restrict__ Zt = a.Z + toff;
       float* __restrict__ Dt = a.Y + 2 * (base * DW_C + (long)p0 * rs) + 2 * (long)(ps * PPS) * rs + cl * 2;
       const int plast = n - 1 - (p0 + ps * PPS);            // last valid position offset of this slot (may be negative)
       constexpr int GG = 2;
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
         for (int j = 0; j < GG; ++j) {
           if (o0 + j < PPS) {
             int oc = o0 + j; oc = oc > plast ? plast : oc; oc = oc < 0 ? 0 : oc;
-            const float* zp = (plast >= 0 ? Zt : a.Z) + 2 * (long)oc * rs;       // an all-padding slot reads a valid dummy row
-            za[j] = *reinterpret_cast<const f32x2*>(zp);
-            zg[j] = *reinterpret_cast<const f32x2*>(zp + DW_C);
+            const long ro = (long)oc * rs;                   // an all-padding slot reads a valid dummy row
+            za[j] = *reinterpret_cast<const f32x2*>((plast >= 0 ? Ut : a.U) + ro);
+            zg[j] = *reinterpret_cast<const f32x2*>((plast >= 0 ? Zt : a.Z) + ro);
           }
         }
 #pragma unroll
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
             for (int e = 0; e < 2; ++e) {
               const float sg = sigmoidf_(zg[j][e]);
               da[e] = acc[o][e] * sg;
-              dg[e] = acc[o][e] * za[j][e] * sg * (1.f - sg);
+              dg[e] = acc[o][e] * za[j][e] * (1.f - sg);
               zmax = fmaxf(zmax, fmaxf(fabsf(da[e]), fabsf(dg[e])));
             }
             DW_STORE(reinterpret_cast<f32x2*>(Dt + 2 * (long)o * rs), da);
@@ -355,11 +359,12 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
   return se_check_launch("se_dwconv31");
 }
 
-extern "C" int se_dwconv31_glu_bwd(const float* dH, const float* W, const float* Z, float* dZ, float* amax_out, int nseq, int n,
-                                   int inner, long outer_stride, long inner_stride, long pos_stride, void* stream) {
-  SE_REQUIRE(dH && W && Z && dZ && nseq > 0 && n > 0 && inner > 0, "dwconv31_glu_bwd: bad arguments");
+extern "C" int se_dwconv31_glu_bwd(const float* dH, const float* W, const float* U, const float* G, float* dZ, float* amax_out,
+                                   int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride,
+                                   void* stream) {
+  SE_REQUIRE(dH && W && U && G && dZ && nseq > 0 && n > 0 && inner > 0, "dwconv31_glu_bwd: bad arguments");
   SE_REQUIRE(pos_stride > 0 && pos_stride * DW_C * 320L < (1L << 30), "dwconv31_glu_bwd: position stride too large for 32-bit tile offsets");
-  DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, dH, W, nullptr, dZ, nullptr, 1, Z, amax_out};
+  DwArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, dH, W, nullptr, dZ, nullptr, 1, G, amax_out, U};
   const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
   const long nitems = (long)nseq * cdiv(n, 8 * pps);
   const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;

@@ -221,24 +221,25 @@ __global__ __launch_bounds__(256) void mask_tail_bwd_kernel(const float* __restr
   block_sum_atomic(sb, dwb + 1);
 }
 
-// GLU backward (models/conformer.py:30-37): Z = [a | g] (2H), dU (H) -> dZ
+// GLU backward (models/conformer.py:30-37): Z = [a | g] (2H), dU (H) -> dZ.  G != NULL: Z = the GLU result u = a sigmoid(g) [M][H]
+// and G = the gate half [M][H] (d g = dU u (1 - sigmoid(g)): the value half a is not needed)
 __global__ void glu_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dU, float* __restrict__ dZ,
-                               long M, int H, float* amax_out) {
+                               long M, int H, float* amax_out, const float* __restrict__ G) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of H per thread
   int hq = H >> 2;
   const bool live = idx < M * hq;
   if (!live) idx = M * hq - 1;           // (no early return: the wave-wide maximum below needs every lane)
   long row = idx / hq;
   int q = (int)(idx - row * hq);
-  float4 a = *reinterpret_cast<const float4*>(Z + row * 2 * H + q * 4);
-  float4 g = *reinterpret_cast<const float4*>(Z + row * 2 * H + H + q * 4);
+  float4 a = *reinterpret_cast<const float4*>(Z + row * (G ? 1 : 2) * H + q * 4);
+  float4 g = G ? *reinterpret_cast<const float4*>(G + row * H + q * 4) : *reinterpret_cast<const float4*>(Z + row * 2 * H + H + q * 4);
   float4 d = *reinterpret_cast<const float4*>(dU + row * H + q * 4);
   float av[4] = {a.x, a.y, a.z, a.w}, gv[4] = {g.x, g.y, g.z, g.w}, dv[4] = {d.x, d.y, d.z, d.w}, da[4], dg[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float s = sigmoidf_(gv[j]);
     da[j] = dv[j] * s;
-    dg[j] = dv[j] * av[j] * s * (1.f - s);
+    dg[j] = dv[j] * av[j] * (G ? 1.f : s) * (1.f - s);
   }
   if (live) {
     st4_stream_(dZ + row * 2 * H + q * 4, make_float4(da[0], da[1], da[2], da[3]));
@@ -548,8 +549,14 @@ extern "C" int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, in
 }
 extern "C" int se_glu_bwd_amax(const float* Z, const float* dU, float* dZ, long M, int H, float* amax_out, void* stream) {
   SE_REQUIRE(Z && dU && dZ && M > 0 && H > 0 && (H % 4) == 0, "glu_bwd: bad arguments");
-  EW_LAUNCH(glu_bwd_kernel, M * (H / 4), stream, Z, dU, dZ, M, H, amax_out);
+  EW_LAUNCH(glu_bwd_kernel, M * (H / 4), stream, Z, dU, dZ, M, H, amax_out, (const float*)nullptr);
   return se_check_launch("se_glu_bwd");
+}
+extern "C" int se_glu_bwd_gate(const float* U, const float* G, const float* dU, float* dZ, long M, int H, float* amax_out,
+                               void* stream) {
+  SE_REQUIRE(U && G && dU && dZ && M > 0 && H > 0 && (H % 4) == 0, "glu_bwd_gate: bad arguments");
+  EW_LAUNCH(glu_bwd_kernel, M * (H / 4), stream, U, dU, dZ, M, H, amax_out, G);
+  return se_check_launch("se_glu_bwd_gate");
 }
 extern "C" int se_gate_tanh(const float* Y, float* G, long M, int C, void* stream) {
   SE_REQUIRE(Y && G && M > 0 && C > 0 && (C % 4) == 0, "gate_tanh: bad arguments");

@@ -749,6 +749,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldr & 3) == 0 && (d->r_off & 3) == 0,
                "gemm: SE_EPI_ROWSTATS needs a row GEMM with N == 64, AUX = [M][2] and a vector-epilogue layout");
   SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
+  SE_REQUIRE(!(ep & SE_EPI_GLU_GATE) || ((ep & SE_EPI_GLU) && AUX), "gemm: SE_EPI_GLU_GATE needs SE_EPI_GLU and AUX");
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
   if (d->prologue == SE_PRO_AFFINE_SWISH) SE_REQUIRE(pro_scale && pro_shift, "gemm: affine prologue operands");
   if (d->precision == 3)

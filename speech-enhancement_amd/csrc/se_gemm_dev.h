@@ -377,8 +377,12 @@ static __device__ __forceinline__ void gemm_epilogue_glu_vec(const GemmArgs& g, 
     a.x += ba.x; a.y += ba.y; a.z += ba.z; a.w += ba.w;
     gt.x += bg.x; gt.y += bg.y; gt.z += bg.z; gt.w += bg.w;
     if (Zb) {
-      *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n)) = a;
-      *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)(No + n))) = gt;
+      if (d.epilogue & SE_EPI_GLU_GATE) {      // the backward needs only (a sigmoid(g), g): the gate half alone, [M][No]
+        *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n)) = gt;
+      } else {
+        *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)n)) = a;
+        *reinterpret_cast<float4*>(Zb + ((unsigned)row * (unsigned)d.ldx + (unsigned)(No + n))) = gt;
+      }
     }
     *reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n)) =
         make_float4(a.x * sigmoidf_(gt.x), a.y * sigmoidf_(gt.y), a.z * sigmoidf_(gt.z), a.w * sigmoidf_(gt.w));
@@ -436,7 +440,11 @@ static __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f3
     const unsigned yo = (unsigned)row * (unsigned)d.ldc;
     if (glu) {
       if (nok0) {
-        if (Xb) { const unsigned xo = (unsigned)row * (unsigned)d.ldx; Xb[xo + n0] = v0; Xb[xo + n1] = v1; }
+        if (Xb) {
+          const unsigned xo = (unsigned)row * (unsigned)d.ldx;
+          if (ep & SE_EPI_GLU_GATE) Xb[xo + n0] = v1;
+          else { Xb[xo + n0] = v0; Xb[xo + n1] = v1; }
+        }
         Yb[yo + n0] = v0 * sigmoidf_(v1);
       }
       continue;

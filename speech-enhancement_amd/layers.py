@@ -511,9 +511,9 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     if st3 is None:
         st3 = O.row_stats(y2, M)
     u = torch.empty(M, 128, device=x.device, dtype=torch.float32)
-    zc = torch.empty(M, 256, device=x.device, dtype=torch.float32)
+    zc = torch.empty(M, 128, device=x.device, dtype=torch.float32)      # the gate half only (GLU backward: (u, gate))
     Wpw1 = _w(P, (f'{p}.conv.net.2.weight', 'lin'), lambda: P[f'{p}.conv.net.2.weight'].view(256, 64))
-    GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=256,
+    GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU | L.EPI_GLU_GATE, ldx=128,
                                **_lin3(Wpw1, a_sexp=GM.LN_SEXP)), y2,
                 Wpw1, u, bias=P[f'{p}.conv.net.2.bias'], AUX=zc, rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                 pb=P[f'{p}.conv.net.0.bias'])
@@ -578,14 +578,14 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
         raise L.SeHipError('conformer_bwd in eval mode is not supported (BatchNorm uses running statistics)')
     Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
     if FUSE_GLU_BWD:       # depthwise input gradient + GLU backward in one kernel: dU (266 MB at batch 16) never goes to memory
-        dzc = O.dwconv31_glu_bwd(dh, Wdw, zc, geom, amax=_amax(dev))
+        dzc = O.dwconv31_glu_bwd(dh, Wdw, u, zc, geom, amax=_amax(dev))
         du = None
     else:
         du = O.dwconv31(dh, Wdw, None, geom, flip=True)
     with GM.leaf_stream(u, dh):
         O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
     if not FUSE_GLU_BWD:
-        dzc = O.glu_bwd(zc, du, M, 128, amax=_amax(dev))
+        dzc = O.glu_bwd_gate(u, zc, du, M, 128, amax=_amax(dev))
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
     with GM.leaf_stream(y2, dzc, st3, dzc._se_amax):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dzc._se_amax), y2, dzc,

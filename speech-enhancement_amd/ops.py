@@ -163,13 +163,14 @@ def dwconv31(x, w, bias, geom, stats=None, flip=False):
     return y
 
 
-def dwconv31_glu_bwd(dh, w, z, geom, amax=None):
-    """dZ [M, 256] = GLU-backward(Z, depthwise-conv input gradient of dh): one kernel, dU never goes to memory"""
+def dwconv31_glu_bwd(dh, w, u, gate, geom, amax=None):
+    """dZ [M, 256] = GLU-backward((u, gate), depthwise-conv input gradient of dh): one kernel, dU never goes to memory;
+    u = a sigmoid(gate) [M, 128] is the forward GLU result, gate [M, 128] the gate half of the pre-GLU activations"""
     M = dh.shape[0]
     dz = torch.empty(M, 256, device=dh.device, dtype=torch.float32)
     nseq, n, inner, os_, is_, ps = geom
-    L.call('se_dwconv31_glu_bwd', L.ptr(dh), L.ptr(w), L.ptr(z), L.ptr(dz), L.ptr(amax), _i(nseq), _i(n), _i(inner), _l(os_),
-           _l(is_), _l(ps), L.stream(), _key='dwconv31 dgrad + glu_bwd', _bytes=4.0 * (dh.numel() + 2 * dz.numel()))
+    L.call('se_dwconv31_glu_bwd', L.ptr(dh), L.ptr(w), L.ptr(u), L.ptr(gate), L.ptr(dz), L.ptr(amax), _i(nseq), _i(n), _i(inner), _l(os_),
+           _l(is_), _l(ps), L.stream(), _key='dwconv31 dgrad + glu_bwd', _bytes=4.0 * (3 * dh.numel() + dz.numel()))
     dz._se_amax = amax
     return dz
 
@@ -276,6 +277,14 @@ def glu_bwd(Z, dU, M, H, amax=None):
     """amax: optional zero-filled device scalar raised to max |dZ| (travels with the result as dZ._se_amax)"""
     dZ = torch.empty_like(Z)
     L.call('se_glu_bwd_amax', L.ptr(Z), L.ptr(dU), L.ptr(dZ), _l(M), _i(H), L.ptr(amax), L.stream())
+    dZ._se_amax = amax
+    return dZ
+
+
+def glu_bwd_gate(U, G, dU, M, H, amax=None):
+    """glu_bwd from the GLU result U = a sigmoid(g) [M, H] and the gate half G [M, H] (the value half is never stored)"""
+    dZ = torch.empty(M, 2 * H, device=U.device, dtype=torch.float32)
+    L.call('se_glu_bwd_gate', L.ptr(U), L.ptr(G), L.ptr(dU), L.ptr(dZ), _l(M), _i(H), L.ptr(amax), L.stream())
     dZ._se_amax = amax
     return dZ
 

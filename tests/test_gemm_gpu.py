@@ -64,6 +64,13 @@ def test_epilogues(G):
     gemm.gemm_tap(d, x, w, y, bias=b, AUX=z)
     assert relerr(z, lin) < 2e-6
     assert relerr(y, lin[:, :N // 2] * torch.sigmoid(lin[:, N // 2:])) < 2e-6
+    # GLU keeping only the gate half (what the GLU backward needs next to the result itself)
+    for prec in (0, 2):                   # (scaled-fp16 planes take the same epilogue: covered by the conformer / model tests)
+        y2, gt = torch.empty(M, N // 2, device='cuda'), torch.empty(M, N // 2, device='cuda')
+        d = gemm.linear_desc(M, Cin, N, ldc=N // 2, epilogue=L.EPI_BIAS | L.EPI_GLU | L.EPI_GLU_GATE, ldx=N // 2,
+                             precision=prec)
+        gemm.gemm_tap(d, x, w, y2, bias=b, AUX=gt)
+        assert relerr(gt, lin[:, N // 2:]) < 2e-6 and relerr(y2, lin[:, :N // 2] * torch.sigmoid(lin[:, N // 2:])) < 2e-6
     # residual with alpha
     r = rnd(M, N, seed=7)
     y = torch.empty(M, N, device='cuda')

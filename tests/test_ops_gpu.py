@@ -129,7 +129,9 @@ def test_dwconv31(axis, B, T, Fq):
     rr = F.conv1d(F.pad(sq.reshape(-1, 128, sq.shape[-1]), (15, 15)), w.double(), None, groups=128).reshape(sq.shape)
     (rr.permute(0, 3, 1, 2) if axis == 'time' else rr.permute(0, 1, 3, 2)).backward(dy.double())
     amax = torch.zeros(1, device='cuda')
-    dz = O.dwconv31_glu_bwd(dy.view(-1, 128), w.view(128, 31), z.view(-1, 256), geom, amax=amax)
+    u = (z[..., :128] * torch.sigmoid(z[..., 128:])).contiguous()            # what a GEMM with EPI_GLU | EPI_GLU_GATE keeps:
+    gate = z[..., 128:].contiguous()                                          # the GLU result and the gate half
+    dz = O.dwconv31_glu_bwd(dy.view(-1, 128), w.view(128, 31), u.view(-1, 128), gate.view(-1, 128), geom, amax=amax)
     assert relerr(dz.view(B, T, Fq, 256), z64.grad) < 1e-5
     assert abs(float(amax) - float(dz.abs().max())) <= 1e-6 * float(amax)
 
@@ -141,6 +143,8 @@ def test_glu_bwd_and_optimizers():
     z64 = z.double().requires_grad_(True)
     (z64[:, :128] * torch.sigmoid(z64[:, 128:])).backward(du.double())
     assert relerr(O.glu_bwd(z, du, M, 128), z64.grad) < 1e-5
+    u = (z[:, :128] * torch.sigmoid(z[:, 128:])).contiguous()
+    assert relerr(O.glu_bwd_gate(u, z[:, 128:].contiguous(), du, M, 128), z64.grad) < 1e-5
     # AdamW / nesterov SGD vs torch.optim on one flat tensor
     p0, g1, g2 = rnd(1000, seed=3), rnd(1000, seed=4), rnd(1000, seed=5)
     for kind in ('adamw', 'sgd'):

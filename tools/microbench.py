@@ -192,7 +192,7 @@ def dw_bench(argv):
         st = torch.zeros(1, 128, 2, device='cuda', dtype=torch.float64)
         z = torch.randn(B * T * Fq, 256, device='cuda')
         for name, fn in (('fwd+stats', lambda: O.dwconv31(x, w, b, geom, stats=st)), ('dgrad', lambda: O.dwconv31(dy, w, None, geom, flip=True)),
-                         ('dgrad+glu', lambda: O.dwconv31_glu_bwd(dy, w, z, geom)),
+                         ('dgrad+glu', lambda: O.dwconv31_glu_bwd(dy, w, x, z[:, :128].contiguous(), geom)),
                          ('wgrad', lambda: O.dwconv31_wgrad(x, dy, torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda'), geom))):
             for _ in range(2): fn()
             torch.cuda.synchronize(); t0 = time.time()
