@@ -1004,6 +1004,7 @@ static int launch_wgrad_lin_f16(const se_gemm_desc* d, const WgradArgs& g, dim3 
     case SE_PRO_NONE: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_NONE, SH, true>), grid, block, 0, s, g); break;
     case SE_PRO_LN: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_LN, SH, true>), grid, block, 0, s, g); break;
     case SE_PRO_SWISH: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_SWISH, SH, true>), grid, block, 0, s, g); break;
+    case SE_PRO_AFFINE_SWISH: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_AFFINE_SWISH, SH, true>), grid, block, 0, s, g); break;
     case SE_PRO_SWISH_DROP: hipLaunchKernelGGL((wgrad_lin_bf16_kernel<SE_PRO_SWISH_DROP, SH, true>), grid, block, 0, s, g); break;
     default: return se_fail("wgrad: no scaled split-fp16 kernel for prologue %d", d->prologue);
   }
@@ -1077,6 +1078,14 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
     else if (d->N <= 64 && d->C > 128 && d->C <= 256) shape = 2;
     else if (d->N <= 64 && d->C > 64 && d->C <= 128 && getenv("SE_WGRAD_LIN_ALL") != nullptr) shape = 3;
     if (d->C <= 64 && d->N > 64 && d->N <= 192 && getenv("SE_WGRAD_LIN_ALL") != nullptr) shape = 1;
+    const bool f16_pro = d->prologue == SE_PRO_NONE || d->prologue == SE_PRO_LN || d->prologue == SE_PRO_SWISH ||
+                         d->prologue == SE_PRO_AFFINE_SWISH || d->prologue == SE_PRO_SWISH_DROP;
+    if (want_f16 && f16_pro && !shape && getenv("SE_WGRAD_F16_NARROW_OFF") == nullptr) {
+      // the two-plane kernel is bound by the HBM stream of its operands, not by its MFMAs: the narrower gradients ([64 x 128] of the
+      // second pointwise conv, [64 x 64] of to_out, [192 x 64] of qkv) run on it too, with the waves of the padding columns idle
+      if (d->C <= 64 && d->N <= 256) shape = 1;
+      else if (d->N <= 64 && d->C <= 256) shape = 2;
+    }
     if (shape && shape <= 2 && d->precision == 2 && getenv("SE_WGRAD_LIN_F32") == nullptr) {
       // split-bf16 form: one resident round of 2 workgroups per CU (60 KB of LDS each)
       long rl = (Mtot + 511) / 512;
@@ -1084,7 +1093,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       rl = ((rl + 31) / 32) * 32;
       const int nch = (int)((Mtot + rl - 1) / rl);
       WgradArgs gl{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rl, nch};
-      if (want_f16 && (d->prologue == SE_PRO_NONE || d->prologue == SE_PRO_LN || d->prologue == SE_PRO_SWISH || d->prologue == SE_PRO_SWISH_DROP))
+      if (want_f16 && f16_pro)
         return shape == 1 ? launch_wgrad_lin_f16<1>(d, gl, dim3((unsigned)nch), s) : launch_wgrad_lin_f16<2>(d, gl, dim3((unsigned)nch), s);
       return shape == 1 ? launch_wgrad_lin_bf16<1>(d, gl, dim3((unsigned)nch), s) : launch_wgrad_lin_bf16<2>(d, gl, dim3((unsigned)nch), s);
     }

@@ -565,8 +565,9 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     dact = torch.empty(M, 128, device=dev, dtype=torch.float32)
     Wpw2T = _w(P, (f'{p}.conv.net.7.weight', 'T'), lambda: _T(Wpw2))
     GM.gemm_tap(GM.linear_desc(M, 64, 128, **_lin3(Wpw2T, a_amax=getattr(dy3, '_se_amax', None))), dy3, Wpw2T, dact)
-    with GM.leaf_stream(h, dy3, sc, sh):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH), h, dy3,
+    with GM.leaf_stream(h, dy3, sc, sh, getattr(dy3, '_se_amax', None)):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, a_sexp=GM.HID_SEXP,
+                                         w_amax=getattr(dy3, '_se_amax', None)), h, dy3,
                           G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
     dh = torch.empty(M, 128, device=dev, dtype=torch.float32)
     g_bn, b_bn = P[f'{p}.conv.net.5.weight'], P[f'{p}.conv.net.5.bias']
@@ -612,8 +613,9 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     WoT = _w(P, (f'{p}.attn.fn.to_out.weight', 'T'), lambda: _T(Wo))
     GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa,
                                **_lin3(WoT, a_amax=getattr(dy2, '_se_amax', None))), dy2, WoT, do)
-    with GM.leaf_stream(o, dy2):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa), o, dy2,
+    with GM.leaf_stream(o, dy2, getattr(dy2, '_se_amax', None)):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa,
+                                         a_sexp=ATTN_O_SEXP, w_amax=getattr(dy2, '_se_amax', None)), o, dy2,
                           G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25,
