@@ -614,11 +614,11 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) { uint4 u = make_uint4(cen[pl][0], cen[pl][1], cen[pl][2], cen[pl][3]); bf[pl] = *reinterpret_cast<bf16x8*>(&u); }
         } else {
-          // element e of the shifted window is an edge row -> cleared
-          const int e = df > 0 ? pL - (8 * jc + 1) : pR - (8 * jc - 1);
-          unsigned mk[4];
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) mk[dd] = e == 2 * dd ? 0xFFFF0000u : (e == 2 * dd + 1 ? 0x0000FFFFu : 0xFFFFFFFFu);
+          // element e of the shifted window is an edge row -> cleared.  A 64-row tile holds at most one edge row of each kind
+          // (Fo > 66), so at most one of the four k-steps sees it: the mask arithmetic (12 VALU per plane pair and tap) sits
+          // behind a wave-uniform test of the edge position against this k-step's 16 window elements
+          const int e0 = (df > 0 ? pL - 1 : pR + 1) - 8 * (2 * ks + 1);      // e of the lanes kg == 0; kg == 1: e0 - 8
+          const bool has_edge = e0 >= 0 && e0 < 16;
 #pragma unroll
           for (int pl = 0; pl < NPL; ++pl) {
             unsigned o[4];
@@ -629,8 +629,19 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
               o[0] = __builtin_amdgcn_alignbit(cen[pl][0], prv[pl], 16); o[1] = __builtin_amdgcn_alignbit(cen[pl][1], cen[pl][0], 16);
               o[2] = __builtin_amdgcn_alignbit(cen[pl][2], cen[pl][1], 16); o[3] = __builtin_amdgcn_alignbit(cen[pl][3], cen[pl][2], 16);
             }
-            uint4 u = make_uint4(o[0] & mk[0], o[1] & mk[1], o[2] & mk[2], o[3] & mk[3]);
+            uint4 u = make_uint4(o[0], o[1], o[2], o[3]);
             bf[pl] = *reinterpret_cast<bf16x8*>(&u);
+          }
+          if (has_edge) {
+            const int e = e0 - 8 * kg;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+              uint4 u = *reinterpret_cast<uint4*>(&bf[pl]);
+              unsigned* w4 = reinterpret_cast<unsigned*>(&u);
+#pragma unroll
+              for (int dd = 0; dd < 4; ++dd) w4[dd] &= e == 2 * dd ? 0xFFFF0000u : (e == 2 * dd + 1 ? 0x0000FFFFu : 0xFFFFFFFFu);
+              bf[pl] = *reinterpret_cast<bf16x8*>(&u);
+            }
           }
         }
 #pragma unroll

@@ -461,8 +461,9 @@ def norm_bwd(argv):
     import speech_enhancement_amd as S
     from speech_enhancement_amd import ops as O
 
-    B, T = 6, 321
-    for Fq, ldy in ((101, 64), (101, 256), (201, 64)):
+    B, T = int(os.environ.get('NB', '6')), 321
+    NCH = int(os.environ.get('NCH', '1'))           # batch chunks: reduce + apply per chunk (second pass out of the MALL)
+    for Fq, ldy in ((101, 64), (101, 256), (201, 64), (201, 256)):
         P = T * Fq
         R = torch.randn(B, T, Fq, 64, device='cuda')
         dy = torch.randn(B, T, Fq, ldy, device='cuda')
@@ -470,7 +471,10 @@ def norm_bwd(argv):
         g, b, sl = torch.randn(64, device='cuda'), torch.randn(64, device='cuda'), torch.full((64,), 0.25, device='cuda')
         dg, db, ds = (torch.zeros(64, device='cuda') for _ in range(3))
         dR = torch.empty_like(R)
-        f = lambda: O.norm_prelu_bwd(R, 64, 0, mr, g, b, sl, dy, ldy, ldy - 64, dR, 64, 0, dg, db, ds, B, P, 64, per_batch=True)
+        def f():
+            cb = B // NCH
+            for b0 in range(0, B, cb):
+                O.norm_prelu_bwd(R[b0:b0 + cb], 64, 0, mr[b0:b0 + cb], g, b, sl, dy[b0:b0 + cb], ldy, ldy - 64, dR[b0:b0 + cb], 64, 0, dg, db, ds, cb, P, 64, per_batch=True)
         for _ in range(3): f()
         torch.cuda.synchronize(); t0 = time.time()
         for _ in range(30): f()
