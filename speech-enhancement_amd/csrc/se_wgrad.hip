@@ -458,7 +458,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
 // F16 (precision 3): two planes of scaled fp16 (se_gemm_dev.h), three fp16 MFMAs per product; the activations are scaled by
 // 2^sexp(a_amax | a_sexp), dY by 2^sexp(w_amax | w_sexp) -- the descriptor's second-operand scale -- and the sums are un-scaled
 // (exactly) where they are added to dW.
-template <int NPL, bool F16 = false>
+// ORD: every triple lists its taps as df = -1, 0, +1 (host-checked; what gemm.conv_taps produces): the tap's shift is then a
+// compile-time constant of the unrolled tap loop -- no run-time selection between the three fragment forms.
+template <int NPL, bool F16 = false, bool ORD = false>
 __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   constexpr int MR = 64;
   constexpr int PLY = (9 * 64 + 4) * 8;       // Yt plane: [64 n][64 m],  cell(r, ch) = 9 r + (r >> 4) + ch
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
       }
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3) {
-        const int df = dfs[s3];
+        const int df = ORD ? s3 - 1 : dfs[s3];
         bf16x8 bf[NPL];
         if (df == 0) {
 #pragma unroll
@@ -1056,18 +1058,20 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
   if (d->prologue == SE_PRO_NONE && !(d->epilogue & SE_EPI_DROP) && !d->up && d->st == 1 && d->sf == 1 &&
       d->Ti == d->To && d->Fi == d->Fo && d->ntap >= 3 && d->ntap % 3 == 0 && d->Fo >= 2 && d->To * d->Fo >= 64 &&
       getenv("SE_GEMM_NO_CONV3") == nullptr) {
-    bool triples = true;
+    bool triples = true, ordered = true;
     for (int t3 = 0; t3 < d->ntap && triples; t3 += 3) {
       int seen = 0;
       for (int j = 0; j < 3; ++j) {
         if (d->dt[t3 + j] != d->dt[t3] || d->df[t3 + j] < -1 || d->df[t3 + j] > 1) triples = false;
         else seen |= 1 << (d->df[t3 + j] + 1);
+        if (d->df[t3 + j] != j - 1) ordered = false;
       }
       if (seen != 7) triples = false;
     }
     if (triples && (d->precision == 0 || d->Fo > 66)) {
       dim3 g3((unsigned)((long)(d->ntap / 3) * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8)));
-      if (d->precision == 3) hipLaunchKernelGGL((wgrad3_bf16_kernel<2, true>), g3, block, 0, s, g);
+      if (d->precision == 3 && ordered) hipLaunchKernelGGL((wgrad3_bf16_kernel<2, true, true>), g3, block, 0, s, g);
+      else if (d->precision == 3) hipLaunchKernelGGL((wgrad3_bf16_kernel<2, true>), g3, block, 0, s, g);
       else if (d->precision == 1) hipLaunchKernelGGL(wgrad3_bf16_kernel<2>, g3, block, 0, s, g);
       else if (d->precision == 2) hipLaunchKernelGGL(wgrad3_bf16_kernel<3>, g3, block, 0, s, g);
       else hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
