@@ -354,7 +354,9 @@ __global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
 // from LDS once and feed both -- 16 fragment reads per 24 MFMAs instead of 12 per 12 (at one read per MFMA the LDS pipe saturates
 // together with the matrix pipe: 48 KB of fragment reads per workgroup and tap = 384 cycles at 128 B/clk, and 48 MFMAs on 4 SIMDs
 // = 384 cycles).
-template <int NPL, bool WPL = false, bool F16 = false, int OCC = 3, int MT = 1>
+// ORD: the taps of every triple are listed as df = -1, 0, +1 (ORD = 1: gemm.conv_taps' order, the forward) or +1, 0, -1 (ORD = 2:
+// the negated taps of an input gradient) -- host-checked; the shift of the unrolled tap loop is then a compile-time constant.
+template <int NPL, bool WPL = false, bool F16 = false, int OCC = 3, int MT = 1, int ORD = 0>
 __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
   constexpr int BM = 128 * MT, BN = 64, BK = 32, SA = 40, HR = BM + 2;
   constexpr int PA = HR * SA, PB = BN * SA;
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
         load_b();
         if (s3 == 0) load_a();
       }
-      const int df = d.df[3 * gi + s3];
+      const int df = ORD == 1 ? s3 - 1 : (ORD == 2 ? 1 - s3 : d.df[3 * gi + s3]);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int bo = frag + 16 * ks;
@@ -808,15 +810,31 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     bool triples = getenv("SE_GEMM_NO_CONV3") == nullptr;
     // the kernel addresses both operands with 32-bit BYTE offsets (range-checked buffer loads)
     if ((long)d->To * d->Fo * d->lda * 4 >= (1L << 31) || (long)d->N * d->ldw * 4 >= (1L << 31)) triples = false;
+    bool fwd_order = true, rev_order = true;
     for (int t3 = 0; t3 < d->ntap && triples; t3 += 3) {
       int seen = 0;
       for (int j = 0; j < 3; ++j) {
         if (d->dt[t3 + j] != d->dt[t3] || d->df[t3 + j] < -1 || d->df[t3 + j] > 1) triples = false;
         else seen |= 1 << (d->df[t3 + j] + 1);
+        if (d->df[t3 + j] != j - 1) fwd_order = false;
+        if (d->df[t3 + j] != 1 - j) rev_order = false;
       }
       if (seen != 7) triples = false;
     }
     if (triples) {
+      const int ord = getenv("SE_CONV3_NO_ORD") != nullptr ? 0 : (fwd_order ? 1 : (rev_order ? 2 : 0));
+      if (d->precision == 3 && d->w_planes && ord) {      // the train step's shapes: compile-time tap order
+        static const bool mt2o = getenv("SE_CONV3_NO_MT2") == nullptr;
+        if (mt2o && d->C >= 192) {
+          g.tiles = cdiv(Mb, 256);
+          g.nouter = d->B * g.tiles;
+          dim3 grid2((unsigned)(ncols * (((long)g.nouter + 7) / 8 * 8)));
+          if (ord == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 2, 2, 1>), grid2, block, 0, s, g);
+          else hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 2, 2, 2>), grid2, block, 0, s, g);
+        } else if (ord == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 4, 1, 1>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 4, 1, 2>), grid, block, 0, s, g);
+        return se_check_launch("se_gemm_tap(conv3)");
+      }
       if (d->precision == 3) {
         // two planes instead of three leave room for 4 waves per SIMD (115 VGPRs, 33 KB of LDS): 1.5 - 7 % (949 -> 934 us at
         // Cin = 256, 226 -> 211 us at Cin = 64); SE_CONV3_OCC3=1 restores the 3-wave build for A/B runs
