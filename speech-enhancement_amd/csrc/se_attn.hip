@@ -1363,12 +1363,17 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
 #pragma unroll
       for (int t = 0; t < TQ; ++t) {
         const f32x4 s4 = prod3(kf, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});      // S^T[key 4g + r][query c]
-        float sc[4], tmax = -1e30f;
+        float sc[4], tmax = -1e30f, uu[4];
+        // the four window cells first, through SELECTED ADDRESSES (a ternary over the two loads compiles to one exec-masked
+        // branch per cell: eight branch regions per key step)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int dl = c - (4 * g + r);
-          const float u = dl >= 0 ? Ul[(t * 2 + hi) * 256 + dl * 16 + c] : Ul[(t * 2 + lo) * 256 + (16 + dl) * 16 + c];
-          sc[r] = (j0 + 4 * g + r < n) ? (s4[r] + u) * l2e : -1e30f;
+          uu[r] = Ul[(dl >= 0 ? (t * 2 + hi) * 256 : (t * 2 + lo) * 256 + 256) + dl * 16 + c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sc[r] = (j0 + 4 * g + r < n) ? (s4[r] + uu[r]) * l2e : -1e30f;
           tmax = fmaxf(tmax, sc[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
