@@ -848,8 +848,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
   const int wq = lane * 4;                                           // wide: this lane's 4 columns, rows 8 * wave + i
   const int nq = (tid & 15) * 4, nrp = tid >> 4;                     // narrow: 4 columns, rows 2 * nrp, 2 * nrp + 1
   const bool wok = wq < wcols, nok = nq < ncols;
-  const float* __restrict__ Wg = (XW ? g.A + d.a_off : g.dY + d.c_off) + wq;
-  const float* __restrict__ Ng = (XW ? g.dY + d.c_off : g.A + d.a_off) + nq;
+  // (lanes of padding columns read column 0 and rows past the chunk read its last row: every load is unconditional -- a
+  // predicated load is its own exec-masked branch region with its own wait -- and `fix` zeroes what must not count)
+  const float* __restrict__ Wg = (XW ? g.A + d.a_off : g.dY + d.c_off) + (wok ? wq : 0);
+  const float* __restrict__ Ng = (XW ? g.dY + d.c_off : g.A + d.a_off) + (nok ? nq : 0);
   const unsigned thr = drop_thr(d.drop_p);
   const float inv_keep = drop_inv_keep(d.drop_p);
   const bool dy_drop = (d.epilogue & SE_EPI_DROP) != 0;
@@ -876,29 +878,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
   auto load_tiles = [&](long mbase) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const long mg = mbase + 8 * wave + i;
-      const bool ok = mg < mend && wok;
-      rw[i] = ok ? *reinterpret_cast<const float4*>(Wg + mg * ldw_) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (XW && PRO == SE_PRO_LN) sw[i] = mg < mend ? *reinterpret_cast<const float2*>(g.rowstats + 2 * mg) : make_float2(0.f, 0.f);
+      long mg = mbase + 8 * wave + i;
+      mg = mg < mend ? mg : mend - 1;
+      rw[i] = *reinterpret_cast<const float4*>(Wg + mg * ldw_);
+      if (XW && PRO == SE_PRO_LN) sw[i] = *reinterpret_cast<const float2*>(g.rowstats + 2 * mg);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const long mg = mbase + 2 * nrp + i;
-      const bool ok = mg < mend && nok;
-      rn[i] = ok ? *reinterpret_cast<const float4*>(Ng + mg * ldn_) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!XW && PRO == SE_PRO_LN) sn[i] = mg < mend ? *reinterpret_cast<const float2*>(g.rowstats + 2 * mg) : make_float2(0.f, 0.f);
+      long mg = mbase + 2 * nrp + i;
+      mg = mg < mend ? mg : mend - 1;
+      rn[i] = *reinterpret_cast<const float4*>(Ng + mg * ldn_);
+      if (!XW && PRO == SE_PRO_LN) sn[i] = *reinterpret_cast<const float2*>(g.rowstats + 2 * mg);
     }
   };
   // operand transforms at staging time: the X prologue (the forward's LayerNorm / Swish / dropout, recomputed) and the dY mask
   auto fix = [&](float4 v, bool is_x, int c0, bool ok, float2 st, float4 ps4, float4 pb4, long mg) -> float4 {
-    if (!(ok && mg < mend)) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool live = ok && mg < mend;            // (selected at the end: an early return is an exec-masked region per call)
     if (is_x) {
       if (PRO != SE_PRO_NONE) v = apply_pro<PRO>(v, c0, d.C, st.x, st.y, ps4, pb4, mg, d.pro_seed, thr, inv_keep);
     } else if (dy_drop) {
       const float4 d4 = drop_scale4(d.epi_seed, (unsigned)(mg * d.N + c0), thr, inv_keep);
       v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
     }
-    return v;
+    return make_float4(live ? v.x : 0.f, live ? v.y : 0.f, live ? v.z : 0.f, live ? v.w : 0.f);
   };
   if (mbeg < mend) load_tiles(mbeg);
   // fragment bases: A = dY^T (rows n), B = X (columns c); this wave's 64 x 64 block of dW
