@@ -542,6 +542,10 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
 }
 
 // ---------------------------------------------------------------------------------------------
+// 3 workgroups per CU (<= 168 VGPRs, no spills in the shapes of the step): qkv 145 -> 133 us, GLU 200 -> 190 us; 4 spills (slower)
+#ifndef K64_OCC
+#define K64_OCC 3
+#endif
 // Row-panel kernel for the token-wise layers with K = 64 and N >= 128 (LN -> 256 / 192 / GLU-256, dY(64) -> 256), split
 // bf16.  The per-column-block kernel above is issue-bound on these shapes: every one of the N/64 sibling workgroups
 // re-loads, re-normalises and re-splits the same A rows and pays the same ~700 VALU instructions of set-up per wave for
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
 // the MFMA A-fragment layout (lane = row, 8 consecutive k), applies the prologue and the bf16 split ONCE and keeps the
 // fragments in 16 * NPL VGPRs; only the 64 x 64 weight blocks stream through LDS (next block prefetched in registers).
 template <int PRO, int NPL, bool PRE2, bool WPL = false, bool F16 = false>
-__global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, K64_OCC) void gemm_k64_panel_kernel(GemmArgs g) {
   constexpr int SB = 72, PB = 64 * SB;         // 64 + 8 bf16 per W row: 144-B stride, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
   __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 36];
@@ -624,12 +628,15 @@ __global__ __launch_bounds__(256) void gemm_k64_panel_kernel(GemmArgs g) {
       int n; bool ok;
       if (glu) { n = (pr >> 5) * (d.N / 2) + by * 32 + (pr & 31); ok = (by * 32 + (pr & 31)) < d.N / 2; }
       else { n = by * 64 + pr; ok = n < d.N; }
-      const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)n * (unsigned)d.ldw + 8 * pc);
+      // (rows past N read row 0 and are zeroed by selects: a predicated load is an exec-masked branch region with its own wait)
+      const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)(ok ? n : 0) * (unsigned)d.ldw + 8 * pc);
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-          rbp[q][h] = ok ? *reinterpret_cast<const uint4*>(wp + (size_t)q * (size_t)d.w_planes + 32 * h) : make_uint4(0u, 0u, 0u, 0u);
+        for (int h = 0; h < 2; ++h) {
+          const uint4 w4 = *reinterpret_cast<const uint4*>(wp + (size_t)q * (size_t)d.w_planes + 32 * h);
+          rbp[q][h] = make_uint4(ok ? w4.x : 0u, ok ? w4.y : 0u, ok ? w4.z : 0u, ok ? w4.w : 0u);
+        }
       return;
     }
 #pragma unroll

@@ -352,8 +352,10 @@ def k64_one(argv):
     x = torch.randn(M, 64, device='cuda'); st = O.row_stats(x, M)
     g, b = torch.rand(64, device='cuda') + 0.5, torch.randn(64, device='cuda') * 0.1
     plan = WeightPlan(torch.device('cuda'))
-    Wq = plan.linear('q', torch.randn(192, 64, device='cuda') * 0.1, planes=True)
-    Wp = plan.linear('p', torch.randn(256, 64, device='cuda') * 0.1, planes=True)
+    f16 = len(sys.argv) > 1 and sys.argv[1] == 'f16'
+    from speech_enhancement_amd import layers as LY
+    Wq = plan.linear('q', torch.randn(192, 64, device='cuda') * 0.1, planes='f16' if f16 else True)
+    Wp = plan.linear('p', torch.randn(256, 64, device='cuda') * 0.1, planes='f16' if f16 else True)
     bp = torch.randn(256, device='cuda') * 0.1
     plan.run()
     def bench(f, n=10):
@@ -362,9 +364,15 @@ def k64_one(argv):
         for _ in range(n): f()
         torch.cuda.synchronize(); return (time.time() - t0) / n * 1e6
     qkv = torch.empty(M, 192, device='cuda')
-    print(f'LN -> 192 (qkv)       {bench(lambda: GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), x, Wq, qkv, rowstats=st, ps=g, pb=b)):7.1f} us')
+    kq = LY._lin3(Wq, a_sexp=GM.LN_SEXP) if f16 else {}
+    kp = LY._lin3(Wp, a_sexp=GM.LN_SEXP) if f16 else {}
+    print(f'LN -> 192 (qkv)       {bench(lambda: GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, **kq), x, Wq, qkv, rowstats=st, ps=g, pb=b)):7.1f} us')
     u = torch.empty(M, 128, device='cuda'); zc = torch.empty(M, 256, device='cuda')
-    print(f'LN -> 256 GLU (pw1)   {bench(lambda: GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=256), x, Wp, u, bias=bp, AUX=zc, rowstats=st, ps=g, pb=b)):7.1f} us')
+    print(f'LN -> 256 GLU + Z     {bench(lambda: GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, ldx=256, **kp), x, Wp, u, bias=bp, AUX=zc, rowstats=st, ps=g, pb=b)):7.1f} us')
+    y256 = torch.empty(M, 256, device='cuda')
+    print(f'LN -> 256 plain       {bench(lambda: GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, epilogue=L.EPI_BIAS, **kp), x, Wp, y256, bias=bp, rowstats=st, ps=g, pb=b)):7.1f} us')
+    print(f'LN -> 256 GLU no aux  {bench(lambda: GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU, **kp), x, Wp, u, bias=bp, rowstats=st, ps=g, pb=b)):7.1f} us')
+    print(f'LN -> 256 GLU + gate  {bench(lambda: GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU | L.EPI_GLU_GATE, ldx=128, **kp), x, Wp, u, bias=bp, AUX=zc, rowstats=st, ps=g, pb=b)):7.1f} us')
 
 @cmd
 def lin_wgrad(argv):
