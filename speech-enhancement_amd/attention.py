@@ -15,13 +15,29 @@ def seq_geometry(B, T, Fq, axis):
     return (B * T, Fq, 1, Fq, 0, 1)
 
 
-def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None):
-    """Es: optional pre-split planes [3, 2*maxpos+1, 16] bf16 of E (weights.WeightPlan)"""
-    L.check_cuda(qkv, E, Es)
+def f16_shape_ok(geom, maxpos=512):
+    """the scaled split-fp16 attention kernels (se_attn_fwd_f16 / se_attn_bwd_f16) take this sequence geometry"""
+    nseq, n, inner, os_, is_, ps = geom
+    npad = (n + 15) // 16 * 16
+    return maxpos % 16 == 0 and npad + 128 <= maxpos and n <= 384 and ps * 192 * npad < 2 ** 31 - 1
+
+
+def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None, qkv_amax=None):
+    """Es: optional pre-split planes of E (weights.WeightPlan): [3, 2*maxpos+1, 16] bf16, or [2, 2*maxpos+1, 16] scaled fp16 with
+    its maximum in Es._se_amax -- together with qkv_amax (device scalar >= max |qkv|, e.g. raised by the qkv GEMM's epilogue) that
+    selects the scaled split-fp16 kernel"""
+    L.check_cuda(qkv, E, Es, qkv_amax)
     ntok = qkv.shape[0]
     O = torch.empty(ntok, 64, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32) if need_lse else None
     nseq, n, inner, os_, is_, ps = geom
+    if Es is not None and Es.dtype == torch.float16:
+        if qkv_amax is None or not f16_shape_ok(geom, maxpos):
+            raise L.SeHipError('attn_fwd: fp16 planes of E need qkv_amax and a sequence the split-fp16 kernel takes')
+        L.call('se_attn_fwd_f16', L.ptr(qkv), L.ptr(Es), C.c_long(Es.stride(0)), L.ptr(qkv_amax), L.ptr(Es._se_amax), L.ptr(O),
+               L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos),
+               C.c_float(scale), L.stream(), _key='attn_fwd3_f16x3', _flops=nseq * 4 * 3 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 256)
+        return O, lse
     L.call('se_attn_fwd_es', L.ptr(qkv), L.ptr(E), L.ptr(Es), C.c_long(Es.stride(0) if Es is not None else 0), L.ptr(O),
            L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner),
            C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos), C.c_float(scale), L.stream(),
@@ -29,10 +45,14 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None):
     return O, lse
 
 
-def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None):
+attn_bwd_f16_ready = True
+
+
+def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None, qkv_amax=None, do_amax=None):
     """returns dQKV [ntok,192]; accumulates into dE [2*maxpos+1, 16].  leaf: optional context-manager factory (gemm.leaf_stream):
-    the reduction of the per-wave dE tiles -- a leaf of the backward graph -- is then issued inside `leaf(ws, ...)`."""
-    L.check_cuda(qkv, E, O, dO, lse, dE)
+    the reduction of the per-wave dE tiles -- a leaf of the backward graph -- is then issued inside `leaf(ws, ...)`.
+    qkv_amax / do_amax: device scalars >= max |qkv| / max |dO| (producer epilogues): both given -> the scaled split-fp16 kernel."""
+    L.check_cuda(qkv, E, O, dO, lse, dE, qkv_amax, do_amax)
     ntok = qkv.shape[0]
     dqkv = torch.empty(ntok, 192, device=qkv.device, dtype=torch.float32)
     nseq, n, inner, os_, is_, ps = geom
@@ -42,7 +62,15 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None):
     v3 = maxpos % 16 == 0 and npad + 128 <= maxpos and n <= 384
     key = ('attn_bwd3_bf16x6 (+delta, tables, dE reduce)' if v3 else
            'attn_bwd2_kernel (+delta)' if n <= 336 and maxpos >= 352 else 'attn_bwd_dkv + attn_bwd_dq (+delta)')
+    f16 = qkv_amax is not None and do_amax is not None and v3 and f16_shape_ok(geom, maxpos)
+    if f16:
+        key = 'attn_bwd3_f16x3 (+delta, tables, dE reduce)'
     def run(phase, **kw):
+        if f16:
+            L.call('se_attn_bwd_f16_phase', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(qkv_amax), L.ptr(do_amax),
+                   L.ptr(dqkv), L.ptr(dE), C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps),
+                   C.c_long(ntok), C.c_int(maxpos), C.c_float(scale), L.ptr(ws), C.c_size_t(nbytes), C.c_int(phase), L.stream(), **kw)
+            return
         L.call('se_attn_bwd_phase', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dqkv), L.ptr(dE),
                C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
                C.c_int(maxpos), C.c_float(scale), L.ptr(ws), C.c_size_t(nbytes), C.c_int(phase), L.stream(), **kw)

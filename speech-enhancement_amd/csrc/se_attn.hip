@@ -35,6 +35,9 @@ struct AttnArgs {
   float scale;
   const void* Es;    // optional: E pre-split into three bf16 planes [3][2*maxpos+1][16] (se_weight_prep), es_plane elements apart
   long es_plane;
+  // scaled split-fp16 form of the v3 kernel (se_attn_fwd_f16): Es = TWO fp16 planes of E * 2^sexp(*e_amax) (se_weight_prep fmt 1),
+  // qkv_amax = device scalar >= max |QKV| (raised by the epilogue of the qkv GEMM: se_gemm_desc.y_amax)
+  const float* qkv_amax; const float* e_amax;
 };
 
 static __device__ __forceinline__ long tok_of(const AttnGeom& g, int s, int p) {
@@ -872,6 +875,72 @@ static __device__ __forceinline__ void prod3x2(const S3& a1, const S3& b1, f32x4
   c1 = MFMA_BF(win_mh(a1), win_mh(b1), c1);
   c2 = MFMA_BF(win_mh(a2), win_mh(b2), c2);
 }
+// ---- scaled split-fp16 form of the same products (round 3) -----------------------------------------------------------------
+// An operand is x * 2^sexp (exact; the tensor's largest magnitude in [2^13, 2^14)) = hi + lo with two fp16 words per value pair:
+// the S3 run keeps hi in words 2..3 and lo in words 4..5 (word 0..1 unused).  A product is THREE v_mfma_f32_16x16x16_f16 (lo.hi,
+// hi.lo, hi.hi: the K = 16 form has the lane layout of one half of the K = 32 form and costs the same 16 matrix-pipe cycles --
+// tools/micro/mfma_rate.hip -- so the matrix pipe does what it did) but the split of 4 values is 8 VALU instructions instead of
+// 18, and every LDS image / table has two planes instead of three.  The kernels are VALU-issue-bound (49 - 97 % busy), 60 % of it
+// splits.  FP16_OVFL clamps instead of producing inf (unreachable: every scale comes from a measured maximum or a proven bound).
+typedef _Float16 f16x4a __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2a __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ unsigned pk_f16a(float a, float b) {            // one v_cvt_pk_f16_f32 (round to nearest even)
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2a));
+}
+static __device__ __forceinline__ void f16_clamp_mode_a() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+static __host__ __device__ __forceinline__ int f16_sexp_a(float amax) {            // amax * 2^sexp in [2^13, 2^14) (as se_gemm_dev.h)
+  unsigned u;
+  __builtin_memcpy(&u, &amax, 4);
+  const int e = (int)((u >> 23) & 0xffu) - 127;
+  const int sx = 13 - e;
+  return !(amax > 0.f) ? 0 : (sx < -60 ? -60 : (sx > 60 ? 60 : sx));
+}
+static __device__ __forceinline__ float exp2ia(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+// (the packed words stay scalar values until the end: reading a word back out of a partially built ext-vector made hipcc 7.2 feed
+// v_fma_mix_f32 from the wrong register -- se_gemm_dev.h split_planes8_h)
+static __device__ __forceinline__ S3 split2h(float x0, float x1, float x2, float x3) {      // inputs already scaled
+  const unsigned h0 = pk_f16a(x0, x1), h1 = pk_f16a(x2, x3);
+  const f16x2a a = __builtin_bit_cast(f16x2a, h0), b = __builtin_bit_cast(f16x2a, h1);
+  x0 -= (float)a[0]; x1 -= (float)a[1]; x2 -= (float)b[0]; x3 -= (float)b[1];
+  const unsigned l0 = pk_f16a(x0, x1), l1 = pk_f16a(x2, x3);
+  S3 s;
+  s.v = (u32x6){0u, 0u, h0, h1, l0, l1};
+  return s;
+}
+// F16: x * sc split into (hi, lo) fp16; otherwise the exact three-way bf16 split (sc is 1 there and ignored)
+template <bool F16>
+static __device__ __forceinline__ S3 splitx(float x0, float x1, float x2, float x3, float sc) {
+  if constexpr (F16) return split2h(x0 * sc, x1 * sc, x2 * sc, x3 * sc);
+  else return split3(x0, x1, x2, x3);
+}
+template <bool F16> static __device__ __forceinline__ S3 splitx(const float4& v, float sc) { return splitx<F16>(v.x, v.y, v.z, v.w, sc); }
+template <bool F16> static __device__ __forceinline__ S3 splitx(const f32x4& v, float sc) { return splitx<F16>(v[0], v[1], v[2], v[3], sc); }
+#define MFMA_HF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4a, (a)), __builtin_bit_cast(f16x4a, (b)), (c), 0, 0, 0)
+template <bool F16>
+static __device__ __forceinline__ f32x4 prodx(const S3& a, const S3& b, f32x4 acc) {
+  if constexpr (F16) {
+    acc = MFMA_HF(get_l(a), get_h(b), acc);
+    acc = MFMA_HF(get_h(a), get_l(b), acc);
+    acc = MFMA_HF(get_h(a), get_h(b), acc);
+    return acc;
+  } else {
+    return prod3(a, b, acc);
+  }
+}
+template <bool F16>
+static __device__ __forceinline__ void prodx2(const S3& a1, const S3& b1, f32x4& c1, const S3& a2, const S3& b2, f32x4& c2) {
+  if constexpr (F16) {
+    c1 = MFMA_HF(get_l(a1), get_h(b1), c1);
+    c2 = MFMA_HF(get_l(a2), get_h(b2), c2);
+    c1 = MFMA_HF(get_h(a1), get_l(b1), c1);
+    c2 = MFMA_HF(get_h(a2), get_l(b2), c2);
+    c1 = MFMA_HF(get_h(a1), get_h(b1), c1);
+    c2 = MFMA_HF(get_h(a2), get_h(b2), c2);
+  } else {
+    prod3x2(a1, b1, c1, a2, b2, c2);
+  }
+}
 static __device__ __forceinline__ u32x2 ld8(const void* p) { return *reinterpret_cast<const u32x2*>(p); }
 static __device__ __forceinline__ void st8(void* p, u32x2 v) { *reinterpret_cast<u32x2*>(p) = v; }
 // hardware-transposed LDS read (ds_read_b64_tr_b16): within each 16-lane group, lane 4q + p supplies the address of row q,
@@ -879,6 +948,32 @@ static __device__ __forceinline__ void st8(void* p, u32x2 v) { *reinterpret_cast
 static __device__ __forceinline__ u32x2 tr8(const unsigned char* lds_ptr) {
   return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (s16x4 __attribute__((address_space(3)))*)(lds_ptr)));
+}
+
+// the planes of one split operand in an image whose planes are `pb` bytes apart: (hi, mid, lo) bf16 or (hi, lo) fp16
+template <bool F16>
+static __device__ __forceinline__ void st_planes(unsigned char* p, int pb, const S3& s) {
+  st8(p, get_h(s));
+  if constexpr (F16) st8(p + pb, get_l(s));
+  else { st8(p + pb, get_m(s)); st8(p + 2 * pb, get_l(s)); }
+}
+template <bool F16>
+static __device__ __forceinline__ S3 ld_planes(const unsigned char* p, long pb) {
+  S3 s;
+  s.v = (u32x6){0u, 0u, 0u, 0u, 0u, 0u};
+  set_h(s, ld8(p));
+  if constexpr (F16) set_l(s, ld8(p + pb));
+  else { set_m(s, ld8(p + pb)); set_l(s, ld8(p + 2 * pb)); }
+  return s;
+}
+template <bool F16>
+static __device__ __forceinline__ S3 tr_planes(const unsigned char* p, int pb) {
+  S3 s;
+  s.v = (u32x6){0u, 0u, 0u, 0u, 0u, 0u};
+  set_h(s, tr8(p));
+  if constexpr (F16) set_l(s, tr8(p + pb));
+  else { set_m(s, tr8(p + pb)); set_l(s, tr8(p + 2 * pb)); }
+  return s;
 }
 
 constexpr int NREP3 = 1;   // (unused by the scratch-based dE reduction; kept for the workspace layout)
@@ -899,6 +994,36 @@ __global__ void attn_split_tables_kernel(const float* __restrict__ E, __bf16* __
     Ets[(long)pl * ET * 16 + ((long)(row >> 4) * 16 + d) * 16 + (row & 15)] = h;      // [plane][tile][d][16 offsets]
   }
 }
+// the same two tables as two fp16 planes of E * 2^sexp(max |E|) (scaled split-fp16 backward): ONE workgroup measures the maximum,
+// publishes it for the main kernel (e_amax) and splits; 16 K elements
+__global__ __launch_bounds__(1024) void attn_split_tables_f16_kernel(const float* __restrict__ E, unsigned short* __restrict__ Es,
+                                                                     unsigned short* __restrict__ Ets, float* __restrict__ e_amax,
+                                                                     int R, int ET) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x;
+  f16_clamp_mode_a();
+  float m = 0.f;
+  for (int idx = tid; idx < R * 16; idx += 1024) m = fmaxf(m, fabsf(E[idx]));
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  if (tid == 0) *e_amax = m;
+  const float sc = exp2ia(f16_sexp_a(m));
+  for (int idx = tid; idx < R * 16; idx += 1024) {
+    const int row = idx >> 4, d = idx & 15;
+    const float x = E[idx] * sc;
+    const _Float16 h = (_Float16)x, l = (_Float16)(x - (float)h);
+    const unsigned short hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
+    Es[((long)0 * R + row) * 16 + d] = hb;
+    Es[((long)1 * R + row) * 16 + d] = lb;
+    const long to = ((long)(row >> 4) * 16 + d) * 16 + (row & 15);      // [plane][tile][d][16 offsets]
+    Ets[(long)0 * ET * 16 + to] = hb;
+    Ets[(long)1 * ET * 16 + to] = lb;
+  }
+}
 // fp32 transposed table Et[16][ld] of the v2 kernel
 __global__ void attn_transpose_table_kernel(const float* __restrict__ E, float* __restrict__ Et, int R, int ld) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -915,6 +1040,9 @@ struct AttnBwd3Args {
   int R, ET, maxpos;
   float scale;
   int dbg;                           // timing ablations: SE_ATTN_DBG bits 1 no dE flush, 4 V := K, 8 E := Q (0 in production)
+  // scaled split-fp16 form (se_attn_bwd_f16): device scalars >= max |QKV|, max |dO|, max |E| (the last one written by the table
+  // kernel of the same call); Es / Ets then hold TWO fp16 planes of E * 2^sexp(*e_amax)
+  const float* qkv_amax; const float* do_amax; const float* e_amax;
 };
 
 // key tiles of wave w when the 4 waves of a workgroup share one (sequence, head)
@@ -924,12 +1052,14 @@ static __device__ __host__ __forceinline__ void group_split(int nkt, int w, int&
   kt0 = w * b + (w < r ? w : r);
 }
 
-template <int KT>
+template <int KT, bool F16 = false>
 struct Lds3 {
   static constexpr int NU = KT + 1;
+  static constexpr int NPLA = F16 ? 2 : 3;                    // planes of a split operand: (hi, mid, lo) bf16 / (hi, lo) fp16
   static constexpr int SW = NU * 16 + (KT == 7 ? 0 : 4);      // strip row stride (floats)
-  static constexpr int KIMG = 3 * KT * 16 * 32;               // bytes: [3 planes][KT*16 keys][16 d] bf16
-  static constexpr int DIMG = 3 * 16 * 32;                    // bytes: [3 planes][16][16] bf16 (one tile, split)
+  static constexpr int KPB = KT * 16 * 32;                    // bytes of one plane of the K image
+  static constexpr int KIMG = NPLA * KPB;                     // bytes: [planes][KT*16 keys][16 d] 16-bit
+  static constexpr int DIMG = NPLA * 16 * 32;                 // bytes: [planes][16][16] 16-bit (one tile, split)
   static constexpr int STRIP = 16 * SW * 4;
   static constexpr int WAVE = KIMG + DIMG + STRIP;
 };
@@ -943,10 +1073,15 @@ struct QSide { float4 q4, do4; float qcf[4], docf[4], lse[4], dl[4]; };
 //           global latencies of step s + 1 with the arithmetic of step s);  otherwise NK = KT and steps s >= nk_w are skipped;
 //   GROUP : the 4 waves of the workgroup share the (sequence, head): dQ tiles are summed through LDS (one barrier per query
 //           tile) and stored once -- deterministic, no atomics.
-template <int KT, int NK, bool EXACT, bool GROUP>
+// F16: scaled split-fp16 operands (two planes, 8-instruction splits, three K = 16 MFMAs per product).  Scales: Q, K, V by 2^sq,
+// dO by 2^sdo, E by 2^se (measured maxima), P by 2^13 (folded into the exponent argument), dS by 2^sds with sds from the bound
+// |dS| <= P scale (|dP| + |D|) <= 32 scale max|dO| max|V| (both are 16-term dot products against V and O, |O| <= max |V|); every
+// accumulator is brought back by ONE power of two where it is stored.  dQ collects K^T dS^T (2^(sq + sds)) and E^T W^T
+// (2^(se + sds)) in two accumulators.
+template <int KT, int NK, bool EXACT, bool GROUP, bool F16 = false>
 static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, unsigned char* smem3, const int wave, const int lane,
                                                       const long item, const int kt0, const int nk_w) {
-  using L3 = Lds3<KT>;
+  using L3 = Lds3<KT, F16>;
   constexpr int NU = NK + 1, SW = L3::SW;
   const int c = lane & 15, g = lane >> 4;
   const int n = a.g.n, nkt = (n + 15) >> 4, nqt = nkt;
@@ -963,12 +1098,28 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
   const float* lseb = a.LSE + base * 4 + head;
   const float* dlb = a.Dl + base * 4 + head;
   float* dqb = a.dQKV + base * 192 + head * 16;
-  const float l2e = 1.4426950408889634f, sc2 = a.scale * l2e;
+  const float l2e = 1.4426950408889634f;
   const long witem = GROUP ? item * 4 + wave : item;
   float* dEs = a.dEs + witem * (long)(nqt + KT) * 256;
   const int trrow = c >> 2, trcol = c & 3;                      // transposed-read address roles of this lane
-  const __bf16 *Es0 = a.Es, *Es1 = a.Es + (long)a.R * 16, *Es2 = a.Es + (long)a.R * 32;
-  const __bf16 *Et0 = a.Ets, *Et1 = a.Ets + (long)a.ET * 16, *Et2 = a.Ets + (long)a.ET * 32;
+  const unsigned char* Esb = reinterpret_cast<const unsigned char*>(a.Es);      // planes (long)R * 32 bytes apart
+  const unsigned char* Etb = reinterpret_cast<const unsigned char*>(a.Ets);     // planes (long)ET * 32 bytes apart
+  const long esp = (long)a.R * 32, etp = (long)a.ET * 32;
+  float sqf = 1.f, sdof = 1.f, kU = 1.f, kD = 1.f, kdl = a.scale, cq1 = 1.f, cq2 = 1.f, cdv = 1.f, lse13 = 0.f;
+  float sc2 = a.scale * 1.4426950408889634f;
+  if (F16) {
+    f16_clamp_mode_a();
+    const float aq = *a.qkv_amax, ado = *a.do_amax;
+    const int sq = f16_sexp_a(aq), sdo = f16_sexp_a(ado), se = f16_sexp_a(*a.e_amax);
+    const int sds = f16_sexp_a(32.f * a.scale * ado * aq);
+    sqf = exp2ia(sq); sdof = exp2ia(sdo);
+    kU = exp2ia(sq - se);                          // strip cells U = q.E at the scale of S = q.k
+    sc2 *= exp2ia(-2 * sq);
+    kD = a.scale * exp2ia(sds - 13 - sdo - sq);    // (dP accumulator) -> scale (dP) 2^(sds - 13): times P 2^13 = dS 2^sds
+    kdl = a.scale * exp2ia(sds - 13);
+    cq1 = exp2ia(-sq - sds); cq2 = exp2ia(-se - sds); cdv = exp2ia(-sdo - 13);
+    lse13 = 13.f;
+  }
 
   // ---- stage this wave's keys: K pre-split into the LDS image (row fragments b64, column fragments tr_b16) ----
   // all NK rows are requested before the first one is split (clamped key index, zeroed by a select): with the load behind
@@ -985,10 +1136,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
     const int key = (kt0 + s) * 16 + c;
     const bool kok = (EXACT || s < nk_w) && key < n;
     const float4 k4 = make_float4(kok ? k4s[s].x : 0.f, kok ? k4s[s].y : 0.f, kok ? k4s[s].z : 0.f, kok ? k4s[s].w : 0.f);
-    const S3 ks = split3(k4);
-    st8(Kimg + ((0 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_h(ks));
-    st8(Kimg + ((1 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_m(ks));
-    st8(Kimg + ((2 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2, get_l(ks));
+    st_planes<F16>(Kimg + ((s * 16 + c) * 16 + 4 * g) * 2, L3::KPB, splitx<F16>(k4, sqf));
   }
   f32x4 dk[NK], dv[NK], de[NU];
 #pragma unroll
@@ -1000,7 +1148,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
   // v[r] = dE[delta = 16 Dtile + c][d = 4g + r]; tiles no (query, key) pair can reach are neither stored nor reduced
   auto flush = [&](const f32x4& v, int Dtile) {
     if (Dtile < -nkt || Dtile > nkt || (a.dbg & 1)) return;
-    *reinterpret_cast<float4*>(dEs + (Dtile + kt0 + KT) * 256 + c * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(dEs + (Dtile + kt0 + KT) * 256 + c * 16 + 4 * g) = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
   };
   auto load_qside = [&](int qt, QSide& o) {
     const int q0 = qt * 16;
@@ -1029,13 +1177,15 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       // C-layout rows are queries 4g + r: p = exp2((s + u) * scale * log2e - lse * log2e); rows beyond n get -inf -> p = 0
-      nlse2[j] = (q0 + 4 * g + j < n) ? -cur.lse[j] * l2e : -__builtin_inff();
-      dl4s[j] = cur.dl[j] * a.scale;
+      nlse2[j] = (q0 + 4 * g + j < n) ? lse13 - cur.lse[j] * l2e : -__builtin_inff();      // (F16: p carries P's factor 2^13)
+      dl4s[j] = cur.dl[j] * kdl;
     }
-    const S3 qrow = split3(cur.q4);
-    const S3 dorow = split3(cur.do4.x * a.scale, cur.do4.y * a.scale, cur.do4.z * a.scale, cur.do4.w * a.scale);   // dP pre-scaled
-    const S3 qcol = split3(cur.qcf[0], cur.qcf[1], cur.qcf[2], cur.qcf[3]);
-    const S3 docol = split3(cur.docf[0], cur.docf[1], cur.docf[2], cur.docf[3]);
+    const S3 qrow = splitx<F16>(cur.q4, sqf);
+    // dP pre-scaled by `scale` (F16: the factor is part of kD instead)
+    const float dps = F16 ? sdof : a.scale;
+    const S3 dorow = F16 ? splitx<true>(cur.do4, dps) : split3(cur.do4.x * dps, cur.do4.y * dps, cur.do4.z * dps, cur.do4.w * dps);
+    const S3 qcol = splitx<F16>(cur.qcf[0], cur.qcf[1], cur.qcf[2], cur.qcf[3], sqf);
+    const S3 docol = splitx<F16>(cur.docf[0], cur.docf[1], cur.docf[2], cur.docf[3], sdof);
 
     // ---- offset strip: U[q][delta] for the NU tiles Dtile = qt - kt0 - u, strip columns 16 (NK - u) + (delta & 15) ----
     // the E row fragments are requested in batches of EB tiles before their products: one L2 round trip per batch, not per tile
@@ -1049,20 +1199,21 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
         if (u < NU) {
           const int row = 16 * (qt - kt0 - u) + c + a.maxpos;      // in range by the launch conditions
           const unsigned eo = (unsigned)(row * 16 + 4 * g);
-          set_h(es[e], ld8(Es0 + eo)); set_m(es[e], ld8(Es1 + eo)); set_l(es[e], ld8(Es2 + eo));
+          es[e] = ld_planes<F16>(Esb + 2 * eo, esp);
         }
       }
 #pragma unroll
       for (int e = 0; e < EB; ++e) {
         const int u = u0 + e;
         if (u < NU) {
-          const f32x4 uu = prod3(qrow, es[e], (f32x4){0.f, 0.f, 0.f, 0.f});   // C[q = 4g + r][delta_local = c]
+          const f32x4 uu = prodx<F16>(qrow, es[e], (f32x4){0.f, 0.f, 0.f, 0.f});   // C[q = 4g + r][delta_local = c]
 #pragma unroll
-          for (int r = 0; r < 4; ++r) strip[(4 * g + r) * SW + 16 * (NK - u) + c] = uu[r];
+          for (int r = 0; r < 4; ++r) strip[(4 * g + r) * SW + 16 * (NK - u) + c] = F16 ? uu[r] * kU : uu[r];
         }
       }
     }
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                 // dQ^T[d = 4g + r][q = c]
+    f32x4 dq2 = {0.f, 0.f, 0.f, 0.f};                                // F16: the E^T W^T part (its own scale)
     auto load_v = [&](int s_) {
       int kj = (kt0 + s_) * 16 + c; if (kj > n - 1) kj = n - 1;
       return *reinterpret_cast<const float4*>(qb + (unsigned)(kj * ps * 192 + 128 + 4 * g));
@@ -1075,17 +1226,14 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
       if (EXACT || s < nk_w) {                                       // wave-uniform
         const int j0 = (kt0 + s) * 16;
         const bool kv = j0 + c < n;
-        S3 krow;
-        set_h(krow, ld8(Kimg + ((0 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
-        set_m(krow, ld8(Kimg + ((1 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
-        set_l(krow, ld8(Kimg + ((2 * KT * 16 + s * 16 + c) * 16 + 4 * g) * 2));
+        const S3 krow = ld_planes<F16>(Kimg + ((s * 16 + c) * 16 + 4 * g) * 2, L3::KPB);
         const float4 vcur = vnext;
         if (s + 1 < NK) vnext = load_v(s + 1);                       // one step ahead
         // (the run-time ablation switches double as scheduling fences: without these branch points the scheduler hoists
         // whole steps' loads, spills, and the kernel runs 8 % slower)
-        const S3 vrow = (a.dbg & 4) ? krow : split3(vcur);
+        const S3 vrow = (a.dbg & 4) ? krow : splitx<F16>(vcur, sqf);
         f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        prod3x2(qrow, krow, s4, dorow, vrow, dp);                    // S[q = 4g + r][key = c], scale * dP[q][key]
+        prodx2<F16>(qrow, krow, s4, dorow, vrow, dp);                // S[q = 4g + r][key = c], scale * dP[q][key]
         f32x4 pp, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1093,26 +1241,19 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
           float p = __builtin_amdgcn_exp2f(fmaf(s4[r] + *cell, sc2, nlse2[r]));
           p = kv ? p : 0.f;
           pp[r] = p;
-          ds[r] = p * (dp[r] - dl4s[r]);
+          ds[r] = F16 ? p * fmaf(dp[r], kD, -dl4s[r]) : p * (dp[r] - dl4s[r]);
           *cell = ds[r];                                             // W = skew(dS) replaces U in place
         }
         // contraction over the query rows 4g + r: the accumulator registers ARE the B operands
-        const S3 pps = split3(pp), dss = split3(ds);
+        const S3 pps = splitx<F16>(pp, 1.f), dss = splitx<F16>(ds, 1.f);
         // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
-        prod3x2(docol, pps, dv[s], qcol, dss, dk[s]);
+        prodx2<F16>(docol, pps, dv[s], qcol, dss, dk[s]);
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: both operands through hardware-transposed reads -- A from the K row
         // image, B from the split dS tile stored [key][q] (each lane writes 4 consecutive queries of its key: 8 bytes)
-        st8(Dimg + (0 * 16 + c) * 32 + g * 8, get_h(dss));
-        st8(Dimg + (1 * 16 + c) * 32 + g * 8, get_m(dss));
-        st8(Dimg + (2 * 16 + c) * 32 + g * 8, get_l(dss));
-        S3 kcol, dst;
-        set_h(kcol, tr8(Kimg + ((0 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
-        set_m(kcol, tr8(Kimg + ((1 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
-        set_l(kcol, tr8(Kimg + ((2 * KT * 16 + s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
-        set_h(dst, tr8(Dimg + (0 * 16 + 4 * g + trrow) * 32 + trcol * 8));
-        set_m(dst, tr8(Dimg + (1 * 16 + 4 * g + trrow) * 32 + trcol * 8));
-        set_l(dst, tr8(Dimg + (2 * 16 + 4 * g + trrow) * 32 + trcol * 8));
-        dq = prod3(kcol, dst, dq);
+        st_planes<F16>(Dimg + c * 32 + g * 8, 512, dss);
+        const S3 kcol = tr_planes<F16>(Kimg + ((s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2, L3::KPB);
+        const S3 dst = tr_planes<F16>(Dimg + (4 * g + trrow) * 32 + trcol * 8, 512);
+        dq = prodx<F16>(kcol, dst, dq);
       }
     }
 
@@ -1126,7 +1267,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
         const int u = u0 + e;
         if (u < NU) {
           const unsigned eo = (unsigned)(((qt - kt0 - u) * 16 + a.maxpos + c) * 16 + 4 * g);   // tile (qt-kt0-u) + maxpos/16, row d = c
-          set_h(ecs[e], ld8(Et0 + eo)); set_m(ecs[e], ld8(Et1 + eo)); set_l(ecs[e], ld8(Et2 + eo));
+          ecs[e] = ld_planes<F16>(Etb + 2 * eo, etp);
         }
       }
 #pragma unroll
@@ -1143,16 +1284,11 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
             if ((unsigned)(kr - 2) >= (unsigned)lim) w4.z = 0.f;
             if ((unsigned)(kr - 3) >= (unsigned)lim) w4.w = 0.f;
           }
-          const S3 ws = split3(w4);
-          st8(Dimg + (0 * 16 + c) * 32 + g * 8, get_h(ws));             // image [a][dl]
-          st8(Dimg + (1 * 16 + c) * 32 + g * 8, get_m(ws));
-          st8(Dimg + (2 * 16 + c) * 32 + g * 8, get_l(ws));
-          S3 wt;
-          set_h(wt, tr8(Dimg + (0 * 16 + 4 * g + trrow) * 32 + trcol * 8));   // W[a = 4g + j][dl = c]
-          set_m(wt, tr8(Dimg + (1 * 16 + 4 * g + trrow) * 32 + trcol * 8));
-          set_l(wt, tr8(Dimg + (2 * 16 + 4 * g + trrow) * 32 + trcol * 8));
+          const S3 ws = splitx<F16>(w4, 1.f);                           // (W = skew(dS): already at dS's scale)
+          st_planes<F16>(Dimg + c * 32 + g * 8, 512, ws);                // image [a][dl]
+          const S3 wt = tr_planes<F16>(Dimg + (4 * g + trrow) * 32 + trcol * 8, 512);      // W[a = 4g + j][dl = c]
           // dQ^T[d][q] += E^T[d][dl] W^T[dl][q];  dE^T[d][dl] += Q^T[d][q] W[q][dl]
-          prod3x2(ecs[e], ws, dq, qcol, wt, de[u]);
+          prodx2<F16>(ecs[e], ws, F16 ? dq2 : dq, qcol, wt, de[u]);
           if (a.dbg & 16) __builtin_amdgcn_s_sleep(1);               // (branch point: see the note at the V operand)
         }
       }
@@ -1166,6 +1302,10 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
     asm volatile("" : "+v"(nxt.qcf[0]), "+v"(nxt.qcf[1]), "+v"(nxt.qcf[2]), "+v"(nxt.qcf[3]), "+v"(nxt.docf[0]), "+v"(nxt.docf[1]), "+v"(nxt.docf[2]), "+v"(nxt.docf[3]));
     asm volatile("" : "+v"(nxt.lse[0]), "+v"(nxt.lse[1]), "+v"(nxt.lse[2]), "+v"(nxt.lse[3]), "+v"(nxt.dl[0]), "+v"(nxt.dl[1]), "+v"(nxt.dl[2]), "+v"(nxt.dl[3]));
     // ---- dQ of this query tile ----
+    if (F16) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dq[r] = fmaf(dq[r], cq1, dq2[r] * cq2);
+    }
     if (GROUP) {
       float* slot = dqs + ((qt & 1) * 4) * 256;
       *reinterpret_cast<float4*>(slot + wave * 256 + c * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
@@ -1196,13 +1336,13 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
     const int key = (kt0 + s) * 16 + c;
     if ((EXACT || s < nk_w) && key < n) {
       float* p = dqb + (unsigned)(key * ps * 192 + 4 * g);
-      *reinterpret_cast<float4*>(p + 64) = make_float4(dk[s][0], dk[s][1], dk[s][2], dk[s][3]);
-      *reinterpret_cast<float4*>(p + 128) = make_float4(dv[s][0], dv[s][1], dv[s][2], dv[s][3]);
+      *reinterpret_cast<float4*>(p + 64) = make_float4(dk[s][0] * cq1, dk[s][1] * cq1, dk[s][2] * cq1, dk[s][3] * cq1);
+      *reinterpret_cast<float4*>(p + 128) = make_float4(dv[s][0] * cdv, dv[s][1] * cdv, dv[s][2] * cdv, dv[s][3] * cdv);
     }
   }
 }
 
-template <int KT, bool GROUP>
+template <int KT, bool GROUP, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1211,14 +1351,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
     int kt0, cnt;
     group_split(nkt, wave, kt0, cnt);
     // every wave runs nqt barriers whichever branch it takes (s_barrier counts arrivals, not program counters)
-    if (cnt == KT) attn_bwd3_body<KT, KT, true, true>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
-    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
-    else attn_bwd3_body<KT, KT, false, true>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
+    if (cnt == KT) attn_bwd3_body<KT, KT, true, true, F16>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
+    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true, F16>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
+    else attn_bwd3_body<KT, KT, false, true, F16>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
   } else {
     const long item = (long)blockIdx.x * 4 + wave;
     if (item >= (long)a.g.nseq * 4) return;                     // whole wave leaves: EXEC stays full for the others
-    if (nkt == KT) attn_bwd3_body<KT, KT, true, false>(a, smem3, wave, lane, item, 0, nkt);
-    else attn_bwd3_body<KT, KT, false, false>(a, smem3, wave, lane, item, 0, nkt);
+    if (nkt == KT) attn_bwd3_body<KT, KT, true, false, F16>(a, smem3, wave, lane, item, 0, nkt);
+    else attn_bwd3_body<KT, KT, false, false, F16>(a, smem3, wave, lane, item, 0, nkt);
   }
 }
 
@@ -1267,11 +1407,16 @@ __global__ __launch_bounds__(256) void attn_de_reduce3_kernel(const float* __res
 //                     through ds_read_b64_tr_b16; P^T's accumulator registers are the B operand after one split
 // 48 instead of 128 matrix-pipe cycles per 16x16x16 product; only V lives in LDS (32 KB at n = 321): two 8-wave workgroups per CU.
 // =====================================================================================================================
-template <int TQ>
+// F16: the scaled split-fp16 form (two planes, three K = 16 MFMAs per product, 8-instruction splits): Q, K, V are scaled by
+// 2^sq (sq from *qkv_amax), the E table arrives as two fp16 planes scaled by 2^se (se from *e_amax), P by 2^13 (folded into the
+// exponent argument); S and U are brought to the logit scale by the two factors of one multiply + one FMA per element, the
+// output by one multiply per element at the end.
+template <int TQ, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
-  unsigned char* Vimg = smem_f3;                               // [3 planes][NP keys][16 d] bf16
-  float* Ubase = reinterpret_cast<float*>(smem_f3 + (size_t)3 * NP * 32);
+  constexpr int NPLA = F16 ? 2 : 3;
+  unsigned char* Vimg = smem_f3;                               // [NPLA planes][NP keys][16 d] 16-bit
+  float* Ubase = reinterpret_cast<float*>(smem_f3 + (size_t)NPLA * NP * 32);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NT = blockDim.x, NW = NT >> 6;
   const int c = lane & 15, g = lane >> 4;
@@ -1280,6 +1425,16 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   const long base = seq_base(a.g, seq);
   const int ps = (int)a.g.pos_stride;
   const float* qb = a.QKV + base * 192 + head * 16;
+  const int vpb = NP * 32;                                     // bytes between the planes of the V image
+  float sqf = 1.f, cS = 1.4426950408889634f * a.scale, cU = cS, osc = 1.f;
+  if (F16) {
+    f16_clamp_mode_a();
+    const int sq = f16_sexp_a(*a.qkv_amax), se = f16_sexp_a(*a.e_amax);
+    sqf = exp2ia(sq);
+    cU = cS * exp2ia(-sq - se);
+    cS = cS * exp2ia(-2 * sq);
+    osc = exp2ia(-sq);
+  }
   // V rows in batches of 4 per thread: requested together (clamped row, zeroed by a select), then split -- one load behind
   // `if (j < n)` per loop iteration was one dependent HBM round trip per iteration
   for (int i0 = tid; i0 < NP * 4; i0 += 4 * NT) {
@@ -1295,10 +1450,8 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
       const int i = i0 + e * NT, j = i >> 2, q = i & 3;          // NT is a multiple of 4: q == tid & 3
       if (i < NP * 4) {
         const bool ok = j < n;
-        const S3 vs = split3(make_float4(ok ? vv[e].x : 0.f, ok ? vv[e].y : 0.f, ok ? vv[e].z : 0.f, ok ? vv[e].w : 0.f));
-        st8(Vimg + ((0 * NP + j) * 16 + 4 * q) * 2, get_h(vs));
-        st8(Vimg + ((1 * NP + j) * 16 + 4 * q) * 2, get_m(vs));
-        st8(Vimg + ((2 * NP + j) * 16 + 4 * q) * 2, get_l(vs));
+        const S3 vs = splitx<F16>(make_float4(ok ? vv[e].x : 0.f, ok ? vv[e].y : 0.f, ok ? vv[e].z : 0.f, ok ? vv[e].w : 0.f), sqf);
+        st_planes<F16>(Vimg + (j * 16 + 4 * q) * 2, vpb, vs);
       }
     }
   }
@@ -1307,16 +1460,13 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   const float l2e = 1.4426950408889634f * a.scale;
   const int qblocks = (n + 16 * TQ - 1) / (16 * TQ), nkt = (n + 15) / 16;
   const int trrow = c >> 2, trcol = c & 3;
-  const __bf16* Esp = reinterpret_cast<const __bf16*>(a.Es);
+  const unsigned char* Esp = reinterpret_cast<const unsigned char*>(a.Es);
   auto e_row = [&](int D) -> S3 {             // E[clamp(D + c)][4g..4g+3], split: the A operand rows are offsets
     int d = D + c;
     d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
     const unsigned eo = (unsigned)((d + a.maxpos) * 16 + 4 * g);
-    if (Esp) {                                 // pre-split table: three 8-byte loads instead of a 16-byte load + an 18-instruction split
-      S3 r;
-      set_h(r, ld8(Esp + eo)); set_m(r, ld8(Esp + a.es_plane + eo)); set_l(r, ld8(Esp + 2 * a.es_plane + eo));
-      return r;
-    }
+    if (F16 || Esp)                            // pre-split table: 8-byte loads per plane instead of a 16-byte load + a split
+      return ld_planes<F16>(Esp + 2 * eo, 2 * a.es_plane);
     return split3(*reinterpret_cast<const float4*>(a.E + eo));
   };
   auto k_row = [&](int j0) {                  // K[j0 + c][4g..4g+3]
@@ -1329,14 +1479,14 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
       int qi = i0 + 16 * t + c; if (qi > n - 1) qi = n - 1;
-      qf[t] = split3(*reinterpret_cast<const float4*>(qb + (unsigned)(qi * ps * 192 + 4 * g)));
+      qf[t] = splitx<F16>(*reinterpret_cast<const float4*>(qb + (unsigned)(qi * ps * 192 + 4 * g)), sqf);
     }
     f32x4 o[TQ];
     float m[TQ], l[TQ];
 #pragma unroll
     for (int t = 0; t < TQ; ++t) { m[t] = -1e30f; l[t] = 0.f; o[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     auto u_tile = [&](const S3& es, int t, int slot) {
-      const f32x4 u = prod3(es, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});
+      const f32x4 u = prodx<F16>(es, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int r = 0; r < 4; ++r) Ul[(t * 2 + slot) * 256 + (4 * g + r) * 16 + c] = u[r];
     };
@@ -1352,17 +1502,15 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
     for (int kt = 0; kt < nkt; ++kt) {
       const int j0 = kt * 16, lo = hi ^ 1;
       ef[0] = enext;
-      const S3 kf = split3(knext);
+      const S3 kf = splitx<F16>(knext, sqf);
       if (kt + 1 < nkt) { enext = e_row(i0 - j0 - 32); knext = k_row(j0 + 16); }      // one step ahead
 #pragma unroll
       for (int t = 0; t < TQ; ++t) u_tile(ef[t], t, lo);          // lo tile of query tile t: offsets base i0 + 16 (t - 1) - j0
-      S3 vcol;                                                     // V[j0 + 4g + j][d = c]: transposed read of the row image
-      set_h(vcol, tr8(Vimg + ((0 * NP + j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
-      set_m(vcol, tr8(Vimg + ((1 * NP + j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
-      set_l(vcol, tr8(Vimg + ((2 * NP + j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2));
+      // V[j0 + 4g + j][d = c]: transposed read of the row image
+      const S3 vcol = tr_planes<F16>(Vimg + ((j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2, vpb);
 #pragma unroll
       for (int t = 0; t < TQ; ++t) {
-        const f32x4 s4 = prod3(kf, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});      // S^T[key 4g + r][query c]
+        const f32x4 s4 = prodx<F16>(kf, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});      // S^T[key 4g + r][query c]
         float sc[4], tmax = -1e30f, uu[4];
         // the four window cells first, through SELECTED ADDRESSES (a ternary over the two loads compiles to one exec-masked
         // branch per cell: eight branch regions per key step)
@@ -1373,7 +1521,8 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          sc[r] = (j0 + 4 * g + r < n) ? (s4[r] + uu[r]) * l2e : -1e30f;
+          const float lg = F16 ? fmaf(uu[r], cU, s4[r] * cS) : (s4[r] + uu[r]) * l2e;
+          sc[r] = (j0 + 4 * g + r < n) ? lg : -1e30f;
           tmax = fmaxf(tmax, sc[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
@@ -1381,14 +1530,15 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
         const float mn = fmaxf(m[t], tmax);
         const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
         m[t] = mn;
+        const float mnp = F16 ? mn - 13.f : mn;                     // F16: p and the running sum carry the factor 2^13 of P's scale
         f32x4 p;
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mn); psum += p[r]; }
+        for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mnp); psum += p[r]; }
         l[t] = l[t] * corr + psum;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[t][r] *= corr;
-        o[t] = prod3(vcol, split3(p), o[t]);                        // O^T[d 4g + r][query c] += V^T[d][key] P^T[key][query]
+        o[t] = prodx<F16>(vcol, splitx<F16>(p, 1.f), o[t]);         // O^T[d 4g + r][query c] += V^T[d][key] P^T[key][query]
       }
       // slide the offset window: next step's hi fragments are this step's lo fragments
 #pragma unroll
@@ -1403,9 +1553,9 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
       const int qi = i0 + 16 * t + c;
       if (qi < n) {
         const long tok = base + (long)qi * ps;
-        const float inv = 1.0f / lt;
+        const float inv = osc / lt;                                 // (F16: the 2^13 of P cancels, V's 2^sq is taken out here)
         *reinterpret_cast<float4*>(a.O + tok * 64 + head * 16 + 4 * g) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
-        if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt)) * 0.6931471805599453f;
+        if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt) - (F16 ? 13.f : 0.f)) * 0.6931471805599453f;
       }
     }
   }
@@ -1417,7 +1567,13 @@ static int check_geom(const AttnGeom& g) {
 }
 
 static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
-                         int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
+                         int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream,
+                         const float* qkv_amax = nullptr, const float* e_amax = nullptr);
+// shapes the split-fp16 forward takes (32-bit lane offsets, V image + strips within the LDS of a CU)
+static bool attn_f16_fwd_ok(int n, long pos_stride) {
+  const long NP = ((n + 15) / 16) * 16;
+  return pos_stride * 192 * NP < 2147483647L && (size_t)2 * NP * 32 + (size_t)512 * 2 * 8 * sizeof(float) <= 160 * 1024;
+}
 
 extern "C" int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq, int n, int inner,
                            long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale,
@@ -1432,10 +1588,22 @@ extern "C" int se_attn_fwd_es(const float* QKV, const float* E, const void* Es, 
              "attn_fwd_es: the pre-split table needs planes of >= (2 maxpos + 1) * 16 elements, 8-byte aligned");
   return attn_fwd_impl(QKV, E, Es, es_plane, O, LSE, nseq, n, inner, outer_stride, inner_stride, pos_stride, maxpos, scale, stream);
 }
+extern "C" int se_attn_fwd_f16(const float* QKV, const void* Es, long es_plane, const float* qkv_amax, const float* e_amax, float* O,
+                               float* LSE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride,
+                               int maxpos, float scale, void* stream) {
+  SE_REQUIRE(Es && qkv_amax && e_amax, "attn_fwd_f16: the fp16 planes of E and both maxima are required");
+  SE_REQUIRE(es_plane >= (long)(2 * maxpos + 1) * 16 && (es_plane % 4) == 0 && ((size_t)Es & 7) == 0,
+             "attn_fwd_f16: the pre-split table needs planes of >= (2 maxpos + 1) * 16 elements, 8-byte aligned");
+  SE_REQUIRE(attn_f16_fwd_ok(n, pos_stride), "attn_fwd_f16: shape outside the split-fp16 kernel (n = %d): use se_attn_fwd_es", n);
+  return attn_fwd_impl(QKV, reinterpret_cast<const float*>(Es), Es, es_plane, O, LSE, nseq, n, inner, outer_stride, inner_stride,
+                       pos_stride, maxpos, scale, stream, qkv_amax, e_amax);
+}
 
 static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
-                         int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream) {
-  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale, Es, es_plane};
+                         int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream,
+                         const float* qkv_amax, const float* e_amax) {
+  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale, Es, es_plane, qkv_amax, e_amax};
+  const bool f16 = qkv_amax != nullptr;
   if (int e = check_geom(a.g)) return e;
   SE_REQUIRE(QKV && E && O, "attn_fwd: null operand");
   const int NP = ((n + 15) / 16) * 16;
@@ -1456,20 +1624,24 @@ static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long 
     int nw3 = qb32 <= 4 ? 4 : 8, tq3 = qb32 <= 4 ? 1 : 2;
     if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v >= 1 && v <= 8) nw3 = v; }
     if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq3 = v; }
-    const size_t sh3 = (size_t)3 * NP * 32 + (size_t)512 * tq3 * nw3 * sizeof(float);
+    const size_t sh3 = (size_t)(f16 ? 2 : 3) * NP * 32 + (size_t)512 * tq3 * nw3 * sizeof(float);
     if (sh3 <= 160 * 1024) {
-      static size_t raised3[3] = {0, 0, 0};
-      if (sh3 > 64 * 1024 && sh3 > raised3[tq3]) {
-        const void* fn = tq3 == 1 ? (const void*)attn_fwd3_kernel<1> : (const void*)attn_fwd3_kernel<2>;
+      static size_t raised3[2][3] = {{0, 0, 0}, {0, 0, 0}};
+      if (sh3 > 64 * 1024 && sh3 > raised3[f16][tq3]) {
+        const void* fn = f16 ? (tq3 == 1 ? (const void*)attn_fwd3_kernel<1, true> : (const void*)attn_fwd3_kernel<2, true>)
+                             : (tq3 == 1 ? (const void*)attn_fwd3_kernel<1> : (const void*)attn_fwd3_kernel<2>);
         SE_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3) == hipSuccess,
                    "attn_fwd: cannot raise the dynamic LDS limit to %zu", sh3);
-        raised3[tq3] = sh3;
+        raised3[f16][tq3] = sh3;
       }
-      if (tq3 == 1) hipLaunchKernelGGL(attn_fwd3_kernel<1>, dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
+      if (f16 && tq3 == 1) hipLaunchKernelGGL((attn_fwd3_kernel<1, true>), dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
+      else if (f16) hipLaunchKernelGGL((attn_fwd3_kernel<2, true>), dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
+      else if (tq3 == 1) hipLaunchKernelGGL(attn_fwd3_kernel<1>, dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
       else hipLaunchKernelGGL(attn_fwd3_kernel<2>, dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
       return se_check_launch("se_attn_fwd");
     }
   }
+  SE_REQUIRE(!f16, "attn_fwd_f16: the sequence does not fit the split-fp16 kernel (n = %d)", n);
   const size_t sh = ((size_t)NP * 16 + 16 * (size_t)(NP + 4) + 512 * (size_t)tq * nw) * sizeof(float);
   if (sh <= 160 * 1024) {       // K / V of one (sequence, head) fit in LDS: staged kernel
     static size_t raised[3] = {0, 0, 0};
@@ -1517,15 +1689,15 @@ extern "C" size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, i
   return (ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0) ? attn_ws(ntok, maxpos, nseq, n).total : 0;
 }
 
-template <int KT, bool GROUP>
+template <int KT, bool GROUP, bool F16 = false>
 static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float* dE, int phase) {
-  using L3 = Lds3<KT>;
+  using L3 = Lds3<KT, F16>;
   const size_t sh = (size_t)4 * L3::WAVE + (GROUP ? 2 * 4 * 256 * sizeof(float) : 0);
   static unsigned raised = 0;
-  SE_REQUIRE(se_raise_lds((const void*)attn_bwd3_kernel<KT, GROUP>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit to %zu", sh);
+  SE_REQUIRE(se_raise_lds((const void*)attn_bwd3_kernel<KT, GROUP, F16>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit to %zu", sh);
   const long items = (long)b.g.nseq * 4;
   const int nkt = (b.g.n + 15) / 16;
-  if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
+  if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP, F16>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
   if (phase & 2) hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 256)), dim3(256), 0, s, b.dEs,
                                     dE, nwitems, nkt, b.maxpos, b.R);
   return 0;
@@ -1533,7 +1705,8 @@ static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float
 
 static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
                          float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
-                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream);
+                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
+                         const float* qkv_amax = nullptr, const float* do_amax = nullptr);
 
 extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                            float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
@@ -1552,9 +1725,22 @@ extern "C" int se_attn_bwd_phase(const float* QKV, const float* E, const float* 
                        ws, ws_bytes, phase, stream);
 }
 
+extern "C" int se_attn_bwd_f16_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
+                                     const float* qkv_amax, const float* do_amax, float* dQKV, float* dE, int nseq, int n, int inner,
+                                     long outer_stride, long inner_stride, long pos_stride, long ntok, int maxpos, float scale,
+                                     void* ws, size_t ws_bytes, int phase, void* stream) {
+  SE_REQUIRE(phase == 1 || phase == 2 || phase == 3, "attn_bwd_f16_phase: phase must be 1, 2 or 3");
+  SE_REQUIRE(qkv_amax && do_amax, "attn_bwd_f16: the maxima of QKV and dO are required");
+  SE_REQUIRE(attn_v3_shape(n, maxpos) && pos_stride * 192 * (long)(16 * ((n + 15) / 16)) < 2147483647L,
+             "attn_bwd_f16: shape outside the split-fp16 kernel (n = %d, maxpos = %d): use se_attn_bwd", n, maxpos);
+  return attn_bwd_impl(QKV, E, O, dO, LSE, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
+                       ws, ws_bytes, phase, stream, qkv_amax, do_amax);
+}
+
 static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
                          float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
-                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream) {
+                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
+                         const float* qkv_amax, const float* do_amax) {
   SE_REQUIRE(QKV && E && O && dO && LSE && dQKV && dE && ws, "attn_bwd: null operand");
   SE_REQUIRE(ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0, "attn_bwd: bad sizes");
   const AttnWs w = attn_ws(ntok, maxpos, nseq, n);
@@ -1575,15 +1761,23 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     // decoupled split-bf16 kernel: one wave per (sequence, head[, key group]); no offset clamp can be active
     __bf16* Es = reinterpret_cast<__bf16*>((char*)ws + w.es);
     __bf16* Ets = reinterpret_cast<__bf16*>((char*)ws + w.ets);
+    const bool f16 = qkv_amax != nullptr;
+    // (F16: two planes in the room of three; the third plane's room of the Es region holds the measured max |E|)
+    float* e_amax = reinterpret_cast<float*>((char*)ws + w.es + al256((size_t)2 * w.R * 16 * 2));
     if (phase & 1) {
       SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.des - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
-      hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
+      if (f16) hipLaunchKernelGGL(attn_split_tables_f16_kernel, dim3(1), dim3(1024), 0, s, E, reinterpret_cast<unsigned short*>(Es),
+                                  reinterpret_cast<unsigned short*>(Ets), e_amax, w.R, w.ET);
+      else hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
     }
     AttnBwd3Args b{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, dO, LSE, Dl, dQKV, Es, Ets,
-                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0};
+                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax};
     if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
     const long items = (long)nseq * 4;
-    if (int e = (kt3 == 7 ? launch_bwd3<7, false>(b, items, s, dE, phase) : launch_bwd3<6, true>(b, items * 4, s, dE, phase))) return e;
+    int e;
+    if (f16) e = kt3 == 7 ? launch_bwd3<7, false, true>(b, items, s, dE, phase) : launch_bwd3<6, true, true>(b, items * 4, s, dE, phase);
+    else e = kt3 == 7 ? launch_bwd3<7, false>(b, items, s, dE, phase) : launch_bwd3<6, true>(b, items * 4, s, dE, phase);
+    if (e) return e;
     return se_check_launch("se_attn_bwd");
   }
   // transposed table for the v2 kernel (fp32): built in the Ets region of the workspace

@@ -53,6 +53,24 @@ def attn_bench(argv):
             fl = nseq * 4 * 2.0 * n * n * 16
             print(f'{axis} bwd-mode={mode}: bwd {tb*1e3:.3f} ms ({7 * fl / tb / 1e12:.1f} TFLOP/s algorithmic)  '
                   f'fwd {tf*1e3:.3f} ms ({3 * fl / tf / 1e12:.1f} TFLOP/s)', flush=True)
+        # scaled split-fp16 kernels
+        from speech_enhancement_amd.weights import WeightPlan
+        plan = WeightPlan(torch.device('cuda')); Es = plan.linear('e', E, planes='f16'); plan.run()
+        am = qkv.abs().max().reshape(1).clone()
+        dO._se_amax = dO.abs().max().reshape(1).clone()
+        for _ in range(2): A.attn_fwd(qkv, E, geom, Es=Es, qkv_amax=am)
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(5): A.attn_fwd(qkv, E, geom, Es=Es, qkv_amax=am)
+        torch.cuda.synchronize(); tf = (time.time() - t0) / 5
+        tb = float('nan')
+        if hasattr(A, 'attn_bwd_f16_ready'):
+            dE = torch.zeros_like(E)
+            f = lambda: A.attn_bwd(qkv, E, O, dO, lse, geom, dE, qkv_amax=am, do_amax=dO._se_amax)
+            for _ in range(2): f()
+            torch.cuda.synchronize(); t0 = time.time()
+            for _ in range(5): f()
+            torch.cuda.synchronize(); tb = (time.time() - t0) / 5
+        print(f'{axis} f16x3: bwd {tb*1e3:.3f} ms  fwd {tf*1e3:.3f} ms ({3 * fl / tf / 1e12:.1f} TFLOP/s)', flush=True)
 
 @cmd
 def attn_fwd_es(argv):
