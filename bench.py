@@ -259,9 +259,11 @@ def main():
                 # BASELINE.json's north_star names for this path (the kernels execute each 16-deep product as three 16x16x32
                 # bf16 MFMAs on an exact three-way operand split: 6x the algorithmic FLOPs on the bf16 pipe)
                 peak = PEAK_F32_MFMA_TFLOPS
+                xparts, xkind = (3, 'three 16x16x16 fp16 MFMAs per 16-deep product on scaled (hi, lo) fp16 operands') if 'f16x3' in k else \
+                                (6, 'three 16x16x32 bf16 MFMAs per 16-deep product on an exact three-way operand split')
                 note = ('algorithmic fp32 FLOPs of the attention contractions (forward: QK^T, q.E, AV; backward: their nine '
                         'products) / family launch time (incl. the delta / table / dE-reduce helpers); peak = dense fp32 MFMA '
-                        f'(north_star bar); executed as split-bf16 MFMAs: {round(ach * 6, 1)} TFLOP/s on the 2.5 PFLOP/s bf16 pipe')
+                        f'(north_star bar); executed as {xkind}: {round(ach * xparts, 1)} TFLOP/s on the 2.5 PFLOP/s 16-bit pipe')
             elif 'bf16x6' in k or 'bf16x3' in k or 'f16x3' in k:
                 parts = 6 if 'bf16x6' in k else 3
                 kind = 'scaled fp16 hi/lo' if 'f16x3' in k and 'bf16' not in k else 'bf16 hi/mid/lo'
@@ -333,7 +335,7 @@ def main():
         'config': {'workload': f'{a.arch} generator+discriminator train step (main_gan.py train_gan loop body), '
                                f'batch {B}/GPU, 2 s @ 16 kHz, n_fft=400 hop=100, AdamW lr 5e-4, PESQ labels supplied, '
                                f'kaiming-init weights; fp32 results throughout: conv and token GEMMs as scaled fp16 hi/lo splits '
-                               f'(3 MFMAs per product, 2^-24 relative, fp32 accumulate), attention as exact 3-way bf16 splits, '
+                               f'(3 MFMAs per product, 2^-24 relative, fp32 accumulate), attention on the same scaled fp16 splits (scales from measured operand maxima), '
                                f'everything else fp32 MFMA / fp32 VALU',
                    'global_batch': world * B, 'parallelism': f'dp{world}',
                    'effective_tflops': round(world * B * a.steps * GFLOP_PER_UTT_STEP / dt / 1e3, 2),

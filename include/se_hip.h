@@ -85,6 +85,10 @@ typedef struct {
                             kernel derives the scale 2^(13 - floor(log2 amax)) from it.  NULL: a_sexp                     */
   const float* w_amax;   /* the same for W; with pre-split fp16 planes it must be the scalar se_weight_prep scaled them by.
                             se_gemm_tap_wgrad: a_* scale the activations A, w_* the second operand dY                     */
+  float* y_amax;         /* se_gemm_tap, any precision: when not NULL, a (zero-initialised or running) device scalar that the
+                            vector epilogue raises to max |Y| over everything this launch stores -- the operand scale of a
+                            scaled split-fp16 consumer (qkv -> se_attn_fwd_f16, dO -> se_attn_bwd_f16_phase).  Ignored by the
+                            GLU / shuffle / scalar epilogues (host error if set with those)                              */
 } se_gemm_desc;
 
 int se_version(void);

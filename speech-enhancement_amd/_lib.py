@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
                 ('ldr', C.c_int), ('r_off', C.c_int), ('ldx', C.c_int), ('x_off', C.c_int),
                 ('pro_seed', C.c_uint), ('epi_seed', C.c_uint), ('drop_p', C.c_float), ('precision', C.c_int),
                 ('w_planes', C.c_int), ('a_sexp', C.c_int), ('w_sexp', C.c_int), ('a_amax', C.c_void_p),
-                ('w_amax', C.c_void_p)]
+                ('w_amax', C.c_void_p), ('y_amax', C.c_void_p)]
 
 
 class F16Scales(C.Structure):

@@ -770,6 +770,10 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     SE_REQUIRE((long)d->w_planes * 6 < (1L << 31), "gemm: pre-split weight planes exceed 2^31 bytes");
   }
   GemmArgs g{*d, A, W, bias, Y, R, AUX, rowstats, pro_scale, pro_shift, stats, nullptr, nullptr, 0, 0, 0, 0};
+  g.amax_out = d->y_amax;
+  SE_REQUIRE(!d->y_amax || (!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | 256)) && (d->N & 3) == 0 && (d->ldc & 3) == 0 && (d->c_off & 3) == 0 &&
+                            (d->ldx & 3) == 0 && (d->x_off & 3) == 0 && (d->ldr & 3) == 0 && (d->r_off & 3) == 0),
+             "gemm: y_amax needs the vector epilogue (no GLU / shuffle, 4-aligned strides)");
   const int Mb = d->To * d->Fo;
   const int ncols = (ep & SE_EPI_GLU) ? cdiv(d->N / 2, 32) : cdiv(d->N, 64);
   g.ncb = ncols;

@@ -148,6 +148,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
   const int cq = lane & 7, rr = lane >> 3;          // read-back role: float4 column, row within an 8-row pass
   const bool rowstats = (ep & SE_EPI_ROWSTATS) != 0;  // N == 64 (host-checked): the 8 lanes cq = 0..7 of an rr group hold a whole row
   float4 kept[2][4];
+  float vmax = 0.f;                                  // max |stored value| (se_gemm_desc.y_amax)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const f32x16& acc = nt ? acc1 : acc0;
@@ -183,6 +184,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
         if (ep & SE_EPI_ACCUM) { float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *yp = v;
+        if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (rowstats) kept[nt][i] = v;
       }
     }
@@ -195,6 +197,10 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         for (int j = 0; j < 4; ++j) { red[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sv[j]; red[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sv[4 + j]; }
       }
     }
+  }
+  if (g.amax_out) {                                  // (wave-uniform pointer test; one guarded atomic per wave)
+    vmax = wave_max(vmax);
+    if (lane == 0) amax_raise_(g.amax_out, vmax);
   }
   if (rowstats) {
     // (mean, rstd) over the 64 channels of every RESULT row -- the statistics the next LayerNorm(64) needs (se_row_stats on Y):

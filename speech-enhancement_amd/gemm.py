@@ -14,7 +14,7 @@ def conv_taps(kh, kw, dil=(1, 1), pad=(0, 0)):
 
 def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=None, st=1, sf=1, up=0,
               prologue=L.PRO_NONE, epilogue=0, alpha=1.0, ldr=0, r_off=0, ldx=0, x_off=0, pro_seed=0, epi_seed=0,
-              drop_p=0.0, precision=0, a_sexp=0, w_sexp=0, a_amax=None, w_amax=None):
+              drop_p=0.0, precision=0, a_sexp=0, w_sexp=0, a_amax=None, w_amax=None, y_amax=None):
     d = GemmDesc()
     d.B, d.To, d.Fo, d.Ti, d.Fi = B, To, Fo, Ti, Fi
     d.st, d.sf, d.up = st, sf, up
@@ -31,7 +31,8 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
     d.a_sexp, d.w_sexp = a_sexp, w_sexp
     d.a_amax = a_amax.data_ptr() if a_amax is not None else None
     d.w_amax = w_amax.data_ptr() if w_amax is not None else None
-    d._keep = (a_amax, w_amax)                # the descriptor holds raw pointers: keep the scalars alive with it
+    d.y_amax = y_amax.data_ptr() if y_amax is not None else None      # raised to max |Y| by the vector epilogue
+    d._keep = (a_amax, w_amax, y_amax)        # the descriptor holds raw pointers: keep the scalars alive with it
     return d
 
 

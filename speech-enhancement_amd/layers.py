@@ -39,6 +39,10 @@ CONV_PRECISION = _PREC[_os.environ.get('SE_CONV_PRECISION', 'f16x3')]
 # are scaled by their MEASURED maxima instead (amax scalars).
 ACT_SEXP = 4
 ATTN_O_SEXP = 4    # attention outputs (convex combinations of the value rows): |o| < 4094
+# attention products: 'f16x3' = the scaled split-fp16 kernels (se_attn_fwd_f16 / se_attn_bwd_f16_phase; operand scales from the
+# maxima the qkv / to_out input-gradient GEMMs raise: se_gemm_desc.y_amax) wherever the sequence fits them, 'bf16x6' = the exact
+# three-way bf16 split kernels everywhere (SE_ATTN_PRECISION)
+ATTN_PRECISION = [_os.environ.get('SE_ATTN_PRECISION', 'f16x3')]
 
 
 # weight-gradient GEMMs of the same convolutions (contraction over pixels; same operand splits, transposed staging).
@@ -260,7 +264,9 @@ def build_generator_plan(P, device):
             plan.linear_T((f'{a}.to_out.weight', 'T'), P[f'{a}.to_out.weight'], planes='f16' if l3 == 'f16' else False)
             if l3 == 'f16':
                 plan.linear((f'{a}.to_out.weight', 'lin'), P[f'{a}.to_out.weight'], planes='f16')
-            plan.linear((f'{a}.rel_pos_emb.weight', 'es'), P[f'{a}.rel_pos_emb.weight'], planes=True)     # [3][2 maxpos + 1][16]
+            # [3][2 maxpos + 1][16] bf16 or [2][..][16] scaled fp16 (+ max |E|)
+            plan.linear((f'{a}.rel_pos_emb.weight', 'es'), P[f'{a}.rel_pos_emb.weight'],
+                        planes='f16' if ATTN_PRECISION[0] == 'f16x3' else True)
             n = f'{p}.conv.net.2.weight'
             plan.linear((n, 'lin'), P[n], planes=l3)
             plan.linear_T((n, 'T'), P[n], planes=l3)
@@ -491,12 +497,18 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     Wqkv = _w(P, (f'{p}.attn.fn', 'qkv'),
               lambda: torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0).contiguous())
     qkv = torch.empty(M, 192, device=x.device, dtype=torch.float32)
-    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, **_lin3(Wqkv, a_sexp=GM.LN_SEXP)), y1, Wqkv, qkv, rowstats=st2,
-                ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
     E = P[f'{p}.attn.fn.rel_pos_emb.weight']
     maxpos = (E.shape[0] - 1) // 2
-    o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25,
-                        Es=_w(P, (f'{p}.attn.fn.rel_pos_emb.weight', 'es'), lambda: None))
+    Es = _w(P, (f'{p}.attn.fn.rel_pos_emb.weight', 'es'), lambda: None)
+    # scaled split-fp16 attention: the qkv GEMM raises max |qkv| for it; sequences outside that kernel (10 s clips) take the
+    # three-way bf16 split / streaming kernels with the table split on the fly
+    attn16 = Es is not None and Es.dtype == torch.float16 and A.f16_shape_ok(geom, maxpos)
+    qkv_amax = O.zeros(1, device=x.device) if attn16 else None
+    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, y_amax=qkv_amax, **_lin3(Wqkv, a_sexp=GM.LN_SEXP)), y1, Wqkv, qkv,
+                rowstats=st2, ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
+    if Es is not None and Es.dtype == torch.float16 and not attn16:
+        Es = None
+    o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25, Es=Es, qkv_amax=qkv_amax)
     y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     sa = site_seed(seed, 2)
     st3 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None
@@ -506,7 +518,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
                                (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64, epi_seed=sa, drop_p=pa,
                                **_lin3(Wo_, a_sexp=ATTN_O_SEXP)), o,
                 Wo_, y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1, AUX=st3)
-    ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa)
+    ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa, qkv_amax)
     # conv module
     if st3 is None:
         st3 = O.row_stats(y2, M)
@@ -607,11 +619,12 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     ctx['conv'] = None
     del dact, dh, du, dzc, dy3, dy4
     # attention: y2 = y1 + o @ Wo^T + bo
-    y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa = ctx['attn']
+    y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa, qkv_amax = ctx['attn']
     Wo = P[f'{p}.attn.fn.to_out.weight']
     do = torch.empty(M, 64, device=dev, dtype=torch.float32)
     WoT = _w(P, (f'{p}.attn.fn.to_out.weight', 'T'), lambda: _T(Wo))
-    GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa,
+    do_amax = O.zeros(1, device=dev) if qkv_amax is not None else None      # max |dO| for the scaled split-fp16 attention backward
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa, y_amax=do_amax,
                                **_lin3(WoT, a_amax=getattr(dy2, '_se_amax', None))), dy2, WoT, do)
     with GM.leaf_stream(o, dy2, getattr(dy2, '_se_amax', None)):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa,
@@ -619,7 +632,8 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
                           G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25,
-                      leaf=None if _os.environ.get('SE_ATTN_DE_MAIN') == '1' else GM.leaf_stream)
+                      leaf=None if _os.environ.get('SE_ATTN_DE_MAIN') == '1' else GM.leaf_stream,
+                      qkv_amax=qkv_amax, do_amax=do_amax)
     WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv))
     gq, gkv = G[f'{p}.attn.fn.to_q.weight'], G[f'{p}.attn.fn.to_kv.weight']
     # to_q / to_kv are neighbours in the flat gradient buffer of the optimizers: the [192, 64] gradient of the fused projection

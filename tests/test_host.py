@@ -207,7 +207,7 @@ def test_ctypes_struct_layouts_match_the_c_header(tmp_path):
     from speech_enhancement_amd import _lib as L
     from speech_enhancement_amd.weights import WItem
     src = tmp_path / 'layout.c'
-    fields_d = ['B', 'ntap', 'dt', 'df', 'C', 'N', 'ldw', 'prologue', 'alpha', 'ldx', 'pro_seed', 'drop_p', 'precision', 'w_planes']
+    fields_d = ['B', 'ntap', 'dt', 'df', 'C', 'N', 'ldw', 'prologue', 'alpha', 'ldx', 'pro_seed', 'drop_p', 'precision', 'w_planes', 'w_amax', 'y_amax']
     fields_w = ['src', 'dst', 'No', 'Ni_dst', 'so', 'stt', 'si', 'rev', 'dst_ld', 'c_off', 'scale', 'plane_stride']
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "se_hip.h"\nint main(void) {\n'
     prog += '  printf("%zu\\n", sizeof(se_gemm_desc));\n' + ''.join(f'  printf("%zu\\n", offsetof(se_gemm_desc, {f}));\n' for f in fields_d)
