@@ -48,10 +48,11 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None, qkv_a
 attn_bwd_f16_ready = True
 
 
-def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None, qkv_amax=None, do_amax=None):
+def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None, qkv_amax=None, do_amax=None, dqkv_amax=None):
     """returns dQKV [ntok,192]; accumulates into dE [2*maxpos+1, 16].  leaf: optional context-manager factory (gemm.leaf_stream):
     the reduction of the per-wave dE tiles -- a leaf of the backward graph -- is then issued inside `leaf(ws, ...)`.
-    qkv_amax / do_amax: device scalars >= max |qkv| / max |dO| (producer epilogues): both given -> the scaled split-fp16 kernel."""
+    qkv_amax / do_amax: device scalars >= max |qkv| / max |dO| (producer epilogues): both given -> the scaled split-fp16 kernel,
+    which raises the zero-filled scalar dqkv_amax (optional) to max |dQKV| (returned as dqkv._se_amax)."""
     L.check_cuda(qkv, E, O, dO, lse, dE, qkv_amax, do_amax)
     ntok = qkv.shape[0]
     dqkv = torch.empty(ntok, 192, device=qkv.device, dtype=torch.float32)
@@ -68,13 +69,15 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None, qk
     def run(phase, **kw):
         if f16:
             L.call('se_attn_bwd_f16_phase', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(qkv_amax), L.ptr(do_amax),
-                   L.ptr(dqkv), L.ptr(dE), C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps),
+                   L.ptr(dqkv_amax), L.ptr(dqkv), L.ptr(dE), C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps),
                    C.c_long(ntok), C.c_int(maxpos), C.c_float(scale), L.ptr(ws), C.c_size_t(nbytes), C.c_int(phase), L.stream(), **kw)
             return
         L.call('se_attn_bwd_phase', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(dqkv), L.ptr(dE),
                C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_long(ntok),
                C.c_int(maxpos), C.c_float(scale), L.ptr(ws), C.c_size_t(nbytes), C.c_int(phase), L.stream(), **kw)
     tk = dict(_key=key + (' n>128' if n > 128 else ' n<=128'), _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
+    if f16 and dqkv_amax is not None:
+        dqkv._se_amax = dqkv_amax
     if leaf is None:
         run(3, **tk)
     else:

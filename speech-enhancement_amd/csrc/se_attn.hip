@@ -1043,6 +1043,7 @@ struct AttnBwd3Args {
   // scaled split-fp16 form (se_attn_bwd_f16): device scalars >= max |QKV|, max |dO|, max |E| (the last one written by the table
   // kernel of the same call); Es / Ets then hold TWO fp16 planes of E * 2^sexp(*e_amax)
   const float* qkv_amax; const float* do_amax; const float* e_amax;
+  float* dqkv_amax;                  // optional (F16): raised to max |dQKV| (operand scale of the consumers of the gradient)
 };
 
 // key tiles of wave w when the 4 waves of a workgroup share one (sequence, head)
@@ -1139,6 +1140,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
     st_planes<F16>(Kimg + ((s * 16 + c) * 16 + 4 * g) * 2, L3::KPB, splitx<F16>(k4, sqf));
   }
   f32x4 dk[NK], dv[NK], de[NU];
+  float omax = 0.f;                                                  // F16: max |dQKV| this wave stores
 #pragma unroll
   for (int s = 0; s < NK; ++s) { dk[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
@@ -1317,9 +1319,11 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
         const float4 t3 = *reinterpret_cast<const float4*>(slot + 3 * 256 + c * 16 + 4 * g);
         t0.x += t1.x + (t2.x + t3.x); t0.y += t1.y + (t2.y + t3.y); t0.z += t1.z + (t2.z + t3.z); t0.w += t1.w + (t2.w + t3.w);
         *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = t0;
+        if (F16) omax = fmaxf(fmaxf(omax, fmaxf(fabsf(t0.x), fabsf(t0.y))), fmaxf(fabsf(t0.z), fabsf(t0.w)));
       }
     } else if (q0 + c < n) {
       *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = make_float4(dq[0], dq[1], dq[2], dq[3]);
+      if (F16) omax = fmaxf(fmaxf(omax, fmaxf(fabsf(dq[0]), fabsf(dq[1]))), fmaxf(fabsf(dq[2]), fabsf(dq[3])));
     }
     // ---- slide the dE window: tile qt - kt0 - NK is complete ----
     flush(de[NU - 1], qt - kt0 - NK);
@@ -1338,7 +1342,15 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
       float* p = dqb + (unsigned)(key * ps * 192 + 4 * g);
       *reinterpret_cast<float4*>(p + 64) = make_float4(dk[s][0] * cq1, dk[s][1] * cq1, dk[s][2] * cq1, dk[s][3] * cq1);
       *reinterpret_cast<float4*>(p + 128) = make_float4(dv[s][0] * cdv, dv[s][1] * cdv, dv[s][2] * cdv, dv[s][3] * cdv);
+      if (F16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) omax = fmaxf(omax, fmaxf(fabsf(dk[s][r] * cq1), fabsf(dv[s][r] * cdv)));
+      }
     }
+  }
+  if (F16 && a.dqkv_amax) {
+    omax = wave_max(omax);
+    if (lane == 0) amax_raise_(a.dqkv_amax, omax);
   }
 }
 
@@ -1706,7 +1718,7 @@ static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float
 static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
                          float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
                          int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
-                         const float* qkv_amax = nullptr, const float* do_amax = nullptr);
+                         const float* qkv_amax = nullptr, const float* do_amax = nullptr, float* dqkv_amax = nullptr);
 
 extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                            float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
@@ -1726,21 +1738,21 @@ extern "C" int se_attn_bwd_phase(const float* QKV, const float* E, const float* 
 }
 
 extern "C" int se_attn_bwd_f16_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
-                                     const float* qkv_amax, const float* do_amax, float* dQKV, float* dE, int nseq, int n, int inner,
-                                     long outer_stride, long inner_stride, long pos_stride, long ntok, int maxpos, float scale,
-                                     void* ws, size_t ws_bytes, int phase, void* stream) {
+                                     const float* qkv_amax, const float* do_amax, float* dqkv_amax, float* dQKV, float* dE, int nseq,
+                                     int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok, int maxpos,
+                                     float scale, void* ws, size_t ws_bytes, int phase, void* stream) {
   SE_REQUIRE(phase == 1 || phase == 2 || phase == 3, "attn_bwd_f16_phase: phase must be 1, 2 or 3");
   SE_REQUIRE(qkv_amax && do_amax, "attn_bwd_f16: the maxima of QKV and dO are required");
   SE_REQUIRE(attn_v3_shape(n, maxpos) && pos_stride * 192 * (long)(16 * ((n + 15) / 16)) < 2147483647L,
              "attn_bwd_f16: shape outside the split-fp16 kernel (n = %d, maxpos = %d): use se_attn_bwd", n, maxpos);
   return attn_bwd_impl(QKV, E, O, dO, LSE, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
-                       ws, ws_bytes, phase, stream, qkv_amax, do_amax);
+                       ws, ws_bytes, phase, stream, qkv_amax, do_amax, dqkv_amax);
 }
 
 static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
                          float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
                          int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
-                         const float* qkv_amax, const float* do_amax) {
+                         const float* qkv_amax, const float* do_amax, float* dqkv_amax) {
   SE_REQUIRE(QKV && E && O && dO && LSE && dQKV && dE && ws, "attn_bwd: null operand");
   SE_REQUIRE(ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0, "attn_bwd: bad sizes");
   const AttnWs w = attn_ws(ntok, maxpos, nseq, n);
@@ -1771,7 +1783,7 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
       else hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
     }
     AttnBwd3Args b{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, dO, LSE, Dl, dQKV, Es, Ets,
-                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax};
+                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax, dqkv_amax};
     if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
     const long items = (long)nseq * 4;
     int e;

@@ -257,10 +257,13 @@ def build_generator_plan(P, device):
             a = f'{p}.attn.fn'
             plan.linear((a, 'qkv'), P[f'{a}.to_q.weight'], planes=l3, rows=192)
             plan.linear((a, 'qkv'), P[f'{a}.to_kv.weight'], planes=l3, o_off=64)
-            # the attention backward does not measure max |dqkv| (its 256-VGPR kernel has no room for it): the input-gradient
-            # GEMM of the qkv projection keeps the six-product kernel
+            # the three-way bf16 attention backward does not measure max |dqkv|: the input-gradient GEMM of the qkv projection keeps
+            # the six-product kernel there; the scaled split-fp16 backward does (dqkv._se_amax) -> fp16 planes for that case
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_q.weight'], planes=lpl, ld=192)
             plan.linear_T((a, 'qkvT'), P[f'{a}.to_kv.weight'], planes=lpl, c_off=64)
+            if l3 == 'f16' and ATTN_PRECISION[0] == 'f16x3':
+                plan.linear_T((a, 'qkvT16'), P[f'{a}.to_q.weight'], planes='f16', ld=192)
+                plan.linear_T((a, 'qkvT16'), P[f'{a}.to_kv.weight'], planes='f16', c_off=64)
             plan.linear_T((f'{a}.to_out.weight', 'T'), P[f'{a}.to_out.weight'], planes='f16' if l3 == 'f16' else False)
             if l3 == 'f16':
                 plan.linear((f'{a}.to_out.weight', 'lin'), P[f'{a}.to_out.weight'], planes='f16')
@@ -633,27 +636,30 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25,
                       leaf=None if _os.environ.get('SE_ATTN_DE_MAIN') == '1' else GM.leaf_stream,
-                      qkv_amax=qkv_amax, do_amax=do_amax)
-    WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT'), lambda: _T(Wqkv))
+                      qkv_amax=qkv_amax, do_amax=do_amax, dqkv_amax=_amax(dev) if (qkv_amax is not None and _os.environ.get('SE_NO_QKVT16') != '1') else None)
+    dq_amax = getattr(dqkv, '_se_amax', None)
+    WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT16' if dq_amax is not None else 'qkvT'), lambda: _T(Wqkv))
+    if WqkvT.dtype != torch.float16:
+        dq_amax = None
     gq, gkv = G[f'{p}.attn.fn.to_q.weight'], G[f'{p}.attn.fn.to_kv.weight']
     # to_q / to_kv are neighbours in the flat gradient buffer of the optimizers: the [192, 64] gradient of the fused projection
     # then accumulates in place; otherwise through a scratch matrix
     adjacent = gq.is_contiguous() and gkv.is_contiguous() and gq.data_ptr() + gq.numel() * 4 == gkv.data_ptr()
     dWqkv = torch.as_strided(gq, (192, 64), (64, 1)) if adjacent and gq.untyped_storage().nbytes() - gq.storage_offset() * 4 >= 192 * 64 * 4 \
         else O.zeros(192, 64, device=dev)
-    with GM.leaf_stream(y1, dqkv, st2):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN), y1, dqkv, dWqkv, None, rowstats=st2,
-                          ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
+    with GM.leaf_stream(y1, dqkv, st2, dq_amax):
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dq_amax), y1, dqkv, dWqkv, None,
+                          rowstats=st2, ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
         if dWqkv.data_ptr() != gq.data_ptr():
             gq += dWqkv[:64]
             gkv += dWqkv[64:]
     if FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
-        # (six-product kernel: max |dqkv| is not measured; its OUTPUT dy1 feeds the scaled-fp16 feed-forward backward -> max |dy1|)
+        # (its OUTPUT dy1 feeds the scaled-fp16 feed-forward backward -> max |dy1|)
         dy1 = GM.gemm_ln_bwd(dqkv, WqkvT, y1, st2, P[f'{p}.attn.norm.weight'], dy2, G[f'{p}.attn.norm.weight'],
                              G[f'{p}.attn.norm.bias'], out_amax=_amax(dev))
     else:
         dl2 = torch.empty(M, 64, device=dev, dtype=torch.float32)
-        GM.gemm_tap(GM.linear_desc(M, 192, 64), dqkv, WqkvT, dl2)
+        GM.gemm_tap(GM.linear_desc(M, 192, 64, **_lin3(WqkvT, a_amax=dq_amax)), dqkv, WqkvT, dl2)
         dy1 = O.layernorm_bwd(y1, st2, P[f'{p}.attn.norm.weight'], dl2, G[f'{p}.attn.norm.weight'],
                               G[f'{p}.attn.norm.bias'], dR=dy2, amax=_amax(dev))
         del dl2
