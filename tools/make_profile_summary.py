@@ -72,14 +72,16 @@ def fam(name):
     m = re.match(r'ff_(fwd|bwd)_kernel<(\d)', n)
     if m:
         return f'ff_{m.group(1)}{"_dgrad" if m.group(1) == "bwd" else ""}_bf16x{3 if m.group(2) == "2" else 6}'
+    f16 = n.rstrip('>').endswith(', true') and (n.startswith('attn_bwd3_kernel<6, true, true') or n.startswith('attn_bwd3_kernel<7, false, true')
+                                                or n.startswith('attn_fwd3_kernel<'))
     if n.startswith('attn_bwd3_kernel<6'):
-        return 'attn_bwd3_bf16x6 (+delta, tables, dE reduce) n>128'
+        return ('attn_bwd3_f16x3' if f16 else 'attn_bwd3_bf16x6') + ' (+delta, tables, dE reduce) n>128'
     if n.startswith('attn_bwd3_kernel<7'):
-        return 'attn_bwd3_bf16x6 (+delta, tables, dE reduce) n<=128'
+        return ('attn_bwd3_f16x3' if f16 else 'attn_bwd3_bf16x6') + ' (+delta, tables, dE reduce) n<=128'
     if n.startswith('attn_fwd2_kernel'):
         return 'attn_fwd2_kernel'
     if n.startswith('attn_fwd3_kernel'):
-        return 'attn_fwd3_bf16x6'
+        return 'attn_fwd3_f16x3' if f16 else 'attn_fwd3_bf16x6'
     if n.startswith('stft_fused_kernel') or n.startswith('istft_fused_kernel'):
         return n.replace('_kernel', '')
     return None
