@@ -322,6 +322,23 @@ int se_attn_bwd_phase(const float* QKV, const float* E, const float* O, const fl
                       float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
                       long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws, size_t ws_bytes,
                       int phase, void* stream);
+/* Scaled split-fp16 forms of the same attention (round 3; models/conformer.py:103-122): every operand is x * 2^sexp = hi + lo in
+ * two fp16 planes (the scale from a measured maximum, see se_gemm_desc.precision 3), every 16-deep product three
+ * v_mfma_f32_16x16x16_f16: fp32-equivalent results (tests/test_attn_gpu.py: 5e-6 / 2e-5 vs fp64 like the bf16 kernels) with
+ * 8-instruction operand splits instead of 18.  Sequence shapes: n <= 384, 16 ceil(n / 16) + 128 <= maxpos, maxpos % 16 == 0,
+ * 32-bit lane offsets (pos_stride * 192 * padded n < 2^31): anything else is a host error -- use se_attn_fwd_es / se_attn_bwd.
+ *   Es        : TWO fp16 planes [2][>= 2 maxpos + 1][16] of E * 2^sexp(*e_amax) (se_weight_prep fmt 1), es_plane elements apart
+ *   qkv_amax  : device scalar >= max |QKV| (e.g. raised by the qkv GEMM: se_gemm_desc.y_amax)
+ *   do_amax   : device scalar >= max |dO|  (the to_out input-gradient GEMM likewise)
+ *   dqkv_amax : optional zero-initialised device scalar raised to max |dQKV| (the scale of the gradient's consumers)
+ * The backward splits E itself (and measures its maximum) in its workspace; phases as se_attn_bwd_phase. */
+int se_attn_fwd_f16(const float* QKV, const void* Es, long es_plane, const float* qkv_amax, const float* e_amax, float* O,
+                    float* LSE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos,
+                    float scale, void* stream);
+int se_attn_bwd_f16_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
+                          const float* qkv_amax, const float* do_amax, float* dqkv_amax, float* dQKV, float* dE, int nseq, int n,
+                          int inner, long outer_stride, long inner_stride, long pos_stride, long ntok, int maxpos, float scale,
+                          void* ws, size_t ws_bytes, int phase, void* stream);
 
 /* ---- depthwise conv k=31 along the sequence axis (csrc/se_dwconv.hip) -------------------------- */
 /* DepthWiseConv1d forward (models/conformer.py:40-48,166) on [tokens][128] (+ fp64 BatchNorm statistics
