@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
 // 72 VGPRs the ordinary GEMMs must not pay)
 // F16 (precision 3): scaled split-fp16, NPL = 2 (se_gemm_dev.h); the accumulators are un-scaled before the epilogue.
 template <int PRO, int NPL, bool LIN, bool WPL = false, bool LNB = false, bool F16 = false>
-__global__ __launch_bounds__(256) void gemm_tap_bf16x3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, (LNB && F16) ? 3 : 1) void gemm_tap_bf16x3_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 64, BK = 32, SA = 40;     // rows of 32 bf16 + 8 pad = 80 B: conflict-free b128 reads
   constexpr int KQ = BK / 4, RPP = 256 / KQ, NA = BM / RPP, NB = BN / RPP;
   constexpr int PA = BM * SA, PB = BN * SA;               // plane strides
