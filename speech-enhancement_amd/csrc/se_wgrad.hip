@@ -10,6 +10,7 @@ struct WgradArgs {
   const float* rowstats; const float* ps; const float* pb;
   long rows_per_chunk;
   int nchunks;
+  int buf_ok;            // both operands span < 2^32 bytes: the triple-tap split kernels use range-checked buffer loads
 };
 
 template <int PRO>
@@ -503,6 +504,12 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   const bool nok = n_ld < d.N, cok = c_ld < d.C;
   const float* __restrict__ Yg = g.dY + d.c_off + n_ld;
   const float* __restrict__ Ag = g.A + d.a_off + c_ld;
+  // BUF (host-checked: both operands span < 2^32 bytes): range-checked buffer loads with 32-bit offsets instead of predicated
+  // 64-bit-address loads -- an invalid row / channel is sent out of range and reads zeros; no branch per load
+  const bool BUF = g.buf_ok != 0;
+  const __amdgpu_buffer_rsrc_t Yr = make_rsrc_(g.dY + d.c_off, BUF ? (unsigned)((((long)Mtot - 1) * d.ldc + d.N) * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t Ar = make_rsrc_(g.A + d.a_off, BUF ? (unsigned)((((long)Mtot - 1) * d.lda + d.C) * 4) : 0u);
+  const unsigned yb = nok ? (unsigned)n_ld * 4u : BUF_OOB_, xb = cok ? (unsigned)c_ld * 4u : BUF_OOB_;
 
   float4 ry[4], rx[4], rh;
   long eb[5];
@@ -519,10 +526,15 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
     for (int i = 0; i < 4; ++i) {
       const long mg = mbase + rg * 4 + i;
       const bool ok = mg < mend;
-      ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
       const int inb = ip[i] + ishift;
       const bool v = ok && cok && inb >= 0 && inb < Mb;
-      rx[i] = v ? *reinterpret_cast<const float4*>(Ag + (eb[i] + inb) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BUF) {      // (wave-uniform)
+        ry[i] = buf_load4_(Yr, ok ? (unsigned)mg * (unsigned)d.ldc * 4u + yb : BUF_OOB_);
+        rx[i] = buf_load4_(Ar, v ? (unsigned)(eb[i] + inb) * (unsigned)d.lda * 4u + xb : BUF_OOB_);
+      } else {
+        ry[i] = (ok && nok) ? *reinterpret_cast<const float4*>(Yg + mg * d.ldc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rx[i] = v ? *reinterpret_cast<const float4*>(Ag + (eb[i] + inb) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     if (tid < 32) {
       const int hsel = tid >> 4;
@@ -530,7 +542,8 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
       const int inb = ip[4] + ishift;
       const int nbp = hsel ? inb + 1 : inb - 1;
       const bool v = mg < mend && cok && inb >= 0 && inb < Mb && nbp >= 0 && nbp < Mb;
-      rh = v ? *reinterpret_cast<const float4*>(Ag + (eb[4] + nbp) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BUF) rh = buf_load4_(Ar, v ? (unsigned)(eb[4] + nbp) * (unsigned)d.lda * 4u + xb : BUF_OOB_);
+      else rh = v ? *reinterpret_cast<const float4*>(Ag + (eb[4] + nbp) * d.lda) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
@@ -666,6 +679,239 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
       int n = nb * 64 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], oscale * acc[s3][r]);
     }
+  }
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(Yt);
+    *reinterpret_cast<float4*>(&red[rg * 64 + 4 * q]) = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s_ += red[r * 64 + tid];
+      if (nb * 64 + tid < d.N) atomicAdd(&g.dbias[nb * 64 + tid], d.alpha * s_);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// WIDE form of wgrad3_bf16_kernel<2, F16, ORD> for C >= 128 (round 3): a workgroup owns 64 n x 128 c x 3 taps, a wave ALL 64 n (two
+// A fragments) x one 32-channel block.  The expensive part of a k-step is the B side -- the unaligned +-1 window (four v_alignbit
+// per plane), its edge test, three LDS reads per plane -- and it now feeds six MFMAs per tap instead of three; the dY tile is
+// split and staged once per 128 channels instead of once per 64.  VALU per MFMA 12 -> 7.  Same cell layouts (rows 64..127 of the
+// activation image continue the 10 r + (r >> 3) pattern), same scaled split-fp16 arithmetic, taps in the order df = -1, 0, +1.
+__global__ __launch_bounds__(256, 2) void wgrad3w_f16_kernel(WgradArgs g) {
+  constexpr int MR = 64, NPL = 2;
+  constexpr int PLY = (9 * 64 + 4) * 8;        // Yt plane: [64 n][64 m],  cell(r, ch) = 9 r + (r >> 4) + ch
+  constexpr int PLX = (10 * 128 + 16) * 8;     // Xt plane: [128 c][80 positions], cell(r, ch) = 10 r + (r >> 3) + ch
+  __shared__ __attribute__((aligned(16))) __bf16 Yt[NPL * PLY];
+  __shared__ __attribute__((aligned(16))) __bf16 Xt[NPL * PLX];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = (d.C + 127) / 128, nnb = (d.N + 63) / 64, ngrp = d.ntap / 3;
+  const WorkId wk_ = decode_work(ngrp * ncb * nnb, g.nchunks, 0);
+  if (wk_.outer >= g.nchunks) return;
+  const int chunk = wk_.outer, tc = wk_.inner / nnb, nb = wk_.inner - tc * nnb;
+  const int gi = tc / ncb, cb = tc - gi * ncb;
+  const int Mb = d.To * d.Fo;
+  const long Mtot = (long)d.B * Mb;
+  const long mbeg = (long)chunk * g.rows_per_chunk;
+  long mend = mbeg + g.rows_per_chunk;
+  if (mend > Mtot) mend = Mtot;
+  const int q = tid & 15, rg = tid >> 4;
+  const bool do_bias = g.dbias != nullptr && tc == 0;
+  const int ishift = d.dt[3 * gi] * d.Fo;
+  f16_clamp_mode_();
+  const int ex = operand_sexp_(d.a_amax, d.a_sexp), ey = operand_sexp_(d.w_amax, d.w_sexp);
+  const float sx = exp2i_(ex), sy = exp2i_(ey), unscale = exp2i_(-ex - ey);
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][s3][r] = 0.f;
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int n_ld = nb * 64 + q * 4, c_ld = cb * 128 + q * 4;
+  const bool nok = n_ld < d.N;
+  const bool cok[2] = {c_ld < d.C, c_ld + 64 < d.C};
+  // range-checked buffer descriptors, 32-bit byte offsets (host-checked < 2^32): an invalid row / channel is sent out of range
+  // and reads zeros -- no branch, no 64-bit address per load (the predicated form spilled a pointer and reloaded it, with a full
+  // vmcnt(0), in front of every load: the step's twelve loads ran one after the other)
+  const __amdgpu_buffer_rsrc_t Yr = make_rsrc_(g.dY + d.c_off, (unsigned)((((long)Mtot - 1) * d.ldc + d.N) * 4));
+  const __amdgpu_buffer_rsrc_t Ar = make_rsrc_(g.A + d.a_off, (unsigned)((((long)Mtot - 1) * d.lda + d.C) * 4));
+  const unsigned yb = nok ? (unsigned)n_ld * 4u : BUF_OOB_;
+  const unsigned xb[2] = {cok[0] ? (unsigned)c_ld * 4u : BUF_OOB_, cok[1] ? (unsigned)(c_ld + 64) * 4u : BUF_OOB_};
+
+  float4 ry[4], rx[2][4], rh[2];
+  long eb[5];
+  int ip[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const long mg = mbeg + (i < 4 ? rg * 4 + i : ((tid >> 4) & 1) * (MR - 1));
+    const long bq = mg / Mb;
+    eb[i] = bq * Mb;
+    ip[i] = (int)(mg - eb[i]);
+  }
+  auto load_tiles = [&](long mbase) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long mg = mbase + rg * 4 + i;
+      const bool ok = mg < mend;
+      ry[i] = buf_load4_(Yr, ok ? (unsigned)mg * (unsigned)d.ldc * 4u + yb : BUF_OOB_);
+      const int inb = ip[i] + ishift;
+      const bool v = ok && inb >= 0 && inb < Mb;
+      const unsigned ro = (unsigned)(eb[i] + inb) * (unsigned)d.lda * 4u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) rx[h][i] = buf_load4_(Ar, v ? ro + xb[h] : BUF_OOB_);
+    }
+    if (tid < 32) {
+      const int hsel = tid >> 4;
+      const long mg = hsel ? mbase + MR - 1 : mbase;
+      const int inb = ip[4] + ishift;
+      const int nbp = hsel ? inb + 1 : inb - 1;
+      const bool v = mg < mend && inb >= 0 && inb < Mb && nbp >= 0 && nbp < Mb;
+      const unsigned ro = (unsigned)(eb[4] + nbp) * (unsigned)d.lda * 4u;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) rh[h] = buf_load4_(Ar, v ? ro + xb[h] : BUF_OOB_);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      ip[i] += MR;
+      if (ip[i] >= Mb) { ip[i] -= Mb; eb[i] += Mb; }
+    }
+  };
+  // 4 x 4 register transpose + split + 8-B store per column (row r0 + 4 q + j of the image)
+  auto stage_t = [&](const float4 (&v)[4], __bf16* T, int pln, bool halo_layout, float sc, int r0) {
+    const float x[4][4] = {{v[0].x, v[0].y, v[0].z, v[0].w}, {v[1].x, v[1].y, v[1].z, v[1].w},
+                           {v[2].x, v[2].y, v[2].z, v[2].w}, {v[3].x, v[3].y, v[3].z, v[3].w}};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + 4 * q + j;
+      __bf16* dst = halo_layout ? T + (10 * r + (r >> 3)) * 8 + 8 + 4 * rg : T + (9 * r + (r >> 4)) * 8 + 4 * rg;
+      split_store_h(make_float4(x[0][j], x[1][j], x[2][j], x[3][j]), sc, dst, pln);
+    }
+  };
+  int fbase = (int)((mbeg % Mb) % d.Fo);      // frequency index of the step's first row (wave-uniform)
+  if (mbeg < mend) load_tiles(mbeg);
+  const int l31 = lane & 31, kg = lane >> 5;
+  const int rb_ = wave * 32 + l31;
+  const __bf16* yfrag[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { const int ra_ = a * 32 + l31; yfrag[a] = Yt + (9 * ra_ + (ra_ >> 4)) * 8 + 8 * kg; }
+  const __bf16* xrow = Xt + (10 * rb_ + (rb_ >> 3)) * 8;
+  const bool active = cb * 128 + wave * 32 < d.C;            // (wave-uniform) a wave whose channel block is padding skips the products
+  for (long mb = mbeg; mb < mend; mb += MR) {
+    stage_t(rx[0], Xt, PLX, true, sx, 0);
+    stage_t(rx[1], Xt, PLX, true, sx, 64);
+    stage_t(ry, Yt, PLY, false, sy, 0);
+    if (tid < 32) {                            // halo rows: positions 7 and 72
+      const int ph = (tid >> 4) ? 72 : 7;
+      unsigned short* xt = reinterpret_cast<unsigned short*>(Xt);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float hv[4] = {rh[h].x, rh[h].y, rh[h].z, rh[h].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 64 * h + 4 * q + j;
+          const float e = hv[j] * sx;
+          const _Float16 hh = (_Float16)e, ll = (_Float16)(e - (float)hh);
+          xt[(10 * r + (r >> 3)) * 8 + ph] = __builtin_bit_cast(unsigned short, hh);
+          xt[PLX + (10 * r + (r >> 3)) * 8 + ph] = __builtin_bit_cast(unsigned short, ll);
+        }
+      }
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bsum.x += ry[i].x; bsum.y += ry[i].y; bsum.z += ry[i].z; bsum.w += ry[i].w; }
+    }
+    // positions (in the 80-slot LDS row) of the frequency-edge rows of this tile, -100 when there is none
+    const int r0f = fbase == 0 ? 0 : d.Fo - fbase;                  // tile row with frequency 0
+    const int pL = r0f <= 64 ? 8 + r0f : (r0f == d.Fo - 1 ? 7 : -100);
+    const int r1f = d.Fo - 1 - fbase;                                // tile row with frequency Fo - 1
+    const int pR = r1f <= 64 ? 8 + r1f : (r1f == d.Fo - 1 ? 7 : -100);
+    fbase += MR % d.Fo;
+    if (fbase >= d.Fo) fbase -= d.Fo;
+    __syncthreads();
+    if (mb + MR < mend) load_tiles(mb + MR);
+    if (active) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int jc = 2 * ks + kg + 1;
+        bf16x8 af[2][NPL];
+        unsigned cen[NPL][4], prv[NPL], nxt[NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) af[a][pl] = *reinterpret_cast<const bf16x8*>(yfrag[a] + pl * PLY + 16 * ks);
+          const __bf16* xp = xrow + pl * PLX + 8 * jc;
+          const uint4 cv = *reinterpret_cast<const uint4*>(xp);
+          cen[pl][0] = cv.x; cen[pl][1] = cv.y; cen[pl][2] = cv.z; cen[pl][3] = cv.w;
+          prv[pl] = *reinterpret_cast<const unsigned*>(xp - 2);
+          nxt[pl] = *reinterpret_cast<const unsigned*>(xp + 8);
+        }
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+          const int df = s3 - 1;
+          bf16x8 bf[NPL];
+          if (df == 0) {
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) { uint4 u = make_uint4(cen[pl][0], cen[pl][1], cen[pl][2], cen[pl][3]); bf[pl] = *reinterpret_cast<bf16x8*>(&u); }
+          } else {
+            const int e0 = (df > 0 ? pL - 1 : pR + 1) - 8 * (2 * ks + 1);      // e of the lanes kg == 0; kg == 1: e0 - 8
+            const bool has_edge = e0 >= 0 && e0 < 16;
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) {
+              unsigned o[4];
+              if (df > 0) {
+                o[0] = __builtin_amdgcn_alignbit(cen[pl][1], cen[pl][0], 16); o[1] = __builtin_amdgcn_alignbit(cen[pl][2], cen[pl][1], 16);
+                o[2] = __builtin_amdgcn_alignbit(cen[pl][3], cen[pl][2], 16); o[3] = __builtin_amdgcn_alignbit(nxt[pl], cen[pl][3], 16);
+              } else {
+                o[0] = __builtin_amdgcn_alignbit(cen[pl][0], prv[pl], 16); o[1] = __builtin_amdgcn_alignbit(cen[pl][1], cen[pl][0], 16);
+                o[2] = __builtin_amdgcn_alignbit(cen[pl][2], cen[pl][1], 16); o[3] = __builtin_amdgcn_alignbit(cen[pl][3], cen[pl][2], 16);
+              }
+              uint4 u = make_uint4(o[0], o[1], o[2], o[3]);
+              bf[pl] = *reinterpret_cast<bf16x8*>(&u);
+            }
+            if (has_edge) {
+              const int e = e0 - 8 * kg;
+#pragma unroll
+              for (int pl = 0; pl < NPL; ++pl) {
+                uint4 u = *reinterpret_cast<uint4*>(&bf[pl]);
+                unsigned* w4 = reinterpret_cast<unsigned*>(&u);
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) w4[dd] &= e == 2 * dd ? 0xFFFF0000u : (e == 2 * dd + 1 ? 0x0000FFFFu : 0xFFFFFFFFu);
+                bf[pl] = *reinterpret_cast<bf16x8*>(&u);
+              }
+            }
+          }
+#pragma unroll
+          for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+            for (int qa = 0; qa <= ord; ++qa)
+#pragma unroll
+              for (int a = 0; a < 2; ++a)
+                acc[a][s3] = mfma32_<true>(af[a][qa], bf[ord - qa], acc[a][s3]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int col = lane & 31, half = lane >> 5;
+  const int c = cb * 128 + wave * 32 + col;
+  const float oscale = d.alpha * unscale;
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int tap = 3 * gi + s3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = nb * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (n < d.N && c < d.C) atomicAdd(&g.dW[(long)n * d.ldw + (long)tap * d.C + c], oscale * acc[a][s3][r]);
+        }
+      }
   }
   if (do_bias) {
     float* red = reinterpret_cast<float*>(Yt);
@@ -1054,7 +1300,9 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
   long rpc = (Mtot + chunks - 1) / chunks;
   rpc = ((rpc + 63) / 64) * 64;
   chunks = (int)((Mtot + rpc - 1) / rpc);
-  WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc, chunks};
+  WgradArgs g{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rpc, chunks, 0};
+  g.buf_ok = ((Mtot - 1) * d->lda + d->C) * 4 < 4294967280L && ((Mtot - 1) * d->ldc + d->N) * 4 < 4294967280L &&
+             getenv("SE_WGRAD3_NO_BUF") == nullptr;
   dim3 grid((unsigned)((long)d->ntap * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8))), block(256);
   hipStream_t s = as_stream(stream);
   if (d->prologue == SE_PRO_NONE && !(d->epilogue & SE_EPI_DROP) && !d->up && d->st == 1 && d->sf == 1 &&
@@ -1072,7 +1320,11 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
     }
     if (triples && (d->precision == 0 || d->Fo > 66)) {
       dim3 g3((unsigned)((long)(d->ntap / 3) * cdiv(d->C, 64) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8)));
-      if (d->precision == 3 && ordered) hipLaunchKernelGGL((wgrad3_bf16_kernel<2, true, true>), g3, block, 0, s, g);
+      if (d->precision == 3 && ordered && d->C >= 128 && getenv("SE_WGRAD3_NARROW") == nullptr && g.buf_ok) {
+        dim3 g3w((unsigned)((long)(d->ntap / 3) * cdiv(d->C, 128) * cdiv(d->N, 64) * ((chunks + 7) / 8 * 8)));
+        hipLaunchKernelGGL(wgrad3w_f16_kernel, g3w, block, 0, s, g);
+      }
+      else if (d->precision == 3 && ordered) hipLaunchKernelGGL((wgrad3_bf16_kernel<2, true, true>), g3, block, 0, s, g);
       else if (d->precision == 3) hipLaunchKernelGGL((wgrad3_bf16_kernel<2, true>), g3, block, 0, s, g);
       else if (d->precision == 1) hipLaunchKernelGGL(wgrad3_bf16_kernel<2>, g3, block, 0, s, g);
       else if (d->precision == 2) hipLaunchKernelGGL(wgrad3_bf16_kernel<3>, g3, block, 0, s, g);
