@@ -18,6 +18,9 @@
 // ([B*T, F', C], generator.py:71) both run on the one channels-last [B, T, F', C] buffer with no transposes.
 #include "se_common.h"
 #include <stdlib.h>
+#ifndef SE_ATTN_NO_XCD_MAP
+#define SE_ATTN_NO_XCD_MAP 0
+#endif
 
 struct AttnGeom {
   int nseq, n;             // sequences, positions per sequence
@@ -466,6 +469,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ite
 // fragment loads are single 16-byte LDS / global accesses (contraction index d = 4g + s, so a lane's 4 MFMA steps read
 // one contiguous float4), token address arithmetic hoisted out of the loops.
 // =====================================================================================================================
+// (sequence, head) item of workgroup b when ONE workgroup handles one item: workgroups are dealt round-robin to the 8 XCDs, so with
+// item = b the four heads of a sequence -- which share every 128-B line of its QKV / dO rows (a head is 64 B of them) -- land on
+// four different L2s and every line crosses the fabric twice.  Here the heads of a sequence are the workgroups b, b + 8, b + 16,
+// b + 24: same XCD, dispatched together.  Measured (FETCH_SIZE): forward 0.86 -> see DESIGN.md; the tail (grid % 32) keeps item = b.
+static __device__ __forceinline__ int xcd_item(int b, int nb) {
+  if (b >= (nb & ~31) || SE_ATTN_NO_XCD_MAP) return b;
+  return (((b >> 5) * 8 + (b & 7)) << 2) | ((b >> 3) & 3);
+}
 static __device__ __forceinline__ long seq_base(const AttnGeom& g, int s) {
   return (long)(s / g.inner) * g.outer_stride + (long)(s % g.inner) * g.inner_stride;
 }
@@ -1363,9 +1374,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
     int kt0, cnt;
     group_split(nkt, wave, kt0, cnt);
     // every wave runs nqt barriers whichever branch it takes (s_barrier counts arrivals, not program counters)
-    if (cnt == KT) attn_bwd3_body<KT, KT, true, true, F16>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
-    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true, F16>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
-    else attn_bwd3_body<KT, KT, false, true, F16>(a, smem3, wave, lane, blockIdx.x, kt0, cnt);
+    const long gitem = xcd_item((int)blockIdx.x, (int)gridDim.x);
+    if (cnt == KT) attn_bwd3_body<KT, KT, true, true, F16>(a, smem3, wave, lane, gitem, kt0, cnt);
+    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true, F16>(a, smem3, wave, lane, gitem, kt0, cnt);
+    else attn_bwd3_body<KT, KT, false, true, F16>(a, smem3, wave, lane, gitem, kt0, cnt);
   } else {
     const long item = (long)blockIdx.x * 4 + wave;
     if (item >= (long)a.g.nseq * 4) return;                     // whole wave leaves: EXEC stays full for the others
@@ -1433,7 +1445,8 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   const int NT = blockDim.x, NW = NT >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int n = a.g.n;
-  const int head = blockIdx.x & 3, seq = blockIdx.x >> 2;
+  const int item_ = xcd_item((int)blockIdx.x, (int)gridDim.x);
+  const int head = item_ & 3, seq = item_ >> 2;
   const long base = seq_base(a.g, seq);
   const int ps = (int)a.g.pos_stride;
   const float* qb = a.QKV + base * 192 + head * 16;
