@@ -1068,7 +1068,9 @@ template <int KT, bool F16 = false>
 struct Lds3 {
   static constexpr int NU = KT + 1;
   static constexpr int NPLA = F16 ? 2 : 3;                    // planes of a split operand: (hi, mid, lo) bf16 / (hi, lo) fp16
-  static constexpr int SW = NU * 16 + (KT == 7 ? 0 : 4);      // strip row stride (floats)
+  // strip row stride (floats): + 4 makes the skewed cell accesses (row stride SW + 1) conflict free -- the three-plane images of
+  // the bf16 form at KT = 7 left no room for it within 80 KB per workgroup (two per CU); the two-plane fp16 form has it
+  static constexpr int SW = NU * 16 + ((KT == 7 && !F16) ? 0 : 4);
   static constexpr int KPB = KT * 16 * 32;                    // bytes of one plane of the K image
   static constexpr int KIMG = NPLA * KPB;                     // bytes: [planes][KT*16 keys][16 d] 16-bit
   static constexpr int DIMG = NPLA * 16 * 32;                 // bytes: [planes][16][16] 16-bit (one tile, split)
