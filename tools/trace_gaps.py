@@ -10,7 +10,8 @@ for r in csv.DictReader(open(f)):
 rows.sort()
 # the optimizer kernel closes a step: take the window between the 3rd-last and the last adamw of the generator
 ends = [i for i, r in enumerate(rows) if 'adamw' in r[2]]
-steps = ends[1::2] if len(ends) >= 4 else ends
+per_step = 4                      # AdamW launches per step: two flat buffers (decay / no decay) for each of the two models
+steps = ends[per_step - 1::per_step]
 i0, i1 = steps[-3], steps[-1]
 win = rows[i0 + 1:i1 + 1]
 t0, t1 = win[0][0], max(r[1] for r in win)
