@@ -1437,6 +1437,7 @@ __global__ __launch_bounds__(256) void attn_de_reduce3_kernel(const float* __res
 // 2^sq (sq from *qkv_amax), the E table arrives as two fp16 planes scaled by 2^se (se from *e_amax), P by 2^13 (folded into the
 // exponent argument); S and U are brought to the logit scale by the two factors of one multiply + one FMA per element, the
 // output by one multiply per element at the end.
+template <int V> struct IC_ { static constexpr int value = V; };
 template <int TQ, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
@@ -1487,6 +1488,16 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   const float l2e = 1.4426950408889634f * a.scale;
   const int qblocks = (n + 16 * TQ - 1) / (16 * TQ), nkt = (n + 15) / 16;
   const int trrow = c >> 2, trcol = c & 3;
+  // lane-constant offsets (floats, without the tile's t * 512) of the four window cells, per parity of the hi slot: cell (key 4g + r,
+  // query c) holds offset dl = c - (4g + r): in the hi strip for dl >= 0, else in the lo strip at 16 + dl
+  int coff[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dl = c - (4 * g + r);
+      coff[h][r] = (dl >= 0 ? h * 256 : (h ^ 1) * 256 + 256) + dl * 16 + c;
+    }
   const unsigned char* Esp = reinterpret_cast<const unsigned char*>(a.Es);
   auto e_row = [&](int D) -> S3 {             // E[clamp(D + c)][4g..4g+3], split: the A operand rows are offsets
     int d = D + c;
@@ -1525,9 +1536,13 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
     for (int t = 0; t < TQ; ++t) { ef[t + 1] = e_row(i0 + 16 * t); u_tile(ef[t + 1], t, 0); }
     S3 enext = e_row(i0 - 16);
     float4 knext = k_row(0);
-    int hi = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int j0 = kt * 16, lo = hi ^ 1;
+    // The strip slot that holds the hi offsets alternates with the key step: the loop is unrolled by two so that the slot is a
+    // compile-time constant (cell addresses = lane-constant offset + immediate), and only the LAST key tile can hold keys >= n:
+    // the validity selects live in its own instantiation of the step.
+    auto key_step = [&](auto HC, auto MC, const int kt) {
+      constexpr int hi = decltype(HC)::value, lo = hi ^ 1;
+      constexpr bool MASK = decltype(MC)::value != 0;
+      const int j0 = kt * 16;
       ef[0] = enext;
       const S3 kf = splitx<F16>(knext, sqf);
       if (kt + 1 < nkt) { enext = e_row(i0 - j0 - 32); knext = k_row(j0 + 16); }      // one step ahead
@@ -1542,14 +1557,11 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
         // the four window cells first, through SELECTED ADDRESSES (a ternary over the two loads compiles to one exec-masked
         // branch per cell: eight branch regions per key step)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int dl = c - (4 * g + r);
-          uu[r] = Ul[(dl >= 0 ? (t * 2 + hi) * 256 : (t * 2 + lo) * 256 + 256) + dl * 16 + c];
-        }
+        for (int r = 0; r < 4; ++r) uu[r] = Ul[t * 512 + coff[hi][r]];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float lg = F16 ? fmaf(uu[r], cU, s4[r] * cS) : (s4[r] + uu[r]) * l2e;
-          sc[r] = (j0 + 4 * g + r < n) ? lg : -1e30f;
+          sc[r] = (!MASK || j0 + 4 * g + r < n) ? lg : -1e30f;
           tmax = fmaxf(tmax, sc[r]);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
@@ -1570,7 +1582,13 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
       // slide the offset window: next step's hi fragments are this step's lo fragments
 #pragma unroll
       for (int t = TQ; t > 0; --t) ef[t] = ef[t - 1];
-      hi = lo;
+    };
+    {
+      const int nlast = nkt - 1;
+      int kt = 0;
+      for (; kt + 2 <= nlast; kt += 2) { key_step(IC_<0>{}, IC_<0>{}, kt); key_step(IC_<1>{}, IC_<0>{}, kt + 1); }
+      if (kt < nlast) { key_step(IC_<0>{}, IC_<0>{}, kt); ++kt; }
+      if (kt & 1) key_step(IC_<1>{}, IC_<1>{}, kt); else key_step(IC_<0>{}, IC_<1>{}, kt);
     }
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
