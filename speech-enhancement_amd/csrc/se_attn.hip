@@ -926,6 +926,15 @@ static __device__ __forceinline__ S3 splitx(float x0, float x1, float x2, float 
   else return split3(x0, x1, x2, x3);
 }
 template <bool F16> static __device__ __forceinline__ S3 splitx(const float4& v, float sc) { return splitx<F16>(v.x, v.y, v.z, v.w, sc); }
+// operands that are already at their scale (P with its 2^13 in the exponent argument, dS, W): no multiply (x * 1.0f is not dropped)
+template <bool F16> static __device__ __forceinline__ S3 splitn(const f32x4& v) {
+  if constexpr (F16) return split2h(v[0], v[1], v[2], v[3]);
+  else return split3(v[0], v[1], v[2], v[3]);
+}
+template <bool F16> static __device__ __forceinline__ S3 splitn(const float4& v) {
+  if constexpr (F16) return split2h(v.x, v.y, v.z, v.w);
+  else return split3(v.x, v.y, v.z, v.w);
+}
 template <bool F16> static __device__ __forceinline__ S3 splitx(const f32x4& v, float sc) { return splitx<F16>(v[0], v[1], v[2], v[3], sc); }
 #define MFMA_HF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4a, (a)), __builtin_bit_cast(f16x4a, (b)), (c), 0, 0, 0)
 template <bool F16>
@@ -1260,7 +1269,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
           *cell = ds[r];                                             // W = skew(dS) replaces U in place
         }
         // contraction over the query rows 4g + r: the accumulator registers ARE the B operands
-        const S3 pps = splitx<F16>(pp, 1.f), dss = splitx<F16>(ds, 1.f);
+        const S3 pps = splitn<F16>(pp), dss = splitn<F16>(ds);
         // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
         prodx2<F16>(docol, pps, dv[s], qcol, dss, dk[s]);
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: both operands through hardware-transposed reads -- A from the K row
@@ -1299,7 +1308,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
             if ((unsigned)(kr - 2) >= (unsigned)lim) w4.z = 0.f;
             if ((unsigned)(kr - 3) >= (unsigned)lim) w4.w = 0.f;
           }
-          const S3 ws = splitx<F16>(w4, 1.f);                           // (W = skew(dS): already at dS's scale)
+          const S3 ws = splitn<F16>(w4);                           // (W = skew(dS): already at dS's scale)
           st_planes<F16>(Dimg + c * 32 + g * 8, 512, ws);                // image [a][dl]
           const S3 wt = tr_planes<F16>(Dimg + (4 * g + trrow) * 32 + trcol * 8, 512);      // W[a = 4g + j][dl = c]
           // dQ^T[d][q] += E^T[d][dl] W^T[dl][q];  dE^T[d][dl] += Q^T[d][q] W[q][dl]
@@ -1577,7 +1586,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
         l[t] = l[t] * corr + psum;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[t][r] *= corr;
-        o[t] = prodx<F16>(vcol, splitx<F16>(p, 1.f), o[t]);         // O^T[d 4g + r][query c] += V^T[d][key] P^T[key][query]
+        o[t] = prodx<F16>(vcol, splitn<F16>(p), o[t]);         // O^T[d 4g + r][query c] += V^T[d][key] P^T[key][query]
       }
       // slide the offset window: next step's hi fragments are this step's lo fragments
 #pragma unroll
