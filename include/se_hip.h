@@ -398,6 +398,8 @@ int se_glu_bwd_amax(const float* Z, const float* dU, float* dZ, long M, int H, f
 int se_glu_bwd_gate(const float* U, const float* G, const float* dU, float* dZ, long M, int H, float* amax_out, void* stream);
 /* MergeBlock gate of the TSC-diffusion hybrid (models/tsc_diffusion.py:34-35): Y [M][2C] (gate | filter) -> G [M][C] = sigmoid(gate) tanh(filter) */
 int se_gate_tanh(const float* Y, float* G, long M, int C, void* stream);
+/* its backward (training of the hybrid, core/function.py:453-532): dY [M][2C] from Y and dG [M][C] */
+int se_gate_tanh_bwd(const float* Y, const float* dG, float* dY, long M, int C, void* stream);
 /* loss reductions of train_gan (core/function.py:251-258) and their gradient seeds (`up` = device scalars) */
 int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream);
 int se_spec_loss_bwd(const float* A, const float* Bp, float* dA, const float* up, float cmag, float cri, long n,

@@ -66,3 +66,29 @@ def predict_tsc(sd, noisy_signal, sched, noises, comp='pow'):
             audio = float(c1[n]) * audio - float(c3[n]) * pred
             audio = 0.8 * audio + 0.2 * noisy_audio
     return (audio / c[:, None]).flatten()[:length]
+
+
+def add_noise(audio, noisy, noise_schedule, t, noise):
+    """core/function.py:25-44 with the draws supplied (t [N] int64, noise like audio)"""
+    beta = np.array(noise_schedule)
+    noise_level = torch.tensor(np.cumprod(1 - beta).astype(np.float32))
+    ns = noise_level[t].unsqueeze(1)
+    m = (((1 - noise_level[t]) / noise_level[t] ** 0.5) ** 0.5).unsqueeze(1)
+    tail = (1.0 - (1 + m ** 2) * ns) ** 0.5 * noise
+    noisy_audio = (1 - m) * ns ** 0.5 * audio + m * ns ** 0.5 * noisy + tail
+    combine_noise = (m * ns ** 0.5 * (noisy - audio) + tail) / (1 - ns) ** 0.5
+    return noisy_audio, combine_noise
+
+
+def train_loss(sd, clean, noisy, noise_schedule, t, noise, comp='pow'):
+    """the loss of one train_tsc_diffusion iteration (core/function.py:472-505) as a differentiable function of the state dict `sd`
+    (train mode: BatchNorm batch statistics; dropout 0 like the goldens): normalize_batch, add_noise, two compressed STFTs, the
+    hybrid generator, iSTFT, mean |predicted - combine_noise|"""
+    c = torch.sqrt(noisy.shape[-1] / torch.sum(noisy ** 2, -1))
+    clean, noisy = clean * c[:, None], noisy * c[:, None]
+    noisy_audio, combine_noise = add_noise(clean, noisy, noise_schedule, t, noise)
+    orig = SO.compressed_stft(noisy, comp=comp)
+    nz = SO.compressed_stft(noisy_audio, comp=comp)
+    er, ei = forward(sd, nz, orig, t, train=True)
+    pred = SO.uncompressed_istft(torch.complex(er, ei).squeeze(1).permute(0, 2, 1), comp=comp)
+    return torch.mean(torch.abs(pred - combine_noise))

@@ -270,6 +270,30 @@ __global__ void gate_tanh_kernel(const float* __restrict__ Y, float* __restrict_
                                                                 sigmoidf_(a.z) * th(f.z), sigmoidf_(a.w) * th(f.w));
 }
 
+// backward of the gate: dY [M, 2C] = (dG tanh(f) s (1 - s) | dG s (1 - tanh(f)^2)), s = sigmoid(gate)   (training of the hybrid,
+// core/function.py:453-532)
+__global__ void gate_tanh_bwd_kernel(const float* __restrict__ Y, const float* __restrict__ dG, float* __restrict__ dY, long M, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of C per thread
+  const int cq = C >> 2;
+  if (idx >= M * cq) return;
+  const long row = idx / cq;
+  const int q = (int)(idx - row * cq);
+  const float4 a = *reinterpret_cast<const float4*>(Y + row * 2 * C + q * 4);
+  const float4 f = *reinterpret_cast<const float4*>(Y + row * 2 * C + C + q * 4);
+  const float4 d = *reinterpret_cast<const float4*>(dG + row * C + q * 4);
+  auto th = [](float x) { const float e = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x)); const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e); return x < 0.f ? -t : t; };
+  const float av[4] = {a.x, a.y, a.z, a.w}, fv[4] = {f.x, f.y, f.z, f.w}, dv[4] = {d.x, d.y, d.z, d.w};
+  float da[4], df[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float s_ = sigmoidf_(av[j]), t = th(fv[j]);
+    da[j] = dv[j] * t * s_ * (1.f - s_);
+    df[j] = dv[j] * s_ * (1.f - t * t);
+  }
+  *reinterpret_cast<float4*>(dY + row * 2 * C + q * 4) = make_float4(da[0], da[1], da[2], da[3]);
+  *reinterpret_cast<float4*>(dY + row * 2 * C + C + q * 4) = make_float4(df[0], df[1], df[2], df[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // spectral losses on planes (mag, re, im, -): sums[0] += sum (mag-mag')^2, sums[1] += sum (re-re')^2 + (im-im')^2
 __global__ __launch_bounds__(256) void spec_loss_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
@@ -562,6 +586,11 @@ extern "C" int se_gate_tanh(const float* Y, float* G, long M, int C, void* strea
   SE_REQUIRE(Y && G && M > 0 && C > 0 && (C % 4) == 0, "gate_tanh: bad arguments");
   EW_LAUNCH(gate_tanh_kernel, M * (C / 4), stream, Y, G, M, C);
   return se_check_launch("se_gate_tanh");
+}
+extern "C" int se_gate_tanh_bwd(const float* Y, const float* dG, float* dY, long M, int C, void* stream) {
+  SE_REQUIRE(Y && dG && dY && M > 0 && C > 0 && (C % 4) == 0, "gate_tanh_bwd: bad arguments");
+  EW_LAUNCH(gate_tanh_bwd_kernel, M * (C / 4), stream, Y, dG, dY, M, C);
+  return se_check_launch("se_gate_tanh_bwd");
 }
 extern "C" int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream) {
   SE_REQUIRE(A && Bp && sums && n > 0, "spec_loss: bad arguments");

@@ -355,8 +355,7 @@ def encoder_fwd(P, xin, B, T, Fq, p='dense_encoder'):
     return out, ctx
 
 
-def encoder_bwd(P, G, ctx, dout, B, T, Fq):
-    p = 'dense_encoder'
+def encoder_bwd(P, G, ctx, dout, B, T, Fq, p='dense_encoder'):
     Fo = ctx['Fo']
     dR5 = inorm_prelu_bwd(ctx['R5'], ctx['mr5'], P[f'{p}.conv_2.1.weight'], P[f'{p}.conv_2.1.bias'],
                           P[f'{p}.conv_2.2.weight'], dout, 64, 0, G[f'{p}.conv_2.1.weight'],

@@ -295,6 +295,12 @@ def gate_tanh(Y, M, C_):
     return G
 
 
+def gate_tanh_bwd(Y, dG, M, C_):
+    dY = torch.empty(M, 2 * C_, device=Y.device, dtype=torch.float32)
+    L.call('se_gate_tanh_bwd', L.ptr(Y), L.ptr(dG), L.ptr(dY), _l(M), _i(C_), L.stream())
+    return dY
+
+
 def spec_loss(A, B_, sums):
     L.call('se_spec_loss', L.ptr(A), L.ptr(B_), L.ptr(sums), _l(A.numel() // 4), L.stream())
     return sums
