@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
 // the MFMA A-fragment layout (lane = row, 8 consecutive k), applies the prologue and the bf16 split ONCE and keeps the
 // fragments in 16 * NPL VGPRs; only the 64 x 64 weight blocks stream through LDS (next block prefetched in registers).
 template <int PRO, int NPL, bool PRE2, bool WPL = false, bool F16 = false>
-__global__ __launch_bounds__(256, PRE2 ? 1 : K64_OCC) void gemm_k64_panel_kernel(GemmArgs g) {   // (the PRE2 forms hold 32 more registers: they spill under the bound)
+__global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k64_panel_kernel(GemmArgs g) {   // (the PRE2 and three-plane forms hold more registers: they spill under the bound)
   constexpr int SB = 72, PB = 64 * SB;         // 64 + 8 bf16 per W row: 144-B stride, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
   __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 36];
