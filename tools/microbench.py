@@ -208,9 +208,9 @@ def dw_bench(argv):
     for axis in ('time', 'freq'):
         geom = A.seq_geometry(B, T, Fq, axis)
         st = torch.zeros(1, 128, 2, device='cuda', dtype=torch.float64)
-        z = torch.randn(B * T * Fq, 256, device='cuda')
+        gate = torch.randn(B * T * Fq, 128, device='cuda')
         for name, fn in (('fwd+stats', lambda: O.dwconv31(x, w, b, geom, stats=st)), ('dgrad', lambda: O.dwconv31(dy, w, None, geom, flip=True)),
-                         ('dgrad+glu', lambda: O.dwconv31_glu_bwd(dy, w, x, z[:, :128].contiguous(), geom)),
+                         ('dgrad+glu', lambda: O.dwconv31_glu_bwd(dy, w, x, gate, geom)),
                          ('wgrad', lambda: O.dwconv31_wgrad(x, dy, torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda'), geom))):
             for _ in range(2): fn()
             torch.cuda.synchronize(); t0 = time.time()
