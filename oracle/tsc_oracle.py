@@ -80,7 +80,7 @@ def add_noise(audio, noisy, noise_schedule, t, noise):
     return noisy_audio, combine_noise
 
 
-def train_loss(sd, clean, noisy, noise_schedule, t, noise, comp='pow'):
+def train_loss(sd, clean, noisy, noise_schedule, t, noise, comp='pow', train=True):
     """the loss of one train_tsc_diffusion iteration (core/function.py:472-505) as a differentiable function of the state dict `sd`
     (train mode: BatchNorm batch statistics; dropout 0 like the goldens): normalize_batch, add_noise, two compressed STFTs, the
     hybrid generator, iSTFT, mean |predicted - combine_noise|"""
@@ -89,6 +89,6 @@ def train_loss(sd, clean, noisy, noise_schedule, t, noise, comp='pow'):
     noisy_audio, combine_noise = add_noise(clean, noisy, noise_schedule, t, noise)
     orig = SO.compressed_stft(noisy, comp=comp)
     nz = SO.compressed_stft(noisy_audio, comp=comp)
-    er, ei = forward(sd, nz, orig, t, train=True)
+    er, ei = forward(sd, nz, orig, t, train=train)      # train=False: validate_tsc_diffusion (eval mode: running statistics)
     pred = SO.uncompressed_istft(torch.complex(er, ei).squeeze(1).permute(0, 2, 1), comp=comp)
     return torch.mean(torch.abs(pred - combine_noise))

@@ -13,4 +13,4 @@ from .criterion import build_criterion  # noqa: F401
 from .frontend import disassemble_spectrogram, power_compress, power_uncompress  # noqa: F401
 from .diffuse import DiffuSE, inference_schedule  # noqa: F401
 from .diffuse import predict as predict_diffuse  # noqa: F401
-from .tsc_diffusion import TSCNetDiffusion, predict_tsc, tsc_diffusion_step, add_noise  # noqa: F401
+from .tsc_diffusion import TSCNetDiffusion, predict_tsc, tsc_diffusion_step, tsc_diffusion_validation_loss, add_noise  # noqa: F401

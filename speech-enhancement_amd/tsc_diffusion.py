@@ -292,6 +292,22 @@ def tsc_diffusion_step(model, optimizer, clean, noisy, noise_schedule, n_fft=400
 
 
 @torch.no_grad()
+def tsc_diffusion_validation_loss(model, clean, noisy, noise_schedule, n_fft=400, hop=100, comp_type='pow', t=None, noise=None):
+    """One iteration of validate_tsc_diffusion (core/function.py:566-597): the same pipeline as the training step in eval mode
+    (BatchNorm running statistics, no dropout), no backward.  Returns the loss (0-d tensor)."""
+    if model.training:
+        raise L.SeHipError('tsc_diffusion_validation_loss: call model.eval() first (the reference validates in eval mode)')
+    c = O.clip_scale(noisy.contiguous())
+    clean, noisy = clean * c[:, None], noisy * c[:, None]
+    noisy_audio, combine_noise, t = add_noise(clean, noisy, noise_schedule, t, noise)
+    orig_pl, _ = FE.stft_planes(noisy.contiguous(), n_fft, hop, comp_type, padded=False)
+    nz_pl, _ = FE.stft_planes(noisy_audio.contiguous(), n_fft, hop, comp_type, padded=False)
+    est = model.forward_planes(nz_pl, orig_pl, t)
+    predicted = FE.istft_planes(est, n_fft, hop, comp_type)
+    return LS.l1_time_loss(predicted, combine_noise.contiguous()).detach()
+
+
+@torch.no_grad()
 def predict_tsc(model, args, config, noisy_signal, alpha, beta, alpha_cum, sigmas, T, c1, c2, c3, delta, delta_bar,
                 device=torch.device('cuda'), noises=None):
     """inference_diffuse.py:231-269: the supportive reverse process in the compressed-STFT domain -- every step re-analyses the
