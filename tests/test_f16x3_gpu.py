@@ -192,3 +192,32 @@ def test_input_gradient_gemm_with_layernorm_backward(env):
     (F.layer_norm(x64, (64,), g64, b64, 1e-5) @ W.double().T).backward(dy.double())
     assert relerr(dX, x64.grad + dR.double()) < 5e-6 and relerr(dg, g64.grad) < 1e-5 and relerr(db, b64.grad) < 1e-5
     assert abs(float(am) - float(dX.abs().max())) <= 1e-6 * float(am)
+
+
+def test_output_maximum_of_the_vector_epilogue(env):
+    """se_gemm_desc.y_amax: the scalar a GEMM raises to max |Y| (operand scale of the scaled split-fp16 attention: max |qkv| from the
+    row panel, max |dO| from the generic row GEMM with the dropout prologue), ragged last tile, a running maximum on entry"""
+    GM, L, LY, O, WeightPlan = env
+    M = 128 * 6 + 51
+    x = rnd(M, 64, seed=1) * 1.5 + 0.2
+    st = O.row_stats(x, M)
+    g, b = rnd(64, seed=2) * 0.2 + 1.0, rnd(64, seed=3) * 0.1
+    Wq, Wo = rnd(192, 64, seed=4, scale=0.3), rnd(64, 64, seed=5, scale=0.3)
+    plan = WeightPlan(torch.device('cuda'))
+    pq, po = plan.linear('q', Wq, planes='f16'), plan.linear_T('o', Wo, planes='f16')
+    plan.run()
+    am = torch.zeros(1, device='cuda')
+    q = torch.empty(M, 192, device='cuda')
+    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, y_amax=am, **LY._lin3(pq, a_sexp=GM.LN_SEXP)), x, pq, q, rowstats=st, ps=g, pb=b)
+    assert float(am) == float(q.abs().max())
+    dy = _amax(rnd(M, 64, seed=6, scale=2e-4))
+    am2 = torch.full((1,), 1e-9, device='cuda')             # a smaller running maximum on entry is raised
+    do = torch.empty(M, 64, device='cuda')
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP, pro_seed=3, drop_p=0.2, y_amax=am2, **LY._lin3(po, a_amax=dy._se_amax)),
+                dy, po, do)
+    assert float(am2) == float(do.abs().max())
+    am3 = torch.full((1,), 1e9, device='cuda')              # a larger one is kept
+    GM.gemm_tap(GM.linear_desc(M, 64, 64, y_amax=am3, **LY._lin3(po, a_amax=dy._se_amax)), dy, po, do)
+    assert float(am3) == 1e9
+    with pytest.raises(L.SeHipError):                       # the GLU / shuffle epilogues do not track it
+        GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, epilogue=L.EPI_GLU, y_amax=am), x, rnd(256, 64, seed=7), torch.empty(M, 128, device='cuda'))
