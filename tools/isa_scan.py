@@ -1,0 +1,27 @@
+"""Static scan of the compiled kernels for the three things that cost this project the most without showing in the source:
+scratch use, occupancy 1, and global / buffer loads issued right behind a full `s_waitcnt vmcnt(0)` (serialised loads: usually a
+spilled address or an exec-masked region per load).  usage: python tools/isa_scan.py   (compiles every csrc/*.hip with -save-temps)"""
+import glob, os, re, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CS = os.path.join(ROOT, 'speech-enhancement_amd', 'csrc')
+tmp = tempfile.mkdtemp()
+rows = []
+for src in sorted(glob.glob(CS + '/*.hip')):
+    base = os.path.basename(src)[:-4]
+    fl = [] if base == 'se_dwconv' else ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+    subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-munsafe-fp-atomics', '-fPIC', '-std=c++17', '-Wno-unused-result'] + fl +
+                   ['-c', src, '-o', os.path.join(tmp, base + '.o'), '-save-temps=obj'], cwd=tmp, stderr=subprocess.DEVNULL)
+    txt = open(os.path.join(tmp, base + '-hip-amdgcn-amd-amdhsa-gfx950.s')).read()
+    parts = re.split(r'\n(_Z[\w]+):\s+; @', txt)
+    for i in range(1, len(parts), 2):
+        name, body = parts[i], parts[i + 1]
+        meta = body[:body.find('; Occupancy') + 40]
+        g = lambda k: int((re.findall(k + r': (\d+)', meta) or ['0'])[0])
+        code = [l.strip() for l in body.split('s_endpgm')[0].split('\n') if l.strip() and not l.strip().startswith(';')]
+        ser = sum(1 for j, l in enumerate(code) if (l.startswith('global_load') or l.startswith('buffer_load')) and
+                  any(p.startswith('s_waitcnt vmcnt(0)') for p in code[max(0, j - 4):j]))
+        if g('ScratchSize') or g('Occupancy') <= 1 or ser >= 4:
+            rows.append((base, name, g('TotalNumVgprs'), g('ScratchSize'), g('Occupancy'), ser))
+names = subprocess.run(['c++filt'], input='\n'.join(r[1] for r in rows), capture_output=True, text=True).stdout.strip().split('\n')
+for r, d in zip(rows, names):
+    print(f'{r[0]:10s} {d[:84]:84s} vgpr {r[2]:3d} scratch {r[3]:4d} occ {r[4]} loads-behind-vmcnt0 {r[5]}')
