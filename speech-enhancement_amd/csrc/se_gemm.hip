@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
   for (int mt = 0; mt < MT; ++mt) {
     if (mt) __syncthreads();                   // the statistics epilogue folds the waves through `red`: one row block at a time
     if (m0 + mt * 128 >= Mb) break;            // (block-uniform) the second row block of the last tile may be empty
-    if (vec_ep) gemm_epilogue_vec(g, acc[mt][0], acc[mt][1], m0 + mt * 128, by, b, cs, 36, thr, inv_keep, red, bias_s);
+    if (vec_ep) gemm_epilogue_vec<false, false>(g, acc[mt][0], acc[mt][1], m0 + mt * 128, by, b, cs, 36, thr, inv_keep, red, bias_s);
     else gemm_epilogue(g, acc[mt][0], acc[mt][1], m0 + mt * 128, by, b, red, thr, inv_keep);
   }
 }
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
     }
-    if (vec_ep) gemm_epilogue_vec<PRE2>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, red, bias_s, pre);
+    if (vec_ep) gemm_epilogue_vec<PRE2, false>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, red, bias_s, pre);      // (residuals come in `pre`)
     else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, 0, cs, 36);
     __syncthreads();
   }

@@ -131,7 +131,7 @@ static __device__ __forceinline__ void load_pro_vec(const float* ps, const float
 // is transposed through a wave-private LDS patch so that every lane then owns 4 consecutive output columns: the
 // AUX / R reads and the Y writes are 16-byte accesses (8 lanes = one 128-B row segment) and there are 4 of them per
 // lane and tile instead of 16 four-byte ones.  cs: the wave's [32][cs_ld] patch (reuses the A staging tile).
-template <bool HASPRE = false>
+template <bool HASPRE = false, bool HOISTR = true>      // HOISTR: request an in-place residual for all row groups up front (16 VGPRs)
 static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
                                                          int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
                                                          float inv_keep, float* red, const float* bias_s,
@@ -158,6 +158,27 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
     float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f), qsum = ssum;
     if (n < d.N) {                                   // N % 4 == 0 (host-checked)
       const float4 bias4 = *reinterpret_cast<const float4*>(bias_s + nt * 32 + cq * 4);   // staged before the K loop
+      // the accumulate operand of the four row groups is requested up front (four named registers quads, not an array: an array
+      // indexed under these conditions goes to scratch): loaded where it is used, every `load -> s_waitcnt vmcnt(0) -> store`
+      // exposed one full memory latency per group -- the store of group i may alias the load of group i + 1
+      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+      if (ep & SE_EPI_ACCUM) {
+        const unsigned rb = (unsigned)(wave * 32 + rr), co = (unsigned)n;
+        if (m0 + (int)rb < Mb) a0 = *reinterpret_cast<const float4*>(Yb + (rb * (unsigned)d.ldc + co));
+        if (m0 + (int)rb + 8 < Mb) a1 = *reinterpret_cast<const float4*>(Yb + ((rb + 8) * (unsigned)d.ldc + co));
+        if (m0 + (int)rb + 16 < Mb) a2 = *reinterpret_cast<const float4*>(Yb + ((rb + 16) * (unsigned)d.ldc + co));
+        if (m0 + (int)rb + 24 < Mb) a3 = *reinterpret_cast<const float4*>(Yb + ((rb + 24) * (unsigned)d.ldc + co));
+      }
+      // ... and likewise the residual when it was not fetched before the K loop
+      float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+      const bool res_here = HOISTR && !HASPRE && (ep & SE_EPI_RESID) != 0;
+      if (res_here) {
+        const unsigned rb = (unsigned)(wave * 32 + rr), co = (unsigned)n;
+        if (m0 + (int)rb < Mb) r0 = *reinterpret_cast<const float4*>(Rb + (rb * (unsigned)d.ldr + co));
+        if (m0 + (int)rb + 8 < Mb) r1 = *reinterpret_cast<const float4*>(Rb + ((rb + 8) * (unsigned)d.ldr + co));
+        if (m0 + (int)rb + 16 < Mb) r2 = *reinterpret_cast<const float4*>(Rb + ((rb + 16) * (unsigned)d.ldr + co));
+        if (m0 + (int)rb + 24 < Mb) r3 = *reinterpret_cast<const float4*>(Rb + ((rb + 24) * (unsigned)d.ldr + co));
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + rr + 8 * i;
@@ -178,11 +199,12 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
           v.x *= swish_gradf_(z.x); v.y *= swish_gradf_(z.y); v.z *= swish_gradf_(z.z); v.w *= swish_gradf_(z.w);
         }
         if (ep & SE_EPI_RESID) {
-          float4 rv = HASPRE ? pre[nt * 4 + i] : *reinterpret_cast<const float4*>(Rb + ((unsigned)row * (unsigned)d.ldr + (unsigned)n));
+          float4 rv = HASPRE ? pre[nt * 4 + i] : (HOISTR ? (i == 0 ? r0 : (i == 1 ? r1 : (i == 2 ? r2 : r3)))
+                                                         : *reinterpret_cast<const float4*>(Rb + ((unsigned)row * (unsigned)d.ldr + (unsigned)n)));
           v.x = rv.x + d.alpha * v.x; v.y = rv.y + d.alpha * v.y; v.z = rv.z + d.alpha * v.z; v.w = rv.w + d.alpha * v.w;
         }
         float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
-        if (ep & SE_EPI_ACCUM) { float4 o = *yp; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (ep & SE_EPI_ACCUM) { const float4 o = i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *yp = v;
         if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (rowstats) kept[nt][i] = v;
