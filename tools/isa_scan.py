@@ -20,8 +20,11 @@ for src in sorted(glob.glob(CS + '/*.hip')):
         code = [l.strip() for l in body.split('s_endpgm')[0].split('\n') if l.strip() and not l.strip().startswith(';')]
         ser = sum(1 for j, l in enumerate(code) if (l.startswith('global_load') or l.startswith('buffer_load')) and
                   any(p.startswith('s_waitcnt vmcnt(0)') for p in code[max(0, j - 4):j]))
-        if g('ScratchSize') or g('Occupancy') <= 1 or ser >= 4:
-            rows.append((base, name, g('TotalNumVgprs'), g('ScratchSize'), g('Occupancy'), ser))
+        # loads whose result is waited for at once (a full vmcnt(0) within two instructions): exposed latency unless other waves cover it
+        imm = sum(1 for j, l in enumerate(code) if (l.startswith('global_load') or l.startswith('buffer_load')) and
+                  any(p.startswith('s_waitcnt vmcnt(0)') for p in code[j + 1:j + 3]))
+        if g('ScratchSize') or g('Occupancy') <= 1 or ser >= 4 or (imm >= 4 and '--imm' in sys.argv):
+            rows.append((base, name, g('TotalNumVgprs'), g('ScratchSize'), g('Occupancy'), ser, imm))
 names = subprocess.run(['c++filt'], input='\n'.join(r[1] for r in rows), capture_output=True, text=True).stdout.strip().split('\n')
 for r, d in zip(rows, names):
-    print(f'{r[0]:10s} {d[:84]:84s} vgpr {r[2]:3d} scratch {r[3]:4d} occ {r[4]} loads-behind-vmcnt0 {r[5]}')
+    print(f'{r[0]:10s} {d[:84]:84s} vgpr {r[2]:3d} scratch {r[3]:4d} occ {r[4]} loads-behind-vmcnt0 {r[5]} waited-at-once {r[6]}')
