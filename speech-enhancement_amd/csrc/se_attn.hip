@@ -1073,6 +1073,8 @@ static __device__ __host__ __forceinline__ void group_split(int nkt, int w, int&
   kt0 = w * b + (w < r ? w : r);
 }
 
+// key tiles of the register window a grouped wave with cnt tiles runs (the body is instantiated for KT and KT - 1 exactly)
+static __device__ __host__ __forceinline__ int group_window(int KT, int cnt) { return (cnt == KT || cnt == KT - 1) ? cnt : KT; }
 template <int KT, bool F16 = false>
 struct Lds3 {
   static constexpr int NU = KT + 1;
@@ -1101,7 +1103,14 @@ struct QSide { float4 q4, do4; float qcf[4], docf[4], lse[4], dl[4]; };
 // |dS| <= P scale (|dP| + |D|) <= 32 scale max|dO| max|V| (both are 16-term dot products against V and O, |O| <= max |V|); every
 // accumulator is brought back by ONE power of two where it is stored.  dQ collects K^T dS^T (2^(sq + sds)) and E^T W^T
 // (2^(se + sds)) in two accumulators.
-template <int KT, int NK, bool EXACT, bool GROUP, bool F16 = false>
+// RING (grouped fp16 form, nkt <= 21): the dE tiles of the four waves of a workgroup are summed in LDS before they leave the CU.
+// Wave w flushes offset tile D at query tile D + kt0_w + cnt_w (strictly increasing in w), so the contributions to one tile arrive
+// in wave order, 5 - 6 query tiles apart, always behind the per-query-tile barrier of the dQ reduction: the first contributor
+// STORES its tile into a 16-slot ring (slot = D mod 16: at most 16 tiles are open at any time), the next ones add to it, the last
+// adds and writes the finished tile to the (sequence, head) item's table [2 nkt][256] -- 41 tile writes per item instead of 108,
+// and the reduction kernel reads as much less.  The tiles still in the register windows after the last query tile go out in four
+// rounds (wave 0 .. 3) with a barrier in between.  dQ's LDS exchange drops to one parity (+ one barrier) to make room for the ring.
+template <int KT, int NK, bool EXACT, bool GROUP, bool F16 = false, bool RING = false>
 static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, unsigned char* smem3, const int wave, const int lane,
                                                       const long item, const int kt0, const int nk_w) {
   using L3 = Lds3<KT, F16>;
@@ -1112,7 +1121,8 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
   unsigned char* Kimg = wl;
   unsigned char* Dimg = wl + L3::KIMG;
   float* strip = reinterpret_cast<float*>(wl + L3::KIMG + L3::DIMG);
-  float* dqs = reinterpret_cast<float*>(smem3 + (size_t)4 * L3::WAVE);      // GROUP: [2 parities][4 waves][256]
+  float* dqs = reinterpret_cast<float*>(smem3 + (size_t)4 * L3::WAVE);      // GROUP: [2 parities (RING: 1)][4 waves][256]
+  float* ring = dqs + 4 * 256;                                              // RING: [16 slots][256]
   const int head = (int)(item & 3), seq = (int)(item >> 2);
   const long base = seq_base(a.g, seq);
   const int ps = (int)a.g.pos_stride;
@@ -1123,7 +1133,18 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
   float* dqb = a.dQKV + base * 192 + head * 16;
   const float l2e = 1.4426950408889634f;
   const long witem = GROUP ? item * 4 + wave : item;
-  float* dEs = a.dEs + witem * (long)(nqt + KT) * 256;
+  float* dEs = RING ? a.dEs + item * (long)(2 * nkt) * 256 : a.dEs + witem * (long)(nqt + KT) * 256;
+  // RING: the offset tiles wave w flushes are [-(kt0_w + cnt_w), nqt - kt0_w - 1]
+  int rlo[4] = {0, 0, 0, 0}, rhi[4] = {0, 0, 0, 0};
+  if (RING) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {      // (a wave whose tile count is neither KT nor KT - 1 runs the KT-wide window: group_window)
+      int k0, cn;
+      group_split(nkt, w, k0, cn);
+      rlo[w] = -(k0 + group_window(KT, cn));
+      rhi[w] = nqt - k0 - 1;
+    }
+  }
   const int trrow = c >> 2, trcol = c & 3;                      // transposed-read address roles of this lane
   const unsigned char* Esb = reinterpret_cast<const unsigned char*>(a.Es);      // planes (long)R * 32 bytes apart
   const unsigned char* Etb = reinterpret_cast<const unsigned char*>(a.Ets);     // planes (long)ET * 32 bytes apart
@@ -1172,7 +1193,20 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
   // v[r] = dE[delta = 16 Dtile + c][d = 4g + r]; tiles no (query, key) pair can reach are neither stored nor reduced
   auto flush = [&](const f32x4& v, int Dtile) {
     if (Dtile < -nkt || Dtile > nkt || (a.dbg & 1)) return;
-    *reinterpret_cast<float4*>(dEs + (Dtile + kt0 + KT) * 256 + c * 16 + 4 * g) = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
+    float4 val = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
+    if (RING) {
+      int first = 3, last = 0;                                    // (wave-uniform; this wave is one of the contributors)
+#pragma unroll
+      for (int w = 3; w >= 0; --w) if (Dtile >= rlo[w] && Dtile <= rhi[w]) first = w;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) if (Dtile >= rlo[w] && Dtile <= rhi[w]) last = w;
+      float4* rs = reinterpret_cast<float4*>(ring + ((Dtile + 64) & 15) * 256 + c * 16 + 4 * g);
+      if (wave != first) { const float4 o = *rs; val.x += o.x; val.y += o.y; val.z += o.z; val.w += o.w; }
+      if (wave == last) *reinterpret_cast<float4*>(dEs + (Dtile + nkt) * 256 + c * 16 + 4 * g) = val;
+      else *rs = val;
+      return;
+    }
+    *reinterpret_cast<float4*>(dEs + (Dtile + kt0 + KT) * 256 + c * 16 + 4 * g) = val;
   };
   auto load_qside = [&](int qt, QSide& o) {
     const int q0 = qt * 16;
@@ -1331,7 +1365,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
       for (int r = 0; r < 4; ++r) dq[r] = fmaf(dq[r], cq1, dq2[r] * cq2);
     }
     if (GROUP) {
-      float* slot = dqs + ((qt & 1) * 4) * 256;
+      float* slot = dqs + (RING ? 0 : (qt & 1) * 4) * 256;
       *reinterpret_cast<float4*>(slot + wave * 256 + c * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
       __syncthreads();
       if (wave == (qt & 3) && q0 + c < n) {
@@ -1343,6 +1377,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
         *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = t0;
         if (F16) omax = fmaxf(fmaxf(omax, fmaxf(fabsf(t0.x), fabsf(t0.y))), fmaxf(fabsf(t0.z), fabsf(t0.w)));
       }
+      if (RING) __syncthreads();            // one parity: the slots are rewritten in the next query tile
     } else if (q0 + c < n) {
       *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = make_float4(dq[0], dq[1], dq[2], dq[3]);
       if (F16) omax = fmaxf(fmaxf(omax, fmaxf(fabsf(dq[0]), fabsf(dq[1]))), fmaxf(fabsf(dq[2]), fabsf(dq[3])));
@@ -1354,8 +1389,19 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
     de[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   // after the last rotation slot u holds tile nqt - kt0 - u
+  if (RING) {                                // the remaining window tiles leave in wave order (contribution order), a barrier apart
 #pragma unroll
-  for (int u = 1; u < NU; ++u) flush(de[u], nqt - kt0 - u);
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int u = 1; u < NU; ++u) flush(de[u], nqt - kt0 - u);
+      }
+      __syncthreads();
+    }
+  } else {
+#pragma unroll
+    for (int u = 1; u < NU; ++u) flush(de[u], nqt - kt0 - u);
+  }
   // ---- dK, dV of the wave's keys: C layout [d = 4g + r][key = c] ----
 #pragma unroll
   for (int s = 0; s < NK; ++s) {
@@ -1376,7 +1422,7 @@ static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, uns
   }
 }
 
-template <int KT, bool GROUP, bool F16 = false>
+template <int KT, bool GROUP, bool F16 = false, bool RING = false>
 __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1386,9 +1432,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
     group_split(nkt, wave, kt0, cnt);
     // every wave runs nqt barriers whichever branch it takes (s_barrier counts arrivals, not program counters)
     const long gitem = xcd_item((int)blockIdx.x, (int)gridDim.x);
-    if (cnt == KT) attn_bwd3_body<KT, KT, true, true, F16>(a, smem3, wave, lane, gitem, kt0, cnt);
-    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true, F16>(a, smem3, wave, lane, gitem, kt0, cnt);
-    else attn_bwd3_body<KT, KT, false, true, F16>(a, smem3, wave, lane, gitem, kt0, cnt);
+    if (cnt == KT) attn_bwd3_body<KT, KT, true, true, F16, RING>(a, smem3, wave, lane, gitem, kt0, cnt);
+    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true, F16, RING>(a, smem3, wave, lane, gitem, kt0, cnt);
+    else attn_bwd3_body<KT, KT, false, true, F16, RING>(a, smem3, wave, lane, gitem, kt0, cnt);
   } else {
     const long item = (long)blockIdx.x * 4 + wave;
     if (item >= (long)a.g.nseq * 4) return;                     // whole wave leaves: EXEC stays full for the others
@@ -1425,6 +1471,34 @@ __global__ __launch_bounds__(256) void attn_de_reduce3_kernel(const float* __res
     const float4 b = part[1][t], c4 = part[2][t], d = part[3][t];
     s.x += b.x + (c4.x + d.x); s.y += b.y + (c4.y + d.y); s.z += b.z + (c4.z + d.z); s.w += b.w + (c4.w + d.w);
     const int row = 16 * Dtile + (t >> 2) + maxpos;              // element index in the tile = 4 t .. 4 t + 3 = [delta_l][d]
+    if (row >= 0 && row < R) {
+      float* p = &dE[(long)row * 16 + (t & 3) * 4];
+      atomicAdd(p, s.x); atomicAdd(p + 1, s.y); atomicAdd(p + 2, s.z); atomicAdd(p + 3, s.w);
+    }
+  }
+}
+
+// the same reduction over the per-ITEM tables of the ring form: dEs [items][2 nkt][256], tile slot = D + nkt, D = -nkt .. nkt - 1
+__global__ __launch_bounds__(256) void attn_de_reduce_items_kernel(const float* __restrict__ dEs, float* __restrict__ dE, long nitems,
+                                                                   int nkt, int maxpos, int R) {
+  __shared__ float4 part[4][64];
+  const int Dtile = (int)blockIdx.x - nkt;                       // -nkt .. nkt - 1
+  const long w0 = (long)blockIdx.y * 256;
+  const int nslot = 2 * nkt, t = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);                    // (the table is shared by the heads: every item adds to it)
+#pragma unroll 8
+  for (int i = sub; i < 256; i += 4) {
+    const long it = w0 + i;
+    const long itc = it < nitems ? it : nitems - 1;              // (unconditional load, zeroed by the select)
+    const float4 v = *reinterpret_cast<const float4*>(dEs + (itc * nslot + blockIdx.x) * 256 + t * 4);
+    if (it < nitems) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  }
+  part[sub][t] = s;
+  __syncthreads();
+  if (sub == 0) {
+    const float4 b = part[1][t], c4 = part[2][t], d = part[3][t];
+    s.x += b.x + (c4.x + d.x); s.y += b.y + (c4.y + d.y); s.z += b.z + (c4.z + d.z); s.w += b.w + (c4.w + d.w);
+    const int row = 16 * Dtile + (t >> 2) + maxpos;
     if (row >= 0 && row < R) {
       float* p = &dE[(long)row * 16 + (t & 3) * 4];
       atomicAdd(p, s.x); atomicAdd(p + 1, s.y); atomicAdd(p + 2, s.z); atomicAdd(p + 3, s.w);
@@ -1746,11 +1820,34 @@ extern "C" size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, i
 template <int KT, bool GROUP, bool F16 = false>
 static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float* dE, int phase) {
   using L3 = Lds3<KT, F16>;
+  const long items = (long)b.g.nseq * 4;
+  const int nkt = (b.g.n + 15) / 16;
+  if constexpr (GROUP && F16) {
+    // ring form: the four waves' dE tiles are summed in LDS (16 open tiles at most: nkt - cnt_0 + 1 <= 16)
+    int span_lo = 1 << 30, span_hi = 0;
+    bool ordered = true;
+    for (int w = 0, prev = -1; w < 4; ++w) {
+      int k0, cn;
+      group_split(nkt, w, k0, cn);
+      const int tq = k0 + group_window(KT, cn);          // wave w flushes tile D at query tile D + tq
+      span_lo = tq < span_lo ? tq : span_lo;
+      span_hi = tq > span_hi ? tq : span_hi;
+      ordered = ordered && tq > prev;
+      prev = tq;
+    }
+    if (ordered && span_hi - span_lo + 1 <= 16 && getenv("SE_ATTN_NO_RING") == nullptr) {
+      const size_t shr = (size_t)4 * L3::WAVE + (size_t)(4 * 256 + 16 * 256) * sizeof(float);
+      static unsigned raised_r = 0;
+      SE_REQUIRE(se_raise_lds((const void*)attn_bwd3_kernel<KT, true, true, true>, shr, &raised_r), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+      if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, true, true, true>), dim3(items), dim3(256), shr, s, b);
+      if (phase & 2) hipLaunchKernelGGL(attn_de_reduce_items_kernel, dim3(2 * nkt, cdiv(items, 256)), dim3(256), 0, s, b.dEs, dE, items, nkt,
+                                        b.maxpos, b.R);
+      return 0;
+    }
+  }
   const size_t sh = (size_t)4 * L3::WAVE + (GROUP ? 2 * 4 * 256 * sizeof(float) : 0);
   static unsigned raised = 0;
   SE_REQUIRE(se_raise_lds((const void*)attn_bwd3_kernel<KT, GROUP, F16>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit to %zu", sh);
-  const long items = (long)b.g.nseq * 4;
-  const int nkt = (b.g.n + 15) / 16;
   if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP, F16>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
   if (phase & 2) hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 256)), dim3(256), 0, s, b.dEs,
                                     dE, nwitems, nkt, b.maxpos, b.R);
