@@ -870,10 +870,12 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     }
   }
   if (d->precision == 3) {        // scaled split-fp16, generic tap kernel: prologue-free shapes with pre-split planes
-    SE_REQUIRE((d->prologue == SE_PRO_NONE || (d->prologue == SE_PRO_DROP && lin)) && d->w_planes,
+    SE_REQUIRE((d->prologue == SE_PRO_NONE || ((d->prologue == SE_PRO_DROP || d->prologue == SE_PRO_AFFINE_SWISH) && lin)) && d->w_planes,
                "gemm: precision 3 outside the triple-tap / K = 64 row-panel kernels needs pre-split fp16 planes and no prologue "
-               "(row GEMMs: or the dropout prologue)");
+               "(row GEMMs: or the dropout / BatchNorm-Swish prologue)");
     if (d->prologue == SE_PRO_DROP) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_DROP, 2, true, true, false, true>), grid, block, 0, s, g);
+    else if (d->prologue == SE_PRO_AFFINE_SWISH)
+      hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_AFFINE_SWISH, 2, true, true, false, true>), grid, block, 0, s, g);
     else if (lin) hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 2, true, true, false, true>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_tap_bf16x3_kernel<SE_PRO_NONE, 2, false, true, false, true>), grid, block, 0, s, g);
     return se_check_launch("se_gemm_tap(f16x3)");

@@ -84,7 +84,7 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
                  (f'gemm_k64_panel_f16x3<{d.prologue}>' if d.precision == 3 else f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>')
                  if d.precision in (1, 2, 3) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1
                  and not d.epilogue & (L.EPI_ACCUM | L.EPI_STATS | L.EPI_SHUFFLE2) else
-                 'gemm_tap_f16x3_kernel<0>' if d.precision == 3 else
+                 f'gemm_tap_f16x3_kernel<{d.prologue}>' if d.precision == 3 else
                  f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
                  f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>'), _flops=2.0 * M * d.N * d.ntap * d.C,
            _bytes=4.0 * M * (d.C + d.N))

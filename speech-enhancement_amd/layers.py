@@ -38,6 +38,7 @@ CONV_PRECISION = _PREC[_os.environ.get('SE_CONV_PRECISION', 'f16x3')]
 # |beta| = 254 |gamma| + |beta|; out-of-range values would be clamped (FP16_OVFL), not turned into inf.  Gradients and weights
 # are scaled by their MEASURED maxima instead (amax scalars).
 ACT_SEXP = 4
+PW2_F16 = _os.environ.get('SE_PW2_F32') is None      # pointwise conv 128 -> 64 behind BatchNorm + Swish on the scaled-fp16 kernel
 ATTN_O_SEXP = 4    # attention outputs (convex combinations of the value rows): |o| < 4094
 # attention products: 'f16x3' = the scaled split-fp16 kernels (se_attn_fwd_f16 / se_attn_bwd_f16_phase; operand scales from the
 # maxima the qkv / to_out input-gradient GEMMs raise: se_gemm_desc.y_amax) wherever the sequence fits them, 'bf16x6' = the exact
@@ -275,6 +276,8 @@ def build_generator_plan(P, device):
             plan.linear_T((n, 'T'), P[n], planes=l3)
             n = f'{p}.conv.net.7.weight'
             plan.linear_T((n, 'T'), P[n], planes=l3)
+            if l3 == 'f16' and PW2_F16:
+                plan.linear((n, 'lin'), P[n], planes='f16')
     return plan
 
 
@@ -549,10 +552,12 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     sc = ss[0, :, 0].contiguous()
     sh = ss[0, :, 1].contiguous()
     y3 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
-    Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
+    # Swish(BatchNorm(h)) is bounded like the FF hidden activations (the weight gradient of this layer uses the same exponent)
+    Wpw2 = _w(P, (f'{p}.conv.net.7.weight', 'lin'), lambda: P[f'{p}.conv.net.7.weight'].view(64, 128))
     st4 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None
     GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID |
-                               (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64), h, Wpw2, y3,
+                               (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64,
+                               **_lin3(Wpw2, a_sexp=GM.HID_SEXP)), h, Wpw2, y3,
                 bias=P[f'{p}.conv.net.7.bias'], R=y2, ps=sc, pb=sh, AUX=st4)
     ctx['conv'] = (y2, st3, zc, u, h, mr, sc, sh, count)
     y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M, pf, site_seed(seed, 3), site_seed(seed, 4), st=st4)

@@ -114,6 +114,33 @@ def test_row_panels_and_glu_gate(env):
     assert relerr(gate, z[:, 128:]) < 3e-6 and relerr(u, z[:, :128] * torch.sigmoid(z[:, 128:])) < 3e-6
 
 
+def test_pointwise_conv_behind_batchnorm_swish(env):
+    """second pointwise conv of the Conformer conv module, 128 -> 64, with the BatchNorm-apply + Swish prologue, bias, residual and
+    the fused row statistics (conformer.py:167-170): scaled split-fp16 generic row GEMM under the static exponent of the hidden
+    activations; ragged last tile; an outlier of 60 standard deviations stays exact (|x| < 8191)"""
+    GM, L, LY, O, WeightPlan = env
+    M = 128 * 9 + 77
+    h = rnd(M, 128, seed=1) * 2.0 + 0.3
+    h[5, 17] = 130.0
+    sc, sh = rnd(128, seed=2) * 0.2 + 0.5, rnd(128, seed=3) * 0.2
+    W, b = rnd(64, 128, seed=4, scale=0.1), rnd(64, seed=5, scale=0.1)
+    R = rnd(M, 64, seed=6)
+    plan = WeightPlan(torch.device('cuda'))
+    pw = plan.linear('w', W, planes='f16')
+    plan.run()
+    y, st = torch.empty(M, 64, device='cuda'), torch.empty(M, 2, device='cuda')
+    GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID | L.EPI_ROWSTATS, alpha=1.0,
+                               ldr=64, **LY._lin3(pw, a_sexp=GM.HID_SEXP)), h, pw, y, bias=b, R=R, ps=sc, pb=sh, AUX=st)
+    z = h.double() * sc.double() + sh.double()
+    ref = (z * torch.sigmoid(z)) @ W.double().t() + b.double() + R.double()
+    assert relerr(y, ref) < 3e-6
+    assert relerr(st[:, 0], ref.mean(1)) < 1e-5 and relerr(st[:, 1], 1.0 / torch.sqrt(ref.var(1, unbiased=False) + 1e-5)) < 1e-5
+    y32 = torch.empty(M, 64, device='cuda')
+    GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID, alpha=1.0, ldr=64),
+                h, W, y32, bias=b, R=R, ps=sc, pb=sh)
+    assert relerr(y, ref) < 4 * relerr(y32, ref) + 1e-6          # at the level of the fp32-MFMA kernel it replaces
+
+
 def test_feed_forward_pair(env):
     """fused feed-forward forward / input-gradient chain (conformer.py:53-71,128-145) on fp16 planes vs fp64"""
     GM, L, LY, O, WeightPlan = env
