@@ -22,6 +22,14 @@ def f16_shape_ok(geom, maxpos=512):
     return maxpos % 16 == 0 and npad + 128 <= maxpos and n <= 384 and ps * 192 * npad < 2 ** 31 - 1
 
 
+def f16_fwd_shape_ok(geom, maxpos=512):
+    """se_attn_fwd_f16 alone (no backward: inference) takes longer sequences: the V image (two fp16 planes) and the offset strips of
+    8 waves within the 160 KB of LDS -- n <= 4079, e.g. the 1601 frames of a 10 s utterance; offsets beyond +-maxpos are clamped"""
+    nseq, n, inner, os_, is_, ps = geom
+    npad = (n + 15) // 16 * 16
+    return maxpos % 16 == 0 and 2 * npad * 32 + 512 * 2 * 8 * 4 <= 160 * 1024 and ps * 192 * npad < 2 ** 31 - 1
+
+
 def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None, qkv_amax=None):
     """Es: optional pre-split planes of E (weights.WeightPlan): [3, 2*maxpos+1, 16] bf16, or [2, 2*maxpos+1, 16] scaled fp16 with
     its maximum in Es._se_amax -- together with qkv_amax (device scalar >= max |qkv|, e.g. raised by the qkv GEMM's epilogue) that
@@ -32,7 +40,7 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None, qkv_a
     lse = torch.empty(ntok, 4, device=qkv.device, dtype=torch.float32) if need_lse else None
     nseq, n, inner, os_, is_, ps = geom
     if Es is not None and Es.dtype == torch.float16:
-        if qkv_amax is None or not f16_shape_ok(geom, maxpos):
+        if qkv_amax is None or not (f16_shape_ok(geom, maxpos) or (not need_lse and f16_fwd_shape_ok(geom, maxpos))):
             raise L.SeHipError('attn_fwd: fp16 planes of E need qkv_amax and a sequence the split-fp16 kernel takes')
         L.call('se_attn_fwd_f16', L.ptr(qkv), L.ptr(Es), C.c_long(Es.stride(0)), L.ptr(qkv_amax), L.ptr(Es._se_amax), L.ptr(O),
                L.ptr(lse), C.c_int(nseq), C.c_int(n), C.c_int(inner), C.c_long(os_), C.c_long(is_), C.c_long(ps), C.c_int(maxpos),

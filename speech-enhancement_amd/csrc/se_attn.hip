@@ -1522,7 +1522,7 @@ __global__ __launch_bounds__(256) void attn_de_reduce_items_kernel(const float* 
 // output by one multiply per element at the end.
 template <int V> struct IC_ { static constexpr int value = V; };
 template <int TQ, bool F16 = false>
-__global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
+__global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
   constexpr int NPLA = F16 ? 2 : 3;
   unsigned char* Vimg = smem_f3;                               // [NPLA planes][NP keys][16 d] 16-bit
@@ -1531,7 +1531,10 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
   const int NT = blockDim.x, NW = NT >> 6;
   const int c = lane & 15, g = lane >> 4;
   const int n = a.g.n;
-  const int item_ = xcd_item((int)blockIdx.x, (int)gridDim.x);
+  // qsplit > 1 (few long sequences: a 10 s utterance is 101 x 4 items of 1601 positions): the query blocks of an item are dealt to
+  // qsplit workgroups, each with its own V image
+  const int part = qsplit > 1 ? (int)blockIdx.x % qsplit : 0;
+  const int item_ = qsplit > 1 ? (int)blockIdx.x / qsplit : xcd_item((int)blockIdx.x, (int)gridDim.x);
   const int head = item_ & 3, seq = item_ >> 2;
   const long base = seq_base(a.g, seq);
   const int ps = (int)a.g.pos_stride;
@@ -1594,7 +1597,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP) {
     int kj = j0 + c; if (kj > n - 1) kj = n - 1;
     return *reinterpret_cast<const float4*>(qb + (unsigned)(kj * ps * 192 + 64 + 4 * g));
   };
-  for (int qbk = wave; qbk < qblocks; qbk += NW) {
+  for (int qbk = part * NW + wave; qbk < qblocks; qbk += NW * qsplit) {
     const int i0 = qbk * 16 * TQ;
     S3 qf[TQ];
 #pragma unroll
@@ -1752,6 +1755,13 @@ static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long 
     int nw3 = qb32 <= 4 ? 4 : 8, tq3 = qb32 <= 4 ? 1 : 2;
     if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v >= 1 && v <= 8) nw3 = v; }
     if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq3 = v; }
+    // fewer items than two rounds of workgroups (batch-1 inference): split the query blocks of an item over several workgroups
+    int qsplit = 1;
+    {
+      const long items = (long)nseq * 4, qblk = (n + 16 * tq3 - 1) / (16 * tq3);
+      while (items * qsplit < 1024 && (long)nw3 * qsplit * 2 <= qblk && qsplit < 8) ++qsplit;
+      if (const char* e = getenv("SE_ATTN_FWD_QSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) qsplit = v; }
+    }
     const size_t sh3 = (size_t)(f16 ? 2 : 3) * NP * 32 + (size_t)512 * tq3 * nw3 * sizeof(float);
     if (sh3 <= 160 * 1024) {
       static size_t raised3[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -1762,10 +1772,11 @@ static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long 
                    "attn_fwd: cannot raise the dynamic LDS limit to %zu", sh3);
         raised3[f16][tq3] = sh3;
       }
-      if (f16 && tq3 == 1) hipLaunchKernelGGL((attn_fwd3_kernel<1, true>), dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
-      else if (f16) hipLaunchKernelGGL((attn_fwd3_kernel<2, true>), dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
-      else if (tq3 == 1) hipLaunchKernelGGL(attn_fwd3_kernel<1>, dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
-      else hipLaunchKernelGGL(attn_fwd3_kernel<2>, dim3(nseq * 4), dim3(64 * nw3), sh3, as_stream(stream), a, NP);
+      const dim3 grid3((unsigned)(nseq * 4 * qsplit));
+      if (f16 && tq3 == 1) hipLaunchKernelGGL((attn_fwd3_kernel<1, true>), grid3, dim3(64 * nw3), sh3, as_stream(stream), a, NP, qsplit);
+      else if (f16) hipLaunchKernelGGL((attn_fwd3_kernel<2, true>), grid3, dim3(64 * nw3), sh3, as_stream(stream), a, NP, qsplit);
+      else if (tq3 == 1) hipLaunchKernelGGL(attn_fwd3_kernel<1>, grid3, dim3(64 * nw3), sh3, as_stream(stream), a, NP, qsplit);
+      else hipLaunchKernelGGL(attn_fwd3_kernel<2>, grid3, dim3(64 * nw3), sh3, as_stream(stream), a, NP, qsplit);
       return se_check_launch("se_attn_fwd");
     }
   }

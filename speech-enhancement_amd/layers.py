@@ -507,13 +507,15 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     Es = _w(P, (f'{p}.attn.fn.rel_pos_emb.weight', 'es'), lambda: None)
     # scaled split-fp16 attention: the qkv GEMM raises max |qkv| for it; sequences outside that kernel (10 s clips) take the
     # three-way bf16 split / streaming kernels with the table split on the fly
-    attn16 = Es is not None and Es.dtype == torch.float16 and A.f16_shape_ok(geom, maxpos)
+    # (eval mode has no backward: the forward kernel alone also takes the 1601 frames of a 10 s utterance)
+    attn16 = Es is not None and Es.dtype == torch.float16 and (A.f16_shape_ok(geom, maxpos) or
+                                                               (not train and A.f16_fwd_shape_ok(geom, maxpos)))
     qkv_amax = O.zeros(1, device=x.device) if attn16 else None
     GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, y_amax=qkv_amax, **_lin3(Wqkv, a_sexp=GM.LN_SEXP)), y1, Wqkv, qkv,
                 rowstats=st2, ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
     if Es is not None and Es.dtype == torch.float16 and not attn16:
         Es = None
-    o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25, Es=Es, qkv_amax=qkv_amax)
+    o, lse = A.attn_fwd(qkv, E, geom, maxpos=maxpos, scale=0.25, Es=Es, qkv_amax=qkv_amax, need_lse=train)
     y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     sa = site_seed(seed, 2)
     st3 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None

@@ -99,3 +99,32 @@ def test_attention_scaled_fp16(B, T, Fq, axis, mag):
         assert err < 2e-5, (name, err)
     err = float((dE.double() - E64.grad).abs().max() / torch.maximum(E64.grad.abs().max(), 0.1 * q64.grad.abs().max()))
     assert err < 2e-5, ('dE', err)
+
+
+@pytest.mark.parametrize('B,T,Fq,axis,qsplit', [(1, 1601, 2, 'time', None), (1, 600, 3, 'time', None), (1, 600, 3, 'time', '1'),
+                                                (1, 1203, 1, 'time', '5'), (2, 333, 2, 'time', '3')])
+def test_attention_scaled_fp16_forward_only_long_sequences(B, T, Fq, axis, qsplit, monkeypatch):
+    """inference (no backward, need_lse=False): se_attn_fwd_f16 beyond the training shapes -- the 1601 frames of a 10 s utterance
+    (BASELINE config 4), offsets clamped at +-512 (conformer.py:113-114), the query blocks of an item dealt to several workgroups
+    (chosen by the launcher for few long sequences; forced through SE_ATTN_FWD_QSPLIT) -- against the fp64 restatement"""
+    from speech_enhancement_amd import attention as A
+    from speech_enhancement_amd.weights import WeightPlan
+    if qsplit is not None:
+        monkeypatch.setenv('SE_ATTN_FWD_QSPLIT', qsplit)
+    maxpos = 512
+    g = torch.Generator().manual_seed(T)
+    qkv = (torch.randn(B, T, Fq, 192, generator=g) * 1.2).cuda()
+    E = (torch.randn(2 * maxpos + 1, 16, generator=g) * 0.7).cuda()
+    geom = A.seq_geometry(B, T, Fq, axis)
+    assert A.f16_fwd_shape_ok(geom, maxpos)
+    plan = WeightPlan(torch.device('cuda'))
+    Es = plan.linear('e', E, planes='f16')
+    plan.run()
+    amax = qkv.abs().max().reshape(1).clone()
+    O, lse = A.attn_fwd(qkv.view(-1, 192), E, geom, maxpos=maxpos, Es=Es, qkv_amax=amax, need_lse=False)
+    assert lse is None
+    ref = ref_attention(qkv.double(), E.double(), B, T, Fq, axis, maxpos, 0.25)
+    assert relerr(O.view(B, T, Fq, 64), ref) < 5e-6
+    if not A.f16_shape_ok(geom, maxpos):
+        with pytest.raises(Exception):              # with a backward to come (need_lse) the training shapes only
+            A.attn_fwd(qkv.view(-1, 192), E, geom, maxpos=maxpos, Es=Es, qkv_amax=amax)
