@@ -456,11 +456,18 @@ int se_diff_upsample(const float* in, const float* w, const float* bias, float* 
 /* x = relu(w a + b) (input_projection, models/DiffuSE.py:150-151), y = x + d0[b or 0] (first diffusion_projection, :113-116) */
 int se_diff_input(const float* audio, const float* w, const float* bias, const float* d0, int dB, float* x, float* y, int B,
                   long L, int C, void* stream);
+/* the same, and the device scalar y_amax (zero-filled by the caller, may be NULL) is raised to max |y|: the operand scale of the
+ * scaled split-fp16 dilated conv (se_gemm_desc precision 3, a_amax) that reads y */
+int se_diff_input_amax(const float* audio, const float* w, const float* bias, const float* d0, int dB, float* x, float* y, int B,
+                       long L, int C, float* y_amax, void* stream);
 /* y = sigmoid(z[:C]) * tanh(z[C:]), z = R * scale + shift (GroupNorm of the dilated conv) + cond   (:117-122) */
 int se_diff_gate(const float* R, const float* ss, const float* cond, float* y, int B, long L, int C, void* stream);
 /* x <- (x + R2[:C]) / sqrt(2); ynext = x + d_next; skip (+)= GroupNorm(R2[C:])   (:124-127, 155-158) */
 int se_diff_mix(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip, int first,
                 int B, long L, int C, void* stream);
+/* the same, and y_amax (zero-filled, may be NULL) is raised to max |ynext| */
+int se_diff_mix_amax(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip, int first,
+                     int B, long L, int C, float* y_amax, void* stream);
 /* nn.GroupNorm statistics -> ss [B][N][2] = (scale, shift) per (batch, channel) for channels [c_off, c_off + N) of the
  * fp64 (sum, sumsq) table stats [B][Ntot][2] a GEMM epilogue produced (SE_EPI_STATS), groups of gsize channels */
 int se_group_finalize(const double* stats, int B, int Ntot, int c_off, int N, int gsize, double count_per_channel,

@@ -38,9 +38,10 @@ __global__ void diff_upsample_kernel(const float* __restrict__ in, const float* 
 // one thread = one position x 4 channels
 __global__ void diff_input_kernel(const float* __restrict__ audio, const float* __restrict__ w, const float* __restrict__ bias,
                                   const float* __restrict__ d0, int dB, float* __restrict__ x, float* __restrict__ y, long L, int C,
-                                  long total) {
+                                  long total, float* __restrict__ y_amax) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+  const bool live = idx < total;                 // (no early exit: the wave maximum below needs every lane)
+  if (!live) idx = total - 1;
   const int q = C / 4, c4 = (int)(idx % q) * 4;
   const long pos = idx / q;
   const int b = (int)(pos / L);
@@ -49,8 +50,15 @@ __global__ void diff_input_kernel(const float* __restrict__ audio, const float* 
   const float4 d4 = *reinterpret_cast<const float4*>(d0 + (long)(dB > 1 ? b : 0) * C + c4);
   float4 xv = make_float4(fmaxf(w4.x * a + b4.x, 0.f), fmaxf(w4.y * a + b4.y, 0.f), fmaxf(w4.z * a + b4.z, 0.f),
                           fmaxf(w4.w * a + b4.w, 0.f));
-  *reinterpret_cast<float4*>(x + idx * 4) = xv;
-  *reinterpret_cast<float4*>(y + idx * 4) = make_float4(xv.x + d4.x, xv.y + d4.y, xv.z + d4.z, xv.w + d4.w);
+  const float4 yv = make_float4(xv.x + d4.x, xv.y + d4.y, xv.z + d4.z, xv.w + d4.w);
+  if (live) {
+    *reinterpret_cast<float4*>(x + idx * 4) = xv;
+    *reinterpret_cast<float4*>(y + idx * 4) = yv;
+  }
+  if (y_amax) {        // max |y|: the operand scale of the scaled split-fp16 dilated conv that reads y
+    const float m = wave_max(live ? fmaxf(fmaxf(fabsf(yv.x), fabsf(yv.y)), fmaxf(fabsf(yv.z), fabsf(yv.w))) : 0.f);
+    if ((threadIdx.x & 63) == 0) amax_raise_(y_amax, m);
+  }
 }
 
 // R [B, L, 2C], ss [B][2C][2] (scale, shift of the GroupNorm), cond [B, L, 2C] -> y [B, L, C]
@@ -82,9 +90,10 @@ __global__ void diff_gate_kernel(const float* __restrict__ R, const float* __res
 // skip_sum (+)= GroupNorm(skip)
 __global__ void diff_mix_kernel(float* __restrict__ x, const float* __restrict__ R2, const float* __restrict__ ss,
                                 const float* __restrict__ dn, int dB, float* __restrict__ ynext, float* __restrict__ skip, int first,
-                                long L, int C, long total) {
+                                long L, int C, long total, float* __restrict__ y_amax) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+  const bool live = idx < total;
+  if (!live) idx = total - 1;
   const int q = C / 4, c4 = (int)(idx % q) * 4;
   const long pos = idx / q;
   const int b = (int)(pos / L);
@@ -94,11 +103,19 @@ __global__ void diff_mix_kernel(float* __restrict__ x, const float* __restrict__
   const float4 rs = *reinterpret_cast<const float4*>(r + c4), sk = *reinterpret_cast<const float4*>(r + C + c4);
   const float k = 0.70710678118654752f;
   float4 xn = make_float4((xr.x + rs.x) * k, (xr.y + rs.y) * k, (xr.z + rs.z) * k, (xr.w + rs.w) * k);
-  *reinterpret_cast<float4*>(x + idx * 4) = xn;
+  float ym = 0.f;
   if (dn) {
     const float4 d4 = *reinterpret_cast<const float4*>(dn + (long)(dB > 1 ? b : 0) * C + c4);
-    *reinterpret_cast<float4*>(ynext + idx * 4) = make_float4(xn.x + d4.x, xn.y + d4.y, xn.z + d4.z, xn.w + d4.w);
+    const float4 yv = make_float4(xn.x + d4.x, xn.y + d4.y, xn.z + d4.z, xn.w + d4.w);
+    if (live) *reinterpret_cast<float4*>(ynext + idx * 4) = yv;
+    ym = fmaxf(fmaxf(fabsf(yv.x), fabsf(yv.y)), fmaxf(fabsf(yv.z), fabsf(yv.w)));
   }
+  if (y_amax) {
+    const float m = wave_max(live ? ym : 0.f);
+    if ((threadIdx.x & 63) == 0) amax_raise_(y_amax, m);
+  }
+  if (!live) return;
+  *reinterpret_cast<float4*>(x + idx * 4) = xn;
   float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(skip + idx * 4);
   acc.x += sk.x * s[(c4 + 0) * 2] + s[(c4 + 0) * 2 + 1];
   acc.y += sk.y * s[(c4 + 1) * 2] + s[(c4 + 1) * 2 + 1];
@@ -134,12 +151,16 @@ extern "C" int se_diff_upsample(const float* in, const float* w, const float* bi
   DF_LAUNCH(diff_upsample_kernel, total, stream, in, w, bias, out, F, Tin, layout, ldo, total);
   return se_check_launch("se_diff_upsample");
 }
-extern "C" int se_diff_input(const float* audio, const float* w, const float* bias, const float* d0, int dB, float* x, float* y,
-                             int B, long L, int C, void* stream) {
+extern "C" int se_diff_input_amax(const float* audio, const float* w, const float* bias, const float* d0, int dB, float* x, float* y,
+                                  int B, long L, int C, float* y_amax, void* stream) {
   SE_REQUIRE(audio && w && bias && d0 && x && y && B > 0 && L > 0 && C > 0 && (C % 4) == 0, "diff_input: bad arguments");
   const long total = (long)B * L * (C / 4);
-  DF_LAUNCH(diff_input_kernel, total, stream, audio, w, bias, d0, dB, x, y, L, C, total);
+  DF_LAUNCH(diff_input_kernel, total, stream, audio, w, bias, d0, dB, x, y, L, C, total, y_amax);
   return se_check_launch("se_diff_input");
+}
+extern "C" int se_diff_input(const float* audio, const float* w, const float* bias, const float* d0, int dB, float* x, float* y,
+                             int B, long L, int C, void* stream) {
+  return se_diff_input_amax(audio, w, bias, d0, dB, x, y, B, L, C, nullptr, stream);
 }
 extern "C" int se_diff_gate(const float* R, const float* ss, const float* cond, float* y, int B, long L, int C, void* stream) {
   SE_REQUIRE(R && ss && cond && y && B > 0 && L > 0 && C > 0 && (C % 4) == 0, "diff_gate: bad arguments");
@@ -147,12 +168,16 @@ extern "C" int se_diff_gate(const float* R, const float* ss, const float* cond, 
   DF_LAUNCH(diff_gate_kernel, total, stream, R, ss, cond, y, L, C, total);
   return se_check_launch("se_diff_gate");
 }
-extern "C" int se_diff_mix(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip,
-                           int first, int B, long L, int C, void* stream) {
+extern "C" int se_diff_mix_amax(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip,
+                                int first, int B, long L, int C, float* y_amax, void* stream) {
   SE_REQUIRE(x && R2 && ss && skip && (!d_next || ynext) && B > 0 && L > 0 && C > 0 && (C % 4) == 0, "diff_mix: bad arguments");
   const long total = (long)B * L * (C / 4);
-  DF_LAUNCH(diff_mix_kernel, total, stream, x, R2, ss, d_next, dB, ynext, skip, first, L, C, total);
+  DF_LAUNCH(diff_mix_kernel, total, stream, x, R2, ss, d_next, dB, ynext, skip, first, L, C, total, y_amax);
   return se_check_launch("se_diff_mix");
+}
+extern "C" int se_diff_mix(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip,
+                           int first, int B, long L, int C, void* stream) {
+  return se_diff_mix_amax(x, R2, ss, d_next, dB, ynext, skip, first, B, L, C, nullptr, stream);
 }
 extern "C" int se_diff_out(const float* h, const float* w, const float* bias, float* out, long npos, int C, void* stream) {
   SE_REQUIRE(h && w && bias && out && npos > 0 && C > 0 && (C % 64) == 0, "diff_out: C must be a multiple of 64");

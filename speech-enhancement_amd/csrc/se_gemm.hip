@@ -552,8 +552,13 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
 // 64 MFMAs.  Here one workgroup owns 128 rows and sweeps ALL column blocks: each wave loads its 32 rows straight into
 // the MFMA A-fragment layout (lane = row, 8 consecutive k), applies the prologue and the bf16 split ONCE and keeps the
 // fragments in 16 * NPL VGPRs; only the 64 x 64 weight blocks stream through LDS (next block prefetched in registers).
-template <int PRO, int NPL, bool PRE2, bool WPL = false, bool F16 = false>
-__global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k64_panel_kernel(GemmArgs g) {   // (the PRE2 and three-plane forms hold more registers: they spill under the bound)
+// NT = 3 (round 3, CDiffuSE): a 1-D convolution with three taps (0, df[t]) over channels-last [B][L][64] maps -- the dilated
+// convolutions of the DiffWave residual layers (models/DiffuSE.py:98-127) -- as the same panel with K = 3 x 64: the fragments of
+// the three shifted rows are loaded, split and kept in registers once (96 VGPRs), the [64 x 64] weight block of every (column
+// block, tap) streams through LDS.  The generic tap kernel staged (and split) every A tile once per tap AND per column block.
+// B > 1 (NT = 1 or 3): blockIdx = batch entry x row tile; the SE_EPI_STATS sums go to the entry's row of the table.
+template <int PRO, int NPL, bool PRE2, bool WPL = false, bool F16 = false, int NT = 1>
+__global__ __launch_bounds__(256, NT == 3 ? 2 : ((PRE2 || NPL == 3) ? 1 : K64_OCC)) void gemm_k64_panel_kernel(GemmArgs g) {   // (the PRE2 and three-plane forms hold more registers: they spill under the bound)
   constexpr int SB = 72, PB = 64 * SB;         // 64 + 8 bf16 per W row: 144-B stride, conflict-free b128 fragment reads
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
   __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 36];
@@ -561,8 +566,10 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
   __shared__ __attribute__((aligned(16))) float bias_s[64];
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int Mb = d.To * d.Fo;                  // row GEMM: B == 1
-  const int m0 = blockIdx.x * 128;
+  const int Mb = d.To * d.Fo;                  // rows per batch entry (row GEMM: B == 1)
+  const int b = d.B == 1 ? 0 : (int)blockIdx.x / g.tiles;
+  const int m0 = ((int)blockIdx.x - b * g.tiles) * 128;
+  const long brow = (long)b * Mb;
   const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
   const unsigned thr = drop_thr(d.drop_p);
   const float inv_keep = drop_inv_keep(d.drop_p);
@@ -576,12 +583,16 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
   // ---- A fragments: row = lane & 31 of this wave's 32 rows, k = 16 ks + 8 (lane >> 5) .. + 7
   const int row = m0 + wave * 32 + (lane & 31), kg = lane >> 5;
   const bool rok = row < Mb;
-  bf16x8 af[4][NPL];
-  {
+  bf16x8 af[NT][4][NPL];
+#pragma unroll
+  for (int tp = 0; tp < NT; ++tp) {
     // no predicated loads: rows past the end read the last row and are zeroed by selects; the per-channel prologue operands
     // (LayerNorm gamma / beta, BatchNorm scale / shift) go through LDS.  Behind `rok ? load : 0` the compiler emitted one
     // divergent branch + s_waitcnt vmcnt(0) per load: ~10 dependent L2 round trips before a workgroup's first MFMA.
-    const long rowl = rok ? row : Mb - 1;
+    // (NT = 3: the row shifted by the tap, zero outside the batch entry)
+    const int srow = NT == 1 ? row : row + d.df[tp];
+    const bool sok = NT == 1 ? rok : (rok && srow >= 0 && srow < Mb);
+    const long rowl = brow + (sok ? srow : (NT == 1 ? Mb - 1 : 0));
     const float* __restrict__ ap = g.A + rowl * d.lda + d.a_off + 8 * kg;
     float mean = 0.f, rstd = 0.f;
     if (PRO == SE_PRO_LN) { const float2 mr = *reinterpret_cast<const float2*>(g.rowstats + 2 * rowl); mean = mr.x; rstd = mr.y; }
@@ -592,7 +603,7 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
       v[ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
     }
     float* pss = patch;                          // [ps 64 | pb 64], the patch is not in use yet
-    if (PRO == SE_PRO_LN || PRO == SE_PRO_AFFINE_SWISH) {
+    if ((PRO == SE_PRO_LN || PRO == SE_PRO_AFFINE_SWISH) && tp == 0) {
       if (tid < 32) *reinterpret_cast<float4*>(&pss[4 * tid]) = *reinterpret_cast<const float4*>((tid < 16 ? g.ps : g.pb - 64) + 4 * tid);
       __syncthreads();
     }
@@ -609,11 +620,11 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
             ps4 = *reinterpret_cast<const float4*>(&pss[c]);
             pb4 = *reinterpret_cast<const float4*>(&pss[64 + c]);
           }
-          w = apply_pro<PRO>(w, c, 64, mean, rstd, ps4, pb4, (unsigned)row, d.pro_seed, thr, inv_keep);
+          w = apply_pro<PRO>(w, c, 64, mean, rstd, ps4, pb4, (unsigned)(brow + row), d.pro_seed, thr, inv_keep);
         }
-        x[4 * h] = rok ? w.x : 0.f; x[4 * h + 1] = rok ? w.y : 0.f; x[4 * h + 2] = rok ? w.z : 0.f; x[4 * h + 3] = rok ? w.w : 0.f;
+        x[4 * h] = sok ? w.x : 0.f; x[4 * h + 1] = sok ? w.y : 0.f; x[4 * h + 2] = sok ? w.z : 0.f; x[4 * h + 3] = sok ? w.w : 0.f;
       }
-      if constexpr (F16) split_planes8_h(x, sa, af[ks]); else split_planes8<NPL>(x, af[ks]);
+      if constexpr (F16) split_planes8_h(x, sa, af[tp][ks]); else split_planes8<NPL>(x, af[tp][ks]);
     }
   }
   // ---- W blocks: 64 rows x 64 k, 4 float4 per thread
@@ -623,13 +634,13 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
   // pre-split weights: thread -> (row tid >> 2, 16-B chunks (tid & 3) and (tid & 3) + 4) of the 64 x 64 bf16 block of every plane
   const int pr = tid >> 2, pc = tid & 3;
   uint4 rbp[NPL][2];
-  auto load_w = [&](int by) {
+  auto load_w = [&](int by, int tap = 0) {
     if (WPL) {
       int n; bool ok;
       if (glu) { n = (pr >> 5) * (d.N / 2) + by * 32 + (pr & 31); ok = (by * 32 + (pr & 31)) < d.N / 2; }
       else { n = by * 64 + pr; ok = n < d.N; }
       // (rows past N read row 0 and are zeroed by selects: a predicated load is an exec-masked branch region with its own wait)
-      const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)(ok ? n : 0) * (unsigned)d.ldw + 8 * pc);
+      const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)(ok ? n : 0) * (unsigned)d.ldw + 64 * tap + 8 * pc);
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
 #pragma unroll
@@ -653,6 +664,11 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
   const int frag = (lane & 31) * SB + 8 * (lane >> 5);
   float* cs = patch + wave * 32 * 36;
   for (int by = 0; by < ncb; ++by) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+   for (int tp = 0; tp < NT; ++tp) {
     if (WPL) {
 #pragma unroll
       for (int q = 0; q < NPL; ++q)
@@ -662,14 +678,15 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
 #pragma unroll
       for (int i = 0; i < 4; ++i) split_store<NPL>(rb[i], &Bp[(r0 + 16 * i) * SB + kq * 4], PB);
     }
-    if (vec_ep) stage_bias(g, by, bias_s);
+    if (vec_ep && tp == 0) stage_bias(g, by, bias_s);
     __syncthreads();
-    if (by + 1 < ncb) load_w(by + 1);
+    if (tp + 1 < NT) load_w(by, tp + 1);
+    else if (by + 1 < ncb) load_w(by + 1);
     // second epilogue operand (pre-activation for the swish gradient, or the residual) of this column block: issued
     // before the MFMAs -- with 2 waves per SIMD nothing else would cover its latency at the tail
     float4 pre[8];
     if (PRE2) {
-      const float* __restrict__ src = (d.epilogue & SE_EPI_SWISH_GRAD) ? g.AUX + (long)m0 * d.ldx + d.x_off : g.R + (long)m0 * d.ldr + d.r_off;
+      const float* __restrict__ src = (d.epilogue & SE_EPI_SWISH_GRAD) ? g.AUX + (brow + m0) * d.ldx + d.x_off : g.R + (brow + m0) * d.ldr + d.r_off;
       const unsigned ld2 = (d.epilogue & SE_EPI_SWISH_GRAD) ? d.ldx : d.ldr;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
@@ -680,9 +697,6 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 bf0[NPL], bf1[NPL];
@@ -695,17 +709,121 @@ __global__ __launch_bounds__(256, (PRE2 || NPL == 3) ? 1 : K64_OCC) void gemm_k6
       for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
         for (int qa = 0; qa <= ord; ++qa) {
-          acc0 = mfma32_<F16>(af[ks][qa], bf0[ord - qa], acc0);
-          acc1 = mfma32_<F16>(af[ks][qa], bf1[ord - qa], acc1);
+          acc0 = mfma32_<F16>(af[tp][ks][qa], bf0[ord - qa], acc0);
+          acc1 = mfma32_<F16>(af[tp][ks][qa], bf1[ord - qa], acc1);
         }
     }
+    if (tp + 1 < NT) { __syncthreads(); continue; }      // the next tap's weight block replaces this one in LDS
     if (F16) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
     }
-    if (vec_ep) gemm_epilogue_vec<PRE2, false>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, red, bias_s, pre);      // (residuals come in `pre`)
-    else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, 0, cs, 36);
+    if (vec_ep) gemm_epilogue_vec<PRE2, false>(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s, pre);      // (residuals come in `pre`)
+    else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, b, cs, 36);
     __syncthreads();
+   }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// W-stationary persistent kernel for the two GEMMs of a DiffWave residual layer (CDiffuSE, models/DiffuSE.py:98-127) on
+// channels-last 1-D maps [B][L][64]: the dilated Conv1d(64 -> N, k = 3) (NT = 3: taps (0, df[t]), zero padding) and the
+// 1 x 1 projections (NT = 1), scaled split-fp16, bias + the per-(entry, channel) GroupNorm sums in the vector epilogue.
+// The row panel above streams the [64 x 64] weight block of every (column block, tap) through LDS: two barriers per
+// 24 MFMAs of a wave and a weight load from the L2 that nothing covers between two taps -- 325 us for 0.79 GB (batch 32 x
+// 32 000 samples), and 8 000 workgroups x 98 KB of weight traffic.  Here a workgroup owns ONE column block, stages its
+// [64 x NT 64] weights (two planes) in LDS once and loops over row tiles: no barrier and no weight load in the steady state;
+// the A rows of the next tap / next tile (one tap's fragments = 32 VGPRs) are in flight during the 24 MFMAs of the
+// current tap.  LDS 51 KB (+ the epilogue patch 18 KB): two workgroups per CU.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, int ngroups) {
+  constexpr int SW = NT * 64 + 8, PW = 64 * SW;    // 64 + 8 / 192 + 8 bf16 per W row: 16-B chunks at an odd stride
+  __shared__ __attribute__((aligned(16))) __bf16 Wl[2 * PW];
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 36];
+  __shared__ float red[4 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) float bias_s[64];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Mb = d.Fo;                            // To == 1 (host-checked)
+  // the ncb column blocks of a row group sit on the same XCD (blocks x and x + 8): its L2 serves the rows to both
+  const int bx = (int)blockIdx.x, ncb = g.ncb;
+  const int by = (bx >> 3) % ncb, grp = (bx & 7) + 8 * (bx / (8 * ncb));
+  if (grp >= ngroups) return;
+  f16_clamp_mode_();
+  const int ea = operand_sexp_(d.a_amax, d.a_sexp), ew = operand_sexp_(d.w_amax, d.w_sexp);
+  const float sa = exp2i_(ea), unscale = exp2i_(-ea - ew);
+  {   // the column block's weights: thread -> row tid >> 2, 16-B chunks (tid & 3) + 4 j of the NT * 8 chunks of every plane
+    const int pr = tid >> 2, pc = tid & 3;
+    const int n = by * 64 + pr;
+    const bool ok = n < d.N;
+    const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)(ok ? n : 0) * (unsigned)d.ldw + 8 * pc);
+    uint4 w[2][2 * NT];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 2 * NT; ++j) w[q][j] = *reinterpret_cast<const uint4*>(wp + (size_t)q * (size_t)d.w_planes + 32 * j);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int j = 0; j < 2 * NT; ++j)
+        *reinterpret_cast<uint4*>(&Wl[q * PW + pr * SW + 8 * pc + 32 * j]) =
+            make_uint4(ok ? w[q][j].x : 0u, ok ? w[q][j].y : 0u, ok ? w[q][j].z : 0u, ok ? w[q][j].w : 0u);
+  }
+  stage_bias(g, by, bias_s);
+  __syncthreads();
+  const int kg = lane >> 5;
+  const int frag = (lane & 31) * SW + 8 * kg;
+  float* cs = patch + wave * 32 * 36;
+  const int ntile = d.B * g.tiles;
+  // raw rows of the tap that is split next: row (lane & 31) of the wave's 32 rows, floats 16 ks + 8 kg .. + 7
+  float4 v[4][2];
+  bool vok = false;
+  auto request = [&](int tile, int tp) {
+    const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
+    const int row = m0 + wave * 32 + (lane & 31);
+    const int srow = row + (NT == 1 ? 0 : d.df[tp]);
+    vok = row < Mb && srow >= 0 && srow < Mb;       // (zero padding; rows past the end of a ragged last tile)
+    const float* __restrict__ ap = g.A + ((long)b * Mb + (vok ? srow : 0)) * d.lda + d.a_off + 8 * kg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v[ks][0] = *reinterpret_cast<const float4*>(ap + 16 * ks);
+      v[ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
+    }
+  };
+  if (grp < ntile) request(grp, 0);
+  for (int tile = grp; tile < ntile; tile += ngroups) {
+    const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+      bf16x8 af[4][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        float x[8] = {vok ? v[ks][0].x : 0.f, vok ? v[ks][0].y : 0.f, vok ? v[ks][0].z : 0.f, vok ? v[ks][0].w : 0.f,
+                      vok ? v[ks][1].x : 0.f, vok ? v[ks][1].y : 0.f, vok ? v[ks][1].z : 0.f, vok ? v[ks][1].w : 0.f};
+        split_planes8_h(x, sa, af[ks]);
+      }
+      if (tp + 1 < NT) request(tile, tp + 1);
+      else if (tile + ngroups < ntile) request(tile + ngroups, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 bf0[2], bf1[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wl[pl * PW + frag + 64 * tp + 16 * ks]);
+          bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wl[pl * PW + 32 * SW + frag + 64 * tp + 16 * ks]);
+        }
+        acc0 = mfma32_<true>(af[ks][1], bf0[0], acc0); acc1 = mfma32_<true>(af[ks][1], bf1[0], acc1);     // smallest terms first
+        acc0 = mfma32_<true>(af[ks][0], bf0[1], acc0); acc1 = mfma32_<true>(af[ks][0], bf1[1], acc1);
+        acc0 = mfma32_<true>(af[ks][0], bf0[0], acc0); acc1 = mfma32_<true>(af[ks][0], bf1[0], acc1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
+    gemm_epilogue_vec<false, false>(g, acc0, acc1, m0, by, b, cs, 36, 0u, 1.f, red, bias_s);
+    if (d.epilogue & SE_EPI_STATS) __syncthreads();      // `red` is reused by the next tile
   }
 }
 
@@ -792,9 +910,34 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                                                        SE_EPI_SWISH_GRAD | 256)) &&
                         (d->N & 7) == 0 && (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldx & 3) == 0 && (d->x_off & 3) == 0;
     static const bool no_panel = getenv("SE_GEMM_NO_PANEL") != nullptr;
-    if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && (d->precision >= 1 && d->precision <= 3) && (vec_ok || glu_ok) &&
+    // 1-D maps [B][L][64] (CDiffuSE: To == Ti == 1): the panel also takes batch entries, the SE_EPI_STATS sums (GroupNorm) and
+    // three taps along L (scaled split-fp16 only)
+    const bool map1d = d->To == 1 && d->Ti == 1 && d->Fi == d->Fo && d->st == 1 && d->sf == 1 && !d->up;
+    const bool vec_st = vec_ok || ((ep & SE_EPI_STATS) && map1d && !(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | SE_EPI_ROWSTATS | 256)) &&
+                                   (d->N & 3) == 0 && (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldx & 3) == 0 &&
+                                   (d->x_off & 3) == 0 && (d->ldr & 3) == 0 && (d->r_off & 3) == 0);
+    const bool tap3 = map1d && d->ntap == 3 && d->dt[0] == 0 && d->dt[1] == 0 && d->dt[2] == 0 && d->precision == 3 && d->w_planes &&
+                      d->prologue == SE_PRO_NONE && !(ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) && d->ldw == 192;
+    // enough row tiles for a persistent sweep: the W-stationary kernel (weights of a column block resident in LDS)
+    static const bool no_wstat = getenv("SE_GEMM_NO_WSTAT") != nullptr;
+    if (map1d && (tap3 || (lin && d->precision == 3 && d->w_planes && d->prologue == SE_PRO_NONE && d->ldw == 64)) && d->C == 64 && vec_st &&
+        !(ep & (SE_EPI_ACCUM | SE_EPI_DROP | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ROWSTATS)) && (long)d->B * g.tiles >= 2048 &&
+        (d->w_planes % 8) == 0 && !no_wstat) {
+      int ngroups = 512 / ncols < 8 ? 8 : 512 / ncols;
+      if (const char* e = getenv("SE_WSTAT_GROUPS")) { int v = atoi(e); if (v >= 8) ngroups = v; }
+      if ((long)ngroups > (long)d->B * g.tiles) ngroups = d->B * g.tiles;
+      const dim3 wgrid((unsigned)(ncols * ((ngroups + 7) / 8 * 8)));
+      if (tap3) hipLaunchKernelGGL(conv1d_k64_wstat_kernel<3>, wgrid, block, 0, s, g, ngroups);
+      else hipLaunchKernelGGL(conv1d_k64_wstat_kernel<1>, wgrid, block, 0, s, g, ngroups);
+      return se_check_launch("se_gemm_tap(W-stationary 1-D)");
+    }
+    if ((lin || tap3) && (d->B == 1 || map1d) && d->C == 64 && ncols >= 2 && (d->precision >= 1 && d->precision <= 3) && (vec_st || glu_ok) &&
         !(ep & SE_EPI_ACCUM) && !((ep & SE_EPI_SWISH_GRAD) && (ep & SE_EPI_RESID)) && !no_panel) {
-      dim3 pgrid(g.tiles);
+      dim3 pgrid((unsigned)(d->B * g.tiles));
+      if (tap3) {
+        hipLaunchKernelGGL((gemm_k64_panel_kernel<SE_PRO_NONE, 2, false, true, true, 3>), pgrid, block, 0, s, g);
+        return se_check_launch("se_gemm_tap(k64 panel, 3 taps)");
+      }
       SE_REQUIRE(d->precision != 3 || d->w_planes, "gemm: the scaled split-fp16 row-panel kernel reads pre-split fp16 planes");
       const bool pre2 = (ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) != 0;
 #define LAUNCHP2(PRO, P2) do { if (d->precision == 3) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2, true, true>), pgrid, block, 0, s, g); \

@@ -25,6 +25,7 @@ from . import _lib as L
 from . import frontend as FE
 from . import gemm as GM
 from . import layers as LY
+from .weights import WeightPlan
 
 _i, _l, _f, _d = C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -101,7 +102,12 @@ class DiffuSE(nn.Module):
         Cc, nl = self.C, len(self.residual_layers)
         K = (self.n_specs + 3) // 4 * 4
         pk = {'ver': ver, 'K': K, 'layers': []}
-        for blk in self.residual_layers:
+        # scaled split-fp16 planes of the two GEMMs of every residual layer (precision 3, as in the generator): the weights are
+        # static at inference, prepared once per weight version in one launch
+        f16 = LY.CONV_PRECISION == 3 and os.environ.get('SE_DIFFUSE_PRECISION', 'f16x3') == 'f16x3'
+        plan = WeightPlan(next(self.parameters()).device) if f16 else None
+        pk['plan'] = plan
+        for li, blk in enumerate(self.residual_layers):
             wc = blk.conditioner_projection.weight.detach().reshape(2 * Cc, self.n_specs)
             wcp = torch.zeros(2 * Cc, K, device=wc.device)
             wcp[:, :self.n_specs] = wc
@@ -113,6 +119,13 @@ class DiffuSE(nn.Module):
                                  blk.output_projection[0].weight.detach().reshape(Cc, Cc)], 0).contiguous(),   # res | skip
                 'b2': torch.cat([blk.output_residual.bias.detach(), blk.output_projection[0].bias.detach()]).contiguous(),
                 'taps': [(0, -blk.dilation), (0, 0), (0, blk.dilation)]})
+            if f16:
+                lay = pk['layers'][-1]
+                lay['wd16'] = plan.conv_fwd((li, 'wd'), blk.dilated_conv[0].weight.detach().unsqueeze(2), planes='f16')
+                plan.linear((li, 'w2'), blk.output_residual.weight.detach().reshape(Cc, Cc), planes='f16', rows=2 * Cc)
+                lay['w216'] = plan.linear((li, 'w2'), blk.output_projection[0].weight.detach().reshape(Cc, Cc), planes='f16', o_off=Cc)
+        if f16:
+            plan.run()
         pk['wdp'] = torch.cat([b.diffusion_projection.weight.detach() for b in self.residual_layers], 0).contiguous()  # [nl C, 512]
         pk['bdp'] = torch.cat([b.diffusion_projection.bias.detach() for b in self.residual_layers]).contiguous()
         pk['ws'] = (self.skip_projection.weight.detach().reshape(Cc, Cc) / math.sqrt(nl)).contiguous()
@@ -167,27 +180,42 @@ class DiffuSE(nn.Module):
         ss = torch.empty(B, 2 * Cc, 2, device=dev)
         ss2 = torch.empty(B, Cc, 2, device=dev)
         audio = audio.float().contiguous()
-        L.call('se_diff_input', L.ptr(audio), L.ptr(self.input_projection.weight.detach().reshape(-1).contiguous()),
-               L.ptr(self.input_projection.bias), L.ptr(dproj[0]), _i(dB), L.ptr(x), L.ptr(y), _i(B), _l(Lp), _i(Cc), L.stream())
+        # scaled split-fp16: the producers of y (se_diff_input / se_diff_mix) raise max |y| per layer -- the operand scale of the
+        # dilated conv; the gate output sigmoid * tanh lies in (-1, 1): static exponent 13
+        f16 = pk['plan'] is not None
+        yam = torch.zeros(nl, device=dev) if f16 else None
+        L.call('se_diff_input_amax', L.ptr(audio), L.ptr(self.input_projection.weight.detach().reshape(-1).contiguous()),
+               L.ptr(self.input_projection.bias), L.ptr(dproj[0]), _i(dB), L.ptr(x), L.ptr(y), _i(B), _l(Lp), _i(Cc),
+               L.ptr(yam[0:1] if f16 else None), L.stream())
         for i, (lay, blk) in enumerate(zip(pk['layers'], self.residual_layers)):
             st = torch.zeros(B, 2 * Cc, 2, device=dev, dtype=torch.float64)
-            d = GM.make_desc(B, 1, Lp, 1, Lp, lay['taps'], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
-                             precision=min(LY.CONV_PRECISION, 2))      # no scaled-fp16 kernel for these tap shapes
-            GM.gemm_tap(d, y, lay['wd'], R, bias=lay['bd'], stats=st)
+            if f16:
+                d = GM.make_desc(B, 1, Lp, 1, Lp, lay['taps'], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
+                                 precision=3, a_amax=yam[i:i + 1])
+                GM.gemm_tap(d, y, lay['wd16'], R, bias=lay['bd'], stats=st)
+            else:
+                d = GM.make_desc(B, 1, Lp, 1, Lp, lay['taps'], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
+                                 precision=min(LY.CONV_PRECISION, 2))
+                GM.gemm_tap(d, y, lay['wd'], R, bias=lay['bd'], stats=st)
             gn = blk.dilated_conv[1]
             L.call('se_group_finalize', L.ptr(st), _i(B), _i(2 * Cc), _i(0), _i(2 * Cc), _i(16), _d(float(Lp)), L.ptr(gn.weight),
                    L.ptr(gn.bias), L.ptr(ss), _f(gn.eps), L.stream())
             L.call('se_diff_gate', L.ptr(R), L.ptr(ss), L.ptr(cond[i]), L.ptr(y2), _i(B), _l(Lp), _i(Cc), L.stream())
             st2 = torch.zeros(B, 2 * Cc, 2, device=dev, dtype=torch.float64)
-            d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
-                              precision=min(LY.CONV_PRECISION, 2))      # no scaled-fp16 kernel for these tap shapes
-            GM.gemm_tap(d2, y2, lay['w2'], R2, bias=lay['b2'], stats=st2)
+            if f16:
+                d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
+                                  precision=3, a_sexp=13)
+                GM.gemm_tap(d2, y2, lay['w216'], R2, bias=lay['b2'], stats=st2)
+            else:
+                d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
+                                  precision=min(LY.CONV_PRECISION, 2))
+                GM.gemm_tap(d2, y2, lay['w2'], R2, bias=lay['b2'], stats=st2)
             gn2 = blk.output_projection[1]
             L.call('se_group_finalize', L.ptr(st2), _i(B), _i(2 * Cc), _i(Cc), _i(Cc), _i(16), _d(float(Lp)), L.ptr(gn2.weight),
                    L.ptr(gn2.bias), L.ptr(ss2), _f(gn2.eps), L.stream())
             nxt = dproj[i + 1] if i + 1 < nl else None
-            L.call('se_diff_mix', L.ptr(x), L.ptr(R2), L.ptr(ss2), L.ptr(nxt), _i(dB), L.ptr(y), L.ptr(skip), _i(int(i == 0)),
-                   _i(B), _l(Lp), _i(Cc), L.stream())
+            L.call('se_diff_mix_amax', L.ptr(x), L.ptr(R2), L.ptr(ss2), L.ptr(nxt), _i(dB), L.ptr(y), L.ptr(skip), _i(int(i == 0)),
+                   _i(B), _l(Lp), _i(Cc), L.ptr(yam[i + 1:i + 2] if (f16 and i + 1 < nl) else None), L.stream())
         GM.gemm_tap(GM.make_desc(1, 1, B * Lp, 1, B * Lp, [(0, 0)], Cc, Cc, Cc, Cc, epilogue=L.EPI_BIAS), skip, pk['ws'], y2,
                     bias=self.skip_projection.bias)
         out = torch.empty(B, Lp, device=dev)

@@ -55,12 +55,12 @@ def dft_matrices(n_fft, hop, device):
 def envelope(n_fft, hop, T, device):
     key = ('env', n_fft, hop, T, str(device))
     if key not in _CACHE:
-        w2 = hamming(n_fft, device) ** 2
+        w2 = (hamming(n_fft, device) ** 2).cpu()                 # summed on the host: T tiny device launches otherwise (1601 at 10 s)
         Lp = n_fft + hop * (T - 1)
-        env = torch.zeros(Lp, dtype=torch.float64, device=device)
+        env = torch.zeros(Lp, dtype=torch.float64)
         for t in range(T):
             env[t * hop:t * hop + n_fft] += w2
-        _CACHE[key] = env.float().contiguous()
+        _CACHE[key] = env.float().contiguous().to(device)
     return _CACHE[key]
 
 

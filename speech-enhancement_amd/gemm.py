@@ -82,8 +82,8 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
                  if d.precision in (1, 2, 3) and d.C >= 32 and d.prologue == 0 and d.ntap >= 3 and d.ntap % 3 == 0 and not d.up
                  and d.st == 1 and d.sf == 1 and d.Ti == d.To and d.Fi == d.Fo and not d.epilogue & (L.EPI_GLU | L.EPI_DROP) else
                  (f'gemm_k64_panel_f16x3<{d.prologue}>' if d.precision == 3 else f'gemm_k64_panel_bf16x{3 if d.precision == 1 else 6}<{d.prologue}>')
-                 if d.precision in (1, 2, 3) and d.C == 64 and d.N >= 128 and d.ntap == 1 and d.B == 1 and d.To == 1
-                 and not d.epilogue & (L.EPI_ACCUM | L.EPI_STATS | L.EPI_SHUFFLE2) else
+                 if d.precision in (1, 2, 3) and d.C == 64 and d.N >= 128 and d.To == 1 and d.Ti == 1 and not d.epilogue & (L.EPI_ACCUM | L.EPI_SHUFFLE2)
+                 and (d.ntap == 1 or (d.ntap == 3 and d.precision == 3)) else
                  f'gemm_tap_f16x3_kernel<{d.prologue}>' if d.precision == 3 else
                  f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
                  f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>'), _flops=2.0 * M * d.N * d.ntap * d.C,

@@ -141,6 +141,38 @@ def test_pointwise_conv_behind_batchnorm_swish(env):
     assert relerr(y, ref) < 4 * relerr(y32, ref) + 1e-6          # at the level of the fp32-MFMA kernel it replaces
 
 
+@pytest.mark.parametrize('dil,Lp,B', [(1, 900, 2), (4, 1000, 3), (512, 900, 2), (64, 128 * 5, 1),
+                                      (8, 128 * 1100 + 77, 2), (512, 128 * 700, 3)])       # >= 2048 row tiles: the W-stationary kernel
+def test_dilated_conv1d_and_projection_panels_with_groupnorm_sums(env, dil, Lp, B):
+    """the two GEMMs of a DiffWave residual layer (models/DiffuSE.py:98-127) on the K = 64 row panel: the dilated Conv1d(64 -> 128,
+    k = 3, padding = dilation) as three shifted row fragments held in registers, and the 1 x 1 projections 64 -> 128 with batch
+    entries; both with bias and the per-(entry, channel) fp64 sums of GroupNorm (SE_EPI_STATS); ragged last tile, dilation beyond
+    the tile and beyond half the map; small maps take the row panel, long ones the persistent W-stationary kernel"""
+    GM, L, LY, O, WeightPlan = env
+    C = 64
+    y = _amax(rnd(B, Lp, C, seed=dil) * 1.7)
+    Wd, bd = rnd(2 * C, C, 3, seed=2, scale=0.08), rnd(2 * C, seed=3, scale=0.1)
+    W2, b2 = rnd(2 * C, C, seed=4, scale=0.1), rnd(2 * C, seed=5, scale=0.1)
+    plan = WeightPlan(torch.device('cuda'))
+    pd = plan.conv_fwd('d', Wd.unsqueeze(2).contiguous(), planes='f16')
+    p2 = plan.linear('2', W2, planes='f16')
+    plan.run()
+    taps = [(0, -dil), (0, 0), (0, dil)]
+    R, st = torch.empty(B, Lp, 2 * C, device='cuda'), torch.zeros(B, 2 * C, 2, device='cuda', dtype=torch.float64)
+    d = GM.make_desc(B, 1, Lp, 1, Lp, taps, C, C, 2 * C, 2 * C, epilogue=L.EPI_BIAS | L.EPI_STATS, precision=3, a_amax=y._se_amax)
+    GM.gemm_tap(d, y, pd, R, bias=bd, stats=st)
+    ref = F.conv1d(y.double().transpose(1, 2), Wd.double(), bd.double(), padding=dil, dilation=dil).transpose(1, 2)
+    assert relerr(R, ref) < 3e-6
+    assert relerr(st[..., 0], ref.sum(1)) < 1e-5 and relerr(st[..., 1], (ref * ref).sum(1)) < 1e-5
+    g = torch.tanh(rnd(B, Lp, C, seed=7))                      # the gate output lies in (-1, 1): static exponent 13
+    R2, st2 = torch.empty(B, Lp, 2 * C, device='cuda'), torch.zeros(B, 2 * C, 2, device='cuda', dtype=torch.float64)
+    d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], C, C, 2 * C, 2 * C, epilogue=L.EPI_BIAS | L.EPI_STATS, precision=3, a_sexp=13)
+    GM.gemm_tap(d2, g, p2, R2, bias=b2, stats=st2)
+    ref2 = g.double() @ W2.double().t() + b2.double()
+    assert relerr(R2, ref2) < 3e-6
+    assert relerr(st2[..., 0], ref2.sum(1)) < 1e-5 and relerr(st2[..., 1], (ref2 * ref2).sum(1)) < 1e-5
+
+
 def test_feed_forward_pair(env):
     """fused feed-forward forward / input-gradient chain (conformer.py:53-71,128-145) on fp16 planes vs fp64"""
     GM, L, LY, O, WeightPlan = env
