@@ -822,8 +822,118 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
-    gemm_epilogue_vec<false, false>(g, acc0, acc1, m0, by, b, cs, 36, 0u, 1.f, red, bias_s);
+    gemm_epilogue_vec<false, false, true>(g, acc0, acc1, m0, by, b, cs, 36, 0u, 1.f, red, bias_s);
     if (d.epilogue & SE_EPI_STATS) __syncthreads();      // `red` is reused by the next tile
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// W-stationary persistent form of the row panel for the token-wise layers of the train step (qkv 64 -> 192, pointwise-GLU
+// 64 -> 256, the 64 -> 128 input gradient), scaled split-fp16: one 8-wave workgroup per CU keeps ALL column blocks of the
+// weight (two planes, <= 74 KB) in LDS and loops over 256-row tiles.  The panel kernel has one tile per workgroup: the rows'
+// load latency at its start is covered only by the other resident workgroups (wave-wait 64 %), and every column block costs
+// two barriers and a weight block from the L2.  Here the next tile's rows (and LayerNorm statistics) are requested right after
+// the split of the current ones and arrive during the whole sweep; the sweep itself has no barrier and no global load.
+template <int PRO>
+__global__ __launch_bounds__(512, 1) void gemm_k64_wstat_kernel(GemmArgs g) {
+  constexpr int SB = 72;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_ws[];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Mb = d.To * d.Fo;                      // row GEMM: B == 1
+  const int ncb = g.ncb, NR = ncb * 64, PB = NR * SB;
+  __bf16* Bp = reinterpret_cast<__bf16*>(smem_ws);                                   // [2 planes][NR][SB]
+  float* patch = reinterpret_cast<float*>(smem_ws + (size_t)2 * PB * 2);              // [8 waves][32][36]
+  float* pss = patch + 8 * 32 * 36;                                                    // [ps 64 | pb 64]
+  float* bias_all = pss + 128;                                                         // [NR]
+  const bool glu = (d.epilogue & SE_EPI_GLU) != 0;
+  const unsigned thr = drop_thr(d.drop_p);
+  const float inv_keep = drop_inv_keep(d.drop_p);
+  f16_clamp_mode_();
+  const int ea = operand_sexp_(d.a_amax, d.a_sexp), ew = operand_sexp_(d.w_amax, d.w_sexp);
+  const float sa = exp2i_(ea), unscale = exp2i_(-ea - ew);
+  for (int i = tid; i < NR * 8; i += 512) {        // 16-B chunk i & 7 of staged row i >> 3, both planes
+    const int j = i >> 3, ch = i & 7, by = j >> 6, jl = j & 63;
+    int n; bool ok;
+    if (glu) { n = (jl >> 5) * (d.N / 2) + by * 32 + (jl & 31); ok = (by * 32 + (jl & 31)) < d.N / 2; }
+    else { n = j; ok = n < d.N; }
+    const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)(ok ? n : 0) * (unsigned)d.ldw + 8 * ch);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint4 w4 = *reinterpret_cast<const uint4*>(wp + (size_t)q * (size_t)d.w_planes);
+      *reinterpret_cast<uint4*>(&Bp[q * PB + j * SB + 8 * ch]) = make_uint4(ok ? w4.x : 0u, ok ? w4.y : 0u, ok ? w4.z : 0u, ok ? w4.w : 0u);
+    }
+  }
+  if (PRO == SE_PRO_LN && tid < 32) *reinterpret_cast<float4*>(&pss[4 * tid]) = *reinterpret_cast<const float4*>((tid < 16 ? g.ps : g.pb - 64) + 4 * tid);
+  for (int i = tid; i < NR; i += 512) {            // bias in the order of the staged rows (GLU: [value 32 | gate 32] per column block)
+    const int by = i >> 6, jl = i & 63;
+    int n; bool ok;
+    if (glu) { n = (jl >> 5) * (d.N / 2) + by * 32 + (jl & 31); ok = (by * 32 + (jl & 31)) < d.N / 2; }
+    else { n = i; ok = n < d.N; }
+    bias_all[i] = ((d.epilogue & SE_EPI_BIAS) && ok) ? g.bias[n] : 0.f;
+  }
+  __syncthreads();
+  const bool vec_ep = epilogue_vec_ok(d);
+  const int kg = lane >> 5;
+  const int frag = (lane & 31) * SB + 8 * kg;
+  float* cs = patch + wave * 32 * 36;
+  const int ntile = (Mb + 255) / 256;
+  float4 v[4][2];
+  float2 mr = make_float2(0.f, 0.f);
+  auto request = [&](int tile) {                    // rows past the end read the last row (zeroed by selects at the split)
+    const int row = tile * 256 + wave * 32 + (lane & 31);
+    const long rowl = row < Mb ? row : Mb - 1;
+    const float* __restrict__ ap = g.A + rowl * d.lda + d.a_off + 8 * kg;
+    if (PRO == SE_PRO_LN) mr = *reinterpret_cast<const float2*>(g.rowstats + 2 * rowl);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v[ks][0] = *reinterpret_cast<const float4*>(ap + 16 * ks);
+      v[ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
+    }
+  };
+  if ((int)blockIdx.x < ntile) request(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int m0 = tile * 256;
+    const int row = m0 + wave * 32 + (lane & 31);
+    const bool rok = row < Mb;
+    bf16x8 af[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = 16 * ks + 8 * kg + 4 * h;
+        float4 w = v[ks][h];
+        if (PRO == SE_PRO_LN)
+          w = apply_pro<PRO>(w, c, 64, mr.x, mr.y, *reinterpret_cast<const float4*>(&pss[c]), *reinterpret_cast<const float4*>(&pss[64 + c]),
+                             (unsigned)row, d.pro_seed, thr, inv_keep);
+        x[4 * h] = rok ? w.x : 0.f; x[4 * h + 1] = rok ? w.y : 0.f; x[4 * h + 2] = rok ? w.z : 0.f; x[4 * h + 3] = rok ? w.w : 0.f;
+      }
+      split_planes8_h(x, sa, af[ks]);
+    }
+    if (tile + (int)gridDim.x < ntile) request(tile + gridDim.x);
+    for (int by = 0; by < ncb; ++by) {
+      f32x16 acc0, acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      const __bf16* Bb = Bp + by * 64 * SB;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 bf0[2], bf1[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          bf0[pl] = *reinterpret_cast<const bf16x8*>(&Bb[pl * PB + frag + 16 * ks]);
+          bf1[pl] = *reinterpret_cast<const bf16x8*>(&Bb[pl * PB + 32 * SB + frag + 16 * ks]);
+        }
+        acc0 = mfma32_<true>(af[ks][0], bf0[1], acc0); acc1 = mfma32_<true>(af[ks][0], bf1[1], acc1);     // (the row panel's order)
+        acc0 = mfma32_<true>(af[ks][1], bf0[0], acc0); acc1 = mfma32_<true>(af[ks][1], bf1[0], acc1);
+        acc0 = mfma32_<true>(af[ks][0], bf0[0], acc0); acc1 = mfma32_<true>(af[ks][0], bf1[0], acc1);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
+      if (vec_ep) gemm_epilogue_vec<false, false, true>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, nullptr, bias_all + by * 64);
+      else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, 0, cs, 36, bias_all + by * 64);
+    }
   }
 }
 
@@ -930,6 +1040,27 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       if (tap3) hipLaunchKernelGGL(conv1d_k64_wstat_kernel<3>, wgrid, block, 0, s, g, ngroups);
       else hipLaunchKernelGGL(conv1d_k64_wstat_kernel<1>, wgrid, block, 0, s, g, ngroups);
       return se_check_launch("se_gemm_tap(W-stationary 1-D)");
+    }
+    // token-wise layers of the train step with enough 256-row tiles for every CU: the W-stationary persistent form
+    static const bool no_wstat_lin = getenv("SE_GEMM_NO_WSTAT_LIN") != nullptr;
+    if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && d->precision == 3 && d->w_planes && (d->w_planes % 8) == 0 && d->ldw == 64 &&
+        (d->prologue == SE_PRO_NONE || d->prologue == SE_PRO_LN) && (vec_ok || glu_ok) &&
+        !(ep & (SE_EPI_ACCUM | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_STATS)) && Mb >= 256 * 1024 && !no_wstat_lin) {
+      const size_t shw = (size_t)2 * ncols * 64 * 72 * 2 + (size_t)8 * 32 * 36 * 4 + 128 * 4 + (size_t)ncols * 64 * 4;
+      if (shw <= 160 * 1024) {
+        int nwg = 256;
+        if (const char* e = getenv("SE_WSTAT_WGS")) { int v = atoi(e); if (v >= 1) nwg = v; }
+        if (nwg > (Mb + 255) / 256) nwg = (Mb + 255) / 256;
+        static unsigned raised_ws[2] = {0u, 0u};
+        if (d->prologue == SE_PRO_LN) {
+          SE_REQUIRE(se_raise_lds((const void*)gemm_k64_wstat_kernel<SE_PRO_LN>, 160 * 1024, &raised_ws[1]), "gemm: cannot raise the dynamic LDS limit");
+          hipLaunchKernelGGL(gemm_k64_wstat_kernel<SE_PRO_LN>, dim3(nwg), dim3(512), shw, s, g);
+        } else {
+          SE_REQUIRE(se_raise_lds((const void*)gemm_k64_wstat_kernel<SE_PRO_NONE>, 160 * 1024, &raised_ws[0]), "gemm: cannot raise the dynamic LDS limit");
+          hipLaunchKernelGGL(gemm_k64_wstat_kernel<SE_PRO_NONE>, dim3(nwg), dim3(512), shw, s, g);
+        }
+        return se_check_launch("se_gemm_tap(W-stationary row panel)");
+      }
     }
     if ((lin || tap3) && (d->B == 1 || map1d) && d->C == 64 && ncols >= 2 && (d->precision >= 1 && d->precision <= 3) && (vec_st || glu_ok) &&
         !(ep & SE_EPI_ACCUM) && !((ep & SE_EPI_SWISH_GRAD) && (ep & SE_EPI_RESID)) && !no_panel) {

@@ -131,14 +131,18 @@ static __device__ __forceinline__ void load_pro_vec(const float* ps, const float
 // is transposed through a wave-private LDS patch so that every lane then owns 4 consecutive output columns: the
 // AUX / R reads and the Y writes are 16-byte accesses (8 lanes = one 128-B row segment) and there are 4 of them per
 // lane and tile instead of 16 four-byte ones.  cs: the wave's [32][cs_ld] patch (reuses the A staging tile).
-template <bool HASPRE = false, bool HOISTR = true>      // HOISTR: request an in-place residual for all row groups up front (16 VGPRs)
+// NOLOAD: the caller guarantees (host-checked) that none of the flags with a global LOAD in this epilogue is set (accumulate,
+// residual, swish gradient): their branches vanish at compile time.  With run-time flags every row group's store sat behind an
+// `s_waitcnt vmcnt(0)` for a load that was never issued -- which also drains the PREVIOUS group's store and any prefetch in flight:
+// the stores of a wave were serialised at one memory round trip each (24 per 256-row tile of the qkv projection = 17 us per tile).
+template <bool HASPRE = false, bool HOISTR = true, bool NOLOAD = false>      // HOISTR: request an in-place residual for all row groups up front (16 VGPRs)
 static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
                                                          int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
                                                          float inv_keep, float* red, const float* bias_s,
                                                          const float4 (&pre)[8] = {}) {   // pre[nt*4+i]: AUX / R values fetched early
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int Mb = d.To * d.Fo, ep = d.epilogue;
+  const int Mb = d.To * d.Fo, ep = NOLOAD ? (d.epilogue & ~(SE_EPI_ACCUM | SE_EPI_RESID | SE_EPI_SWISH_GRAD)) : d.epilogue;
   const long ptile = (long)b * Mb + m0;
   float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
   const float* __restrict__ Xb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
@@ -376,8 +380,9 @@ static __device__ __forceinline__ void gemm_epilogue_ln_bwd(const GemmArgs& g, c
 // GLU flavour of the vectorised epilogue: accumulator 0 = value columns, accumulator 1 = gate columns of the same 32
 // outputs.  The gate tile is transposed first and parked in registers, then the value tile; Y = a * sigmoid(g) and
 // the pre-GLU Z (both halves) leave as float4 stores.
+// bias_lds: optional [value 32 | gate 32] bias of this column block staged in LDS (no global load at the tail of the block)
 static __device__ __forceinline__ void gemm_epilogue_glu_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
-                                                             int m0, int by, int b, float* cs, int cs_ld) {
+                                                             int m0, int by, int b, float* cs, int cs_ld, const float* bias_lds = nullptr) {
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Mb = d.To * d.Fo, No = d.N / 2;
@@ -395,7 +400,8 @@ static __device__ __forceinline__ void gemm_epilogue_glu_vec(const GemmArgs& g, 
   for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * cs_ld + col] = acc0[r];
   if (n >= No) return;
   float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
-  if (d.epilogue & SE_EPI_BIAS) { ba = *reinterpret_cast<const float4*>(g.bias + n); bg = *reinterpret_cast<const float4*>(g.bias + No + n); }
+  if (bias_lds) { ba = *reinterpret_cast<const float4*>(bias_lds + cq * 4); bg = *reinterpret_cast<const float4*>(bias_lds + 32 + cq * 4); }
+  else if (d.epilogue & SE_EPI_BIAS) { ba = *reinterpret_cast<const float4*>(g.bias + n); bg = *reinterpret_cast<const float4*>(g.bias + No + n); }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = wave * 32 + rr + 8 * i;

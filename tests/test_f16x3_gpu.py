@@ -90,11 +90,11 @@ def _ln64(x, g, b):
     return F.layer_norm(x.double(), (64,), g.double(), b.double(), 1e-5)
 
 
-def test_row_panels_and_glu_gate(env):
+@pytest.mark.parametrize('M', [4096 + 37, 256 * 1024 + 293])
+def test_row_panels_and_glu_gate(env, M):
     """K = 64 row panels with the LayerNorm prologue: qkv (N = 192) and the first pointwise conv with the GLU epilogue keeping
-    only the gate half (conformer.py:103-108,160-166)"""
+    only the gate half (conformer.py:103-108,160-166); from 256 K rows on: the W-stationary persistent form (ragged last tile)"""
     GM, L, LY, O, WeightPlan = env
-    M = 4096 + 37
     x = rnd(M, 64, seed=1) * 1.5 + 0.2
     st = O.row_stats(x, M)
     g, b = rnd(64, seed=2) * 0.2 + 1.0, rnd(64, seed=3) * 0.1
