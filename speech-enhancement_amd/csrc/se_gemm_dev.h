@@ -183,6 +183,10 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
         if (m0 + (int)rb + 16 < Mb) r2 = *reinterpret_cast<const float4*>(Rb + ((rb + 16) * (unsigned)d.ldr + co));
         if (m0 + (int)rb + 24 < Mb) r3 = *reinterpret_cast<const float4*>(Rb + ((rb + 24) * (unsigned)d.ldr + co));
       }
+      // two phases: every row group's value first (whatever loads the flags ask for are waited for HERE), then the four stores
+      // back to back.  With the store inside the first loop each group's store sat behind the `s_waitcnt vmcnt(0)` of the next
+      // group's (possibly never issued) load -- which drains the store before it too: one memory round trip per group.
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + rr + 8 * i;
@@ -207,11 +211,16 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
                                                          : *reinterpret_cast<const float4*>(Rb + ((unsigned)row * (unsigned)d.ldr + (unsigned)n)));
           v.x = rv.x + d.alpha * v.x; v.y = rv.y + d.alpha * v.y; v.z = rv.z + d.alpha * v.z; v.w = rv.w + d.alpha * v.w;
         }
-        float4* yp = reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n));
         if (ep & SE_EPI_ACCUM) { const float4 o = i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *yp = v;
+        if (i == 0) v0 = v; else if (i == 1) v1 = v; else if (i == 2) v2 = v; else v3 = v;
         if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (rowstats) kept[nt][i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wave * 32 + rr + 8 * i;
+        if (m0 + row >= Mb) continue;
+        *reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n)) = i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3));
       }
     }
     if (ep & SE_EPI_STATS) {      // fold the 8 row-lanes that share this column group, park per-wave partials in LDS
