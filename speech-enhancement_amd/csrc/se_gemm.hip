@@ -735,6 +735,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : ((PRE2 || NPL == 3) ? 1 : K64_OC
 // [64 x NT 64] weights (two planes) in LDS once and loops over row tiles: no barrier and no weight load in the steady state;
 // the A rows of the next tap / next tile (one tap's fragments = 32 VGPRs) are in flight during the 24 MFMAs of the
 // current tap.  LDS 51 KB (+ the epilogue patch 18 KB): two workgroups per CU.
+template <int V> struct WsTap_ { static constexpr int value = V; };
 template <int NT>
 __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, int ngroups) {
   constexpr int SW = NT * 64 + 8, PW = 64 * SW;    // 64 + 8 / 192 + 8 bf16 per W row: 16-B chunks at an odd stride
@@ -775,38 +776,44 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
   const int frag = (lane & 31) * SW + 8 * kg;
   float* cs = patch + wave * 32 * 36;
   const int ntile = d.B * g.tiles;
-  // raw rows of the tap that is split next: row (lane & 31) of the wave's 32 rows, floats 16 ks + 8 kg .. + 7
-  float4 v[4][2];
-  bool vok = false;
-  auto request = [&](int tile, int tp) {
+  // raw rows, one buffer per tap (row lane & 31 of the wave's 32 rows, floats 16 ks + 8 kg .. + 7): a tap's buffer is refilled for
+  // the NEXT tile right after its split -- a whole tile (3 x 24 MFMAs + the epilogue) of distance; one tap ahead (24 MFMAs = 0.3 us)
+  // left the L2 / HBM latency exposed (conv 303 -> see DESIGN)
+  float4 v[NT][4][2];
+  bool vok[NT];
+  auto request = [&](int tile, auto TP) {
+    constexpr int tp = decltype(TP)::value;
     const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
     const int row = m0 + wave * 32 + (lane & 31);
     const int srow = row + (NT == 1 ? 0 : d.df[tp]);
-    vok = row < Mb && srow >= 0 && srow < Mb;       // (zero padding; rows past the end of a ragged last tile)
-    const float* __restrict__ ap = g.A + ((long)b * Mb + (vok ? srow : 0)) * d.lda + d.a_off + 8 * kg;
+    vok[tp] = row < Mb && srow >= 0 && srow < Mb;       // (zero padding; rows past the end of a ragged last tile)
+    const float* __restrict__ ap = g.A + ((long)b * Mb + (vok[tp] ? srow : 0)) * d.lda + d.a_off + 8 * kg;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      v[ks][0] = *reinterpret_cast<const float4*>(ap + 16 * ks);
-      v[ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
+      v[tp][ks][0] = *reinterpret_cast<const float4*>(ap + 16 * ks);
+      v[tp][ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
     }
   };
-  if (grp < ntile) request(grp, 0);
+  if (grp < ntile) {
+    request(grp, WsTap_<0>{});
+    if (NT == 3) { request(grp, WsTap_<NT == 3 ? 1 : 0>{}); request(grp, WsTap_<NT == 3 ? 2 : 0>{}); }
+  }
   for (int tile = grp; tile < ntile; tile += ngroups) {
     const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-    for (int tp = 0; tp < NT; ++tp) {
+    auto tap_step = [&](auto TP) {
+      constexpr int tp = decltype(TP)::value;
       bf16x8 af[4][2];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        float x[8] = {vok ? v[ks][0].x : 0.f, vok ? v[ks][0].y : 0.f, vok ? v[ks][0].z : 0.f, vok ? v[ks][0].w : 0.f,
-                      vok ? v[ks][1].x : 0.f, vok ? v[ks][1].y : 0.f, vok ? v[ks][1].z : 0.f, vok ? v[ks][1].w : 0.f};
+        const bool ok = vok[tp];
+        float x[8] = {ok ? v[tp][ks][0].x : 0.f, ok ? v[tp][ks][0].y : 0.f, ok ? v[tp][ks][0].z : 0.f, ok ? v[tp][ks][0].w : 0.f,
+                      ok ? v[tp][ks][1].x : 0.f, ok ? v[tp][ks][1].y : 0.f, ok ? v[tp][ks][1].z : 0.f, ok ? v[tp][ks][1].w : 0.f};
         split_planes8_h(x, sa, af[ks]);
       }
-      if (tp + 1 < NT) request(tile, tp + 1);
-      else if (tile + ngroups < ntile) request(tile + ngroups, 0);
+      if (tile + ngroups < ntile) request(tile + ngroups, TP);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 bf0[2], bf1[2];
@@ -819,7 +826,9 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
         acc0 = mfma32_<true>(af[ks][0], bf0[1], acc0); acc1 = mfma32_<true>(af[ks][0], bf1[1], acc1);
         acc0 = mfma32_<true>(af[ks][0], bf0[0], acc0); acc1 = mfma32_<true>(af[ks][0], bf1[0], acc1);
       }
-    }
+    };
+    tap_step(WsTap_<0>{});
+    if (NT == 3) { tap_step(WsTap_<NT == 3 ? 1 : 0>{}); tap_step(WsTap_<NT == 3 ? 2 : 0>{}); }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
     gemm_epilogue_vec<false, false, true>(g, acc0, acc1, m0, by, b, cs, 36, 0u, 1.f, red, bias_s);
