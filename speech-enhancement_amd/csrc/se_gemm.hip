@@ -775,14 +775,23 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
   const int kg = lane >> 5;
   const int frag = (lane & 31) * SW + 8 * kg;
   float* cs = patch + wave * 32 * 36;
-  const int ntile = d.B * g.tiles;
+  // every XCD (= grp & 7: round-robin dispatch) sweeps a CONTIGUOUS eighth of the row tiles, its groups side by side: the rows a tap
+  // shifts to (up to +-512 = 4 tiles away) are rows the same L2 holds or has just seen.  (Measured against dealing the tiles
+  // round-robin, where the neighbours of a tile sit on other XCDs: no difference, 275 - 305 us either way -- the MALL absorbs the
+  // re-fetches; kept because it cannot hurt.  PMC: VALU 36 %, MFMA 22 %, waiting 30 % at two waves per SIMD -- the 948 VALU
+  // instructions per tile and wave are the six-fold split of every row: three taps x two column-block workgroups.)
+  const int ntile_all = d.B * g.tiles, gx = ngroups >> 3;            // ngroups is a multiple of 8 (host)
+  const int tpx = (ntile_all + 7) / 8, xbase = (grp & 7) * tpx;
+  const int ntile = min(tpx, ntile_all - xbase);                       // tiles of this XCD (may be <= 0 for the last ones)
+  const int k0 = grp >> 3;
   // raw rows, one buffer per tap (row lane & 31 of the wave's 32 rows, floats 16 ks + 8 kg .. + 7): a tap's buffer is refilled for
-  // the NEXT tile right after its split -- a whole tile (3 x 24 MFMAs + the epilogue) of distance; one tap ahead (24 MFMAs = 0.3 us)
-  // left the L2 / HBM latency exposed (conv 303 -> see DESIGN)
+  // the NEXT tile right after its split -- a whole tile (3 x 24 MFMAs + the epilogue) of distance (one tap ahead measured the
+  // same: the load latency is not what bounds this kernel)
   float4 v[NT][4][2];
   bool vok[NT];
-  auto request = [&](int tile, auto TP) {
+  auto request = [&](int kk, auto TP) {
     constexpr int tp = decltype(TP)::value;
+    const int tile = xbase + kk;
     const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
     const int row = m0 + wave * 32 + (lane & 31);
     const int srow = row + (NT == 1 ? 0 : d.df[tp]);
@@ -794,11 +803,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
       v[tp][ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
     }
   };
-  if (grp < ntile) {
-    request(grp, WsTap_<0>{});
-    if (NT == 3) { request(grp, WsTap_<NT == 3 ? 1 : 0>{}); request(grp, WsTap_<NT == 3 ? 2 : 0>{}); }
+  if (k0 < ntile) {
+    request(k0, WsTap_<0>{});
+    if (NT == 3) { request(k0, WsTap_<NT == 3 ? 1 : 0>{}); request(k0, WsTap_<NT == 3 ? 2 : 0>{}); }
   }
-  for (int tile = grp; tile < ntile; tile += ngroups) {
+  for (int kk = k0; kk < ntile; kk += gx) {
+    const int tile = xbase + kk;
     const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
     f32x16 acc0, acc1;
 #pragma unroll
@@ -813,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
                       ok ? v[tp][ks][1].x : 0.f, ok ? v[tp][ks][1].y : 0.f, ok ? v[tp][ks][1].z : 0.f, ok ? v[tp][ks][1].w : 0.f};
         split_planes8_h(x, sa, af[ks]);
       }
-      if (tile + ngroups < ntile) request(tile + ngroups, TP);
+      if (kk + gx < ntile) request(kk + gx, TP);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         bf16x8 bf0[2], bf1[2];
@@ -1045,7 +1055,8 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       int ngroups = 512 / ncols < 8 ? 8 : 512 / ncols;
       if (const char* e = getenv("SE_WSTAT_GROUPS")) { int v = atoi(e); if (v >= 8) ngroups = v; }
       if ((long)ngroups > (long)d->B * g.tiles) ngroups = d->B * g.tiles;
-      const dim3 wgrid((unsigned)(ncols * ((ngroups + 7) / 8 * 8)));
+      ngroups = (ngroups + 7) / 8 * 8;
+      const dim3 wgrid((unsigned)(ncols * ngroups));
       if (tap3) hipLaunchKernelGGL(conv1d_k64_wstat_kernel<3>, wgrid, block, 0, s, g, ngroups);
       else hipLaunchKernelGGL(conv1d_k64_wstat_kernel<1>, wgrid, block, 0, s, g, ngroups);
       return se_check_launch("se_gemm_tap(W-stationary 1-D)");
