@@ -26,7 +26,9 @@ struct FfArgs {
 // planes and their amax scalars).  LN(X) is scaled by 2^in_sexp (a LayerNorm output is bounded by 7.94 |gamma| + |beta|), the
 // activated hidden block by 2^mid_sexp; H (when stored) and Y are un-scaled exactly.  H == nullptr: H is not stored (the
 // recomputing backward does not read it).
-template <int NPL, bool WPL = false, int NB = 0, bool F16 = false>
+// STH: H is stored (compile time: behind a run-time `if (a.H)` the wait-count pass cannot count the H stores and falls back to
+// draining them before every weight block -- the very thing NB avoids)
+template <int NPL, bool WPL = false, int NB = 0, bool F16 = false, bool STH = true>
 __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 workgroups per CU: VGPR + AGPR <= 256
   static_assert(!F16 || (WPL && NPL == 2), "the scaled split-fp16 kernels read pre-split fp16 planes");
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
         const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
         cs[rl * SP + col] = F16 ? (nt ? acc1[r] * u1 + bb1 : acc0[r] * u1 + bb0) : (nt ? acc1[r] + bb1 : acc0[r] + bb0);
       }
-      if (a.H != nullptr) {
+      if (STH) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int rl = rr + 8 * i;
@@ -1165,7 +1167,9 @@ extern "C" int se_ff_fwd_f16(const float* X, const float* rowstats, const float*
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_fwd: dropout index exceeds 32 bits");
   FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats, sc ? *sc : se_f16_scales{}};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
-  if (precision == 3) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true>), grid, block, 0, as_stream(stream), a);
+  SE_REQUIRE(precision == 3 || H != nullptr, "ff_fwd: only the scaled split-fp16 form runs without storing H");
+  if (precision == 3 && a.H) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, true>), grid, block, 0, as_stream(stream), a);
+  else if (precision == 3) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, false>), grid, block, 0, as_stream(stream), a);
   else if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
   else if (wpl && hid == 256) hipLaunchKernelGGL((ff_fwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);
   else if (wpl) hipLaunchKernelGGL((ff_fwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
