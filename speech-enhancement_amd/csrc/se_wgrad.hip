@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs g) {
     }
     __syncthreads();
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see wgrad_lin_bf16_kernel (no wait in front of every atomic)
   const int col = lane & 31, half = lane >> 5;
   const int c = cb * 64 + wc * 32 + col;
 #pragma unroll
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradArgs g) {
     }
     __syncthreads();
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see wgrad_lin_bf16_kernel (no wait in front of every atomic)
   const int col = lane & 31, half = lane >> 5;
   const int c = cb * 64 + wc * 32 + col;
 #pragma unroll
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
     step(mb, R0);
     if (mb + MR < mend) step(mb + MR, R1);
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see wgrad_lin_bf16_kernel (no wait in front of every atomic)
   const int col = lane & 31, half = lane >> 5;
   const int c = cb * 64 + wc * 32 + col;
 #pragma unroll
@@ -671,6 +674,7 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   const int col = lane & 31, half = lane >> 5;
   const int c = cb * 64 + wc * 32 + col;
   const float oscale = d.alpha * unscale;
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see wgrad_lin_bf16_kernel
 #pragma unroll
   for (int s3 = 0; s3 < 3; ++s3) {
     const int tap = 3 * gi + s3;
@@ -900,6 +904,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3w_f16_kernel(WgradArgs g) {
   const int col = lane & 31, half = lane >> 5;
   const int c = cb * 128 + wave * 32 + col;
   const float oscale = d.alpha * unscale;
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see wgrad_lin_bf16_kernel
   if (active) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1031,6 +1036,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_lin_kernel(WgradArgs g) {
     }
     __syncthreads();
   }
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): see wgrad_lin_bf16_kernel (no wait in front of every atomic)
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -1231,6 +1237,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
     }
     __syncthreads();
   }
+  // one full wait here: the wait-count pass still sees the (guarded, on the last step never issued) prefetch of the next tile as
+  // pending and put an `s_waitcnt vmcnt(0)` in front of EVERY atomic below that reuses one of its destination registers -- which
+  // also waits for the previous atomic: the 48 - 96 atomics of a wave left one L2 round trip apart
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
   const int wn = XW ? 0 : wave, wc = XW ? wave : 0;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
