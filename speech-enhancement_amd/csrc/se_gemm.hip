@@ -718,7 +718,8 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : ((PRE2 || NPL == 3) ? 1 : K64_OC
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
     }
-    if (vec_ep) gemm_epilogue_vec<PRE2, false>(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s, pre);      // (residuals come in `pre`)
+    // (PRE2 == false: the host sends no residual / swish-gradient / accumulate flag here -> the NOLOAD form)
+    if (vec_ep) gemm_epilogue_vec<PRE2, false, !PRE2>(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s, pre);      // (residuals come in `pre`)
     else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, b, cs, 36);
     __syncthreads();
    }
@@ -1065,7 +1066,7 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     static const bool no_wstat_lin = getenv("SE_GEMM_NO_WSTAT_LIN") != nullptr;
     if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && d->precision == 3 && d->w_planes && (d->w_planes % 8) == 0 && d->ldw == 64 &&
         (d->prologue == SE_PRO_NONE || d->prologue == SE_PRO_LN) && (vec_ok || glu_ok) &&
-        !(ep & (SE_EPI_ACCUM | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_STATS)) && Mb >= 256 * 1024 && !no_wstat_lin) {
+        !(ep & (SE_EPI_ACCUM | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_STATS)) && Mb >= 128 * 1024 && !no_wstat_lin) {      // >= 2 tiles per workgroup
       const size_t shw = (size_t)2 * ncols * 64 * 72 * 2 + (size_t)8 * 32 * 36 * 4 + 128 * 4 + (size_t)ncols * 64 * 4;
       if (shw <= 160 * 1024) {
         int nwg = 256;
