@@ -212,16 +212,21 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
           v.x = rv.x + d.alpha * v.x; v.y = rv.y + d.alpha * v.y; v.z = rv.z + d.alpha * v.z; v.w = rv.w + d.alpha * v.w;
         }
         if (ep & SE_EPI_ACCUM) { const float4 o = i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+#ifdef SE_EPI_ONE_PHASE      // (A/B builds: the store inside the first loop, as before)
+        *reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n)) = v;
+#endif
         if (i == 0) v0 = v; else if (i == 1) v1 = v; else if (i == 2) v2 = v; else v3 = v;
         if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (rowstats) kept[nt][i] = v;
       }
+#ifndef SE_EPI_ONE_PHASE
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = wave * 32 + rr + 8 * i;
         if (m0 + row >= Mb) continue;
         *reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n)) = i == 0 ? v0 : (i == 1 ? v1 : (i == 2 ? v2 : v3));
       }
+#endif
     }
     if (ep & SE_EPI_STATS) {      // fold the 8 row-lanes that share this column group, park per-wave partials in LDS
       float sv[8] = {ssum.x, ssum.y, ssum.z, ssum.w, qsum.x, qsum.y, qsum.z, qsum.w};
