@@ -187,8 +187,9 @@ class DiffuSE(nn.Module):
         L.call('se_diff_input_amax', L.ptr(audio), L.ptr(self.input_projection.weight.detach().reshape(-1).contiguous()),
                L.ptr(self.input_projection.bias), L.ptr(dproj[0]), _i(dB), L.ptr(x), L.ptr(y), _i(B), _l(Lp), _i(Cc),
                L.ptr(yam[0:1] if f16 else None), L.stream())
+        st_all = torch.zeros(nl, 2, B, 2 * Cc, 2, device=dev, dtype=torch.float64)      # GroupNorm sums of all layers: ONE fill
         for i, (lay, blk) in enumerate(zip(pk['layers'], self.residual_layers)):
-            st = torch.zeros(B, 2 * Cc, 2, device=dev, dtype=torch.float64)
+            st = st_all[i, 0]
             if f16:
                 d = GM.make_desc(B, 1, Lp, 1, Lp, lay['taps'], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
                                  precision=3, a_amax=yam[i:i + 1])
@@ -201,7 +202,7 @@ class DiffuSE(nn.Module):
             L.call('se_group_finalize', L.ptr(st), _i(B), _i(2 * Cc), _i(0), _i(2 * Cc), _i(16), _d(float(Lp)), L.ptr(gn.weight),
                    L.ptr(gn.bias), L.ptr(ss), _f(gn.eps), L.stream())
             L.call('se_diff_gate', L.ptr(R), L.ptr(ss), L.ptr(cond[i]), L.ptr(y2), _i(B), _l(Lp), _i(Cc), L.stream())
-            st2 = torch.zeros(B, 2 * Cc, 2, device=dev, dtype=torch.float64)
+            st2 = st_all[i, 1]
             if f16:
                 d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
                                   precision=3, a_sexp=13)
