@@ -1294,8 +1294,12 @@ __global__ void weight_amax_kernel(const se_wprep_item* __restrict__ items, int 
     const int o = (int)(idx / ((long)it.Ni * it.Nt));
     m = fmaxf(m, fabsf(it.scale * it.src[o * it.so + i * it.si + t * it.stt]));      // a maximum: the slab reversal is irrelevant
   }
+  // one (guarded) atomic per workgroup, not per wave: the scalar of an item is a single address
+  __shared__ float wm[4];
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) amax_raise_(it.amax, m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) amax_raise_(it.amax, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 
 extern "C" int se_weight_prep(const se_wprep_item* items_dev, int nitems, long max_elems, void* stream) {

@@ -46,11 +46,13 @@ class WeightPlan:
                 if ld % 8:
                     raise L.SeHipError(f'weight plan: {key}: plane rows must be multiples of 8 elements (ld={ld})')
                 if planes == 'f16':        # precision 3: two scaled fp16 planes + the amax scalar they were scaled by
+                    # one scalar per 128-B line: 32 scalars in a line made the atomic maxima of 32 matrices contend for it
+                    # (weight_amax_kernel: 238 us per step for 7 MB of weights)
                     if self._amax is None:
-                        self._amax = torch.zeros(1024, device=self.device, dtype=torch.float32)
-                    if len(self._amax_slot) >= self._amax.numel():
+                        self._amax = torch.zeros(1024 * 32, device=self.device, dtype=torch.float32)
+                    if len(self._amax_slot) >= self._amax.numel() // 32:
                         raise L.SeHipError('weight plan: more than 1024 fp16-plane matrices')
-                    self._amax_slot[key] = len(self._amax_slot)
+                    self._amax_slot[key] = 32 * len(self._amax_slot)
                     self.out[key] = torch.zeros(2, rows, ld, device=self.device, dtype=torch.float16)
                     self.out[key]._se_amax = self._amax[self._amax_slot[key]:self._amax_slot[key] + 1]
                 else:
