@@ -17,14 +17,37 @@ static inline int gs_grid(long n, int per_block) {
   long nb = (n + per_block - 1) / per_block;
   return (int)(nb > 2048 ? 2048 : (nb < 1 ? 1 : nb));
 }
+// reductions that end in block_sum_atomic: every workgroup adds to the SAME one or two doubles -- 2048 workgroups queued 4096
+// atomics on one cache line (spec_loss: 54 us for 33 MB); one workgroup per CU
+static inline int red_grid(long n, int per_block) {
+  long nb = (n + per_block - 1) / per_block;
+  return (int)(nb > 256 ? 256 : (nb < 1 ? 1 : nb));
+}
 
 // ---------------------------------------------------------------------------------------------
 // c[b] = sqrt(L / sum x^2)   (normalize_batch, core/function.py:647-659; inference_gan.py:79-81)
 __global__ __launch_bounds__(256) void clip_scale_kernel(const float* __restrict__ x, float* __restrict__ c, int L) {
   __shared__ double part[4];
   const float* xb = x + (long)blockIdx.x * L;
+  // 16-B loads, four of them requested per trip (one 4-B load per trip left 125 dependent round trips: 52 us at the head of
+  // every step); the tail and a base that is not 16-B aligned (L % 4 != 0) take the scalar loop
   double s = 0.0;
-  for (int i = threadIdx.x; i < L; i += 256) { float v = xb[i]; s += (double)v * v; }
+  int i0 = 0;
+  if ((L & 3) == 0 && (((size_t)xb) & 15) == 0) {
+    const int L4 = L >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(xb);
+    int i = threadIdx.x;
+    for (; i + 768 < L4; i += 1024) {
+      const float4 a = x4[i], b = x4[i + 256], c4 = x4[i + 512], d = x4[i + 768];
+      s += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w);
+      s += ((double)b.x * b.x + (double)b.y * b.y) + ((double)b.z * b.z + (double)b.w * b.w);
+      s += ((double)c4.x * c4.x + (double)c4.y * c4.y) + ((double)c4.z * c4.z + (double)c4.w * c4.w);
+      s += ((double)d.x * d.x + (double)d.y * d.y) + ((double)d.z * d.z + (double)d.w * d.w);
+    }
+    for (; i < L4; i += 256) { const float4 a = x4[i]; s += ((double)a.x * a.x + (double)a.y * a.y) + ((double)a.z * a.z + (double)a.w * a.w); }
+    i0 = L;
+  }
+  for (int i = i0 + threadIdx.x; i < L; i += 256) { float v = xb[i]; s += (double)v * v; }
   s = wave_sum_d(s);
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -202,20 +225,32 @@ __global__ void mask_tail_kernel(const float* __restrict__ U, int ldu, const flo
   M[idx] = v >= 0.f ? v : v * slope[idx % F];
 }
 // backward: dU (channel 0 of an ld-4 buffer, channels 1..3 zeroed), dwb[2] += , dslope[F] +=
+// A thread owns ONE frequency column f of a run of rows: the PReLU(201) slope gradient is summed in a register and leaves with one
+// atomic per (thread, run).  (One atomic per element with v < 0 -- half a million on 201 addresses in 7 cache lines -- made this
+// 4 MB kernel take 152 us at the head of the generator backward.)
 __global__ __launch_bounds__(256) void mask_tail_bwd_kernel(const float* __restrict__ U, int ldu, const float* __restrict__ wb,
                                                             const float* __restrict__ slope, const float* __restrict__ dM,
                                                             float* __restrict__ dU, double* __restrict__ dwb,
-                                                            float* __restrict__ dslope, long n, int F) {
+                                                            float* __restrict__ dslope, long n, int F, int rows_per_block) {
   double sw = 0.0, sb = 0.0;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
-    int f = (int)(idx % F);
-    float u = U[idx * ldu];
-    float v = u * wb[0] + wb[1];
-    float dm = dM[idx];
-    float dv = v >= 0.f ? dm : dm * slope[f];
-    if (v < 0.f) atomicAdd(&dslope[f], dm * v);
-    sw += (double)dv * u; sb += dv;
-    *reinterpret_cast<float4*>(dU + idx * 4) = make_float4(dv * wb[0], 0.f, 0.f, 0.f);
+  const long nrows = n / F;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < nrows ? r0 + rows_per_block : nrows;
+  const float w0 = wb[0], w1 = wb[1];
+  for (int f = blockIdx.x * 256 + threadIdx.x; f < F; f += gridDim.x * 256) {
+    const float sl = slope[f];
+    float ds = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const long idx = r * F + f;
+      const float u = U[idx * ldu];
+      const float v = u * w0 + w1;
+      const float dm = dM[idx];
+      const float dv = v >= 0.f ? dm : dm * sl;
+      ds += v < 0.f ? dm * v : 0.f;
+      sw += (double)dv * u; sb += dv;
+      *reinterpret_cast<float4*>(dU + idx * 4) = make_float4(dv * w0, 0.f, 0.f, 0.f);
+    }
+    if (ds != 0.f) atomicAdd(&dslope[f], ds);
   }
   block_sum_atomic(sw, dwb);
   block_sum_atomic(sb, dwb + 1);
@@ -299,6 +334,7 @@ __global__ void gate_tanh_bwd_kernel(const float* __restrict__ Y, const float* _
 __global__ __launch_bounds__(256) void spec_loss_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
                                                         double* __restrict__ sums, long n) {
   double sm = 0.0, sr = 0.0;
+#pragma unroll 4
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
     float4 a = *reinterpret_cast<const float4*>(A + idx * 4);
     float4 b = *reinterpret_cast<const float4*>(Bp + idx * 4);
@@ -328,6 +364,7 @@ __global__ void spec_loss_bwd_kernel(const float* __restrict__ A, const float* _
 __global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ a, long lda, const float* __restrict__ b,
                                                       long ldb, double* __restrict__ sums, int L, long n) {
   double s = 0.0;
+#pragma unroll 4
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
     long r = idx / L; int i = (int)(idx - r * L);
     s += fabsf(a[r * lda + i] - b[r * ldb + i]);
@@ -564,8 +601,11 @@ extern "C" int se_mask_tail(const float* U, int ldu, const float* wb, const floa
 extern "C" int se_mask_tail_bwd(const float* U, int ldu, const float* wb, const float* slope, const float* dM, float* dU,
                                 double* dwb, float* dslope, long n, int F, void* stream) {
   SE_REQUIRE(U && wb && slope && dM && dU && dwb && dslope && n > 0, "mask_tail_bwd: bad arguments");
-  hipLaunchKernelGGL(mask_tail_bwd_kernel, dim3(gs_grid(n, 256)), dim3(256), 0, as_stream(stream), U, ldu, wb, slope, dM,
-                     dU, dwb, dslope, n, F);
+  SE_REQUIRE(F > 0 && n % F == 0, "mask_tail_bwd: n must be a whole number of rows of F");
+  const long nrows = n / F;
+  const int rpb = nrows >= 4096 ? 48 : 1;                 // rows per workgroup run (one slope atomic per thread and run)
+  hipLaunchKernelGGL(mask_tail_bwd_kernel, dim3((unsigned)((F + 255) / 256), (unsigned)((nrows + rpb - 1) / rpb)), dim3(256), 0,
+                     as_stream(stream), U, ldu, wb, slope, dM, dU, dwb, dslope, n, F, rpb);
   return se_check_launch("se_mask_tail_bwd");
 }
 extern "C" int se_glu_bwd(const float* Z, const float* dU, float* dZ, long M, int H, void* stream) {
@@ -594,7 +634,7 @@ extern "C" int se_gate_tanh_bwd(const float* Y, const float* dG, float* dY, long
 }
 extern "C" int se_spec_loss(const float* A, const float* Bp, double* sums, long n, void* stream) {
   SE_REQUIRE(A && Bp && sums && n > 0, "spec_loss: bad arguments");
-  hipLaunchKernelGGL(spec_loss_kernel, dim3(gs_grid(n, 256)), dim3(256), 0, as_stream(stream), A, Bp, sums, n);
+  hipLaunchKernelGGL(spec_loss_kernel, dim3(red_grid(n, 256)), dim3(256), 0, as_stream(stream), A, Bp, sums, n);
   return se_check_launch("se_spec_loss");
 }
 extern "C" int se_spec_loss_bwd(const float* A, const float* Bp, float* dA, const float* up, float cmag, float cri, long n,
@@ -606,7 +646,7 @@ extern "C" int se_spec_loss_bwd(const float* A, const float* Bp, float* dA, cons
 extern "C" int se_l1_loss(const float* a, long lda, const float* b, long ldb, double* sums, long rows, int L, void* stream) {
   SE_REQUIRE(a && b && sums && rows > 0 && L > 0, "l1_loss: bad arguments");
   long n = rows * L;
-  hipLaunchKernelGGL(l1_loss_kernel, dim3(gs_grid(n, 256)), dim3(256), 0, as_stream(stream), a, lda, b, ldb, sums, L, n);
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(red_grid(n, 256)), dim3(256), 0, as_stream(stream), a, lda, b, ldb, sums, L, n);
   return se_check_launch("se_l1_loss");
 }
 extern "C" int se_l1_loss_bwd(const float* a, long lda, const float* b, long ldb, float* da, const float* up, float ck,
