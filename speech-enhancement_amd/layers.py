@@ -551,8 +551,8 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     else:
         h = O.dwconv31(u, Wdw, P[f'{p}.conv.net.4.conv.bias'], geom)
         mr, ss = O.bn_eval_scale(P[f'{p}.conv.net.5.running_mean'], P[f'{p}.conv.net.5.running_var'], g_bn, b_bn)
-    sc = ss[0, :, 0].contiguous()
-    sh = ss[0, :, 1].contiguous()
+    sst = ss[0].t().contiguous()            # [2][128]: scale row, shift row (one small launch, not two)
+    sc, sh = sst[0], sst[1]
     y3 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     # Swish(BatchNorm(h)) is bounded like the FF hidden activations (the weight gradient of this layer uses the same exponent)
     Wpw2 = _w(P, (f'{p}.conv.net.7.weight', 'lin'), lambda: P[f'{p}.conv.net.7.weight'].view(64, 128))
