@@ -62,6 +62,28 @@ def _ptr_array(ts):
     return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
 
 
+def _zeros_like_many(ts):
+    """zero tensors shaped like every tensor of `ts` (None stays None), carved out of ONE zero-filled buffer: the backward functions
+    below need a dozen small zero-initialised outputs each -- a dozen fill launches per call otherwise (16-B aligned views)"""
+    live = [t for t in ts if t is not None]
+    if not live:
+        return [None for _ in ts]
+    offs, o = [], 0
+    for t in live:
+        offs.append(o)
+        o += (t.numel() + 3) // 4 * 4
+    flat = torch.zeros(o, device=live[0].device, dtype=torch.float32)
+    it = iter(zip(live, offs))
+    out = []
+    for t in ts:
+        if t is None:
+            out.append(None)
+        else:
+            t_, o_ = next(it)
+            out.append(flat[o_:o_ + t_.numel()].view(t_.shape))
+    return out
+
+
 def spectral_weights(holders, train, detach=False):
     """the spectrally-normalised weights of several _SNHolder layers from ONE launch (se_spectral_norm)"""
     Ws = [h.weight_orig.detach() if detach else h.weight_orig for h in holders]
@@ -83,18 +105,21 @@ class _SpectralNormFn(torch.autograd.Function):
         L.call('se_spectral_norm', C.c_int(n), _ptr_array(Wc), _ptr_array(us), _ptr_array(vs), _ptr_array(Wn), ha, wa,
                L.ptr(sigma), C.c_int(int(train)), C.c_float(1e-12), L.stream())
         # the hook treats the (updated) u, v as constants of the graph
-        ctx.save_for_backward(sigma, *Wn, *[u.clone() for u in us], *[v.clone() for v in vs])
+        uvc = torch.cat([t.reshape(-1) for t in (*us, *vs)])       # ONE copy of the 2 n small vectors (twelve clones before)
+        ctx.save_for_backward(sigma, uvc, *Wn)
         ctx.n, ctx.hw = n, (hs, ws_)
+        ctx.uv_sizes = [t.numel() for t in (*us, *vs)]
         return tuple(Wn)
 
     @staticmethod
     def backward(ctx, *dWn):
         n = ctx.n
-        sigma, *rest = ctx.saved_tensors
-        Wn, us, vs = rest[:n], rest[n:2 * n], rest[2 * n:]
+        sigma, uvc, *Wn = ctx.saved_tensors
+        uvs = list(torch.split(uvc, ctx.uv_sizes))
+        us, vs = uvs[:n], uvs[n:]
         hs, ws_ = ctx.hw
         need = ctx.needs_input_grad[2:2 + n]
-        dW = [torch.zeros_like(Wn[i]) if need[i] and dWn[i] is not None else None for i in range(n)]
+        dW = _zeros_like_many([Wn[i] if need[i] and dWn[i] is not None else None for i in range(n)])
         if any(d is not None for d in dW):
             dc = [dWn[i].contiguous() if dW[i] is not None else None for i in range(n)]
             L.call('se_spectral_norm_bwd', C.c_int(n), _ptr_array(dc), _ptr_array(Wn), _ptr_array(us), _ptr_array(vs),
@@ -129,8 +154,8 @@ class _DiscTailFn(torch.autograd.Function):
         B, To, Fo, _ = ctx.shape
         need = ctx.needs_input_grad
         dA = torch.zeros(ctx.shape, device=dout.device, dtype=torch.float32) if need[0] else None
-        g = lambda i, like: torch.zeros_like(like) if need[i] else None
-        dW1, db1, ds1, dW2, db2, dss = g(1, W1), g(2, b1), g(4, slope1), g(5, W2), g(6, b2), g(7, sslope)
+        dW1, db1, ds1, dW2, db2, dss = _zeros_like_many([t if need[i] else None for i, t in
+                                                          ((1, W1), (2, b1), (4, slope1), (5, W2), (6, b2), (7, sslope))])
         L.call('se_disc_tail_bwd', L.ptr(dout.contiguous().view(-1)), L.ptr(ws), C.c_int(B), C.c_int(To * Fo), L.ptr(W1),
                L.ptr(mask), L.ptr(slope1), L.ptr(W2), L.ptr(sslope), C.c_float(ctx.beta), L.ptr(dA), L.ptr(dW1), L.ptr(db1),
                L.ptr(ds1), L.ptr(dW2), L.ptr(db2), L.ptr(dss), L.stream())
@@ -169,10 +194,8 @@ class _DConvStackFn(torch.autograd.Function):
     def backward(ctx, dout):
         Ws, gs, bs, sl = ctx.wts[0:4], ctx.wts[4:8], ctx.wts[8:12], ctx.wts[12:16]
         B = ctx.B
-        dW = [torch.zeros_like(w) for w in Ws]
-        dg = [torch.zeros_like(t) for t in gs]
-        db = [torch.zeros_like(t) for t in bs]
-        ds = [torch.zeros_like(t) for t in sl]
+        zz = _zeros_like_many([*Ws, *gs, *bs, *sl])
+        dW, dg, db, ds = zz[0:4], zz[4:8], zz[8:12], zz[12:16]
         dy = dout.contiguous()
         dxy = None
         for i in (3, 2, 1, 0):
