@@ -547,7 +547,11 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
         rv = buffers[f'{p}.conv.net.5.running_var'] if buffers is not None else None
         mr, ss = O.norm_finalize(bnstats, g_bn, b_bn, 1, 128, count, running_mean=rm, running_var=rv, momentum=0.1)
         if buffers is not None:
-            buffers[f'{p}.conv.net.5.num_batches_tracked'] += 1
+            nbt = buffers.get('_nbt_pending')            # tscnet_fwd: the eight counters are incremented with ONE launch
+            if nbt is not None:
+                nbt.append(buffers[f'{p}.conv.net.5.num_batches_tracked'])
+            else:
+                buffers[f'{p}.conv.net.5.num_batches_tracked'] += 1
     else:
         h = O.dwconv31(u, Wdw, P[f'{p}.conv.net.4.conv.bias'], geom)
         mr, ss = O.bn_eval_scale(P[f'{p}.conv.net.5.running_mean'], P[f'{p}.conv.net.5.running_var'], g_bn, b_bn)
@@ -796,6 +800,9 @@ def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed
     tok = x.view(B * T * Fp, 64)
     ctx['tscb'] = []
     st_tok = None                  # row statistics of `tok`, handed from one block's post_norm to the next block's first LayerNorm
+    if buffers is not None and train:
+        buffers = dict(buffers)
+        buffers['_nbt_pending'] = []
     for i in range(1, 5):
         tok, c1 = conformer_fwd(P, f'TSCB_{i}.time_conformer', tok, B, T, Fp, 'time', train, dp, buffers, drop,
                                 site_seed(seed, 100 + 2 * i), st_in=st_tok)
@@ -804,6 +811,8 @@ def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed
                                 site_seed(seed, 101 + 2 * i), st_in=st_tok)
         st_tok = c2.pop('out_stats', None)
         ctx['tscb'].append((c1, c2))
+    if buffers is not None and buffers.get('_nbt_pending'):
+        torch._foreach_add_(buffers['_nbt_pending'], 1)
     # the two decoders are independent branches (models/generator.py:154-156): the complex decoder runs on a second stream
     with GM.branch_stream(tok) as br:
         cplx, ctx['cplx'] = complex_decoder_fwd(P, tok, B, T, Fp)
