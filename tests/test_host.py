@@ -246,3 +246,22 @@ def test_zero_arena_bookkeeping_on_cpu():
     big2 = ar.take((4096,), torch.float32, dev)
     assert a2.eq(0).all() and big2.eq(0).all() and ar.missed == 0
     ar.end()
+
+
+def test_zero_outputs_of_the_discriminator_backward_share_one_buffer():
+    """discriminator._zeros_like_many: shapes kept, None kept, every view zero, 16-byte aligned and disjoint (the backward kernels
+    accumulate into them with atomics)"""
+    import torch
+    from speech_enhancement_amd import discriminator as DM
+    like = [torch.empty(16, 2, 4, 4), None, torch.empty(1), torch.empty(201), None, torch.empty(64, 33)]
+    out = DM._zeros_like_many(like)
+    assert [o is None for o in out] == [t is None for t in like]
+    live = [(o, t) for o, t in zip(out, like) if t is not None]
+    assert all(o.shape == t.shape and o.dtype == torch.float32 and float(o.abs().sum()) == 0.0 for o, t in live)
+    assert all(o.data_ptr() % 16 == 0 and o.is_contiguous() for o, _ in live)
+    spans = sorted((o.data_ptr(), o.data_ptr() + 4 * o.numel()) for o, _ in live)
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:]))
+    for i, (o, _) in enumerate(live):
+        o.fill_(i + 1.0)
+    assert all(float(o.min()) == float(o.max()) == i + 1.0 for i, (o, _) in enumerate(live))
+    assert DM._zeros_like_many([None, None]) == [None, None]
