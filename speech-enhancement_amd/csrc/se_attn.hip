@@ -1517,6 +1517,8 @@ __global__ __launch_bounds__(256) void attn_de_reduce_items_kernel(const float* 
   }
 }
 
+#include "se_attn_bwd4.h"
+
 // =====================================================================================================================
 // v3 forward: the fwd2 structure (one workgroup per (sequence, head), 32- or 16-query blocks dealt to the waves, online
 // softmax, sliding rel-pos window skewed through wave-private LDS) on the packed split-bf16 products of the v3 backward:
@@ -1948,6 +1950,35 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
     const long items = (long)nseq * 4;
     int e;
+    // round 4: the workgroup-cooperative kernel (se_attn_bwd4.h) for every shape its two instantiations cover; SE_ATTN_BWD4=0: v3
+    static const int bwd4_mode = getenv("SE_ATTN_BWD4") ? atoi(getenv("SE_ATTN_BWD4")) : 3;
+    if (f16) {
+      const int nkt = (n + 15) / 16;
+      // <4 waves, 6 key tiles, 3 classes> (two workgroups per CU) for 8 <= nkt <= 21 (n = 321: 5+5+5+6 key tiles), <4, 2, 2> (three
+      // per CU) up to nkt = 7 (n = 101)
+      const bool small = nkt <= 7;
+      const AttnBwd4Plan pl = small ? attn_bwd4_plan(nkt, 4, 1) : attn_bwd4_plan(nkt, 4, 3);
+      int kmax = 0;
+      for (int w4 = 0; w4 < 8; ++w4) kmax = pl.cnt[w4] > kmax ? pl.cnt[w4] : kmax;
+      const bool fits = pl.M > 0 && (small ? kmax <= 2 : (kmax <= 6 && nkt <= 21));
+      const size_t shr = small ? attn_bwd4_lds<4, 7>(nkt) : attn_bwd4_lds<4, 21>(nkt);
+      if (fits && (bwd4_mode & (small ? 1 : 2))) {
+        if (phase & 1) {
+          if (small) {
+            static unsigned raised_s = 0;
+            SE_REQUIRE(se_raise_lds((const void*)attn_bwd4_kernel<4, 2, 1, 7, 3>, shr, &raised_s), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+            hipLaunchKernelGGL((attn_bwd4_kernel<4, 2, 1, 7, 3>), dim3(items), dim3(256), shr, s, b, pl);
+          } else {
+            static unsigned raised_b = 0;
+            SE_REQUIRE(se_raise_lds((const void*)attn_bwd4_kernel<4, 6, 3, 21, 2>, shr, &raised_b), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+            hipLaunchKernelGGL((attn_bwd4_kernel<4, 6, 3, 21, 2>), dim3(items), dim3(256), shr, s, b, pl);
+          }
+        }
+        if (phase & 2) hipLaunchKernelGGL(attn_de_reduce_items_kernel, dim3(2 * nkt, cdiv(items, 256)), dim3(256), 0, s, b.dEs, dE, items, nkt,
+                                          b.maxpos, b.R);
+        return se_check_launch("se_attn_bwd");
+      }
+    }
     if (f16) e = kt3 == 7 ? launch_bwd3<7, false, true>(b, items, s, dE, phase) : launch_bwd3<6, true, true>(b, items * 4, s, dE, phase);
     else e = kt3 == 7 ? launch_bwd3<7, false>(b, items, s, dE, phase) : launch_bwd3<6, true>(b, items * 4, s, dE, phase);
     if (e) return e;

@@ -648,7 +648,12 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
                       leaf=None if _os.environ.get('SE_ATTN_DE_MAIN') == '1' else GM.leaf_stream,
                       qkv_amax=qkv_amax, do_amax=do_amax, dqkv_amax=_amax(dev) if (qkv_amax is not None and _os.environ.get('SE_NO_QKVT16') != '1') else None)
     dq_amax = getattr(dqkv, '_se_amax', None)
-    WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT16' if dq_amax is not None else 'qkvT'), lambda: _T(Wqkv))
+    # plan keys in order of preference: the fp16 planes exist only under LINEAR_PRECISION 3 + fp16 attention ('qkvT16'); with the
+    # bf16 linear kernels next to the fp16 attention backward the six-product planes ('qkvT') serve; no plan: fp32 from the parameters
+    WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT16'), lambda: None) if dq_amax is not None else None
+    if WqkvT is None:
+        WqkvT = _w(P, (f'{p}.attn.fn', 'qkvT'),
+                   lambda: _T(torch.cat([P[f'{p}.attn.fn.to_q.weight'], P[f'{p}.attn.fn.to_kv.weight']], 0)))
     if WqkvT.dtype != torch.float16:
         dq_amax = None
     gq, gkv = G[f'{p}.attn.fn.to_q.weight'], G[f'{p}.attn.fn.to_kv.weight']
