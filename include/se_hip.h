@@ -115,13 +115,13 @@ int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W, const flo
  * scalars: an input amax must be >= max |operand| (raised by the kernel that produced the operand, or by se_weight_prep for
  * weight planes); output amax scalars must be zero (or a running maximum) on entry and are raised with one atomic per wave */
 typedef struct {
-  const float* in_amax;  /* first A operand when it is a gradient (se_ff_bwd_dgrad_f16: dY); NULL: 2^(13 - in_sexp) is assumed */
+  const float* in_amax;  /* first A operand: se_ff_bwd_dgrad_f16: max |dY|; se_ff_fwd_f16: a bound of |LN(X)| (se_act_bounds); NULL: in_sexp */
   int in_sexp;           /* static exponent of a bounded first A operand (LayerNorm output: 6 -> |x| < 1023)                    */
   int mid_sexp;          /* static exponent of the in-kernel second A operand of se_ff_fwd_f16 (Swish(H) * mask: 3 -> < 8191)  */
   const float* wa_amax;  /* scalar of the first weight matrix's fp16 planes (W1 / W2T)                                       */
   const float* wb_amax;  /* the same for the second one (W2 / W1T)                                                            */
   float* out_amax;       /* se_ff_bwd_dgrad_f16: raised to max |dX|; may be NULL                                              */
-  float* mid_amax;       /* se_ff_bwd_dgrad_f16: raised to max |dZ|; may be NULL                                              */
+  float* mid_amax;       /* se_ff_bwd_dgrad_f16: raised to max |dZ|; se_ff_fwd_f16: READ as a bound of |Swish(H) * mask| (NULL: mid_sexp) */
 } se_f16_scales;
 
 /* Fused feed-forward forward of a Conformer block (models/conformer.py:53-71,128-145: Scale(0.5, PreNorm(FeedForward))):
@@ -235,6 +235,23 @@ int se_repack(const float* src, float* dst, int No, int Nt, int Ni, long so, lon
 int se_unpack(const float* src, float* dst, int No, int Nt, int Ni, long so, long stt, long si,
               int rev, int accumulate, void* stream);
 
+/* ---- operand scales of bounded / copied activations (csrc/se_elem.hip; round 4) ------------------------------------- */
+/* dst[r][0..C) = src[r][0..C) for `rows` rows (strides lds / ldd floats, C % 4 == 0) and *amax_out (zero-filled device scalar, may be
+ * NULL) raised to max |src|: the slab copy at a decoder's entry (models/generator.py:84,113) */
+int se_copy_cols_amax(const float* src, int lds, float* dst, int ldd, long rows, int C, float* amax_out, void* stream);
+/* proven bound of a normalised activation from the current parameters:
+ *   b = (k max|g| + max|b|) max(1, max|alpha|);  W: b = b max_j sum_i |W[j][i]| + max|wb|;  b *= post;  *out = b
+ * k = kconst (ksel 0: LayerNorm(64): sqrt(63)), or the run-time arguments k1 / k2 of se_act_bounds (ksel 1 / 2: sqrt(count - 1)
+ * of a BatchNorm / InstanceNorm whose count is known per call).  One launch per forward over a device-resident item table. */
+typedef struct {
+  const float* g; const float* b; const float* alpha;   /* gamma [n], beta [n] or NULL, PReLU slopes [na] or NULL */
+  const float* W; const float* wb;                      /* optional linear layer behind the norm: W [rows][cols], bias [rows] or NULL */
+  int n, na, rows, cols, ksel;
+  float kconst, post;
+  float* out;                                           /* one item per scalar */
+} se_bound_item;
+int se_act_bounds(const se_bound_item* items_dev, int nitems, float k1, float k2, void* stream);
+
 /* ---- normalisation (csrc/se_norms.hip) ------------------------------------------------------ */
 /* per-row (mean, rstd) over C=64 channels: the statistics of every nn.LayerNorm(64) that feeds a GEMM
  * prologue (models/conformer.py:67,162) */
@@ -275,6 +292,11 @@ int se_affine_prelu(const float* X, int ldx, int x_off, const float* ss, const f
 int se_inorm_prelu_fwd(const float* X, int ldx, int x_off, const double* stats, const float* g, const float* beta,
                        const float* slope, float* Y, int ldy, int y_off, float* mr, int B, long P, int C, double count,
                        float eps, void* stream);
+/* the same, raising the zero-filled device scalar *amax_out (may be NULL) to max |Y|: the operand scale (se_gemm_desc.a_amax) of the
+ * scaled split-fp16 convolutions that read Y -- measured, so that no promise about gamma / beta is needed */
+int se_inorm_prelu_fwd_amax(const float* X, int ldx, int x_off, const double* stats, const float* g, const float* beta,
+                       const float* slope, float* Y, int ldy, int y_off, float* mr, int B, long P, int C, double count,
+                       float eps, float* amax_out, void* stream);
 /* backward of Y = act(xhat*g + beta), act = PReLU (act=0; slope NULL = identity) or Swish (act=1), for
  * instance (per_batch=1) or batch (per_batch=0; BatchNorm1d+Swish, conformer.py:167-168) statistics;
  * red: workspace double[nb][C][3]; dg/dbeta/dslope accumulate.  phase bits: 1 = reduction, 4 = parameter

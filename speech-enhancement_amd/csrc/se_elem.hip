@@ -929,3 +929,80 @@ extern "C" int se_disc_tail_bwd(const float* dout, const float* ws, int B, int P
                      dA, dW1, db1, dslope1, dW2, db2, dsslope);
   return se_check_launch("se_disc_tail_bwd");
 }
+
+
+// ---- operand scales of the scaled split-fp16 kernels that are NOT gradients (round 4) -------------------------------------------
+// dst[r][0 .. C) = src[r][0 .. C) (row strides lds / ldd, C % 4 == 0), raising *amax_out to max |src|: the slab copy at a decoder's
+// entry (models/generator.py:84,113: the dense block's input, the TSCB output, has no bound by construction) hands the skip
+// stack its operand scale
+__global__ __launch_bounds__(256) void copy_cols_amax_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                                             long rows, int C4, float* __restrict__ amax_out) {
+  float m = 0.f;
+  const long total = rows * C4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / C4;
+    const int q = (int)(i - r * C4);
+    const float4 v = *reinterpret_cast<const float4*>(src + r * lds + 4 * q);
+    *reinterpret_cast<float4*>(dst + r * ldd + 4 * q) = v;
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (amax_out) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) amax_raise_(amax_out, m);
+  }
+}
+extern "C" int se_copy_cols_amax(const float* src, int lds, float* dst, int ldd, long rows, int C, float* amax_out, void* stream) {
+  SE_REQUIRE(src && dst && rows > 0 && C > 0 && (C % 4) == 0 && (lds % 4) == 0 && (ldd % 4) == 0 && lds >= C && ldd >= C,
+             "copy_cols_amax: bad arguments (C=%d lds=%d ldd=%d)", C, lds, ldd);
+  const long total = rows * (C / 4);
+  long nb = (total + 256 * 8 - 1) / (256 * 8);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(copy_cols_amax_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), src, lds, dst, ldd, rows, C / 4, amax_out);
+  return se_check_launch("se_copy_cols_amax");
+}
+
+// PROVEN bounds of normalised activations from the CURRENT parameters, one workgroup per item, every step (weights.WeightPlan):
+//   b = (k max |gamma| + max |beta|) * max(1, max |slope|)        a normalised row / plane: |x_hat| <= sqrt(count - 1) = k
+//   W != NULL:  b = b * max_j sum_i |W[j][i]| + max |wb|           the linear layer behind it (feed-forward: H = W1 LN(x) + b1)
+//   b *= post                                                     (Swish(h) <= |h|; dropout keep factor)
+// stored to *out (one item per scalar).  k = kconst, or the kernel argument k1 / k2 (counts
+// known only at run time: BatchNorm over the tokens of the batch).
+__global__ __launch_bounds__(256) void act_bounds_kernel(const se_bound_item* __restrict__ items, float k1, float k2) {
+  const se_bound_item it = items[blockIdx.x];
+  __shared__ float red[3][4];
+  const int tid = threadIdx.x;
+  float mg = 0.f, mb = 0.f, ma = 1.f, ml = 0.f, mw = 0.f;
+  for (int i = tid; i < it.n; i += 256) { mg = fmaxf(mg, fabsf(it.g[i])); if (it.b) mb = fmaxf(mb, fabsf(it.b[i])); }
+  if (it.alpha) for (int i = tid; i < it.na; i += 256) ma = fmaxf(ma, fabsf(it.alpha[i]));
+  if (it.W) {
+    for (int j = tid; j < it.rows; j += 256) {
+      float l1 = 0.f;
+      for (int i = 0; i < it.cols; ++i) l1 += fabsf(it.W[(long)j * it.cols + i]);
+      ml = fmaxf(ml, l1);
+      if (it.wb) mw = fmaxf(mw, fabsf(it.wb[j]));
+    }
+  }
+  float v[5] = {mg, mb, ma, ml, mw};
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    v[q] = wave_max(v[q]);
+    __syncthreads();
+    if ((tid & 63) == 0) red[0][tid >> 6] = v[q];
+    __syncthreads();
+    v[q] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  }
+  if (tid == 0) {
+    const float k = it.ksel == 1 ? k1 : (it.ksel == 2 ? k2 : it.kconst);
+    float bnd = (k * v[0] + v[1]) * v[2];
+    if (it.W) bnd = bnd * v[3] + v[4];
+    bnd *= it.post;
+    // (one rounding up: the scale only has to be >= the true maximum).  A plain store: one item per scalar, and no window in
+    // which a kernel of another stream could read a zeroed scalar
+    *it.out = bnd * 1.0000002f;
+  }
+}
+extern "C" int se_act_bounds(const se_bound_item* items_dev, int nitems, float k1, float k2, void* stream) {
+  SE_REQUIRE(items_dev && nitems > 0 && nitems <= 65535, "act_bounds: bad arguments");
+  hipLaunchKernelGGL(act_bounds_kernel, dim3((unsigned)nitems), dim3(256), 0, as_stream(stream), items_dev, k1, k2);
+  return se_check_launch("se_act_bounds");
+}

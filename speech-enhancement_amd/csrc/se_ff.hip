@@ -50,8 +50,11 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
   if (F16) {
     f16_clamp_mode_();
     const int e1 = operand_sexp_(a.sc.wa_amax, 0), e2 = operand_sexp_(a.sc.wb_amax, 0);
-    s_in = exp2i_(a.sc.in_sexp); s_mid = exp2i_(a.sc.mid_sexp);
-    u1 = exp2i_(-a.sc.in_sexp - e1); u2 = exp2i_(-a.sc.mid_sexp - e2);
+    // (round 4) in_amax / mid_amax, when given, are device scalars >= max |LN(X)| / max |Swish(H) * mask| -- proven bounds from the
+    // current parameters (se_act_bounds) -- and replace the static exponents: no promise about gamma or W1 is left to break
+    const int ein = operand_sexp_(a.sc.in_amax, a.sc.in_sexp), emid = operand_sexp_(a.sc.mid_amax, a.sc.mid_sexp);
+    s_in = exp2i_(ein); s_mid = exp2i_(emid);
+    u1 = exp2i_(-ein - e1); u2 = exp2i_(-emid - e2);
   }
 
   bf16x8 af1[4][NPL];

@@ -227,9 +227,10 @@ constexpr int NB_U = 4;      // lines (line pairs) in flight per lane in the nor
 __global__ __launch_bounds__(256) void inorm_prelu_fwd_kernel(
     const float* __restrict__ X, int ldx, int x_off, const double* __restrict__ stats, const float* __restrict__ g,
     const float* __restrict__ beta, const float* __restrict__ slope, float* __restrict__ Y, int ldy, int y_off,
-    float* __restrict__ mr, long P, int C, double count, float eps) {
+    float* __restrict__ mr, long P, int C, double count, float eps, float* __restrict__ amax_out) {
   ChanIter it(C);
   const int b = blockIdx.y;
+  float ymax = 0.f;                  // amax_out: max |Y| -- the operand scale of the scaled split-fp16 convolutions that read Y
   // one thread per channel does the fp64 arithmetic (two divisions, a square root, a reciprocal), the others pick the result up
   // from LDS: done by every lane for its 4 channels it was 256 / (C / 4) times redundant and cost more than the finalize launch
   __shared__ float scs[256], shs[256];
@@ -272,8 +273,15 @@ __global__ __launch_bounds__(256) void inorm_prelu_fwd_kernel(
       float u[4] = {v[k].x * sc[0] + sh[0], v[k].y * sc[1] + sh[1], v[k].z * sc[2] + sh[2], v[k].w * sc[3] + sh[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) u[j] = u[j] >= 0.f ? u[j] : u[j] * sl[j];
-      if (p < p_end) st4_stream_(Yb + p * ldy, make_float4(u[0], u[1], u[2], u[3]));
+      if (p < p_end) {
+        st4_stream_(Yb + p * ldy, make_float4(u[0], u[1], u[2], u[3]));
+        ymax = fmaxf(fmaxf(ymax, fmaxf(fabsf(u[0]), fabsf(u[1]))), fmaxf(fabsf(u[2]), fabsf(u[3])));
+      }
     }
+  }
+  if (amax_out) {
+    ymax = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0) amax_raise_(amax_out, ymax);
   }
 }
 
@@ -504,6 +512,12 @@ extern "C" int se_affine_prelu(const float* X, int ldx, int x_off, const float* 
 extern "C" int se_inorm_prelu_fwd(const float* X, int ldx, int x_off, const double* stats, const float* g, const float* beta,
                                   const float* slope, float* Y, int ldy, int y_off, float* mr, int B, long P, int C,
                                   double count, float eps, void* stream) {
+  return se_inorm_prelu_fwd_amax(X, ldx, x_off, stats, g, beta, slope, Y, ldy, y_off, mr, B, P, C, count, eps, nullptr, stream);
+}
+
+extern "C" int se_inorm_prelu_fwd_amax(const float* X, int ldx, int x_off, const double* stats, const float* g, const float* beta,
+                                       const float* slope, float* Y, int ldy, int y_off, float* mr, int B, long P, int C,
+                                       double count, float eps, float* amax_out, void* stream) {
   SE_REQUIRE(X && stats && g && beta && Y && mr && B > 0 && P > 0 && count > 0 && chan_ok(C), "inorm_prelu_fwd: bad arguments (C=%d)", C);
   SE_REQUIRE((ldx % 4) == 0 && (x_off % 4) == 0 && (ldy % 4) == 0 && (y_off % 4) == 0, "inorm_prelu_fwd: alignment");
   const int psub = 256 / (C / 4);
@@ -511,7 +525,7 @@ extern "C" int se_inorm_prelu_fwd(const float* X, int ldx, int x_off, const doub
   const long nb_cap = 2048 / B > 1 ? 2048 / B : 1;
   if (nb > nb_cap) nb = nb_cap;
   hipLaunchKernelGGL(inorm_prelu_fwd_kernel, dim3((int)nb, B), dim3(256), 0, as_stream(stream), X, ldx, x_off, stats, g, beta,
-                     slope, Y, ldy, y_off, mr, P, C, count, eps);
+                     slope, Y, ldy, y_off, mr, P, C, count, eps, amax_out);
   return se_check_launch("se_inorm_prelu_fwd");
 }
 

@@ -289,7 +289,7 @@ FF_RECOMPUTE = __import__('os').environ.get('SE_FF_RECOMPUTE') == '1'
 
 
 def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None, hid=None,
-           out_stats=False, store_h=True):
+           out_stats=False, store_h=True, in_bound=None, mid_bound=None):
     """fused Scale(alpha, PreNorm(FeedForward)) forward (csrc/se_gemm.hip: ff_fwd_kernel): returns (Y, H) with
     H = W1 LN(x) + b1 kept for the backward."""
     L.check_cuda(x, rowstats, gamma, beta, W1, b1, W2, b2)
@@ -303,7 +303,12 @@ def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_
     Y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     prec = (3 if f16 else min(LINEAR_PRECISION, 2)) if precision is None else precision
     ost = torch.empty(M, 2, device=x.device, dtype=torch.float32) if out_stats else None     # (mean, rstd) of the rows of Y
-    sc = L.F16Scales(None, LN_SEXP, HID_SEXP, W1._se_amax.data_ptr(), W2._se_amax.data_ptr(), None, None) if f16 else None
+    # in_bound / mid_bound: device scalars >= max |LN(x)| / max |Swish(H) mask / keep| (proven from the current parameters:
+    # weights.WeightPlan.run_bounds); without them the static exponents LN_SEXP / HID_SEXP
+    if mid_bound is not None and drop_p > 0.5:
+        raise L.SeHipError('ff_fwd: the hidden-activation bound assumes a dropout keep probability >= 1/2')
+    sc = L.F16Scales(in_bound.data_ptr() if in_bound is not None else None, LN_SEXP, HID_SEXP, W1._se_amax.data_ptr(),
+                     W2._se_amax.data_ptr(), None, mid_bound.data_ptr() if mid_bound is not None else None) if f16 else None
     L.call('se_ff_fwd_f16', L.ptr(x), L.ptr(rowstats), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
            L.ptr(H), L.ptr(Y), L.ptr(ost), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF),
            C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec | (16 if pl else 0)), C.byref(sc) if f16 else None,

@@ -115,25 +115,27 @@ def _T(w):
 # conv (+ InstanceNorm + PReLU) building block
 # ------------------------------------------------------------------------------------------------
 def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None, sf=1, shuffle2=False,
-             want_stats=True):
-    """raw conv output R [B, To, Fo(*2 if shuffle2), N(/2)] (+ fp64 (sum, sumsq) statistics)."""
+             want_stats=True, a_amax=None):
+    """raw conv output R [B, To, Fo(*2 if shuffle2), N(/2)] (+ fp64 (sum, sumsq) statistics).
+    a_amax: device scalar >= max |x| over the channels read (raised by the producers of x: inorm_prelu_fwd / copy_cols_amax) -- the
+    operand scale of the scaled split-fp16 kernels; None: the static exponent ACT_SEXP (callers without a measured maximum)"""
     To = To or Ti
     Fo = Fo or Fi
     ep = L.EPI_BIAS | (L.EPI_STATS if want_stats else 0) | (L.EPI_SHUFFLE2 if shuffle2 else 0)
     No = N // 2 if shuffle2 else N
     d = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, No, a_off=a_off, sf=sf, epilogue=ep,
-                     precision=_prec_w(CONV_PRECISION, wp, taps, sf, C_in, Fo), a_sexp=ACT_SEXP, w_sexp=8)
+                     precision=_prec_w(CONV_PRECISION, wp, taps, sf, C_in, Fo), a_sexp=ACT_SEXP, a_amax=a_amax, w_sexp=8)
     R = torch.empty(B, To, Fo * (2 if shuffle2 else 1), No, device=x.device, dtype=torch.float32)
     stats = O.zeros(B, No, 2, device=x.device, dtype=torch.float64) if want_stats else None
     GM.gemm_tap(d, x, wp, R, bias=bias, stats=stats)
     return R, stats
 
 
-def inorm_prelu_fwd(R, stats, g, b, slope, out, ldy, y_off):
+def inorm_prelu_fwd(R, stats, g, b, slope, out, ldy, y_off, amax=None):
     B = R.shape[0]
     C_ = R.shape[-1]
     P = R.numel() // (B * C_)
-    return O.inorm_prelu_fwd(R, C_, 0, stats, g, b, slope, out, ldy, y_off, B, P, C_)
+    return O.inorm_prelu_fwd(R, C_, 0, stats, g, b, slope, out, ldy, y_off, B, P, C_, amax=amax)
 
 
 def inorm_prelu_bwd(R, mr, g, b, slope, dy, ldy, y_off, dg, db, dslope):
@@ -149,7 +151,7 @@ def inorm_prelu_bwd(R, mr, g, b, slope, dy, ldy, y_off, dg, db, dslope):
 
 
 def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=1, rev=False, dx=None, lddx=None,
-             dx_off=0, accumulate=False, need_dx=True, w_for_dgrad=None, wd=None):
+             dx_off=0, accumulate=False, need_dx=True, w_for_dgrad=None, wd=None, a_amax=None):
     """gradients of a (non-shuffled) conv: weight/bias into dw/dbias (PyTorch layout, accumulated), input
     gradient into dx[..., dx_off:dx_off+C_in] (pixel stride lddx)."""
     N = dR.shape[-1]
@@ -157,8 +159,8 @@ def conv_bwd(x, B, Ti, Fi, lda, a_off, C_in, w, taps, dR, To, Fo, dw, dbias, sf=
     amax = getattr(dR, '_se_amax', None)            # producer-measured max |dR| (inorm_prelu_bwd); None: no scaled-fp16 kernels here
     fd = GM.make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, N, a_off=a_off, sf=sf,
                       precision=_prec(WGRAD_PRECISION[0], taps, sf, C_in, Fo, have_scale=amax is not None and Fo > 66),
-                      a_sexp=ACT_SEXP, w_amax=amax)
-    with GM.leaf_stream(x, dR, amax):
+                      a_sexp=ACT_SEXP, a_amax=a_amax, w_amax=amax)
+    with GM.leaf_stream(x, dR, amax, a_amax):
         dwp = O.zeros(N, ntap * C_in, device=dR.device)
         GM.gemm_tap_wgrad(fd, x, dR, dwp, dbias)
         _unpack_w(dwp, dw, C_in, rev)
@@ -255,6 +257,16 @@ def build_generator_plan(P, device):
                     plan.linear((n2, 'lin'), P[n2], planes=f3)
                     plan.linear_T((n2, 'T0.5'), P[n2], planes=f3, scale=0.5)
                     plan.linear_T((n1, 'T'), P[n1], planes=f3)
+            # proven bounds of the normalised activations that feed scaled split-fp16 GEMMs (refreshed by run_bounds every forward)
+            for ff in ('ff1', 'ff2'):
+                g_, b_ = P[f'{p}.{ff}.fn.norm.weight'], P[f'{p}.{ff}.fn.norm.bias']
+                plan.bound(('ln', f'{p}.{ff}'), g_, b_)
+                # |Swish(H) mask / keep| <= (|LN(x)| max row-l1(W1) + max |b1|) / keep, keep >= 1/2 (checked where it is used)
+                plan.bound(('hid', f'{p}.{ff}'), g_, b_, W=P[f'{p}.{ff}.fn.fn.net.0.weight'], wb=P[f'{p}.{ff}.fn.fn.net.0.bias'], post=2.0)
+            plan.bound(('ln', f'{p}.attn'), P[f'{p}.attn.norm.weight'], P[f'{p}.attn.norm.bias'])
+            plan.bound(('ln', f'{p}.conv'), P[f'{p}.conv.net.0.weight'], P[f'{p}.conv.net.0.bias'])
+            # train-mode BatchNorm over M tokens: |x_hat| <= sqrt(M - 1) (k1 of run_bounds); Swish(y) <= |y|
+            plan.bound(('bn', f'{p}.conv'), P[f'{p}.conv.net.5.weight'], P[f'{p}.conv.net.5.bias'], ksel=1)
             a = f'{p}.attn.fn'
             plan.linear((a, 'qkv'), P[f'{a}.to_q.weight'], planes=l3, rows=192)
             plan.linear((a, 'qkv'), P[f'{a}.to_kv.weight'], planes=l3, o_off=64)
@@ -289,21 +301,23 @@ def dense_taps(i):
     return GM.conv_taps(2, 3, (d, 1), (d, 1))      # causal in time: dt in {-d, 0}, df in {-1, 0, 1}
 
 
-def dense_block_fwd(P, p, skip, B, T, Fq):
-    """skip: [B,T,Fq,256] whose slab 0 already holds the block input.  Returns (out [B,T,Fq,64], ctx)."""
-    ctx = {'skip': skip, 'R': [], 'mr': []}
+def dense_block_fwd(P, p, skip, B, T, Fq, amax=None):
+    """skip: [B,T,Fq,256] whose slab 0 already holds the block input.  Returns (out [B,T,Fq,64], ctx).
+    amax: device scalar >= max |block input| (raised by its producer); every InstanceNorm + PReLU of the block raises it further,
+    so that layer i reads the maximum over the slabs 0 .. i it convolves (and the consumer of `out` the maximum over everything)"""
+    ctx = {'skip': skip, 'R': [], 'mr': [], 'amax': amax}
     out = None
     for i in range(4):
         C_in = 64 * (i + 1)
         wp = _w(P, (f'{p}.conv{i+1}.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv{i+1}.weight'], rev=True))
-        R, stats = conv_fwd(skip, B, T, Fq, 256, 0, C_in, wp, P[f'{p}.conv{i+1}.bias'], dense_taps(i), 64)
+        R, stats = conv_fwd(skip, B, T, Fq, 256, 0, C_in, wp, P[f'{p}.conv{i+1}.bias'], dense_taps(i), 64, a_amax=amax)
         if i < 3:
             mr = inorm_prelu_fwd(R, stats, P[f'{p}.norm{i+1}.weight'], P[f'{p}.norm{i+1}.bias'],
-                                 P[f'{p}.prelu{i+1}.weight'], skip, 256, 64 * (i + 1))
+                                 P[f'{p}.prelu{i+1}.weight'], skip, 256, 64 * (i + 1), amax=amax)
         else:
             out = torch.empty(B, T, Fq, 64, device=skip.device, dtype=torch.float32)
             mr = inorm_prelu_fwd(R, stats, P[f'{p}.norm{i+1}.weight'], P[f'{p}.norm{i+1}.bias'],
-                                 P[f'{p}.prelu{i+1}.weight'], out, 64, 0)
+                                 P[f'{p}.prelu{i+1}.weight'], out, 64, 0, amax=amax)
         ctx['R'].append(R)
         ctx['mr'].append(mr)
     return out, ctx
@@ -324,7 +338,7 @@ def dense_block_bwd(P, G, p, ctx, dout, B, T, Fq):
                              G[f'{p}.norm{i+1}.bias'], G[f'{p}.prelu{i+1}.weight'])
         conv_bwd(skip, B, T, Fq, 256, 0, C_in, P[f'{p}.conv{i+1}.weight'], dense_taps(i), dR, T, Fq,
                  G[f'{p}.conv{i+1}.weight'], G[f'{p}.conv{i+1}.bias'], rev=True, dx=dskip, lddx=256, dx_off=0,
-                 accumulate=(i != 3), wd=_w(P, (f'{p}.conv{i+1}.weight', 'dgrad'), lambda: None))
+                 accumulate=(i != 3), wd=_w(P, (f'{p}.conv{i+1}.weight', 'dgrad'), lambda: None), a_amax=ctx.get('amax'))
         ctx['R'][i] = None
     return dskip
 
@@ -343,14 +357,15 @@ def encoder_fwd(P, xin, B, T, Fq, p='dense_encoder'):
                        _w(P, (f'{p}.conv_1.0.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv_1.0.weight'], C_pad=4)),
                        P[f'{p}.conv_1.0.bias'], TAPS_1x1, 64)
     skip = torch.empty(B, T, Fq, 256, device=xin.device, dtype=torch.float32)
+    blk = _amax(xin.device)                 # max |activation| of the skip stack / the block output: raised by every norm below
     ctx['mr0'] = inorm_prelu_fwd(R0, st0, P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
-                                 P[f'{p}.conv_1.2.weight'], skip, 256, 0)
+                                 P[f'{p}.conv_1.2.weight'], skip, 256, 0, amax=blk)
     ctx['R0'] = R0
-    a2, ctx['dense'] = dense_block_fwd(P, f'{p}.dilated_dense', skip, B, T, Fq)
+    a2, ctx['dense'] = dense_block_fwd(P, f'{p}.dilated_dense', skip, B, T, Fq, amax=blk)
     Fo = (Fq + 2 - 3) // 2 + 1
     R5, st5 = conv_fwd(a2, B, T, Fq, 64, 0, 64,
                        _w(P, (f'{p}.conv_2.0.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv_2.0.weight'])),
-                       P[f'{p}.conv_2.0.bias'], TAPS_1x3, 64, To=T, Fo=Fo, sf=2)
+                       P[f'{p}.conv_2.0.bias'], TAPS_1x3, 64, To=T, Fo=Fo, sf=2, a_amax=blk)
     out = torch.empty(B, T, Fo, 64, device=xin.device, dtype=torch.float32)
     ctx['mr5'] = inorm_prelu_fwd(R5, st5, P[f'{p}.conv_2.1.weight'], P[f'{p}.conv_2.1.bias'],
                                  P[f'{p}.conv_2.2.weight'], out, 64, 0)
@@ -365,7 +380,7 @@ def encoder_bwd(P, G, ctx, dout, B, T, Fq, p='dense_encoder'):
                           G[f'{p}.conv_2.1.bias'], G[f'{p}.conv_2.2.weight'])
     da2 = conv_bwd(ctx['a2'], B, T, Fq, 64, 0, 64, P[f'{p}.conv_2.0.weight'], TAPS_1x3, dR5, T, Fo,
                    G[f'{p}.conv_2.0.weight'], G[f'{p}.conv_2.0.bias'], sf=2,
-                   wd=_w(P, (f'{p}.conv_2.0.weight', 'dgrad'), lambda: None))
+                   wd=_w(P, (f'{p}.conv_2.0.weight', 'dgrad'), lambda: None), a_amax=ctx['dense'].get('amax'))
     dskip = dense_block_bwd(P, G, f'{p}.dilated_dense', ctx['dense'], da2, B, T, Fq)
     dR0 = inorm_prelu_bwd(ctx['R0'], ctx['mr0'], P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
                           P[f'{p}.conv_1.2.weight'], dskip, 256, 0, G[f'{p}.conv_1.1.weight'],
@@ -391,6 +406,15 @@ def _lin3(W, **kw):
     return {}
 
 
+def _bnd(P, key, sexp):
+    """operand-scale keywords of a bounded activation: the proven bound of this forward (weights.WeightPlan.run_bounds: a device
+    scalar computed from the current parameters) when there is one, the static exponent otherwise (direct calls without a plan)"""
+    plan = P.get('__prep__')
+    if plan is not None and plan.bounds_ready and key in plan.bounds:
+        return dict(a_amax=plan.bounds[key])
+    return dict(a_sexp=sexp)
+
+
 def _amax(dev):
     """a zero-filled device scalar for a producer kernel to raise to max |output| (None when no scaled-fp16 kernel runs)"""
     return O.zeros(1, device=dev) if 3 in (GM.LINEAR_PRECISION, GM.WGRAD_LINEAR_PRECISION, CONV_PRECISION, WGRAD_PRECISION[0]) else None
@@ -413,7 +437,8 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0, st=None, want_out_stats=Fa
         res = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
                          W1p, P[f'{p}.fn.fn.net.0.bias'],
                          _w(P, (f'{p}.fn.fn.net.3.weight', 'lin'), lambda: W2), P[f'{p}.fn.fn.net.3.bias'], drop, seed_h,
-                         seed_o, 0.5, hid=W1.shape[0], out_stats=want_out_stats, store_h=not rc)
+                         seed_o, 0.5, hid=W1.shape[0], out_stats=want_out_stats, store_h=not rc,
+                         in_bound=_bnd(P, ('ln', p), 0).get('a_amax'), mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'))
         if want_out_stats:
             y, z, ost = res
             return y, (x, st, z, drop, seed_h, seed_o), ost
@@ -469,10 +494,10 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     with GM.leaf_stream(z, dy, x, dz, st, dy_amax, dz_amax):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH,
                                          epilogue=L.EPI_DROP if dr else 0, pro_seed=seed_h, epi_seed=seed_o, drop_p=drop,
-                                         a_sexp=GM.HID_SEXP, w_amax=dy_amax),
+                                         w_amax=dy_amax, **_bnd(P, ('hid', p), GM.HID_SEXP)),
                           z, dy, G[f'{p}.fn.fn.net.3.weight'], G[f'{p}.fn.fn.net.3.bias'], scale=0.5)
         # dW1 = dz^T LN(x);  db1 = sum dz
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dz_amax), x, dz,
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, w_amax=dz_amax, **_bnd(P, ('ln', p), GM.LN_SEXP)), x, dz,
                           G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'],
                           pb=P[f'{p}.fn.norm.bias'])
     if fused:
@@ -511,7 +536,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     attn16 = Es is not None and Es.dtype == torch.float16 and (A.f16_shape_ok(geom, maxpos) or
                                                                (not train and A.f16_fwd_shape_ok(geom, maxpos)))
     qkv_amax = O.zeros(1, device=x.device) if attn16 else None
-    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, y_amax=qkv_amax, **_lin3(Wqkv, a_sexp=GM.LN_SEXP)), y1, Wqkv, qkv,
+    GM.gemm_tap(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, y_amax=qkv_amax, **_lin3(Wqkv, **_bnd(P, ('ln', f'{p}.attn'), GM.LN_SEXP))), y1, Wqkv, qkv,
                 rowstats=st2, ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
     if Es is not None and Es.dtype == torch.float16 and not attn16:
         Es = None
@@ -519,11 +544,12 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     y2 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     sa = site_seed(seed, 2)
     st3 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None
-    # the attention output is a convex combination of value rows v = LN(y1) Wv: bounded like them -> static exponent ATTN_O_SEXP
+    # the attention output is a convex combination of value rows: |o| <= max |v| <= max |qkv| -- the measured scalar of the qkv GEMM
+    # is its operand scale (ATTN_O_SEXP only without one: the bf16 attention kernels)
     Wo_ = _w(P, (f'{p}.attn.fn.to_out.weight', 'lin'), lambda: P[f'{p}.attn.fn.to_out.weight'])
     GM.gemm_tap(GM.linear_desc(M, 64, 64, epilogue=L.EPI_BIAS | L.EPI_RESID | (L.EPI_DROP if pa > 0 else 0) |
                                (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64, epi_seed=sa, drop_p=pa,
-                               **_lin3(Wo_, a_sexp=ATTN_O_SEXP)), o,
+                               **_lin3(Wo_, **(dict(a_amax=qkv_amax) if qkv_amax is not None else dict(a_sexp=ATTN_O_SEXP)))), o,
                 Wo_, y2, bias=P[f'{p}.attn.fn.to_out.bias'], R=y1, AUX=st3)
     ctx['attn'] = (y1, st2, Wqkv, qkv, o, lse, maxpos, pa, sa, qkv_amax)
     # conv module
@@ -533,7 +559,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     zc = torch.empty(M, 128, device=x.device, dtype=torch.float32)      # the gate half only (GLU backward: (u, gate))
     Wpw1 = _w(P, (f'{p}.conv.net.2.weight', 'lin'), lambda: P[f'{p}.conv.net.2.weight'].view(256, 64))
     GM.gemm_tap(GM.linear_desc(M, 64, 256, ldc=128, prologue=L.PRO_LN, epilogue=L.EPI_BIAS | L.EPI_GLU | L.EPI_GLU_GATE, ldx=128,
-                               **_lin3(Wpw1, a_sexp=GM.LN_SEXP)), y2,
+                               **_lin3(Wpw1, **_bnd(P, ('ln', f'{p}.conv'), GM.LN_SEXP))), y2,
                 Wpw1, u, bias=P[f'{p}.conv.net.2.bias'], AUX=zc, rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                 pb=P[f'{p}.conv.net.0.bias'])
     Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
@@ -559,11 +585,15 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     sc, sh = sst[0], sst[1]
     y3 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     # Swish(BatchNorm(h)) is bounded like the FF hidden activations (the weight gradient of this layer uses the same exponent)
-    Wpw2 = _w(P, (f'{p}.conv.net.7.weight', 'lin'), lambda: P[f'{p}.conv.net.7.weight'].view(64, 128))
+    # (eval mode: running statistics bound nothing -- |BN(h)| depends on the data -- so the projection then runs on the fp32 kernel)
+    bn_b = _bnd(P, ('bn', f'{p}.conv'), GM.HID_SEXP) if train else {}
+    Wpw2 = _w(P, (f'{p}.conv.net.7.weight', 'lin'), lambda: None) if (train or 'a_amax' in bn_b) else None
+    if Wpw2 is None:
+        Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
     st4 = torch.empty(M, 2, device=x.device, dtype=torch.float32) if FUSE_ROWSTATS else None
     GM.gemm_tap(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, epilogue=L.EPI_BIAS | L.EPI_RESID |
                                (L.EPI_ROWSTATS if FUSE_ROWSTATS else 0), alpha=1.0, ldr=64,
-                               **_lin3(Wpw2, a_sexp=GM.HID_SEXP)), h, Wpw2, y3,
+                               **_lin3(Wpw2, **bn_b)), h, Wpw2, y3,
                 bias=P[f'{p}.conv.net.7.bias'], R=y2, ps=sc, pb=sh, AUX=st4)
     ctx['conv'] = (y2, st3, zc, u, h, mr, sc, sh, count)
     y4, ctx['ff2'] = _ff_fwd(P, f'{p}.ff2', y3, M, pf, site_seed(seed, 3), site_seed(seed, 4), st=st4)
@@ -591,7 +621,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     Wpw2T = _w(P, (f'{p}.conv.net.7.weight', 'T'), lambda: _T(Wpw2))
     GM.gemm_tap(GM.linear_desc(M, 64, 128, **_lin3(Wpw2T, a_amax=getattr(dy3, '_se_amax', None))), dy3, Wpw2T, dact)
     with GM.leaf_stream(h, dy3, sc, sh, getattr(dy3, '_se_amax', None)):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, a_sexp=GM.HID_SEXP,
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, **_bnd(P, ('bn', f'{p}.conv'), GM.HID_SEXP),
                                          w_amax=getattr(dy3, '_se_amax', None)), h, dy3,
                           G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
     dh = torch.empty(M, 128, device=dev, dtype=torch.float32)
@@ -614,7 +644,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
         dzc = O.glu_bwd_gate(u, zc, du, M, 128, amax=_amax(dev))
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
     with GM.leaf_stream(y2, dzc, st3, dzc._se_amax):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dzc._se_amax), y2, dzc,
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, w_amax=dzc._se_amax, **_bnd(P, ('ln', f'{p}.conv'), GM.LN_SEXP)), y2, dzc,
                           G[f'{p}.conv.net.2.weight'].view(256, 64),
                           G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
                           pb=P[f'{p}.conv.net.0.bias'])
@@ -641,7 +671,8 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
                                **_lin3(WoT, a_amax=getattr(dy2, '_se_amax', None))), dy2, WoT, do)
     with GM.leaf_stream(o, dy2, getattr(dy2, '_se_amax', None)):
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa,
-                                         a_sexp=ATTN_O_SEXP, w_amax=getattr(dy2, '_se_amax', None)), o, dy2,
+                                         w_amax=getattr(dy2, '_se_amax', None),
+                                         **(dict(a_amax=qkv_amax) if qkv_amax is not None else dict(a_sexp=ATTN_O_SEXP))), o, dy2,
                           G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25,
@@ -663,7 +694,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     dWqkv = torch.as_strided(gq, (192, 64), (64, 1)) if adjacent and gq.untyped_storage().nbytes() - gq.storage_offset() * 4 >= 192 * 64 * 4 \
         else O.zeros(192, 64, device=dev)
     with GM.leaf_stream(y1, dqkv, st2, dq_amax):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, a_sexp=GM.LN_SEXP, w_amax=dq_amax), y1, dqkv, dWqkv, None,
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, w_amax=dq_amax, **_bnd(P, ('ln', f'{p}.attn'), GM.LN_SEXP)), y1, dqkv, dWqkv, None,
                           rowstats=st2, ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
         if dWqkv.data_ptr() != gq.data_ptr():
             gq += dWqkv[:64]
@@ -691,8 +722,11 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
 # ------------------------------------------------------------------------------------------------
 def _decoder_head_fwd(P, p, x, B, T, Fq):
     skip = torch.empty(B, T, Fq, 256, device=x.device, dtype=torch.float32)
-    skip[..., :64].copy_(x.view(B, T, Fq, 64))      # strided slab copy (plumbing; the only one per decoder)
-    return dense_block_fwd(P, f'{p}.dense_block', skip, B, T, Fq)
+    # strided slab copy (the only one per decoder) + max |x|: the TSCB output (LayerNorm + residual chain) has no bound by
+    # construction, and it is the first operand of the block's scaled split-fp16 convolutions
+    blk = _amax(x.device)
+    O.copy_cols_amax(x.view(B * T * Fq, 64), 64, skip, 256, B * T * Fq, 64, amax=blk)
+    return dense_block_fwd(P, f'{p}.dense_block', skip, B, T, Fq, amax=blk)
 
 
 def mask_decoder_fwd(P, x, B, T, Fq):
@@ -701,7 +735,8 @@ def mask_decoder_fwd(P, x, B, T, Fq):
     d4, ctx['dense'] = _decoder_head_fwd(P, p, x, B, T, Fq)
     S, _ = conv_fwd(d4, B, T, Fq, 64, 0, 64,
                     _w(P, (f'{p}.sub_pixel.conv.weight', 'fwd'), lambda: pack_w(P[f'{p}.sub_pixel.conv.weight'])),
-                    P[f'{p}.sub_pixel.conv.bias'], TAPS_1x3, 128, shuffle2=True, want_stats=False)          # [B,T,2Fq,64]
+                    P[f'{p}.sub_pixel.conv.bias'], TAPS_1x3, 128, shuffle2=True, want_stats=False,
+                    a_amax=ctx['dense'].get('amax'))                                                      # [B,T,2Fq,64]
     F2 = 2 * Fq
     Fo = F2 - 1
     w1 = _w(P, (f'{p}.conv_1.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv_1.weight'], 4)))
@@ -740,12 +775,12 @@ def mask_decoder_bwd(P, G, ctx, dmask, B, T, Fq):
     with GM.leaf_stream(dw1, dbias1):            # dw1 / dbias1 are written on the weight-gradient stream (conv_bwd)
         G[f'{p}.conv_1.weight'] += dw1[:1]
         G[f'{p}.conv_1.bias'] += dbias1[:1]
-    dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq)
+    dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq, a_amax=ctx['dense'].get('amax'))
     dskip = dense_block_bwd(P, G, f'{p}.dense_block', ctx['dense'], dd4, B, T, Fq)
     return dskip        # slab 0 = input gradient
 
 
-def _subpixel_bwd(P, G, p, x, dS, B, T, Fq):
+def _subpixel_bwd(P, G, p, x, dS, B, T, Fq, a_amax=None):
     """SPConvTranspose2d backward: dS [B,T,2Fq,64] is the un-shuffled gradient; view it as [B,T,Fq,128] with
     channel r*64+c <- pixel 2f+r (the pixel shuffle is a pure re-indexing of the same memory)."""
     dconv = dS.view(B, T, Fq, 128)                      # [.., f, (r, c)] : memory order is already (f, r, c)
@@ -753,7 +788,7 @@ def _subpixel_bwd(P, G, p, x, dS, B, T, Fq):
     w = P[f'{p}.conv.weight']
     dw = G[f'{p}.conv.weight']
     return conv_bwd(x, B, T, Fq, 64, 0, 64, w, TAPS_1x3, dconv, T, Fq, dw, G[f'{p}.conv.bias'],
-                    wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None))
+                    wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None), a_amax=a_amax)
 
 
 def complex_decoder_fwd(P, x, B, T, Fq):
@@ -762,7 +797,7 @@ def complex_decoder_fwd(P, x, B, T, Fq):
     d4, ctx['dense'] = _decoder_head_fwd(P, p, x, B, T, Fq)
     S, st = conv_fwd(d4, B, T, Fq, 64, 0, 64,
                      _w(P, (f'{p}.sub_pixel.conv.weight', 'fwd'), lambda: pack_w(P[f'{p}.sub_pixel.conv.weight'])),
-                     P[f'{p}.sub_pixel.conv.bias'], TAPS_1x3, 128, shuffle2=True, want_stats=True)
+                     P[f'{p}.sub_pixel.conv.bias'], TAPS_1x3, 128, shuffle2=True, want_stats=True, a_amax=ctx['dense'].get('amax'))
     F2 = 2 * Fq
     Fo = F2 - 1
     a = torch.empty_like(S)
@@ -787,7 +822,7 @@ def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
         G[f'{p}.conv.bias'] += dbc[:2]
     dS = inorm_prelu_bwd(ctx['S'], ctx['mr'], P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], da,
                          64, 0, G[f'{p}.norm.weight'], G[f'{p}.norm.bias'], G[f'{p}.prelu.weight'])
-    dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq)
+    dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq, a_amax=ctx['dense'].get('amax'))
     return dense_block_bwd(P, G, f'{p}.dense_block', ctx['dense'], dd4, B, T, Fq)
 
 
@@ -799,6 +834,12 @@ def tscnet_fwd(P, xin, train=True, dp=NO_DP, buffers=None, drop=(0.0, 0.0), seed
     returns est planes [B, T, F, 4] = (|est|, Re est, Im est, 0) and the ctx for tscnet_bwd."""
     B, T, Fq, _ = xin.shape
     ctx = {'xin': xin, 'dims': (B, T, Fq)}
+    plan = P.get('__prep__')
+    if plan is not None:
+        # proven bounds of the normalised activations of this forward (LayerNorm outputs, feed-forward hidden activations, train-mode
+        # BatchNorm outputs: |x_hat| <= sqrt(tokens over all ranks - 1)) from the current parameters: one launch
+        Fp_ = (Fq + 2 - 3) // 2 + 1
+        plan.run_bounds(k1=float(max(B * T * Fp_ * dp.world - 1, 1)) ** 0.5)
     x, ctx['enc'] = encoder_fwd(P, xin, B, T, Fq)
     Fp = x.shape[2]
     ctx['Fp'] = Fp

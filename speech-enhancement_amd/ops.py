@@ -110,12 +110,20 @@ def norm_finalize(stats, g, beta, nb, C_, count, eps=1e-5, running_mean=None, ru
     return mr, ss
 
 
-def inorm_prelu_fwd(x, ldx, x_off, stats, g, beta, slope, y, ldy, y_off, B, P, C_, eps=1e-5):
-    """InstanceNorm(affine) + PReLU from the producer's (sum, sumsq): one launch; returns mr [B, C, 2] = (mean, rstd)"""
+def inorm_prelu_fwd(x, ldx, x_off, stats, g, beta, slope, y, ldy, y_off, B, P, C_, eps=1e-5, amax=None):
+    """InstanceNorm(affine) + PReLU from the producer's (sum, sumsq): one launch; returns mr [B, C, 2] = (mean, rstd).
+    amax: optional device scalar raised to max |y| (the operand scale of the scaled split-fp16 convolutions that read y)"""
     mr = _new(B, C_, 2, like=g)
-    L.call('se_inorm_prelu_fwd', L.ptr(x), _i(ldx), _i(x_off), L.ptr(stats), L.ptr(g), L.ptr(beta), L.ptr(slope), L.ptr(y),
-           _i(ldy), _i(y_off), L.ptr(mr), _i(B), _l(P), _i(C_), _d(float(P)), _f(eps), L.stream())
+    L.call('se_inorm_prelu_fwd_amax', L.ptr(x), _i(ldx), _i(x_off), L.ptr(stats), L.ptr(g), L.ptr(beta), L.ptr(slope), L.ptr(y),
+           _i(ldy), _i(y_off), L.ptr(mr), _i(B), _l(P), _i(C_), _d(float(P)), _f(eps), L.ptr(amax), L.stream())
     return mr
+
+
+def copy_cols_amax(src, lds, dst, ldd, rows, C_, amax=None):
+    """dst[r, :C] = src[r, :C] (row strides lds / ldd) and amax (zero-filled device scalar) raised to max |src|"""
+    L.check_cuda(src, dst, amax)
+    L.call('se_copy_cols_amax', L.ptr(src), _i(lds), L.ptr(dst), _i(ldd), _l(rows), _i(C_), L.ptr(amax), L.stream())
+    return dst
 
 
 def bn_eval_scale(rm, rv, g, beta, eps=1e-5):

@@ -21,9 +21,20 @@ class WItem(C.Structure):
                 ('plane_stride', C.c_long), ('fmt', C.c_int), ('amax', C.c_void_p)]
 
 
+class BItem(C.Structure):        # se_bound_item (include/se_hip.h)
+    _fields_ = [('g', C.c_void_p), ('b', C.c_void_p), ('alpha', C.c_void_p), ('W', C.c_void_p), ('wb', C.c_void_p),
+                ('n', C.c_int), ('na', C.c_int), ('rows', C.c_int), ('cols', C.c_int), ('ksel', C.c_int),
+                ('kconst', C.c_float), ('post', C.c_float), ('out', C.c_void_p)]
+
+
 class WeightPlan:
     def __init__(self, device):
         self.device = device
+        self.bounds = {}       # key -> device scalar: proven bound of a normalised activation (se_act_bounds), valid after run_bounds()
+        self._bitems = []
+        self._btable = None
+        self._bscal = None
+        self.bounds_ready = False
         self.out = {}          # key -> prepared tensor: fp32 [rows, ld], bf16 planes [3, rows, ld] or scaled fp16 planes [2, rows, ld]
         self._items = []
         self._srcs = []        # keeps the source tensors alive / lets `stale()` detect re-allocated parameters
@@ -73,11 +84,49 @@ class WeightPlan:
         self._table = None
         return dst
 
+    def bound(self, key, g, b=None, alpha=None, W=None, wb=None, ksel=0, kconst=7.9372539, post=1.0):
+        """register a proven activation bound (k max|g| + max|b|) max(1, max|alpha|) [* max row-l1(W) + max|wb|] * post, stored in
+        the scalar of `key`; k = kconst (LayerNorm(64): sqrt(63)) or the
+        run-time k1 / k2 of run_bounds (ksel 1 / 2).  Returns the device scalar (valid after run_bounds)."""
+        for t in (g, b, alpha, W, wb):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous()):
+                raise L.SeHipError(f'weight plan: bound {key}: parameters must be contiguous fp32 CUDA tensors')
+        if self._bscal is None:
+            self._bscal = torch.zeros(256 * 32, device=self.device, dtype=torch.float32)     # one scalar per 128-B line
+        if key in self.bounds:
+            raise L.SeHipError(f'weight plan: bound {key} registered twice (one item per scalar)')
+        if key not in self.bounds:
+            if len(self.bounds) >= self._bscal.numel() // 32:
+                raise L.SeHipError('weight plan: more than 256 activation bounds')
+            i = 32 * len(self.bounds)
+            self.bounds[key] = self._bscal[i:i + 1]
+        pt = lambda t: t.data_ptr() if t is not None else None
+        rows = W.shape[0] if W is not None else 0
+        self._bitems.append(BItem(pt(g), pt(b), pt(alpha), pt(W), pt(wb), g.numel(), alpha.numel() if alpha is not None else 0, rows,
+                                  W.numel() // rows if W is not None else 0, ksel, float(kconst), float(post),
+                                  self.bounds[key].data_ptr()))
+        for t in (g, b, alpha, W, wb):
+            if t is not None:
+                self._srcs.append((t, t.data_ptr()))
+        self._btable = None
+        return self.bounds[key]
+
+    def run_bounds(self, k1=0.0, k2=0.0):
+        """refresh every registered bound from the current parameter values (one launch)"""
+        if not self._bitems:
+            return
+        if self._btable is None:
+            arr = (BItem * len(self._bitems))(*self._bitems)
+            self._btable = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        L.call('se_act_bounds', L.ptr(self._btable), C.c_int(len(self._bitems)), C.c_float(k1), C.c_float(k2), L.stream())
+        self.bounds_ready = True
+
     def stale(self):
         """True when a source parameter has been re-allocated since the plan was built (.to(), .data = ...)."""
         return any(t.data_ptr() != p for t, p in self._srcs)
 
     def run(self):
+        self.bounds_ready = False           # (the bounds of the previous parameter values; run_bounds follows where they are used)
         if not self._items:
             return
         if self._table is None:

@@ -197,28 +197,34 @@ def test_cli_surface(S, tmp_path):
 
 
 def test_ctypes_struct_layouts_match_the_c_header(tmp_path):
-    """the two structs that cross the C ABI by value / by table (se_gemm_desc, se_wprep_item): size and field offsets of the
-    ctypes mirrors equal what the C compiler lays out for include/se_hip.h"""
+    """the structs that cross the C ABI by value / by table (se_gemm_desc, se_wprep_item, se_bound_item, se_f16_scales): size and
+    field offsets of the ctypes mirrors equal what the C compiler lays out for include/se_hip.h"""
     import ctypes
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     from speech_enhancement_amd import _lib as L
-    from speech_enhancement_amd.weights import WItem
+    from speech_enhancement_amd.weights import WItem, BItem
     src = tmp_path / 'layout.c'
     fields_d = ['B', 'ntap', 'dt', 'df', 'C', 'N', 'ldw', 'prologue', 'alpha', 'ldx', 'pro_seed', 'drop_p', 'precision', 'w_planes', 'w_amax', 'y_amax']
     fields_w = ['src', 'dst', 'No', 'Ni_dst', 'so', 'stt', 'si', 'rev', 'dst_ld', 'c_off', 'scale', 'plane_stride']
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "se_hip.h"\nint main(void) {\n'
     prog += '  printf("%zu\\n", sizeof(se_gemm_desc));\n' + ''.join(f'  printf("%zu\\n", offsetof(se_gemm_desc, {f}));\n' for f in fields_d)
     prog += '  printf("%zu\\n", sizeof(se_wprep_item));\n' + ''.join(f'  printf("%zu\\n", offsetof(se_wprep_item, {f}));\n' for f in fields_w)
+    fields_b = ['g', 'b', 'alpha', 'W', 'wb', 'n', 'na', 'rows', 'cols', 'ksel', 'kconst', 'post', 'out']
+    fields_s = ['in_amax', 'in_sexp', 'mid_sexp', 'wa_amax', 'wb_amax', 'out_amax', 'mid_amax']
+    prog += '  printf("%zu\\n", sizeof(se_bound_item));\n' + ''.join(f'  printf("%zu\\n", offsetof(se_bound_item, {f}));\n' for f in fields_b)
+    prog += '  printf("%zu\\n", sizeof(se_f16_scales));\n' + ''.join(f'  printf("%zu\\n", offsetof(se_f16_scales, {f}));\n' for f in fields_s)
     prog += '  return 0;\n}\n'
     src.write_text(prog)
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
     vals = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(L.GemmDesc)] + [getattr(L.GemmDesc, f).offset for f in fields_d] + \
-           [ctypes.sizeof(WItem)] + [getattr(WItem, f).offset for f in fields_w]
+           [ctypes.sizeof(WItem)] + [getattr(WItem, f).offset for f in fields_w] + \
+           [ctypes.sizeof(BItem)] + [getattr(BItem, f).offset for f in fields_b] + \
+           [ctypes.sizeof(L.F16Scales)] + [getattr(L.F16Scales, f).offset for f in fields_s]
     assert vals == want
 
 
