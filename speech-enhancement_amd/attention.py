@@ -73,7 +73,7 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None, qk
            'attn_bwd2_kernel (+delta)' if n <= 336 and maxpos >= 352 else 'attn_bwd_dkv + attn_bwd_dq (+delta)')
     f16 = qkv_amax is not None and do_amax is not None and v3 and f16_shape_ok(geom, maxpos)
     if f16:
-        key = 'attn_bwd3_f16x3 (+delta, tables, dE reduce)'
+        key = 'attn_bwd_f16x3 (+delta, tables, dE reduce)'
     def run(phase, **kw):
         if f16:
             L.call('se_attn_bwd_f16_phase', L.ptr(qkv), L.ptr(E), L.ptr(O), L.ptr(dO), L.ptr(lse), L.ptr(qkv_amax), L.ptr(do_amax),

@@ -35,6 +35,14 @@ def golden3():
     return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_v3.npz'))
 
 
+@pytest.fixture(scope='session')
+def golden4():
+    """round-4 vectors (tests/golden/make_golden_v4.py): the reference's FULL-SIZE train_gan steps -- the fp32 twin of golden_v2's
+    fp64 cmgan step (calibrates the full-size gradient bars) and one `cp` step (fp64 + fp32) on the conditioned clip pair"""
+    import numpy as np
+    return np.load(os.path.join(ROOT, 'tests', 'golden', 'golden_v4.npz'))
+
+
 def full_size_signals(seed, B=2, L=32000):
     """the inputs of the full-size golden step, regenerated from the seed (numpy legacy RandomState is bit-stable)"""
     import numpy as np

@@ -4,9 +4,12 @@ run these sizes in seconds, so every check is a size-independent property: two i
 agree, a transform inverts, an op is linear / equivariant, or a random SAMPLE of the output matches fp64 torch."""
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+
+import formula
 
 pytestmark = pytest.mark.gpu
 B, T, Fe, Fp = 16, 321, 201, 101
@@ -270,3 +273,133 @@ def test_streams_do_not_change_the_full_size_step():
         if diff > 1e-2 * upd + 1e-6 * max(1.0, float(p0.abs().max())):
             bad.append((n, diff, upd))
     assert not bad, bad[:10]
+
+
+# ---- round 4: config 3's per-rank workload under a check ---------------------------------------------
+@pytest.mark.parametrize('comp', ['pow', 'log'])
+def test_full_size_stft_backward_vs_oracle_fp64(comp):
+    """frontend._STFTFn.backward at the bench geometry (B = 2, L = 32 000: T = 321 frames; every scp / cp step runs it,
+    core/function.py:231-249) against the oracle's fp64 autograd on the well-conditioned clip (formula.cond_signals); bar as in
+    tests/test_consistency_gpu.py: 2e-5 of max |dx| + 1.5 x the torch-CPU fp32 floor of the same chain"""
+    from speech_enhancement_amd import frontend as FE
+    from oracle import se_oracle as Or
+    _, noisy = formula.cond_signals(2, 32000, 31)
+    x0 = noisy.double()
+    x0 = (x0 * torch.sqrt(x0.shape[-1] / (x0 ** 2).sum(-1, keepdim=True)))          # the normalised clip the loop re-analyses
+    Bq, T = 2, 321
+    k = torch.arange(Bq * 201 * T, dtype=torch.float64).view(Bq, 201, T)
+    wr, wi, wm = torch.cos(k * 0.013), torch.sin(k * 0.017), torch.cos(k * 0.0071 + 1.0)
+    x64 = x0.clone().requires_grad_(True)
+    s64 = Or.compressed_stft(x64, comp=comp)
+    (s64.real * wr + s64.imag * wi + s64.abs() * wm).sum().backward()
+    dref = x64.grad.numpy()
+    x32 = x0.float().clone().requires_grad_(True)
+    s32 = Or.compressed_stft(x32, comp=comp)
+    (s32.real * wr.float() + s32.imag * wi.float() + s32.abs() * wm.float()).sum().backward()
+    floor = float(np.abs(x32.grad.double().numpy() - dref).max())
+    x = x0.float().cuda().requires_grad_(True)
+    P = FE.stft_planes_grad(x, 400, 100, comp)                             # [B, T, F, 4] = (|z|, Re, Im, 0)
+    f = lambda w: w.permute(0, 2, 1).float().contiguous().cuda()
+    fe = float((P[..., 1].detach().permute(0, 2, 1).double().cpu() - s64.real.detach()).abs().max()) / float(s64.detach().abs().max())
+    f32e = float((s32.real.detach().double() - s64.real.detach()).abs().max()) / float(s64.detach().abs().max())
+    print(comp, 'forward max err / max |z|', fe, '(torch-CPU fp32:', f32e, ')')
+    assert fe < 5e-6 + 2.0 * f32e
+    (P[..., 1] * f(wr) + P[..., 2] * f(wi) + P[..., 0] * f(wm)).sum().backward()
+    err = float(np.abs(x.grad.double().cpu().numpy() - dref).max())
+    print(comp, 'full-size dx max err', err, 'of max', float(np.abs(dref).max()), '(torch-CPU fp32 floor:', floor, ')')
+    assert err < 2e-5 * float(np.abs(dref).max()) + 1.5 * floor
+
+
+def test_scp_full_size_step_streams_equal_serial():
+    """BASELINE config 3's per-rank share: ONE scp train step at B = 8, T = 321 (self-correcting weights, the consistency-preserving
+    iSTFT / re-STFT path, three discriminator forwards) with the three HIP streams on vs the serial order: every loss finite and
+    equal, w_E / w_N equal, every parameter relative to the size of its update (one step: the two-step comparison of scp is chaotic
+    on white noise, DESIGN_APPENDIX A; the clips here are the well-conditioned ones)"""
+    import types
+    from speech_enhancement_amd import train as TR, optim, gemm as GM
+    B8 = 8
+    clean, noisy = formula.cond_signals(B8, 32000, 41)
+    clean, noisy = clean.cuda(), noisy.cuda()
+    gen = torch.Generator().manual_seed(5)
+    labels = {k: (lo + (hi - lo) * torch.rand(B8, generator=gen)).cuda() for k, (lo, hi) in
+              (('est', (0.3, 0.7)), ('clean', (0.9, 1.0)), ('noisy', (0.1, 0.5)))}
+    saved = (GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled)
+    res, init = [], None
+    try:
+        for on in (False, True):
+            GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled = on, on, on
+            g, d = _models()
+            named = lambda: list(g.named_parameters()) + [('D.' + n, p) for n, p in d.named_parameters()]
+            if init is None:
+                init = {n: p.detach().clone() for n, p in named()}
+            a = types.SimpleNamespace(optimizer='sgd', lr=0.01, weight_decay=0.01, momentum=0.9, max_norm=0.0)
+            og, od = optim.build_optimizer(a, g), optim.build_optimizer(a, d, lr=0.02)
+            out = TR.gan_step(g, d, og, od, clean, noisy, 'scp', (0.3, 0.7, 0.2, 0.05), labels=labels)
+            torch.cuda.synchronize()
+            res.append(({k: float(v) for k, v in out.items()}, {n: p.detach().clone() for n, p in named()}))
+    finally:
+        GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled = saved
+    print('scp B=8 T=321 step:', {k: float('%.5g' % v) for k, v in res[0][0].items()})
+    for k, v in res[0][0].items():
+        assert np.isfinite(v), (k, v)
+        assert abs(v - res[1][0][k]) <= 1e-4 * abs(v) + 1e-7, (k, v, res[1][0][k])
+    assert 'w_E' in res[0][0] and 'w_N' in res[0][0]
+    bad = []
+    for n, p0 in res[0][1].items():
+        upd = float((p0 - init[n]).abs().max())
+        diff = float((p0 - res[1][1][n]).abs().max())
+        if diff > 1e-2 * upd + 1e-6 * max(1.0, float(p0.abs().max())):
+            bad.append((n, diff, upd))
+    assert not bad, bad[:10]
+
+
+def test_cp_full_size_step_vs_reference_loop(golden4):
+    """ONE FULL-SIZE train_gan step of the REFERENCE for the consistency-preserving recipe `cp` (core/function.py:231-254; fp64
+    golden, its own fp32 run gives the rounding spread) on the conditioned pair, B = 2, T = 321, vs gan_step: loss terms, every
+    post-step parameter norm, the gradients of six generator and two discriminator tensors (first nesterov step: u = -1.9 lr g)"""
+    import types
+    from speech_enhancement_amd import train as TR, optim
+    from oracle import se_oracle as Or
+    clean, noisy = formula.cond_signals(2, 32000, int(golden4['cp_full_seed'][0]))
+    g, d = _models()
+    args = types.SimpleNamespace(optimizer='sgd', lr=0.01, weight_decay=0.01, momentum=0.9, max_norm=0.0)
+    og, od = optim.build_optimizer(args, g), optim.build_optimizer(args, d, lr=0.02)
+    lr = Or.lr_at(10.0, 0.01, 100)
+    for o in (og, od):
+        for grp in o.param_groups:
+            grp['lr'] = lr
+    out = TR.gan_step(g, d, og, od, clean.cuda(), noisy.cuda(), 'cp', (0.1, 0.9, 0.2, 0.05),
+                      labels={'est': torch.tensor([0.35, 0.62], device='cuda')})
+    torch.cuda.synchronize()
+    pre, pre32 = 'cp_full_f64_', 'cp_full_f32_'
+    mse = golden4[pre + 'mse_calls']
+    for k, b in (('loss_mag', mse[0]), ('loss_ri', mse[1] + mse[2]), ('gan', mse[3]), ('L_E', mse[4]), ('L_C', mse[5]),
+                 ('loss_g', golden4[pre + 'losses'][0]), ('loss_d', golden4[pre + 'losses'][1])):
+        e = abs(float(out[k]) - b) / abs(b)
+        assert e < (2e-4 if k in ('loss_mag', 'loss_ri', 'loss_g') else 1e-3), (k, float(out[k]), b)
+    gs, ds = g.state_dict(), d.state_dict()
+    gnorm = np.array([float(v.double().norm()) for v in gs.values()])
+    dnorm = np.array([float(v.double().norm()) for v in ds.values()])
+    ref_g, ref_d = golden4[pre + 'g_norm'], golden4[pre + 'd_norm']
+    tol_g = 3e-4 * ref_g + 1e-5 + 1.5 * np.abs(golden4[pre32 + 'g_norm'] - ref_g)
+    tol_d = 3e-4 * ref_d + 1e-5 + 1.5 * np.abs(golden4[pre32 + 'd_norm'] - ref_d)
+    names_g = list(gs.keys())
+    bad = [(names_g[i], gnorm[i], ref_g[i]) for i in range(len(ref_g)) if abs(gnorm[i] - ref_g[i]) > tol_g[i]]
+    assert not bad, bad[:8]
+    assert np.all(np.abs(dnorm - ref_d) <= tol_d)
+    gp, dp = dict(g.named_parameters()), dict(d.named_parameters())
+    scale = -1.0 / (lr * 1.9)
+    rmsf = lambda a, b: float(np.sqrt(np.mean((np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64) - b) ** 2)))
+    for k in golden4.files:
+        if not (k.startswith(pre + 'gupd:') or k.startswith(pre + 'dupd:')):
+            continue
+        name = k.split(':', 1)[1]
+        gref = golden4[k].astype(np.float64) * scale
+        nrm = np.sqrt(np.mean(gref ** 2)) + 1e-300
+        spread = rmsf(golden4[pre32 + k[len(pre):]].astype(np.float64) * scale, gref)
+        got = (gp if k.startswith(pre + 'gupd:') else dp)[name].grad
+        e = rmsf(got, gref)
+        print('cp full size', name, 'grad rel err %.2e (reference fp32 spread %.2e)' % (e / nrm, spread / nrm))
+        # (fp32 storage of the reference's updates: relative 6e-8 of the PARAMETER, i.e. up to a few 1e-3 of a tiny update)
+        store = 1.2e-7 * float(np.abs((gp if 'gupd' in k else dp)[name].detach().cpu().numpy()).max()) * abs(scale)
+        assert e < 2e-4 * nrm + 1.5 * spread + store, (name, e / nrm, spread / nrm)

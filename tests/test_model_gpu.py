@@ -578,7 +578,7 @@ def test_frontend_public_api(S, golden, golden2):
         S.uncompressed_istft(s, 400, 100, torch.ones(400, device='cuda'))
 
 
-def test_full_size_train_step_vs_reference(S, golden2):
+def test_full_size_train_step_vs_reference(S, golden2, golden4):
     """ONE FULL-SIZE train_gan step of the reference (cmgan, nesterov-SGD, B=2, L=32 000 -> T=321, fp64 golden) vs gan_step:
     the first end-to-end comparison at the benchmark's geometry -- attn_bwd2_kernel<336,8,false>, the triple-tap
     weight-gradient kernels, the 201-wide decoders and the XCD-aware decode all run here.  Every loss term, every
@@ -616,10 +616,15 @@ def test_full_size_train_step_vs_reference(S, golden2):
         if k.startswith('full_step_gupd:') or k.startswith('full_step_dupd:'):
             name = k.split(':', 1)[1]
             ref = golden2[k].astype(np.float64) / (-lr * 1.9)
-            e = rms(grads[('g' if 'gupd' in k else 'd', name)], ref) / (np.sqrt(np.mean(ref ** 2)) + 1e-30)
-            errs[name] = e
-            assert e < 2e-2, (k, e)
-    print('full-size step relative errors:', {k: float('%.2e' % v) for k, v in errs.items()})
+            nrm = np.sqrt(np.mean(ref ** 2)) + 1e-30
+            e = rms(grads[('g' if 'gupd' in k else 'd', name)], ref) / nrm
+            # calibrated bar (round 4): 2e-4 + 1.5 x the spread of the REFERENCE's own fp32 run of this step against its fp64 run
+            # (golden_v4: 3e-3 .. 1e-2 on the interior tensors: the fp32 floor through 16 InstanceNorms and 8 Conformers)
+            spread = rms(golden4['full32_step_' + k[len('full_step_'):]].astype(np.float64) / (-lr * 1.9), ref) / nrm
+            errs[name] = (e, spread)
+            assert e < 2e-4 + 1.5 * spread, (k, e, spread)
+    print('full-size step relative errors (ours, reference fp32 spread):',
+          {k: (tuple(float('%.2e' % x) for x in v) if isinstance(v, tuple) else float('%.2e' % v)) for k, v in errs.items()})
 
 
 @pytest.mark.parametrize('kind', ['lars', 'lamb'])

@@ -29,61 +29,51 @@ def short(n):
 
 
 def fam(name):
-    """KernelTimer family (bench.py roofline keys) of a kernel name, or None"""
+    """KernelTimer family (bench.py roofline keys) of a kernel name, or None.  The LAST template argument of the scaled split-fp16
+    instantiations (precision 3) is F16 = true (ff_fwd carries one more flag behind it)."""
     n = short(name)
-    # the scaled split-fp16 instantiations (precision 3) carry a trailing `true` template argument (F16)
-    m = re.match(r'gemm_tap_bf16x3_kernel<(\d), (\d), (?:true|false), (?:true|false), (?:true|false), true>', n)
-    if m:
-        return 'gemm_tap_f16x3_kernel<0>'
-    m = re.match(r'gemm_tap_bf16x3_kernel<(\d), (\d), (true|false)', n)
-    if m:
-        return f'gemm_tap_bf16x{3 if m.group(2) == "2" else 6}_kernel<{m.group(1)}>'
-    if re.match(r'conv3_bf16_kernel<2, (?:true|false), true', n):
-        return 'conv3_f16x3'
-    m = re.match(r'conv3_bf16_kernel<(\d)', n)
-    if m:
-        return f'conv3_bf16x{3 if m.group(1) == "2" else 6}'
-    m = re.match(r'gemm_k64_panel_kernel<(\d), 2, (?:true|false), true, true>', n)
-    if m:
-        return f'gemm_k64_panel_f16x3<{m.group(1)}>'
-    m = re.match(r'gemm_k64_panel_kernel<(\d), (\d), (true|false)', n)
-    if m:
-        return f'gemm_k64_panel_bf16x{3 if m.group(2) == "2" else 6}<{m.group(1)}>'
-    if re.match(r'dwconv_kernel<\d+, true>', n):
-        return 'dwconv31 dgrad + glu_bwd'
-    m = re.match(r'ff_(fwd|bwd)_kernel<2, true, \d, true>', n)
-    if m:
-        return f'ff_{m.group(1)}{"_dgrad" if m.group(1) == "bwd" else ""}_f16x3'
-    m = re.match(r'wgrad_lin_bf16_kernel<(\d)', n)
-    if m:
-        return f'wgrad_kernel<{m.group(1)}>'
-    m = re.match(r'gemm_tap_kernel<(\d+), (\d), (true|false)>', n)
-    if m:
-        return f'gemm_tap_kernel<{m.group(1)},{m.group(2)}>'
-    m = re.match(r'wgrad_kernel<(\d)>', n) or re.match(r'wgrad_lin_kernel<(\d)', n)
-    if m:
-        return f'wgrad_kernel<{m.group(1)}>'
-    if n.startswith('dwconv_kernel'):
-        return 'dwconv31 (fwd / dgrad)'
-    if n.startswith('dwconv_wgrad_kernel'):
+    args = [a.strip() for a in re.sub(r'^[^<]*<?', '', n).rstrip('>').split(',')] if '<' in n else []
+    base = n.split('<')[0]
+    if base == 'gemm_tap_bf16x3_kernel':              # <PRO, NPL, planes, LIN, NOLOAD?, F16>
+        if args[-1] == 'true':
+            return f'gemm_tap_f16x3_kernel<{args[0]}>'
+        return f'gemm_tap_bf16x{3 if args[1] == "2" else 6}_kernel<{args[0]}>'
+    if base == 'conv3_bf16_kernel':                   # <NPL, planes, F16, ...>
+        if args[0] == '2' and args[2] == 'true':
+            return 'conv3_f16x3'
+        return f'conv3_bf16x{3 if args[0] == "2" else 6}'
+    if base in ('gemm_k64_wstat_kernel',):            # the W-stationary row panel of the train step (scaled fp16 only)
+        return f'gemm_k64_panel_f16x3<{args[0]}>'
+    if base == 'gemm_k64_panel_kernel':
+        if args[-1] == 'true' and args[1] == '2' and len(args) >= 5:
+            return f'gemm_k64_panel_f16x3<{args[0]}>'
+        return f'gemm_k64_panel_bf16x{3 if args[1] == "2" else 6}<{args[0]}>'
+    if base == 'dwconv_kernel':
+        return 'dwconv31 dgrad + glu_bwd' if len(args) > 1 and args[1] == 'true' else 'dwconv31 (fwd / dgrad)'
+    if base in ('dwconv_wgrad_kernel', 'dwconv_wgrad_reduce_kernel'):
         return 'dwconv31_wgrad (+ reduce)'
-    if n.startswith('wgrad3_kernel') or n.startswith('wgrad3_bf16_kernel'):
+    if base in ('ff_fwd_kernel', 'ff_bwd_kernel'):    # <NPL, planes, NB, F16 [, STORE_H]>
+        kind = 'fwd' if base == 'ff_fwd_kernel' else 'bwd_dgrad'
+        if len(args) >= 4 and args[3] == 'true':
+            return f'ff_{kind}_f16x3'
+        return f'ff_{kind}_bf16x{3 if args[0] == "2" else 6}'
+    if base == 'wgrad_lin_bf16_kernel' or base == 'wgrad_lin_kernel' or base == 'wgrad_kernel':
+        return f'wgrad_kernel<{args[0]}>'
+    if base in ('wgrad3_kernel', 'wgrad3_bf16_kernel', 'wgrad3w_f16_kernel'):
         return 'wgrad_kernel<0>'
-    m = re.match(r'ff_(fwd|bwd)_kernel<(\d)', n)
-    if m:
-        return f'ff_{m.group(1)}{"_dgrad" if m.group(1) == "bwd" else ""}_bf16x{3 if m.group(2) == "2" else 6}'
-    f16 = n.rstrip('>').endswith(', true') and (n.startswith('attn_bwd3_kernel<6, true, true') or n.startswith('attn_bwd3_kernel<7, false, true')
-                                                or n.startswith('attn_fwd3_kernel<'))
-    if n.startswith('attn_bwd3_kernel<6'):
-        return ('attn_bwd3_f16x3' if f16 else 'attn_bwd3_bf16x6') + ' (+delta, tables, dE reduce) n>128'
-    if n.startswith('attn_bwd3_kernel<7'):
-        return ('attn_bwd3_f16x3' if f16 else 'attn_bwd3_bf16x6') + ' (+delta, tables, dE reduce) n<=128'
-    if n.startswith('attn_fwd2_kernel'):
+    if base == 'gemm_tap_kernel':
+        return f'gemm_tap_kernel<{args[0]},{args[1]}>'
+    if base == 'attn_bwd4_kernel':                    # <NW, KPW, NCW, NKTM, MINW>: round 4, scaled fp16 only
+        return 'attn_bwd_f16x3 (+delta, tables, dE reduce) ' + ('n>128' if args[1] != '2' else 'n<=128')
+    if base == 'attn_bwd3_kernel':                    # <KT, GROUP, F16, RING>
+        f16 = len(args) > 2 and args[2] == 'true'
+        return ('attn_bwd_f16x3' if f16 else 'attn_bwd3_bf16x6') + ' (+delta, tables, dE reduce) ' + ('n>128' if args[0] == '6' else 'n<=128')
+    if base == 'attn_fwd2_kernel':
         return 'attn_fwd2_kernel'
-    if n.startswith('attn_fwd3_kernel'):
-        return 'attn_fwd3_f16x3' if f16 else 'attn_fwd3_bf16x6'
-    if n.startswith('stft_fused_kernel') or n.startswith('istft_fused_kernel'):
-        return n.replace('_kernel', '')
+    if base == 'attn_fwd3_kernel':
+        return 'attn_fwd3_f16x3' if len(args) > 1 and args[1] == 'true' else 'attn_fwd3_bf16x6'
+    if base in ('stft_fused_kernel', 'istft_fused_kernel'):
+        return base.replace('_kernel', '')
     return None
 
 
@@ -158,5 +148,21 @@ out = {'source': f'tools/make_profile_summary.py {tag}: separate rocprofv3 --pmc
 for k, a in famacc.items():
     out['kernels'][k] = {'traffic_bytes_per_launch': int(a['bytes'] / max(a['calls'], 1)),
                          'mfma_busy_pct': round(a['mfma_busy_w'] / max(a['ns'], 1.0), 1)}
+# step-level figures (the committed profile the bench line quotes): time-weighted MFMA-busy over every kernel of the trace and the
+# HBM-side bytes of one step (2 FETCH_SIZE + WRITE_SIZE over all launches of a step)
+tw = sum(r.get('mfma_busy_pct', 0.0) * float(st['TotalDurationNs']) for r, st in zip(rows, stats))
+out['step'] = {'mfma_busy_pct_time_weighted': round(tw / max(total_ns, 1.0), 1),
+               'hbm_side_gb_per_step': round(sum((r.get('fetch_bytes_x2', 0) + r.get('write_bytes', 0)) * int(st['Calls'])
+                                                 for r, st in zip(rows, stats)) / steps_in_trace / 1e9, 1),
+               'kernel_ms_per_step_serial_order': round(total_ns / steps_in_trace / 1e6, 2),
+               'launches_per_step': round(sum(int(st['Calls']) for st in stats) / steps_in_trace)}
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
+bl = os.path.join(src, 'bench_line.json')
+if os.path.exists(bl):          # every family of the bench line that carries work must have found its counters
+    try:
+        fams = json.loads(open(bl).read().strip().splitlines()[-1])['roofline']['families']
+        missing = [k for k in fams if k not in out['kernels']]
+        print('families of the bench line WITHOUT PMC counters:', missing)
+    except Exception as e:
+        print('bench line not parsed:', e)
 print(open(os.path.join(ROOT, 'profiles', f'{tag}_kernel_summary.md')).read()[:6000])
