@@ -42,6 +42,8 @@ def fam(name):
         if args[0] == '2' and args[2] == 'true':
             return 'conv3_f16x3'
         return f'conv3_bf16x{3 if args[0] == "2" else 6}'
+    if base == 'conv1d_k64_wstat_kernel':             # in the train step: the K = 64 row GEMMs without a prologue (64 -> 128 input gradient)
+        return 'gemm_k64_panel_f16x3<0>'
     if base in ('gemm_k64_wstat_kernel',):            # the W-stationary row panel of the train step (scaled fp16 only)
         return f'gemm_k64_panel_f16x3<{args[0]}>'
     if base == 'gemm_k64_panel_kernel':
