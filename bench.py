@@ -47,6 +47,52 @@ def _oracle_step(B, threads):
     return time.time() - t0
 
 
+try:
+    _DW_TWIN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04_dwconv_twin.json')))['inside_step']
+except Exception:
+    _DW_TWIN = {}
+
+
+def _pipe16_parts(key):
+    """16-bit MFMAs a kernel family executes per fp32-equivalent product (None: fp32 MFMA / no MFMA)"""
+    if 'f16x3' in key or 'bf16x3' in key:
+        return 3
+    if 'bf16x6' in key:
+        return 6
+    return None
+
+
+def _family_entry(key, v, steps, pmc):
+    """one line of roofline.families: time per step + the rate against the roof that bounds the family; every scaled-fp16 /
+    split-bf16 family ALSO carries frac_of_16bit_pipe (executed 16-bit MFMA rate / 2.5 PFLOP/s: the same arithmetic, one peak)"""
+    e = {'ms_per_step': round(v['ms'] / steps, 3)}
+    sec = v['ms'] * 1e-3
+    if key in ('stft_fused', 'istft_fused'):
+        # 0.64 MB per utterance and transform: latency-sized launches (0.2 % of the step); both roofs stated, neither binds
+        nbytes = v['flops'] / (2.0 * 400 * 402) * (400 + 402) * 4.0          # frames x (400 samples in + 402 plane floats out)
+        e.update({'tflops': round(v['flops'] / sec / 1e12, 2), 'gbs': round(nbytes / sec / 1e9, 1),
+                  'frac_of_hbm_peak': round(nbytes / sec / 1e9 / PEAK_HBM_GBS, 4), 'bound': 'latency (10 MB per launch)'})
+    elif v['flops'] > 0:
+        tf = v['flops'] / sec / 1e12
+        e['tflops'] = round(tf, 2)
+        if _pipe16_parts(key):
+            e['frac_of_16bit_pipe'] = round(tf * _pipe16_parts(key) / PEAK_BF16_MFMA_TFLOPS, 4)
+        else:
+            e['frac_of_f32_mfma'] = round(tf / PEAK_F32_MFMA_TFLOPS, 4)
+    else:                                                                     # HBM-bound families: algorithmic bytes
+        e.update({'gbs': round(v['bytes'] / sec / 1e9, 1), 'frac_of_hbm_peak': round(v['bytes'] / sec / 1e9 / PEAK_HBM_GBS, 3)})
+    if key in _DW_TWIN:          # committed measurement of the access-pattern twin (profiles/r04_dwconv_twin.json): the structure's ceiling
+        e['access_pattern_twin_gbs'] = _DW_TWIN[key]['twin_gbs']
+        e['access_pattern_twin_frac_of_hbm_peak'] = round(_DW_TWIN[key]['twin_gbs'] / PEAK_HBM_GBS, 3)
+        e['twin_source'] = 'profiles/r04_dwconv_twin.json (same loads / LDS staging / stores without the 31-tap FIR, inside the step)'
+    p = pmc.get(key, {})
+    if p.get('traffic_bytes_per_launch') is not None:
+        e['traffic_bytes_per_launch_pmc'] = p['traffic_bytes_per_launch']
+    if p.get('mfma_busy_pct'):
+        e['mfma_busy_pct_pmc'] = p['mfma_busy_pct']
+    return e
+
+
 def cpu_baseline(budget_s=40.0):
     """The CPU oracle's CMGAN train step (torch-CPU port of the reference step: AdamW, PESQ labels supplied) timed on
     the host cores: thread count chosen by a quick sweep of a generator-only forward, then 1 warm-up + up to 3 timed
@@ -279,6 +325,8 @@ def main():
             roof = {'bound': 'mfma', 'kernel': k, 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
                     'frac': round(ach / peak, 4), 'traffic': traffic, 'mfma_busy_pct_pmc': mfma_busy,
                     'traffic_source': traffic_source, 'note': note}
+            if _pipe16_parts(k):
+                roof['frac_of_16bit_pipe'] = round(ach * _pipe16_parts(k) / PEAK_BF16_MFMA_TFLOPS, 4)
         cv = conc.get(k)
         # the two bars BASELINE.json's north_star names: attention vs the fp32-MFMA peak, depthwise conv vs the HBM peak
         secondary = []
@@ -290,13 +338,17 @@ def main():
                                   'launches_per_step': vv['launches'] // a.steps,
                                   'avg_launch_ms': round(vv['ms'] / vv['launches'], 4),
                                   'traffic': pmc.get(kk, {}).get('traffic_bytes_per_launch'), 'traffic_source': traffic_source,
+                                  'frac_of_16bit_pipe': round(ach2 * _pipe16_parts(kk) / PEAK_BF16_MFMA_TFLOPS, 4) if _pipe16_parts(kk) else None,
+                                  'mfma_busy_pct_pmc': pmc.get(kk, {}).get('mfma_busy_pct'),
                                   'note': 'algorithmic fp32 FLOPs of QK^T, q.E, AV (+ their backward) / family launch time; '
-                                          'peak = dense fp32 MFMA'})
+                                          'peak = dense fp32 MFMA (the bar north_star names); frac_of_16bit_pipe = the same work priced '
+                                          'like conv3: executed 16-bit MFMAs (3 per product) / 2.5 PFLOP/s'})
             elif kk.startswith('conv3_') and vv['flops'] > 0:
                 parts2 = 6 if 'bf16x6' in kk else 3
                 ach2 = vv['flops'] / (vv['ms'] * 1e-3) / 1e12
                 secondary.append({'bound': 'mfma', 'kernel': kk, 'achieved': round(ach2, 2), 'peak': round(PEAK_BF16_MFMA_TFLOPS / parts2, 1),
                                   'unit': 'TFLOP/s', 'frac': round(ach2 * parts2 / PEAK_BF16_MFMA_TFLOPS, 4),
+                                  'frac_of_16bit_pipe': round(ach2 * parts2 / PEAK_BF16_MFMA_TFLOPS, 4),
                                   'launches_per_step': vv['launches'] // a.steps, 'avg_launch_ms': round(vv['ms'] / vv['launches'], 4),
                                   'traffic': pmc.get(kk, {}).get('traffic_bytes_per_launch'), 'traffic_source': traffic_source,
                                   'mfma_busy_pct_pmc': pmc.get(kk, {}).get('mfma_busy_pct'),
@@ -320,12 +372,12 @@ def main():
                                      f'{conc_steps} instrumented steps after the timed region (launches of the three streams overlap: '
                                      f'elapsed time per launch is not the kernel\'s own)'),
                      'share_of_step_time': round(v['ms'] / a.steps / (dt / a_steps * 1e3), 3),
-                     'families': {kk: ({'ms_per_step': round(vv['ms'] / a.steps, 3),
-                                        'tflops': round(vv['flops'] / (vv['ms'] * 1e-3) / 1e12, 2)} if vv['flops'] > 0 else
-                                       {'ms_per_step': round(vv['ms'] / a.steps, 3),      # HBM-bound families: algorithmic bytes
-                                        'gbs': round(vv['bytes'] / (vv['ms'] * 1e-3) / 1e9, 1),
-                                        'frac_of_hbm_peak': round(vv['bytes'] / (vv['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)})
-                                  for kk, vv in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}})
+                     'families': {kk: _family_entry(kk, vv, a.steps, pmc) for kk, vv in sorted(summ.items(), key=lambda kv: -kv[1]['ms'])}})
+        # step-level figures of the committed profile (separate rocprofv3 passes in serial stream order; NOT measured in this run)
+        if os.path.exists(tpath) and pj.get('step'):
+            roof['step_profile'] = dict(pj['step'], source=traffic_source,
+                                        note='time-weighted MFMA-busy over every kernel of a step and HBM-side bytes per step '
+                                             '(2 FETCH_SIZE + WRITE_SIZE over all launches), from the committed PMC passes')
     a = argparse.Namespace(**{**vars(a), 'steps': a_steps})
     res = {
         'metric': 'utterances/sec (2 s @16 kHz) CMGAN train step', 'value': round(world * B * a.steps / dt, 3),

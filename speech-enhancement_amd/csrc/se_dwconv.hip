@@ -54,7 +54,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // dZ[:, 128 + c] = dU a sigmoid(g) (1 - sigmoid(g)) = dU u (1 - sigmoid(g)) with u = a sigmoid(g) the forward GLU result (so the
 // pre-GLU value half a is never stored: 266 MB less written by the pw1 GEMM and read here, per block) -- the stand-alone glu_bwd pass (read Z and dU, write dZ: 1.33 GB per block at
 // batch 16, 214 us x 8 per step) and the write + re-read of dU disappear; max |dZ| is raised for the scaled-fp16 consumers.
-template <int PPS, bool GLU = false>
+// TWIN (timing only, SE_DW_TWIN=1: wrong results): the exact load / LDS staging / store pattern of the kernel with the 31-tap FIR
+// replaced by one LDS read per output -- what the access pattern alone costs inside the step
+template <int PPS, bool GLU = false, bool TWIN = false>
 __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
   constexpr int TILE = 8 * PPS, ROWS = TILE + DW_K - 1;
   __shared__ __attribute__((aligned(16))) float xs[ROWS * DW_C];
@@ -113,10 +115,14 @@ __global__ __launch_bounds__(512, 4) void dwconv_kernel(DwArgs a) {
     constexpr int NR = PPS + DW_K - 1, NG = (NR + 3) / 4;
     const float* xrow = &xs[(ps * PPS) * DW_C + cl * 2];
     f32x2 xg[2][4];
+    if constexpr (TWIN) {
+#pragma unroll
+      for (int o = 0; o < PPS; ++o) acc[o] = *reinterpret_cast<const f32x2*>(xrow + (o + 15) * DW_C) * w[15];
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) xg[0][j] = *reinterpret_cast<const f32x2*>(xrow + j * DW_C);
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    for (int g = 0; g < (TWIN ? 0 : NG); ++g) {
       asm volatile("" ::: "memory");
       if (g + 1 < NG) {
 #pragma unroll
@@ -353,7 +359,10 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
   const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
   const long nitems = (long)nseq * cdiv(n, 8 * pps);
   const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;    // persistent: 2 workgroups (<= 72 KB LDS each) per CU; multiple of 8
-  if (pps == 8) hipLaunchKernelGGL(dwconv_kernel<8>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  static const bool twin = getenv("SE_DW_TWIN") != nullptr;
+  if (twin && pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, false, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (twin && pps == 14) hipLaunchKernelGGL((dwconv_kernel<14, false, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (pps == 8) hipLaunchKernelGGL(dwconv_kernel<8>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else if (pps == 13) hipLaunchKernelGGL(dwconv_kernel<13>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else hipLaunchKernelGGL(dwconv_kernel<14>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31");
@@ -368,7 +377,10 @@ extern "C" int se_dwconv31_glu_bwd(const float* dH, const float* W, const float*
   const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
   const long nitems = (long)nseq * cdiv(n, 8 * pps);
   const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;
-  if (pps == 8) hipLaunchKernelGGL((dwconv_kernel<8, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  static const bool twin = getenv("SE_DW_TWIN") != nullptr;
+  if (twin && pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, true, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (twin && pps == 14) hipLaunchKernelGGL((dwconv_kernel<14, true, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (pps == 8) hipLaunchKernelGGL((dwconv_kernel<8, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else if (pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else hipLaunchKernelGGL((dwconv_kernel<14, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31_glu_bwd");

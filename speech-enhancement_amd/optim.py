@@ -50,6 +50,7 @@ class FlatOptimizer:
         self.trust_coefficient, self.max_grad_norm = trust_coefficient, max_grad_norm
         self.bias_correction, self.grad_averaging = bias_correction, grad_averaging
         self.trust_clip, self.always_adapt = trust_clip, always_adapt
+        subs = []
         for g in groups:
             params = [p for p in g['params']]
             if not params:
@@ -61,18 +62,26 @@ class FlatOptimizer:
                 sub = [hi, lo]
             else:
                 sub = [dict(g, params=params)]
-            for sg in sub:
-                self._add_group(sg, lr, weight_decay)
+            subs.extend(sub)
+        # ONE gradient allocation for the whole model (the groups are 16-byte-aligned slices of it): the data-parallel exchange is a
+        # single all-reduce per model and step (main_gan.py:133-171's DDP buckets), zero_grad a single fill
+        dev0 = subs[0]['params'][0].device
+        pads = [(sum(p.numel() for p in sg['params']) + 3) // 4 * 4 for sg in subs]
+        self._grad_all = torch.zeros(sum(pads), device=dev0, dtype=torch.float32)
+        o = 0
+        for sg, npad in zip(subs, pads):
+            self._add_group(sg, lr, weight_decay, self._grad_all[o:o + npad])
+            o += npad
         dev = self.param_groups[0]['flat'].device
         self._sums = torch.zeros(len(self.param_groups), device=dev, dtype=torch.float64)
 
-    def _add_group(self, g, lr, weight_decay):
+    def _add_group(self, g, lr, weight_decay, grad_buf):
         params = g['params']
         n = sum(p.numel() for p in params)
         dev = params[0].device
         npad = (n + 3) // 4 * 4
         flat = torch.zeros(npad, device=dev, dtype=torch.float32)[:n]
-        grad = torch.zeros(npad, device=dev, dtype=torch.float32)[:n]
+        grad = grad_buf[:n]
         o, offs = 0, [0]
         for p in params:
             k = p.numel()
@@ -95,11 +104,12 @@ class FlatOptimizer:
         self.param_groups.append(grp)
 
     def flat_grads(self):
-        return [g['grad'] for g in self.param_groups]
+        """the buffers a data-parallel exchange reduces: ONE per optimizer (every group's gradient is a slice of it)"""
+        return [self._grad_all]
 
     def zero_grad(self, set_to_none=False):
+        self._grad_all.zero_()
         for g in self.param_groups:
-            g['grad'].zero_()
             o = 0
             for p in g['params']:          # keep .grad aliased to the flat buffer
                 k = p.numel()
