@@ -1954,25 +1954,32 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     static const int bwd4_mode = getenv("SE_ATTN_BWD4") ? atoi(getenv("SE_ATTN_BWD4")) : 3;
     if (f16) {
       const int nkt = (n + 15) / 16;
-      // <4 waves, 6 key tiles, 3 classes> (two workgroups per CU) for 8 <= nkt <= 21 (n = 321: 5+5+5+6 key tiles), <4, 2, 2> (three
-      // per CU) up to nkt = 7 (n = 101)
+      // 8 <= nkt <= 21 (n = 321): four waves (two workgroups per CU), up to 6 key tiles and 3 classes per wave; nkt <= 7 (n = 101): two
+      // waves with up to 4 key tiles and 2 classes (SE_ATTN_BWD4_SMALL_NW=4: four waves, 2 tiles / 1 class: 0.79 vs 0.77 ms)
+      static const int small_nw = getenv("SE_ATTN_BWD4_SMALL_NW") ? atoi(getenv("SE_ATTN_BWD4_SMALL_NW")) : 2;
       const bool small = nkt <= 7;
-      const AttnBwd4Plan pl = small ? attn_bwd4_plan(nkt, 4, 1) : attn_bwd4_plan(nkt, 4, 3);
+      const AttnBwd4Plan pl = small ? (small_nw == 4 ? attn_bwd4_plan(nkt, 4, 1) : attn_bwd4_plan(nkt, 2, 2)) : attn_bwd4_plan(nkt, 4, 3);
       int kmax = 0;
       for (int w4 = 0; w4 < 8; ++w4) kmax = pl.cnt[w4] > kmax ? pl.cnt[w4] : kmax;
-      const bool fits = pl.M > 0 && (small ? kmax <= 2 : (kmax <= 6 && nkt <= 21));
-      const size_t shr = small ? attn_bwd4_lds<4, 7>(nkt) : attn_bwd4_lds<4, 21>(nkt);
+      const bool fits = pl.M > 0 && (small ? kmax <= (small_nw == 4 ? 2 : 4) : (kmax <= 6 && nkt <= 21));
+      const size_t shr = small ? (small_nw == 4 ? attn_bwd4_lds<4, 7>(nkt) : attn_bwd4_lds<2, 7>(nkt)) : attn_bwd4_lds<4, 21>(nkt);
       if (fits && (bwd4_mode & (small ? 1 : 2))) {
         if (phase & 1) {
-          if (small) {
-            // (four waves per SIMD at 128 VGPRs was measured: spills in the key phase, 1.00 vs 0.79 ms)
+          if (small && small_nw == 4) {
             static unsigned raised_s = 0;
-            SE_REQUIRE(se_raise_lds((const void*)attn_bwd4_kernel<4, 2, 1, 7, 3>, shr, &raised_s), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
-            hipLaunchKernelGGL((attn_bwd4_kernel<4, 2, 1, 7, 3>), dim3(items), dim3(256), shr, s, b, pl);
+            auto kfn = attn_bwd4_kernel<4, 2, 1, 7, 3, 2, 1, 2, 1, 1, 1>;
+            SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_s), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+            hipLaunchKernelGGL(kfn, dim3(items), dim3(256), shr, s, b, pl);
+          } else if (small) {                  // two waves, 256 VGPRs: four workgroups per CU (168 VGPRs: spills in the key phase, 1.00 ms)
+            static unsigned raised_s2 = 0;
+            auto kfn = attn_bwd4_kernel<2, 4, 2, 7, 2, 3, 2, 4, 2>;
+            SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_s2), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+            hipLaunchKernelGGL(kfn, dim3(items), dim3(128), shr, s, b, pl);
           } else {
             static unsigned raised_b = 0;
-            SE_REQUIRE(se_raise_lds((const void*)attn_bwd4_kernel<4, 6, 3, 21, 2>, shr, &raised_b), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
-            hipLaunchKernelGGL((attn_bwd4_kernel<4, 6, 3, 21, 2>), dim3(items), dim3(256), shr, s, b, pl);
+            auto kfn = attn_bwd4_kernel<4, 6, 3, 21, 2, 5, 3, 6, 2>;
+            SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_b), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+            hipLaunchKernelGGL(kfn, dim3(items), dim3(256), shr, s, b, pl);
           }
         }
         if (phase & 2) hipLaunchKernelGGL(attn_de_reduce_items_kernel, dim3(2 * nkt, cdiv(items, 256)), dim3(256), 0, s, b.dEs, dE, items, nkt,

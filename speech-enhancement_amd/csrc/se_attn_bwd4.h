@@ -195,6 +195,10 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   }
   if (wave == 0) stage_store();
 
+  // short sequences (few key steps per query tile: the raw rows of the next tile do not arrive within one key phase): the loader
+  // requests its rows TWO query tiles ahead and holds them in registers for one tile
+  constexpr bool PF2 = KPW <= 4;
+  if (PF2 && wave == 1 % NW && nqt > 1) stage_load(1);
   constexpr int NCA = NC > 0 ? NC : 1;                       // (array extents; NC = 0: a wave without offset tiles)
   f32x4 dk[CN], dv[CN], de0[NCA], de1[NCA];
   int j0[NCA];                                               // position of the younger tile of class ci at this query tile
@@ -288,8 +292,9 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
 #pragma unroll
       for (int t = 0; t < 2; ++t) ecs[2 * ci + t] = e_cols(qt, j0[ci] + M * t, own(ci, j0[ci] + M * t));
     }
-    const bool loader = more && wave == (qt + 1) % NW;                   // wave-uniform
-    if (loader) stage_load(qt + 1);
+    const bool loader = more && wave == (qt + 1) % NW;                   // wave-uniform: stores the stage of tile qt + 1 at the end of P1
+    if (PF2) { if (qt + 2 < nqt && wave == (qt + 2) % NW) stage_load(qt + 2); }
+    else if (loader) stage_load(qt + 1);
 
     f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                     // dQ^T[d = 4g + r][q = c]: K^T dS^T part
     f32x4 dq2 = {0.f, 0.f, 0.f, 0.f}, dq3 = {0.f, 0.f, 0.f, 0.f};        // E^T W^T part (its own scale; two chains)
@@ -499,24 +504,23 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   }
 }
 
-// MINW: waves per SIMD the register allocation is bounded for.  Exact bodies (TL: with the key mask of the tail tile, which is the
-// last tile of the last wave): KPW = 6 (n = 321: key tiles 5 + 5 + 5 + 6, classes 3 + 3 + 3 + 2): (5, 3) for the first waves,
-// (6, 2, TL) for the last; KPW = 2 (n = 101: 1 + 2 + 2 + 2, one class each): (1, 1), (2, 1), (2, 1, TL); every other split takes
-// the tested body.  Every body runs the same barriers (2 + 2 per query tile).
-template <int NW, int KPW, int NCW, int NKTM, int MINW>
+// MINW: waves per SIMD the register allocation is bounded for.  Exact bodies are named by the instantiation: (CA key tiles, NA
+// classes) for the waves before the last one, (CB, NB) with the key mask of the tail tile (TL) for the last wave, optionally a
+// second pair (CC, NC_) for earlier waves (CC < 0: none); every other split takes the tested body.  n = 321: four waves, key tiles
+// 5 + 5 + 5 + 6, classes 3 + 3 + 3 + 2 -> A = (5, 3), B = (6, 2).  n = 101: two waves, 3 + 4 key tiles, 2 + 2 classes -> A = (3, 2),
+// B = (4, 2) (four waves with 1 + 2 + 2 + 2 key tiles: 0.79 vs 0.77 ms).
+// Every body runs the same barriers (2 + 2 per query tile).
+template <int NW, int KPW, int NCW, int NKTM, int MINW, int CA, int NA, int CB, int NB, int CC = -1, int NC_ = 0>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_bwd4_kernel(AttnBwd3Args a, AttnBwd4Plan pl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkt = (a.g.n + 15) >> 4;
   const int cnt = pl.cnt[wave], ncls = pl.ncls[wave];
   const bool full = 2 * pl.M == nkt + 1 && !(a.dbg & 64), last = wave == NW - 1;
-  if constexpr (KPW > 2) {
-    if (full && last && cnt == KPW && ncls == NCW - 1) return attn_bwd4_body<NW, KPW, NCW, NKTM, KPW, NCW - 1, true, true>(a, pl, smem4, wave, lane);
-    if (full && !last && cnt == KPW - 1 && ncls == NCW) return attn_bwd4_body<NW, KPW, NCW, NKTM, KPW - 1, NCW, true, false>(a, pl, smem4, wave, lane);
-  } else {
-    if (full && last && cnt == KPW && ncls == NCW) return attn_bwd4_body<NW, KPW, NCW, NKTM, KPW, NCW, true, true>(a, pl, smem4, wave, lane);
-    if (full && !last && cnt == KPW && ncls == NCW) return attn_bwd4_body<NW, KPW, NCW, NKTM, KPW, NCW, true, false>(a, pl, smem4, wave, lane);
-    if (full && !last && cnt == KPW - 1 && ncls == NCW) return attn_bwd4_body<NW, KPW, NCW, NKTM, KPW - 1, NCW, true, false>(a, pl, smem4, wave, lane);
+  if (full && last && cnt == CB && ncls == NB) return attn_bwd4_body<NW, KPW, NCW, NKTM, CB, NB, true, true>(a, pl, smem4, wave, lane);
+  if (full && !last && cnt == CA && ncls == NA) return attn_bwd4_body<NW, KPW, NCW, NKTM, CA, NA, true, false>(a, pl, smem4, wave, lane);
+  if constexpr (CC >= 0) {
+    if (full && !last && cnt == CC && ncls == NC_) return attn_bwd4_body<NW, KPW, NCW, NKTM, (CC >= 0 ? CC : 1), NC_, true, false>(a, pl, smem4, wave, lane);
   }
   attn_bwd4_body<NW, KPW, NCW, NKTM, KPW, NCW, false, true>(a, pl, smem4, wave, lane);
 }
