@@ -1161,9 +1161,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
   // 16-B bank groups (column-major cells made every staging write a 4-way bank conflict: 0.68 conflict cycles per active one)
   auto swz = [](int c) { return 64 * (c & 3) + (((c >> 2) + 4 * (c & 3)) & 63); };
   const int wf0 = swz(wave * 64 + l31), wf1 = swz(wave * 64 + 32 + l31);
-  const __bf16* abase = XW ? Ns + (half * NARROW + l31) * 8 : Ws + (half * WIDE) * 8;
-  const __bf16* bbase = XW ? Ws + (half * WIDE) * 8 : Ns + (half * NARROW + l31) * 8;
-  const int aoff[2] = {XW ? 0 : wf0 * 8, XW ? 32 * 8 : wf1 * 8}, boff[2] = {XW ? wf0 * 8 : 0, XW ? wf1 * 8 : 32 * 8};
+  // narrow image (round 4): the same swizzle on 64 columns -- column c in cell 16 (c & 3) + ((c >> 2) + 4 (c & 3)) mod 16.  Column-
+  // major cells put the 16 lanes of a staging write (columns 4 t + j: 16 dwords apart) on 2 banks x the row-pair dword: an 8-way
+  // conflict on each of the 8 ds_write_b32 per lane and step (SQ_LDS_BANK_CONFLICT / IDX_ACTIVE 0.44 - 0.54 in profiles/r04a)
+  auto swn = [](int c) { return 16 * (c & 3) + (((c >> 2) + 4 * (c & 3)) & 15); };
+  const int nf0 = swn(l31), nf1 = swn(32 + l31);
+  const __bf16* abase = XW ? Ns + (half * NARROW) * 8 : Ws + (half * WIDE) * 8;
+  const __bf16* bbase = XW ? Ws + (half * WIDE) * 8 : Ns + (half * NARROW) * 8;
+  const int aoff[2] = {XW ? nf0 * 8 : wf0 * 8, XW ? nf1 * 8 : wf1 * 8}, boff[2] = {XW ? wf0 * 8 : nf0 * 8, XW ? wf1 * 8 : nf1 * 8};
   constexpr int APL = XW ? NPLN : WPLN, BPL = XW ? WPLN : NPLN, AOC = (XW ? NARROW : WIDE) * 8, BOC = (XW ? WIDE : NARROW) * 8;
   const bool active = wave * 64 < wcols;                              // a wave whose whole block is padding idles
   for (long mb = mbeg; mb < mend; mb += MR) {
@@ -1190,15 +1195,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
       float4 v1 = fix(rn[1], !XW, nq, nok, (!XW && PRO == SE_PRO_LN) ? sn[1] : make_float2(0.f, 0.f), psn, pbn, mb + 2 * nrp + 1);
       if (XW && do_bias) { bsum.x += v0.x + v1.x; bsum.y += v0.y + v1.y; bsum.z += v0.z + v1.z; bsum.w += v0.w + v1.w; }
       float a4[4] = {v0.x, v0.y, v0.z, v0.w}, b4[4] = {v1.x, v1.y, v1.z, v1.w};
-      unsigned* cell = reinterpret_cast<unsigned*>(&Ns[((nrp >> 2) * NARROW + nq) * 8 + 2 * (nrp & 3)]);
+      // (swizzled cells: column nq + j = 4 t + j -> cell 16 j + (t + 4 j) mod 16, t = tid & 15)
+      unsigned* cell = reinterpret_cast<unsigned*>(&Ns[((nrp >> 2) * NARROW) * 8 + 2 * (nrp & 3)]);
+      const int tq = tid & 15;
       if constexpr (F16) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float ya = a4[j] * s_narrow, yb = b4[j] * s_narrow;
           const unsigned w = pk_f16_(ya, yb);
           const f16x2_ hh = __builtin_bit_cast(f16x2_, w);
-          cell[(j * 8) / 2] = w;
-          cell[(NPLN + j * 8) / 2] = pk_f16_(ya - (float)hh[0], yb - (float)hh[1]);
+          const int pc = (16 * j + ((tq + 4 * j) & 15)) * 8;
+          cell[pc / 2] = w;
+          cell[(NPLN + pc) / 2] = pk_f16_(ya - (float)hh[0], yb - (float)hh[1]);
         }
       } else {
 #pragma unroll
@@ -1206,7 +1214,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_lin_bf16_kernel(WgradArgs g) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const unsigned w = pk_bf16_(a4[j], b4[j]);
-            cell[(q * NPLN + j * 8) / 2] = w;
+            cell[(q * NPLN + (16 * j + ((tq + 4 * j) & 15)) * 8) / 2] = w;
             if (q < 2) { a4[j] -= __builtin_bit_cast(float, w << 16); b4[j] -= __builtin_bit_cast(float, w & 0xffff0000u); }
           }
       }
