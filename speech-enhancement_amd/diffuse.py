@@ -96,7 +96,9 @@ class DiffuSE(nn.Module):
     # ---- weight packing (once per weight version) ----------------------------------------------------------------
     def _pack(self):
         # data_ptr and device too: model.to(device) / p.data = ... swap the storage without bumping _version
-        ver = tuple((p._version, p.data_ptr(), str(p.device)) for p in self.parameters())
+        # ... and the arithmetic mode the planes are built for (tests flip it in-process: a stale pack would compare a mode with itself)
+        mode = (LY.CONV_PRECISION, os.environ.get('SE_DIFFUSE_PRECISION', 'f16x3'))
+        ver = (mode,) + tuple((p._version, p.data_ptr(), str(p.device)) for p in self.parameters())
         if self._packed is not None and self._packed['ver'] == ver:
             return self._packed
         Cc, nl = self.C, len(self.residual_layers)

@@ -63,6 +63,11 @@ def linear_desc(M, C_in, N, lda=None, ldc=None, **kw):
 def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb=None, stats=None):
     L.check_cuda(A, W, Y, bias, R, AUX, rowstats, ps, pb, stats)
     M = d.B * d.To * d.Fo
+    # the weight-form fields are written into a COPY: in gemm_tap_wgrad the descriptor's w_amax means the scale of dY (and switches
+    # precision 3 on), so a caller's descriptor reused there must not carry this call's weight scalar
+    keep = getattr(d, '_keep', None)
+    d = type(d).from_buffer_copy(d)
+    d._keep = keep
     if W.dtype == torch.bfloat16:        # weights pre-split by the step's WeightPlan: [3 planes][rows][ld] bf16
         if d.precision != 2:
             raise L.SeHipError('gemm_tap: bf16 weight planes need a precision-2 descriptor')

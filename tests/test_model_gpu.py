@@ -750,7 +750,7 @@ def test_world1_hooks_equal_plain_step(S):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('arch', ['cmgan', 'scp'])
+@pytest.mark.parametrize('arch', ['cmgan', 'scp', 'scp_cond'])
 def test_streams_do_not_change_the_step(S, arch):
     """HIP-stream concurrency inside a step (weight gradients on a leaf stream during the generator backward; + the two-stage
     backward with the discriminator step on a side stream) against the fully serial order: losses and EVERY parameter of both
@@ -765,6 +765,12 @@ def test_streams_do_not_change_the_step(S, arch):
     torch.manual_seed(5)
     clean = 0.1 * torch.randn(4, 3200, device='cuda')
     noisy = clean + 0.05 * torch.randn(4, 3200, device='cuda')
+    cond = arch == 'scp_cond'
+    if cond:
+        #  scp on a WELL-CONDITIONED clip pair (no near-zero bin in the re-analysed spectrum): the two-step parameter
+        # comparison holds there too, so a stream-ordering race on the scratch recycled in step 2 of scp is detected
+        arch = 'scp'
+        clean, noisy = (x.cuda() for x in formula.cond_signals(4, 3200, 7))
     labels = {'est': torch.tensor([0.4, 0.6, 0.5, 0.7], device='cuda'), 'clean': torch.full((4,), 0.96, device='cuda'),
               'noisy': torch.tensor([0.3, 0.2, 0.25, 0.35], device='cuda')}
     w = (0.1, 0.9, 0.2, 0.05) if arch == 'cmgan' else (0.3, 0.7, 0.2, 0.05)
@@ -791,13 +797,13 @@ def test_streams_do_not_change_the_step(S, arch):
             # re-ordering can cause: measured 3.7e-9 absolute between any two stream modes, tools/streams_diag.py with STEPS=1)
             # move single step-2 gradient tensors by percents in ANY two runs, serial or not
             res.append(([{k: float(v) for k, v in o.items()} for o in outs],
-                        first if arch == 'scp' else {n: p.detach().clone() for n, p in named()}))
+                        first if (arch == 'scp' and not cond) else {n: p.detach().clone() for n, p in named()}))
     finally:
         GM._LeafStream.enabled, TR._D_OVERLAP, GM.branch_stream.enabled = saved
     for other in (1, 2):
         for si, (o0, o1) in enumerate(zip(res[0][0], res[other][0])):
             for k in o0:
-                tol = 1e-4 if (arch == 'cmgan' or si == 0) else 5e-3
+                tol = 1e-4 if (arch == 'cmgan' or si == 0 or cond) else 5e-3
                 assert abs(o0[k] - o1[k]) <= tol * abs(o0[k]) + 1e-7, (other, si, k, o0[k], o1[k])
     bad = []
     for n, p0 in res[0][1].items():
