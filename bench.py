@@ -65,7 +65,7 @@ def _pipe16_parts(key):
 def _family_entry(key, v, steps, pmc):
     """one line of roofline.families: time per step + the rate against the roof that bounds the family; every scaled-fp16 /
     split-bf16 family ALSO carries frac_of_16bit_pipe (executed 16-bit MFMA rate / 2.5 PFLOP/s: the same arithmetic, one peak)"""
-    e = {'ms_per_step': round(v['ms'] / steps, 3)}
+    e = {'ms_per_step': round(v['ms'] / steps, 3), 'launches_per_step': round(v['launches'] / steps, 2)}
     sec = v['ms'] * 1e-3
     if key in ('stft_fused', 'istft_fused'):
         # 0.64 MB per utterance and transform: latency-sized launches (0.2 % of the step); both roofs stated, neither binds

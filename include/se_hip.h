@@ -470,6 +470,15 @@ int se_disc_tail_bwd(const float* dout, const float* ws, int B, int P, const flo
                      const float* W2, const float* sslope, float beta, float* dA, float* dW1, float* db1, float* dslope1,
                      float* dW2, float* db2, float* dsslope, void* stream);
 
+/* ---- the discriminator's first stage as direct kernels (csrc/se_thin.hip; round 4) ------------------------------------- */
+/* Conv2d(2, 16, 4, stride 2, padding 1, bias=False) of models/discriminator.py:39 on the transposed [T, F] image: X planes
+ * [B][T][F][4] (channels 0, 1), W in the PyTorch layout [16][2][4][4] (already spectrally normalised), R / dR [B][To][Fo][16],
+ * To = (T - 2) / 2 + 1.  fwd: stats (may be NULL) += fp64 (sum, sum of squares) per (b, channel) (the InstanceNorm that follows);
+ * dgrad: dX [B][T][F][4] written (channels 2, 3 zero); wgrad: dW [16][2][4][4] accumulated (zero-fill first). */
+int se_dconv1_fwd(const float* X, const float* W, float* R, double* stats, int B, int T, int F, int N, void* stream);
+int se_dconv1_dgrad(const float* dR, const float* W, float* dX, int B, int T, int F, int N, void* stream);
+int se_dconv1_wgrad(const float* X, const float* dR, float* dW, int B, int T, int F, int N, void* stream);
+
 /* ---- CDiffuSE denoiser glue (models/DiffuSE.py; csrc/se_diffuse.hip), channels-last [B, L, C] maps ---------------------- */
 /* SpectrogramUpsampler stage: ConvTranspose2d(1,1,[3,20], stride [1,10], padding [1,5]) + leaky_relu(0.4) on in [B][F][Tin];
  * layout 0: out [B][F][10 Tin], layout 1: out [B][10 Tin][ldo] (channels-last, the conditioner GEMM operand) */

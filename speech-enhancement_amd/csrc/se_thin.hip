@@ -1,0 +1,202 @@
+// "Thin" convolutions of the discriminator's first stage (models/discriminator.py:39-41: spectral-norm Conv2d(2, ndf, 4, 2, 1)),
+// round 4.  On the [T, F] grid of the magnitude planes this layer has 2 input channels (4 in the plane format, two of them zero),
+// ndf = 16 output channels and 16 taps with stride 2: as a tap GEMM it is a 128 x 64 x (16 taps x 16-channel chunk) tile problem
+// whose tiles are 94 % padding and whose transposed form (the input gradient) zero-fills 12 of its 16 taps per pixel -- measured
+// inside the step (bench.py with SE_KEY_SHAPES=1): forward 110 us x 3, input gradient 404 us (on the critical path of the
+// generator loss), weight gradient 397 us x 2 for 8 / 16 / 33 MB of operands.  Direct kernels, one pixel (quarter) per thread:
+//   forward        R[b][to][fo][n] = sum_{c, kh, kw} W[n][c][kh][kw] x[b][2 to + kw - 1][2 fo + kh - 1][c]   (+ InstanceNorm sums)
+//   input gradient dx[b][t][f][c]  = sum over the 2 x 2 output pixels and 4 taps of its parity class
+//   weight gradient dW[n][c][kh][kw] = sum_pixels dR[p][n] x[src(p, kh, kw)][c]
+// x: planes [B][T][F][4] (channels 0, 1 used); W: the PyTorch layout [16][2][4][4] (kh over F, kw over T: the image is processed
+// transposed, see discriminator.py); R, dR: [B][To][Fo][16].
+#include "se_common.h"
+
+namespace {
+constexpr int DN = 16;      // output channels (ndf); host-checked
+
+__device__ __forceinline__ double wave_sum_dd(double v) { return wave_sum_d(v); }
+
+// ---- forward: 4 threads per output pixel (4 channels each); one batch entry per blockIdx.y ----
+__global__ __launch_bounds__(256) void dconv1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ R,
+                                                         double* __restrict__ stats, int T, int F, int To, int Fo) {
+  __shared__ __attribute__((aligned(16))) float ws[DN * 32];      // [kh][kw][c][n]: a thread's 4 channels are one 16-byte read
+  __shared__ double red[4][DN][2];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int i = tid; i < DN * 32; i += 256) {           // W[n][c][kh][kw]
+    const int kw = i & 3, kh = (i >> 2) & 3, c = (i >> 4) & 1, n = i >> 5;
+    ws[((kh * 4 + kw) * 2 + c) * DN + n] = W[i];
+  }
+  __syncthreads();
+  const int cg = tid & 3;                              // channels 4 cg .. 4 cg + 3
+  const long P = (long)To * Fo;
+  const float* __restrict__ Xb = X + (long)b * T * F * 4;
+  float* __restrict__ Rb = R + (long)b * P * DN;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long p = (long)blockIdx.x * 64 + (tid >> 2); p < P; p += (long)gridDim.x * 64) {
+    const int to = (int)(p / Fo), fo = (int)(p - (long)to * Fo);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float2 xv[16];
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw) {
+      const int t = 2 * to + kw - 1;
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh) {
+        const int f = 2 * fo + kh - 1;
+        const bool ok = t >= 0 && t < T && f >= 0 && f < F;
+        const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t), fc = f < 0 ? 0 : (f >= F ? F - 1 : f);      // (unconditional loads)
+        const float2 v = *reinterpret_cast<const float2*>(Xb + ((long)tc * F + fc) * 4);
+        xv[kh * 4 + kw] = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float4 w0 = *reinterpret_cast<const float4*>(&ws[(k * 2 + 0) * DN + 4 * cg]);
+      const float4 w1 = *reinterpret_cast<const float4*>(&ws[(k * 2 + 1) * DN + 4 * cg]);
+      acc[0] = fmaf(w0.x, xv[k].x, fmaf(w1.x, xv[k].y, acc[0]));
+      acc[1] = fmaf(w0.y, xv[k].x, fmaf(w1.y, xv[k].y, acc[1]));
+      acc[2] = fmaf(w0.z, xv[k].x, fmaf(w1.z, xv[k].y, acc[2]));
+      acc[3] = fmaf(w0.w, xv[k].x, fmaf(w1.w, xv[k].y, acc[3]));
+    }
+    *reinterpret_cast<float4*>(Rb + p * DN + 4 * cg) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s[j] += acc[j]; q[j] = fmaf(acc[j], acc[j], q[j]); }
+  }
+  if (stats) {            // (sum, sum of squares) per (b, channel): lanes with equal cg folded, then the four waves, fp64 atomics
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 4; o < 64; o <<= 1) { s[j] += __shfl_xor(s[j], o, 64); q[j] += __shfl_xor(q[j], o, 64); }
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[wave][4 * lane + j][0] = s[j]; red[wave][4 * lane + j][1] = q[j]; }
+    }
+    __syncthreads();
+    if (tid < 2 * DN) {
+      const int n = tid >> 1, k = tid & 1;
+      const double v = red[0][n][k] + red[1][n][k] + red[2][n][k] + red[3][n][k];
+      atomicAdd(&stats[((long)b * DN + n) * 2 + k], v);
+    }
+  }
+}
+
+// ---- input gradient: one input pixel per thread; dx channels 2, 3 are the zero padding of the plane format ----
+__global__ __launch_bounds__(256) void dconv1_dgrad_kernel(const float* __restrict__ dR, const float* __restrict__ W, float* __restrict__ dX,
+                                                           int T, int F, int To, int Fo) {
+  __shared__ float ws[4 * 4 * DN * 2];                // [kw][kh][n][c]
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int i = tid; i < DN * 32; i += 256) {           // W[n][c][kh][kw]
+    const int kw = i & 3, kh = (i >> 2) & 3, c = (i >> 4) & 1, n = i >> 5;
+    ws[((kw * 4 + kh) * DN + n) * 2 + c] = W[i];
+  }
+  __syncthreads();
+  const long P = (long)T * F;
+  const float* __restrict__ Rb = dR + (long)b * To * Fo * DN;
+  float* __restrict__ Xb = dX + (long)b * P * 4;
+  for (long p = (long)blockIdx.x * 256 + tid; p < P; p += (long)gridDim.x * 256) {
+    const int t = (int)(p / F), f = (int)(p - (long)t * F);
+    float a0 = 0.f, a1 = 0.f;
+    // t = 2 to + kw - 1: kw has the parity of t + 1; the same in f
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kw = ((t + 1) & 1) + 2 * i, to = (t + 1 - kw) >> 1;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kh = ((f + 1) & 1) + 2 * j, fo = (f + 1 - kh) >> 1;
+        if (to >= 0 && to < To && fo >= 0 && fo < Fo) {
+          const float4* __restrict__ r4 = reinterpret_cast<const float4*>(Rb + ((long)to * Fo + fo) * DN);
+          const float* w = &ws[(kw * 4 + kh) * DN * 2];
+#pragma unroll
+          for (int n4 = 0; n4 < 4; ++n4) {
+            const float4 v = r4[n4];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a0 = fmaf(vv[e], w[(4 * n4 + e) * 2], a0);
+              a1 = fmaf(vv[e], w[(4 * n4 + e) * 2 + 1], a1);
+            }
+          }
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(Xb + p * 4) = make_float4(a0, a1, 0.f, 0.f);
+  }
+}
+
+// ---- weight gradient: a workgroup walks chunks of up to 64 output pixels of one row (b, to); the chunk's dR tile and its 4-row
+// input window are staged in LDS by coalesced loads, thread (tap, n) sums its two input channels over the chunk ----
+__global__ __launch_bounds__(256) void dconv1_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dR, float* __restrict__ dW,
+                                                           int B, int T, int F, int To, int Fo, int fchunks) {
+  constexpr int FC = 64, XW = 2 * FC + 2;
+  __shared__ __attribute__((aligned(16))) float rs[FC * DN];
+  __shared__ float2 xs[4][XW];
+  const int tid = threadIdx.x, n = tid & 15, tap = tid >> 4, kw = tap & 3, kh = tap >> 2;
+  const long nchunk = (long)B * To * fchunks;
+  double d0 = 0.0, d1 = 0.0;                           // fp32 inside a chunk (64 terms), fp64 across a workgroup's chunks
+  for (long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    float a0 = 0.f, a1 = 0.f;
+    const int fcix = (int)(ch % fchunks);
+    const long bt = ch / fchunks;
+    const int to = (int)(bt % To), b = (int)(bt / To), fo0 = fcix * FC;
+    const int nf = Fo - fo0 < FC ? Fo - fo0 : FC;
+    __syncthreads();                                   // the previous chunk is consumed
+    {
+      const int p = tid >> 2, q4 = tid & 3;            // dR tile: 64 pixels x 16 channels = 256 float4
+      const float4 v = p < nf ? *reinterpret_cast<const float4*>(dR + (((long)b * To + to) * Fo + fo0 + p) * DN + 4 * q4)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&rs[p * DN + 4 * q4]) = v;
+    }
+    for (int i = tid; i < 4 * XW; i += 256) {          // input window: rows 2 to - 1 .. 2 to + 2, columns 2 fo0 - 1 .. 2 fo0 + 2 FC
+      const int r = i / XW, cc = i - r * XW;
+      const int t = 2 * to + r - 1, f = 2 * fo0 + cc - 1;
+      const bool ok = t >= 0 && t < T && f >= 0 && f < F;
+      const int tc = t < 0 ? 0 : (t >= T ? T - 1 : t), fc = f < 0 ? 0 : (f >= F ? F - 1 : f);
+      const float2 v = *reinterpret_cast<const float2*>(X + (((long)b * T + tc) * F + fc) * 4);
+      xs[r][cc] = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < FC; ++p) {                     // (pixels past nf carry dR = 0)
+      const float r = rs[p * DN + n];
+      const float2 x = xs[kw][2 * p + kh];
+      a0 = fmaf(r, x.x, a0);
+      a1 = fmaf(r, x.y, a1);
+    }
+    d0 += (double)a0;
+    d1 += (double)a1;
+  }
+  // dW[n][c][kh][kw] (accumulated: the caller zero-fills)
+  atomicAdd(&dW[(n * 2 + 0) * 16 + kh * 4 + kw], (float)d0);
+  atomicAdd(&dW[(n * 2 + 1) * 16 + kh * 4 + kw], (float)d1);
+}
+}  // namespace
+
+extern "C" int se_dconv1_fwd(const float* X, const float* W, float* R, double* stats, int B, int T, int F, int N, void* stream) {
+  SE_REQUIRE(X && W && R && B > 0 && T > 1 && F > 1 && N == DN, "dconv1_fwd: bad arguments (N = %d: built for ndf = 16)", N);
+  const int To = (T + 2 - 4) / 2 + 1, Fo = (F + 2 - 4) / 2 + 1;
+  const long P = (long)To * Fo;
+  long nb = (P + 64 * 4 - 1) / (64 * 4);               // ~4 pixel groups per workgroup: the 2 KB weight table is staged once per workgroup
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(dconv1_fwd_kernel, dim3((unsigned)nb, B), dim3(256), 0, as_stream(stream), X, W, R, stats, T, F, To, Fo);
+  return se_check_launch("se_dconv1_fwd");
+}
+
+extern "C" int se_dconv1_dgrad(const float* dR, const float* W, float* dX, int B, int T, int F, int N, void* stream) {
+  SE_REQUIRE(dR && W && dX && B > 0 && T > 1 && F > 1 && N == DN, "dconv1_dgrad: bad arguments (N = %d: built for ndf = 16)", N);
+  const int To = (T + 2 - 4) / 2 + 1, Fo = (F + 2 - 4) / 2 + 1;
+  long nb = ((long)T * F + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(dconv1_dgrad_kernel, dim3((unsigned)nb, B), dim3(256), 0, as_stream(stream), dR, W, dX, T, F, To, Fo);
+  return se_check_launch("se_dconv1_dgrad");
+}
+
+extern "C" int se_dconv1_wgrad(const float* X, const float* dR, float* dW, int B, int T, int F, int N, void* stream) {
+  SE_REQUIRE(X && dR && dW && B > 0 && T > 1 && F > 1 && N == DN, "dconv1_wgrad: bad arguments (N = %d: built for ndf = 16)", N);
+  const int To = (T + 2 - 4) / 2 + 1, Fo = (F + 2 - 4) / 2 + 1;
+  const int fchunks = (Fo + 63) / 64;
+  long nwg = (long)B * To * fchunks;                   // chunks; at most 512 workgroups (512 x 512 atomics at the end)
+  if (nwg > 512) nwg = 512;
+  hipLaunchKernelGGL(dconv1_wgrad_kernel, dim3((unsigned)nwg), dim3(256), 0, as_stream(stream), X, dR, dW, B, T, F, To, Fo, fchunks);
+  return se_check_launch("se_dconv1_wgrad");
+}

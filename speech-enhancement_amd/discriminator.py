@@ -18,6 +18,8 @@ from . import _lib as L
 from . import layers as LY
 from . import ops as O
 
+THIN_CONV1 = __import__('os').environ.get('SE_NO_THIN_CONV1') != '1'      # A/B switch: the first stage through the tap GEMM again
+
 # weight index (kh over F, kw over T)  ->  tap offset on the [T, F] grid
 D_TAPS = [(kw - 1, kh - 1) for kh in range(4) for kw in range(4)]
 
@@ -178,11 +180,16 @@ class _DConvStackFn(torch.autograd.Function):
         for i in range(4):
             N = Ws[i].shape[0]
             To, Fo = _out(Ti), _out(Fi)
-            wp = LY.pack_w(Ws[i].contiguous(), C_pad=Cin)
-            d = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2, epilogue=L.EPI_STATS)
             R = torch.empty(B, To, Fo, N, device=x.device, dtype=torch.float32)
             stats = LY.O.zeros(B, N, 2, device=x.device, dtype=torch.float64)
-            LY.GM.gemm_tap(d, x, wp, R, stats=stats)
+            if i == 0 and N == 16 and THIN_CONV1:
+                # 2 input channels, 16 taps, stride 2: a direct kernel (csrc/se_thin.hip) -- as a tap GEMM its tiles are 94 % padding
+                L.call('se_dconv1_fwd', L.ptr(x), L.ptr(Ws[0].detach().contiguous()), L.ptr(R), L.ptr(stats), C.c_int(B), C.c_int(Ti),
+                       C.c_int(Fi), C.c_int(N), L.stream(), _key='dconv1 (thin)', _bytes=4.0 * B * (Ti * Fi * 4 + To * Fo * N))
+            else:
+                wp = LY.pack_w(Ws[i].contiguous(), C_pad=Cin)
+                d = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2, epilogue=L.EPI_STATS)
+                LY.GM.gemm_tap(d, x, wp, R, stats=stats)
             a = torch.empty_like(R)
             mr = LY.inorm_prelu_fwd(R, stats, gs[i], bs[i], sl[i], a, N, 0)
             saved.append((x, R, mr, Ti, Fi, To, Fo, Cin, N))
@@ -202,12 +209,22 @@ class _DConvStackFn(torch.autograd.Function):
             x, R, mr, Ti, Fi, To, Fo, Cin, N = ctx.saved[i]
             dR = LY.inorm_prelu_bwd(R, mr, gs[i], bs[i], sl[i], dy, N, 0, dg[i], db[i], ds[i])
             need_dx = i > 0 or ctx.needs_input_grad[0]
-            if ctx.needs_input_grad[1 + i]:
+            thin = i == 0 and N == 16 and THIN_CONV1
+            if ctx.needs_input_grad[1 + i] and thin:
+                L.call('se_dconv1_wgrad', L.ptr(x), L.ptr(dR), L.ptr(dW[0]), C.c_int(B), C.c_int(Ti), C.c_int(Fi), C.c_int(N), L.stream(),
+                       _key='dconv1 (thin)', _bytes=4.0 * B * (Ti * Fi * 4 + To * Fo * N))
+            elif ctx.needs_input_grad[1 + i]:
                 fd = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2)
                 dwp = LY.O.zeros(N, 16 * Cin, device=dR.device)
                 LY.GM.gemm_tap_wgrad(fd, x, dR, dwp, None)
                 LY._unpack_w(dwp, dW[i], Cin, False)
-            if need_dx:
+            if need_dx and thin:
+                dx = torch.empty(B, Ti, Fi, Cin, device=dR.device, dtype=torch.float32)
+                L.call('se_dconv1_dgrad', L.ptr(dR), L.ptr(Ws[0].detach().contiguous()), L.ptr(dx), C.c_int(B), C.c_int(Ti), C.c_int(Fi),
+                       C.c_int(N), L.stream(), _key='dconv1 (thin)', _bytes=4.0 * B * (Ti * Fi * 4 + To * Fo * N))
+                dy = dx
+                dxy = dx
+            elif need_dx:
                 wd = LY.GM.pack_conv_dgrad(Ws[i].contiguous())            # [Cin_true][16][N]
                 if wd.shape[0] != Cin:
                     wd = torch.cat([wd, wd.new_zeros(Cin - wd.shape[0], wd.shape[1])], 0)

@@ -91,7 +91,8 @@ def gemm_tap(d, A, W, Y, bias=None, R=None, AUX=None, rowstats=None, ps=None, pb
                  and (d.ntap == 1 or (d.ntap == 3 and d.precision == 3)) else
                  f'gemm_tap_f16x3_kernel<{d.prologue}>' if d.precision == 3 else
                  f'gemm_tap_bf16x{3 if d.precision == 1 else 6}_kernel<{d.prologue}>' if d.precision in (1, 2) and d.C >= 32 else
-                 f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>'), _flops=2.0 * M * d.N * d.ntap * d.C,
+                 f'gemm_tap_kernel<{16 if d.C < 32 else 32},{d.prologue}>') +
+                (f' C{d.C} N{d.N} t{d.ntap} M{M} e{d.epilogue}' if _KEY_SHAPES else ''), _flops=2.0 * M * d.N * d.ntap * d.C,
            _bytes=4.0 * M * (d.C + d.N))
     return Y
 
@@ -221,9 +222,13 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
     return dW
 
 
+_KEY_SHAPES = __import__('os').environ.get('SE_KEY_SHAPES') == '1'      # diagnostic: one timer family per GEMM shape
+
+
 def _wgrad_call(d, A, dY, dW, dbias, rowstats, ps, pb, chunks, Mt):
     L.call('se_gemm_tap_wgrad', C.byref(d), L.ptr(A), L.ptr(dY), L.ptr(dW), L.ptr(dbias), L.ptr(rowstats),
-           L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream(), _key=f'wgrad_kernel<{d.prologue}>',
+           L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream(),
+           _key=f'wgrad_kernel<{d.prologue}>' + (f' C{d.C} N{d.N} t{d.ntap} M{Mt} p{d.precision} sf{d.sf}' if _KEY_SHAPES else ''),
            _flops=2.0 * Mt * d.N * d.ntap * d.C, _bytes=4.0 * Mt * (d.C + d.N))
     return dW
 

@@ -646,3 +646,40 @@ def test_feed_forward_recompute_kernels():
             sg = torch.sigmoid(h64)
             dz64 = (dy.double() @ (0.5 * W2.double())) * (sg * (1 + h64 * (1 - sg)))
             assert rel(dW1b, dz64.t() @ xl) < 1e-6 and rel(dW2b, 0.5 * dy.double().t() @ (h64 * sg)) < 1e-6
+
+
+@pytest.mark.parametrize('B,T,Fq', [(2, 321, 201), (3, 16, 18), (1, 2, 2), (2, 37, 131), (16, 64, 300)])
+def test_discriminator_first_stage_direct_kernels(G, B, T, Fq):
+    """csrc/se_thin.hip vs torch: Conv2d(2, 16, 4, 2, 1, bias=False) (models/discriminator.py:39) on the transposed image --
+    forward (+ the fp64 InstanceNorm sums), input gradient (channels 2, 3 of the planes zero), weight gradient (accumulating)."""
+    import ctypes as C
+    gemm, L = G
+    x = rnd(B, T, Fq, 4, seed=1)
+    x[..., 2:] = 0.25                                      # never read
+    w = rnd(16, 2, 4, 4, seed=2, scale=0.2)
+    To, Fo = (T - 2) // 2 + 1, (Fq - 2) // 2 + 1
+    R = torch.empty(B, To, Fo, 16, device='cuda')
+    stats = torch.zeros(B, 16, 2, device='cuda', dtype=torch.float64)
+    L.call('se_dconv1_fwd', L.ptr(x), L.ptr(w), L.ptr(R), L.ptr(stats), C.c_int(B), C.c_int(T), C.c_int(Fq), C.c_int(16), L.stream())
+    # the reference image is [B, 2, F, T] with kernel index (kh over F, kw over T)
+    xi = x[..., :2].permute(0, 3, 2, 1).double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    ref = F.conv2d(xi, wd, None, 2, 1)                     # [B, 16, Fo, To]
+    assert ref.shape == (B, 16, Fo, To)
+    assert relerr(R, ref.detach().permute(0, 3, 2, 1)) < 2e-6
+    rr = R.double()
+    # fp32 partial sums over a workgroup's <= 4 x 64 pixels, fp64 from there on
+    assert relerr(stats[..., 0], rr.sum((1, 2))) < 1e-6 and relerr(stats[..., 1], (rr * rr).sum((1, 2))) < 2e-7
+    dR = rnd(B, To, Fo, 16, seed=3)
+    ref.backward(dR.permute(0, 3, 2, 1).double())
+    dx = torch.full((B, T, Fq, 4), 7.0, device='cuda')
+    L.call('se_dconv1_dgrad', L.ptr(dR), L.ptr(w), L.ptr(dx), C.c_int(B), C.c_int(T), C.c_int(Fq), C.c_int(16), L.stream())
+    assert relerr(dx[..., :2], xi.grad.permute(0, 3, 2, 1)) < 2e-6
+    assert float(dx[..., 2:].abs().max()) == 0.0
+    dw = torch.zeros(16, 2, 4, 4, device='cuda')
+    L.call('se_dconv1_wgrad', L.ptr(x), L.ptr(dR), L.ptr(dw), C.c_int(B), C.c_int(T), C.c_int(Fq), C.c_int(16), L.stream())
+    assert relerr(dw, wd.grad) < 3e-6
+    L.call('se_dconv1_wgrad', L.ptr(x), L.ptr(dR), L.ptr(dw), C.c_int(B), C.c_int(T), C.c_int(Fq), C.c_int(16), L.stream())
+    assert relerr(dw, 2 * wd.grad) < 3e-6                  # accumulates
+    with pytest.raises(L.SeHipError):
+        L.call('se_dconv1_fwd', L.ptr(x), L.ptr(w), L.ptr(R), None, C.c_int(B), C.c_int(T), C.c_int(Fq), C.c_int(32), L.stream())
