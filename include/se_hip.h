@@ -105,6 +105,19 @@ size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n);
 size_t se_norm_prelu_bwd_workspace_bytes(int B, int C, int per_batch);
 size_t se_segnorm_workspace_bytes(int nseg);
 
+/* InstanceNorm(affine) + PReLU backward in one pass over HBM (models/generator.py:21-22 and discriminator.py:41: the backward of
+ * InstanceNorm2d(affine=True) -> PReLU).  Same arithmetic and arguments as se_norm_prelu_bwd with per_batch = 1, act = 0, both
+ * phases + parameter gradients; the (X, dY) tiles stay in registers between the reduction and the apply step.
+ * se_inorm_prelu_bwd_fused_fits: 1 when (B, P, C) fits the resident grid (otherwise call se_norm_prelu_bwd).  ws:
+ * se_inorm_prelu_bwd_fused_workspace_bytes(B, C) bytes, zero-filled by the caller.  spin_us: deadline of the in-kernel wait of an
+ * entry's workgroups for each other; tiles that miss it are redone by the second launch of the same call (always correct). */
+int se_inorm_prelu_bwd_fused_fits(int B, long P, int C);
+size_t se_inorm_prelu_bwd_fused_workspace_bytes(int B, int C);
+int se_inorm_prelu_bwd_fused(const float* X, int ldx, int x_off, const float* mr, const float* g, const float* beta,
+                             const float* slope, const float* dY, int ldy, int y_off, void* ws, float* dX, int lddx, int dx_off,
+                             float* dg, float* dbeta, float* dslope, int B, long P, int C, double count, int spin_us,
+                             float* amax_out, void* stream);
+
 /* forward / input-gradient tap GEMM.  rowstats: [M][2] (mean, rstd) for SE_PRO_LN;
  * pro_scale/pro_shift: per-channel (LN gamma/beta or BN scale/shift); stats: double [B][N][2]. */
 int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W, const float* bias,

@@ -52,7 +52,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.se_last_error.restype = C.c_char_p
         for f in ('se_attn_bwd_workspace_bytes', 'se_norm_prelu_bwd_workspace_bytes', 'se_segnorm_workspace_bytes',
-                  'se_dwconv31_wgrad_workspace_bytes', 'se_disc_tail_workspace_bytes'):
+                  'se_dwconv31_wgrad_workspace_bytes', 'se_disc_tail_workspace_bytes', 'se_inorm_prelu_bwd_fused_workspace_bytes'):
             getattr(_lib, f).restype = C.c_size_t
     return _lib
 

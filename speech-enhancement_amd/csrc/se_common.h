@@ -76,5 +76,23 @@ static __device__ __forceinline__ void st4_stream_(float* p, float4 v) {
 #endif
 }
 
+// Buffer (SRSRC) loads with the hardware range check: a lane whose byte offset is >= `bytes` gets zeros.  The tile loaders use
+// them instead of `ok ? load : 0`: predicated flat loads compile to divergent branches, after which the compiler can no
+// longer count the loads in flight and falls back to s_waitcnt vmcnt(0) at the first use of ANY of them (the prefetch of the
+// next tile then stalls the current one).  The descriptor is built from wave-uniform values only (readfirstlane'd).
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_(const void* p, unsigned bytes) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)p);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)p >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((size_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+static __device__ __forceinline__ float4 buf_load4_(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  typedef unsigned u32x4b_ __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(float4, (u32x4b_)__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+static __device__ __forceinline__ void buf_store4_(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
+  typedef unsigned u32x4b_ __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b_, v), r, byte_off, 0, 0);
+}
+constexpr unsigned BUF_OOB_ = 0xfffffff0u;      // a byte offset no descriptor of ours covers
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
