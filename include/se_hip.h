@@ -492,6 +492,19 @@ int se_dconv1_fwd(const float* X, const float* W, float* R, double* stats, int B
 int se_dconv1_dgrad(const float* dR, const float* W, float* dX, int B, int T, int F, int N, void* stream);
 int se_dconv1_wgrad(const float* X, const float* dR, float* dW, int B, int T, int F, int N, void* stream);
 
+/* ---- the generator's thin convolutions as direct kernels (csrc/se_thin.hip; round 4) --------------------------------------- */
+/* Conv2d(64, n, (1, 2)), n = 1 (models/generator.py:114, mask decoder) or 2 (:128, complex decoder): X [B T][F2][64] channels-last,
+ * W [n][64][1][2] and bias [n] in the PyTorch layout, Y / dY [B T][F2 - 1][4] (channels >= n written as zero / ignored); stats (may
+ * be NULL) += fp64 (sum, sum of squares) per (b, channel) as double [B][4][2]; dgrad writes dX [rows][F2][64]; wgrad accumulates
+ * dW [n][64][1][2] and dbias [n]. */
+int se_conv1x2_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats, int B, int T, int F2, int n, void* stream);
+int se_conv1x2_dgrad(const float* dY, const float* W, float* dX, long rows, int F2, int n, void* stream);
+int se_conv1x2_wgrad(const float* X, const float* dY, float* dW, float* dbias, long rows, int F2, int n, void* stream);
+/* Conv2d(3, 64, (1, 1)) of the encoder (models/generator.py:39): X planes [B][P][4] (channel 3 ignored), W [64][3][1][1], bias [64],
+ * R / dR [B][P][64]; stats (may be NULL) += double [B][64][2]; wgrad accumulates dW [64][3] and dbias [64] over npix = B P pixels. */
+int se_conv3to64_fwd(const float* X, const float* W, const float* bias, float* R, double* stats, int B, long P, void* stream);
+int se_conv3to64_wgrad(const float* X, const float* dR, float* dW, float* dbias, long npix, void* stream);
+
 /* ---- CDiffuSE denoiser glue (models/DiffuSE.py; csrc/se_diffuse.hip), channels-last [B, L, C] maps ---------------------- */
 /* SpectrogramUpsampler stage: ConvTranspose2d(1,1,[3,20], stride [1,10], padding [1,5]) + leaky_relu(0.4) on in [B][F][Tin];
  * layout 0: out [B][F][10 Tin], layout 1: out [B][10 Tin][ldo] (channels-last, the conditioner GEMM operand) */

@@ -170,6 +170,265 @@ __global__ __launch_bounds__(256) void dconv1_wgrad_kernel(const float* __restri
   atomicAdd(&dW[(n * 2 + 0) * 16 + kh * 4 + kw], (float)d0);
   atomicAdd(&dW[(n * 2 + 1) * 16 + kh * 4 + kw], (float)d1);
 }
+
+// ================================================================================================================================
+// Thin convolutions of the generator (round 4): the decoders' last convolutions (models/generator.py:114 `conv_1 = Conv2d(64, 1,
+// (1, 2))` of the mask decoder, :128 `conv = Conv2d(64, 2, (1, 2))` of the complex decoder) and the encoder's first one (:39
+// `Conv2d(3, 64, (1, 1))`).  As tap GEMMs their 64-column tiles are 94 - 98 % padding (N = 1 / 2 of 64, or K = 3 of 16): 118 - 249 us
+// per launch for 0.27 GB of operands.  Direct kernels, 16 lanes per pixel (one float4 of the 64 channels each).
+//   x: [rows = B T][F2][64] channels-last; W: PyTorch layouts [n][64][1][2] / [64][3][1][1]; y: [rows][Fo = F2 - 1][4] (channels >= n zero)
+// ================================================================================================================================
+constexpr int TU = 4;        // pixels in flight per lane group
+
+template <int NO>
+__global__ __launch_bounds__(256) void conv1x2_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                          float* __restrict__ Y, double* __restrict__ stats, int T, int F2) {
+  const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4, b = blockIdx.y;
+  const int Fo = F2 - 1;
+  const long P = (long)T * Fo;
+  float w[NO][2][4], bs[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    bs[n] = bias[n];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w[n][0][j] = W[(n * 64 + 4 * l + j) * 2]; w[n][1][j] = W[(n * 64 + 4 * l + j) * 2 + 1]; }
+  }
+  const float* __restrict__ Xb = X + (long)b * T * F2 * 64 + 4 * l;
+  float* __restrict__ Yb = Y + (long)b * P * 4;
+  float s[NO], q[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) { s[n] = 0.f; q[n] = 0.f; }
+  for (long p0 = ((long)blockIdx.x * 16 + grp) * TU; p0 < P; p0 += (long)gridDim.x * 16 * TU) {
+    float4 a[TU], c[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const long p = p0 + u < P ? p0 + u : P - 1;
+      const int t = (int)(p / Fo), f = (int)(p - (long)t * Fo);
+      const float* xp = Xb + ((long)t * F2 + f) * 64;
+      a[u] = *reinterpret_cast<const float4*>(xp);
+      c[u] = *reinterpret_cast<const float4*>(xp + 64);
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      float y[NO];
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        float v = a[u].x * w[n][0][0] + a[u].y * w[n][0][1] + a[u].z * w[n][0][2] + a[u].w * w[n][0][3];
+        v += c[u].x * w[n][1][0] + c[u].y * w[n][1][1] + c[u].z * w[n][1][2] + c[u].w * w[n][1][3];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+        y[n] = v + bs[n];
+      }
+      if (l == 0 && p0 + u < P) {
+        *reinterpret_cast<float4*>(Yb + (p0 + u) * 4) = make_float4(y[0], NO > 1 ? y[NO > 1 ? 1 : 0] : 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < NO; ++n) { s[n] += y[n]; q[n] = fmaf(y[n], y[n], q[n]); }
+      }
+    }
+  }
+  if (stats) {               // InstanceNorm sums of the mask decoder: (sum, sum of squares) per (b, channel), fp64 atomics per workgroup
+    __shared__ float red[16][NO][2];
+    if (l == 0) {
+#pragma unroll
+      for (int n = 0; n < NO; ++n) { red[grp][n][0] = s[n]; red[grp][n][1] = q[n]; }
+    }
+    __syncthreads();
+    if (tid < NO * 2) {
+      const int n = tid >> 1, k = tid & 1;
+      double v = 0.0;
+      for (int g = 0; g < 16; ++g) v += (double)red[g][n][k];
+      atomicAdd(&stats[((long)b * 4 + n) * 2 + k], v);
+    }
+  }
+}
+
+// input gradient: dX[t][f][c] = sum_n dY[t][f][n] W[n][c][0] + dY[t][f - 1][n] W[n][c][1]
+template <int NO>
+__global__ __launch_bounds__(256) void conv1x2_dgrad_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ dX,
+                                                            long rows, int F2) {
+  const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4;
+  const int Fo = F2 - 1;
+  float w[NO][2][4];
+#pragma unroll
+  for (int n = 0; n < NO; ++n)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { w[n][0][j] = W[(n * 64 + 4 * l + j) * 2]; w[n][1][j] = W[(n * 64 + 4 * l + j) * 2 + 1]; }
+  const long P = rows * F2;
+  for (long p0 = ((long)blockIdx.x * 16 + grp) * TU; p0 < P; p0 += (long)gridDim.x * 16 * TU) {
+    float4 d0[TU], d1[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const long p = p0 + u < P ? p0 + u : P - 1;
+      const long r = p / F2;
+      const int f = (int)(p - r * F2);
+      const float* dp = dY + (r * Fo + f) * 4;
+      d0[u] = f < Fo ? *reinterpret_cast<const float4*>(dp) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d1[u] = f >= 1 ? *reinterpret_cast<const float4*>(dp - 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const float e0[2] = {d0[u].x, d0[u].y}, e1[2] = {d1[u].x, d1[u].y};
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v = 0.f;
+#pragma unroll
+        for (int n = 0; n < NO; ++n) v += e0[n] * w[n][0][j] + e1[n] * w[n][1][j];
+        o[j] = v;
+      }
+      if (p0 + u < P) *reinterpret_cast<float4*>(dX + (p0 + u) * 64 + 4 * l) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+// weight / bias gradient: dW[n][c][k] += sum_pixels dY[t][f' - k][n] x[t][f'][c] over the INPUT pixels f' (each x line is read once)
+template <int NO>
+__global__ __launch_bounds__(256) void conv1x2_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ dW,
+                                                            float* __restrict__ dbias, long rows, int F2) {
+  const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4;
+  const int Fo = F2 - 1;
+  float acc[NO][2][4], ab[NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+    ab[n] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[n][0][j] = 0.f; acc[n][1][j] = 0.f; }
+  }
+  const long P = rows * F2;
+  for (long p0 = ((long)blockIdx.x * 16 + grp) * TU; p0 < P; p0 += (long)gridDim.x * 16 * TU) {
+    float4 x[TU], d0[TU], d1[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const bool ok = p0 + u < P;
+      const long p = ok ? p0 + u : P - 1;
+      const long r = p / F2;
+      const int f = (int)(p - r * F2);
+      const float* dp = dY + (r * Fo + f) * 4;
+      x[u] = *reinterpret_cast<const float4*>(X + p * 64 + 4 * l);
+      d0[u] = ok && f < Fo ? *reinterpret_cast<const float4*>(dp) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d1[u] = ok && f >= 1 ? *reinterpret_cast<const float4*>(dp - 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, e0[2] = {d0[u].x, d0[u].y}, e1[2] = {d1[u].x, d1[u].y};
+#pragma unroll
+      for (int n = 0; n < NO; ++n) {
+        ab[n] += e0[n];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[n][0][j] = fmaf(e0[n], xv[j], acc[n][0][j]); acc[n][1][j] = fmaf(e1[n], xv[j], acc[n][1][j]); }
+      }
+    }
+  }
+  __shared__ float red[16][NO * 2 * 64 + NO];
+#pragma unroll
+  for (int n = 0; n < NO; ++n) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[grp][(n * 64 + 4 * l + j) * 2] = acc[n][0][j]; red[grp][(n * 64 + 4 * l + j) * 2 + 1] = acc[n][1][j]; }
+    if (l == 0) red[grp][NO * 128 + n] = ab[n];
+  }
+  __syncthreads();
+  for (int i = tid; i < NO * 128 + NO; i += 256) {
+    float v = 0.f;
+    for (int g = 0; g < 16; ++g) v += red[g][i];
+    if (i < NO * 128) atomicAdd(&dW[i], v);            // [n][c][1][2]
+    else atomicAdd(&dbias[i - NO * 128], v);
+  }
+}
+
+// encoder head: R[p][n] = b[n] + sum_{c < 3} W[n][c] x[p][c]  (+ InstanceNorm sums); 16 lanes per pixel, 4 output channels each
+__global__ __launch_bounds__(256) void conv3to64_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+                                                            float* __restrict__ R, double* __restrict__ stats, long P) {
+  const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4, b = blockIdx.y;
+  float w[4][3], bs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    bs[j] = bias[4 * l + j];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w[j][c] = W[(4 * l + j) * 3 + c];
+  }
+  const float* __restrict__ Xb = X + (long)b * P * 4;
+  float* __restrict__ Rb = R + (long)b * P * 64 + 4 * l;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long p0 = ((long)blockIdx.x * 16 + grp) * TU; p0 < P; p0 += (long)gridDim.x * 16 * TU) {
+    float4 x[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) x[u] = *reinterpret_cast<const float4*>(Xb + (p0 + u < P ? p0 + u : P - 1) * 4);
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = fmaf(w[j][2], x[u].z, fmaf(w[j][1], x[u].y, fmaf(w[j][0], x[u].x, bs[j])));
+      if (p0 + u < P) {
+        *reinterpret_cast<float4*>(Rb + (p0 + u) * 64) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += o[j]; q[j] = fmaf(o[j], o[j], q[j]); }
+      }
+    }
+  }
+  if (stats) {
+    __shared__ float red[16][64][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[grp][4 * l + j][0] = s[j]; red[grp][4 * l + j][1] = q[j]; }
+    __syncthreads();
+    if (tid < 128) {
+      const int n = tid >> 1, k = tid & 1;
+      double v = 0.0;
+      for (int g = 0; g < 16; ++g) v += (double)red[g][n][k];
+      atomicAdd(&stats[((long)b * 64 + n) * 2 + k], v);
+    }
+  }
+}
+
+// dW[n][c] += sum_p dR[p][n] x[p][c] (c < 3), dbias[n] += sum_p dR[p][n]
+__global__ __launch_bounds__(256) void conv3to64_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dR, float* __restrict__ dW,
+                                                              float* __restrict__ dbias, long P) {
+  const int tid = threadIdx.x, l = tid & 15, grp = tid >> 4;
+  float acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[j][c] = 0.f;
+  for (long p0 = ((long)blockIdx.x * 16 + grp) * TU; p0 < P; p0 += (long)gridDim.x * 16 * TU) {
+    float4 x[TU], d[TU];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const bool ok = p0 + u < P;
+      const long p = ok ? p0 + u : P - 1;
+      x[u] = *reinterpret_cast<const float4*>(X + p * 4);
+      d[u] = ok ? *reinterpret_cast<const float4*>(dR + p * 64 + 4 * l) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const float dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j][0] = fmaf(dv[j], x[u].x, acc[j][0]);
+        acc[j][1] = fmaf(dv[j], x[u].y, acc[j][1]);
+        acc[j][2] = fmaf(dv[j], x[u].z, acc[j][2]);
+        acc[j][3] += dv[j];
+      }
+    }
+  }
+  __shared__ float red[16][64][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[grp][4 * l + j][c] = acc[j][c];
+  __syncthreads();
+  {
+    const int n = tid >> 2, c = tid & 3;
+    float v = 0.f;
+    for (int g = 0; g < 16; ++g) v += red[g][n][c];
+    if (c < 3) atomicAdd(&dW[n * 3 + c], v);
+    else atomicAdd(&dbias[n], v);
+  }
+}
+
+static int thin_grid(long pixels, long cap) {
+  long nb = (pixels + 16 * TU - 1) / (16 * TU);
+  if (nb > cap) nb = cap;
+  return (int)(nb < 1 ? 1 : nb);
+}
 }  // namespace
 
 extern "C" int se_dconv1_fwd(const float* X, const float* W, float* R, double* stats, int B, int T, int F, int N, void* stream) {
@@ -199,4 +458,42 @@ extern "C" int se_dconv1_wgrad(const float* X, const float* dR, float* dW, int B
   if (nwg > 512) nwg = 512;
   hipLaunchKernelGGL(dconv1_wgrad_kernel, dim3((unsigned)nwg), dim3(256), 0, as_stream(stream), X, dR, dW, B, T, F, To, Fo, fchunks);
   return se_check_launch("se_dconv1_wgrad");
+}
+
+extern "C" int se_conv1x2_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats, int B, int T, int F2, int n,
+                              void* stream) {
+  SE_REQUIRE(X && W && bias && Y && B > 0 && T > 0 && F2 > 1 && (n == 1 || n == 2), "conv1x2_fwd: bad arguments (n = %d: 1 or 2)", n);
+  const dim3 grid(thin_grid((long)T * (F2 - 1), 2048 / B > 1 ? 2048 / B : 1), B);
+  if (n == 1) hipLaunchKernelGGL(conv1x2_fwd_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, W, bias, Y, stats, T, F2);
+  else hipLaunchKernelGGL(conv1x2_fwd_kernel<2>, grid, dim3(256), 0, as_stream(stream), X, W, bias, Y, stats, T, F2);
+  return se_check_launch("se_conv1x2_fwd");
+}
+
+extern "C" int se_conv1x2_dgrad(const float* dY, const float* W, float* dX, long rows, int F2, int n, void* stream) {
+  SE_REQUIRE(dY && W && dX && rows > 0 && F2 > 1 && (n == 1 || n == 2), "conv1x2_dgrad: bad arguments (n = %d: 1 or 2)", n);
+  const dim3 grid(thin_grid(rows * F2, 4096));
+  if (n == 1) hipLaunchKernelGGL(conv1x2_dgrad_kernel<1>, grid, dim3(256), 0, as_stream(stream), dY, W, dX, rows, F2);
+  else hipLaunchKernelGGL(conv1x2_dgrad_kernel<2>, grid, dim3(256), 0, as_stream(stream), dY, W, dX, rows, F2);
+  return se_check_launch("se_conv1x2_dgrad");
+}
+
+extern "C" int se_conv1x2_wgrad(const float* X, const float* dY, float* dW, float* dbias, long rows, int F2, int n, void* stream) {
+  SE_REQUIRE(X && dY && dW && dbias && rows > 0 && F2 > 1 && (n == 1 || n == 2), "conv1x2_wgrad: bad arguments (n = %d: 1 or 2)", n);
+  const dim3 grid(thin_grid(rows * F2, 1024));
+  if (n == 1) hipLaunchKernelGGL(conv1x2_wgrad_kernel<1>, grid, dim3(256), 0, as_stream(stream), X, dY, dW, dbias, rows, F2);
+  else hipLaunchKernelGGL(conv1x2_wgrad_kernel<2>, grid, dim3(256), 0, as_stream(stream), X, dY, dW, dbias, rows, F2);
+  return se_check_launch("se_conv1x2_wgrad");
+}
+
+extern "C" int se_conv3to64_fwd(const float* X, const float* W, const float* bias, float* R, double* stats, int B, long P, void* stream) {
+  SE_REQUIRE(X && W && bias && R && B > 0 && P > 0, "conv3to64_fwd: bad arguments");
+  const dim3 grid(thin_grid(P, 2048 / B > 1 ? 2048 / B : 1), B);
+  hipLaunchKernelGGL(conv3to64_fwd_kernel, grid, dim3(256), 0, as_stream(stream), X, W, bias, R, stats, P);
+  return se_check_launch("se_conv3to64_fwd");
+}
+
+extern "C" int se_conv3to64_wgrad(const float* X, const float* dR, float* dW, float* dbias, long npix, void* stream) {
+  SE_REQUIRE(X && dR && dW && dbias && npix > 0, "conv3to64_wgrad: bad arguments");
+  hipLaunchKernelGGL(conv3to64_wgrad_kernel, dim3(thin_grid(npix, 1024)), dim3(256), 0, as_stream(stream), X, dR, dW, dbias, npix);
+  return se_check_launch("se_conv3to64_wgrad");
 }

@@ -6,6 +6,8 @@ strides).  Each ``*_fwd`` returns (output, ctx); each ``*_bwd`` consumes the ctx
 adds parameter gradients into ``G`` (dict name -> tensor, fp32, zero-initialised by the caller).
 Parameter names are the reference's state_dict keys.
 """
+import ctypes as C
+
 import torch
 
 from . import _lib as L
@@ -131,6 +133,32 @@ def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None
     return R, stats
 
 
+# SE_NO_THIN_CONV=1: the decoders' last convolutions and the encoder's first one through the tap GEMM again (A/B switch)
+THIN_CONV = _os.environ.get('SE_NO_THIN_CONV') != '1'
+
+
+def conv1x2_fwd(x, w, bias, B, T, F2, want_stats):
+    """Conv2d(64, n, (1, 2)), n = 1 / 2, as a direct kernel (csrc/se_thin.hip): x [B,T,F2,64] -> [B,T,F2-1,4] (+ fp64 sums [B,4,2])"""
+    n = w.shape[0]
+    y = torch.empty(B, T, F2 - 1, 4, device=x.device, dtype=torch.float32)
+    st = O.zeros(B, 4, 2, device=x.device, dtype=torch.float64) if want_stats else None
+    L.call('se_conv1x2_fwd', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(st), C.c_int(B), C.c_int(T), C.c_int(F2), C.c_int(n),
+           L.stream(), _key='thin conv (generator)', _bytes=4.0 * B * T * (F2 * 64 + (F2 - 1) * 4))
+    return y, st
+
+
+def conv1x2_bwd(x, w, dy, dw, dbias, B, T, F2):
+    """gradients of conv1x2_fwd: dw / dbias accumulated in place (PyTorch layout) on the weight-gradient stream, returns dx"""
+    n = w.shape[0]
+    with GM.leaf_stream(x, dy):
+        L.call('se_conv1x2_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(dbias), C.c_long(B * T), C.c_int(F2), C.c_int(n), L.stream(),
+               _key='thin conv (generator)', _bytes=4.0 * B * T * (F2 * 64 + (F2 - 1) * 4))
+    dx = torch.empty(B, T, F2, 64, device=x.device, dtype=torch.float32)
+    L.call('se_conv1x2_dgrad', L.ptr(dy), L.ptr(w), L.ptr(dx), C.c_long(B * T), C.c_int(F2), C.c_int(n), L.stream(),
+           _key='thin conv (generator)', _bytes=4.0 * B * T * (F2 * 64 + (F2 - 1) * 4))
+    return dx
+
+
 def inorm_prelu_fwd(R, stats, g, b, slope, out, ldy, y_off, amax=None):
     B = R.shape[0]
     C_ = R.shape[-1]
@@ -234,7 +262,8 @@ def build_generator_plan(P, device):
     for e in ('dense_encoder', 'dense_encoder_noisy'):       # (the second one: TSC-diffusion hybrid, models/tsc_diffusion.py:47)
         if f'{e}.conv_1.0.weight' not in P:
             continue
-        plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
+        if not (THIN_CONV and P[f'{e}.conv_1.0.weight'].shape[:2] == (64, 3)):      # (direct kernel: reads the PyTorch layout)
+            plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
         dense(f'{e}.dilated_dense')
         plan.conv_fwd((f'{e}.conv_2.0.weight', 'fwd'), P[f'{e}.conv_2.0.weight'], planes=c3)          # strided: generic split kernel
         plan.conv_dgrad((f'{e}.conv_2.0.weight', 'dgrad'), P[f'{e}.conv_2.0.weight'], planes=c3)
@@ -244,8 +273,9 @@ def build_generator_plan(P, device):
         plan.conv_fwd((n, 'fwd'), P[n], planes=c3)
         plan.conv_dgrad((n, 'dgrad'), P[n], planes=c3 if dec == 'complex_decoder' else cpl)      # mask decoder: dS has no measured amax
         n = f'{dec}.{last}.weight'                                   # 64 -> 1 / 2 channels, rows padded to 4
-        plan.conv_fwd((n, 'fwd'), P[n], N_pad=4, planes=cpl)
-        plan.conv_dgrad((n, 'dgrad'), P[n], N_pad=4)                  # C = 4 < 32: fp32 kernel
+        if not THIN_CONV:                                             # (direct kernels: read the PyTorch layout)
+            plan.conv_fwd((n, 'fwd'), P[n], N_pad=4, planes=cpl)
+            plan.conv_dgrad((n, 'dgrad'), P[n], N_pad=4)              # C = 4 < 32: fp32 kernel
     for i in range(1, 5):
         for ax in ('time', 'freq'):
             p = f'TSCB_{i}.{ax}_conformer'
@@ -353,9 +383,15 @@ TAPS_1x2 = [(0, 0), (0, 1)]
 
 def encoder_fwd(P, xin, B, T, Fq, p='dense_encoder'):
     ctx = {'xin': xin}
-    R0, st0 = conv_fwd(xin, B, T, Fq, 4, 0, 4,
-                       _w(P, (f'{p}.conv_1.0.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv_1.0.weight'], C_pad=4)),
-                       P[f'{p}.conv_1.0.bias'], TAPS_1x1, 64)
+    if THIN_CONV and P[f'{p}.conv_1.0.weight'].shape[:2] == (64, 3):
+        R0 = torch.empty(B, T, Fq, 64, device=xin.device, dtype=torch.float32)
+        st0 = O.zeros(B, 64, 2, device=xin.device, dtype=torch.float64)
+        L.call('se_conv3to64_fwd', L.ptr(xin), L.ptr(P[f'{p}.conv_1.0.weight']), L.ptr(P[f'{p}.conv_1.0.bias']), L.ptr(R0), L.ptr(st0),
+               C.c_int(B), C.c_long(T * Fq), L.stream(), _key='thin conv (generator)', _bytes=4.0 * B * T * Fq * 68)
+    else:
+        R0, st0 = conv_fwd(xin, B, T, Fq, 4, 0, 4,
+                           _w(P, (f'{p}.conv_1.0.weight', 'fwd'), lambda: pack_w(P[f'{p}.conv_1.0.weight'], C_pad=4)),
+                           P[f'{p}.conv_1.0.bias'], TAPS_1x1, 64)
     skip = torch.empty(B, T, Fq, 256, device=xin.device, dtype=torch.float32)
     blk = _amax(xin.device)                 # max |activation| of the skip stack / the block output: raised by every norm below
     ctx['mr0'] = inorm_prelu_fwd(R0, st0, P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
@@ -385,8 +421,13 @@ def encoder_bwd(P, G, ctx, dout, B, T, Fq, p='dense_encoder'):
     dR0 = inorm_prelu_bwd(ctx['R0'], ctx['mr0'], P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
                           P[f'{p}.conv_1.2.weight'], dskip, 256, 0, G[f'{p}.conv_1.1.weight'],
                           G[f'{p}.conv_1.1.bias'], G[f'{p}.conv_1.2.weight'])
-    conv_bwd(ctx['xin'], B, T, Fq, 4, 0, 4, P[f'{p}.conv_1.0.weight'], TAPS_1x1, dR0, T, Fq,
-             G[f'{p}.conv_1.0.weight'], G[f'{p}.conv_1.0.bias'], need_dx=False)
+    if THIN_CONV and P[f'{p}.conv_1.0.weight'].shape[:2] == (64, 3):
+        with GM.leaf_stream(ctx['xin'], dR0):
+            L.call('se_conv3to64_wgrad', L.ptr(ctx['xin']), L.ptr(dR0), L.ptr(G[f'{p}.conv_1.0.weight']), L.ptr(G[f'{p}.conv_1.0.bias']),
+                   C.c_long(B * T * Fq), L.stream(), _key='thin conv (generator)', _bytes=4.0 * B * T * Fq * 68)
+    else:
+        conv_bwd(ctx['xin'], B, T, Fq, 4, 0, 4, P[f'{p}.conv_1.0.weight'], TAPS_1x1, dR0, T, Fq,
+                 G[f'{p}.conv_1.0.weight'], G[f'{p}.conv_1.0.bias'], need_dx=False)
     return None
 
 
@@ -739,9 +780,12 @@ def mask_decoder_fwd(P, x, B, T, Fq):
                     a_amax=ctx['dense'].get('amax'))                                                      # [B,T,2Fq,64]
     F2 = 2 * Fq
     Fo = F2 - 1
-    w1 = _w(P, (f'{p}.conv_1.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv_1.weight'], 4)))
-    b1 = pad_rows(P[f'{p}.conv_1.bias'], 4)
-    r, st = conv_fwd(S, B, T, F2, 64, 0, 64, w1, b1, TAPS_1x2, 4, To=T, Fo=Fo)            # [B,T,Fo,4], channel 0
+    if THIN_CONV:
+        r, st = conv1x2_fwd(S, P[f'{p}.conv_1.weight'], P[f'{p}.conv_1.bias'], B, T, F2, True)       # [B,T,Fo,4], channel 0
+    else:
+        w1 = _w(P, (f'{p}.conv_1.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv_1.weight'], 4)))
+        b1 = pad_rows(P[f'{p}.conv_1.bias'], 4)
+        r, st = conv_fwd(S, B, T, F2, 64, 0, 64, w1, b1, TAPS_1x2, 4, To=T, Fo=Fo)            # [B,T,Fo,4], channel 0
     g4, be4, a4 = pad_rows(P[f'{p}.norm.weight'], 4), pad_rows(P[f'{p}.norm.bias'], 4), pad_rows(P[f'{p}.prelu.weight'], 4)
     uact = torch.empty_like(r)
     mr = inorm_prelu_fwd(r, st, g4, be4, a4, uact, 4, 0)
@@ -768,13 +812,16 @@ def mask_decoder_bwd(P, G, ctx, dmask, B, T, Fq):
     G[f'{p}.norm.weight'] += dg4[:1]
     G[f'{p}.norm.bias'] += db4[:1]
     G[f'{p}.prelu.weight'] += da4[:1]
-    dw1 = O.zeros(4, 64, 1, 2, device=dev)
-    dbias1 = O.zeros(4, device=dev)
-    dS = conv_bwd(ctx['S'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv_1.weight'], 4), TAPS_1x2, dr, T, Fo, dw1, dbias1,
-                  wd=_w(P, (f'{p}.conv_1.weight', 'dgrad'), lambda: None))
-    with GM.leaf_stream(dw1, dbias1):            # dw1 / dbias1 are written on the weight-gradient stream (conv_bwd)
-        G[f'{p}.conv_1.weight'] += dw1[:1]
-        G[f'{p}.conv_1.bias'] += dbias1[:1]
+    if THIN_CONV:
+        dS = conv1x2_bwd(ctx['S'], P[f'{p}.conv_1.weight'], dr, G[f'{p}.conv_1.weight'], G[f'{p}.conv_1.bias'], B, T, F2)
+    else:
+        dw1 = O.zeros(4, 64, 1, 2, device=dev)
+        dbias1 = O.zeros(4, device=dev)
+        dS = conv_bwd(ctx['S'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv_1.weight'], 4), TAPS_1x2, dr, T, Fo, dw1, dbias1,
+                      wd=_w(P, (f'{p}.conv_1.weight', 'dgrad'), lambda: None))
+        with GM.leaf_stream(dw1, dbias1):            # dw1 / dbias1 are written on the weight-gradient stream (conv_bwd)
+            G[f'{p}.conv_1.weight'] += dw1[:1]
+            G[f'{p}.conv_1.bias'] += dbias1[:1]
     dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq, a_amax=ctx['dense'].get('amax'))
     dskip = dense_block_bwd(P, G, f'{p}.dense_block', ctx['dense'], dd4, B, T, Fq)
     return dskip        # slab 0 = input gradient
@@ -802,9 +849,12 @@ def complex_decoder_fwd(P, x, B, T, Fq):
     Fo = F2 - 1
     a = torch.empty_like(S)
     mr = inorm_prelu_fwd(S, st, P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], a, 64, 0)
-    wc = _w(P, (f'{p}.conv.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv.weight'], 4)))
-    bc = pad_rows(P[f'{p}.conv.bias'], 4)
-    cplx, _ = conv_fwd(a, B, T, F2, 64, 0, 64, wc, bc, TAPS_1x2, 4, To=T, Fo=Fo, want_stats=False)
+    if THIN_CONV:
+        cplx, _ = conv1x2_fwd(a, P[f'{p}.conv.weight'], P[f'{p}.conv.bias'], B, T, F2, False)
+    else:
+        wc = _w(P, (f'{p}.conv.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv.weight'], 4)))
+        bc = pad_rows(P[f'{p}.conv.bias'], 4)
+        cplx, _ = conv_fwd(a, B, T, F2, 64, 0, 64, wc, bc, TAPS_1x2, 4, To=T, Fo=Fo, want_stats=False)
     ctx.update(d4=d4, S=S, mr=mr, a=a, Fo=Fo)
     return cplx, ctx
 
@@ -813,13 +863,16 @@ def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
     p = 'complex_decoder'
     Fo, F2 = ctx['Fo'], 2 * Fq
     dev = dcplx.device
-    dwc = O.zeros(4, 64, 1, 2, device=dev)
-    dbc = O.zeros(4, device=dev)
-    da = conv_bwd(ctx['a'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv.weight'], 4), TAPS_1x2, dcplx, T, Fo, dwc, dbc,
-                  wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None))
-    with GM.leaf_stream(dwc, dbc):               # written on the weight-gradient stream (conv_bwd)
-        G[f'{p}.conv.weight'] += dwc[:2]
-        G[f'{p}.conv.bias'] += dbc[:2]
+    if THIN_CONV:
+        da = conv1x2_bwd(ctx['a'], P[f'{p}.conv.weight'], dcplx.contiguous(), G[f'{p}.conv.weight'], G[f'{p}.conv.bias'], B, T, F2)
+    else:
+        dwc = O.zeros(4, 64, 1, 2, device=dev)
+        dbc = O.zeros(4, device=dev)
+        da = conv_bwd(ctx['a'], B, T, F2, 64, 0, 64, pad_rows(P[f'{p}.conv.weight'], 4), TAPS_1x2, dcplx, T, Fo, dwc, dbc,
+                      wd=_w(P, (f'{p}.conv.weight', 'dgrad'), lambda: None))
+        with GM.leaf_stream(dwc, dbc):               # written on the weight-gradient stream (conv_bwd)
+            G[f'{p}.conv.weight'] += dwc[:2]
+            G[f'{p}.conv.bias'] += dbc[:2]
     dS = inorm_prelu_bwd(ctx['S'], ctx['mr'], P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], da,
                          64, 0, G[f'{p}.norm.weight'], G[f'{p}.norm.bias'], G[f'{p}.prelu.weight'])
     dd4 = _subpixel_bwd(P, G, f'{p}.sub_pixel', ctx['d4'], dS, B, T, Fq, a_amax=ctx['dense'].get('amax'))

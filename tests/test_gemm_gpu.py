@@ -683,3 +683,56 @@ def test_discriminator_first_stage_direct_kernels(G, B, T, Fq):
     assert relerr(dw, 2 * wd.grad) < 3e-6                  # accumulates
     with pytest.raises(L.SeHipError):
         L.call('se_dconv1_fwd', L.ptr(x), L.ptr(w), L.ptr(R), None, C.c_int(B), C.c_int(T), C.c_int(Fq), C.c_int(32), L.stream())
+
+
+@pytest.mark.parametrize('B,T,F2,n', [(2, 7, 202, 1), (3, 5, 33, 2), (1, 1, 2, 2), (16, 9, 202, 2)])
+def test_generator_thin_convolutions_1x2(G, B, T, F2, n):
+    """csrc/se_thin.hip vs torch fp64: Conv2d(64, n, (1, 2)) (models/generator.py:114, :128) forward (+ InstanceNorm sums), input
+    gradient, weight / bias gradient (accumulating into PyTorch-layout tensors)."""
+    import ctypes as C
+    gemm, L = G
+    Fo = F2 - 1
+    x = rnd(B, T, F2, 64, seed=1)
+    w, bias = rnd(n, 64, 1, 2, seed=2, scale=0.1), rnd(n, seed=3)
+    y = torch.full((B, T, Fo, 4), 9.0, device='cuda')
+    st = torch.zeros(B, 4, 2, device='cuda', dtype=torch.float64)
+    L.call('se_conv1x2_fwd', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), L.ptr(st), C.c_int(B), C.c_int(T), C.c_int(F2), C.c_int(n), L.stream())
+    xi = x.permute(0, 3, 1, 2).double().requires_grad_(True)          # [B, 64, T, F2]
+    wd, bd = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = F.conv2d(xi, wd, bd)                                         # [B, n, T, Fo]
+    assert relerr(y[..., :n], ref.detach().permute(0, 2, 3, 1)) < 2e-6
+    assert float(y[..., n:].abs().max()) == 0.0
+    yy = y.double()
+    assert relerr(st[..., 0], yy.sum((1, 2))) < 1e-6 and relerr(st[..., 1], (yy * yy).sum((1, 2))) < 1e-6
+    dy = rnd(B, T, Fo, 4, seed=4)
+    ref.backward(dy[..., :n].permute(0, 3, 1, 2).double())
+    dx = torch.full((B, T, F2, 64), 5.0, device='cuda')
+    L.call('se_conv1x2_dgrad', L.ptr(dy), L.ptr(w), L.ptr(dx), C.c_long(B * T), C.c_int(F2), C.c_int(n), L.stream())
+    assert relerr(dx, xi.grad.permute(0, 2, 3, 1)) < 2e-6
+    dw, db = torch.full((n, 64, 1, 2), 0.25, device='cuda'), torch.full((n,), 0.5, device='cuda')
+    L.call('se_conv1x2_wgrad', L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), C.c_long(B * T), C.c_int(F2), C.c_int(n), L.stream())
+    assert relerr(dw - 0.25, wd.grad) < 5e-6 and relerr(db - 0.5, bd.grad) < 5e-6
+    with pytest.raises(L.SeHipError):
+        L.call('se_conv1x2_fwd', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), None, C.c_int(B), C.c_int(T), C.c_int(F2), C.c_int(3), L.stream())
+
+
+@pytest.mark.parametrize('B,P', [(2, 1000), (3, 77), (16, 6421)])
+def test_generator_thin_convolution_3_to_64(G, B, P):
+    """csrc/se_thin.hip vs torch fp64: the encoder's Conv2d(3, 64, (1, 1)) (models/generator.py:39) on the planes [B, P, 4]"""
+    import ctypes as C
+    gemm, L = G
+    x = rnd(B, P, 4, seed=1)
+    w, bias = rnd(64, 3, 1, 1, seed=2, scale=0.5), rnd(64, seed=3)
+    R = torch.empty(B, P, 64, device='cuda')
+    st = torch.zeros(B, 64, 2, device='cuda', dtype=torch.float64)
+    L.call('se_conv3to64_fwd', L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(R), L.ptr(st), C.c_int(B), C.c_long(P), L.stream())
+    wd, bd = w.view(64, 3).double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = x[..., :3].double() @ wd.t() + bd
+    assert relerr(R, ref.detach()) < 2e-6
+    rr = R.double()
+    assert relerr(st[..., 0], rr.sum(1)) < 1e-6 and relerr(st[..., 1], (rr * rr).sum(1)) < 1e-6
+    dR = rnd(B, P, 64, seed=4)
+    ref.backward(dR.double())
+    dw, db = torch.full((64, 3, 1, 1), 0.25, device='cuda'), torch.full((64,), 0.5, device='cuda')
+    L.call('se_conv3to64_wgrad', L.ptr(x), L.ptr(dR), L.ptr(dw), L.ptr(db), C.c_long(B * P), L.stream())
+    assert relerr(dw.view(64, 3) - 0.25, wd.grad) < 5e-6 and relerr(db - 0.5, bd.grad) < 5e-6
