@@ -1083,7 +1083,9 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
         return se_check_launch("se_gemm_tap(W-stationary row panel)");
       }
     }
-    if ((lin || tap3) && (d->B == 1 || map1d) && d->C == 64 && ncols >= 2 && (d->precision >= 1 && d->precision <= 3) && (vec_st || glu_ok) &&
+    // one column block (N = 64): the panel form wins only with the dropout-hash prologue (dO = (mask dY) Wo: 99 -> 78 us; the
+    // residual + dropout epilogue of to_out is 87 -> 103 us in it)
+    if ((lin || tap3) && (d->B == 1 || map1d) && d->C == 64 && (ncols >= 2 || d->prologue == SE_PRO_DROP) && (d->precision >= 1 && d->precision <= 3) && (vec_st || glu_ok) &&
         !(ep & SE_EPI_ACCUM) && !((ep & SE_EPI_SWISH_GRAD) && (ep & SE_EPI_RESID)) && !no_panel) {
       dim3 pgrid((unsigned)(d->B * g.tiles));
       if (tap3) {
