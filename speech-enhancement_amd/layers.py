@@ -134,7 +134,7 @@ def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None
 
 
 # SE_NO_THIN_CONV=1: the decoders' last convolutions and the encoder's first one through the tap GEMM again (A/B switch)
-THIN_CONV = _os.environ.get('SE_NO_THIN_CONV') != '1'
+THIN_CONV = 0 if _os.environ.get('SE_NO_THIN_CONV') == '1' else int(_os.environ.get('SE_THIN_CONV', '15'))     # bits: 1 encoder fwd, 2 encoder wgrad, 4 decoders fwd, 8 decoders bwd
 
 
 def conv1x2_fwd(x, w, bias, B, T, F2, want_stats):
@@ -262,7 +262,7 @@ def build_generator_plan(P, device):
     for e in ('dense_encoder', 'dense_encoder_noisy'):       # (the second one: TSC-diffusion hybrid, models/tsc_diffusion.py:47)
         if f'{e}.conv_1.0.weight' not in P:
             continue
-        if not (THIN_CONV and P[f'{e}.conv_1.0.weight'].shape[:2] == (64, 3)):      # (direct kernel: reads the PyTorch layout)
+        if not ((THIN_CONV & 3) == 3 and P[f'{e}.conv_1.0.weight'].shape[:2] == (64, 3)):      # (direct kernel: reads the PyTorch layout)
             plan.conv_fwd((f'{e}.conv_1.0.weight', 'fwd'), P[f'{e}.conv_1.0.weight'], C_pad=4)
         dense(f'{e}.dilated_dense')
         plan.conv_fwd((f'{e}.conv_2.0.weight', 'fwd'), P[f'{e}.conv_2.0.weight'], planes=c3)          # strided: generic split kernel
@@ -273,7 +273,7 @@ def build_generator_plan(P, device):
         plan.conv_fwd((n, 'fwd'), P[n], planes=c3)
         plan.conv_dgrad((n, 'dgrad'), P[n], planes=c3 if dec == 'complex_decoder' else cpl)      # mask decoder: dS has no measured amax
         n = f'{dec}.{last}.weight'                                   # 64 -> 1 / 2 channels, rows padded to 4
-        if not THIN_CONV:                                             # (direct kernels: read the PyTorch layout)
+        if (THIN_CONV & 12) != 12:                                             # (direct kernels: read the PyTorch layout)
             plan.conv_fwd((n, 'fwd'), P[n], N_pad=4, planes=cpl)
             plan.conv_dgrad((n, 'dgrad'), P[n], N_pad=4)              # C = 4 < 32: fp32 kernel
     for i in range(1, 5):
@@ -383,7 +383,7 @@ TAPS_1x2 = [(0, 0), (0, 1)]
 
 def encoder_fwd(P, xin, B, T, Fq, p='dense_encoder'):
     ctx = {'xin': xin}
-    if THIN_CONV and P[f'{p}.conv_1.0.weight'].shape[:2] == (64, 3):
+    if (THIN_CONV & 1) and P[f'{p}.conv_1.0.weight'].shape[:2] == (64, 3):
         R0 = torch.empty(B, T, Fq, 64, device=xin.device, dtype=torch.float32)
         st0 = O.zeros(B, 64, 2, device=xin.device, dtype=torch.float64)
         L.call('se_conv3to64_fwd', L.ptr(xin), L.ptr(P[f'{p}.conv_1.0.weight']), L.ptr(P[f'{p}.conv_1.0.bias']), L.ptr(R0), L.ptr(st0),
@@ -421,7 +421,7 @@ def encoder_bwd(P, G, ctx, dout, B, T, Fq, p='dense_encoder'):
     dR0 = inorm_prelu_bwd(ctx['R0'], ctx['mr0'], P[f'{p}.conv_1.1.weight'], P[f'{p}.conv_1.1.bias'],
                           P[f'{p}.conv_1.2.weight'], dskip, 256, 0, G[f'{p}.conv_1.1.weight'],
                           G[f'{p}.conv_1.1.bias'], G[f'{p}.conv_1.2.weight'])
-    if THIN_CONV and P[f'{p}.conv_1.0.weight'].shape[:2] == (64, 3):
+    if (THIN_CONV & 2) and P[f'{p}.conv_1.0.weight'].shape[:2] == (64, 3):
         with GM.leaf_stream(ctx['xin'], dR0):
             L.call('se_conv3to64_wgrad', L.ptr(ctx['xin']), L.ptr(dR0), L.ptr(G[f'{p}.conv_1.0.weight']), L.ptr(G[f'{p}.conv_1.0.bias']),
                    C.c_long(B * T * Fq), L.stream(), _key='thin conv (generator)', _bytes=4.0 * B * T * Fq * 68)
@@ -780,7 +780,7 @@ def mask_decoder_fwd(P, x, B, T, Fq):
                     a_amax=ctx['dense'].get('amax'))                                                      # [B,T,2Fq,64]
     F2 = 2 * Fq
     Fo = F2 - 1
-    if THIN_CONV:
+    if THIN_CONV & 4:
         r, st = conv1x2_fwd(S, P[f'{p}.conv_1.weight'], P[f'{p}.conv_1.bias'], B, T, F2, True)       # [B,T,Fo,4], channel 0
     else:
         w1 = _w(P, (f'{p}.conv_1.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv_1.weight'], 4)))
@@ -812,7 +812,7 @@ def mask_decoder_bwd(P, G, ctx, dmask, B, T, Fq):
     G[f'{p}.norm.weight'] += dg4[:1]
     G[f'{p}.norm.bias'] += db4[:1]
     G[f'{p}.prelu.weight'] += da4[:1]
-    if THIN_CONV:
+    if THIN_CONV & 8:
         dS = conv1x2_bwd(ctx['S'], P[f'{p}.conv_1.weight'], dr, G[f'{p}.conv_1.weight'], G[f'{p}.conv_1.bias'], B, T, F2)
     else:
         dw1 = O.zeros(4, 64, 1, 2, device=dev)
@@ -849,7 +849,7 @@ def complex_decoder_fwd(P, x, B, T, Fq):
     Fo = F2 - 1
     a = torch.empty_like(S)
     mr = inorm_prelu_fwd(S, st, P[f'{p}.norm.weight'], P[f'{p}.norm.bias'], P[f'{p}.prelu.weight'], a, 64, 0)
-    if THIN_CONV:
+    if THIN_CONV & 4:
         cplx, _ = conv1x2_fwd(a, P[f'{p}.conv.weight'], P[f'{p}.conv.bias'], B, T, F2, False)
     else:
         wc = _w(P, (f'{p}.conv.weight', 'fwd'), lambda: pack_w(pad_rows(P[f'{p}.conv.weight'], 4)))
@@ -863,7 +863,7 @@ def complex_decoder_bwd(P, G, ctx, dcplx, B, T, Fq):
     p = 'complex_decoder'
     Fo, F2 = ctx['Fo'], 2 * Fq
     dev = dcplx.device
-    if THIN_CONV:
+    if THIN_CONV & 8:
         da = conv1x2_bwd(ctx['a'], P[f'{p}.conv.weight'], dcplx.contiguous(), G[f'{p}.conv.weight'], G[f'{p}.conv.bias'], B, T, F2)
     else:
         dwc = O.zeros(4, 64, 1, 2, device=dev)
