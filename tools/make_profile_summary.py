@@ -105,6 +105,15 @@ for r in stats:
         key = re.sub(r'[<(].*', '', k)
         cand = [v for kk, v in pmc.items() if key and key in kk]
         p = cand[0] if len(cand) == 1 else {}
+    if not p:       # a mangled name the PMC summary cut short (c++filt refuses it): compare (identifier, integer template arguments)
+        base = re.sub(r'^void ', '', re.sub(r'[<(].*', '', k)).strip()
+        args = [a.strip() for a in re.sub(r'^[^<]*<', '', k).rsplit('>', 1)[0].split(',')] if '<' in k else []
+        args = [{'true': '1', 'false': '0'}.get(a, a) for a in args]
+        for kk, v in pmc.items():
+            mm = re.match(r'^_Z\d+' + re.escape(base) + r'I((?:L[ib]n?\d+E)+)E', kk)
+            if mm and [('-' if t[2] == 'n' else '') + re.sub(r'\D', '', t) for t in re.findall(r'L[ib]n?\d+', mm.group(1))] == args:
+                p = v
+                break
     row = {'kernel': k, 'calls_per_step': round(int(r['Calls']) / steps_in_trace, 2), 'avg_us': round(float(r['AverageNs']) / 1e3, 1),
            'pct_gpu_time': round(100 * float(r['TotalDurationNs']) / total_ns, 2)}
     busy = p.get('SQ_BUSY_CYCLES')
