@@ -1665,17 +1665,24 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int 
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m[t], tmax);
-        const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
-        m[t] = mn;
-        const float mnp = F16 ? mn - 13.f : mn;                     // F16: p and the running sum carry the factor 2^13 of P's scale
+        // F16: the running reference m moves only when some query of the tile outgrows it by more than 2^LAZY (wave-uniform test):
+        // after the first key tiles that is rare, and the rescale of o / l (an exp2, 5 multiplies) and its dependency on this
+        // tile's maximum leave the chain.  p <= 2^LAZY then, so P's fp16 scale is 2^(13 - LAZY) (hi plane <= 2^13).
+        constexpr float LAZY = 4.f, PSC = F16 ? 13.f - LAZY : 0.f;
+        if (!F16 || __builtin_amdgcn_ballot_w64(tmax > m[t] + LAZY) != 0) {
+          const float mn = fmaxf(m[t], tmax);
+          const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
+          m[t] = mn;
+          l[t] *= corr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[t][r] *= corr;
+        }
+        const float mnp = m[t] - PSC;                               // F16: p and the running sum carry the factor 2^PSC of P's scale
         f32x4 p;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mnp); psum += p[r]; }
-        l[t] = l[t] * corr + psum;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[t][r] *= corr;
+        l[t] += psum;
         o[t] = prodx<F16>(vcol, splitn<F16>(p), o[t]);         // O^T[d 4g + r][query c] += V^T[d][key] P^T[key][query]
       }
       // slide the offset window: next step's hi fragments are this step's lo fragments
@@ -1699,7 +1706,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int 
         const long tok = base + (long)qi * ps;
         const float inv = osc / lt;                                 // (F16: the 2^13 of P cancels, V's 2^sq is taken out here)
         *reinterpret_cast<float4*>(a.O + tok * 64 + head * 16 + 4 * g) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
-        if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt) - (F16 ? 13.f : 0.f)) * 0.6931471805599453f;
+        if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt) - (F16 ? 9.f : 0.f)) * 0.6931471805599453f;      // (9 = 13 - LAZY)
       }
     }
   }

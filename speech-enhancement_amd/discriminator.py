@@ -18,6 +18,9 @@ from . import _lib as L
 from . import layers as LY
 from . import ops as O
 
+# arithmetic of the 4x4 stride-2 convolutions with >= 32 input channels (forward, input gradients): 2 = exact three-way bf16 split, six
+# products (fp32-equivalent, the generic split kernel: K = 16 taps x C >= 512); 0 = fp32 MFMA (SE_D_PRECISION=0: A/B switch)
+D_PRECISION = int(__import__('os').environ.get('SE_D_PRECISION', '2'))
 THIN_CONV1 = __import__('os').environ.get('SE_NO_THIN_CONV1') != '1'      # A/B switch: the first stage through the tap GEMM again
 
 # weight index (kh over F, kw over T)  ->  tap offset on the [T, F] grid
@@ -188,7 +191,8 @@ class _DConvStackFn(torch.autograd.Function):
                        C.c_int(Fi), C.c_int(N), L.stream(), _key='dconv1 (thin)', _bytes=4.0 * B * (Ti * Fi * 4 + To * Fo * N))
             else:
                 wp = LY.pack_w(Ws[i].contiguous(), C_pad=Cin)
-                d = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2, epilogue=L.EPI_STATS)
+                d = LY.GM.make_desc(B, To, Fo, Ti, Fi, D_TAPS, Cin, Cin, N, N, st=2, sf=2, epilogue=L.EPI_STATS,
+                                    precision=D_PRECISION if Cin >= 32 else 0)
                 LY.GM.gemm_tap(d, x, wp, R, stats=stats)
             a = torch.empty_like(R)
             mr = LY.inorm_prelu_fwd(R, stats, gs[i], bs[i], sl[i], a, N, 0)
@@ -229,7 +233,8 @@ class _DConvStackFn(torch.autograd.Function):
                 if wd.shape[0] != Cin:
                     wd = torch.cat([wd, wd.new_zeros(Cin - wd.shape[0], wd.shape[1])], 0)
                 dx = torch.empty(B, Ti, Fi, Cin, device=dR.device, dtype=torch.float32)
-                dd = LY.GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in D_TAPS], N, N, Cin, Cin, st=2, sf=2, up=1)
+                dd = LY.GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in D_TAPS], N, N, Cin, Cin, st=2, sf=2, up=1,
+                                     precision=D_PRECISION if N >= 32 else 0)
                 LY.GM.gemm_tap(dd, dR, wd, dx)
                 dy = dx
                 if i == 0:
