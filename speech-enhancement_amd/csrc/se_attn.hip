@@ -1537,6 +1537,7 @@ template <int V> struct IC_ { static constexpr int value = V; };
 template <int TQ, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
+  static_assert(TQ == 1 || TQ == 2, "the offset-fragment ring of key_step is indexed by the step parity");
   constexpr int NPLA = F16 ? 2 : 3;
   unsigned char* Vimg = smem_f3;                               // [NPLA planes][NP keys][16 d] 16-bit
   float* Ubase = reinterpret_cast<float*>(smem_f3 + (size_t)NPLA * NP * 32);
@@ -1642,11 +1643,15 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int 
       constexpr int hi = decltype(HC)::value, lo = hi ^ 1;
       constexpr bool MASK = decltype(MC)::value != 0;
       const int j0 = kt * 16;
-      ef[0] = enext;
+      // the window slides by one fragment per step and a step reads the TQ newest ones: they live in a ring of TQ registers sets,
+      // LOGICAL fragment t of step kt in slot (t - kt) mod TQ = (t - hi) mod TQ (TQ <= 2) -- nothing is moved (the shifting form
+      // cost 4 TQ register moves per plane and step); ef[TQ] is only the hi fragment of the last tile at the start of a block
+      constexpr int RR = hi % TQ;
+      ef[(TQ - RR) % TQ] = enext;
       const S3 kf = splitx<F16>(knext, sqf);
       if (kt + 1 < nkt) { enext = e_row(i0 - j0 - 32); knext = k_row(j0 + 16); }      // one step ahead
 #pragma unroll
-      for (int t = 0; t < TQ; ++t) u_tile(ef[t], t, lo);          // lo tile of query tile t: offsets base i0 + 16 (t - 1) - j0
+      for (int t = 0; t < TQ; ++t) u_tile(ef[(t + TQ - RR) % TQ], t, lo);          // lo tile of query tile t: offsets base i0 + 16 (t - 1) - j0
       // V[j0 + 4g + j][d = c]: transposed read of the row image
       const S3 vcol = tr_planes<F16>(Vimg + ((j0 + 4 * g + trrow) * 16 + 4 * trcol) * 2, vpb);
 #pragma unroll
@@ -1685,9 +1690,6 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int 
         l[t] += psum;
         o[t] = prodx<F16>(vcol, splitn<F16>(p), o[t]);         // O^T[d 4g + r][query c] += V^T[d][key] P^T[key][query]
       }
-      // slide the offset window: next step's hi fragments are this step's lo fragments
-#pragma unroll
-      for (int t = TQ; t > 0; --t) ef[t] = ef[t - 1];
     };
     {
       const int nlast = nkt - 1;
