@@ -492,6 +492,11 @@ int se_dconv1_fwd(const float* X, const float* W, float* R, double* stats, int B
 int se_dconv1_dgrad(const float* dR, const float* W, float* dX, int B, int T, int F, int N, void* stream);
 int se_dconv1_wgrad(const float* X, const float* dR, float* dW, int B, int T, int F, int N, void* stream);
 
+/* Input gradient of Conv2d(Cin, N, 4, 2, 1) (models/discriminator.py:42-50, stages 2 - 4) by parity class: dR [B][To][Fo][N]
+ * (To = (Ti - 2) / 2 + 1), Wd [Cin][16 taps = kh * 4 + kw][N] (the packed input-gradient matrix), dX [B][Ti][Fi][Cin] written
+ * whole.  N % 32 == 0, Cin <= 64, Cin % 4 == 0. */
+int se_dconv_dgrad(const float* dR, const float* Wd, float* dX, int B, int Ti, int Fi, int N, int Cin, void* stream);
+
 /* ---- the generator's thin convolutions as direct kernels (csrc/se_thin.hip; round 4) --------------------------------------- */
 /* Conv2d(64, n, (1, 2)), n = 1 (models/generator.py:114, mask decoder) or 2 (:128, complex decoder): X [B T][F2][64] channels-last,
  * W [n][64][1][2] and bias [n] in the PyTorch layout, Y / dY [B T][F2 - 1][4] (channels >= n written as zero / ignored); stats (may

@@ -424,6 +424,108 @@ __global__ __launch_bounds__(256) void conv3to64_wgrad_kernel(const float* __res
   }
 }
 
+// ================================================================================================================================
+// Input gradient of the discriminator's 4x4 stride-2 padding-1 convolutions (models/discriminator.py:42-50, stages 2 - 4) by PARITY
+// CLASS.  dx[t][f] = sum over the taps (kw, kh) with t + 1 - kw and f + 1 - kh even: 4 of the 16 taps, the same 4 for every pixel of
+// a class (t mod 2, f mod 2).  The tap GEMM in `up` mode walks all 16 taps for every 128-pixel tile and zero-fills 12 of them per row
+// (148 / 92 / 148 us per launch for 1 GFLOP of real work).  Here a workgroup owns 128 pixels of ONE class: K = 4 taps x N, no zero
+// rows, output scattered to the class's pixels.  fp32 MFMA (32x32x2), LDS tiles as in gemm_tap_kernel (row-major, +4 pad).
+//   dR [B][To][Fo][N], Wd [Cin][16 taps = kh * 4 + kw][N] (gemm.pack_conv_dgrad), dX [B][Ti][Fi][Cin]
+// ================================================================================================================================
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+template <int BN>
+__global__ __launch_bounds__(256) void dconv_dgrad_cls_kernel(const float* __restrict__ dR, const float* __restrict__ Wd, float* __restrict__ dX,
+                                                              int To, int Fo, int Ti, int Fi, int N, int Cin) {
+  constexpr int BM = 128, BK = 32, SA = BK + 4, KQ = BK / 4, RPP = 256 / KQ, NA = BM / RPP, NB = (BN + RPP - 1) / RPP;
+  __shared__ __attribute__((aligned(16))) float As[BM * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * SA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cls = blockIdx.y, pt = cls >> 1, pf = cls & 1, b = blockIdx.z;
+  const int Tc = (Ti - pt + 1) >> 1, Fc = (Fi - pf + 1) >> 1, Mc = Tc * Fc;
+  const int m0 = blockIdx.x * BM, cb = 0;
+  if (m0 >= Mc) return;
+  const int kq = tid % KQ, r0 = tid / KQ;
+  const float* __restrict__ Rb = dR + (long)b * To * Fo * N;
+  const int ldw = 16 * N;
+  // the class's taps and their source offsets: kw = kw0, kw0 + 2 with to = t' + dto; the same along f
+  const int kw0 = (pt + 1) & 1, kh0 = (pf + 1) & 1;
+  const int dto0 = (pt + 1 - kw0) >> 1, dfo0 = (pf + 1 - kh0) >> 1;          // (second tap of a pair: one less)
+  int rt[NA], rf[NA];
+  bool rok[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int m = m0 + r0 + i * RPP;
+    rok[i] = m < Mc;
+    rt[i] = m / Fc; rf[i] = m - rt[i] * Fc;
+  }
+  const int nchunk = N / BK, NI = 4 * nchunk;            // N % 32 == 0 (host-checked)
+  float4 ra[NA], rb[NB];
+  auto load_tiles = [&](int it) {
+    const int chunk = it >> 2, j = it & 3, jw = j & 1, jh = j >> 1;    // channel chunk outer, the 4 taps inner
+    const int tap = (kh0 + 2 * jh) * 4 + kw0 + 2 * jw;
+    const int c = chunk * BK + kq * 4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int to = rt[i] + dto0 - jw, fo = rf[i] + dfo0 - jh;
+      const bool ok = rok[i] && to >= 0 && to < To && fo >= 0 && fo < Fo;
+      ra[i] = ok ? *reinterpret_cast<const float4*>(Rb + ((unsigned)(to * Fo + fo) * (unsigned)N + (unsigned)c)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int n = cb * BN + r0 + i * RPP;
+      rb[i] = (n < Cin && r0 + i * RPP < BN) ? *reinterpret_cast<const float4*>(Wd + ((unsigned)n * (unsigned)ldw + (unsigned)(tap * N + c)))
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  f32x16t acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  load_tiles(0);
+  const float* Ap = &As[(wave * 32 + (lane & 31)) * SA + (lane >> 5) * (BK / 2)];
+  const float* Bp0 = &Bs[(lane & 31) * SA + (lane >> 5) * (BK / 2)];
+  const float* Bp1 = Bp0 + 32 * SA;
+  for (int it = 0; it < NI; ++it) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<float4*>(&As[(r0 + i * RPP) * SA + kq * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (r0 + i * RPP < BN) *reinterpret_cast<float4*>(&Bs[(r0 + i * RPP) * SA + kq * 4]) = rb[i];
+    __syncthreads();
+    if (it + 1 < NI) load_tiles(it + 1);
+#pragma unroll
+    for (int s4 = 0; s4 < BK / 2; s4 += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(Ap + s4);
+      const float4 b0 = *reinterpret_cast<const float4*>(Bp0 + s4);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0);
+      if (BN > 32) {
+        const float4 b1 = *reinterpret_cast<const float4*>(Bp1 + s4);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // C layout: lane (col = lane & 31, half = lane >> 5) holds rows (r & 3) + 8 (r >> 2) + 4 half: 32 lanes store 128 contiguous bytes
+  const int col = lane & 31, half = lane >> 5;
+  float* __restrict__ Xb = dX + (long)b * Ti * Fi * Cin;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (m < Mc) {
+      const int tq = m / Fc, fq = m - tq * Fc;
+      float* o = Xb + ((long)(2 * tq + pt) * Fi + 2 * fq + pf) * Cin;
+      if (col < Cin) o[col] = acc0[r];
+      if (BN > 32 && col + 32 < Cin) o[col + 32] = acc1[r];
+    }
+  }
+}
+
 static int thin_grid(long pixels, long cap) {
   long nb = (pixels + 16 * TU - 1) / (16 * TU);
   if (nb > cap) nb = cap;
@@ -496,4 +598,15 @@ extern "C" int se_conv3to64_wgrad(const float* X, const float* dR, float* dW, fl
   SE_REQUIRE(X && dR && dW && dbias && npix > 0, "conv3to64_wgrad: bad arguments");
   hipLaunchKernelGGL(conv3to64_wgrad_kernel, dim3(thin_grid(npix, 1024)), dim3(256), 0, as_stream(stream), X, dR, dW, dbias, npix);
   return se_check_launch("se_conv3to64_wgrad");
+}
+
+extern "C" int se_dconv_dgrad(const float* dR, const float* Wd, float* dX, int B, int Ti, int Fi, int N, int Cin, void* stream) {
+  SE_REQUIRE(dR && Wd && dX && B > 0 && Ti > 1 && Fi > 1 && N >= 32 && (N % 32) == 0 && Cin >= 4 && Cin <= 64 && (Cin % 4) == 0,
+             "dconv_dgrad: bad arguments (N = %d: a multiple of 32; Cin = %d: <= 64)", N, Cin);
+  const int To = (Ti + 2 - 4) / 2 + 1, Fo = (Fi + 2 - 4) / 2 + 1;
+  const int Tc = (Ti + 1) / 2, Fc = (Fi + 1) / 2;            // the largest class
+  const dim3 grid((unsigned)((Tc * Fc + 127) / 128), 4, (unsigned)B);
+  if (Cin <= 32) hipLaunchKernelGGL(dconv_dgrad_cls_kernel<32>, grid, dim3(256), 0, as_stream(stream), dR, Wd, dX, To, Fo, Ti, Fi, N, Cin);
+  else hipLaunchKernelGGL(dconv_dgrad_cls_kernel<64>, grid, dim3(256), 0, as_stream(stream), dR, Wd, dX, To, Fo, Ti, Fi, N, Cin);
+  return se_check_launch("se_dconv_dgrad");
 }

@@ -21,6 +21,7 @@ from . import ops as O
 # arithmetic of the 4x4 stride-2 convolutions with >= 32 input channels (forward, input gradients): 2 = exact three-way bf16 split, six
 # products (fp32-equivalent, the generic split kernel: K = 16 taps x C >= 512); 0 = fp32 MFMA (SE_D_PRECISION=0: A/B switch)
 D_PRECISION = int(__import__('os').environ.get('SE_D_PRECISION', '2'))
+CLASS_DGRAD = __import__('os').environ.get('SE_NO_CLASS_DGRAD') != '1'      # A/B switch: the input gradients through the `up`-mode tap GEMM
 THIN_CONV1 = __import__('os').environ.get('SE_NO_THIN_CONV1') != '1'      # A/B switch: the first stage through the tap GEMM again
 
 # weight index (kh over F, kw over T)  ->  tap offset on the [T, F] grid
@@ -233,9 +234,14 @@ class _DConvStackFn(torch.autograd.Function):
                 if wd.shape[0] != Cin:
                     wd = torch.cat([wd, wd.new_zeros(Cin - wd.shape[0], wd.shape[1])], 0)
                 dx = torch.empty(B, Ti, Fi, Cin, device=dR.device, dtype=torch.float32)
-                dd = LY.GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in D_TAPS], N, N, Cin, Cin, st=2, sf=2, up=1,
-                                     precision=D_PRECISION if N >= 32 else 0)
-                LY.GM.gemm_tap(dd, dR, wd, dx)
+                if CLASS_DGRAD and N % 32 == 0 and Cin <= 64 and To == _out(Ti) and Fo == _out(Fi):
+                    # 4 of the 16 taps reach a pixel: one workgroup per 128 pixels of a parity class (csrc/se_thin.hip)
+                    L.call('se_dconv_dgrad', L.ptr(dR), L.ptr(wd), L.ptr(dx), C.c_int(B), C.c_int(Ti), C.c_int(Fi), C.c_int(N), C.c_int(Cin),
+                           L.stream(), _key='dconv dgrad (parity classes)', _flops=2.0 * B * Ti * Fi * Cin * 4 * N)
+                else:
+                    dd = LY.GM.make_desc(B, Ti, Fi, To, Fo, [(-a, -c) for a, c in D_TAPS], N, N, Cin, Cin, st=2, sf=2, up=1,
+                                         precision=D_PRECISION if N >= 32 else 0)
+                    LY.GM.gemm_tap(dd, dR, wd, dx)
                 dy = dx
                 if i == 0:
                     dxy = dx

@@ -736,3 +736,22 @@ def test_generator_thin_convolution_3_to_64(G, B, P):
     dw, db = torch.full((64, 3, 1, 1), 0.25, device='cuda'), torch.full((64,), 0.5, device='cuda')
     L.call('se_conv3to64_wgrad', L.ptr(x), L.ptr(dR), L.ptr(dw), L.ptr(db), C.c_long(B * P), L.stream())
     assert relerr(dw.view(64, 3) - 0.25, wd.grad) < 5e-6 and relerr(db - 0.5, bd.grad) < 5e-6
+
+
+@pytest.mark.parametrize('B,Ti,Fi,Cin,N', [(2, 160, 100, 16, 32), (2, 80, 50, 32, 64), (1, 40, 25, 64, 128), (3, 37, 21, 16, 32),
+                                            (1, 2, 2, 32, 32), (2, 9, 300, 4, 64)])
+def test_discriminator_input_gradient_by_parity_class(G, B, Ti, Fi, Cin, N):
+    """se_dconv_dgrad (csrc/se_thin.hip) vs torch autograd in fp64: the input gradient of Conv2d(Cin, N, 4, 2, 1)
+    (models/discriminator.py:42-50) on the transposed [T, F] image, one workgroup per 128 pixels of a parity class"""
+    import ctypes as C
+    gemm, L = G
+    To, Fo = (Ti - 2) // 2 + 1, (Fi - 2) // 2 + 1
+    w = rnd(N, Cin, 4, 4, seed=1, scale=(16 * Cin) ** -0.5)
+    dR = rnd(B, To, Fo, N, seed=2)
+    wd = gemm.pack_conv_dgrad(w)                               # [Cin][16][N]
+    dx = torch.full((B, Ti, Fi, Cin), 7.0, device='cuda')
+    L.call('se_dconv_dgrad', L.ptr(dR), L.ptr(wd), L.ptr(dx), C.c_int(B), C.c_int(Ti), C.c_int(Fi), C.c_int(N), C.c_int(Cin), L.stream())
+    xi = torch.zeros(B, Cin, Fi, Ti, device='cuda', dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(xi, w.double(), None, 2, 1)                 # [B, N, Fo, To]
+    ref.backward(dR.permute(0, 3, 2, 1).double())
+    assert relerr(dx, xi.grad.permute(0, 3, 2, 1)) < 3e-6
