@@ -604,6 +604,7 @@ extern "C" int se_dconv_dgrad(const float* dR, const float* Wd, float* dX, int B
   SE_REQUIRE(dR && Wd && dX && B > 0 && Ti > 1 && Fi > 1 && N >= 32 && (N % 32) == 0 && Cin >= 4 && Cin <= 64 && (Cin % 4) == 0,
              "dconv_dgrad: bad arguments (N = %d: a multiple of 32; Cin = %d: <= 64)", N, Cin);
   const int To = (Ti + 2 - 4) / 2 + 1, Fo = (Fi + 2 - 4) / 2 + 1;
+  SE_REQUIRE((long)To * Fo * N < (1L << 31) && (long)Ti * Fi * Cin < (1L << 31), "dconv_dgrad: a batch entry must stay below 2^31 elements");
   const int Tc = (Ti + 1) / 2, Fc = (Fi + 1) / 2;            // the largest class
   const dim3 grid((unsigned)((Tc * Fc + 127) / 128), 4, (unsigned)B);
   if (Cin <= 32) hipLaunchKernelGGL(dconv_dgrad_cls_kernel<32>, grid, dim3(256), 0, as_stream(stream), dR, Wd, dX, To, Fo, Ti, Fi, N, Cin);
