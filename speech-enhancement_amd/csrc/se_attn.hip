@@ -1777,6 +1777,7 @@ static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long 
     int nw3 = qb32 <= 4 ? 4 : 8, tq3 = qb32 <= 4 ? 1 : 2;
     if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v >= 1 && v <= 8) nw3 = v; }
     if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq3 = v; }
+    if (qb32 <= 4) { if (const char* e = getenv("SE_ATTN_FWD_WAVES_SMALL")) { int v = atoi(e); if (v >= 1 && v <= 8) nw3 = v; } }
     // fewer items than two rounds of workgroups (batch-1 inference): split the query blocks of an item over several workgroups
     int qsplit = 1;
     {
