@@ -14,8 +14,6 @@
 namespace {
 constexpr int DN = 16;      // output channels (ndf); host-checked
 
-__device__ __forceinline__ double wave_sum_dd(double v) { return wave_sum_d(v); }
-
 // ---- forward: 4 threads per output pixel (4 channels each); one batch entry per blockIdx.y ----
 __global__ __launch_bounds__(256) void dconv1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W, float* __restrict__ R,
                                                          double* __restrict__ stats, int T, int F, int To, int Fo) {
