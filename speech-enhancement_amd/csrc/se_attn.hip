@@ -1075,6 +1075,7 @@ struct AttnBwd3Args {
   // kernel of the same call); Es / Ets then hold TWO fp16 planes of E * 2^sexp(*e_amax)
   const float* qkv_amax; const float* do_amax; const float* e_amax;
   float* dqkv_amax;                  // optional (F16): raised to max |dQKV| (operand scale of the consumers of the gradient)
+  const float* O;                    // the forward output (attn_bwd4 at n <= 112: delta computed in the kernel)
 };
 
 // key tiles of wave w when the 4 waves of a workgroup share one (sequence, head)
@@ -1941,7 +1942,18 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
   // phase 2 = the reduction of the per-wave dE tiles alone (a leaf of the backward graph: the caller may issue it on another
   // stream once phase 1 has been queued); only the decoupled kernel has one -- the other kernels do everything in phase 1
   if (!(phase & 1) && !v3) return 0;
-  if (phase & 1) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
+  // (the cooperative kernel at n <= 112 computes delta from the O rows itself: no table, no launch)
+  static const int bwd4_mode0 = getenv("SE_ATTN_BWD4") ? atoi(getenv("SE_ATTN_BWD4")) : 3;
+  static const int small_nw0 = getenv("SE_ATTN_BWD4_SMALL_NW") ? atoi(getenv("SE_ATTN_BWD4_SMALL_NW")) : 2;
+  bool delta_in_kernel = false;
+  if (v3 && qkv_amax != nullptr && (n + 15) / 16 <= 7 && (bwd4_mode0 & 1)) {
+    const int nkt0 = (n + 15) / 16;
+    const AttnBwd4Plan p0 = small_nw0 == 4 ? attn_bwd4_plan(nkt0, 4, 1) : attn_bwd4_plan(nkt0, 2, 2);
+    int kmax0 = 0;
+    for (int w4 = 0; w4 < 8; ++w4) kmax0 = p0.cnt[w4] > kmax0 ? p0.cnt[w4] : kmax0;
+    delta_in_kernel = p0.M > 0 && kmax0 <= (small_nw0 == 4 ? 2 : 4);
+  }
+  if ((phase & 1) && !delta_in_kernel) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
   if (v3) {
     // decoupled split-bf16 kernel: one wave per (sequence, head[, key group]); no offset clamp can be active
     __bf16* Es = reinterpret_cast<__bf16*>((char*)ws + w.es);
@@ -1956,7 +1968,7 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
       else hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
     }
     AttnBwd3Args b{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, dO, LSE, Dl, dQKV, Es, Ets,
-                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax, dqkv_amax};
+                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax, dqkv_amax, O};
     if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
     const long items = (long)nseq * 4;
     int e;

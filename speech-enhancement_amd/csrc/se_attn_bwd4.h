@@ -112,6 +112,11 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   const float* dob = a.dO + base * 64 + head * 16;
   const float* lseb = a.LSE + base * 4 + head;
   const float* dlb = a.Dl + base * 4 + head;
+  // DLT: delta = rowsum(dO . O) of the head is computed by the loader from the O row (one more 16-byte load per query row and lane
+  // group, 4 FMAs, two cross-group adds) instead of read from the table of attn_delta_kernel -- that launch (41 us, 274 MB) is not
+  // issued then.  Only where the registers allow it: the n > 128 instantiation is at its 256 with 96 bytes of scratch already.
+  constexpr bool DLT = NKTM <= 7;
+  const float* ob = a.O + base * 64 + head * 16;
   float* dqb = a.dQKV + base * 192 + head * 16;
   float* dEs = a.dEs + item * (long)(2 * nkt) * 256;
   const int trrow = c >> 2, trcol = c & 3;
@@ -157,18 +162,26 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   // ---- query-side stage: raw loads of one query tile (loader wave only), later split into the two images ----
   float4 lq = make_float4(0.f, 0.f, 0.f, 0.f), ldo = lq;
   float lr0 = 0.f, lr1 = 0.f;
+  float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto stage_load = [&](int qt_) {
     int qc = qt_ * 16 + c;
     if (qc > n - 1) qc = n - 1;
     lq = *reinterpret_cast<const float4*>(qb + (unsigned)(qc * ps * 192 + 4 * g));
     ldo = *reinterpret_cast<const float4*>(dob + (unsigned)(qc * ps * 64 + 4 * g));
     lr0 = lseb[(unsigned)(qc * ps * 4)];
-    lr1 = dlb[(unsigned)(qc * ps * 4)];
+    if (DLT) lo4 = *reinterpret_cast<const float4*>(ob + (unsigned)(qc * ps * 64 + 4 * g));
+    else lr1 = dlb[(unsigned)(qc * ps * 4)];
   };
   auto stage_store = [&]() {
     st_planes<true>(Qimg + rfo, 512, splitx<true>(lq, sqf));
     st_planes<true>(Oimg + rfo, 512, splitx<true>(ldo, sdof));
     if (g == 0) rowc[c] = lr0;
+    if (DLT) {
+      float dl = ldo.x * lo4.x + ldo.y * lo4.y + ldo.z * lo4.z + ldo.w * lo4.w;      // this lane group's 4 of the head's 16 dims
+      dl += __shfl_xor(dl, 16, 64);
+      dl += __shfl_xor(dl, 32, 64);
+      lr1 = dl;
+    }
     if (g == 1) rowc[16 + c] = lr1;
   };
   if (wave == 0) stage_load(0);
