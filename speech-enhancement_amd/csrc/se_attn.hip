@@ -1075,7 +1075,7 @@ struct AttnBwd3Args {
   // kernel of the same call); Es / Ets then hold TWO fp16 planes of E * 2^sexp(*e_amax)
   const float* qkv_amax; const float* do_amax; const float* e_amax;
   float* dqkv_amax;                  // optional (F16): raised to max |dQKV| (operand scale of the consumers of the gradient)
-  const float* O;                    // the forward output (attn_bwd4 at n <= 112: delta computed in the kernel)
+  const float* O;                    // the forward output (attn_bwd4: delta computed in the kernel)
 };
 
 // key tiles of wave w when the 4 waves of a workgroup share one (sequence, head)
@@ -1942,16 +1942,17 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
   // phase 2 = the reduction of the per-wave dE tiles alone (a leaf of the backward graph: the caller may issue it on another
   // stream once phase 1 has been queued); only the decoupled kernel has one -- the other kernels do everything in phase 1
   if (!(phase & 1) && !v3) return 0;
-  // (the cooperative kernel at n <= 112 computes delta from the O rows itself: no table, no launch)
+  // (the cooperative kernels compute delta from the O rows themselves: no table, no launch)
   static const int bwd4_mode0 = getenv("SE_ATTN_BWD4") ? atoi(getenv("SE_ATTN_BWD4")) : 3;
   static const int small_nw0 = getenv("SE_ATTN_BWD4_SMALL_NW") ? atoi(getenv("SE_ATTN_BWD4_SMALL_NW")) : 2;
   bool delta_in_kernel = false;
-  if (v3 && qkv_amax != nullptr && (n + 15) / 16 <= 7 && (bwd4_mode0 & 1)) {
+  if (v3 && qkv_amax != nullptr && (n + 15) / 16 <= 21 && (bwd4_mode0 & ((n + 15) / 16 <= 7 ? 1 : 2))) {
     const int nkt0 = (n + 15) / 16;
-    const AttnBwd4Plan p0 = small_nw0 == 4 ? attn_bwd4_plan(nkt0, 4, 1) : attn_bwd4_plan(nkt0, 2, 2);
+    const bool sm0 = nkt0 <= 7;
+    const AttnBwd4Plan p0 = sm0 ? (small_nw0 == 4 ? attn_bwd4_plan(nkt0, 4, 1) : attn_bwd4_plan(nkt0, 2, 2)) : attn_bwd4_plan(nkt0, 4, 3);
     int kmax0 = 0;
     for (int w4 = 0; w4 < 8; ++w4) kmax0 = p0.cnt[w4] > kmax0 ? p0.cnt[w4] : kmax0;
-    delta_in_kernel = p0.M > 0 && kmax0 <= (small_nw0 == 4 ? 2 : 4);
+    delta_in_kernel = p0.M > 0 && (sm0 ? kmax0 <= (small_nw0 == 4 ? 2 : 4) : kmax0 <= 6);
   }
   if ((phase & 1) && !delta_in_kernel) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
   if (v3) {

@@ -114,8 +114,9 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   const float* dlb = a.Dl + base * 4 + head;
   // DLT: delta = rowsum(dO . O) of the head is computed by the loader from the O row (one more 16-byte load per query row and lane
   // group, 4 FMAs, two cross-group adds) instead of read from the table of attn_delta_kernel -- that launch (41 us, 274 MB) is not
-  // issued then.  Only where the registers allow it: the n > 128 instantiation is at its 256 with 96 bytes of scratch already.
-  constexpr bool DLT = NKTM <= 7;
+  // issued then.  (The n > 128 instantiation sits at its 256 registers: 96 -> 112 bytes of scratch with it, still faster: the family
+  // 5.75 -> 5.24 ms per step, n <= 112: 2.55 -> 2.34.)
+  constexpr bool DLT = true;
   const float* ob = a.O + base * 64 + head * 16;
   float* dqb = a.dQKV + base * 192 + head * 16;
   float* dEs = a.dEs + item * (long)(2 * nkt) * 256;
