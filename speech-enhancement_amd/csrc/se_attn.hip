@@ -1945,6 +1945,10 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
   // (the cooperative kernels compute delta from the O rows themselves: no table, no launch)
   static const int bwd4_mode0 = getenv("SE_ATTN_BWD4") ? atoi(getenv("SE_ATTN_BWD4")) : 3;
   static const int small_nw0 = getenv("SE_ATTN_BWD4_SMALL_NW") ? atoi(getenv("SE_ATTN_BWD4_SMALL_NW")) : 2;
+  // SE_ATTN_DELTA_IN_KERNEL=1 (opt-in): the cooperative kernels compute delta from the O rows (no attn_delta_kernel launch).  Same-box
+  // A/B: SLOWER -- n = 321 family 6.31 -> 6.51 ms per step, n = 101 2.77 -> 2.81 (the loader's extra row load and two cross-group adds
+  // sit on the per-query-tile chain; the stand-alone pass is 41 us of pure streaming)
+  static const bool delta_kernel_forced = !(getenv("SE_ATTN_DELTA_IN_KERNEL") != nullptr && atoi(getenv("SE_ATTN_DELTA_IN_KERNEL")) == 1);
   bool delta_in_kernel = false;
   if (v3 && qkv_amax != nullptr && (n + 15) / 16 <= 21 && (bwd4_mode0 & ((n + 15) / 16 <= 7 ? 1 : 2))) {
     const int nkt0 = (n + 15) / 16;
@@ -1952,7 +1956,7 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     const AttnBwd4Plan p0 = sm0 ? (small_nw0 == 4 ? attn_bwd4_plan(nkt0, 4, 1) : attn_bwd4_plan(nkt0, 2, 2)) : attn_bwd4_plan(nkt0, 4, 3);
     int kmax0 = 0;
     for (int w4 = 0; w4 < 8; ++w4) kmax0 = p0.cnt[w4] > kmax0 ? p0.cnt[w4] : kmax0;
-    delta_in_kernel = p0.M > 0 && (sm0 ? kmax0 <= (small_nw0 == 4 ? 2 : 4) : kmax0 <= 6);
+    delta_in_kernel = !delta_kernel_forced && p0.M > 0 && (sm0 ? kmax0 <= (small_nw0 == 4 ? 2 : 4) : kmax0 <= 6);
   }
   if ((phase & 1) && !delta_in_kernel) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
   if (v3) {
@@ -1971,6 +1975,7 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     AttnBwd3Args b{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, dO, LSE, Dl, dQKV, Es, Ets,
                    reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax, dqkv_amax, O};
     if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
+    if (delta_kernel_forced) b.dbg |= 128;
     const long items = (long)nseq * 4;
     int e;
     // round 4: the workgroup-cooperative kernel (se_attn_bwd4.h) for every shape its two instantiations cover; SE_ATTN_BWD4=0: v3

@@ -114,8 +114,7 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   const float* dlb = a.Dl + base * 4 + head;
   // DLT: delta = rowsum(dO . O) of the head is computed by the loader from the O row (one more 16-byte load per query row and lane
   // group, 4 FMAs, two cross-group adds) instead of read from the table of attn_delta_kernel -- that launch (41 us, 274 MB) is not
-  // issued then.  (The n > 128 instantiation sits at its 256 registers: 96 -> 112 bytes of scratch with it, still faster: the family
-  // 5.75 -> 5.24 ms per step, n <= 112: 2.55 -> 2.34.)
+  // issued then.  OPT-IN (dbg bit 128 clear = SE_ATTN_DELTA_IN_KERNEL=1): a same-box A/B shows it slower (se_attn.hip, attn_bwd_impl).
   constexpr bool DLT = true;
   const float* ob = a.O + base * 64 + head * 16;
   float* dqb = a.dQKV + base * 192 + head * 16;
@@ -170,14 +169,14 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
     lq = *reinterpret_cast<const float4*>(qb + (unsigned)(qc * ps * 192 + 4 * g));
     ldo = *reinterpret_cast<const float4*>(dob + (unsigned)(qc * ps * 64 + 4 * g));
     lr0 = lseb[(unsigned)(qc * ps * 4)];
-    if (DLT) lo4 = *reinterpret_cast<const float4*>(ob + (unsigned)(qc * ps * 64 + 4 * g));
-    else lr1 = dlb[(unsigned)(qc * ps * 4)];
+    if (DLT && !(a.dbg & 128)) lo4 = *reinterpret_cast<const float4*>(ob + (unsigned)(qc * ps * 64 + 4 * g));
+    else lr1 = dlb[(unsigned)(qc * ps * 4)];      // (dbg bit 128, the default: the table of attn_delta_kernel)
   };
   auto stage_store = [&]() {
     st_planes<true>(Qimg + rfo, 512, splitx<true>(lq, sqf));
     st_planes<true>(Oimg + rfo, 512, splitx<true>(ldo, sdof));
     if (g == 0) rowc[c] = lr0;
-    if (DLT) {
+    if (DLT && !(a.dbg & 128)) {
       float dl = ldo.x * lo4.x + ldo.y * lo4.y + ldo.z * lo4.z + ldo.w * lo4.w;      // this lane group's 4 of the head's 16 dims
       dl += __shfl_xor(dl, 16, 64);
       dl += __shfl_xor(dl, 32, 64);
