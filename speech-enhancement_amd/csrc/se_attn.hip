@@ -41,6 +41,7 @@ struct AttnArgs {
   // scaled split-fp16 form of the v3 kernel (se_attn_fwd_f16): Es = TWO fp16 planes of E * 2^sexp(*e_amax) (se_weight_prep fmt 1),
   // qkv_amax = device scalar >= max |QKV| (raised by the epilogue of the qkv GEMM: se_gemm_desc.y_amax)
   const float* qkv_amax; const float* e_amax;
+  int eager;         // (A/B switch SE_ATTN_FWD_LAZY=0: the softmax reference follows the running maximum at every key tile)
 };
 
 static __device__ __forceinline__ long tok_of(const AttnGeom& g, int s, int p) {
@@ -1675,7 +1676,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int 
         // after the first key tiles that is rare, and the rescale of o / l (an exp2, 5 multiplies) and its dependency on this
         // tile's maximum leave the chain.  p <= 2^LAZY then, so P's fp16 scale is 2^(13 - LAZY) (hi plane <= 2^13).
         constexpr float LAZY = 4.f, PSC = F16 ? 13.f - LAZY : 0.f;
-        if (!F16 || __builtin_amdgcn_ballot_w64(tmax > m[t] + LAZY) != 0) {
+        if (!F16 || a.eager || __builtin_amdgcn_ballot_w64(tmax > m[t] + LAZY) != 0) {
           const float mn = fmaxf(m[t], tmax);
           const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
           m[t] = mn;
@@ -1756,7 +1757,8 @@ extern "C" int se_attn_fwd_f16(const float* QKV, const void* Es, long es_plane, 
 static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
                          int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream,
                          const float* qkv_amax, const float* e_amax) {
-  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale, Es, es_plane, qkv_amax, e_amax};
+  static const int fwd_eager = getenv("SE_ATTN_FWD_LAZY") != nullptr && atoi(getenv("SE_ATTN_FWD_LAZY")) == 0;
+  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale, Es, es_plane, qkv_amax, e_amax, fwd_eager};
   const bool f16 = qkv_amax != nullptr;
   if (int e = check_geom(a.g)) return e;
   SE_REQUIRE(QKV && E && O, "attn_fwd: null operand");
