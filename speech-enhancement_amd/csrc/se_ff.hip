@@ -1,4 +1,5 @@
 // Fused feed-forward kernels of the Conformer blocks (forward; input-gradient chain + LayerNorm backward).
+#define SE_FF_EARLY_RES        // (A/B: comment out -- 3.97 -> 3.90 ms per step same-box)
 #include "se_gemm_dev.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -124,6 +125,18 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
   for (int r = 0; r < 16; ++r) { y0[r] = 0.f; y1[r] = 0.f; }
   const int frag = (lane & 31) * SB + 8 * kg;
   const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
+#ifdef SE_FF_EARLY_RES
+  // the residual rows in the epilogue's layout, requested right behind the prologue's read of the same lines (L1 / L2 hits) and
+  // kept through the sweep (32 registers): read at the END of the workgroup they were a second HBM-side fetch of X
+  float4 kept[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long rg_ = m0 + wave * 32 + rr + 8 * i;
+      kept[nt][i] = *reinterpret_cast<const float4*>(a.X + (rg_ < a.M ? rg_ : a.M - 1) * 64 + nt * 32 + cq * 4);
+    }
+#endif
   // H and Y leave through buffer stores whose descriptor covers the VALID rows of this workgroup's 128: a row past M is dropped
   // by the range check instead of a branch.  With branches around the stores the compiler can not count them, and the wait
   // for the next weight block (issued BEFORE them, so vmcnt(#stores) would do) became vmcnt(0): every hidden block waited for
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
     __syncthreads();
   }
   // Y = X + alpha * Drop_o(acc + b2)
+#ifndef SE_FF_EARLY_RES
   float4 kept[2][4];          // first the residual rows (all 8 loads in flight at once: they were 8 dependent round trips), then Y
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -227,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
       const long rg_ = m0 + wave * 32 + rr + 8 * i;
       kept[nt][i] = *reinterpret_cast<const float4*>(a.X + (rg_ < a.M ? rg_ : a.M - 1) * 64 + nt * 32 + cq * 4);
     }
+#endif
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
