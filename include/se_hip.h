@@ -215,6 +215,10 @@ int se_gemm_ln_bwd_f16(const float* A, const float* W, int w_planes, long M, int
 int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW, float* dbias,
                       const float* rowstats, const float* pro_scale, const float* pro_shift,
                       int chunks, void* stream);
+/* which kernel class the calling thread's last se_gemm_tap_wgrad dispatched to (measurement only: bench.py keys its
+ * weight-gradient families by it): bits 0..3 arithmetic (0 fp32 MFMA, 1 bf16x3, 2 bf16x6, 3 scaled f16x3), bits 4..7 class
+ * (0 generic tile kernel, 1 triple-tap kernel, 2 whole-gradient token-wise kernel) */
+int se_gemm_tap_wgrad_last_kind(void);
 
 /* Weight preparation of a whole model in ONE launch (the per-step re-packing of every parameter the GEMMs read: tap order
  * of nn.Conv2d weights, transposes for the input gradients, the newest-first slab order of DilatedDenseNet

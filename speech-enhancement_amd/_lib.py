@@ -110,6 +110,8 @@ def call(name, *args, _key=None, _flops=0.0, _bytes=0.0):
         e0.record()
         rc = fn(*args)
         e1.record()
+        if callable(_key):          # a key that depends on what the C side dispatched to (evaluated after the call)
+            _key = _key()
         TIMER.records.append((_key or name, _flops, _bytes, e0, e1, torch.cuda.current_stream().cuda_stream))
     else:
         rc = fn(*args)

@@ -1925,6 +1925,24 @@ extern "C" int se_attn_bwd_f16_phase(const float* QKV, const float* E, const flo
                        ws, ws_bytes, phase, stream, qkv_amax, do_amax, dqkv_amax);
 }
 
+// launch of the workgroup-cooperative backward (se_attn_bwd4.h): the exact-body kernel when every wave of the plan matches one of its
+// bodies, the generic-body kernel otherwise
+template <int NW, int KPW, int NCW, int NKTM, int MINW, int CA, int NA, int CB, int NB, int CC = -1, int NC_ = 0>
+static int launch_bwd4(const AttnBwd3Args& b, const AttnBwd4Plan& pl, int nkt, long items, size_t shr, hipStream_t s) {
+  if (attn_bwd4_exact<NW, CA, NA, CB, NB, CC, NC_>(pl, nkt, b.dbg)) {
+    static unsigned raised = 0;
+    auto kfn = attn_bwd4_kernel<NW, KPW, NCW, NKTM, MINW, CA, NA, CB, NB, CC, NC_, false>;
+    SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+    hipLaunchKernelGGL(kfn, dim3(items), dim3(NW * 64), shr, s, b, pl);
+  } else {
+    static unsigned raised_g = 0;
+    auto kfn = attn_bwd4_kernel<NW, KPW, NCW, NKTM, MINW, CA, NA, CB, NB, CC, NC_, true>;
+    SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_g), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
+    hipLaunchKernelGGL(kfn, dim3(items), dim3(NW * 64), shr, s, b, pl);
+  }
+  return 0;
+}
+
 static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
                          float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
                          int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
@@ -1995,22 +2013,10 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
       const size_t shr = small ? (small_nw == 4 ? attn_bwd4_lds<4, 7>(nkt) : attn_bwd4_lds<2, 7>(nkt)) : attn_bwd4_lds<4, 21>(nkt);
       if (fits && (bwd4_mode & (small ? 1 : 2))) {
         if (phase & 1) {
-          if (small && small_nw == 4) {
-            static unsigned raised_s = 0;
-            auto kfn = attn_bwd4_kernel<4, 2, 1, 7, 3, 2, 1, 2, 1, 1, 1>;
-            SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_s), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
-            hipLaunchKernelGGL(kfn, dim3(items), dim3(256), shr, s, b, pl);
-          } else if (small) {                  // two waves, 256 VGPRs: four workgroups per CU (168 VGPRs: spills in the key phase, 1.00 ms)
-            static unsigned raised_s2 = 0;
-            auto kfn = attn_bwd4_kernel<2, 4, 2, 7, 2, 3, 2, 4, 2>;
-            SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_s2), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
-            hipLaunchKernelGGL(kfn, dim3(items), dim3(128), shr, s, b, pl);
-          } else {
-            static unsigned raised_b = 0;
-            auto kfn = attn_bwd4_kernel<4, 6, 3, 21, 2, 5, 3, 6, 2>;
-            SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_b), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
-            hipLaunchKernelGGL(kfn, dim3(items), dim3(256), shr, s, b, pl);
-          }
+          if (small && small_nw == 4) e = launch_bwd4<4, 2, 1, 7, 3, 2, 1, 2, 1, 1, 1>(b, pl, nkt, items, shr, s);
+          else if (small) e = launch_bwd4<2, 4, 2, 7, 2, 3, 2, 4, 2>(b, pl, nkt, items, shr, s);     // two waves, 256 VGPRs: four workgroups per CU (168 VGPRs: spills in the key phase, 1.00 ms)
+          else e = launch_bwd4<4, 6, 3, 21, 2, 5, 3, 6, 2>(b, pl, nkt, items, shr, s);
+          if (e) return e;
         }
         if (phase & 2) hipLaunchKernelGGL(attn_de_reduce_items_kernel, dim3(2 * nkt, cdiv(items, 256)), dim3(256), 0, s, b.dEs, dE, items, nkt,
                                           b.maxpos, b.R);

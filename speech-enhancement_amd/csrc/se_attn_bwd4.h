@@ -230,9 +230,15 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   };
   // (diagnostic build switch dbg & 32: shader-clock stamps of the phases of the first 64 workgroups, behind the item tables)
   unsigned* const stamps = reinterpret_cast<unsigned*>(a.dEs + (long)gridDim.x * (2 * nkt) * 256);
+  // The stamp area lies BEYOND what se_attn_bwd_workspace_bytes reserves (only tools/attn_bwd_stamps.py over-allocates for it), so
+  // the stores exist only in a diagnostic build (-DSE_ATTN_STAMPS): SE_ATTN_DBG=32 in a product build writes nothing.
   auto stamp = [&](int qt_, int k) {
+#ifdef SE_ATTN_STAMPS
     if ((a.dbg & 32) && blockIdx.x < 64 && lane == 0)
       stamps[((blockIdx.x * NW + wave) * nqt + qt_) * 8 + k] = (unsigned)__builtin_amdgcn_s_memtime();
+#else
+    (void)qt_; (void)k; (void)stamps;
+#endif
   };
   // is the tile at position j of class slot ci one of this wave's (XT: always)
   auto own = [&](int ci, int j) { return XT || (ci < ncls && j <= nkt); };
@@ -522,18 +528,40 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
 // second pair (CC, NC_) for earlier waves (CC < 0: none); every other split takes the tested body.  n = 321: four waves, key tiles
 // 5 + 5 + 5 + 6, classes 3 + 3 + 3 + 2 -> A = (5, 3), B = (6, 2).  n = 101: two waves, 3 + 4 key tiles, 2 + 2 classes -> A = (3, 2),
 // B = (4, 2) (four waves with 1 + 2 + 2 + 2 key tiles: 0.79 vs 0.77 ms).
-// Every body runs the same barriers (2 + 2 per query tile).
-template <int NW, int KPW, int NCW, int NKTM, int MINW, int CA, int NA, int CB, int NB, int CC = -1, int NC_ = 0>
+// BARRIER CONTRACT: the waves of one workgroup return into DIFFERENT attn_bwd4_body instantiations (XT / TL variants), each with its
+// own __syncthreads() sites; s_barrier counts arrivals regardless of the program counter, so this is correct exactly as long as
+// every variant executes the same number of barriers: 2 before the query-tile loop + 2 per query tile, none behind a dbg switch.
+// tests/test_attn_gpu.py::test_bwd4_generic_body_beside_exact_bodies runs the generic body (SE_ATTN_DBG=64) against the exact
+// bodies on the same shapes: a barrier mismatch shows up there as a hang (the test runs under a timeout), not in training.
+// GEN = false: the exact bodies ONLY -- the host launches this form exactly when every wave of the plan matches one (attn_bwd4_exact:
+// the same predicate).  GEN = true: the generic body for every wave (every other split; SE_ATTN_DBG=64 forces it).  Two kernels
+// instead of one with both: the generic body's register demand (KPW key tiles AND NCW classes in one wave) gave the merged kernel
+// 76 bytes of scratch per lane although the default path never ran the spilling code (round-4 review) -- a kernel with scratch
+// pays for the allocation at every wave launch.
+template <int NW, int CA, int NA, int CB, int NB, int CC, int NC_>
+static inline bool attn_bwd4_exact(const AttnBwd4Plan& pl, int nkt, int dbg) {
+  if (2 * pl.M != nkt + 1 || (dbg & 64)) return false;
+  for (int w = 0; w < NW; ++w) {
+    const int cnt = pl.cnt[w], ncls = pl.ncls[w];
+    const bool ok = w == NW - 1 ? (cnt == CB && ncls == NB) : ((cnt == CA && ncls == NA) || (CC >= 0 && cnt == CC && ncls == NC_));
+    if (!ok) return false;
+  }
+  return true;
+}
+template <int NW, int KPW, int NCW, int NKTM, int MINW, int CA, int NA, int CB, int NB, int CC = -1, int NC_ = 0, bool GEN = false>
 __global__ __launch_bounds__(NW * 64, MINW) void attn_bwd4_kernel(AttnBwd3Args a, AttnBwd4Plan pl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nkt = (a.g.n + 15) >> 4;
-  const int cnt = pl.cnt[wave], ncls = pl.ncls[wave];
-  const bool full = 2 * pl.M == nkt + 1 && !(a.dbg & 64), last = wave == NW - 1;
-  if (full && last && cnt == CB && ncls == NB) return attn_bwd4_body<NW, KPW, NCW, NKTM, CB, NB, true, true>(a, pl, smem4, wave, lane);
-  if (full && !last && cnt == CA && ncls == NA) return attn_bwd4_body<NW, KPW, NCW, NKTM, CA, NA, true, false>(a, pl, smem4, wave, lane);
-  if constexpr (CC >= 0) {
-    if (full && !last && cnt == CC && ncls == NC_) return attn_bwd4_body<NW, KPW, NCW, NKTM, (CC >= 0 ? CC : 1), NC_, true, false>(a, pl, smem4, wave, lane);
+  if constexpr (GEN) {
+    attn_bwd4_body<NW, KPW, NCW, NKTM, KPW, NCW, false, true>(a, pl, smem4, wave, lane);
+  } else {
+    const int cnt = pl.cnt[wave], ncls = pl.ncls[wave];
+    const bool last = wave == NW - 1;
+    if (last) return attn_bwd4_body<NW, KPW, NCW, NKTM, CB, NB, true, true>(a, pl, smem4, wave, lane);
+    if constexpr (CC >= 0) {
+      if (cnt == CC && ncls == NC_) return attn_bwd4_body<NW, KPW, NCW, NKTM, (CC >= 0 ? CC : 1), NC_, true, false>(a, pl, smem4, wave, lane);
+    }
+    (void)cnt; (void)ncls;
+    attn_bwd4_body<NW, KPW, NCW, NKTM, CA, NA, true, false>(a, pl, smem4, wave, lane);      // (host-checked: attn_bwd4_exact)
   }
-  attn_bwd4_body<NW, KPW, NCW, NKTM, KPW, NCW, false, true>(a, pl, smem4, wave, lane);
 }

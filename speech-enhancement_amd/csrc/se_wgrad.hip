@@ -1305,6 +1305,13 @@ static int launch_wgrad_lin_bf16(const se_gemm_desc* d, const WgradArgs& g, dim3
   return se_check_launch("se_gemm_tap_wgrad(lin bf16x6)");
 }
 
+// which arithmetic / kernel class the last se_gemm_tap_wgrad of this thread ran (the dispatch below depends on shape, precision, scales and
+// environment switches; bench.py keys its weight-gradient families by THIS, so that no family is priced against the wrong peak):
+// bits 0..3: 0 fp32 MFMA, 1 bf16x3, 2 bf16x6, 3 scaled f16x3; bits 4..7: 0 generic tile kernel, 1 triple-tap (conv3) kernel, 2 whole-gradient
+// (token-wise) kernel
+static thread_local int g_wgrad_kind = 0;
+extern "C" int se_gemm_tap_wgrad_last_kind(void) { return g_wgrad_kind; }
+
 extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const float* dY, float* dW,
                                  float* dbias, const float* rowstats, const float* pro_scale,
                                  const float* pro_shift, int chunks, void* stream) {
@@ -1347,6 +1354,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       else if (d->precision == 1) hipLaunchKernelGGL(wgrad3_bf16_kernel<2>, g3, block, 0, s, g);
       else if (d->precision == 2) hipLaunchKernelGGL(wgrad3_bf16_kernel<3>, g3, block, 0, s, g);
       else hipLaunchKernelGGL(wgrad3_kernel, g3, block, 0, s, g);
+      g_wgrad_kind = 16 | (d->precision & 3);
       return se_check_launch("se_gemm_tap_wgrad(conv3)");
     }
   }
@@ -1380,6 +1388,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       rl = ((rl + 31) / 32) * 32;
       const int nch = (int)((Mtot + rl - 1) / rl);
       WgradArgs gl{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rl, nch};
+      g_wgrad_kind = 32 | ((want_f16 && f16_pro) ? 3 : 2);
       if (want_f16 && f16_pro)
         return shape == 1 ? launch_wgrad_lin_f16<1>(d, gl, dim3((unsigned)nch), s) : launch_wgrad_lin_f16<2>(d, gl, dim3((unsigned)nch), s);
       return shape == 1 ? launch_wgrad_lin_bf16<1>(d, gl, dim3((unsigned)nch), s) : launch_wgrad_lin_bf16<2>(d, gl, dim3((unsigned)nch), s);
@@ -1394,6 +1403,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       const int nch = (int)((Mtot + rl - 1) / rl);
       WgradArgs gl{*d, A, dY, dW, dbias, rowstats, pro_scale, pro_shift, rl, nch};
       const dim3 gg((unsigned)nch);
+      g_wgrad_kind = 32;
       if (shape == 1) return launch_wgrad_lin<4, 2, 2>(d, gl, gg, s);
       if (shape == 2) return launch_wgrad_lin<1, 2, 2>(d, gl, gg, s);
       return launch_wgrad_lin<1, 2, 1>(d, gl, gg, s);
@@ -1414,6 +1424,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
       default: return se_fail("wgrad: unknown prologue %d", d->prologue);
     }
 #undef LAUNCHWB
+    g_wgrad_kind = d->precision;
     return se_check_launch("se_gemm_tap_wgrad(bf16)");
   }
   switch (d->prologue) {
@@ -1425,6 +1436,7 @@ extern "C" int se_gemm_tap_wgrad(const se_gemm_desc* d, const float* A, const fl
     case SE_PRO_DROP: hipLaunchKernelGGL((wgrad_kernel<SE_PRO_DROP>), grid, block, 0, s, g); break;
     default: return se_fail("wgrad: unknown prologue %d", d->prologue);
   }
+  g_wgrad_kind = 0;
   return se_check_launch("se_gemm_tap_wgrad");
 }
 

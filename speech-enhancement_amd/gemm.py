@@ -225,10 +225,22 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
 _KEY_SHAPES = __import__('os').environ.get('SE_KEY_SHAPES') == '1'      # diagnostic: one timer family per GEMM shape
 
 
+_WGRAD_ARITH = {0: 'f32', 1: 'bf16x3', 2: 'bf16x6', 3: 'f16x3'}
+_WGRAD_CLASS = {0: 'wgrad', 1: 'wgrad3', 2: 'wgrad_lin'}
+
+
+def _wgrad_key(prologue):
+    """timer family of the weight-gradient launch that has just been issued: named by what se_gemm_tap_wgrad DISPATCHED to
+    (se_gemm_tap_wgrad_last_kind) -- the dispatch depends on shape, scales and switches, and a family keyed by the request was
+    priced against the wrong peak in round 4 (a 16-bit-pipe kernel against the fp32-MFMA peak: a fraction above 1)"""
+    k = L.lib().se_gemm_tap_wgrad_last_kind()
+    return f'{_WGRAD_CLASS.get(k >> 4, "wgrad")}_{_WGRAD_ARITH[k & 15]}<{prologue}>'
+
+
 def _wgrad_call(d, A, dY, dW, dbias, rowstats, ps, pb, chunks, Mt):
     L.call('se_gemm_tap_wgrad', C.byref(d), L.ptr(A), L.ptr(dY), L.ptr(dW), L.ptr(dbias), L.ptr(rowstats),
            L.ptr(ps), L.ptr(pb), C.c_int(chunks), L.stream(),
-           _key=f'wgrad_kernel<{d.prologue}>' + (f' C{d.C} N{d.N} t{d.ntap} M{Mt} p{d.precision} sf{d.sf}' if _KEY_SHAPES else ''),
+           _key=lambda: _wgrad_key(d.prologue) + (f' C{d.C} N{d.N} t{d.ntap} M{Mt} p{d.precision} sf{d.sf}' if _KEY_SHAPES else ''),
            _flops=2.0 * Mt * d.N * d.ntap * d.C, _bytes=4.0 * Mt * (d.C + d.N))
     return dW
 

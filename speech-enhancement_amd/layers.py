@@ -447,11 +447,13 @@ def _lin3(W, **kw):
     return {}
 
 
-def _bnd(P, key, sexp):
+def _bnd(P, key, sexp, need_k1=None):
     """operand-scale keywords of a bounded activation: the proven bound of this forward (weights.WeightPlan.run_bounds: a device
-    scalar computed from the current parameters) when there is one, the static exponent otherwise (direct calls without a plan)"""
+    scalar computed from the current parameters) when there is one, the static exponent otherwise (direct calls without a plan).
+    need_k1: the sqrt(tokens - 1) a train-mode BatchNorm bound must have been derived with -- a plan whose last run_bounds used a
+    smaller token count (another entry point, another batch) does not bound this call's data: static exponent then."""
     plan = P.get('__prep__')
-    if plan is not None and plan.bounds_ready and key in plan.bounds:
+    if plan is not None and plan.bounds_ready and key in plan.bounds and (need_k1 is None or plan.k1 >= need_k1 * (1.0 - 1e-6)):
         return dict(a_amax=plan.bounds[key])
     return dict(a_sexp=sexp)
 
@@ -627,7 +629,7 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
     y3 = torch.empty(M, 64, device=x.device, dtype=torch.float32)
     # Swish(BatchNorm(h)) is bounded like the FF hidden activations (the weight gradient of this layer uses the same exponent)
     # (eval mode: running statistics bound nothing -- |BN(h)| depends on the data -- so the projection then runs on the fp32 kernel)
-    bn_b = _bnd(P, ('bn', f'{p}.conv'), GM.HID_SEXP) if train else {}
+    bn_b = _bnd(P, ('bn', f'{p}.conv'), GM.HID_SEXP, need_k1=max(count - 1.0, 1.0) ** 0.5) if train else {}
     Wpw2 = _w(P, (f'{p}.conv.net.7.weight', 'lin'), lambda: None) if (train or 'a_amax' in bn_b) else None
     if Wpw2 is None:
         Wpw2 = P[f'{p}.conv.net.7.weight'].view(64, 128)
@@ -647,6 +649,8 @@ def conformer_fwd(P, p, x, B, T, Fq, axis, train=True, dp=NO_DP, buffers=None, d
 
 
 def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
+    if not train:
+        raise L.SeHipError('conformer_bwd in eval mode is not supported (BatchNorm uses running statistics)')
     M = dout.shape[0]
     geom = ctx['geom']
     dev = dout.device
@@ -662,7 +666,8 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     Wpw2T = _w(P, (f'{p}.conv.net.7.weight', 'T'), lambda: _T(Wpw2))
     GM.gemm_tap(GM.linear_desc(M, 64, 128, **_lin3(Wpw2T, a_amax=getattr(dy3, '_se_amax', None))), dy3, Wpw2T, dact)
     with GM.leaf_stream(h, dy3, sc, sh, getattr(dy3, '_se_amax', None)):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH, **_bnd(P, ('bn', f'{p}.conv'), GM.HID_SEXP),
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 128, 64, prologue=L.PRO_AFFINE_SWISH,
+                                         **_bnd(P, ('bn', f'{p}.conv'), GM.HID_SEXP, need_k1=max(count - 1.0, 1.0) ** 0.5),
                                          w_amax=getattr(dy3, '_se_amax', None)), h, dy3,
                           G[f'{p}.conv.net.7.weight'].view(64, 128), G[f'{p}.conv.net.7.bias'], ps=sc, pb=sh)
     dh = torch.empty(M, 128, device=dev, dtype=torch.float32)
@@ -710,7 +715,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     do_amax = O.zeros(1, device=dev) if qkv_amax is not None else None      # max |dO| for the scaled split-fp16 attention backward
     GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa, y_amax=do_amax,
                                **_lin3(WoT, a_amax=getattr(dy2, '_se_amax', None))), dy2, WoT, do)
-    with GM.leaf_stream(o, dy2, getattr(dy2, '_se_amax', None)):
+    with GM.leaf_stream(o, dy2, getattr(dy2, '_se_amax', None), qkv_amax):       # every scalar the side-stream kernel reads stays referenced until the join
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa,
                                          w_amax=getattr(dy2, '_se_amax', None),
                                          **(dict(a_amax=qkv_amax) if qkv_amax is not None else dict(a_sexp=ATTN_O_SEXP))), o, dy2,

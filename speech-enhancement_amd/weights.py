@@ -35,6 +35,7 @@ class WeightPlan:
         self._btable = None
         self._bscal = None
         self.bounds_ready = False
+        self.k1 = self.k2 = 0.0     # the run-time constants the last run_bounds derived the ksel 1 / 2 bounds with
         self.out = {}          # key -> prepared tensor: fp32 [rows, ld], bf16 planes [3, rows, ld] or scaled fp16 planes [2, rows, ld]
         self._items = []
         self._srcs = []        # keeps the source tensors alive / lets `stale()` detect re-allocated parameters
@@ -120,6 +121,7 @@ class WeightPlan:
             self._btable = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
         L.call('se_act_bounds', L.ptr(self._btable), C.c_int(len(self._bitems)), C.c_float(k1), C.c_float(k2), L.stream())
         self.bounds_ready = True
+        self.k1, self.k2 = float(k1), float(k2)
 
     def stale(self):
         """True when a source parameter has been re-allocated since the plan was built (.to(), .data = ...)."""

@@ -132,3 +132,38 @@ def test_attention_scaled_fp16_forward_only_long_sequences(B, T, Fq, axis, qspli
     if not A.f16_shape_ok(geom, maxpos):
         with pytest.raises(Exception):              # with a backward to come (need_lse) the training shapes only
             A.attn_fwd(qkv.view(-1, 192), E, geom, maxpos=maxpos, Es=Es, qkv_amax=amax)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('B,T,Fq,axis', [(1, 321, 3, 'time'), (3, 5, 101, 'freq')])
+def test_bwd4_generic_body_beside_exact_bodies(B, T, Fq, axis, monkeypatch):
+    """the waves of one attn_bwd4 workgroup run different body instantiations that must execute the same number of barriers
+    (se_attn_bwd4.h, BARRIER CONTRACT): the bench shapes take the exact bodies by default and the generic body with
+    SE_ATTN_DBG=64 -- both must finish (a mismatch hangs: this test runs under a timeout) and agree to rounding"""
+    from speech_enhancement_amd import attention as A
+    from speech_enhancement_amd.weights import WeightPlan
+    maxpos = 512
+    g = torch.Generator().manual_seed(7 + T)
+    qkv = (torch.randn(B, T, Fq, 192, generator=g) * 1.5).cuda()
+    E = (torch.randn(2 * maxpos + 1, 16, generator=g) * 0.7).cuda()
+    dO = (torch.randn(B, T, Fq, 64, generator=g) * 1e-3).cuda()
+    geom = A.seq_geometry(B, T, Fq, axis)
+    plan = WeightPlan(torch.device('cuda'))
+    Es = plan.linear('e', E, planes='f16')
+    plan.run()
+    amax = qkv.abs().max().reshape(1).clone()
+    do_amax = dO.abs().max().reshape(1).clone()
+    O, lse = A.attn_fwd(qkv.view(-1, 192), E, geom, maxpos=maxpos, Es=Es, qkv_amax=amax)
+    res = []
+    for dbg in (None, '64'):
+        if dbg is None:
+            monkeypatch.delenv('SE_ATTN_DBG', raising=False)
+        else:
+            monkeypatch.setenv('SE_ATTN_DBG', dbg)
+        dE = torch.zeros_like(E)
+        dqkv = A.attn_bwd(qkv.view(-1, 192), E, O, dO.view(-1, 64), lse, geom, dE, maxpos=maxpos, qkv_amax=amax, do_amax=do_amax)
+        torch.cuda.synchronize()
+        res.append((dqkv.clone(), dE.clone()))
+    (d0, e0), (d1, e1) = res
+    assert float((d0 - d1).abs().max()) <= 2e-6 * float(d0.abs().max())
+    assert float((e0 - e1).abs().max()) <= 2e-6 * float(e0.abs().max())

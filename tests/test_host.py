@@ -271,3 +271,41 @@ def test_zero_outputs_of_the_discriminator_backward_share_one_buffer():
         o.fill_(i + 1.0)
     assert all(float(o.min()) == float(o.max()) == i + 1.0 for i, (o, _) in enumerate(live))
     assert DM._zeros_like_many([None, None]) == [None, None]
+
+
+# kernels that MAY carry scratch: fallback forms off the default path (six-product bf16 arithmetic, shapes outside the exact attention
+# bodies, the opt-in fp32 whole-gradient shape).  Everything else -- every kernel a default train / inference step launches -- must
+# compile without a single byte of it (round-4 review: the merged attn_bwd4 kernel carried 76 B / lane of the generic body's spills).
+_SCRATCH_ALLOWED = [
+    r'^void attn_bwd4_kernel<.*, true>\(',                       # generic-body form (GEN = true): splits outside the exact bodies
+    r'^void attn_bwd3_kernel<\d+, (true|false), false, false>\(',   # three-way bf16 attention backward (SE_ATTN_PRECISION=bf16x6 / no scales)
+    r'^void ff_(fwd|bwd)_kernel<\d+, (true|false), \d+, false(, true)?>\(',   # bf16 feed-forward forms (CDiffuSE-era precision 1 / 2)
+    r'^void wgrad_lin_kernel<1, 1, 2, 2>\(',                     # fp32 whole-gradient shape 3 (SE_WGRAD_LIN_ALL only)
+]
+
+
+def test_no_scratch_in_default_path_kernels(S):
+    """reads the compiler's kernel-resource-usage remarks of the product build (speech-enhancement_amd/build/*.ru.txt, written by
+    build.py from the same compile that produced the objects): no default-path kernel may use scratch memory"""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location('se_build_ru', os.path.join(ROOT, 'speech-enhancement_amd', 'build.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    ru = b.resource_usage()
+    assert len(ru) >= 250, 'resource-usage records missing: rebuild with speech-enhancement_amd/build.py'
+    assert {t for t, _, _ in ru} >= {'se_attn.hip', 'se_ff.hip', 'se_gemm.hip', 'se_wgrad.hip', 'se_dwconv.hip', 'se_norms.hip'}
+    bad = [(t, n, d) for t, n, d in ru if d.get('ScratchSize', 0) > 0]
+    names = subprocess.run(['c++filt'], input='\n'.join(n for _, n, _ in bad), capture_output=True, text=True).stdout.strip().split('\n')
+    offenders = [(t, nm, d['ScratchSize']) for (t, _, d), nm in zip(bad, names) if not any(re.search(p, nm) for p in _SCRATCH_ALLOWED)]
+    assert not offenders, offenders
+    # the hot kernels by name: present, scratch-free, and at the occupancy their launch bounds were written for
+    dem = subprocess.run(['c++filt'], input='\n'.join(n for _, n, _ in ru), capture_output=True, text=True).stdout.strip().split('\n')
+    by = {nm: d for (_, _, d), nm in zip(ru, dem)}
+    for pat, occ in ((r'^void attn_bwd4_kernel<4, 6, 3, 21, 2, 5, 3, 6, 2, -1, 0, false>\(', 2),
+                     (r'^void attn_bwd4_kernel<2, 4, 2, 7, 2, 3, 2, 4, 2, -1, 0, false>\(', 2),
+                     (r'^void attn_fwd3_kernel<2, true>\(', 4), (r'^void ff_fwd_kernel<2, true, 4, true, true>\(', 2),
+                     (r'^void ff_bwd_kernel<2, true, 4, true>\(', 2)):
+        hit = [d for nm, d in by.items() if re.search(pat, nm)]
+        assert hit, pat
+        assert hit[0]['ScratchSize'] == 0 and hit[0]['Occupancy'] >= occ, (pat, hit[0])

@@ -705,10 +705,14 @@ def test_flat_clip_and_state_dict_interop(S):
             assert rms(p1, p2) < 2e-6 * max(1.0, float(p2.abs().max())), (kind, n)
 
 
-def test_world1_hooks_equal_plain_step(S):
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_world1_hooks_equal_plain_step(S, backend):
     """the data-parallel code paths on ONE rank (process group of size 1): deferred generator step behind the
     discriminator step, SyncBatchNorm exchange with count = M * world, averaged scp gradients -- with world == 1 every
-    collective is the identity, so the result must equal the hook-free step (to the fp32-atomics noise of the weight gradients)"""
+    collective is the identity, so the result must equal the hook-free step (to the fp32-atomics noise of the weight gradients).
+    backend 'nccl' (= RCCL): the DEVICE-buffer branch of the hooks -- in-place all-reduce of the flat gradient buffer with
+    async_op=True, statistics reduced on the device (train.DataParallelHooks, stage_host False) -- the branch an N > 1 run on
+    real hardware takes; 'gloo': the host-staged test transport."""
     import os
     import socket
     import types
@@ -718,7 +722,10 @@ def test_world1_hooks_equal_plain_step(S):
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=0, world_size=1)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', torch.cuda.current_device()))
+    else:
+        dist.init_process_group('gloo', rank=0, world_size=1)
     try:
         torch.manual_seed(3)
         clean = 0.1 * torch.randn(2, 1600, device='cuda')
@@ -733,7 +740,7 @@ def test_world1_hooks_equal_plain_step(S):
             hooks = None
             if use_hooks:
                 hooks = TR.attach_data_parallel(g, d)
-                assert hooks.world == 1 and hooks.stage_host
+                assert hooks.world == 1 and hooks.stage_host == (backend == 'gloo')
                 hooks.force_sync = True              # take the two-phase SyncBatchNorm backward although world == 1
                 calls = []
                 orig = hooks.allreduce

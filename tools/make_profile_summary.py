@@ -59,10 +59,23 @@ def fam(name):
         if len(args) >= 4 and args[3] == 'true':
             return f'ff_{kind}_f16x3'
         return f'ff_{kind}_bf16x{3 if args[0] == "2" else 6}'
-    if base == 'wgrad_lin_bf16_kernel' or base == 'wgrad_lin_kernel' or base == 'wgrad_kernel':
-        return f'wgrad_kernel<{args[0]}>'
-    if base in ('wgrad3_kernel', 'wgrad3_bf16_kernel', 'wgrad3w_f16_kernel'):
-        return 'wgrad_kernel<0>'
+    # weight gradients: keyed like gemm._wgrad_key (class + the arithmetic the C side dispatched to)
+    if base == 'wgrad_kernel':
+        return f'wgrad_f32<{args[0]}>'
+    if base == 'wgrad_bf16_kernel':                   # <PRO, NPL>
+        return f'wgrad_bf16x{3 if args[1] == "2" else 6}<{args[0]}>'
+    if base == 'wgrad_lin_kernel':
+        return f'wgrad_lin_f32<{args[0]}>'
+    if base == 'wgrad_lin_bf16_kernel':               # <PRO, SH [, F16]>
+        return f'wgrad_lin_f16x3<{args[0]}>' if args[-1] == 'true' else f'wgrad_lin_bf16x6<{args[0]}>'
+    if base == 'wgrad3_kernel':
+        return 'wgrad3_f32<0>'
+    if base == 'wgrad3w_f16_kernel':
+        return 'wgrad3_f16x3<0>'
+    if base == 'wgrad3_bf16_kernel':                  # <NPL [, F16 [, ORD]]>
+        if len(args) > 1 and args[1] == 'true':
+            return 'wgrad3_f16x3<0>'
+        return f'wgrad3_bf16x{3 if args[0] == "2" else 6}<0>'
     if base == 'gemm_tap_kernel':
         return f'gemm_tap_kernel<{args[0]},{args[1]}>'
     if base == 'attn_bwd4_kernel':                    # <NW, KPW, NCW, NKTM, MINW>: round 4, scaled fp16 only
