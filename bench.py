@@ -110,9 +110,9 @@ def cpu_baseline(budget_s=55.0):
     spec = Or.compressed_stft(nn_)
     sweep = {}
     t_start = time.time()
-    best = None
+    best = last = None
     for th in sorted({min(ncpu, v) for v in (16, 64, 128, 256)}):
-        if best is not None and sweep[max(sweep)] > 1.5 * best:
+        if best is not None and last > 1.5 * best:
             sweep[th] = None                                 # skipped: the trend is already 1.5x off the best
             continue
         torch.set_num_threads(th)
@@ -120,8 +120,8 @@ def cpu_baseline(budget_s=55.0):
             Or.tscnet_forward(gsd, spec, False)              # warm (allocator, thread pool)
             t0 = time.time()
             Or.tscnet_forward(gsd, spec, False)
-        sweep[th] = round(time.time() - t0, 3)
-        best = sweep[th] if best is None else min(best, sweep[th])
+        sweep[th] = last = round(time.time() - t0, 3)
+        best = last if best is None else min(best, last)
     threads = min((k for k, v in sweep.items() if v is not None), key=lambda k: sweep[k])
     warm = []
     while len(warm) < 3 and (not warm or (time.time() - t_start) + 6 * warm[-1] < budget_s):

@@ -78,8 +78,8 @@ def build(force=False, verbose=True):
             sys.stderr.write(err)
             raise RuntimeError(f'hipcc failed on {src}')
         remarks = [l for l in err.split('\n') if 'remark:' in l]
-        other = [l for l in err.split('\n') if l.strip() and 'remark:' not in l]
-        if other and verbose:          # warnings
+        other = [l for l in err.split('\n') if 'warning:' in l or 'error:' in l]
+        if other and verbose:
             sys.stderr.write('\n'.join(other) + '\n')
         with open(ru_of(src), 'w') as f:
             f.write('\n'.join(remarks) + '\n')

@@ -373,6 +373,31 @@ def ff_wgrad_rc(x, st, gamma, beta, dy, W1, b1, W2T_scaled, dW1, db1, dW2, db2, 
            _flops=8.0 * M * 64 * hid, _bytes=4.0 * M * 128)
 
 
+# The fused backward (csrc/se_ff_fused.hip; default with scaled fp16 planes): ONE persistent launch for dX, dgamma / dbeta AND the four
+# weight gradients of the module -- H, S and dZ exist on chip only.  SE_FF_FUSED=0: the stored-H kernels (ff_bwd_dgrad + two
+# whole-gradient launches) again; SE_FF_RECOMPUTE=1 with SE_FF_FUSED=0: the two recomputing kernels of round 3.
+FF_FUSED = __import__('os').environ.get('SE_FF_FUSED', '1') != '0'
+
+
+def ff_bwd_fused(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2, dgamma, dbeta, drop_p=0.0, seed_h=0, seed_o=0,
+                 alpha=0.5, dR2=None, out_amax=None, in_bound=None, mid_bound=None):
+    """dx = dy + dR2 + LNbwd(dZ W1) and dW1 / db1 / dW2 / db2 / dgamma / dbeta accumulated, from x and dy alone (se_ff_bwd_fused)."""
+    L.check_cuda(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2, dgamma, dbeta, dR2)
+    dy_amax = getattr(dy, '_se_amax', None)
+    if dy_amax is None or W1.dtype != torch.float16 or W2T_scaled.dtype != torch.float16:
+        raise L.SeHipError('ff_bwd_fused: needs scaled fp16 weight planes and the measured maximum of dy (dy._se_amax)')
+    M, hid = x.shape[0], W1.shape[-2]
+    dx = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
+    dx._se_amax = out_amax
+    L.call('se_ff_bwd_fused', L.ptr(dy), L.ptr(x), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2T_scaled),
+           L.ptr(dR2), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), C.c_long(M), C.c_int(hid),
+           C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), L.ptr(dy_amax),
+           L.ptr(W1._se_amax), L.ptr(W2T_scaled._se_amax), L.ptr(in_bound), C.c_int(LN_SEXP), L.ptr(mid_bound), C.c_int(HID_SEXP),
+           L.ptr(out_amax), L.stream(), _key='ff_bwd_fused_f16x3', _flops=10.0 * M * 64 * hid,
+           _bytes=4.0 * M * 64 * (4 if dR2 is not None else 3))
+    return dx
+
+
 def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precision=None, ln=None, amax_out=(None, None)):
     """fused dgrad chain of the feed-forward module (ff_bwd_kernel): returns (dZ [M, hid], dLN [M, 64]); with
     ln = (x, rowstats, gamma, dR2 or None, dgamma, dbeta) the LayerNorm backward is applied in the same kernel and the

@@ -476,12 +476,15 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0, st=None, want_out_stats=Fa
         W1p = _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1)
         # scaled fp16 planes: H is neither stored nor read again (recomputing backward, gemm.ff_bwd_rc / ff_wgrad_rc; inference
         # never needed it)
-        rc = GM.FF_RECOMPUTE and W1p.dtype == torch.float16
+        rc = (GM.FF_RECOMPUTE or GM.FF_FUSED) and W1p.dtype == torch.float16
         res = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
                          W1p, P[f'{p}.fn.fn.net.0.bias'],
                          _w(P, (f'{p}.fn.fn.net.3.weight', 'lin'), lambda: W2), P[f'{p}.fn.fn.net.3.bias'], drop, seed_h,
                          seed_o, 0.5, hid=W1.shape[0], out_stats=want_out_stats, store_h=not rc,
-                         in_bound=_bnd(P, ('ln', p), 0).get('a_amax'), mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'))
+                         # (the round-3 recomputing kernels -- SE_FF_FUSED=0 SE_FF_RECOMPUTE=1 -- know the static exponents only: the
+                         # forward then scales with the same ones, so that the recomputed H is the forward's)
+                         in_bound=_bnd(P, ('ln', p), 0).get('a_amax') if (GM.FF_FUSED or not rc) else None,
+                         mid_bound=_bnd(P, ('hid', p), 0).get('a_amax') if (GM.FF_FUSED or not rc) else None)
         if want_out_stats:
             y, z, ost = res
             return y, (x, st, z, drop, seed_h, seed_o), ost
@@ -512,6 +515,14 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
         # weight gradients (one kernel for dW1, db1, dW2, db2 on the leaf stream, reading x and dy only)
         W1p, W2Tp = _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: None), _w(P, (f'{p}.fn.fn.net.3.weight', 'T0.5'), lambda: None)
         b1 = P[f'{p}.fn.fn.net.0.bias']
+        if GM.FF_FUSED:
+            # ONE launch: input gradient, LayerNorm backward and all four weight gradients (the weight gradients are no longer leaves
+            # on the side stream: they accumulate inside the sweep that produces dx)
+            return GM.ff_bwd_fused(dy, x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1p, b1, W2Tp,
+                                   G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], G[f'{p}.fn.fn.net.3.weight'],
+                                   G[f'{p}.fn.fn.net.3.bias'], G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], drop, seed_h, seed_o,
+                                   0.5, dR2=dR2, out_amax=_amax(dy.device), in_bound=_bnd(P, ('ln', p), 0).get('a_amax'),
+                                   mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'))
         dx = GM.ff_bwd_rc(dy, x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1p, b1, W2Tp,
                           _w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: None), drop, seed_h, seed_o, dR2,
                           G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], out_amax=_amax(dy.device))

@@ -755,3 +755,61 @@ def test_discriminator_input_gradient_by_parity_class(G, B, Ti, Fi, Cin, N):
     ref = F.conv2d(xi, w.double(), None, 2, 1)                 # [B, N, Fo, To]
     ref.backward(dR.permute(0, 3, 2, 1).double())
     assert relerr(dx, xi.grad.permute(0, 3, 2, 1)) < 3e-6
+
+
+@pytest.mark.parametrize('M', [37, 4096 + 37, 70000])
+def test_feed_forward_fused_backward(M):
+    """se_ff_bwd_fused (csrc/se_ff_fused.hip): ONE persistent launch for dX, dgamma / dbeta and dW1 / db1 / dW2 / db2 of the module, H,
+    S and dZ recomputed on chip -- against the stored-H kernels (ff_bwd_dgrad + the fp32-MFMA whole-gradient kernels on the stored
+    H / dZ) and, without dropout, against fp64; with and without dropout (the same counter-based masks), with and without the
+    second residual, accumulating into non-zero gradient buffers; row counts: less than one tile, a ragged last workgroup, many
+    workgroups."""
+    from speech_enhancement_amd import gemm as GM, _lib as L, ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    dev = torch.device('cuda')
+    torch.manual_seed(M)
+    x = torch.randn(M, 64, device=dev)
+    st = O.row_stats(x, M)
+    g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    W1, b1 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
+    W2, b2 = torch.randn(64, 256, device=dev) * 0.1, torch.randn(64, device=dev) * 0.1
+    p = WeightPlan(dev)
+    p.linear('w1', W1, planes='f16'); p.linear('w2', W2, planes='f16')
+    p.linear_T('w2t', W2, planes='f16', scale=0.5); p.linear_T('w1t', W1, planes='f16')
+    p.run()
+    rel = lambda a, r: float((a.double() - r.double()).abs().max() / r.double().abs().max())
+    for drop, with_r2 in ((0.0, False), (0.2, True)):
+        dy = torch.randn(M, 64, device=dev) * 1e-3
+        dy._se_amax = dy.abs().max().reshape(1).clone()
+        dR2 = torch.randn(M, 64, device=dev) * 1e-3 if with_r2 else None
+        y, h = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, drop, 11, 12, 0.5, hid=256)
+        dg0, db0 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        dz, dx0 = GM.ff_bwd_dgrad(dy, h, p.out['w2t'], p.out['w1t'], drop, 11, 12, ln=(x, st, g, dR2, dg0, db0),
+                                  amax_out=(torch.zeros(1, device=dev), torch.zeros(1, device=dev)))
+        dr = drop > 0
+        dW1a, db1a, dW2a, db2a = (torch.zeros(s, device=dev) for s in ((256, 64), (256,), (64, 256), (64,)))
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH, epilogue=L.EPI_DROP if dr else 0,
+                                         pro_seed=11, epi_seed=12, drop_p=drop, precision=0), h, dy, dW2a, db2a, scale=0.5,
+                          explicit_precision=True)
+        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, precision=0), x, dz, dW1a, db1a, rowstats=st, ps=g, pb=b,
+                          explicit_precision=True)
+        # the fused launch accumulates into buffers that already hold something
+        init = [torch.randn(s, device=dev) * 1e-2 for s in ((256, 64), (256,), (64, 256), (64,), (64,), (64,))]
+        dW1b, db1b, dW2b, db2b, dg1, db1_ = [t.clone() for t in init]
+        dx1 = GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], dW1b, db1b, dW2b, db2b, dg1, db1_, drop, 11, 12, 0.5,
+                              dR2=dR2, out_amax=torch.zeros(1, device=dev))
+        torch.cuda.synchronize()
+        assert torch.isfinite(dx1).all()
+        assert rel(dx1, dx0) < 2e-6, ('dX', rel(dx1, dx0))
+        assert abs(float(dx1._se_amax) - float(dx1.abs().max())) <= 1e-6 * float(dx1.abs().max())
+        for name, got, ini, ref in (('dW1', dW1b, init[0], dW1a), ('db1', db1b, init[1], db1a), ('dW2', dW2b, init[2], dW2a),
+                                    ('db2', db2b, init[3], db2a), ('dgamma', dg1, init[4], dg0), ('dbeta', db1_, init[5], db0)):
+            e = rel(got - ini, ref)
+            assert e < (4e-6 if name in ('dgamma', 'dbeta') else 3e-6) + 2e-7 * float(ini.abs().max() / ref.abs().max()), (name, e, drop, M)
+        if not dr:
+            xl = ((x.double() - st[:, :1].double()) * st[:, 1:].double()) * g.double() + b.double()
+            h64 = xl @ W1.double().t() + b1.double()
+            sg = torch.sigmoid(h64)
+            dz64 = (dy.double() @ (0.5 * W2.double())) * (sg * (1 + h64 * (1 - sg)))
+            assert rel(dW1b - init[0], dz64.t() @ xl) < 2e-6 and rel(dW2b - init[2], 0.5 * dy.double().t() @ (h64 * sg)) < 2e-6
+            assert rel(db1b - init[1], dz64.sum(0)) < 2e-6 and rel(db2b - init[3], 0.5 * dy.double().sum(0)) < 2e-6
