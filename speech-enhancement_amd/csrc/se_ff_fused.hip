@@ -6,22 +6,30 @@
 //   Replaces se_ff_bwd_dgrad (1.68 GB per module at 518 736 rows) + two whole-gradient launches (0.67 + 0.70 GB) by 0.53 GB.
 //
 // One 8-wave workgroup per CU, rows in tiles of 64, hidden units in four blocks of 64 ("slots"), scaled split-fp16 arithmetic
-// (se_gemm_dev.h, precision 3).  The waves are SPECIALISED; waves w and w + 4 share a SIMD (MI355X_MICROARCH.md):
-//   D waves 0..3 = (row group g = w & 1, hidden half jh = w >> 1): per slot the 32 rows x 32 hidden units tile of
-//       H^T = W1 LN(X)^T + b1 and dP^T = W2s (mask_o dY)^T           (A = weight rows from LDS, B = the rows' fragments in registers:
-//       the C layout then has the ROW on the lane and four consecutive hidden units per register quad -- one dropout hash per quad)
-//       S = Swish(H) mask_h,  dZ = dP mask_h Swish'(H)               (registers; split to fp16 (hi, lo); written ROW-major [r][j]
-//       into the exchange images; dZ's registers ARE the A fragments of)
-//       dLN += dZ W1                                                 (B = W1 rows through transposed reads of the same W1 image)
-//     and per tile the LayerNorm prologue / dropout mask of dY (into row-major fp16 images) and the LayerNorm backward.
-//   W waves 4..7 = (kind = dW1 | dW2, hidden half jh): per slot two 32 x 32 tiles of
-//       dW1[j][c] += sum_r dZ[r][j] LN(X)[r][c]      or      dW2[c][j] += sum_r (mask_o dY)[r][c] S[r][j]
-//     with BOTH operands taken from the row-major images by hardware-transposed reads (ds_read_b64_tr_b16: the contraction index is
-//     the image row); 128 accumulator registers per wave for the four slots; db1 / db2 by packed dot products on the same fragments.
-//   W lags D by one slot (the exchange images are double-buffered); it also streams the next slot's weight block L2 -> registers ->
-//   LDS.  Two barriers per slot: | D: H, dP, S, dZ -> images; W1 fragments for dLN -> registers || W: first half of the previous
-//   slot's tiles; next weight block -> registers | D: dLN MFMAs from registers || W: weight block -> LDS; second half |.
-//   Every wave executes the same number of barriers (D and W run different code paths: s_barrier counts arrivals).
+// (se_gemm_dev.h, precision 3).  The waves are SPECIALISED; waves w and w + 4 share a SIMD (MI355X_MICROARCH.md), so every SIMD
+// runs one wave of each kind and its vector-issue slots and its matrix pipe are shared between the two kinds of work:
+//   D waves 0..3 = (row group g = w & 1, half jh = w >> 1): the matrix products of the input-gradient chain and the elementwise
+//     work between them, nothing else --
+//       H^T = W1 LN(X)^T + b1,  dP^T = W2s (mask_o dY)^T   32 hidden units x 32 rows per wave and slot (A = weight rows from LDS, B = the
+//                                                          rows' fragments in registers: the C layout then has the ROW on the lane
+//                                                          and four consecutive hidden units per register quad)
+//       S = Swish(H) mask_h,  dZ = dP mask_h Swish'(H)     registers -> fp16 (hi, lo) -> ROW-major [r][j] exchange images
+//       dLN[32 rows x 32 channels (half jh)] += dZ W1      A = dZ rows out of the exchange image (both hidden halves: the sum over the
+//                                                          slot's 64 hidden units is complete in ONE wave), B = W1 through transposed reads
+//   W waves 4..7 = (kind = dW1 | dW2, hidden half jh): everything else --
+//       dW1[j][c] += sum_r dZ[r][j] LN(X)[r][c]   or   dW2[c][j] += sum_r (mask_o dY)[r][c] S[r][j]     two 32 x 32 tiles per slot, both
+//         operands by hardware-transposed reads of the row-major images (ds_read_b64_tr_b16: the contraction index is the image
+//         row); 128 accumulator registers per wave for the four slots; db1 / db2 by packed dot products on the same fragments;
+//       the tile PROLOGUE (rows of X / dY -> LayerNorm / dropout mask -> fp16 images), the tile EPILOGUE (LayerNorm backward on the dLN
+//         patch the D waves leave, dX, gamma / beta gradients), the dropout mask BITS of the hidden units (one hash per four
+//         units, handed to the D waves as one word per row and slot), the weight blocks of the next slot (L2 -> registers -> LDS)
+//         (L2-warming touches of the next tile's rows were measured and dropped).
+//   W lags D by one slot (the exchange images are double-buffered).  Two barriers per slot: | D: H, dP, S, dZ -> images, W1
+//   fragments of dLN -> registers || W: the previous slot's tiles, mask bits and weight block of the next | D: dLN || W: weight block
+//   -> LDS |; one per tile for the dLN patch and one for the new row images.  Every wave executes the same number of barriers (D and W
+//   run different code paths: s_barrier counts arrivals).
+//   (v1 of this kernel gave the D waves the prologue, the epilogue and the hashes too: 513 us per launch at the bench shape, the D
+//   waves vector-issue-bound at one wave per SIMD -- tools/ff_fused_bench.py, profiles/r05_ff_fused_ablation.txt.)
 #include "se_gemm_dev.h"
 
 typedef short s16x4f_ __attribute__((ext_vector_type(4)));
@@ -35,41 +43,44 @@ struct FfFusedArgs {
   long M; long rows_per_wg; float drop_p; unsigned seed_h, seed_o; float alpha;
   const float* dy_amax; const float* w1_amax; const float* w2t_amax; const float* in_amax; const float* mid_amax; float* out_amax;
   int ln_sexp, hid_sexp;
+  int dbg;                 // timing ablations (SE_FF_DBG; 0 in production: wrong results otherwise) -- see tools/ff_fused_bench.py
+  unsigned* stamps;        // -DSE_FF_STAMPS builds only (tools/ff_fused_stamps.py): s_memtime of every wave's ARRIVAL at every barrier
 };
+// diagnostic build: [workgroup < 4][wave 8][tile < 8][barrier 10] shader-clock stamps (low 32 bits), written by lane 0
+#ifdef SE_FF_STAMPS
+#define FF_STAMP(k) do { if (a.stamps && blockIdx.x < 4 && t < 8 && lane == 0) \
+    a.stamps[(((int)blockIdx.x * 8 + wave) * 8 + t) * 10 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FF_STAMP(k) do { } while (0)
+#endif
 
 namespace fff {
-constexpr int RS = 144;                 // image row stride in bytes: 64 fp16 + 16 B pad (ds_read_b128 rows conflict-free)
-constexpr int PL = 64 * RS;             // plane stride (hi | lo)
+constexpr int RS = 144;                 // row stride (bytes) of the LN / dY / weight images: 64 fp16 + 16 B pad (ds_read_b128 rows conflict-free)
+constexpr int PL = 64 * RS;             // their plane stride (hi | lo)
 constexpr int IMG = 2 * PL;             // one [64][64] fp16 (hi, lo) image
+constexpr int ZRS = 136;                // row stride of the exchange images (8-byte accesses only: + 8 B pad)
+constexpr int ZPL = 64 * ZRS, ZIMG = 2 * ZPL;
 constexpr int O_LN = 0, O_DY = IMG, O_W1 = 2 * IMG, O_W2 = 3 * IMG, O_ZS = 4 * IMG;     // ZS: [buffer][Z | S] images
-constexpr int O_B1 = O_ZS + 4 * IMG, O_GB = O_B1 + 1024, LDS_BYTES = O_GB + 512;
-constexpr int PS = 68;                  // epilogue patch row stride (floats)
-static_assert(4 * 32 * PS * 4 <= 2 * IMG, "the four dLN patches live in exchange buffer 0");
+constexpr int O_PATCH = O_ZS + 4 * ZIMG;            // dLN of the tile: [64 rows][64 channels] fp32
+constexpr int O_B1 = O_PATCH + 64 * 64 * 4, O_GB = O_B1 + 1024, O_BITS = O_GB + 512, LDS_BYTES = O_BITS + 2 * 64 * 8;
+static_assert(LDS_BYTES <= 163840, "one workgroup per CU: at most the CU's 160 KB");
 
 static __device__ __forceinline__ u32x2_ tr8_(const unsigned char* p) {          // ds_read_b64_tr_b16 (EXEC must be full)
   return __builtin_bit_cast(u32x2_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4f_ __attribute__((address_space(3)))*)(p)));
 }
-// 8-deep fragment of a [rows = contraction index][cols] fp16 image: the lane gets column (lane & 31) of its block, contraction slots
-// 8 kg .. 8 kg + 7 of the 16-deep step whose first row `p` already points at (p = this lane's tr address, see tr_base)
-// DR: image rows between the fragment's elements 0..3 and 4..7 (4: natural order; 8: the order of an accumulator's register quads)
-template <int DR = 4>
+// 8-deep fragment of a [rows = contraction index][cols] fp16 image with row stride STR: the lane gets column (lane & 31) of its block,
+// contraction slots 8 kg .. 8 kg + 7 of the 16-deep step whose first row `p` already points at (p = this lane's tr address)
+template <int STR>
 static __device__ __forceinline__ bf16x8 trfrag_(const unsigned char* p) {
-  const u32x2_ t0 = tr8_(p), t1 = tr8_(p + DR * RS);
+  const u32x2_ t0 = tr8_(p), t1 = tr8_(p + 4 * STR);
   return __builtin_bit_cast(bf16x8, (u32x4_){t0[0], t0[1], t1[0], t1[1]});
-}
-// (already scaled) y0..y3 -> packed fp16 hi words h0 h1 and lo words l0 l1 (scalar words: see split_planes8_h)
-static __device__ __forceinline__ void split4_(float y0, float y1, float y2, float y3, unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
-  h0 = pk_f16_(y0, y1); h1 = pk_f16_(y2, y3);
-  const f16x2_ a = __builtin_bit_cast(f16x2_, h0), b = __builtin_bit_cast(f16x2_, h1);
-  l0 = pk_f16_(y0 - (float)a[0], y1 - (float)a[1]);
-  l1 = pk_f16_(y2 - (float)b[0], y3 - (float)b[1]);
 }
 // the same fragment AND acc += the sum of its 8 fp16 values (v_dot2c_f32_f16 against (1, 1)).  The four words are taken from the
 // two transposed reads BEFORE they are assembled into the fragment: read back out of the assembled ext-vector, hipcc 7.2 fed all
 // four dot products from the fragment's FIRST register (the miscompile split_planes8_h works around; tools/micro/f16chk.hip)
-template <int DR = 4>
+template <int STR>
 static __device__ __forceinline__ bf16x8 trfrag_sum_(const unsigned char* p, float& acc) {
-  const u32x2_ t0 = tr8_(p), t1 = tr8_(p + DR * RS);
+  const u32x2_ t0 = tr8_(p), t1 = tr8_(p + 4 * STR);
   const unsigned a0 = t0[0], a1 = t0[1], a2 = t1[0], a3 = t1[1];
   const h2f_ one = {(_Float16)1.0f, (_Float16)1.0f};
   acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2f_, a0), one, acc, false);
@@ -77,6 +88,16 @@ static __device__ __forceinline__ bf16x8 trfrag_sum_(const unsigned char* p, flo
   acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2f_, a2), one, acc, false);
   acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2f_, a3), one, acc, false);
   return __builtin_bit_cast(bf16x8, (u32x4_){a0, a1, a2, a3});
+}
+// (already scaled) y0..y3 -> packed fp16 hi words h0 h1 and lo words l0 l1 (scalar words: see split_planes8_h); lo = y * 1 - hi with an
+// OPAQUE 1.0 so that the residual is ONE v_fma_mix_f32 per value (the plain form compiles to v_cvt_f32_f16 + v_sub_f32)
+static __device__ __forceinline__ void split4_(float y0, float y1, float y2, float y3, float one, unsigned& h0, unsigned& h1, unsigned& l0,
+                                               unsigned& l1) {
+  h0 = pk_f16_(y0, y1); h1 = pk_f16_(y2, y3);
+  const f16x2_ a = __builtin_bit_cast(f16x2_, h0), b = __builtin_bit_cast(f16x2_, h1);
+  y0 = __builtin_fmaf(y0, one, -(float)a[0]); y1 = __builtin_fmaf(y1, one, -(float)a[1]);
+  y2 = __builtin_fmaf(y2, one, -(float)b[0]); y3 = __builtin_fmaf(y3, one, -(float)b[1]);
+  l0 = pk_f16_(y0, y1); l1 = pk_f16_(y2, y3);
 }
 struct Scales { float s_in, s_dy, s_s, s_z, uh, u1, u2, un1, un2, ub1, ub2; };
 }  // namespace fff
@@ -88,175 +109,36 @@ static __device__ __forceinline__ void ff_fused_D(const FfFusedArgs& a, unsigned
   const int g = wave & 1, jh = wave >> 1;
   const int r = lane & 31, kg = lane >> 5;
   const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const unsigned thr = drop_thr(a.drop_p);
   const float inv_keep = drop_inv_keep(a.drop_p);
   const bool dr = a.drop_p > 0.f;
+  float one;
+  asm volatile("s_mov_b32 %0, 1.0" : "=s"(one));
   const float* b1s = reinterpret_cast<const float*>(sm + O_B1);
-  const float* gbs = reinterpret_cast<const float*>(sm + O_GB);
-  unsigned char* const myimg = sm + (jh == 0 ? O_LN : O_DY);
-  // prologue / epilogue roles
-  const int prr = lane >> 3, pcq = lane & 7;
-  float4 raw[4][2];
-  float2 rst[4];
-  const float* const psrc = jh == 0 ? a.X : a.dY;
-  auto load_raw = [&](long m0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      long m = m0 + 32 * g + prr + 8 * i;
-      if (m > a.M - 1) m = a.M - 1;                      // unconditional loads; rows >= mend are zeroed below
-      raw[i][0] = *reinterpret_cast<const float4*>(psrc + m * 64 + 8 * pcq);
-      raw[i][1] = *reinterpret_cast<const float4*>(psrc + m * 64 + 8 * pcq + 4);
-      rst[i] = *reinterpret_cast<const float2*>(a.stats + 2 * m);
-    }
-  };
-  auto prologue_store = [&](long m0) {
-    const float4 gm0 = *reinterpret_cast<const float4*>(gbs + 8 * pcq), gm1 = *reinterpret_cast<const float4*>(gbs + 8 * pcq + 4);
-    const float4 bt0 = *reinterpret_cast<const float4*>(gbs + 64 + 8 * pcq), bt1 = *reinterpret_cast<const float4*>(gbs + 64 + 8 * pcq + 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long m = m0 + 32 * g + prr + 8 * i;
-      const bool ok = m < mend;
-      float x[8];
-      const float4 w0 = raw[i][0], w1 = raw[i][1];
-      if (jh == 0) {
-        const float mean = rst[i].x, rstd = rst[i].y;
-        x[0] = (w0.x - mean) * rstd * gm0.x + bt0.x; x[1] = (w0.y - mean) * rstd * gm0.y + bt0.y;
-        x[2] = (w0.z - mean) * rstd * gm0.z + bt0.z; x[3] = (w0.w - mean) * rstd * gm0.w + bt0.w;
-        x[4] = (w1.x - mean) * rstd * gm1.x + bt1.x; x[5] = (w1.y - mean) * rstd * gm1.y + bt1.y;
-        x[6] = (w1.z - mean) * rstd * gm1.z + bt1.z; x[7] = (w1.w - mean) * rstd * gm1.w + bt1.w;
-      } else {
-        float4 d0 = make_float4(1.f, 1.f, 1.f, 1.f), d1 = d0;
-        if (dr) {
-          d0 = drop_scale4(a.seed_o, (unsigned)(m * 64 + 8 * pcq), thr, inv_keep);
-          d1 = drop_scale4(a.seed_o, (unsigned)(m * 64 + 8 * pcq + 4), thr, inv_keep);
-        }
-        x[0] = w0.x * d0.x; x[1] = w0.y * d0.y; x[2] = w0.z * d0.z; x[3] = w0.w * d0.w;
-        x[4] = w1.x * d1.x; x[5] = w1.y * d1.y; x[6] = w1.z * d1.z; x[7] = w1.w * d1.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
-      bf16x8 o[2];
-      split_planes8_h(x, jh == 0 ? sc.s_in : sc.s_dy, o);
-      unsigned char* p = myimg + (32 * g + prr + 8 * i) * RS + 16 * pcq;
-      *reinterpret_cast<bf16x8*>(p) = o[0];
-      *reinterpret_cast<bf16x8*>(p + PL) = o[1];
-    }
-  };
   // per-lane LDS bases
   const unsigned char* const fragLN = sm + O_LN + (32 * g + r) * RS + 16 * kg;          // + pl * PL + 32 * ks
   const unsigned char* const fragDY = sm + O_DY + (32 * g + r) * RS + 16 * kg;
   const unsigned char* const w1a = sm + O_W1 + (32 * jh + r) * RS + 16 * kg;            // A fragments: weight row 32 jh + (lane & 31)
   const unsigned char* const w2a = sm + O_W2 + (32 * jh + r) * RS + 16 * kg;
-  // transposed reads of the W1 image for dLN's B operand: contraction slots 8 kg .. of step ks' = hidden units
-  // 32 jh + 16 ks' + {4 kg + 0..3, 8 + 4 kg + 0..3} (the order dZ's accumulator registers come in), column = channel 32 nt + (lane & 31)
-  const unsigned char* const w1t = sm + O_W1 + (32 * jh + 4 * (gi >> 1) + q4) * RS + (16 * (gi & 1) + 4 * p4) * 2;
-  const int zcol = (32 * jh + 4 * kg) * 2;                                               // + 16 q bytes: this lane's quad q of its row
-  float* const patch = reinterpret_cast<float*>(sm + O_ZS);
-  // epilogue role: rows 16 jh + err + 8 i (i = 0, 1) of group g, channels 8 ecq .. + 7
+  // transposed reads of the W1 image for dLN's B operand: column = channel 32 jh + (lane & 31), contraction = the slot's 64 hidden units
+  const unsigned char* const w1t = sm + O_W1 + (8 * (gi >> 1) + q4) * RS + (32 * jh + 16 * (gi & 1) + 4 * p4) * 2;      // + pl * PL + 16 ks * RS
+  const int zoff = (32 * g + r) * ZRS;                                                   // this lane's row of the exchange images
+  const int zcol = (32 * jh + 4 * kg) * 2;                                               // + 16 q bytes: quad q of that row
+  const unsigned char* const bitw = sm + O_BITS + (32 * g + r) * 8 + 4 * jh;             // + 512 * (s & 1): this lane's mask word
+  float* const patch = reinterpret_cast<float*>(sm + O_PATCH);
+  const float* gbs = reinterpret_cast<const float*>(sm + O_GB);
+  const float mkS = inv_keep * sc.s_s, mkZ = inv_keep * sc.u1;
+  float agk = 0.f, abk = 0.f, xmax = 0.f;                  // gamma / beta gradients of channel 8 ecq + err (see the epilogue)
+  // ---- tile epilogue (in the window between the patch barrier (c) and the next tile's images (p), where the D waves would wait for the
+  // W waves' prologue): LayerNorm backward of rows 16 wave + err + 8 i (i = 0, 1), channels 8 ecq .. + 7, from the dLN patch ----
   const int err = lane >> 3, ecq = lane & 7;
-  // gamma / beta gradients of channel 8 ecq + err (two registers per lane: the tile's per-lane sums are folded over the 8 row lanes at
-  // the end of every epilogue and lane (err, ecq) keeps the total of ITS channel -- 16 persistent accumulators per lane did not fit)
-  float agk = 0.f, abk = 0.f;
-  float xmax = 0.f;
-  bf16x8 lnf[4][2], dyf[4][2];
-  f32x16 g0, g1;
-
-  load_raw(mbeg);
-  __syncthreads();                                       // (0) b1 / gamma / beta staged, weight block 0 in LDS
-  for (int t = 0; t < ntile; ++t) {
-    const long m0 = mbeg + 64L * t;
-    prologue_store(m0);
-    __syncthreads();                                     // (p) the tile's LN(X) / mask_o dY images are complete
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        lnf[ks][pl] = *reinterpret_cast<const bf16x8*>(fragLN + pl * PL + 32 * ks);
-        dyf[ks][pl] = *reinterpret_cast<const bf16x8*>(fragDY + pl * PL + 32 * ks);
-      }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { g0[e] = 0.f; g1[e] = 0.f; }
-    const long m = m0 + 32 * g + r;                      // this lane's row in the C layout of H^T / dP^T
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      // ================= A(s) =================
-      f32x16 ah, ad;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { ah[e] = 0.f; ad[e] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(w1a + 32 * ks), a1l = *reinterpret_cast<const bf16x8*>(w1a + PL + 32 * ks);
-        const bf16x8 a2h = *reinterpret_cast<const bf16x8*>(w2a + 32 * ks), a2l = *reinterpret_cast<const bf16x8*>(w2a + PL + 32 * ks);
-        ah = mfma32_<true>(a1h, lnf[ks][1], ah); ad = mfma32_<true>(a2h, dyf[ks][1], ad);
-        ah = mfma32_<true>(a1l, lnf[ks][0], ah); ad = mfma32_<true>(a2l, dyf[ks][0], ad);
-        ah = mfma32_<true>(a1h, lnf[ks][0], ah); ad = mfma32_<true>(a2h, dyf[ks][0], ad);
-      }
-      unsigned zh[8], zl[8];                              // dZ of this lane's row, hidden units (quad q): words 2q, 2q + 1
-      unsigned char* const zrow = sm + O_ZS + (s & 1) * 2 * IMG + (32 * g + r) * RS + zcol;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int jq = 64 * s + 32 * jh + 8 * q + 4 * kg;       // first of the quad's four consecutive hidden units
-        const float4 b4 = *reinterpret_cast<const float4*>(b1s + jq);
-        float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (dr) mk = drop_scale4(a.seed_h, (unsigned)(m * 256 + jq), thr, inv_keep);
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w}, mm[4] = {mk.x, mk.y, mk.z, mk.w};
-        float sv[4], zv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * q + e;
-          const float h = fmaf(ah[i], sc.uh, bb[e]);
-          const float sg = sigmoidf_(h);
-          const float s0 = h * sg;
-          const float sw = fmaf(s0, 1.0f - sg, sg);             // Swish'(h) = sg (1 + h (1 - sg))
-          sv[e] = s0 * (mm[e] * sc.s_s);
-          zv[e] = ad[i] * sw * (mm[e] * sc.u1);                 // (u1 carries the un-scaling of the accumulator AND dZ's scale)
-        }
-        unsigned sh0, sh1, sl0, sl1;
-        split4_(sv[0], sv[1], sv[2], sv[3], sh0, sh1, sl0, sl1);
-        split4_(zv[0], zv[1], zv[2], zv[3], zh[2 * q], zh[2 * q + 1], zl[2 * q], zl[2 * q + 1]);
-        *reinterpret_cast<u32x2_*>(zrow + 16 * q) = (u32x2_){zh[2 * q], zh[2 * q + 1]};
-        *reinterpret_cast<u32x2_*>(zrow + PL + 16 * q) = (u32x2_){zl[2 * q], zl[2 * q + 1]};
-        *reinterpret_cast<u32x2_*>(zrow + IMG + 16 * q) = (u32x2_){sh0, sh1};
-        *reinterpret_cast<u32x2_*>(zrow + IMG + PL + 16 * q) = (u32x2_){sl0, sl1};
-      }
-      // W1 fragments of the dLN product out of the image BEFORE the barrier (the W waves overwrite the weight images after it)
-      bf16x8 wb[2][2][2];
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) wb[nt][k2][pl] = trfrag_<8>(w1t + pl * PL + 16 * k2 * RS + 64 * nt);
-      __syncthreads();                                   // (a)
-      // ================= B(s) =================
-      if (s == 3 && t + 1 < ntile) load_raw(m0 + 64);     // the next tile's rows: in flight during dLN, the patch exchange, the epilogue
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const bf16x8 zhf = __builtin_bit_cast(bf16x8, (u32x4_){zh[4 * k2], zh[4 * k2 + 1], zh[4 * k2 + 2], zh[4 * k2 + 3]});
-        const bf16x8 zlf = __builtin_bit_cast(bf16x8, (u32x4_){zl[4 * k2], zl[4 * k2 + 1], zl[4 * k2 + 2], zl[4 * k2 + 3]});
-        g0 = mfma32_<true>(zhf, wb[0][k2][1], g0); g1 = mfma32_<true>(zhf, wb[1][k2][1], g1);
-        g0 = mfma32_<true>(zlf, wb[0][k2][0], g0); g1 = mfma32_<true>(zlf, wb[1][k2][0], g1);
-        g0 = mfma32_<true>(zhf, wb[0][k2][0], g0); g1 = mfma32_<true>(zhf, wb[1][k2][0], g1);
-      }
-      __syncthreads();                                   // (b)
-    }
-    // ================= A(4): this wave's partial dLN (its 32 hidden units of every slot) -> patch; epilogue operands requested ====
-    {
-      float* P = patch + wave * (32 * PS);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * kg;
-        P[row * PS + r] = g0[e] * sc.u2;
-        P[row * PS + 32 + r] = g1[e] * sc.u2;
-      }
-    }
-    float4 ex[2][2], ey[2][2], er[2][2];
-    float2 est[2];
-    const long rows_ok = mend - m0 < 64 ? mend - m0 : 64;
+  float4 ex[2][2], ey[2][2], er[2][2];
+  float2 est[2];
+  auto epilogue_load = [&](long m0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      long mr = m0 + 32 * g + 16 * jh + err + 8 * i;
+      long mr = m0 + 16 * wave + err + 8 * i;
       if (mr > a.M - 1) mr = a.M - 1;
+      if (a.dbg & 16) mr = mbeg + 16 * wave + err + 8 * i;            // (ablation: the first tile's rows again -- cache hits)
       est[i] = *reinterpret_cast<const float2*>(a.stats + 2 * mr);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -266,57 +148,160 @@ static __device__ __forceinline__ void ff_fused_D(const FfFusedArgs& a, unsigned
         er[i][k] = a.dR2 ? *reinterpret_cast<const float4*>(a.dR2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    __syncthreads();                                     // (c) both halves' patches written
-    // ================= B(4): LayerNorm backward on rows 16 jh + err + 8 i of group g =================
-    {
-      const float* P0 = patch + g * (32 * PS), * P1 = patch + (g + 2) * (32 * PS);
-      const float4 gmA = *reinterpret_cast<const float4*>(gbs + 8 * ecq), gmB = *reinterpret_cast<const float4*>(gbs + 8 * ecq + 4);
-      const float gl[8] = {gmA.x, gmA.y, gmA.z, gmA.w, gmB.x, gmB.y, gmB.z, gmB.w};
-      const __amdgpu_buffer_rsrc_t Xrs = make_rsrc_(a.dX + m0 * 64, (unsigned)(rows_ok * 64 * 4));
-      float ag[8], ab[8];
+  };
+  auto epilogue = [&](long m0) {
+    const long rows_ok = mend - m0 < 64 ? mend - m0 : 64;
+    const __amdgpu_buffer_rsrc_t Xrs = make_rsrc_(a.dX + m0 * 64, (unsigned)(rows_ok * 64 * 4));
+    const float4 gmA = *reinterpret_cast<const float4*>(gbs + 8 * ecq), gmB = *reinterpret_cast<const float4*>(gbs + 8 * ecq + 4);
+    const float gl8[8] = {gmA.x, gmA.y, gmA.z, gmA.w, gmB.x, gmB.y, gmB.z, gmB.w};
+    float ag[8], ab[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int rl = 16 * jh + err + 8 * i;             // row inside the group
-        const long mr = m0 + 32 * g + rl;
-        const bool ok = mr < mend;
-        const float4 pa0 = *reinterpret_cast<const float4*>(P0 + rl * PS + 8 * ecq), pb0 = *reinterpret_cast<const float4*>(P1 + rl * PS + 8 * ecq);
-        const float4 pa1 = *reinterpret_cast<const float4*>(P0 + rl * PS + 8 * ecq + 4), pb1 = *reinterpret_cast<const float4*>(P1 + rl * PS + 8 * ecq + 4);
-        const float dv[8] = {pa0.x + pb0.x, pa0.y + pb0.y, pa0.z + pb0.z, pa0.w + pb0.w, pa1.x + pb1.x, pa1.y + pb1.y, pa1.z + pb1.z, pa1.w + pb1.w};
-        const float xs[8] = {ex[i][0].x, ex[i][0].y, ex[i][0].z, ex[i][0].w, ex[i][1].x, ex[i][1].y, ex[i][1].z, ex[i][1].w};
-        const float mean = est[i].x, rstd = est[i].y;
-        float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[e] = (xs[e] - mean) * rstd;
-          dxh[e] = dv[e] * gl[e];
-          s1 += dxh[e]; s2 += dxh[e] * xh[e];
-          if (ok) { ag[e] += dv[e] * xh[e]; ab[e] += dv[e]; }
-        }
-#pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const float4 r1 = ey[i][k], r2 = er[i][k];
-          float o4[4] = {r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] += rstd * (dxh[4 * k + e] - s1 - xh[4 * k + e] * s2);
-          buf_store4_(Xrs, (unsigned)(((32 * g + rl) * 64 + 8 * ecq + 4 * k) * 4), make_float4(o4[0], o4[1], o4[2], o4[3]));
-          if (ok) xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
-        }
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int rl = 16 * wave + err + 8 * i;               // row inside the tile
+      const bool ok = m0 + rl < mend;
+      const float4 pa = *reinterpret_cast<const float4*>(patch + rl * 64 + 8 * ecq), pb = *reinterpret_cast<const float4*>(patch + rl * 64 + 8 * ecq + 4);
+      const float dv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+      const float xs[8] = {ex[i][0].x, ex[i][0].y, ex[i][0].z, ex[i][0].w, ex[i][1].x, ex[i][1].y, ex[i][1].z, ex[i][1].w};
+      const float mean = est[i].x, rstd = est[i].y;
+      float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        float sg = ag[e], sb = ab[e];
+        xh[e] = (xs[e] - mean) * rstd;
+        dxh[e] = dv[e] * gl8[e];
+        s1 += dxh[e]; s2 += dxh[e] * xh[e];
+        if (ok) { ag[e] += dv[e] * xh[e]; ab[e] += dv[e]; }
+      }
 #pragma unroll
-        for (int o = 8; o < 64; o <<= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
-        agk += err == e ? sg : 0.f;
-        abk += err == e ? sb : 0.f;
+      for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float4 r1 = ey[i][k], r2 = er[i][k];
+        float o4[4] = {r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] += rstd * (dxh[4 * k + e] - s1 - xh[4 * k + e] * s2);
+        buf_store4_(Xrs, (unsigned)((rl * 64 + 8 * ecq + 4 * k) * 4), make_float4(o4[0], o4[1], o4[2], o4[3]));
+        if (ok) xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
       }
     }
-    __syncthreads();                                     // (d) end of the tile: row images, exchange buffers and patches are free
+    // the tile's per-lane sums folded over the 8 row lanes; lane (err, ecq) keeps the total of channel 8 ecq + err
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float sg = ag[e], sb = ab[e];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
+      agk += err == e ? sg : 0.f;
+      abk += err == e ? sb : 0.f;
+    }
+  };
+
+  bf16x8 lnf[4][2], dyf[4][2];
+  f32x16 gl;
+  // (L2-warming touches of the next tile's rows were tried twice -- issued by the W waves every wait for a weight block also waited
+  // for them: +130 us per launch; issued by the D waves, whose next wait is a tile away: still +59 us -- and dropped)
+
+  __syncthreads();                                       // (0) b1 / gamma / beta staged, weight block 0 in LDS
+  for (int t = 0; t < ntile; ++t) {
+    FF_STAMP(0);
+    __syncthreads();                                     // (p) the tile's LN(X) / mask_o dY images and the mask bits of slot 0 are complete
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        lnf[ks][pl] = *reinterpret_cast<const bf16x8*>(fragLN + pl * PL + 32 * ks);
+        dyf[ks][pl] = *reinterpret_cast<const bf16x8*>(fragDY + pl * PL + 32 * ks);
+      }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gl[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      // ================= A(s) =================
+      f32x16 ah, ad;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { ah[e] = 0.f; ad[e] = 0.f; }
+      // H first, THEN dP: the twelve dP products run on the matrix pipe while the vector unit already works on the part of the
+      // elementwise chain that needs H only (sigmoid, Swish, Swish') -- interleaved, both accumulators finished together and the
+      // whole chain waited behind all 24 products
+      if (!(a.dbg & 4)) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(w1a + 32 * ks), a1l = *reinterpret_cast<const bf16x8*>(w1a + PL + 32 * ks);
+          ah = mfma32_<true>(a1h, lnf[ks][1], ah);
+          ah = mfma32_<true>(a1l, lnf[ks][0], ah);
+          ah = mfma32_<true>(a1h, lnf[ks][0], ah);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 a2h = *reinterpret_cast<const bf16x8*>(w2a + 32 * ks), a2l = *reinterpret_cast<const bf16x8*>(w2a + PL + 32 * ks);
+          ad = mfma32_<true>(a2h, dyf[ks][1], ad);
+          ad = mfma32_<true>(a2l, dyf[ks][0], ad);
+          ad = mfma32_<true>(a2h, dyf[ks][0], ad);
+        }
+      }
+      // keep bits of this lane's row: nibble 2 q + kg of the word = the quad's four hidden units
+      unsigned mbits = 0xffffffffu;
+      if (dr) mbits = *reinterpret_cast<const unsigned*>(bitw + 512 * (s & 1)) >> (4 * kg);
+      unsigned char* const zrow = sm + O_ZS + (s & 1) * 2 * ZIMG + zoff + zcol;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int jq = 64 * s + 32 * jh + 8 * q + 4 * kg;       // first of the quad's four consecutive hidden units
+        const float4 b4 = *reinterpret_cast<const float4*>(b1s + jq);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+        float sv[4], zv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * q + e;
+          const float h = fmaf(ah[i], sc.uh, bb[e]);
+          const float sg = (a.dbg & 1) ? 0.5f : sigmoidf_(h);
+          const float s0 = h * sg;
+          const float sw = fmaf(s0, 1.0f - sg, sg);             // Swish'(h) = sg (1 + h (1 - sg))
+          const bool keep = (mbits >> (8 * q + e)) & 1u;
+          sv[e] = keep ? s0 * mkS : 0.f;
+          zv[e] = keep ? ad[i] * sw * mkZ : 0.f;                // (mkZ carries the un-scaling of the accumulator AND dZ's scale)
+        }
+        unsigned zh0, zh1, zl0, zl1, sh0, sh1, sl0, sl1;
+        split4_(sv[0], sv[1], sv[2], sv[3], one, sh0, sh1, sl0, sl1);
+        split4_(zv[0], zv[1], zv[2], zv[3], one, zh0, zh1, zl0, zl1);
+        *reinterpret_cast<u32x2_*>(zrow + 16 * q) = (u32x2_){zh0, zh1};
+        *reinterpret_cast<u32x2_*>(zrow + ZPL + 16 * q) = (u32x2_){zl0, zl1};
+        *reinterpret_cast<u32x2_*>(zrow + ZIMG + 16 * q) = (u32x2_){sh0, sh1};
+        *reinterpret_cast<u32x2_*>(zrow + ZIMG + ZPL + 16 * q) = (u32x2_){sl0, sl1};
+      }
+      // W1 fragments of the dLN product out of the image BEFORE the barrier (the W waves overwrite the weight images after it)
+      bf16x8 wb[4][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) wb[ks][pl] = trfrag_<RS>(w1t + pl * PL + 16 * ks * RS);
+      FF_STAMP(1 + 2 * s);
+      __syncthreads();                                   // (a)
+      // ================= B(s): dLN of (rows of group g) x (channels of half jh) over the slot's 64 hidden units =================
+      if (!(a.dbg & 8)) {
+        const unsigned char* zr = sm + O_ZS + (s & 1) * 2 * ZIMG + zoff + 16 * kg;       // dZ rows as A fragments (natural order)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const u32x2_ h0 = *reinterpret_cast<const u32x2_*>(zr + 32 * ks), h1 = *reinterpret_cast<const u32x2_*>(zr + 32 * ks + 8);
+          const u32x2_ l0 = *reinterpret_cast<const u32x2_*>(zr + ZPL + 32 * ks), l1 = *reinterpret_cast<const u32x2_*>(zr + ZPL + 32 * ks + 8);
+          const bf16x8 zhf = __builtin_bit_cast(bf16x8, (u32x4_){h0[0], h0[1], h1[0], h1[1]});
+          const bf16x8 zlf = __builtin_bit_cast(bf16x8, (u32x4_){l0[0], l0[1], l1[0], l1[1]});
+          gl = mfma32_<true>(zhf, wb[ks][1], gl);
+          gl = mfma32_<true>(zlf, wb[ks][0], gl);
+          gl = mfma32_<true>(zhf, wb[ks][0], gl);
+        }
+      }
+      FF_STAMP(2 + 2 * s);
+      __syncthreads();                                   // (b)
+    }
+    // the tile's dLN -> patch [row][channel] (C layout: row = (e & 3) + 8 (e >> 2) + 4 kg of the group, column = lane & 31 of the half)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) patch[(32 * g + (e & 3) + 8 * (e >> 2) + 4 * kg) * 64 + 32 * jh + r] = gl[e] * sc.u2;
+    const long m0 = mbeg + 64L * t;
+    epilogue_load(m0);                                   // (X, dY: L2 hits -- the prologue read them; dR2: warmed by the W waves)
+    FF_STAMP(9);
+    __syncthreads();                                     // (c) patch complete; the W waves have finished with the tile's row images
+    epilogue(m0);
   }
   if (a.out_amax) {
     xmax = wave_max(xmax);
@@ -328,16 +313,25 @@ static __device__ __forceinline__ void ff_fused_D(const FfFusedArgs& a, unsigned
 }
 
 // ------------------------------------------------------------------------------------------------ W waves
+// (KIND is a template parameter: as a run-time value -- wave-uniform, but the compiler did not know -- every `kind` test inside the
+// unrolled product loops became a branch of its own)
+template <int kind>
 static __device__ __forceinline__ void ff_fused_W(const FfFusedArgs& a, unsigned char* sm, const int wave, const int lane,
-                                                  const int ntile, const fff::Scales& sc) {
+                                                  const long mbeg, const long mend, const int ntile, const fff::Scales& sc) {
   using namespace fff;
-  const int w4 = wave - 4, kind = w4 >> 1, jh = w4 & 1;        // kind 0: dW1 (Z, LN), kind 1: dW2 (dY, S)
+  const int w4 = wave - 4, jh = w4 & 1;                        // kind 0: dW1 (Z, LN), kind 1: dW2 (dY, S)
   const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
   const int tidw = w4 * 64 + lane;
-  // transposed-read address of this lane inside a [64 rows = contraction][64 cols] image: + pl * PL + 16 ks * RS + 2 * col0
-  const int trb = (8 * (gi >> 1) + q4) * RS + (16 * (gi & 1) + 4 * p4) * 2;
-  const unsigned char* const shb = sm + O_ZS + (kind == 0 ? 0 : IMG) + trb + 64 * jh;      // shared operand: Z (dW1) or S (dW2), columns 32 jh ..
-  const unsigned char* const vab = sm + (kind == 0 ? O_LN : O_DY) + trb;                  // varying operand: LN (dW1) or dY (dW2), + 64 nt
+  const unsigned thr = drop_thr(a.drop_p);
+  const float inv_keep = drop_inv_keep(a.drop_p);
+  const bool dr = a.drop_p > 0.f;
+  const float* gbs = reinterpret_cast<const float*>(sm + O_GB);
+  // transposed-read address of this lane inside a [64 rows = contraction][64 cols] image with row stride STR:
+  //   (8 kg + q4) * STR + (16 (gi & 1) + 4 p4) * 2   + pl * plane + 16 ks * STR + 2 * col0
+  const int trz = (8 * (gi >> 1) + q4) * ZRS + (16 * (gi & 1) + 4 * p4) * 2;
+  const int trr = (8 * (gi >> 1) + q4) * RS + (16 * (gi & 1) + 4 * p4) * 2;
+  const unsigned char* const shb = sm + O_ZS + (kind == 0 ? 0 : ZIMG) + trz + 64 * jh;   // shared operand: Z (dW1) or S (dW2), columns 32 jh ..
+  const unsigned char* const vab = sm + (kind == 0 ? O_LN : O_DY) + trr;                  // varying operand: LN (dW1) or dY (dW2), + 64 nt
   f32x16 acc[4][2];
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb)
@@ -345,10 +339,9 @@ static __device__ __forceinline__ void ff_fused_W(const FfFusedArgs& a, unsigned
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[jb][nt][e] = 0.f;
-  float zs[4] = {0.f, 0.f, 0.f, 0.f}, ys[2] = {0.f, 0.f};
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};      // kind 0: db1 of the wave's hidden units of slot jb; kind 1 (jh == 0): bs[nt] = db2 of channel half nt
+  // ---- weight blocks: L2 -> registers -> LDS (buffer loads: one wave-uniform descriptor per matrix + ONE 32-bit lane offset) ----
   float4 stg[8];
-  // (buffer loads: one wave-uniform descriptor per matrix + ONE 32-bit lane offset + immediates -- with flat 64-bit addresses the
-  // compiler kept 14 precomputed address pairs alive and spilled them)
   const __amdgpu_buffer_rsrc_t W1rs = make_rsrc_(a.W1, 2u * 256u * 64u * 2u), W2rs = make_rsrc_(a.W2T, 2u * 256u * 64u * 2u);
   const unsigned stoff = (unsigned)((tidw >> 3) * 128 + (tidw & 7) * 16);               // row (tidw >> 3) of the block, 16-byte chunk tidw & 7
   auto stage_load = [&](int jb) {
@@ -363,21 +356,27 @@ static __device__ __forceinline__ void ff_fused_W(const FfFusedArgs& a, unsigned
       *reinterpret_cast<float4*>(sm + ((i >> 2) ? O_W2 : O_W1) + ((i >> 1) & 1) * PL + row * RS + 16 * ch) = stg[i];
     }
   };
-  // two 16-deep steps (ks0, ks0 + 1) of the tiles of slot jb out of exchange buffer (jb & 1)
-  auto wgrad_half = [&](auto jbc, int ks0) {
+  // ---- the two 32 x 32 tiles of slot jb out of exchange buffer (jb & 1) ----
+  auto wgrad = [&](auto jbc) {
     constexpr int jb = decltype(jbc)::value;
-    const unsigned char* sh = shb + (jb & 1) * 2 * IMG;
+    if (a.dbg & 128) return;
+    const unsigned char* sh = shb + (jb & 1) * 2 * ZIMG;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int ks = ks0 + kk;
-      float zsum = 0.f;                   // (kind 0: this lane's part of db1 = sum over the rows of dZ)
-      const bf16x8 sh_h = trfrag_sum_(sh + 16 * ks * RS, zsum), sh_l = trfrag_sum_(sh + PL + 16 * ks * RS, zsum);
-      if (kind == 0) zs[jb] += zsum;
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 sh_h, sh_l;
+      if (kind == 0) {                    // db1 = sum over the rows of dZ: this lane's part, from the fragments it loads anyway
+        sh_h = trfrag_sum_<ZRS>(sh + 16 * ks * ZRS, bs[jb]); sh_l = trfrag_sum_<ZRS>(sh + ZPL + 16 * ks * ZRS, bs[jb]);
+      } else {
+        sh_h = trfrag_<ZRS>(sh + 16 * ks * ZRS); sh_l = trfrag_<ZRS>(sh + ZPL + 16 * ks * ZRS);
+      }
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        float ysum = 0.f;                 // (kind 1, first slot: db2 = column sums of mask_o dY)
-        const bf16x8 va_h = trfrag_sum_(vab + 16 * ks * RS + 64 * nt, ysum), va_l = trfrag_sum_(vab + PL + 16 * ks * RS + 64 * nt, ysum);
-        if (kind == 1 && jh == 0 && jb == 0) ys[nt] += ysum;
+        bf16x8 va_h, va_l;
+        if (jb == 0 && kind == 1) {       // db2 = column sums of mask_o dY, once per tile (first slot; the jh = 0 wave flushes it)
+          va_h = trfrag_sum_<RS>(vab + 16 * ks * RS + 64 * nt, bs[nt]); va_l = trfrag_sum_<RS>(vab + PL + 16 * ks * RS + 64 * nt, bs[nt]);
+        } else {
+          va_h = trfrag_<RS>(vab + 16 * ks * RS + 64 * nt); va_l = trfrag_<RS>(vab + PL + 16 * ks * RS + 64 * nt);
+        }
         if (kind == 0) {          // dW1[j][c]: A = Z^T (row j on the lane), B = LN (column c on the lane)
           acc[jb][nt] = mfma32_<true>(sh_h, va_l, acc[jb][nt]);
           acc[jb][nt] = mfma32_<true>(sh_l, va_h, acc[jb][nt]);
@@ -390,38 +389,127 @@ static __device__ __forceinline__ void ff_fused_W(const FfFusedArgs& a, unsigned
       }
     }
   };
+  // ---- dropout keep bits of the hidden units of slot s of the tile at m0: lane = (row tidw >> 2, groups 4 (tidw & 3) .. + 3) ----
+  auto mask_bits = [&](long m0, int s) {
+    // (compiler barriers: scheduled together with the weight-block loads and the transposed reads of the products, the four
+    // hashes' temporaries were the last registers this wave did not have)
+    asm volatile("" ::: "memory");
+    if (!dr || (a.dbg & 2)) return;
+    const int row = tidw >> 2, part = tidw & 3;
+    const unsigned grp0 = (unsigned)((m0 + row) * 64 + 16 * s + 4 * part);       // (m * 256 + 64 s + 16 part) >> 2
+    unsigned bits = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned f[4];
+      drop_fields(a.seed_h, grp0 + k, f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bits |= (f[e] >= thr ? 1u : 0u) << (4 * k + e);
+    }
+    *reinterpret_cast<unsigned short*>(sm + O_BITS + 512 * (s & 1) + row * 8 + 2 * part) = (unsigned short)bits;
+    asm volatile("" ::: "memory");
+  };
+  // ---- tile prologue: lane = (row tidw >> 2, channel octets part and part + 4 of X AND of dY) ----
+  const int prow = tidw >> 2, ppart = tidw & 3;
+  float4 raw[8];                         // [tensor][octet][half]
+  float2 rst;
+  // (buffer loads: wave-uniform tile bases + ONE 32-bit lane offset; rows past M come back as zeros from the range check -- flat
+  // 64-bit lane addresses were kept as precomputed pairs across the tile loop and spilled)
+  const unsigned roff = (unsigned)(prow * 256 + ppart * 32);
+  auto load_raw = [&](long m0) {
+    const long avail = a.M - m0 < 64 ? a.M - m0 : 64;
+    const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X + m0 * 64, (unsigned)(avail * 256)), Yr = make_rsrc_(a.dY + m0 * 64, (unsigned)(avail * 256));
+    const __amdgpu_buffer_rsrc_t Sr = make_rsrc_(a.stats + m0 * 2, (unsigned)(avail * 8));
+    const float4 s4 = buf_load4_(Sr, (unsigned)((prow & ~1) * 8));            // (mean, rstd) of rows prow & ~1 and that + 1: 16-byte aligned
+    rst = (prow & 1) ? make_float2(s4.z, s4.w) : make_float2(s4.x, s4.y);
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        raw[2 * o + hf] = buf_load4_(Xr, roff + (unsigned)(128 * o + 16 * hf));
+        raw[4 + 2 * o + hf] = buf_load4_(Yr, roff + (unsigned)(128 * o + 16 * hf));
+      }
+  };
+  auto prologue_store = [&](long m0) {
+    const long m = m0 + prow;
+    const bool ok = m < mend;
+    const float mean = rst.x, rstd = rst.y;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int c0 = 8 * (ppart + 4 * o);
+      float x[8], y[8];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const float4 gm = *reinterpret_cast<const float4*>(gbs + c0 + 4 * hf), bt = *reinterpret_cast<const float4*>(gbs + 64 + c0 + 4 * hf);
+        const float4 w = raw[2 * o + hf];
+        x[4 * hf] = (w.x - mean) * rstd * gm.x + bt.x; x[4 * hf + 1] = (w.y - mean) * rstd * gm.y + bt.y;
+        x[4 * hf + 2] = (w.z - mean) * rstd * gm.z + bt.z; x[4 * hf + 3] = (w.w - mean) * rstd * gm.w + bt.w;
+        float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (dr) d4 = drop_scale4(a.seed_o, (unsigned)(m * 64 + c0 + 4 * hf), thr, inv_keep);
+        const float4 v = raw[4 + 2 * o + hf];
+        y[4 * hf] = v.x * d4.x; y[4 * hf + 1] = v.y * d4.y; y[4 * hf + 2] = v.z * d4.z; y[4 * hf + 3] = v.w * d4.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { x[e] = ok ? x[e] : 0.f; y[e] = ok ? y[e] : 0.f; }
+      bf16x8 ox[2], oy[2];
+      split_planes8_h(x, sc.s_in, ox);
+      split_planes8_h(y, sc.s_dy, oy);
+      unsigned char* p = sm + O_LN + prow * RS + 2 * c0;
+      *reinterpret_cast<bf16x8*>(p) = ox[0];
+      *reinterpret_cast<bf16x8*>(p + PL) = ox[1];
+      *reinterpret_cast<bf16x8*>(p + (O_DY - O_LN)) = oy[0];
+      *reinterpret_cast<bf16x8*>(p + (O_DY - O_LN) + PL) = oy[1];
+    }
+  };
+  // (no run-time switch may skip a stage_load / load_raw: a skipped load makes the OLD register contents live across the whole tile
+  // loop -- 66 registers of a wave that has 128 accumulators)
   stage_load(0);
+  load_raw(mbeg);
   stage_store();
-  __syncthreads();                                       // (0)
+  mask_bits(mbeg, 0);
+  __syncthreads();                                       // (0) gamma / beta (and b1) staged
   for (int t = 0; t < ntile; ++t) {
+    const long m0 = mbeg + 64L * t;
+    const bool more = t + 1 < ntile;
+    // the tile's rows (warmed into L2 by the touches of the previous tile; the D waves run that tile's epilogue meanwhile).  NOT requested
+    // before the last slot's weight-gradient tiles: 34 more live registers there spilled
+    if (t > 0) load_raw(m0);
+    prologue_store(m0);
+    FF_STAMP(0);
     __syncthreads();                                     // (p)
-    // slot 0: nothing to contract yet
+    mask_bits(m0, 1);
     stage_load(1);
+    FF_STAMP(1);
     __syncthreads();                                     // (a0)
     stage_store();
+    FF_STAMP(2);
     __syncthreads();                                     // (b0)
+    wgrad(std::integral_constant<int, 0>{});
+    mask_bits(m0, 2);
     stage_load(2);
-    wgrad_half(std::integral_constant<int, 0>{}, 0);
+    FF_STAMP(3);
     __syncthreads();                                     // (a1)
     stage_store();
-    wgrad_half(std::integral_constant<int, 0>{}, 2);
+    FF_STAMP(4);
     __syncthreads();                                     // (b1)
+    wgrad(std::integral_constant<int, 1>{});
+    mask_bits(m0, 3);
     stage_load(3);
-    wgrad_half(std::integral_constant<int, 1>{}, 0);
+    FF_STAMP(5);
     __syncthreads();                                     // (a2)
     stage_store();
-    wgrad_half(std::integral_constant<int, 1>{}, 2);
+    FF_STAMP(6);
     __syncthreads();                                     // (b2)
+    wgrad(std::integral_constant<int, 2>{});
+    if (more) mask_bits(m0 + 64, 0);
     stage_load(0);
-    wgrad_half(std::integral_constant<int, 2>{}, 0);
+    FF_STAMP(7);
     __syncthreads();                                     // (a3)
     stage_store();
-    wgrad_half(std::integral_constant<int, 2>{}, 2);
+    FF_STAMP(8);
     __syncthreads();                                     // (b3)
-    wgrad_half(std::integral_constant<int, 3>{}, 0);
-    __syncthreads();                                     // (c)
-    wgrad_half(std::integral_constant<int, 3>{}, 2);
-    __syncthreads();                                     // (d)
+    wgrad(std::integral_constant<int, 3>{});
+    FF_STAMP(9);
+    __syncthreads();                                     // (c) every W wave has finished with the tile's row images
   }
   // ---- flush: C layout [row = (e & 3) + 8 (e >> 2) + 4 kg][col = lane & 31] ----
   const int col = lane & 31, kg = lane >> 5;
@@ -438,13 +526,13 @@ static __device__ __forceinline__ void ff_fused_W(const FfFusedArgs& a, unsigned
   if (kind == 0) {
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
-      const float v = zs[jb] + __shfl_xor(zs[jb], 32, 64);
+      const float v = bs[jb] + __shfl_xor(bs[jb], 32, 64);
       if (kg == 0) atomicAdd(&a.db1[64 * jb + 32 * jh + col], v * sc.ub1);
     }
   } else if (jh == 0 && a.db2) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      const float v = ys[nt] + __shfl_xor(ys[nt], 32, 64);
+      const float v = bs[nt] + __shfl_xor(bs[nt], 32, 64);
       if (kg == 0) atomicAdd(&a.db2[32 * nt + col], v * sc.ub2);
     }
   }
@@ -478,8 +566,14 @@ __global__ __launch_bounds__(512, 2) void ff_bwd_fused_kernel(FfFusedArgs a) {
   if (tid < 256) reinterpret_cast<float*>(sm + O_B1)[tid] = a.b1[tid];
   if (tid < 128) reinterpret_cast<float*>(sm + O_GB)[tid] = tid < 64 ? a.gamma[tid] : a.beta[tid - 64];
   if (wave < 4) ff_fused_D(a, sm, wave, lane, mbeg, mend, ntile, sc);
-  else ff_fused_W(a, sm, wave, lane, ntile, sc);
+  else if (wave < 6) ff_fused_W<0>(a, sm, wave, lane, mbeg, mend, ntile, sc);
+  else ff_fused_W<1>(a, sm, wave, lane, mbeg, mend, ntile, sc);
 }
+
+#ifdef SE_FF_STAMPS
+static unsigned* g_ff_stamps = nullptr;
+extern "C" void se_ff_fused_debug_stamps(void* p) { g_ff_stamps = reinterpret_cast<unsigned*>(p); }
+#endif
 
 extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta,
                                const float* W1, const float* b1, const float* W2T, const float* dR2, float* dX, float* dgamma,
@@ -492,7 +586,7 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
   SE_REQUIRE(M > 0 && hid == 256, "ff_bwd_fused: M=%ld hid=%d (built for hid == 256: four slots of 64 hidden units)", M, hid);
   SE_REQUIRE((((size_t)W1 | (size_t)W2T) & 15) == 0, "ff_bwd_fused: weight planes must be 16-byte aligned");
   SE_REQUIRE(drop_p >= 0.f && drop_p <= 0.5f && M * (long)hid < 4294967296L, "ff_bwd_fused: drop_p (keep >= 1/2) / dropout index out of range");
-  // one persistent 8-wave workgroup per CU (146 KB of LDS): rows dealt in multiples of the 64-row tile; at least 4 tiles per
+  // one persistent 8-wave workgroup per CU (159 KB of LDS): rows dealt in multiples of the 64-row tile; at least 4 tiles per
   // workgroup so that the 32 768 atomics a workgroup leaves with are amortised
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -504,7 +598,11 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
   rpw = (rpw + 63) / 64 * 64;
   const int nwg = (int)((M + rpw - 1) / rpw);
   FfFusedArgs a{dY, X, stats, gamma, beta, W1, b1, W2T, dR2, dX, dgamma, dbeta, dW1, db1, dW2, db2, M, rpw, drop_p, seed_h, seed_o, alpha,
-                dy_amax, w1_amax, w2t_amax, in_amax, mid_amax, out_amax, ln_sexp, hid_sexp};
+                dy_amax, w1_amax, w2t_amax, in_amax, mid_amax, out_amax, ln_sexp, hid_sexp, 0, nullptr};
+  if (const char* e = getenv("SE_FF_DBG")) a.dbg = atoi(e);
+#ifdef SE_FF_STAMPS
+  a.stamps = g_ff_stamps;
+#endif
   hipLaunchKernelGGL(ff_bwd_fused_kernel, dim3((unsigned)nwg), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_ff_bwd_fused");
 }
