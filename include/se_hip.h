@@ -191,12 +191,14 @@ int se_ff_bwd_rc(const float* dY, const float* X, const float* stats, const floa
    with H, S = Swish(H) Drop_h-mask and dZ recomputed on chip: nothing [M, hid]-sized is read or written (the backward of
    conformer.py:53-71,128-145 behind se_ff_fwd_f16 with H = NULL).  W1 [hid][64], W2T = (alpha W2)^T [hid][64]: scaled fp16 planes
    with their amax scalars; dy_amax = max |dY|; in_amax / mid_amax (may be NULL: the static exponents ln_sexp / hid_sexp) = the
-   proven bounds of |LN(X)| / |Swish(H) mask| the forward scaled its operands with (se_act_bounds); drop_p <= 1/2. */
+   proven bounds of |LN(X)| / |Swish(H) mask| the forward scaled its operands with (se_act_bounds); drop_p <= 1/2.
+   W1T / w1t_amax (may be NULL): W1^T [64][hid] as scaled fp16 planes -- with them the symmetric-wave kernel (se_ff_fused3.hip) runs,
+   without them the specialised-wave kernel of se_ff_fused.hip. */
 int se_ff_bwd_fused(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta, const float* W1,
                     const float* b1, const float* W2T, const float* dR2, float* dX, float* dgamma, float* dbeta, float* dW1,
                     float* db1, float* dW2, float* db2, long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha,
                     const float* dy_amax, const float* w1_amax, const float* w2t_amax, const float* in_amax, int ln_sexp,
-                    const float* mid_amax, int hid_sexp, float* out_amax, void* stream);
+                    const float* mid_amax, int hid_sexp, float* out_amax, const float* W1T, const float* w1t_amax, void* stream);
 
 /* RECOMPUTING weight gradients of the same module (scaled split-fp16 only; hid == 256): dW1 [hid][64] += dZ^T LN(X), db1 += sum dZ,
    dW2 [64][hid] += alpha (Drop_o dY)^T S, db2 (may be NULL) += alpha sum Drop_o dY, with S = Swish(H) Drop_h-mask, H and dZ as in

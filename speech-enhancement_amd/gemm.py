@@ -380,7 +380,7 @@ FF_FUSED = __import__('os').environ.get('SE_FF_FUSED', '1') != '0'
 
 
 def ff_bwd_fused(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2, dgamma, dbeta, drop_p=0.0, seed_h=0, seed_o=0,
-                 alpha=0.5, dR2=None, out_amax=None, in_bound=None, mid_bound=None):
+                 alpha=0.5, dR2=None, out_amax=None, in_bound=None, mid_bound=None, W1T=None):
     """dx = dy + dR2 + LNbwd(dZ W1) and dW1 / db1 / dW2 / db2 / dgamma / dbeta accumulated, from x and dy alone (se_ff_bwd_fused)."""
     L.check_cuda(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2, dgamma, dbeta, dR2)
     dy_amax = getattr(dy, '_se_amax', None)
@@ -393,7 +393,8 @@ def ff_bwd_fused(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2,
            L.ptr(dR2), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), C.c_long(M), C.c_int(hid),
            C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), L.ptr(dy_amax),
            L.ptr(W1._se_amax), L.ptr(W2T_scaled._se_amax), L.ptr(in_bound), C.c_int(LN_SEXP), L.ptr(mid_bound), C.c_int(HID_SEXP),
-           L.ptr(out_amax), L.stream(), _key='ff_bwd_fused_f16x3', _flops=10.0 * M * 64 * hid,
+           L.ptr(out_amax), L.ptr(W1T), L.ptr(W1T._se_amax if W1T is not None else None), L.stream(), _key='ff_bwd_fused_f16x3',
+           _flops=10.0 * M * 64 * hid,
            _bytes=4.0 * M * 64 * (4 if dR2 is not None else 3))
     return dx
 

@@ -522,7 +522,8 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
                                    G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], G[f'{p}.fn.fn.net.3.weight'],
                                    G[f'{p}.fn.fn.net.3.bias'], G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], drop, seed_h, seed_o,
                                    0.5, dR2=dR2, out_amax=_amax(dy.device), in_bound=_bnd(P, ('ln', p), 0).get('a_amax'),
-                                   mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'))
+                                   mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'),
+                                   W1T=_w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: None))
         dx = GM.ff_bwd_rc(dy, x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1p, b1, W2Tp,
                           _w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: None), drop, seed_h, seed_o, dR2,
                           G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], out_amax=_amax(dy.device))

@@ -757,15 +757,18 @@ def test_discriminator_input_gradient_by_parity_class(G, B, Ti, Fi, Cin, N):
     assert relerr(dx, xi.grad.permute(0, 3, 2, 1)) < 3e-6
 
 
+@pytest.mark.parametrize('ver', ['2', '3'])
 @pytest.mark.parametrize('M', [37, 4096 + 37, 70000])
-def test_feed_forward_fused_backward(M):
+def test_feed_forward_fused_backward(M, ver, monkeypatch):
     """se_ff_bwd_fused (csrc/se_ff_fused.hip): ONE persistent launch for dX, dgamma / dbeta and dW1 / db1 / dW2 / db2 of the module, H,
     S and dZ recomputed on chip -- against the stored-H kernels (ff_bwd_dgrad + the fp32-MFMA whole-gradient kernels on the stored
     H / dZ) and, without dropout, against fp64; with and without dropout (the same counter-based masks), with and without the
     second residual, accumulating into non-zero gradient buffers; row counts: less than one tile, a ragged last workgroup, many
-    workgroups."""
+    workgroups.  ver 2: the specialised-wave kernel (se_ff_fused.hip, the default); ver 3: the symmetric-wave kernel (se_ff_fused3.hip,
+    SE_FF_FUSED_V=3: correct, slower)."""
     from speech_enhancement_amd import gemm as GM, _lib as L, ops as O
     from speech_enhancement_amd.weights import WeightPlan
+    monkeypatch.setenv('SE_FF_FUSED_V', ver)
     dev = torch.device('cuda')
     torch.manual_seed(M)
     x = torch.randn(M, 64, device=dev)
@@ -797,7 +800,7 @@ def test_feed_forward_fused_backward(M):
         init = [torch.randn(s, device=dev) * 1e-2 for s in ((256, 64), (256,), (64, 256), (64,), (64,), (64,))]
         dW1b, db1b, dW2b, db2b, dg1, db1_ = [t.clone() for t in init]
         dx1 = GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], dW1b, db1b, dW2b, db2b, dg1, db1_, drop, 11, 12, 0.5,
-                              dR2=dR2, out_amax=torch.zeros(1, device=dev))
+                              dR2=dR2, out_amax=torch.zeros(1, device=dev), W1T=p.out['w1t'])
         torch.cuda.synchronize()
         assert torch.isfinite(dx1).all()
         assert rel(dx1, dx0) < 2e-6, ('dX', rel(dx1, dx0))

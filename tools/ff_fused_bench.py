@@ -17,7 +17,7 @@ g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
 W1, b1 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
 W2 = torch.randn(64, 256, device=dev) * 0.1
 p = WeightPlan(dev)
-p.linear('w1', W1, planes='f16'); p.linear_T('w2t', W2, planes='f16', scale=0.5)
+p.linear('w1', W1, planes='f16'); p.linear_T('w2t', W2, planes='f16', scale=0.5); p.linear_T('w1t', W1, planes='f16')
 p.run()
 dy = torch.randn(M, 64, device=dev) * 1e-3
 dy._se_amax = dy.abs().max().reshape(1).clone()
@@ -28,11 +28,11 @@ am = torch.zeros(1, device=dev)
 
 def run(n=6, drop=0.2):
     for _ in range(2):
-        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
+        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am, W1T=p.out['w1t'])
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(n):
-        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
+        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am, W1T=p.out['w1t'])
     torch.cuda.synchronize()
     return (time.time() - t0) / n * 1e6
 

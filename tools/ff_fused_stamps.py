@@ -16,14 +16,14 @@ x = torch.randn(M, 64, device=dev); st = O.row_stats(x, M)
 g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
 W1, b1 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
 W2 = torch.randn(64, 256, device=dev) * 0.1
-p = WeightPlan(dev); p.linear('w1', W1, planes='f16'); p.linear_T('w2t', W2, planes='f16', scale=0.5); p.run()
+p = WeightPlan(dev); p.linear('w1', W1, planes='f16'); p.linear_T('w2t', W2, planes='f16', scale=0.5); p.linear_T('w1t', W1, planes='f16'); p.run()
 dy = torch.randn(M, 64, device=dev) * 1e-3; dy._se_amax = dy.abs().max().reshape(1).clone()
 dR2 = torch.randn(M, 64, device=dev) * 1e-3
 gr = [torch.zeros(s, device=dev) for s in ((256, 64), (256,), (64, 256), (64,), (64,), (64,))]
 stamps = torch.zeros(4 * 8 * 8 * 10, device=dev, dtype=torch.int32)
 L.lib().se_ff_fused_debug_stamps(C.c_void_p(stamps.data_ptr()))
 for _ in range(3):
-    GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, 0.2, 11, 12, 0.5, dR2=dR2, out_amax=torch.zeros(1, device=dev))
+    GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, 0.2, 11, 12, 0.5, dR2=dR2, out_amax=torch.zeros(1, device=dev), W1T=p.out['w1t'])
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.uint32).reshape(4, 8, 8, 10).astype(np.int64)
 names = ['p', 'a0', 'b0', 'a1', 'b1', 'a2', 'b2', 'a3', 'b3', 'c']
