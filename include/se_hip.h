@@ -223,6 +223,16 @@ int se_gemm_ln_bwd_f16(const float* A, const float* W, int w_planes, long M, int
                        const float* gamma, const float* dR, float* dX, float* dgamma, float* dbeta, int precision,
                        const float* a_amax, const float* w_amax, float* out_amax, void* stream);
 
+/* se_gemm_ln_bwd_f16 AND the weight gradient of the same layer in one sweep (scaled split-fp16 only; K = 192: the qkv projection,
+   K = 256: the pointwise-GLU convolution -- models/conformer.py:87-89, 160-164 backwards; csrc/se_lnbwd_fused.hip):
+     dX = dR + LNbwd(A WT^T) (dgamma / dbeta accumulated; out_amax, may be NULL, raised to max |dX|),
+     dW [K][64] += A^T LN(X), dbias [K] (may be NULL) += column sums of A.
+   A [M][K] fp32 with a_amax = max |A| (device scalar); WT = W^T [64][K] as scaled fp16 planes with w_amax; in_amax (may be NULL:
+   ln_sexp) = the proven bound of |LN(X)|; dR may be NULL. */
+int se_gemm_ln_bwd_wgrad(const float* A, const float* WT, long M, int K, const float* X, const float* stats, const float* gamma,
+                         const float* beta, const float* dR, float* dX, float* dgamma, float* dbeta, float* dW, float* dbias,
+                         const float* a_amax, const float* w_amax, const float* in_amax, int ln_sexp, float* out_amax, void* stream);
+
 /* weight gradient: dW[n][tap*C + c] += alpha * sum_m dY[m][n] * pro(A[src(m,tap)][c]) (alpha = d->alpha: the factor of a
  * Scale(0.5, .) wrapper goes straight into the gradient buffer);  dW must be initialised by the caller (fp32 atomics across
  * row chunks).  If dbias != NULL also dbias[n] += alpha * sum_m dY[m][n].

@@ -266,6 +266,28 @@ def gemm_ln_bwd(A, WT, x, stats, gamma, dR, dgamma, dbeta, out_amax=None):
     return dX
 
 
+# the LayerNorm-backward GEMM and the weight gradient of the same layer in one sweep over the rows (csrc/se_lnbwd_fused.hip);
+# SE_LNBWD_FUSED=0: two launches again (se_gemm_ln_bwd_f16 + se_gemm_tap_wgrad on the weight-gradient stream)
+LNBWD_FUSED = __import__('os').environ.get('SE_LNBWD_FUSED', '1') != '0'
+
+
+def gemm_ln_bwd_wgrad(A, WT, x, stats, gamma, beta, dR, dgamma, dbeta, dW, dbias=None, out_amax=None, in_bound=None):
+    """dX = dR + LayerNorm-backward(A @ WT.T) and dW [K, 64] += A^T LN(x), dbias [K] += sum A in ONE launch (se_gemm_ln_bwd_wgrad):
+    A [M, K] with A._se_amax, WT [2, 64, K] scaled fp16 planes, K in (192, 256)."""
+    L.check_cuda(A, WT, x, stats, gamma, beta, dR, dgamma, dbeta, dW, dbias)
+    M, K = A.shape
+    a_amax = getattr(A, '_se_amax', None)
+    if WT.dtype != torch.float16 or a_amax is None or K not in (192, 256):
+        raise L.SeHipError('gemm_ln_bwd_wgrad: needs scaled fp16 weight planes, the measured maximum of A and K in (192, 256)')
+    dX = torch.empty(M, 64, device=A.device, dtype=torch.float32)
+    dX._se_amax = out_amax
+    L.call('se_gemm_ln_bwd_wgrad', L.ptr(A), L.ptr(WT), C.c_long(M), C.c_int(K), L.ptr(x), L.ptr(stats), L.ptr(gamma), L.ptr(beta),
+           L.ptr(dR), L.ptr(dX), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dW), L.ptr(dbias), L.ptr(a_amax), L.ptr(WT._se_amax),
+           L.ptr(in_bound), C.c_int(LN_SEXP), L.ptr(out_amax), L.stream(), _key='lnbwd_wgrad_fused_f16x3', _flops=4.0 * M * 64 * K,
+           _bytes=4.0 * M * (K + 192))
+    return dX
+
+
 def repack(src, No, Nt, Ni, so, stt, si, rev=0, out=None, accumulate=False):
     """dst[o][t][i] = src[o*so + i*si + t*stt]."""
     if out is None:

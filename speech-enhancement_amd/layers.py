@@ -701,13 +701,20 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     if not FUSE_GLU_BWD:
         dzc = O.glu_bwd_gate(u, zc, du, M, 128, amax=_amax(dev))
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)
-    with GM.leaf_stream(y2, dzc, st3, dzc._se_amax):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, w_amax=dzc._se_amax, **_bnd(P, ('ln', f'{p}.conv'), GM.LN_SEXP)), y2, dzc,
-                          G[f'{p}.conv.net.2.weight'].view(256, 64),
-                          G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
-                          pb=P[f'{p}.conv.net.0.bias'])
     Wpw1T = _w(P, (f'{p}.conv.net.2.weight', 'T'), lambda: _T(Wpw1))
-    if FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
+    fused_pw1 = GM.LNBWD_FUSED and FUSE_LN_BWD and Wpw1T.dtype == torch.float16 and getattr(dzc, '_se_amax', None) is not None
+    if not fused_pw1:
+        with GM.leaf_stream(y2, dzc, st3, dzc._se_amax):
+            GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, w_amax=dzc._se_amax, **_bnd(P, ('ln', f'{p}.conv'), GM.LN_SEXP)), y2, dzc,
+                              G[f'{p}.conv.net.2.weight'].view(256, 64),
+                              G[f'{p}.conv.net.2.bias'], rowstats=st3, ps=P[f'{p}.conv.net.0.weight'],
+                              pb=P[f'{p}.conv.net.0.bias'])
+    if fused_pw1:
+        # ONE sweep over the rows for the input gradient, the LayerNorm backward and the weight / bias gradient (se_lnbwd_fused.hip)
+        dy2 = GM.gemm_ln_bwd_wgrad(dzc, Wpw1T, y2, st3, P[f'{p}.conv.net.0.weight'], P[f'{p}.conv.net.0.bias'], dy3,
+                                   G[f'{p}.conv.net.0.weight'], G[f'{p}.conv.net.0.bias'], G[f'{p}.conv.net.2.weight'].view(256, 64),
+                                   G[f'{p}.conv.net.2.bias'], out_amax=_amax(dev), in_bound=_bnd(P, ('ln', f'{p}.conv'), 0).get('a_amax'))
+    elif FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
         # input-gradient GEMM + the LayerNorm backward on its accumulators: the [M, 64] product never goes to memory
         dy2 = GM.gemm_ln_bwd(dzc, Wpw1T, y2, st3, P[f'{p}.conv.net.0.weight'], dy3, G[f'{p}.conv.net.0.weight'],
                              G[f'{p}.conv.net.0.bias'], out_amax=_amax(dev))
@@ -751,13 +758,23 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     adjacent = gq.is_contiguous() and gkv.is_contiguous() and gq.data_ptr() + gq.numel() * 4 == gkv.data_ptr()
     dWqkv = torch.as_strided(gq, (192, 64), (64, 1)) if adjacent and gq.untyped_storage().nbytes() - gq.storage_offset() * 4 >= 192 * 64 * 4 \
         else O.zeros(192, 64, device=dev)
-    with GM.leaf_stream(y1, dqkv, st2, dq_amax):
-        GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, w_amax=dq_amax, **_bnd(P, ('ln', f'{p}.attn'), GM.LN_SEXP)), y1, dqkv, dWqkv, None,
-                          rowstats=st2, ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
+    fused_qkv = GM.LNBWD_FUSED and FUSE_LN_BWD and WqkvT.dtype == torch.float16 and dq_amax is not None
+    if not fused_qkv:
+        with GM.leaf_stream(y1, dqkv, st2, dq_amax):
+            GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 192, prologue=L.PRO_LN, w_amax=dq_amax, **_bnd(P, ('ln', f'{p}.attn'), GM.LN_SEXP)), y1, dqkv, dWqkv, None,
+                              rowstats=st2, ps=P[f'{p}.attn.norm.weight'], pb=P[f'{p}.attn.norm.bias'])
+            if dWqkv.data_ptr() != gq.data_ptr():
+                gq += dWqkv[:64]
+                gkv += dWqkv[64:]
+    if fused_qkv:
+        # (its OUTPUT dy1 feeds the scaled-fp16 feed-forward backward -> max |dy1|)
+        dy1 = GM.gemm_ln_bwd_wgrad(dqkv, WqkvT, y1, st2, P[f'{p}.attn.norm.weight'], P[f'{p}.attn.norm.bias'], dy2,
+                                   G[f'{p}.attn.norm.weight'], G[f'{p}.attn.norm.bias'], dWqkv, None, out_amax=_amax(dev),
+                                   in_bound=_bnd(P, ('ln', f'{p}.attn'), 0).get('a_amax'))
         if dWqkv.data_ptr() != gq.data_ptr():
             gq += dWqkv[:64]
             gkv += dWqkv[64:]
-    if FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
+    elif FUSE_LN_BWD and GM.LINEAR_PRECISION in (2, 3):
         # (its OUTPUT dy1 feeds the scaled-fp16 feed-forward backward -> max |dy1|)
         dy1 = GM.gemm_ln_bwd(dqkv, WqkvT, y1, st2, P[f'{p}.attn.norm.weight'], dy2, G[f'{p}.attn.norm.weight'],
                              G[f'{p}.attn.norm.bias'], out_amax=_amax(dev))

@@ -816,3 +816,48 @@ def test_feed_forward_fused_backward(M, ver, monkeypatch):
             dz64 = (dy.double() @ (0.5 * W2.double())) * (sg * (1 + h64 * (1 - sg)))
             assert rel(dW1b - init[0], dz64.t() @ xl) < 2e-6 and rel(dW2b - init[2], 0.5 * dy.double().t() @ (h64 * sg)) < 2e-6
             assert rel(db1b - init[1], dz64.sum(0)) < 2e-6 and rel(db2b - init[3], 0.5 * dy.double().sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize('K', [192, 256])
+@pytest.mark.parametrize('M', [21, 4096 + 37, 60001])
+def test_ln_bwd_gemm_with_weight_gradient_in_one_sweep(M, K):
+    """se_gemm_ln_bwd_wgrad (csrc/se_lnbwd_fused.hip): dX = dR + LNbwd(A W), dgamma / dbeta AND dW [K, 64] += A^T LN(x), db += sum A from
+    ONE pass over A and x -- against se_gemm_ln_bwd_f16 + the fp32-MFMA weight-gradient kernel and against fp64; K = 192 (qkv: no bias,
+    no ... ) and 256 (pointwise-GLU: bias); row counts below one tile, ragged, many workgroups; accumulating into non-zero buffers."""
+    from speech_enhancement_amd import gemm as GM, _lib as L, ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    dev = torch.device('cuda')
+    torch.manual_seed(M + K)
+    x = torch.randn(M, 64, device=dev) * 2 + 0.3
+    st = O.row_stats(x, M)
+    g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    W = torch.randn(K, 64, device=dev) * 0.1                     # y = LN(x) W^T
+    A = torch.randn(M, K, device=dev) * 1e-3
+    A._se_amax = A.abs().max().reshape(1).clone()
+    dR = torch.randn(M, 64, device=dev) * 1e-3 if K == 256 else None
+    plan = WeightPlan(dev)
+    WT = plan.linear_T('wt', W, planes='f16')                    # [2][64][K]
+    plan.run()
+    rel = lambda a_, r_: float((a_.double() - r_.double()).abs().max() / r_.double().abs().max())
+    dg0, db0 = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    dx0 = GM.gemm_ln_bwd(A, WT, x, st, g, dR, dg0, db0, out_amax=torch.zeros(1, device=dev))
+    dW0, dbias0 = torch.zeros(K, 64, device=dev), torch.zeros(K, device=dev)
+    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, K, prologue=L.PRO_LN, precision=0), x, A, dW0, dbias0, rowstats=st, ps=g, pb=b,
+                      explicit_precision=True)
+    init = [torch.randn(s, device=dev) * 1e-2 for s in ((64,), (64,), (K, 64), (K,))]
+    dg1, db1, dW1, dbias1 = [t.clone() for t in init]
+    dx1 = GM.gemm_ln_bwd_wgrad(A, WT, x, st, g, b, dR, dg1, db1, dW1, dbias1 if K == 256 else None, out_amax=torch.zeros(1, device=dev))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx1).all()
+    assert rel(dx1, dx0) < 2e-6, ('dX', rel(dx1, dx0))
+    assert abs(float(dx1._se_amax) - float(dx1.abs().max())) <= 1e-6 * float(dx1.abs().max())
+    checks = [('dgamma', dg1, init[0], dg0), ('dbeta', db1, init[1], db0), ('dW', dW1, init[2], dW0)]
+    if K == 256:
+        checks.append(('dbias', dbias1, init[3], dbias0))
+    for name, got, ini, ref in checks:
+        e = rel(got - ini, ref)
+        assert e < 4e-6 + 2e-7 * float(ini.abs().max() / ref.abs().max()), (name, e, M, K)
+    xl = ((x.double() - st[:, :1].double()) * st[:, 1:].double()) * g.double() + b.double()
+    assert rel(dW1 - init[2], A.double().t() @ xl) < 2e-6
+    if K == 256:
+        assert rel(dbias1 - init[3], A.double().sum(0)) < 2e-6
