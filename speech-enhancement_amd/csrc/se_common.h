@@ -89,6 +89,10 @@ static __device__ __forceinline__ float4 buf_load4_(__amdgpu_buffer_rsrc_t r, un
   typedef unsigned u32x4b_ __attribute__((ext_vector_type(4)));
   return __builtin_bit_cast(float4, (u32x4b_)__builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
+static __device__ __forceinline__ float2 buf_load2_(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  typedef unsigned u32x2b_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(float2, (u32x2b_)__builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
 static __device__ __forceinline__ void buf_store4_(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float4 v) {
   typedef unsigned u32x4b_ __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b_, v), r, byte_off, 0, 0);

@@ -349,8 +349,7 @@ static __device__ __forceinline__ void ff_fused_W(const FfFusedArgs& a, unsigned
     const long avail = a.M - m0 < 64 ? a.M - m0 : 64;
     const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X + m0 * 64, (unsigned)(avail * 256)), Yr = make_rsrc_(a.dY + m0 * 64, (unsigned)(avail * 256));
     const __amdgpu_buffer_rsrc_t Sr = make_rsrc_(a.stats + m0 * 2, (unsigned)(avail * 8));
-    const float4 s4 = buf_load4_(Sr, (unsigned)((prow & ~1) * 8));            // (mean, rstd) of rows prow & ~1 and that + 1: 16-byte aligned
-    rst = (prow & 1) ? make_float2(s4.z, s4.w) : make_float2(s4.x, s4.y);
+    rst = buf_load2_(Sr, (unsigned)(prow * 8));
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll

@@ -118,8 +118,7 @@ __global__ __launch_bounds__(512, 2) void ff_bwd_fused3_kernel(FfFusedArgs a) {
     const __amdgpu_buffer_rsrc_t Sr = make_rsrc_(a.stats + m0 * 2, avail > 0 ? (unsigned)(avail * 8) : 0u);
     raw0 = buf_load4_(Rr, (unsigned)(prow * 256 + poct * 32));
     raw1 = buf_load4_(Rr, (unsigned)(prow * 256 + poct * 32 + 16));
-    const float4 s4 = buf_load4_(Sr, (unsigned)((prow & ~1) * 8));
-    rst = (prow & 1) ? make_float2(s4.z, s4.w) : make_float2(s4.x, s4.y);
+    rst = buf_load2_(Sr, (unsigned)(prow * 8));
   };
   auto prologue_store = [&](long m0) {
     const long m = m0 + prow;
@@ -257,8 +256,7 @@ __global__ __launch_bounds__(512, 2) void ff_bwd_fused3_kernel(FfFusedArgs a) {
       const __amdgpu_buffer_rsrc_t Sr = make_rsrc_(a.stats + m0 * 2, (unsigned)(avail * 8));
       ex = buf_load4_(Xr, eo); ey = buf_load4_(Yr, eo);
       if (a.dR2) er2 = buf_load4_(make_rsrc_(a.dR2 + m0 * 64, (unsigned)(avail * 256)), eo);
-      const float4 s4 = buf_load4_(Sr, (unsigned)(((4 * wave + err) & ~1) * 8));
-      est = (err & 1) ? make_float2(s4.z, s4.w) : make_float2(s4.x, s4.y);
+      est = buf_load2_(Sr, (unsigned)((4 * wave + err) * 8));
     }
     if (more) load_raw(m0 + 32);
     // ---- dLN[32 rows x channels 32 ch ..] over the hidden units 64 kq .. 64 kq + 63 ----

@@ -86,10 +86,15 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     for (int e = 0; e < 16; ++e) aw[nt][e] = 0.f;
   float bsum = 0.f, agk = 0.f, abk = 0.f, xmax = 0.f;
 
-  float4 pa[NA], px, pr = make_float4(0.f, 0.f, 0.f, 0.f);      // the tile being staged / the next tile's rows
-  float2 pst;
+  // rows in flight: TWO tiles ahead (one tile of products + epilogue, ~4 000 cycles, is shorter than the memory latency under load: with
+  // one tile in flight the launch ran at 3.1 TB/s of its 0.93 GB) -- buffer (tile & 1); 52 registers per lane, 116 KB per CU
+  float4 pa2[2][NA], px2[2], pr2[2];
+  float2 pst2[2];
+  pr2[0] = pr2[1] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 kx, kr; float2 kst;                                      // kept for the epilogue of the tile in the images
-  auto load_rows = [&](long m0) {
+  auto load_rows = [&](long m0, auto bufc) {
+    constexpr int bf = decltype(bufc)::value;
+    float4 (&pa)[NA] = pa2[bf]; float4& px = px2[bf]; float4& pr = pr2[bf];
     const long avail = a.M - m0 < 32 ? a.M - m0 : 32;
     const __amdgpu_buffer_rsrc_t Ar = make_rsrc_(a.A + m0 * K, avail > 0 ? (unsigned)(avail * K * 4) : 0u);
     const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X + m0 * 64, avail > 0 ? (unsigned)(avail * 256) : 0u);
@@ -98,10 +103,12 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     for (int i = 0; i < NA; ++i) pa[i] = buf_load4_(Ar, (unsigned)(srow * K * 4 + (scq + 16 * i) * 16));
     px = buf_load4_(Xr, (unsigned)(srow * 256 + scq * 16));
     if (a.dR) pr = buf_load4_(make_rsrc_(a.dR + m0 * 64, avail > 0 ? (unsigned)(avail * 256) : 0u), (unsigned)(srow * 256 + scq * 16));
-    const float4 s4 = buf_load4_(Sr, (unsigned)((srow & ~1) * 8));
-    pst = (srow & 1) ? make_float2(s4.z, s4.w) : make_float2(s4.x, s4.y);
+    pst2[bf] = buf_load2_(Sr, (unsigned)(srow * 8));
   };
-  auto stage = [&](long m0) {
+  auto stage = [&](long m0, auto bufc) {
+    constexpr int bf = decltype(bufc)::value;
+    float4 (&pa)[NA] = pa2[bf]; float4& px = px2[bf]; float4& pr = pr2[bf];
+    const float2 pst = pst2[bf];
     const bool ok = m0 + srow < mend;                    // (rows past M arrive as zeros from the range check; rows past mend are zeroed here)
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -123,15 +130,18 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     kx = px; kr = pr; kst = pst;
   };
 
-  load_rows(mbeg);
+  using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+  load_rows(mbeg, B0{});
+  if (ntile > 1) load_rows(mbeg + 32, B1{});
   __syncthreads();                                       // gamma / beta, weight planes
-  stage(mbeg);
+  stage(mbeg, B0{});
   __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
+  auto tile = [&](int t, auto bufc) {                    // bufc = t & 1: the buffer this tile was staged from
+    constexpr int bf = decltype(bufc)::value;
     const long m0 = mbeg + 32L * t;
     const bool more = t + 1 < ntile;
     // ===================================== products =====================================
-    if (more) load_rows(m0 + 32);
+    if (t + 2 < ntile) load_rows(m0 + 64, bufc);          // (this tile's buffer is free: staged before the previous barrier)
     if (wg_on) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -201,8 +211,12 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
         abk += (srow & 3) == e ? sb : 0.f;
       }
     }
-    if (more) stage(m0 + 32);
+    if (more) stage(m0 + 32, std::integral_constant<int, 1 - bf>{});
     __syncthreads();
+  };
+  for (int t = 0; t < ntile; t += 2) {
+    tile(t, B0{});
+    if (t + 1 < ntile) tile(t + 1, B1{});
   }
   if (a.out_amax) {
     xmax = wave_max(xmax);

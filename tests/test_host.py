@@ -281,6 +281,7 @@ _SCRATCH_ALLOWED = [
     r'^void attn_bwd3_kernel<\d+, (true|false), false, false>\(',   # three-way bf16 attention backward (SE_ATTN_PRECISION=bf16x6 / no scales)
     r'^void ff_(fwd|bwd)_kernel<\d+, (true|false), \d+, false(, true)?>\(',   # bf16 feed-forward forms (CDiffuSE-era precision 1 / 2)
     r'^void wgrad_lin_kernel<1, 1, 2, 2>\(',                     # fp32 whole-gradient shape 3 (SE_WGRAD_LIN_ALL only)
+    r'^ff_bwd_fused3_kernel\(',                                 # symmetric-wave fused FF backward: opt-in (SE_FF_FUSED_V=3), measured slower
 ]
 
 
