@@ -635,6 +635,11 @@ static __device__ __forceinline__ int operand_sexp_(const float* amax, int sexp)
   return amax ? f16_sexp_(__builtin_nontemporal_load(amax)) : sexp;
 }
 static __device__ __forceinline__ void split_store_h(float4 v, float s, __bf16* p, int plane_stride) {
+#ifdef SE_ABL_NOSPLIT      // timing ablation (fp16-accurate results only): HALF of the split's instructions (no lo plane: 6 of 12 per 4 values)
+  *reinterpret_cast<u32x2_*>(p) = (u32x2_){pk_f16_(v.x * s, v.y * s), pk_f16_(v.z * s, v.w * s)};
+  *reinterpret_cast<u32x2_*>(p + plane_stride) = (u32x2_){0u, 0u};
+  return;
+#endif
   float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
   const unsigned a = pk_f16_(x0, x1), b = pk_f16_(x2, x3);
   *reinterpret_cast<u32x2_*>(p) = (u32x2_){a, b};
