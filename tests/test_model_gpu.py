@@ -578,6 +578,86 @@ def test_frontend_public_api(S, golden, golden2):
         S.uncompressed_istft(s, 400, 100, torch.ones(400, device='cuda'))
 
 
+def _discriminator_grads_fp64(Or, clean_mag, est_mag, q_est, flips=None, rec=None):
+    """fp64 gradients of L_C + L_E (cmgan; core/function.py:286-310) on GIVEN magnitudes [B,1,F,T] (the oracle's discriminator,
+    oracle/se_oracle.py:312-331, restated with its PReLU decisions exposed), spectral-norm vectors advanced like the step does:
+    generator-pass forward, then D(clean, est) ('gx'), then D(clean, clean) ('yy').  `rec[(tag, stage)]` receives the PReLU
+    pre-activations; `flips` = {(tag, stage): [flat indices]} takes the OTHER slope at those entries (a pre-activation within
+    rounding distance of zero may legitimately land on either side in fp32)."""
+    import torch.nn.functional as F
+    sd = {k: (v.double().clone().requires_grad_(not k.endswith(('_u', '_v'))) if v.is_floating_point() else v)
+          for k, v in formula.formula_state('discriminator').items()}
+    sn = {}
+
+    def fwd(x, y, tag):
+        h = torch.cat([x, y], dim=1)
+        for si, li in enumerate((0, 3, 6, 9)):
+            W = Or.spectral_weight(sd, f'layers.{li}', True, sn)
+            h = F.conv2d(h, W, None, stride=2, padding=1)
+            m = h.mean(dim=(2, 3), keepdim=True)
+            v = ((h - m) ** 2).mean(dim=(2, 3), keepdim=True)
+            g, b, a = sd[f'layers.{li+1}.weight'], sd[f'layers.{li+1}.bias'], sd[f'layers.{li+2}.weight']
+            yv = (h - m) / torch.sqrt(v + Or.EPS_NORM) * g[None, :, None, None] + b[None, :, None, None]
+            pos = yv >= 0
+            if rec is not None:
+                rec[(tag, si)] = yv.detach()
+            if flips and (tag, si) in flips:
+                pos = pos.clone()
+                pos.view(-1)[torch.tensor(flips[(tag, si)])] ^= True
+            h = torch.where(pos, yv, yv * a[None, :, None, None])
+        h = h.amax(dim=(2, 3))
+        W = Or.spectral_weight(sd, 'layers.14', True, sn)
+        h = h @ W.T + sd['layers.14.bias']
+        a = sd['layers.16.weight']
+        h = torch.where(h >= 0, h, h * a[None, :])
+        W = Or.spectral_weight(sd, 'layers.17', True, sn)
+        h = h @ W.T + sd['layers.17.bias']
+        return torch.sigmoid(sd['layers.18.slope'] * h)
+
+    with torch.no_grad():
+        fwd(clean_mag, est_mag, 'gen')
+    sd.update(sn)
+    d_gx = fwd(clean_mag, est_mag, 'gx')
+    sd.update(sn)
+    d_yy = fwd(clean_mag, clean_mag, 'yy')
+    loss = Or._mse(d_yy.flatten(), torch.ones_like(q_est)) + Or._mse(d_gx.flatten(), q_est)
+    names = [k for k, v in sd.items() if torch.is_tensor(v) and v.requires_grad]
+    gr = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+    return {k: gi.detach() for k, gi in zip(names, gr) if gi is not None}
+
+
+def _explain_by_prelu_kinks(Or, clean_mag, est_mag, q_est, ours, d64, rec, names, tau=1e-4, cap=128):
+    """The discriminator gradient is piecewise smooth in its inputs: at a PReLU pre-activation of (numerically) zero either slope is
+    a legitimate fp32 outcome.  Candidates = the pre-activations of the two differentiated forwards with |y| < tau (y is an
+    InstanceNorm output: O(1)), at most `cap`; for each one the fp64 gradient with THAT decision flipped; the residual ours - fp64 is
+    fitted with 0/1 coefficients on the shifts that carry weight (> 2e-5 of the gradient).  Returns (per-tensor relative residual after the fit, chosen candidates)."""
+    cands = []
+    for key, yv in rec.items():
+        if key[0] == 'gen':
+            continue
+        fl = yv.flatten().abs()
+        for idx in torch.nonzero(fl < tau).flatten().tolist():
+            cands.append((float(fl[idx]), key, idx))
+    cands = sorted(cands)[:cap]
+    nrm = {k: float(d64[k].norm()) + 1e-30 for k in names}
+    vec = lambda gdict: torch.cat([((gdict[k].double().cpu() - d64[k]) / nrm[k]).flatten() for k in names])
+    r = vec(ours)
+    if not cands:
+        return {k: float((ours[k].double().cpu() - d64[k]).norm()) / nrm[k] for k in names}, []
+    cols = [vec(_discriminator_grads_fp64(Or, clean_mag, est_mag, q_est, flips={key: [idx]})) for _, key, idx in cands]
+    big = [i for i, col in enumerate(cols) if float(col.norm()) > 2e-5]      # most decisions carry no weight: not fitted
+    pick = []
+    if big:
+        c = torch.linalg.lstsq(torch.stack([cols[i] for i in big], 1), r[:, None]).solution[:, 0]
+        pick = [i for i, ci in zip(big, c.tolist()) if ci > 0.5]
+    flips = {}
+    for i in pick:
+        flips.setdefault(cands[i][1], []).append(cands[i][2])
+    g_fit = _discriminator_grads_fp64(Or, clean_mag, est_mag, q_est, flips=flips) if pick else d64
+    res = {k: float((ours[k].double().cpu() - g_fit[k]).norm()) / nrm[k] for k in names}
+    return res, [(cands[i][1], cands[i][2], cands[i][0]) for i in pick]
+
+
 def test_full_size_train_step_vs_reference(S, golden2, golden4):
     """ONE FULL-SIZE train_gan step of the reference (cmgan, nesterov-SGD, B=2, L=32 000 -> T=321, fp64 golden) vs gan_step:
     the first end-to-end comparison at the benchmark's geometry -- attn_bwd2_kernel<336,8,false>, the triple-tap
@@ -595,8 +675,18 @@ def test_full_size_train_step_vs_reference(S, golden2, golden4):
     for o in (og, od):
         for grp in o.param_groups:
             grp['lr'] = lr
-    out = TR.gan_step(g, d, og, od, clean.cuda(), noisy.cuda(), 'cmgan', (0.1, 0.9, 0.2, 0.05),
-                      labels={'est': torch.tensor([0.35, 0.62], device='cuda')})
+    seen, orig_update = {}, TR._discriminator_update
+
+    def spy(discriminator, optimizer_disc, est_d, clean_pl, *a, **k):
+        seen['est'], seen['clean'] = est_d[..., 0].detach().clone(), clean_pl[..., 0].detach().clone()   # [B, T, F] magnitudes
+        return orig_update(discriminator, optimizer_disc, est_d, clean_pl, *a, **k)
+    TR._discriminator_update = spy
+    try:
+        out = TR.gan_step(g, d, og, od, clean.cuda(), noisy.cuda(), 'cmgan', (0.1, 0.9, 0.2, 0.05),
+                          labels={'est': torch.tensor([0.35, 0.62], device='cuda')})
+    finally:
+        TR._discriminator_update = orig_update
+    torch.cuda.synchronize()
     mse = golden2['full_step_mse_calls']
     errs = {}
     for k, b in (('loss_mag', mse[0]), ('loss_ri', mse[1] + mse[2]), ('gan', mse[3]), ('L_E', mse[4]), ('L_C', mse[5]),
@@ -612,19 +702,44 @@ def test_full_size_train_step_vs_reference(S, golden2, golden4):
     assert rms(gs['TSCB_1.time_conformer.conv.net.5.running_var'], golden2['full_step_bn_rv']) < 1e-5
     grads = {('g', k): p.grad for k, p in g.named_parameters()}
     grads.update({('d', k): p.grad for k, p in d.named_parameters()})
+    # the fp64 discriminator gradients on exactly the enhanced magnitude the HIP generator produced (its distance from the reference's
+    # forward is bounded by test_full_size_enhanced_magnitude: 1.4e-5 RMS)
+    est_ours = seen['est'].double().cpu().transpose(1, 2)[:, None]
+    clean_ours = seen['clean'].double().cpu().transpose(1, 2)[:, None]
+    q64 = torch.tensor([0.35, 0.62], dtype=torch.float64)
+    rec = {}
+    d64 = _discriminator_grads_fp64(Or, clean_ours, est_ours, q64, rec=rec)
+    dnames = [k.split(':', 1)[1] for k in golden2.files if k.startswith('full_step_dupd:')]
+    kink_res, kinks = _explain_by_prelu_kinks(Or, clean_ours, est_ours, q64, {n: grads[('d', n)] for n in dnames}, d64, rec, dnames)
+    print('discriminator gradients on identical inputs: fp64 with the slope flipped at', kinks, '-> residuals', kink_res)
     for k in golden2.files:
         if k.startswith('full_step_gupd:') or k.startswith('full_step_dupd:'):
             name = k.split(':', 1)[1]
             ref = golden2[k].astype(np.float64) / (-lr * 1.9)
             nrm = np.sqrt(np.mean(ref ** 2)) + 1e-30
             e = rms(grads[('g' if 'gupd' in k else 'd', name)], ref) / nrm
-            # calibrated bar (round 4): 2e-4 + 2 x the spread of the REFERENCE's own fp32 run of this step against its fp64 run
+            # calibrated bar: 2e-4 + 1.5 x the spread of the REFERENCE's own fp32 run of this step against its fp64 run
             # (golden_v4: 3e-3 .. 1e-2 on the interior tensors: the fp32 floor through 16 InstanceNorms and 8 Conformers)
             spread = rms(golden4['full32_step_' + k[len('full_step_'):]].astype(np.float64) / (-lr * 1.9), ref) / nrm
+            if 'dupd' in k:
+                # Discriminator tensors, round 5 (root cause of the round-4 exception for its first convolution: tests/diag_d_first_conv.py,
+                # profiles/r05_d_first_conv_rootcause.txt): their gradient is a DISCONTINUOUS function of the enhanced magnitude and of
+                # the discriminator's own rounding -- on this seed ONE stage-1 PReLU pre-activation (of 2.6 M) lies within 1e-6 of zero
+                # and carries a large back-propagated weight: either slope is a legitimate fp32 outcome and moves layers.0.weight_orig
+                # by a fixed 1.18e-3 (exactly the reference's own fp32-vs-fp64 spread; a second crossing: 1.64e-3).  So the
+                # discriminator's arithmetic is compared on IDENTICAL inputs and decisions: the fp64 gradient on the enhanced magnitude
+                # THIS run produced, with the slope choice at the pre-activations of |y| < 1e-4 fitted (0/1) -- bar 2e-4, tighter than
+                # any spread.  What remains against the golden (fp64 on our magnitude vs fp64 on the reference's, `e_input`) is a
+                # property of the reference's function at two inputs 1.4e-5 apart.
+                e_same = kink_res[name]
+                e_nofit = rms(grads[('d', name)], d64[name]) / nrm
+                e_input = float(np.sqrt(np.mean((d64[name].double().numpy() - ref) ** 2))) / nrm
+                errs[name] = (e, spread, e_same, e_nofit, e_input)
+                assert e_same < 2e-4, (k, e_same, e_nofit, kinks)
+                assert e < 2e-4 + 3.0 * spread, (k, e, spread, e_nofit, e_input)      # sanity cap only: the parity statement is e_same
+                continue
             errs[name] = (e, spread)
-            # (the tightest case is the discriminator's first conv: 1.975e-3 against a spread of 1.18e-3, the same to five digits
-            # through the tap-GEMM weight gradient and through the direct kernel with fp64 chunk sums: the error is upstream of it)
-            assert e < 2e-4 + 2.0 * spread, (k, e, spread)
+            assert e < 2e-4 + 1.5 * spread, (k, e, spread)
     print('full-size step relative errors (ours, reference fp32 spread):',
           {k: (tuple(float('%.2e' % x) for x in v) if isinstance(v, tuple) else float('%.2e' % v)) for k, v in errs.items()})
 
