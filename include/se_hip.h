@@ -418,6 +418,13 @@ int se_dwconv31_glu_bwd(const float* dH, const float* W, const float* U, const f
 /* weight / bias gradient (accumulated into dW [128][31], dbias [128]); ws = workspace of
  * se_dwconv31_wgrad_workspace_bytes() bytes (per-workgroup partial sums, reduced in a fixed order: deterministic) */
 size_t se_dwconv31_wgrad_workspace_bytes(void);
+/* Round 5: input gradient + GLU backward (as se_dwconv31_glu_bwd) AND the weight / bias gradient (as se_dwconv31_wgrad with X = U,
+ * dY = dH) of DepthWiseConv1d (models/conformer.py:40-48,164-166 backwards) in ONE sweep over (dH, U, G): the weight gradient uses the
+ * rows the input-gradient FIR already holds in LDS.  dW [128][31], dbias [128] (may be NULL) are accumulated; ws as above; ntok = rows of
+ * the [tokens][128] operands (32-bit buffer offsets: ntok * 1024 B < 4 GiB, checked). */
+int se_dwconv31_bwd_fused(const float* dH, const float* W, const float* U, const float* G, float* dZ, float* amax_out, float* dW,
+                          float* dbias, float* ws, long ntok, int nseq, int n, int inner, long outer_stride, long inner_stride,
+                          long pos_stride, void* stream);
 int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, float* dbias, int nseq, int n, int inner,
                       long outer_stride, long inner_stride, long pos_stride, float* ws, void* stream);
 

@@ -7,6 +7,7 @@
 //
 // The same kernel with flipped taps is the input gradient; the weight gradient is a persistent kernel that
 // keeps 31 x float4 accumulators per lane and flushes once per workgroup.
+#include <type_traits>
 #include "se_common.h"
 
 struct SeqGeom {
@@ -349,6 +350,249 @@ __global__ void dwconv_wgrad_reduce_kernel(const float* __restrict__ part, int n
   else if (dbias) atomicAdd(&dbias[ch], t);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 5: the WHOLE backward of the depthwise convolution in one sweep -- input gradient + GLU backward (as dwconv_kernel<.., GLU>)
+// AND the weight / bias gradient, which needs exactly the operands this kernel already reads: dW[c][k] = sum_p U[c][p] dH[c][p - k + 15]
+// multiplies the GLU result U at the tile's own positions (read for the GLU backward anyway) with the dH rows of the tile's window.
+// The stand-alone weight-gradient launch re-read (U, dH) = 531 MB per block.
+//
+// Structure (not the two-workgroup tiling above: 62 weight-gradient accumulators next to 62 taps do not fit 128 VGPRs, and folding
+// per-tile sums into an LDS table with ds_add_f32 ran at ~180 cycles per wave-instruction: 1.7 ms per launch):
+// ONE persistent 1024-thread workgroup per CU, 112-position tiles for every sequence length (n = 321: three tiles, n = 101: one),
+// two channels per lane; the dH rows (+ 30 halo rows) AND the U rows of a tile are staged in LDS, both requested one tile ahead.
+//   barrier, staged rows -> LDS, barrier; gate values of the own positions requested;
+//   phase A (wave = position slot: 16 slots x 7 positions): taps from an LDS table (62 VGPRs, dead after the FIR), flipped-tap FIR,
+//            GLU backward with U from LDS and the gate, dZ stores;
+//   rows of the NEXT tile requested (buffer loads: padding rows and "no next tile" are out-of-range offsets -> zeros, no branches);
+//   phase B (wave = tap group x position half: 8 groups of 4 taps x 2 halves of 56 positions): per position ONE new dH row and one
+//            U row from LDS, four FMAs into 4 x 2 accumulators that stay in registers for the whole launch (the 32nd "tap" of group 7
+//            is the bias gradient: the dH row itself).
+// The accumulators go to the workgroup's row of the workspace at the end; dwconv_wgrad_reduce_kernel adds the rows up.
+struct DwBwdArgs {
+  SeqGeom g;
+  const float* dH; const float* W; const float* U; const float* Z; float* dZ; float* amax_out; float* part;
+  unsigned bytes128, bytes256;      // extents of the [tokens][128] operands and of dZ [tokens][256]
+};
+constexpr int FB_PPS = 7, FB_TILE = 16 * FB_PPS, FB_ROWS = FB_TILE + DW_K - 1, FB_NLD = (FB_ROWS * 32 + 1023) / 1024,
+              FB_NLU = (FB_TILE * 32 + 1023) / 1024;
+typedef unsigned u32x2fb_ __attribute__((ext_vector_type(2)));
+#ifndef FB_NT
+#define FB_NT 8                         // taps per wave in the weight-gradient phase (4: twice the LDS reads; 8: +8 persistent VGPRs)
+#endif
+constexpr int FB_LDS_BYTES = (FB_ROWS * DW_C + FB_TILE * DW_C + DW_K * DW_C) * 4;
+
+__global__ __launch_bounds__(1024) void dwconv_bwd_fused_kernel(DwBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float fb_smem[];
+  float* xs = fb_smem;                          // [142][128]: dH rows p0 - 15 .. p0 + 126
+  float* us = fb_smem + FB_ROWS * DW_C;         // [112][128]: U rows p0 .. p0 + 111
+  float* wt = us + FB_TILE * DW_C;              // [31][128]: taps in input-gradient (flipped) order
+  const int tid = threadIdx.x, cl = tid & 63, ps = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned cl8 = (unsigned)cl * 8u;
+  const int n = a.g.n;
+  for (int i = tid; i < DW_C * DW_K; i += 1024) {
+    const int ch = i / DW_K, k = i - ch * DW_K;
+    wt[(DW_K - 1 - k) * DW_C + ch] = a.W[i];
+  }
+  const __amdgpu_buffer_rsrc_t rH = make_rsrc_(a.dH, a.bytes128), rU = make_rsrc_(a.U, a.bytes128), rG = make_rsrc_(a.Z, a.bytes128),
+                               rD = make_rsrc_(a.dZ, a.bytes256);
+  const int tiles = (n + FB_TILE - 1) / FB_TILE;
+  const long nitems = (long)a.g.nseq * tiles;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
+  const long Q = (nitems + 7) >> 3, ibase = (long)xcd * Q, iend = ibase + Q < nitems ? ibase + Q : nitems;
+  const unsigned rsb = (unsigned)(a.g.pos_stride * DW_C * 4);          // bytes between consecutive positions of a sequence
+  float zmax = 0.f;
+  float4 ld[FB_NLD], lu[FB_NLU];
+  // rows of item `it` (all-zero rows for it >= iend): dH row r = (tid >> 5) + 32 k <-> position p0 - 15 + r, U row r <-> p0 + r.
+  // Offsets = a wave-uniform part per load + ONE lane constant (mod 2^32: rows above the sequence wrap and are deselected)
+  const int lrow = tid >> 5;
+  const unsigned lane_off = (unsigned)lrow * rsb + (unsigned)(tid & 31) * 16u;
+  auto request_rows = [&](long it) {
+    const bool live = it < iend;
+    const long itc = live ? it : 0;
+    const int seq = (int)(itc / tiles), p0 = (int)(itc - (long)seq * tiles) * FB_TILE;
+    const unsigned base = (unsigned)(((long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride) * (DW_C * 4));
+    const int plo = 15 - p0 > 0 ? 15 - p0 : 0;           // dH row r is a real position iff plo <= r < phi (ONE unsigned compare)
+    const int phi = n - (p0 - 15) < FB_ROWS ? n - (p0 - 15) : FB_ROWS;
+    const unsigned span = live && phi > plo ? (unsigned)(phi - plo) : 0u;
+    const unsigned uspan = live ? (unsigned)(n - p0 < FB_TILE ? n - p0 : FB_TILE) : 0u;
+#pragma unroll
+    for (int k = 0; k < FB_NLD; ++k) {
+      const int row = lrow + 32 * k;
+      const unsigned off = base + (unsigned)(p0 - 15 + 32 * k) * rsb + lane_off;
+      ld[k] = buf_load4_(rH, (unsigned)(row - plo) < span ? off : BUF_OOB_);
+    }
+#pragma unroll
+    for (int k = 0; k < FB_NLU; ++k) {
+      const int row = lrow + 32 * k;
+      const unsigned off = base + (unsigned)(p0 + 32 * k) * rsb + lane_off;
+      lu[k] = buf_load4_(rU, (unsigned)row < uspan ? off : BUF_OOB_);
+    }
+  };
+  // phase-B role of this wave: taps 4 tg .. 4 tg + 3 (k = 31: bias gradient), positions 56 ph .. 56 ph + 55 of the tile
+  constexpr int NT = FB_NT, NGRP = 32 / NT, NPART = 16 / NGRP, PLEN = FB_TILE / NPART;      // taps per wave, tap groups, position parts
+  const int tg = ps % NGRP, ph = ps / NGRP;
+  f32x2 wacc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) wacc[j] = (f32x2){0.f, 0.f};
+  request_rows(ibase + slot);
+  for (long it = ibase + slot; it < iend; it += S) {
+    const int seq = (int)(it / tiles), p0 = (int)(it - (long)seq * tiles) * FB_TILE;
+    const unsigned base = (unsigned)(((long)(seq / a.g.inner) * a.g.outer_stride + (long)(seq % a.g.inner) * a.g.inner_stride) * (DW_C * 4));
+    __syncthreads();                           // previous tile's LDS reads (phase B) done; first pass: tap table written
+#pragma unroll
+    for (int k = 0; k < FB_NLD; ++k) {
+      const int row = lrow + 32 * k;
+      if (row < FB_ROWS) *reinterpret_cast<float4*>(&xs[row * DW_C + (tid & 31) * 4]) = ld[k];
+    }
+#pragma unroll
+    for (int k = 0; k < FB_NLU; ++k) {
+      const int row = lrow + 32 * k;
+      if (row < FB_TILE) *reinterpret_cast<float4*>(&us[row * DW_C + (tid & 31) * 4]) = lu[k];
+    }
+    __syncthreads();
+    // gate values of the own positions: requested ahead of the FIR that hides their latency
+    const int pbase = p0 + ps * FB_PPS;                       // wave-uniform (ps is)
+    f32x2 gt[FB_PPS];
+#pragma unroll
+    for (int o = 0; o < FB_PPS; ++o)
+      gt[o] = __builtin_bit_cast(f32x2, buf_load2_(rG, pbase + o < n ? base + (unsigned)(pbase + o) * rsb + cl8 : BUF_OOB_));
+    // ---- phase A: flipped-tap FIR + GLU backward
+    {
+      constexpr int NR = FB_PPS + DW_K - 1;
+      const float* xrow = &xs[(ps * FB_PPS) * DW_C + cl * 2];
+      f32x2 acc[FB_PPS];
+#pragma unroll
+      for (int o = 0; o < FB_PPS; ++o) acc[o] = (f32x2){0.f, 0.f};
+      // the 31 taps in two halves (16 + 15): 32 tap registers at a time instead of 62 -- the weight-gradient accumulators of phase
+      // B stay in registers next to them; rows 16 .. 21 of the window are read twice
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        constexpr int KH = 16;
+        const int K0 = h * KH, K1 = h == 0 ? KH : DW_K;
+        f32x2 w[KH];
+#pragma unroll
+        for (int k = 0; k < KH; ++k)
+          if (K0 + k < K1) w[k] = *reinterpret_cast<const f32x2*>(&wt[(K0 + k) * DW_C + cl * 2]);
+        const int R0 = K0, R1 = K1 - 1 + FB_PPS;               // window rows [R0, R1) carry taps [K0, K1)
+        constexpr int GA = 4;
+        f32x2 xg[2][GA];
+#pragma unroll
+        for (int j = 0; j < GA; ++j) xg[0][j] = *reinterpret_cast<const f32x2*>(xrow + (R0 + j) * DW_C);
+#pragma unroll
+        for (int g = 0; g < (KH + FB_PPS - 1 + GA - 1) / GA; ++g) {
+          asm volatile("" ::: "memory");
+          if (R0 + (g + 1) * GA < R1) {
+#pragma unroll
+            for (int j = 0; j < GA; ++j)
+              if (R0 + (g + 1) * GA + j < R1) xg[(g + 1) & 1][j] = *reinterpret_cast<const f32x2*>(xrow + (R0 + (g + 1) * GA + j) * DW_C);
+          }
+          asm volatile("" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < GA; ++j) {
+            const int i = R0 + g * GA + j;
+            if (i < R1) {
+#pragma unroll
+              for (int o = 0; o < FB_PPS; ++o) {
+                const int k = i - o;
+                if (k >= K0 && k < K1) acc[o] = __builtin_elementwise_fma(xg[g & 1][j], w[k - K0], acc[o]);
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int o = 0; o < FB_PPS; ++o) asm volatile("" : "+v"(acc[o]));
+      // GLU backward on the way out: dZ[:, c] = dU sigmoid(g), dZ[:, 128 + c] = dU u (1 - sigmoid(g)); rows of dZ are 256 floats
+      const float* urow = &us[(ps * FB_PPS) * DW_C + cl * 2];
+#pragma unroll
+      for (int o = 0; o < FB_PPS; ++o) {
+        const f32x2 u = *reinterpret_cast<const f32x2*>(urow + o * DW_C);
+        f32x2 da, dg;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+#ifdef FB_ABL_NO_GLU
+          const float sg = gt[o][e];
+#else
+          const float sg = sigmoidf_(gt[o][e]);
+#endif
+          da[e] = acc[o][e] * sg;
+          dg[e] = acc[o][e] * u[e] * (1.f - sg);
+          zmax = fmaxf(zmax, pbase + o < n ? fmaxf(fabsf(da[e]), fabsf(dg[e])) : 0.f);
+        }
+        const unsigned off = pbase + o < n ? 2u * (base + (unsigned)(pbase + o) * rsb) + cl8 : BUF_OOB_;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2fb_, da), rD, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2fb_, dg), rD, off + (off == BUF_OOB_ ? 0u : (unsigned)DW_C * 4u), 0, 0);
+      }
+    }
+    asm volatile("" : "+v"(zmax));             // the maximum is folded HERE (left alone, the compiler parks all 28 |dZ| values across phase B)
+    asm volatile("" ::: "memory");
+    request_rows(it + S);                      // in flight during phase B
+    asm volatile("" ::: "memory");
+    // ---- phase B: dW[k] += U[p] dH[p - k + 15]: dH row index (in xs) of position offset q and tap k = 4 tg + j is q + 30 - k
+#ifndef FB_ABL_NO_B
+    {
+      const int q0 = ph * PLEN;
+      const float* up = &us[q0 * DW_C + cl * 2];
+      const float* xp = &xs[(q0 + 30 - NT * tg) * DW_C + cl * 2];       // row of j = 0; j-th tap: j rows up
+      // BIAS (last tap group): its last slot is the bias gradient -- the dH row of the position itself (row q + 15 = xp row
+      // t + 15 - 30 + NT (NGRP - 1) = t + 17 - NT)
+      auto phase_b = [&](auto bias_tag) {
+        constexpr bool BIAS = decltype(bias_tag)::value;
+        constexpr int UB = 2, BOFF = 17 - NT;
+        static_assert(PLEN % UB == 0, "position part not a multiple of the read group");
+        f32x2 r[NT];                            // r[j]: the row of tap slot j for the CURRENT position (r[0] is read per position)
+#pragma unroll
+        for (int jj = 1; jj < NT; ++jj)
+          if (!(BIAS && jj == NT - 1)) r[jj] = *reinterpret_cast<const f32x2*>(xp - jj * DW_C);
+#pragma unroll 1
+        for (int qq = 0; qq < PLEN; qq += UB) {
+          f32x2 uu[UB], r0[UB], rb[UB];
+#pragma unroll
+          for (int e = 0; e < UB; ++e) {
+            uu[e] = *reinterpret_cast<const f32x2*>(up + (qq + e) * DW_C);
+            r0[e] = *reinterpret_cast<const f32x2*>(xp + (qq + e) * DW_C);
+            if constexpr (BIAS) rb[e] = *reinterpret_cast<const f32x2*>(xp + (qq + e + BOFF) * DW_C);
+          }
+#pragma unroll
+          for (int e = 0; e < UB; ++e) {
+            r[0] = r0[e];
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+              if (BIAS && jj == NT - 1) wacc[jj] += rb[e];
+              else wacc[jj] = __builtin_elementwise_fma(uu[e], r[jj], wacc[jj]);
+            }
+#pragma unroll
+            for (int jj = NT - 1; jj >= 1; --jj) r[jj] = r[jj - 1];
+          }
+        }
+      };
+      if (tg == NGRP - 1) phase_b(std::true_type{}); else phase_b(std::false_type{});
+    }
+#endif
+  }
+  if (a.amax_out) {
+    zmax = wave_max(zmax);
+    if ((tid & 63) == 0) amax_raise_(a.amax_out, zmax);
+  }
+  // the two position halves of every tap group summed through LDS, then the workgroup's [32][128] row of the workspace
+  __syncthreads();
+  float* red = xs;                              // [position parts][32 taps][128]
+  int t2 = threadIdx.x;                         // indices re-derived behind an opaque copy: computed up front they sat in scratch
+  asm volatile("" : "+v"(t2));                  // for the whole tile loop
+  const int w2 = t2 >> 6, c2 = t2 & 63;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x2*>(&red[((w2 / NGRP) * 32 + NT * (w2 % NGRP) + j) * DW_C + c2 * 2]) = wacc[j];
+  __syncthreads();
+  float* prow = a.part + (long)blockIdx.x * 32 * DW_C;
+  float4 t = *reinterpret_cast<const float4*>(red + t2 * 4);
+#pragma unroll
+  for (int h = 1; h < NPART; ++h) {
+    const float4 v = *reinterpret_cast<const float4*>(red + h * 32 * DW_C + t2 * 4);
+    t = make_float4(t.x + v.x, t.y + v.y, t.z + v.z, t.w + v.w);
+  }
+  *reinterpret_cast<float4*>(prow + t2 * 4) = t;
+}
+
 extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, float* Y, double* stats, int flip,
                            int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride,
                            void* stream) {
@@ -403,4 +647,29 @@ extern "C" int se_dwconv31_wgrad(const float* X, const float* dY, float* dW, flo
   hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(32 * DW_C / 256, 32), dim3(256), 0, as_stream(stream), (const float*)ws, nblk,
                      dW, dbias);
   return se_check_launch("se_dwconv31_wgrad");
+}
+
+// input gradient + GLU backward + weight / bias gradient of the depthwise convolution in one sweep (dwconv_bwd_fused_kernel).
+// dW [128][31] and dbias [128] are ACCUMULATED (atomics of the reduce kernel); ws: se_dwconv31_wgrad_workspace_bytes().
+extern "C" int se_dwconv31_bwd_fused(const float* dH, const float* W, const float* U, const float* G, float* dZ, float* amax_out,
+                                     float* dW, float* dbias, float* ws, long ntok, int nseq, int n, int inner, long outer_stride,
+                                     long inner_stride, long pos_stride, void* stream) {
+  SE_REQUIRE(dH && W && U && G && dZ && dW && ws && nseq > 0 && n > 0 && inner > 0 && ntok > 0, "dwconv31_bwd_fused: bad arguments");
+  SE_REQUIRE(ntok * (DW_C * 8L) < (1L << 32) - 4096, "dwconv31_bwd_fused: operands beyond 32-bit buffer offsets (%ld tokens)", ntok);
+  SE_REQUIRE(pos_stride > 0 && (long)(nseq - 1) / inner * outer_stride + (long)(inner - 1) * inner_stride + (long)(n - 1) * pos_stride < ntok,
+             "dwconv31_bwd_fused: sequence geometry reaches past %ld tokens", ntok);
+  DwBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, dH, W, U, G, dZ, amax_out, ws,
+              (unsigned)(ntok * DW_C * 4), (unsigned)(ntok * DW_C * 8)};
+  const long nitems = (long)nseq * cdiv(n, FB_TILE);
+  int dev = 0, ncu = 256;
+  hipGetDevice(&dev);
+  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  int nblk = nitems < ncu ? (int)((nitems + 7) / 8 * 8) : ncu / 8 * 8;      // one workgroup per CU; multiple of 8 (XCD split)
+  if (nblk > 512) nblk = 512;                                              // rows of the workspace
+  static unsigned lds_done = 0;
+  SE_REQUIRE(se_raise_lds((const void*)dwconv_bwd_fused_kernel, FB_LDS_BYTES, &lds_done), "dwconv31_bwd_fused: cannot raise the LDS limit");
+  hipLaunchKernelGGL(dwconv_bwd_fused_kernel, dim3(nblk), dim3(1024), FB_LDS_BYTES, as_stream(stream), a);
+  hipLaunchKernelGGL(dwconv_wgrad_reduce_kernel, dim3(32 * DW_C / 256, 32), dim3(256), 0, as_stream(stream), (const float*)ws, nblk,
+                     dW, dbias);
+  return se_check_launch("se_dwconv31_bwd_fused");
 }

@@ -691,13 +691,19 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     else:
         raise L.SeHipError('conformer_bwd in eval mode is not supported (BatchNorm uses running statistics)')
     Wdw = P[f'{p}.conv.net.4.conv.weight'].view(128, 31)
-    if FUSE_GLU_BWD:       # depthwise input gradient + GLU backward in one kernel: dU (266 MB at batch 16) never goes to memory
+    dw_fused = FUSE_GLU_BWD and O.DW_BWD_FUSED and M * 1024 < (1 << 32) - 4096
+    if dw_fused:           # ... and the weight / bias gradient from the rows the same kernel already holds (round 5)
+        dzc = O.dwconv31_bwd_fused(dh, Wdw, u, zc, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom,
+                                   amax=_amax(dev))
+        du = None
+    elif FUSE_GLU_BWD:     # depthwise input gradient + GLU backward in one kernel: dU (266 MB at batch 16) never goes to memory
         dzc = O.dwconv31_glu_bwd(dh, Wdw, u, zc, geom, amax=_amax(dev))
         du = None
     else:
         du = O.dwconv31(dh, Wdw, None, geom, flip=True)
-    with GM.leaf_stream(u, dh):
-        O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
+    if not dw_fused:
+        with GM.leaf_stream(u, dh):
+            O.dwconv31_wgrad(u, dh, G[f'{p}.conv.net.4.conv.weight'].view(128, 31), G[f'{p}.conv.net.4.conv.bias'], geom)
     if not FUSE_GLU_BWD:
         dzc = O.glu_bwd_gate(u, zc, du, M, 128, amax=_amax(dev))
     Wpw1 = P[f'{p}.conv.net.2.weight'].view(256, 64)

@@ -200,6 +200,24 @@ def dwconv31_glu_bwd(dh, w, u, gate, geom, amax=None):
     return dz
 
 
+# SE_DW_BWD_FUSED=0: the two-launch depthwise backward (dwconv31_glu_bwd + dwconv31_wgrad)
+DW_BWD_FUSED = _os.environ.get('SE_DW_BWD_FUSED', '1') != '0'
+
+
+def dwconv31_bwd_fused(dh, w, u, gate, dw, dbias, geom, amax=None):
+    """the whole depthwise-conv backward in one sweep (csrc/se_dwconv.hip, dwconv_bwd_fused_kernel): returns dZ [M, 256] like
+    dwconv31_glu_bwd AND accumulates dw [128, 31] / dbias [128] like dwconv31_wgrad(u, dh, ...)"""
+    M = dh.shape[0]
+    dz = torch.empty(M, 256, device=dh.device, dtype=torch.float32)
+    nseq, n, inner, os_, is_, ps = geom
+    ws = _new(L.lib().se_dwconv31_wgrad_workspace_bytes() // 4, like=dh)
+    L.call('se_dwconv31_bwd_fused', L.ptr(dh), L.ptr(w), L.ptr(u), L.ptr(gate), L.ptr(dz), L.ptr(amax), L.ptr(dw), L.ptr(dbias),
+           L.ptr(ws), _l(M), _i(nseq), _i(n), _i(inner), _l(os_), _l(is_), _l(ps), L.stream(),
+           _key='dwconv31 dgrad + glu_bwd + wgrad', _bytes=4.0 * (3 * dh.numel() + dz.numel()))
+    dz._se_amax = amax
+    return dz
+
+
 def dwconv31_wgrad(x, dy, dw, dbias, geom):
     nseq, n, inner, os_, is_, ps = geom
     ws = _new(L.lib().se_dwconv31_wgrad_workspace_bytes() // 4, like=x)

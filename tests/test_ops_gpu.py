@@ -180,6 +180,42 @@ def test_dwconv31(axis, B, T, Fq):
     assert abs(float(amax) - float(dz.abs().max())) <= 1e-6 * float(amax)
 
 
+@pytest.mark.parametrize('axis,B,T,Fq', [('time', 2, 37, 5), ('freq', 2, 7, 101), ('time', 1, 321, 9), ('freq', 3, 5, 113),
+                                         ('time', 2, 112, 3), ('freq', 1, 300, 16), ('time', 1, 16, 2)])
+def test_dwconv31_backward_in_one_sweep(axis, B, T, Fq):
+    """se_dwconv31_bwd_fused: dZ, max |dZ| and the ACCUMULATED weight / bias gradient against fp64 autograd of conv(GLU(z)) and
+    against the two-launch path; sequence lengths below / at / above the 112-position tile, both token-stride geometries, more
+    (sequence, tile) items than workgroups and fewer"""
+    from speech_enhancement_amd import ops as O, attention as A
+    w = rnd(128, 1, 31, seed=2, scale=0.2)
+    dy = rnd(B, T, Fq, 128, seed=4)
+    z = rnd(B, T, Fq, 256, seed=5)
+    geom = A.seq_geometry(B, T, Fq, axis)
+    z64 = z.double().requires_grad_(True)
+    w64, b64 = w.double().requires_grad_(True), torch.zeros(128, device='cuda', dtype=torch.float64, requires_grad=True)
+    u64 = z64[..., :128] * torch.sigmoid(z64[..., 128:])
+    sq = u64.permute(0, 2, 3, 1) if axis == 'time' else u64.permute(0, 1, 3, 2)
+    rr = F.conv1d(F.pad(sq.reshape(-1, 128, sq.shape[-1]), (15, 15)), w64, b64, groups=128).reshape(sq.shape)
+    (rr.permute(0, 3, 1, 2) if axis == 'time' else rr.permute(0, 1, 3, 2)).backward(dy.double())
+    u = (z[..., :128] * torch.sigmoid(z[..., 128:])).contiguous()
+    gate = z[..., 128:].contiguous()
+    amax = torch.zeros(1, device='cuda')
+    dw0, db0 = rnd(128, 31, seed=7), rnd(128, seed=8)                       # accumulated into
+    dw, db = dw0.clone(), db0.clone()
+    dz = O.dwconv31_bwd_fused(dy.view(-1, 128), w.view(128, 31), u.view(-1, 128), gate.view(-1, 128), dw, db, geom, amax=amax)
+    assert relerr(dz.view(B, T, Fq, 256), z64.grad) < 1e-5
+    assert abs(float(amax) - float(dz.abs().max())) <= 1e-6 * float(amax)
+    assert relerr(dw - dw0, w64.grad.view(128, 31)) < 2e-5 and relerr(db - db0, b64.grad) < 2e-5
+    dz2 = O.dwconv31_glu_bwd(dy.view(-1, 128), w.view(128, 31), u.view(-1, 128), gate.view(-1, 128), geom)
+    dw2, db2 = torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda')
+    O.dwconv31_wgrad(u.view(-1, 128), dy.view(-1, 128), dw2, db2, geom)
+    assert relerr(dz, dz2) < 2e-6 and relerr(dw - dw0, dw2) < 2e-5 and relerr(db - db0, db2) < 2e-5
+    dbn = None                                                              # bias gradient is optional
+    dw3 = torch.zeros(128, 31, device='cuda')
+    O.dwconv31_bwd_fused(dy.view(-1, 128), w.view(128, 31), u.view(-1, 128), gate.view(-1, 128), dw3, dbn, geom)
+    assert relerr(dw3, dw2) < 2e-5
+
+
 def test_glu_bwd_and_optimizers():
     from speech_enhancement_amd import ops as O
     M = 777

@@ -211,12 +211,13 @@ def dw_bench(argv):
         gate = torch.randn(B * T * Fq, 128, device='cuda')
         for name, fn in (('fwd+stats', lambda: O.dwconv31(x, w, b, geom, stats=st)), ('dgrad', lambda: O.dwconv31(dy, w, None, geom, flip=True)),
                          ('dgrad+glu', lambda: O.dwconv31_glu_bwd(dy, w, x, gate, geom)),
-                         ('wgrad', lambda: O.dwconv31_wgrad(x, dy, torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda'), geom))):
+                         ('wgrad', lambda: O.dwconv31_wgrad(x, dy, torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda'), geom)),
+                         ('bwd fused', lambda: O.dwconv31_bwd_fused(dy, w, x, gate, torch.zeros(128, 31, device='cuda'), torch.zeros(128, device='cuda'), geom))):
             for _ in range(2): fn()
             torch.cuda.synchronize(); t0 = time.time()
             for _ in range(5): fn()
             torch.cuda.synchronize(); dt = (time.time() - t0) / 5
-            print(f'{axis:5s} {name:10s} {dt*1e6:8.1f} us  {(5 if name == "dgrad+glu" else 2)*x.numel()*4/dt/1e9:7.0f} GB/s', flush=True)
+            print(f'{axis:5s} {name:10s} {dt*1e6:8.1f} us  {(5 if name in ("dgrad+glu", "bwd fused") else 2)*x.numel()*4/dt/1e9:7.0f} GB/s', flush=True)
 
 @cmd
 def ff_one(argv):
