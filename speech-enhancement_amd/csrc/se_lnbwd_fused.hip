@@ -7,16 +7,18 @@
 //   once (fp16 (hi, lo) images, scaled split-fp16 arithmetic of se_gemm_dev.h) and feeds both: A 1 KB + x, dR, dX 0.75 KB per row
 //   instead of 2 x (A + x) + dR + dX.
 //
-// One persistent 8-wave workgroup per CU (146 KB of LDS at K = 256: the [64 x K] weight planes stay resident), every wave the same
-// work, two barriers per 32-row tile:
+// One persistent 8-wave workgroup per CU, every wave the same work, ONE barrier per 32-row tile (second form of the round: the
+// first kept the [64 x K] weight planes in LDS -- 70 KB -- and needed two barriers per tile because the images were single; it ran at
+// ~10 K cycles per tile against ~1.5 K cycles of matrix work and 4 K of vector work).  Now every wave holds ITS block of W^T (32
+// channels x 64 outputs x 2 planes = 32 VGPRs) for the whole launch, and the freed LDS double-buffers the images and the patches:
+//   stage      the NEXT tile's rows (requested two tiles ago) -> fp16 images [(t + 1) & 1]; rows of tile t + 3 requested;
 //   products   dW: wave w owns the 32 outputs k = 32 w .. (two 32 x 32 tiles over the channel halves, accumulators kept for the whole
-//              launch), both operands by hardware-transposed reads of the row-major images (the contraction index is the image row);
-//              db by packed dot products on the same fragments;
-//              dLN[32 rows x 32 channels] over 64 of the K outputs per wave (wave = channel half x K part): A rows and W^T rows out of
-//              the images (ds_read_b128) -> partial patches;
-//              the NEXT tile's rows are requested at the top of this phase (26 registers per lane: 96 KB in flight per CU)      | barrier
+//              launch), both operands by hardware-transposed reads of the row-major images [t & 1] (the contraction index is the image
+//              row); db by packed dot products on the same fragments;
+//              dLN[32 rows x 32 channels] over 64 of the K outputs per wave (wave = channel half x K part): A rows out of the image
+//              (ds_read_b128), W^T from registers -> partial patches [t & 1]                                                   | barrier
 //   epilogue   LayerNorm backward of four rows per wave on the summed patches -> dX (x, dR kept from the tile's staging: the lane that
-//              staged a row segment finishes it); then the next tile's rows -> fp16 images                                       | barrier
+//              staged a row segment finishes it) -- no barrier behind it: a fast wave's next stage / products touch the OTHER buffers.
 // The kernel is HBM-bound by construction (1.75 KB per row; 24 matrix instructions per wave and tile).
 #include "se_ff_fused.h"
 
@@ -33,10 +35,10 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
   using fff::trfrag_; using fff::trfrag_sum_; using fff::split4_;
   constexpr int RS = 144, LPL = 32 * RS;                 // LN image [32 rows][64 ch]
   constexpr int ARS = 2 * K + 32, APL = 32 * ARS;        // A image [32 rows][K]: + 32 B pad, rows 16-byte aligned
-  constexpr int WPL = 64 * ARS;                          // W^T image [64 ch][K]
   constexpr int NQ = K / 64;                             // K parts of the dLN product = partial patches
   constexpr int NKB = K / 32;                            // 32-wide output blocks of dW (<= 8: one per wave)
-  constexpr int O_A = 0, O_LN = 2 * APL, O_WT = O_LN + 2 * LPL, O_PATCH = O_WT + 2 * WPL, O_GB = O_PATCH + NQ * 32 * 64 * 4;
+  constexpr int PSZ = NQ * 32 * 64 * 4;                  // one set of partial patches
+  constexpr int O_A = 0, O_LN = 4 * APL, O_PATCH = O_LN + 4 * LPL, O_GB = O_PATCH + 2 * PSZ;      // images / patches: [2 buffers]
   constexpr int LDS_BYTES = O_GB + 512;
   static_assert(LDS_BYTES <= 163840 && NKB <= 8, "one workgroup per CU");
   __shared__ __attribute__((aligned(16))) unsigned char sm[LDS_BYTES];
@@ -52,16 +54,8 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
   const float s_a = exp2i_(e_a), s_in = exp2i_(e_in), u_ln = exp2i_(-e_a - e_w), u_w = exp2i_(-e_a - e_in), u_b = exp2i_(-e_a);
   float one;
   asm volatile("s_mov_b32 %0, 1.0" : "=s"(one));
-  // ---- resident: gamma | beta, the W^T planes ----
+  // ---- resident: gamma | beta ----
   if (tid < 128) reinterpret_cast<float*>(sm + O_GB)[tid] = tid < 64 ? a.gamma[tid] : a.beta[tid - 64];
-  {
-    constexpr int CH = K / 8;                            // 16-byte chunks per row
-    for (int i = tid; i < 2 * 64 * CH; i += 512) {
-      const int pl = i / (64 * CH), rem = i - pl * 64 * CH, row = rem / CH, chk = rem - row * CH;
-      *reinterpret_cast<float4*>(sm + O_WT + pl * WPL + row * ARS + 16 * chk) =
-          *reinterpret_cast<const float4*>(reinterpret_cast<const __bf16*>(a.WT) + (size_t)pl * 64 * K + (size_t)row * K + 8 * chk);
-    }
-  }
   const float* gbs = reinterpret_cast<const float*>(sm + O_GB);
   float* const patch = reinterpret_cast<float*>(sm + O_PATCH);
   const int r = lane & 31, kg = lane >> 5;
@@ -76,8 +70,16 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
   // dLN role: channel half ch, K part kq (64 outputs)
   const int ch = wave & 1, kq = wave >> 1;
   const bool dl_on = kq < NQ;
-  const unsigned char* const arow = sm + O_A + r * ARS + (64 * (dl_on ? kq : 0) + 8 * kg) * 2;             // + pl * APL + 32 ks
-  const unsigned char* const wrow = sm + O_WT + (32 * ch + r) * ARS + (64 * (dl_on ? kq : 0) + 8 * kg) * 2; // + pl * WPL + 32 ks
+  const unsigned char* const arow = sm + O_A + r * ARS + (64 * (dl_on ? kq : 0) + 8 * kg) * 2;             // + buffer * 2 APL + pl * APL + 32 ks
+  // this wave's block of W^T (channel 32 ch + r on the lane, outputs 64 kq + 8 kg + 32 ks ..): registers for the whole launch
+  bf16x8 wfr[4][2];
+  {
+    const __bf16* wp = reinterpret_cast<const __bf16*>(a.WT) + (size_t)(32 * ch + r) * K + 64 * (dl_on ? kq : 0) + 8 * kg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) wfr[ks][pl] = *reinterpret_cast<const bf16x8*>(wp + (size_t)pl * 64 * K + 16 * ks);
+  }
 
   f32x16 aw[2];
 #pragma unroll
@@ -91,22 +93,24 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
   float4 pa2[2][NA], px2[2], pr2[2];
   float2 pst2[2];
   pr2[0] = pr2[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 kx, kr; float2 kst;                                      // kept for the epilogue of the tile in the images
+  float4 kx, kr, nx, nr; float2 kst, nst;                         // kept for the epilogue: (k*) the tile whose patches are summed, (n*) the tile just staged
   auto load_rows = [&](long m0, auto bufc) {
     constexpr int bf = decltype(bufc)::value;
     float4 (&pa)[NA] = pa2[bf]; float4& px = px2[bf]; float4& pr = pr2[bf];
-    const long avail = a.M - m0 < 32 ? a.M - m0 : 32;
+    const long avail = mend - m0 < 32 ? mend - m0 : 32;      // (<= 0 past this workgroup's rows: empty descriptors, zeros, no traffic)
     const __amdgpu_buffer_rsrc_t Ar = make_rsrc_(a.A + m0 * K, avail > 0 ? (unsigned)(avail * K * 4) : 0u);
     const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X + m0 * 64, avail > 0 ? (unsigned)(avail * 256) : 0u);
     const __amdgpu_buffer_rsrc_t Sr = make_rsrc_(a.stats + m0 * 2, avail > 0 ? (unsigned)(avail * 8) : 0u);
 #pragma unroll
     for (int i = 0; i < NA; ++i) pa[i] = buf_load4_(Ar, (unsigned)(srow * K * 4 + (scq + 16 * i) * 16));
     px = buf_load4_(Xr, (unsigned)(srow * 256 + scq * 16));
-    if (a.dR) pr = buf_load4_(make_rsrc_(a.dR + m0 * 64, avail > 0 ? (unsigned)(avail * 256) : 0u), (unsigned)(srow * 256 + scq * 16));
+    // (no residual: an empty descriptor -> zeros.  Every load of this function is UNCONDITIONAL: a load under `if` ends in register
+    // copies at the join and the compiler waits for ALL loads in flight there -- the prefetch was worth nothing)
+    pr = buf_load4_(make_rsrc_(a.dR ? a.dR + m0 * 64 : a.X, (a.dR && avail > 0) ? (unsigned)(avail * 256) : 0u), (unsigned)(srow * 256 + scq * 16));
     pst2[bf] = buf_load2_(Sr, (unsigned)(srow * 8));
   };
-  auto stage = [&](long m0, auto bufc) {
-    constexpr int bf = decltype(bufc)::value;
+  auto stage = [&](long m0, auto bufc, auto imgc) {        // prefetch buffer bf -> images [ib]
+    constexpr int bf = decltype(bufc)::value, ib = decltype(imgc)::value;
     float4 (&pa)[NA] = pa2[bf]; float4& px = px2[bf]; float4& pr = pr2[bf];
     const float2 pst = pst2[bf];
     const bool ok = m0 + srow < mend;                    // (rows past M arrive as zeros from the range check; rows past mend are zeroed here)
@@ -114,8 +118,12 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     for (int i = 0; i < NA; ++i) {
       unsigned h0, h1, l0, l1;
       const float4 v = pa[i];
+#ifdef LNB_ABL_NO_SPLIT
+      h0 = __float_as_uint(v.x); h1 = __float_as_uint(v.y); l0 = __float_as_uint(v.z); l1 = __float_as_uint(v.w);
+#else
       split4_(ok ? v.x * s_a : 0.f, ok ? v.y * s_a : 0.f, ok ? v.z * s_a : 0.f, ok ? v.w * s_a : 0.f, one, h0, h1, l0, l1);
-      unsigned char* p = sm + O_A + srow * ARS + (scq + 16 * i) * 8;
+#endif
+      unsigned char* p = sm + O_A + ib * 2 * APL + srow * ARS + (scq + 16 * i) * 8;
       *reinterpret_cast<u32x2_*>(p) = (u32x2_){h0, h1};
       *reinterpret_cast<u32x2_*>(p + APL) = (u32x2_){l0, l1};
     }
@@ -124,61 +132,74 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     unsigned h0, h1, l0, l1;
     split4_(ok ? ((px.x - mean) * rstd * gm.x + bt.x) * s_in : 0.f, ok ? ((px.y - mean) * rstd * gm.y + bt.y) * s_in : 0.f,
             ok ? ((px.z - mean) * rstd * gm.z + bt.z) * s_in : 0.f, ok ? ((px.w - mean) * rstd * gm.w + bt.w) * s_in : 0.f, one, h0, h1, l0, l1);
-    unsigned char* p = sm + O_LN + srow * RS + scq * 8;
+    unsigned char* p = sm + O_LN + ib * 2 * LPL + srow * RS + scq * 8;
     *reinterpret_cast<u32x2_*>(p) = (u32x2_){h0, h1};
     *reinterpret_cast<u32x2_*>(p + LPL) = (u32x2_){l0, l1};
-    kx = px; kr = pr; kst = pst;
+    nx = px; nr = pr; nst = pst;
   };
 
   using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
   load_rows(mbeg, B0{});
-  if (ntile > 1) load_rows(mbeg + 32, B1{});
-  __syncthreads();                                       // gamma / beta, weight planes
-  stage(mbeg, B0{});
+  load_rows(mbeg + 32, B1{});                            // (rows past M: empty descriptors, no traffic)
+  __syncthreads();                                       // gamma / beta
+  stage(mbeg, B0{}, B0{});
+  load_rows(mbeg + 64, B0{});
+  kx = nx; kr = nr; kst = nst;
   __syncthreads();
-  auto tile = [&](int t, auto bufc) {                    // bufc = t & 1: the buffer this tile was staged from
+  auto tile = [&](int t, auto bufc) {                    // bufc = t & 1: image / patch buffer of this tile
     constexpr int bf = decltype(bufc)::value;
+    using OB = std::integral_constant<int, 1 - bf>;
     const long m0 = mbeg + 32L * t;
-    const bool more = t + 1 < ntile;
-    // ===================================== products =====================================
-    if (t + 2 < ntile) load_rows(m0 + 64, bufc);          // (this tile's buffer is free: staged before the previous barrier)
+    // ===================================== next tile's images, then this tile's products =====================================
+    stage(m0 + 32, OB{}, OB{});                           // (tile t + 1 sits in prefetch buffer (t + 1) & 1; past the last tile: zeros
+    load_rows(m0 + 96, OB{});                             //  into images nobody reads -- straight-line code, see load_rows)
+#ifndef LNB_ABL_NO_DW
     if (wg_on) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 a_h = trfrag_sum_<ARS>(trA + 16 * ks * ARS, bsum), a_l = trfrag_sum_<ARS>(trA + APL + 16 * ks * ARS, bsum);
+        const bf16x8 a_h = trfrag_sum_<ARS>(trA + bf * 2 * APL + 16 * ks * ARS, bsum),
+                     a_l = trfrag_sum_<ARS>(trA + bf * 2 * APL + APL + 16 * ks * ARS, bsum);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-          const bf16x8 l_h = trfrag_<RS>(trL + 16 * ks * RS + 64 * nt), l_l = trfrag_<RS>(trL + LPL + 16 * ks * RS + 64 * nt);
+          const bf16x8 l_h = trfrag_<RS>(trL + bf * 2 * LPL + 16 * ks * RS + 64 * nt), l_l = trfrag_<RS>(trL + bf * 2 * LPL + LPL + 16 * ks * RS + 64 * nt);
           aw[nt] = mfma32_<true>(a_h, l_l, aw[nt]);       // dW[k][c]: A = A^T (output k on the lane), B = LN (channel on the lane)
           aw[nt] = mfma32_<true>(a_l, l_h, aw[nt]);
           aw[nt] = mfma32_<true>(a_h, l_h, aw[nt]);
         }
       }
     }
+#endif
+#ifndef LNB_ABL_NO_DLN
     if (dl_on) {
       f32x16 gl;
 #pragma unroll
       for (int e = 0; e < 16; ++e) gl[e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + 32 * ks), al = *reinterpret_cast<const bf16x8*>(arow + APL + 32 * ks);
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wrow + 32 * ks), wl = *reinterpret_cast<const bf16x8*>(wrow + WPL + 32 * ks);
-        gl = mfma32_<true>(ah, wl, gl);
-        gl = mfma32_<true>(al, wh, gl);
-        gl = mfma32_<true>(ah, wh, gl);
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(arow + bf * 2 * APL + 32 * ks), al = *reinterpret_cast<const bf16x8*>(arow + bf * 2 * APL + APL + 32 * ks);
+        gl = mfma32_<true>(ah, wfr[ks][1], gl);
+        gl = mfma32_<true>(al, wfr[ks][0], gl);
+        gl = mfma32_<true>(ah, wfr[ks][0], gl);
       }
-      float* P = patch + kq * (32 * 64) + 32 * ch + r;    // C layout: row = (e & 3) + 8 (e >> 2) + 4 kg, column = lane & 31
+      float* P = patch + bf * (PSZ / 4) + kq * (32 * 64) + 32 * ch + r;    // C layout: row = (e & 3) + 8 (e >> 2) + 4 kg, column = lane & 31
 #pragma unroll
       for (int e = 0; e < 16; ++e) P[((e & 3) + 8 * (e >> 2) + 4 * kg) * 64] = gl[e] * u_ln;
     }
-    __syncthreads();                                     // patches complete; the images are free
-    // ===================================== epilogue + next tile's images =====================================
+#endif
+    __syncthreads();                                     // patches [bf] complete, images [1 - bf] staged
+    // ===================================== epilogue of tile t =====================================
+#ifdef LNB_ABL_NO_EPI
+    {
+      const long rows_ok = mend - m0 < 32 ? mend - m0 : 32;
+      buf_store4_(make_rsrc_(a.dX + m0 * 64, (unsigned)(rows_ok * 256)), (unsigned)(srow * 256 + scq * 16), make_float4(kx.x + kr.x, kx.y + kr.y, kst.x, kst.y));
+    }
+#else
     {
       const bool ok = m0 + srow < mend;
       float dv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const float4 p4v = *reinterpret_cast<const float4*>(patch + q * 2048 + srow * 64 + 4 * scq);
+        const float4 p4v = *reinterpret_cast<const float4*>(patch + bf * (PSZ / 4) + q * 2048 + srow * 64 + 4 * scq);
         dv[0] += p4v.x; dv[1] += p4v.y; dv[2] += p4v.z; dv[3] += p4v.w;
       }
       const float4 gm = *reinterpret_cast<const float4*>(gbs + 4 * scq);
@@ -211,8 +232,8 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
         abk += (srow & 3) == e ? sb : 0.f;
       }
     }
-    if (more) stage(m0 + 32, std::integral_constant<int, 1 - bf>{});
-    __syncthreads();
+#endif
+    kx = nx; kr = nr; kst = nst;
   };
   for (int t = 0; t < ntile; t += 2) {
     tile(t, B0{});

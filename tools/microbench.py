@@ -220,6 +220,33 @@ def dw_bench(argv):
             print(f'{axis:5s} {name:10s} {dt*1e6:8.1f} us  {(5 if name in ("dgrad+glu", "bwd fused") else 2)*x.numel()*4/dt/1e9:7.0f} GB/s', flush=True)
 
 @cmd
+def lnbwd_one(argv):
+    """se_gemm_ln_bwd_wgrad at the benchmark shape (M = 16 * 321 * 101 rows; K = 192: qkv, 256: pointwise-GLU)"""
+    import time, torch
+    from speech_enhancement_amd import gemm as GM, ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    M = 16 * 321 * 101
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    x = torch.randn(M, 64, device=dev); st = O.row_stats(x, M)
+    g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    dR = torch.randn(M, 64, device=dev) * 1e-3
+    for K in (192, 256):
+        W = torch.randn(K, 64, device=dev) * 0.1
+        A = torch.randn(M, K, device=dev) * 1e-3
+        A._se_amax = A.abs().max().reshape(1).clone()
+        plan = WeightPlan(dev); WT = plan.linear_T('wt', W, planes='f16'); plan.run()
+        dg, db, dW, dbias = torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.zeros(K, 64, device=dev), torch.zeros(K, device=dev)
+        am = torch.zeros(1, device=dev)
+        f = lambda: GM.gemm_ln_bwd_wgrad(A, WT, x, st, g, b, dR, dg, db, dW, dbias, out_amax=am)
+        for _ in range(3): f()
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(20): f()
+        torch.cuda.synchronize(); dt = (time.time() - t0) / 20
+        print(f'lnbwd_wgrad K={K}: {dt*1e6:7.1f} us  {4.0*M*(K+192)/dt/1e9:6.0f} GB/s algorithmic', flush=True)
+
+
+@cmd
 def ff_one(argv):
     __import__('sys').argv = ['ff_one'] + list(argv)
     """fused feed-forward forward / input-gradient kernels at the benchmark shape (M = 16 * 321 * 101 tokens, hidden 256, pre-split weights)"""
