@@ -169,8 +169,12 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
     lq = *reinterpret_cast<const float4*>(qb + (unsigned)(qc * ps * 192 + 4 * g));
     ldo = *reinterpret_cast<const float4*>(dob + (unsigned)(qc * ps * 64 + 4 * g));
     lr0 = lseb[(unsigned)(qc * ps * 4)];
-    if (DLT && !(a.dbg & 128)) lo4 = *reinterpret_cast<const float4*>(ob + (unsigned)(qc * ps * 64 + 4 * g));
-    else lr1 = dlb[(unsigned)(qc * ps * 4)];      // (dbg bit 128, the default: the table of attn_delta_kernel)
+    // BOTH loads unconditional (the unused one reads a line that is in flight anyway): under `if / else` the join copied the loaded
+    // registers behind s_waitcnt vmcnt(0) -- the loader wave then sat out the full memory latency of this stage AND of its dE / key
+    // prefetches at the top of every query tile instead of during phase 1 (found in the ISA, round 5)
+    const bool in_kernel_delta = DLT && !(a.dbg & 128);      // (dbg bit 128, the default: the table of attn_delta_kernel)
+    lo4 = *reinterpret_cast<const float4*>(in_kernel_delta ? ob + (unsigned)(qc * ps * 64 + 4 * g) : dob + (unsigned)(qc * ps * 64 + 4 * g));
+    lr1 = (in_kernel_delta ? lseb : dlb)[(unsigned)(qc * ps * 4)];
   };
   auto stage_store = [&]() {
     st_planes<true>(Qimg + rfo, 512, splitx<true>(lq, sqf));
