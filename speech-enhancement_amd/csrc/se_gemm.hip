@@ -747,6 +747,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Mb = d.Fo;                            // To == 1 (host-checked)
+  float ymax = 0.f;                               // max |stored value| over all tiles of this wave (raised once, after the loop)
   // the ncb column blocks of a row group sit on the same XCD (blocks x and x + 8): its L2 serves the rows to both
   const int bx = (int)blockIdx.x, ncb = g.ncb;
   const int by = (bx >> 3) % ncb, grp = (bx & 7) + 8 * (bx / (8 * ncb));
@@ -842,8 +843,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
     if (NT == 3) { tap_step(WsTap_<NT == 3 ? 1 : 0>{}); tap_step(WsTap_<NT == 3 ? 2 : 0>{}); }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
-    gemm_epilogue_vec<false, false, true>(g, acc0, acc1, m0, by, b, cs, 36, 0u, 1.f, red, bias_s);
+    gemm_epilogue_vec<false, false, true>(g, acc0, acc1, m0, by, b, cs, 36, 0u, 1.f, red, bias_s, {}, &ymax);
     if (d.epilogue & SE_EPI_STATS) __syncthreads();      // `red` is reused by the next tile
+  }
+  if (g.amax_out) {
+    ymax = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0) amax_raise_(g.amax_out, ymax);
   }
 }
 
@@ -861,6 +866,7 @@ __global__ __launch_bounds__(512, 1) void gemm_k64_wstat_kernel(GemmArgs g) {
   const se_gemm_desc& d = g.d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int Mb = d.To * d.Fo;                      // row GEMM: B == 1
+  float ymax = 0.f;                                // max |stored value| over all tiles of this wave (raised once, after the loop)
   const int ncb = g.ncb, NR = ncb * 64, PB = NR * SB;
   __bf16* Bp = reinterpret_cast<__bf16*>(smem_ws);                                   // [2 planes][NR][SB]
   float* patch = reinterpret_cast<float*>(smem_ws + (size_t)2 * PB * 2);              // [8 waves][32][36]
@@ -951,9 +957,13 @@ __global__ __launch_bounds__(512, 1) void gemm_k64_wstat_kernel(GemmArgs g) {
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
-      if (vec_ep) gemm_epilogue_vec<false, false, true>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, nullptr, bias_all + by * 64);
+      if (vec_ep) gemm_epilogue_vec<false, false, true>(g, acc0, acc1, m0, by, 0, cs, 36, thr, inv_keep, nullptr, bias_all + by * 64, {}, &ymax);
       else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, 0, cs, 36, bias_all + by * 64);
     }
+  }
+  if (g.amax_out) {
+    ymax = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0) amax_raise_(g.amax_out, ymax);
   }
 }
 

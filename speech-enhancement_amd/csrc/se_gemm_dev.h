@@ -139,7 +139,8 @@ template <bool HASPRE = false, bool HOISTR = true, bool NOLOAD = false>      // 
 static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
                                                          int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
                                                          float inv_keep, float* red, const float* bias_s,
-                                                         const float4 (&pre)[8] = {}) {   // pre[nt*4+i]: AUX / R values fetched early
+                                                         const float4 (&pre)[8] = {},     // pre[nt*4+i]: AUX / R values fetched early
+                                                         float* vmax_defer = nullptr) {   // persistent callers: see below
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Mb = d.To * d.Fo, ep = NOLOAD ? (d.epilogue & ~(SE_EPI_ACCUM | SE_EPI_RESID | SE_EPI_SWISH_GRAD)) : d.epilogue;
@@ -238,7 +239,11 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
       }
     }
   }
-  if (g.amax_out) {                                  // (wave-uniform pointer test; one guarded atomic per wave)
+  // A PERSISTENT kernel passes vmax_defer and raises the scalar once, after its tile loop: amax_raise_ starts with a plain load whose
+  // result is needed at once -- s_waitcnt vmcnt(0) in the middle of the loop, which also drains the next tile's prefetch and this
+  // tile's stores (found in the ISA of gemm_k64_wstat_kernel, round 5)
+  if (vmax_defer) *vmax_defer = fmaxf(*vmax_defer, vmax);
+  else if (g.amax_out) {                             // (wave-uniform pointer test; one guarded atomic per wave)
     vmax = wave_max(vmax);
     if (lane == 0) amax_raise_(g.amax_out, vmax);
   }
