@@ -25,7 +25,12 @@ extern "C" {
 /* prologue applied to the A operand while it is staged into LDS */
 enum { SE_PRO_NONE = 0, SE_PRO_LN = 1, SE_PRO_SWISH = 2, SE_PRO_AFFINE_SWISH = 3,
        SE_PRO_SWISH_DROP = 4,   /* swish then dropout (nn.Dropout after Swish, models/conformer.py:139)  */
-       SE_PRO_DROP = 5 };       /* dropout only (backward of an output dropout: mask * dY as the A operand) */
+       SE_PRO_DROP = 5,         /* dropout only (backward of an output dropout: mask * dY as the A operand) */
+       SE_PRO_GATE = 6 };       /* CDiffuSE residual block (models/DiffuSE.py:117-122) as the prologue of its 1 x 1 output projection: the A
+                                   operand is y2[c] = sigmoid(zg[c]) tanh(zf[c]), z = GroupNorm(R) + conditioner, built from rows of
+                                   A = R [.., 128] (gate half | filter half, lda = 128), AUX = conditioner rows (same layout) and
+                                   pro_scale = the GroupNorm (scale, shift) pairs [B][128][2]; C = 64, 1-D maps, precision 3 with a static
+                                   a_sexp (|y2| < 1), N = 128: y2 never goes to memory */
 /* epilogue flags (bit mask) */
 enum {
   SE_EPI_BIAS = 1,       /* + bias[n]                                                   */

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('SE_HIP_LIB') or os.path.join(HERE, 'libse_hip.so')
 SE_MAX_TAPS = 16
 
-PRO_NONE, PRO_LN, PRO_SWISH, PRO_AFFINE_SWISH, PRO_SWISH_DROP, PRO_DROP = 0, 1, 2, 3, 4, 5
+PRO_NONE, PRO_LN, PRO_SWISH, PRO_AFFINE_SWISH, PRO_SWISH_DROP, PRO_DROP, PRO_GATE = 0, 1, 2, 3, 4, 5, 6
 EPI_BIAS, EPI_ACCUM, EPI_RESID, EPI_GLU, EPI_STATS, EPI_SWISH_GRAD, EPI_SHUFFLE2, EPI_DROP = 1, 2, 4, 8, 16, 32, 64, 128
 EPI_ROWSTATS = 512
 EPI_GLU_GATE = 2048

@@ -737,8 +737,13 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : ((PRE2 || NPL == 3) ? 1 : K64_OC
 // the A rows of the next tap / next tile (one tap's fragments = 32 VGPRs) are in flight during the 24 MFMAs of the
 // current tap.  LDS 51 KB (+ the epilogue patch 18 KB): two workgroups per CU.
 template <int V> struct WsTap_ { static constexpr int value = V; };
-template <int NT>
+// GATE (NT == 1, SE_PRO_GATE): the rows of the A operand are BUILT while they are staged -- y2 = sigmoid(GN(R)[gate] + cond[gate]) *
+// tanh(GN(R)[filter] + cond[filter]) from the rows of R (g.A, 128 floats) and of the conditioner (g.AUX), GroupNorm (scale, shift) pairs of
+// the batch entry from LDS: the CDiffuSE gate kernel (read 4 planes, write 1) and the projection's read of its result disappear
+template <int NT, bool GATE = false>
 __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, int ngroups) {
+  static_assert(!GATE || NT == 1, "the gate prologue belongs to the 1 x 1 projection");
+  __shared__ __attribute__((aligned(16))) float ss_s[GATE ? 256 : 4];      // GATE: [128 channels][scale, shift] of the tile's batch entry
   constexpr int SW = NT * 64 + 8, PW = 64 * SW;    // 64 + 8 / 192 + 8 bf16 per W row: 16-B chunks at an odd stride
   __shared__ __attribute__((aligned(16))) __bf16 Wl[2 * PW];
   __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 36];
@@ -790,6 +795,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
   // the NEXT tile right after its split -- a whole tile (3 x 24 MFMAs + the epilogue) of distance (one tap ahead measured the
   // same: the load latency is not what bounds this kernel)
   float4 v[NT][4][2];
+  float4 vx[GATE ? 3 : 1][4][2];                       // GATE: filter half of R, gate half / filter half of the conditioner
   bool vok[NT];
   auto request = [&](int kk, auto TP) {
     constexpr int tp = decltype(TP)::value;
@@ -804,17 +810,38 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
       v[tp][ks][0] = *reinterpret_cast<const float4*>(ap + 16 * ks);
       v[tp][ks][1] = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
     }
+    if constexpr (GATE) {
+      const float* __restrict__ cp = g.AUX + ((long)b * Mb + (vok[tp] ? srow : 0)) * d.ldx + d.x_off + 8 * kg;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        vx[0][ks][0] = *reinterpret_cast<const float4*>(ap + 64 + 16 * ks);
+        vx[0][ks][1] = *reinterpret_cast<const float4*>(ap + 64 + 16 * ks + 4);
+        vx[1][ks][0] = *reinterpret_cast<const float4*>(cp + 16 * ks);
+        vx[1][ks][1] = *reinterpret_cast<const float4*>(cp + 16 * ks + 4);
+        vx[2][ks][0] = *reinterpret_cast<const float4*>(cp + 64 + 16 * ks);
+        vx[2][ks][1] = *reinterpret_cast<const float4*>(cp + 64 + 16 * ks + 4);
+      }
+    }
   };
   if (k0 < ntile) {
     request(k0, WsTap_<0>{});
     if (NT == 3) { request(k0, WsTap_<NT == 3 ? 1 : 0>{}); request(k0, WsTap_<NT == 3 ? 2 : 0>{}); }
   }
+  int b_staged = -1;
   for (int kk = k0; kk < ntile; kk += gx) {
     const int tile = xbase + kk;
     const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    if constexpr (GATE) {                                // the batch entry's GroupNorm pairs (b is uniform over the workgroup)
+      if (b != b_staged) {
+        __syncthreads();
+        ss_s[tid] = g.ps[(long)b * 256 + tid];
+        __syncthreads();
+        b_staged = b;
+      }
+    }
     auto tap_step = [&](auto TP) {
       constexpr int tp = decltype(TP)::value;
       bf16x8 af[4][2];
@@ -823,6 +850,23 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
         const bool ok = vok[tp];
         float x[8] = {ok ? v[tp][ks][0].x : 0.f, ok ? v[tp][ks][0].y : 0.f, ok ? v[tp][ks][0].z : 0.f, ok ? v[tp][ks][0].w : 0.f,
                       ok ? v[tp][ks][1].x : 0.f, ok ? v[tp][ks][1].y : 0.f, ok ? v[tp][ks][1].z : 0.f, ok ? v[tp][ks][1].w : 0.f};
+        if constexpr (GATE) {
+          const float fr[8] = {vx[0][ks][0].x, vx[0][ks][0].y, vx[0][ks][0].z, vx[0][ks][0].w, vx[0][ks][1].x, vx[0][ks][1].y, vx[0][ks][1].z, vx[0][ks][1].w};
+          const float cg[8] = {vx[1][ks][0].x, vx[1][ks][0].y, vx[1][ks][0].z, vx[1][ks][0].w, vx[1][ks][1].x, vx[1][ks][1].y, vx[1][ks][1].z, vx[1][ks][1].w};
+          const float cf[8] = {vx[2][ks][0].x, vx[2][ks][0].y, vx[2][ks][0].z, vx[2][ks][0].w, vx[2][ks][1].x, vx[2][ks][1].y, vx[2][ks][1].z, vx[2][ks][1].w};
+          const float* sg = ss_s + 2 * (16 * ks + 8 * kg);      // (scale, shift) pairs of this lane's 8 gate channels; filter: + 128
+#pragma unroll
+          for (int j = 0; j < 8; j += 2) {
+            const float4 pg = *reinterpret_cast<const float4*>(sg + 2 * j), pf = *reinterpret_cast<const float4*>(sg + 128 + 2 * j);
+            const float zg0 = fmaf(x[j], pg.x, pg.y) + cg[j], zg1 = fmaf(x[j + 1], pg.z, pg.w) + cg[j + 1];
+            const float zf0 = fmaf(fr[j], pf.x, pf.y) + cf[j], zf1 = fmaf(fr[j + 1], pf.z, pf.w) + cf[j + 1];
+            // sigmoid(zg) tanh(zf) = (1 - 2 / (1 + e^{2 zf})) / (1 + e^{-zg}): hardware exp2 / rcp (~1 ulp each)
+            const float t0 = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * zf0));
+            const float t1 = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * zf1));
+            x[j] = ok ? sigmoidf_(zg0) * t0 : 0.f;
+            x[j + 1] = ok ? sigmoidf_(zg1) * t1 : 0.f;
+          }
+        }
         split_planes8_h(x, sa, af[ks]);
       }
       if (kk + gx < ntile) request(kk + gx, TP);
@@ -1060,15 +1104,22 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                       d->prologue == SE_PRO_NONE && !(ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) && d->ldw == 192;
     // enough row tiles for a persistent sweep: the W-stationary kernel (weights of a column block resident in LDS)
     static const bool no_wstat = getenv("SE_GEMM_NO_WSTAT") != nullptr;
-    if (map1d && (tap3 || (lin && d->precision == 3 && d->w_planes && d->prologue == SE_PRO_NONE && d->ldw == 64)) && d->C == 64 && vec_st &&
-        !(ep & (SE_EPI_ACCUM | SE_EPI_DROP | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ROWSTATS)) && (long)d->B * g.tiles >= 2048 &&
-        (d->w_planes % 8) == 0 && !no_wstat) {
+    const bool gate = d->prologue == SE_PRO_GATE;
+    if (gate)
+      SE_REQUIRE(map1d && lin && d->precision == 3 && d->w_planes && d->ldw == 64 && d->C == 64 && d->lda >= 128 && d->ldx >= 128 && (d->ldx & 3) == 0 &&
+                 (d->x_off & 3) == 0 && AUX && pro_scale && !d->a_amax && vec_st && (d->w_planes % 8) == 0 &&
+                 !(ep & (SE_EPI_ACCUM | SE_EPI_DROP | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ROWSTATS)),
+                 "gemm: SE_PRO_GATE needs a 1-D row GEMM with C = 64, 128-wide A / AUX rows, scaled fp16 weight planes, a static a_sexp");
+    if (map1d && (tap3 || (lin && d->precision == 3 && d->w_planes && (d->prologue == SE_PRO_NONE || gate) && d->ldw == 64)) && d->C == 64 && vec_st &&
+        !(ep & (SE_EPI_ACCUM | SE_EPI_DROP | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ROWSTATS)) && ((long)d->B * g.tiles >= 2048 || gate) &&
+        (d->w_planes % 8) == 0 && (!no_wstat || gate)) {
       int ngroups = 512 / ncols < 8 ? 8 : 512 / ncols;
       if (const char* e = getenv("SE_WSTAT_GROUPS")) { int v = atoi(e); if (v >= 8) ngroups = v; }
       if ((long)ngroups > (long)d->B * g.tiles) ngroups = d->B * g.tiles;
       ngroups = (ngroups + 7) / 8 * 8;
       const dim3 wgrid((unsigned)(ncols * ngroups));
       if (tap3) hipLaunchKernelGGL(conv1d_k64_wstat_kernel<3>, wgrid, block, 0, s, g, ngroups);
+      else if (gate) hipLaunchKernelGGL((conv1d_k64_wstat_kernel<1, true>), wgrid, block, 0, s, g, ngroups);
       else hipLaunchKernelGGL(conv1d_k64_wstat_kernel<1>, wgrid, block, 0, s, g, ngroups);
       return se_check_launch("se_gemm_tap(W-stationary 1-D)");
     }

@@ -27,6 +27,9 @@ from . import gemm as GM
 from . import layers as LY
 from .weights import WeightPlan
 
+# SE_DIFF_GATE_FUSED=0: the stand-alone gate kernel in front of the projection GEMM
+GATE_FUSED = os.environ.get('SE_DIFF_GATE_FUSED', '1') != '0'
+
 _i, _l, _f, _d = C.c_int, C.c_long, C.c_float, C.c_double
 
 
@@ -203,13 +206,20 @@ class DiffuSE(nn.Module):
             gn = blk.dilated_conv[1]
             L.call('se_group_finalize', L.ptr(st), _i(B), _i(2 * Cc), _i(0), _i(2 * Cc), _i(16), _d(float(Lp)), L.ptr(gn.weight),
                    L.ptr(gn.bias), L.ptr(ss), _f(gn.eps), L.stream())
-            L.call('se_diff_gate', L.ptr(R), L.ptr(ss), L.ptr(cond[i]), L.ptr(y2), _i(B), _l(Lp), _i(Cc), L.stream())
             st2 = st_all[i, 1]
-            if f16:
+            if f16 and GATE_FUSED:
+                # the gate as the PROLOGUE of the projection (SE_PRO_GATE, round 5): y2 = sigmoid * tanh of GroupNorm(R) + conditioner is
+                # built while the rows are staged and never goes to memory (17 -> 15 plane passes per layer)
+                d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, 2 * Cc, 2 * Cc, 2 * Cc, ldw=Cc, ldx=2 * Cc, prologue=L.PRO_GATE,
+                                  epilogue=L.EPI_BIAS | L.EPI_STATS, precision=3, a_sexp=13)
+                GM.gemm_tap(d2, R, lay['w216'], R2, bias=lay['b2'], AUX=cond[i], ps=ss, stats=st2)
+            elif f16:
+                L.call('se_diff_gate', L.ptr(R), L.ptr(ss), L.ptr(cond[i]), L.ptr(y2), _i(B), _l(Lp), _i(Cc), L.stream())
                 d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
                                   precision=3, a_sexp=13)
                 GM.gemm_tap(d2, y2, lay['w216'], R2, bias=lay['b2'], stats=st2)
             else:
+                L.call('se_diff_gate', L.ptr(R), L.ptr(ss), L.ptr(cond[i]), L.ptr(y2), _i(B), _l(Lp), _i(Cc), L.stream())
                 d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS,
                                   precision=min(LY.CONV_PRECISION, 2))
                 GM.gemm_tap(d2, y2, lay['w2'], R2, bias=lay['b2'], stats=st2)
