@@ -155,3 +155,42 @@ def test_diffuse_bench_size_parts_on_streams_match_serial():
     perm = rng.permutation(B)
     yp = S.predict_diffuse(m, cfg, x[perm], *sched, noises=nz[:, perm], streams=2)
     assert np.abs(yp - y1[perm]).max() < 1e-5 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,Lp', [(1, 128), (3, 1000), (2, 4133)])
+def test_gate_prologue_projection_vs_fp64(B, Lp):
+    """SE_PRO_GATE (csrc/se_gemm.hip, conv1d_k64_wstat_kernel<1, true>): the residual block's gate built in the prologue of its 1 x 1
+    projection -- R2 = W2 (sigmoid(GN(R)[:C] + cond[:C]) * tanh(GN(R)[C:] + cond[C:])) + b2 and the GroupNorm sums of R2 -- against
+    fp64 torch and against the stand-alone gate kernel + the same GEMM; one tile, ragged last tiles, several batch entries"""
+    import ctypes as C
+    from speech_enhancement_amd import _lib as L, gemm as GM
+    from speech_enhancement_amd.weights import WeightPlan
+    dev = torch.device('cuda')
+    torch.manual_seed(B * 7 + Lp)
+    Cc = 64
+    R = torch.randn(B, Lp, 2 * Cc, device=dev) * 1.5
+    cond = torch.randn(B, Lp, 2 * Cc, device=dev)
+    ss = torch.stack([torch.rand(B, 2 * Cc, device=dev) + 0.5, torch.randn(B, 2 * Cc, device=dev) * 0.3], -1).contiguous()   # (scale, shift)
+    W2, b2 = torch.randn(2 * Cc, Cc, device=dev) * 0.2, torch.randn(2 * Cc, device=dev) * 0.1
+    plan = WeightPlan(dev)
+    w16 = plan.linear('w2', W2, planes='f16')
+    plan.run()
+    z = R.double() * ss[..., 0].double()[:, None, :] + ss[..., 1].double()[:, None, :] + cond.double()
+    y2 = torch.sigmoid(z[..., :Cc]) * torch.tanh(z[..., Cc:])
+    ref = y2 @ W2.double().t() + b2.double()
+    out, st = torch.empty(B, Lp, 2 * Cc, device=dev), torch.zeros(B, 2 * Cc, 2, device=dev, dtype=torch.float64)
+    d = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, 2 * Cc, 2 * Cc, 2 * Cc, ldw=Cc, ldx=2 * Cc, prologue=L.PRO_GATE,
+                     epilogue=L.EPI_BIAS | L.EPI_STATS, precision=3, a_sexp=13)
+    GM.gemm_tap(d, R, w16, out, bias=b2, AUX=cond, ps=ss, stats=st)
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) < 2e-6 * scale
+    assert float((st[..., 0] - ref.sum(1)).abs().max()) < 1e-6 * scale * Lp
+    assert float((st[..., 1] - (ref ** 2).sum(1)).abs().max()) < 2e-6 * scale * scale * Lp
+    # the two-launch path (gate kernel + the same projection kernel without prologue)
+    y2k = torch.empty(B, Lp, Cc, device=dev)
+    L.call('se_diff_gate', L.ptr(R), L.ptr(ss), L.ptr(cond), L.ptr(y2k), C.c_int(B), C.c_long(Lp), C.c_int(Cc), L.stream())
+    out2, st2 = torch.empty_like(out), torch.zeros_like(st)
+    d2 = GM.make_desc(B, 1, Lp, 1, Lp, [(0, 0)], Cc, Cc, 2 * Cc, 2 * Cc, epilogue=L.EPI_BIAS | L.EPI_STATS, precision=3, a_sexp=13)
+    GM.gemm_tap(d2, y2k, w16, out2, bias=b2, stats=st2)
+    assert float((out - out2).abs().max()) < 2e-6 * scale
