@@ -220,6 +220,28 @@ def dw_bench(argv):
             print(f'{axis:5s} {name:10s} {dt*1e6:8.1f} us  {(5 if name in ("dgrad+glu", "bwd fused") else 2)*x.numel()*4/dt/1e9:7.0f} GB/s', flush=True)
 
 @cmd
+def normbwd_one(argv):
+    """InstanceNorm + PReLU backward (reduce + apply launches) at the dense-block shape of the step: B = 16, 321 x 101 pixels, C = 64, the
+    operands living in 256-wide skip slabs like in the model"""
+    import time, torch
+    from speech_enhancement_amd import ops as O
+    B, P, C = 16, 321 * 101, 64
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    x = torch.randn(B, P, C, device=dev); dy = torch.randn(B, P, 256, device=dev); dx = torch.empty(B, P, C, device=dev)
+    mr = torch.stack([x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)], -1).contiguous()
+    g, be, sl = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1, torch.full((C,), 0.25, device=dev)
+    dg, db, ds = torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    am = torch.zeros(1, device=dev)
+    f = lambda: O.norm_prelu_bwd(x, C, 0, mr, g, be, sl, dy, 256, 64, dx, C, 0, dg, db, ds, B, P, C, amax=am)
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(20): f()
+    torch.cuda.synchronize(); dt = (time.time() - t0) / 20
+    print(f'norm_prelu_bwd reduce + apply: {dt*1e6:7.1f} us  ({5 * 4.0 * B * P * C / dt / 1e9:6.0f} GB/s over 5 plane passes)', flush=True)
+
+
+@cmd
 def lnbwd_one(argv):
     """se_gemm_ln_bwd_wgrad at the benchmark shape (M = 16 * 321 * 101 rows; K = 192: qkv, 256: pointwise-GLU)"""
     import time, torch
