@@ -1537,7 +1537,14 @@ __global__ __launch_bounds__(256) void attn_de_reduce_items_kernel(const float* 
 // output by one multiply per element at the end.
 template <int V> struct IC_ { static constexpr int value = V; };
 template <int TQ, bool F16 = false>
-__global__ __launch_bounds__(512) void attn_fwd3_kernel(AttnArgs a, int NP, int qsplit) {
+// packed fp32 VALU ops allowed in THIS kernel (se_common.h): it is VALU-bound (83 % VALU-busy, 36 % MFMA-busy); halving the issue slots of
+// part of its softmax chain pays for the matrix-pipe stalls: 0.681 -> 0.651 ms (n = 321), 0.270 -> 0.263 (n = 101); SE_ATTN_FWD_NO_PK builds: off
+#ifdef SE_ATTN_FWD_NO_PK
+#define ATTN_FWD_PK_ATTR
+#else
+#define ATTN_FWD_PK_ATTR SE_PACKED_FP32_KERNEL
+#endif
+__global__ __launch_bounds__(512) ATTN_FWD_PK_ATTR void attn_fwd3_kernel(AttnArgs a, int NP, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
   static_assert(TQ == 1 || TQ == 2, "the offset-fragment ring of key_step is indexed by the step parity");
   constexpr int NPLA = F16 ? 2 : 3;

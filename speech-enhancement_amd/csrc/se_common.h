@@ -4,6 +4,15 @@
 #include <stdio.h>
 #include "../../include/se_hip.h"
 
+// Packed fp32 VALU ops (v_pk_mul / add / fma_f32) for ONE kernel of a translation unit that is built without them (build.py: they
+// run on the matrix pipe and stall the MFMAs of the SIMD): worth it where the vector unit, not the matrix pipe, is the busy one --
+// measured per kernel (attention forward: 0.681 -> 0.651 ms).
+// (tried on ff_fwd_kernel and ff_bwd_fused_kernel too: no gain, 57.16 vs 57.22 / 57.10 vs 57.03 ms per step same box.)
+#ifdef __HIP_DEVICE_COMPILE__
+#define SE_PACKED_FP32_KERNEL __attribute__((target("packed-fp32-ops")))
+#else
+#define SE_PACKED_FP32_KERNEL            /* the host pass does not know the feature name */
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
