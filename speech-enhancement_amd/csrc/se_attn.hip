@@ -1677,8 +1677,8 @@ __global__ __launch_bounds__(512) ATTN_FWD_PK_ATTR void attn_fwd3_kernel(AttnArg
           sc[r] = (!MASK || j0 + 4 * g + r < n) ? lg : -1e30f;
           tmax = fmaxf(tmax, sc[r]);
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = xor16_max_(tmax);                             // (VALU row swaps, not ds_bpermute: se_common.h)
+        tmax = xor32_max_(tmax);
         // F16: the running reference m moves only when some query of the tile outgrows it by more than 2^LAZY (wave-uniform test):
         // after the first key tiles that is rare, and the rescale of o / l (an exp2, 5 multiplies) and its dependency on this
         // tile's maximum leave the chain.  p <= 2^LAZY then, so P's fp16 scale is 2^(13 - LAZY) (hi plane <= 2^13).
@@ -1710,8 +1710,8 @@ __global__ __launch_bounds__(512) ATTN_FWD_PK_ATTR void attn_fwd3_kernel(AttnArg
 #pragma unroll
     for (int t = 0; t < TQ; ++t) {
       float lt = l[t];
-      lt += __shfl_xor(lt, 16, 64);
-      lt += __shfl_xor(lt, 32, 64);
+      lt = xor16_sum_(lt);
+      lt = xor32_sum_(lt);
       const int qi = i0 + 16 * t + c;
       if (qi < n) {
         const long tok = base + (long)qi * ps;

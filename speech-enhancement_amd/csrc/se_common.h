@@ -34,6 +34,29 @@ static __device__ __forceinline__ float swish_gradf_(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// xor-16 / xor-32 butterfly steps on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange the odd 16- (32-) lane rows of
+// one register with the even rows of another -- applied to two copies of v, the two results hold (own row's value, partner row's
+// value) in some order on every lane, so a COMMUTATIVE combine of them is the butterfly step.  __shfl_xor(v, 16 | 32) is a
+// ds_bpermute_b32 through the LDS crossbar: ~100 cycles of latency each, and in the attention kernels they sit on the softmax chain
+// (tile maximum -> rescale decision -> exp2).  Checked against __shfl_xor on the device: tools/micro/permlane_chk.hip.
+typedef unsigned u32x2sw_ __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ float xor32_max_(float v) {
+  const u32x2sw_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float xor16_max_(float v) {
+  const u32x2sw_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+static __device__ __forceinline__ float xor32_sum_(float v) {
+  const u32x2sw_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+static __device__ __forceinline__ float xor16_sum_(float v) {
+  const u32x2sw_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // full-wave (64-lane) butterfly sum
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

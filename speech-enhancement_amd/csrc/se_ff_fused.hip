@@ -120,8 +120,9 @@ static __device__ __forceinline__ void ff_fused_D(const FfFusedArgs& a, unsigned
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float sg = ag[e], sb = ab[e];
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
+      sg += __shfl_xor(sg, 8, 64); sb += __shfl_xor(sb, 8, 64);
+      sg = xor16_sum_(sg); sb = xor16_sum_(sb);
+      sg = xor32_sum_(sg); sb = xor32_sum_(sb);
       agk += err == e ? sg : 0.f;
       abk += err == e ? sb : 0.f;
     }

@@ -232,7 +232,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
     if (ep & SE_EPI_STATS) {      // fold the 8 row-lanes that share this column group, park per-wave partials in LDS
       float sv[8] = {ssum.x, ssum.y, ssum.z, ssum.w, qsum.x, qsum.y, qsum.z, qsum.w};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { sv[k] += __shfl_xor(sv[k], 8, 64); sv[k] += __shfl_xor(sv[k], 16, 64); sv[k] += __shfl_xor(sv[k], 32, 64); }
+      for (int k = 0; k < 8; ++k) { sv[k] += __shfl_xor(sv[k], 8, 64); sv[k] = xor16_sum_(sv[k]); sv[k] = xor32_sum_(sv[k]); }
       if (rr == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { red[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sv[j]; red[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sv[4 + j]; }

@@ -226,8 +226,8 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float sg = ag[e], sb = ab[e];
-        sg += __shfl_xor(sg, 16, 64); sb += __shfl_xor(sb, 16, 64);
-        sg += __shfl_xor(sg, 32, 64); sb += __shfl_xor(sb, 32, 64);
+        sg = xor16_sum_(sg); sb = xor16_sum_(sb);
+        sg = xor32_sum_(sg); sb = xor32_sum_(sb);
         agk += (srow & 3) == e ? sg : 0.f;
         abk += (srow & 3) == e ? sb : 0.f;
       }
