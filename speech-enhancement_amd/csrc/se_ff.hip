@@ -33,6 +33,13 @@ template <int NPL, bool WPL = false, int NB = 0, bool F16 = false, bool STH = tr
 __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 workgroups per CU: VGPR + AGPR <= 256
   static_assert(!F16 || (WPL && NPL == 2), "the scaled split-fp16 kernels read pre-split fp16 planes");
   constexpr int SB = 72, PB = 64 * SB, SP = 36;
+  // CHAIN (round 5; the default form: scaled fp16, H not stored): the hidden block never leaves the registers between the two GEMMs.
+  // GEMM 1 runs TRANSPOSED (A = the W1 rows, B = the LayerNorm rows), so a lane holds 16 hidden units of ITS token row per 32-unit
+  // half: (r & 3) + 8 (r >> 2) + 4 kg -- after bias / Swish / dropout exactly the eight values per k-group that a row fragment of
+  // GEMM 2 needs, if GEMM 2 contracts the hidden units of a 16-block in the order [0-3, 8-11 | 4-7, 12-15]: the W2 block is staged
+  // into LDS in that order (two 8-byte writes per chunk instead of one 16-byte write).  Gone: the 32 x 32 transposes through the
+  // wave's LDS patch (16 ds_write_b32 + 4 ds_read_b128 per half and block) and the LDS round trip between the matrix products.
+  constexpr bool CHAIN = F16 && !STH;
   __shared__ __attribute__((aligned(16))) __bf16 W1p[NPL * PB];
   __shared__ __attribute__((aligned(16))) __bf16 W2p[NPL * PB];
   __shared__ __attribute__((aligned(16))) float patch[4 * 32 * SP];    // wave-private 32 x 32 transposes
@@ -152,7 +159,15 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           *reinterpret_cast<f32x4*>(&W1p[q * PB + pr * SB + 8 * pc + 32 * h]) = rp1[q * 2 + h];
-          *reinterpret_cast<f32x4*>(&W2p[q * PB + pr * SB + 8 * pc + 32 * h]) = rp2[q * 2 + h];
+          if constexpr (CHAIN) {      // chunk c = pc + 4 h (hidden 8 c .. + 7) -> 16-block c >> 1, groups of four at 4 (c & 1) and 8 + 4 (c & 1)
+            typedef float f32x2c_ __attribute__((ext_vector_type(2)));
+            const int c = pc + 4 * h, at = 16 * (c >> 1) + 4 * (c & 1);
+            const f32x4 v = rp2[q * 2 + h];
+            *reinterpret_cast<f32x2c_*>(&W2p[q * PB + pr * SB + at]) = (f32x2c_){v[0], v[1]};
+            *reinterpret_cast<f32x2c_*>(&W2p[q * PB + pr * SB + at + 8]) = (f32x2c_){v[2], v[3]};
+          } else {
+            *reinterpret_cast<f32x4*>(&W2p[q * PB + pr * SB + 8 * pc + 32 * h]) = rp2[q * 2 + h];
+          }
         }
     } else {
 #pragma unroll
@@ -179,9 +194,53 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
       for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
         for (int qa = 0; qa <= ord; ++qa) {
-          acc0 = mfma32_<F16>(af1[ks][qa], bf0[ord - qa], acc0);
-          acc1 = mfma32_<F16>(af1[ks][qa], bf1[ord - qa], acc1);
+          if constexpr (CHAIN) {      // H^T: hidden units down the accumulator rows, token rows across the lanes
+            acc0 = mfma32_<F16>(bf0[ord - qa], af1[ks][qa], acc0);
+            acc1 = mfma32_<F16>(bf1[ord - qa], af1[ks][qa], acc1);
+          } else {
+            acc0 = mfma32_<F16>(af1[ks][qa], bf0[ord - qa], acc0);
+            acc1 = mfma32_<F16>(af1[ks][qa], bf1[ord - qa], acc1);
+          }
         }
+    }
+    if constexpr (CHAIN) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {            // k-step 2 nt + j of GEMM 2: accumulator registers 8 j .. 8 j + 7 of this half
+          const int ks = 2 * nt + j;
+          float x[8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int q = 2 * j + h;              // quad: hidden 32 nt + 8 q + 4 kg .. + 3 of the block
+            const int hu = 32 * nt + 8 * q + 4 * kg;
+            const float4 b4 = *reinterpret_cast<const float4*>(&b1s[hu]);
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (dr) sc = drop_scale4(a.seed_h, (unsigned)(row * a.hid + jb * 64 + hu), thr, inv_keep);
+            const f32x16& ac = nt ? acc1 : acc0;
+            x[4 * h] = swishf_(fmaf(ac[4 * q], u1, b4.x)) * sc.x;
+            x[4 * h + 1] = swishf_(fmaf(ac[4 * q + 1], u1, b4.y)) * sc.y;
+            x[4 * h + 2] = swishf_(fmaf(ac[4 * q + 2], u1, b4.z)) * sc.z;
+            x[4 * h + 3] = swishf_(fmaf(ac[4 * q + 3], u1, b4.w)) * sc.w;
+          }
+          bf16x8 af2[NPL], bf0[NPL], bf1[NPL];
+          split_planes8_h(x, s_mid, af2);
+#pragma unroll
+          for (int pl = 0; pl < NPL; ++pl) {
+            bf0[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + frag + 16 * ks]);
+            bf1[pl] = *reinterpret_cast<const bf16x8*>(&W2p[pl * PB + 32 * SB + frag + 16 * ks]);
+          }
+#pragma unroll
+          for (int ord = NPL - 1; ord >= 0; --ord)
+#pragma unroll
+            for (int qa = 0; qa <= ord; ++qa) {
+              y0 = mfma32_<F16>(af2[qa], bf0[ord - qa], y0);
+              y1 = mfma32_<F16>(af2[qa], bf1[ord - qa], y1);
+            }
+        }
+      }
+      __syncthreads();
+      continue;
     }
     const float bb0 = b1s[col], bb1 = b1s[32 + col];
     // per 32-column half of the block: transpose through the wave's patch, write H, re-split, second GEMM
@@ -287,6 +346,184 @@ __global__ __launch_bounds__(256, 2) void ff_fwd_kernel(FfArgs a) {    // 2 work
       sq += __shfl_xor(sq, 1, 64); sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 4, 64);
       if (cq == 0 && ok) *reinterpret_cast<float2*>(a.out_stats + 2 * rg) = make_float2(mean, rsqrtf(sq * (1.f / 64.f) + 1e-5f));
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 5: the default forward (scaled fp16, hid = 256, H not stored) as a W-STATIONARY, barrier-free persistent kernel.
+// ff_fwd_kernel re-stages the four weight blocks of both matrices for every 128 rows (128 KB of L2 -> LDS traffic and eight barriers
+// per workgroup) and runs at ~200 us against ~90 us of vector work and ~46 us of matrix work.  Here ALL of W1 and W2 (two fp16
+// planes each: 141 KB) sit in LDS for the whole launch, one 8-wave workgroup per CU; after the one barrier behind the staging every
+// wave runs on its own: 32-row tiles, GEMM 1 transposed and the hidden block chained through registers into GEMM 2 (CHAIN above),
+// GEMM 2 transposed as well -- Y^T[out][token] -- so that a lane ends with 32 of the 64 channels of ITS token: bias, dropout,
+// residual, the row statistics (one v_permlane32_swap per sum) and the 16-byte stores all happen in registers.  The input channels
+// are contracted in the same permuted order as the hidden units ([0-3, 8-11 | 4-7, 12-15] per 16-block), which makes the residual
+// registers and the LayerNorm prologue registers THE SAME eight float4 (X is read once).  No LDS traffic besides the weight fragments.
+constexpr int FW_SB1 = 72, FW_P1 = 256 * FW_SB1;       // W1 image: [256 hidden][64 channel positions], halves
+constexpr int FW_SB2 = 264, FW_P2 = 64 * FW_SB2;       // W2 image: [64 outputs][256 hidden positions]
+constexpr int FW_O_W2 = 2 * FW_P1 * 2, FW_O_B1 = FW_O_W2 + 2 * FW_P2 * 2, FW_O_B2 = FW_O_B1 + 1024, FW_O_GB = FW_O_B2 + 256;
+constexpr int FW_LDS_BYTES = FW_O_GB + 512;
+
+__global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fw_sm[];
+  __bf16* W1i = reinterpret_cast<__bf16*>(fw_sm);
+  __bf16* W2i = reinterpret_cast<__bf16*>(fw_sm + FW_O_W2);
+  float* b1s = reinterpret_cast<float*>(fw_sm + FW_O_B1);
+  float* b2s = reinterpret_cast<float*>(fw_sm + FW_O_B2);
+  float* gbs = reinterpret_cast<float*>(fw_sm + FW_O_GB);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  typedef float f32x2w_ __attribute__((ext_vector_type(2)));
+  // ---- staging: chunk c of a row's 16-byte chunks (8 consecutive units) -> positions 16 (c >> 1) + 4 (c & 1) and + 8 ----
+  for (int i = tid; i < 2 * 256 * 8; i += 512) {        // W1 planes [2][256][64]
+    const int pl = i >> 11, row = (i >> 3) & 255, c = i & 7;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.W1) + (size_t)pl * 256 * 64 + row * 64 + 8 * c);
+    __bf16* d = W1i + pl * FW_P1 + row * FW_SB1 + 16 * (c >> 1) + 4 * (c & 1);
+    *reinterpret_cast<f32x2w_*>(d) = (f32x2w_){v[0], v[1]};
+    *reinterpret_cast<f32x2w_*>(d + 8) = (f32x2w_){v[2], v[3]};
+  }
+  for (int i = tid; i < 2 * 64 * 32; i += 512) {        // W2 planes [2][64][256]
+    const int pl = i >> 11, row = (i >> 5) & 63, c = i & 31;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(a.W2) + (size_t)pl * 64 * 256 + row * 256 + 8 * c);
+    __bf16* d = W2i + pl * FW_P2 + row * FW_SB2 + 16 * (c >> 1) + 4 * (c & 1);
+    *reinterpret_cast<f32x2w_*>(d) = (f32x2w_){v[0], v[1]};
+    *reinterpret_cast<f32x2w_*>(d + 8) = (f32x2w_){v[2], v[3]};
+  }
+  if (tid < 256) b1s[tid] = a.b1[tid];
+  else if (tid < 320) b2s[tid - 256] = a.b2[tid - 256];
+  else if (tid < 448) gbs[tid - 320] = tid < 384 ? a.gamma[tid - 320] : a.beta[tid - 384];
+  f16_clamp_mode_();
+  const int e1 = operand_sexp_(a.sc.wa_amax, 0), e2 = operand_sexp_(a.sc.wb_amax, 0);
+  const int ein = operand_sexp_(a.sc.in_amax, a.sc.in_sexp), emid = operand_sexp_(a.sc.mid_amax, a.sc.mid_sexp);
+  const float s_in = exp2i_(ein), s_mid = exp2i_(emid), u1 = exp2i_(-ein - e1), u2 = exp2i_(-emid - e2);
+  const unsigned thr = drop_thr(a.drop_p);
+  const float inv_keep = drop_inv_keep(a.drop_p);
+  const bool dr = a.drop_p > 0.f;
+  const int t = lane & 31, kg = lane >> 5;
+  const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X, (unsigned)(a.M * 256)), Sr = make_rsrc_(a.rowstats, (unsigned)(a.M * 8)),
+                               Yr = make_rsrc_(a.Y, (unsigned)(a.M * 256));
+  const __amdgpu_buffer_rsrc_t Or = make_rsrc_(a.out_stats ? a.out_stats : a.Y, a.out_stats ? (unsigned)(a.M * 8) : 0u);
+  __syncthreads();                                       // the only barrier: the images are read-only from here on
+  const long ntile = (a.M + 31) / 32, stride = (long)gridDim.x * 8;
+  // rows of a tile in the quad layout: xq[nt * 4 + q] = X[row][32 nt + 8 q + 4 kg .. + 3]
+  float4 xq[8], xn[8];
+  float2 st, stn;
+  auto request = [&](long tile, float4 (&x)[8], float2& s2) {
+    const long row = tile * 32 + t;                      // (rows past M: out-of-range offsets -> zeros)
+    const unsigned off = (unsigned)(row < a.M ? row * 256 : 0xfffffff0L) + (unsigned)kg * 16u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = buf_load4_(Xr, row < a.M ? off + (unsigned)((i >> 2) * 128 + (i & 3) * 32) : BUF_OOB_);
+    s2 = buf_load2_(Sr, row < a.M ? (unsigned)(row * 8) : BUF_OOB_);
+  };
+  long tile = (long)blockIdx.x * 8 + wave;
+  request(tile, xq, st);
+  for (; tile < ntile; tile += stride) {
+    const long row = tile * 32 + t;
+    // ---- LayerNorm -> B fragments of GEMM 1 (k-step ks = 2 nt + j: quads q = 2 j, 2 j + 1 of half nt) ----
+    bf16x8 af1[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int qi = (ks >> 1) * 4 + 2 * (ks & 1) + h, c = 32 * (ks >> 1) + 8 * (2 * (ks & 1) + h) + 4 * kg;
+        const float4 gm = *reinterpret_cast<const float4*>(&gbs[c]), bt = *reinterpret_cast<const float4*>(&gbs[64 + c]);
+        const float4 w = xq[qi];
+        x[4 * h] = (w.x - st.x) * st.y * gm.x + bt.x; x[4 * h + 1] = (w.y - st.x) * st.y * gm.y + bt.y;
+        x[4 * h + 2] = (w.z - st.x) * st.y * gm.z + bt.z; x[4 * h + 3] = (w.w - st.x) * st.y * gm.w + bt.w;
+      }
+      split_planes8_h(x, s_in, af1[ks]);
+    }
+    f32x16 yT[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { yT[0][r] = 0.f; yT[1][r] = 0.f; }
+#pragma unroll 1
+    for (int jb = 0; jb < 4; ++jb) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 w0[2], w1[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          w0[pl] = *reinterpret_cast<const bf16x8*>(&W1i[pl * FW_P1 + (64 * jb + t) * FW_SB1 + 16 * ks + 8 * kg]);
+          w1[pl] = *reinterpret_cast<const bf16x8*>(&W1i[pl * FW_P1 + (64 * jb + 32 + t) * FW_SB1 + 16 * ks + 8 * kg]);
+        }
+        acc[0] = mfma32_<true>(w0[1], af1[ks][0], acc[0]); acc[1] = mfma32_<true>(w1[1], af1[ks][0], acc[1]);      // smallest terms first
+        acc[0] = mfma32_<true>(w0[0], af1[ks][1], acc[0]); acc[1] = mfma32_<true>(w1[0], af1[ks][1], acc[1]);
+        acc[0] = mfma32_<true>(w0[0], af1[ks][0], acc[0]); acc[1] = mfma32_<true>(w1[0], af1[ks][0], acc[1]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          asm volatile("" ::: "memory");          // one k-step's fragment reads and hashes at a time (all four hoisted: spills)
+          float x[8];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int q = 2 * j + h, hu = 64 * jb + 32 * hh + 8 * q + 4 * kg;      // hidden units hu .. hu + 3 of this token
+            const float4 b4 = *reinterpret_cast<const float4*>(&b1s[hu]);
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (dr) sc = drop_scale4(a.seed_h, (unsigned)(row * 256 + hu), thr, inv_keep);
+            x[4 * h] = swishf_(fmaf(acc[hh][4 * q], u1, b4.x)) * sc.x;
+            x[4 * h + 1] = swishf_(fmaf(acc[hh][4 * q + 1], u1, b4.y)) * sc.y;
+            x[4 * h + 2] = swishf_(fmaf(acc[hh][4 * q + 2], u1, b4.z)) * sc.z;
+            x[4 * h + 3] = swishf_(fmaf(acc[hh][4 * q + 3], u1, b4.w)) * sc.w;
+          }
+          bf16x8 af2[2], v0[2], v1[2];
+          split_planes8_h(x, s_mid, af2);
+          const int pos = 64 * jb + 16 * (2 * hh + j) + 8 * kg;
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+            v0[pl] = *reinterpret_cast<const bf16x8*>(&W2i[pl * FW_P2 + t * FW_SB2 + pos]);
+            v1[pl] = *reinterpret_cast<const bf16x8*>(&W2i[pl * FW_P2 + (32 + t) * FW_SB2 + pos]);
+          }
+          yT[0] = mfma32_<true>(v0[1], af2[0], yT[0]); yT[1] = mfma32_<true>(v1[1], af2[0], yT[1]);
+          yT[0] = mfma32_<true>(v0[0], af2[1], yT[0]); yT[1] = mfma32_<true>(v1[0], af2[1], yT[1]);
+          yT[0] = mfma32_<true>(v0[0], af2[0], yT[0]); yT[1] = mfma32_<true>(v1[0], af2[0], yT[1]);
+        }
+      }
+    }
+    // next tile's rows: requested HERE (the 64 registers of the LayerNorm fragments and of the hidden block are free again; in flight
+    // during the epilogue and, on the SIMD's other wave, its products; past the end nothing is fetched)
+    request(tile + stride, xn, stn);
+    // ---- Y = X + alpha * Drop_o(acc + b2), row statistics: this lane holds channels 32 oh + 8 q + 4 kg + e of token t ----
+    float4 yo[8];
+    float sm = 0.f;
+#pragma unroll
+    for (int oh = 0; oh < 2; ++oh)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = 32 * oh + 8 * q + 4 * kg;
+        const float4 b2v = *reinterpret_cast<const float4*>(&b2s[n]);
+        float4 v = make_float4(fmaf(yT[oh][4 * q], u2, b2v.x), fmaf(yT[oh][4 * q + 1], u2, b2v.y), fmaf(yT[oh][4 * q + 2], u2, b2v.z),
+                               fmaf(yT[oh][4 * q + 3], u2, b2v.w));
+        if (dr) {
+          const float4 d4 = drop_scale4(a.seed_o, (unsigned)(row * 64 + n), thr, inv_keep);
+          v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
+        }
+        const float4 xr = xq[oh * 4 + q];
+        const float4 o4 = make_float4(xr.x + a.alpha * v.x, xr.y + a.alpha * v.y, xr.z + a.alpha * v.z, xr.w + a.alpha * v.w);
+        buf_store4_(Yr, row < a.M ? (unsigned)(row * 256 + n * 4) : BUF_OOB_, o4);
+        yo[oh * 4 + q] = o4;
+        sm += (o4.x + o4.y) + (o4.z + o4.w);
+      }
+    if (a.out_stats) {                                   // (mean, rstd) of the row of Y: own 32 channels + the partner lane's
+      const float mean = xor32_sum_(sm) * (1.f / 64.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float a0 = yo[i].x - mean, a1 = yo[i].y - mean, a2 = yo[i].z - mean, a3 = yo[i].w - mean;
+        sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+      sq = xor32_sum_(sq);
+      typedef unsigned u32x2o_ __attribute__((ext_vector_type(2)));
+      const float2 ms = make_float2(mean, rsqrtf(sq * (1.f / 64.f) + 1e-5f));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2o_, ms), Or, (row < a.M && kg == 0) ? (unsigned)(row * 8) : BUF_OOB_, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xq[i] = xn[i];
+    st = stn;
   }
 }
 
@@ -1186,7 +1423,18 @@ extern "C" int se_ff_fwd_f16(const float* X, const float* rowstats, const float*
   FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats, sc ? *sc : se_f16_scales{}};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
   SE_REQUIRE(precision == 3 || H != nullptr, "ff_fwd: only the scaled split-fp16 form runs without storing H");
-  if (precision == 3 && a.H) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, true>), grid, block, 0, as_stream(stream), a);
+  static const bool fwd_ws = !(getenv("SE_FF_FWD_WS") && atoi(getenv("SE_FF_FWD_WS")) == 0);      // SE_FF_FWD_WS=0: the per-128-row kernel
+  if (precision == 3 && !a.H && fwd_ws && M * 256 < 4294963200L) {
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    const long need = (M + 255) / 256;
+    static unsigned raised = 0;
+    SE_REQUIRE(se_raise_lds((const void*)ff_fwd_ws_kernel, FW_LDS_BYTES, &raised), "ff_fwd: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(ff_fwd_ws_kernel, dim3((unsigned)(need < ncu ? need : ncu)), dim3(512), FW_LDS_BYTES, as_stream(stream), a);
+  } else if (precision == 3 && a.H) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, true>), grid, block, 0, as_stream(stream), a);
   else if (precision == 3) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, false>), grid, block, 0, as_stream(stream), a);
   else if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
   else if (wpl && hid == 256) hipLaunchKernelGGL((ff_fwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);

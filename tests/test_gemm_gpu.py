@@ -620,7 +620,9 @@ def test_feed_forward_recompute_kernels():
         dy._se_amax = dy.abs().max().reshape(1).clone()
         y, h = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, drop, 11, 12, 0.5, hid=256)
         y2, h2 = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, drop, 11, 12, 0.5, hid=256, store_h=False)
-        assert h2 is None and torch.equal(y, y2)
+        # (round 5: without the H store the forward chains the two products in registers and contracts the hidden units of a 16-block
+        # in a permuted order: the same products, summed in another order)
+        assert h2 is None and rel(y2, y) < 1e-6
         dg0, db0, dg1, db1_ = (torch.zeros(64, device=dev) for _ in range(4))
         dz, dx0 = GM.ff_bwd_dgrad(dy, h, p.out['w2t'], p.out['w1t'], drop, 11, 12, ln=(x, st, g, None, dg0, db0),
                                   amax_out=(torch.zeros(1, device=dev), torch.zeros(1, device=dev)))

@@ -220,6 +220,29 @@ def dw_bench(argv):
             print(f'{axis:5s} {name:10s} {dt*1e6:8.1f} us  {(5 if name in ("dgrad+glu", "bwd fused") else 2)*x.numel()*4/dt/1e9:7.0f} GB/s', flush=True)
 
 @cmd
+def ff_f16(argv):
+    """the default feed-forward forward (scaled fp16, H not stored) at the benchmark shape"""
+    import time, torch
+    from speech_enhancement_amd import gemm as GM, ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    M = 16 * 321 * 101
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    x = torch.randn(M, 64, device=dev); st = O.row_stats(x, M)
+    g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    W1, b1 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
+    W2, b2 = torch.randn(64, 256, device=dev) * 0.05, torch.randn(64, device=dev) * 0.1
+    p = WeightPlan(dev); p.linear('w1', W1, planes='f16'); p.linear('w2', W2, planes='f16'); p.run()
+    for sh in (False, True):
+        f = lambda: GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, 0.2, 11, 12, 0.5, hid=256, store_h=sh)
+        for _ in range(3): f()
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(20): f()
+        torch.cuda.synchronize(); dt = (time.time() - t0) / 20
+        print(f'ff_fwd f16x3 store_h={sh}: {dt*1e6:7.1f} us', flush=True)
+
+
+@cmd
 def normbwd_one(argv):
     """InstanceNorm + PReLU backward (reduce + apply launches) at the dense-block shape of the step: B = 16, 321 x 101 pixels, C = 64, the
     operands living in 256-wide skip slabs like in the model"""
