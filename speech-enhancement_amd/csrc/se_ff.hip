@@ -364,6 +364,7 @@ constexpr int FW_SB2 = 264, FW_P2 = 64 * FW_SB2;       // W2 image: [64 outputs]
 constexpr int FW_O_W2 = 2 * FW_P1 * 2, FW_O_B1 = FW_O_W2 + 2 * FW_P2 * 2, FW_O_B2 = FW_O_B1 + 1024, FW_O_GB = FW_O_B2 + 256;
 constexpr int FW_LDS_BYTES = FW_O_GB + 512;
 
+template <bool DR>       // DR: dropout on (compile time: a run-time test around every hash splits the tile's straight-line code)
 __global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fw_sm[];
   __bf16* W1i = reinterpret_cast<__bf16*>(fw_sm);
@@ -397,7 +398,6 @@ __global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
   const float s_in = exp2i_(ein), s_mid = exp2i_(emid), u1 = exp2i_(-ein - e1), u2 = exp2i_(-emid - e2);
   const unsigned thr = drop_thr(a.drop_p);
   const float inv_keep = drop_inv_keep(a.drop_p);
-  const bool dr = a.drop_p > 0.f;
   const int t = lane & 31, kg = lane >> 5;
   const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X, (unsigned)(a.M * 256)), Sr = make_rsrc_(a.rowstats, (unsigned)(a.M * 8)),
                                Yr = make_rsrc_(a.Y, (unsigned)(a.M * 256));
@@ -436,54 +436,71 @@ __global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
     f32x16 yT[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { yT[0][r] = 0.f; yT[1][r] = 0.f; }
-#pragma unroll 1
+    // one k-step of GEMM 1 of hidden block jb -> acc (6 matrix instructions)
+    auto gemm1_step = [&](int jb, int ks, f32x16 (&acc)[2]) {
+      bf16x8 w0[2], w1[2];
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        w0[pl] = *reinterpret_cast<const bf16x8*>(&W1i[pl * FW_P1 + (64 * jb + t) * FW_SB1 + 16 * ks + 8 * kg]);
+        w1[pl] = *reinterpret_cast<const bf16x8*>(&W1i[pl * FW_P1 + (64 * jb + 32 + t) * FW_SB1 + 16 * ks + 8 * kg]);
+      }
+      acc[0] = mfma32_<true>(w0[1], af1[ks][0], acc[0]); acc[1] = mfma32_<true>(w1[1], af1[ks][0], acc[1]);      // smallest terms first
+      acc[0] = mfma32_<true>(w0[0], af1[ks][1], acc[0]); acc[1] = mfma32_<true>(w1[0], af1[ks][1], acc[1]);
+      acc[0] = mfma32_<true>(w0[0], af1[ks][0], acc[0]); acc[1] = mfma32_<true>(w1[0], af1[ks][0], acc[1]);
+    };
+    // bias / Swish / dropout / split of 16 hidden units (k-step 2 hh + j) of block jb and their GEMM 2 step (6 matrix instructions)
+    auto chain_step = [&](int jb, int hh, int j, const f32x16 (&acc)[2]) {
+      float x[8];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int q = 2 * j + h, hu = 64 * jb + 32 * hh + 8 * q + 4 * kg;      // hidden units hu .. hu + 3 of this token
+        const float4 b4 = *reinterpret_cast<const float4*>(&b1s[hu]);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        if constexpr (DR) sc = drop_scale4(a.seed_h, (unsigned)(row * 256 + hu), thr, inv_keep);
+        x[4 * h] = swishf_(fmaf(acc[hh][4 * q], u1, b4.x)) * sc.x;
+        x[4 * h + 1] = swishf_(fmaf(acc[hh][4 * q + 1], u1, b4.y)) * sc.y;
+        x[4 * h + 2] = swishf_(fmaf(acc[hh][4 * q + 2], u1, b4.z)) * sc.z;
+        x[4 * h + 3] = swishf_(fmaf(acc[hh][4 * q + 3], u1, b4.w)) * sc.w;
+      }
+      bf16x8 af2[2], v0[2], v1[2];
+      split_planes8_h(x, s_mid, af2);
+      const int pos = 64 * jb + 16 * (2 * hh + j) + 8 * kg;
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        v0[pl] = *reinterpret_cast<const bf16x8*>(&W2i[pl * FW_P2 + t * FW_SB2 + pos]);
+        v1[pl] = *reinterpret_cast<const bf16x8*>(&W2i[pl * FW_P2 + (32 + t) * FW_SB2 + pos]);
+      }
+      yT[0] = mfma32_<true>(v0[1], af2[0], yT[0]); yT[1] = mfma32_<true>(v1[1], af2[0], yT[1]);
+      yT[0] = mfma32_<true>(v0[0], af2[1], yT[0]); yT[1] = mfma32_<true>(v1[0], af2[1], yT[1]);
+      yT[0] = mfma32_<true>(v0[0], af2[0], yT[0]); yT[1] = mfma32_<true>(v1[0], af2[0], yT[1]);
+    };
+    // software pipeline: k-step s of GEMM 1 of block jb + 1 sits in the instruction stream next to chain step s of block jb -- the two
+    // are independent, so the in-order wave feeds the matrix pipe while its own vector instructions issue.  The memory fences keep the
+    // scheduler from hoisting the fragment reads of LATER steps (everything hoisted at once: 650 spilled registers).
+    f32x16 accA[2], accB[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accA[0][r] = 0.f; accA[1][r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) gemm1_step(0, ks, accA);
+#pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
-      f32x16 acc[2];
+      f32x16 (&cur)[2] = (jb & 1) ? accB : accA;
+      f32x16 (&nxt)[2] = (jb & 1) ? accA : accB;
+      if (jb < 3) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 w0[2], w1[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          w0[pl] = *reinterpret_cast<const bf16x8*>(&W1i[pl * FW_P1 + (64 * jb + t) * FW_SB1 + 16 * ks + 8 * kg]);
-          w1[pl] = *reinterpret_cast<const bf16x8*>(&W1i[pl * FW_P1 + (64 * jb + 32 + t) * FW_SB1 + 16 * ks + 8 * kg]);
-        }
-        acc[0] = mfma32_<true>(w0[1], af1[ks][0], acc[0]); acc[1] = mfma32_<true>(w1[1], af1[ks][0], acc[1]);      // smallest terms first
-        acc[0] = mfma32_<true>(w0[0], af1[ks][1], acc[0]); acc[1] = mfma32_<true>(w1[0], af1[ks][1], acc[1]);
-        acc[0] = mfma32_<true>(w0[0], af1[ks][0], acc[0]); acc[1] = mfma32_<true>(w1[0], af1[ks][0], acc[1]);
+        for (int r = 0; r < 16; ++r) { nxt[0][r] = 0.f; nxt[1][r] = 0.f; }
       }
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          asm volatile("" ::: "memory");          // one k-step's fragment reads and hashes at a time (all four hoisted: spills)
-          float x[8];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int q = 2 * j + h, hu = 64 * jb + 32 * hh + 8 * q + 4 * kg;      // hidden units hu .. hu + 3 of this token
-            const float4 b4 = *reinterpret_cast<const float4*>(&b1s[hu]);
-            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (dr) sc = drop_scale4(a.seed_h, (unsigned)(row * 256 + hu), thr, inv_keep);
-            x[4 * h] = swishf_(fmaf(acc[hh][4 * q], u1, b4.x)) * sc.x;
-            x[4 * h + 1] = swishf_(fmaf(acc[hh][4 * q + 1], u1, b4.y)) * sc.y;
-            x[4 * h + 2] = swishf_(fmaf(acc[hh][4 * q + 2], u1, b4.z)) * sc.z;
-            x[4 * h + 3] = swishf_(fmaf(acc[hh][4 * q + 3], u1, b4.w)) * sc.w;
-          }
-          bf16x8 af2[2], v0[2], v1[2];
-          split_planes8_h(x, s_mid, af2);
-          const int pos = 64 * jb + 16 * (2 * hh + j) + 8 * kg;
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-            v0[pl] = *reinterpret_cast<const bf16x8*>(&W2i[pl * FW_P2 + t * FW_SB2 + pos]);
-            v1[pl] = *reinterpret_cast<const bf16x8*>(&W2i[pl * FW_P2 + (32 + t) * FW_SB2 + pos]);
-          }
-          yT[0] = mfma32_<true>(v0[1], af2[0], yT[0]); yT[1] = mfma32_<true>(v1[1], af2[0], yT[1]);
-          yT[0] = mfma32_<true>(v0[0], af2[1], yT[0]); yT[1] = mfma32_<true>(v1[0], af2[1], yT[1]);
-          yT[0] = mfma32_<true>(v0[0], af2[0], yT[0]); yT[1] = mfma32_<true>(v1[0], af2[0], yT[1]);
-        }
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        asm volatile("" ::: "memory");
+        if (jb < 3) gemm1_step(jb + 1, sidx, nxt);
+        chain_step(jb, sidx >> 1, sidx & 1, cur);
       }
     }
+    // (measured and not kept: the GEMM 2 step issued one stage later, and __builtin_amdgcn_sched_group_barrier shaping every stage
+    // as one matrix instruction per ten vector instructions -- 178.6 / 176.0 us against 174.9: the kernel is not bound by the order of
+    // its instructions but by what two waves per SIMD can hide; the output accumulators pinned to AccVGPRs (asm "+a": the compiler then
+    // keeps 123 AGPRs next to 128 VGPRs and all 192 matrix instructions on a[..]): 184.5 against 183.6 us same box)
     // next tile's rows: requested HERE (the 64 registers of the LayerNorm fragments and of the hidden block are free again; in flight
     // during the epilogue and, on the SIMD's other wave, its products; past the end nothing is fetched)
     request(tile + stride, xn, stn);
@@ -498,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
         const float4 b2v = *reinterpret_cast<const float4*>(&b2s[n]);
         float4 v = make_float4(fmaf(yT[oh][4 * q], u2, b2v.x), fmaf(yT[oh][4 * q + 1], u2, b2v.y), fmaf(yT[oh][4 * q + 2], u2, b2v.z),
                                fmaf(yT[oh][4 * q + 3], u2, b2v.w));
-        if (dr) {
+        if constexpr (DR) {
           const float4 d4 = drop_scale4(a.seed_o, (unsigned)(row * 64 + n), thr, inv_keep);
           v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
         }
@@ -1432,8 +1449,12 @@ extern "C" int se_ff_fwd_f16(const float* X, const float* rowstats, const float*
     }
     const long need = (M + 255) / 256;
     static unsigned raised = 0;
-    SE_REQUIRE(se_raise_lds((const void*)ff_fwd_ws_kernel, FW_LDS_BYTES, &raised), "ff_fwd: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(ff_fwd_ws_kernel, dim3((unsigned)(need < ncu ? need : ncu)), dim3(512), FW_LDS_BYTES, as_stream(stream), a);
+    const bool dr = drop_p > 0.f;
+    static unsigned raised0 = 0;
+    SE_REQUIRE(se_raise_lds(dr ? (const void*)ff_fwd_ws_kernel<true> : (const void*)ff_fwd_ws_kernel<false>, FW_LDS_BYTES, dr ? &raised : &raised0),
+               "ff_fwd: cannot raise the dynamic LDS limit");
+    if (dr) hipLaunchKernelGGL(ff_fwd_ws_kernel<true>, dim3((unsigned)(need < ncu ? need : ncu)), dim3(512), FW_LDS_BYTES, as_stream(stream), a);
+    else hipLaunchKernelGGL(ff_fwd_ws_kernel<false>, dim3((unsigned)(need < ncu ? need : ncu)), dim3(512), FW_LDS_BYTES, as_stream(stream), a);
   } else if (precision == 3 && a.H) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, true>), grid, block, 0, as_stream(stream), a);
   else if (precision == 3) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, false>), grid, block, 0, as_stream(stream), a);
   else if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
