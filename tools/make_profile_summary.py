@@ -54,6 +54,15 @@ def fam(name):
         return 'dwconv31 dgrad + glu_bwd' if len(args) > 1 and args[1] == 'true' else 'dwconv31 (fwd / dgrad)'
     if base in ('dwconv_wgrad_kernel', 'dwconv_wgrad_reduce_kernel'):
         return 'dwconv31_wgrad (+ reduce)'
+    # round 5: the fused kernels
+    if base == 'dwconv_bwd_fused_kernel':
+        return 'dwconv31 dgrad + glu_bwd + wgrad'
+    if base == 'ff_fwd_ws_kernel':
+        return 'ff_fwd_f16x3'
+    if base == 'ff_bwd_fused_kernel':
+        return 'ff_bwd_fused_f16x3'
+    if base == 'lnbwd_fused_kernel':
+        return 'lnbwd_wgrad_fused_f16x3'
     if base in ('ff_fwd_kernel', 'ff_bwd_kernel'):    # <NPL, planes, NB, F16 [, STORE_H]>
         kind = 'fwd' if base == 'ff_fwd_kernel' else 'bwd_dgrad'
         if len(args) >= 4 and args[3] == 'true':
