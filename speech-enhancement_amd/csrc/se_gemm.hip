@@ -897,6 +897,154 @@ __global__ __launch_bounds__(256, 2) void conv1d_k64_wstat_kernel(GemmArgs g, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// CDiffuSE gate + 1 x 1 projection with BOTH column blocks (N = 128) in one workgroup (round 5, second form of SE_PRO_GATE): in
+// conv1d_k64_wstat_kernel<1, true> the two column-block workgroups of a row tile each build the gate (2 x the exponentials, 2 x the
+// reads of R and the conditioner out of L2).  Here a workgroup builds the eight gated values of a k-step once, splits them, and feeds
+// the matrix instructions of both column blocks; the rows of the NEXT tile are requested k-step by k-step into the registers the
+// current k-step has just released (128 VGPRs of loads in flight without a second set of registers).
+__global__ __launch_bounds__(256, 2) void gate_proj_kernel(GemmArgs g, int ngroups) {
+  constexpr int SW = 72, PW = 64 * SW;
+  __shared__ __attribute__((aligned(16))) float ss_s[256];              // [128 channels][scale, shift] of the tile's batch entry
+  __shared__ __attribute__((aligned(16))) __bf16 Wl[2 * 2 * PW];        // [column block][plane][64 rows][SW]
+  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * 36];
+  __shared__ float red[4 * 64 * 2];
+  __shared__ __attribute__((aligned(16))) float bias_s[128];
+  const se_gemm_desc& d = g.d;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int Mb = d.Fo;
+  float ymax = 0.f;
+  const int grp = (int)blockIdx.x;
+  if (grp >= ngroups) return;
+  f16_clamp_mode_();
+  const int ea = operand_sexp_(d.a_amax, d.a_sexp), ew = operand_sexp_(d.w_amax, d.w_sexp);
+  const float sa = exp2i_(ea), unscale = exp2i_(-ea - ew);
+  {
+    const int pr = tid >> 2, pc = tid & 3;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n = cb * 64 + pr;
+      const bool ok = n < d.N;
+      const __bf16* wp = reinterpret_cast<const __bf16*>(g.W) + ((unsigned)(ok ? n : 0) * (unsigned)d.ldw + 8 * pc);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint4 w = *reinterpret_cast<const uint4*>(wp + (size_t)q * (size_t)d.w_planes + 32 * j);
+          *reinterpret_cast<uint4*>(&Wl[(cb * 2 + q) * PW + pr * SW + 8 * pc + 32 * j]) = make_uint4(ok ? w.x : 0u, ok ? w.y : 0u, ok ? w.z : 0u, ok ? w.w : 0u);
+        }
+    }
+    if (tid < 128) bias_s[tid] = ((d.epilogue & SE_EPI_BIAS) && tid < d.N) ? g.bias[tid] : 0.f;
+  }
+  __syncthreads();
+  const int kg = lane >> 5;
+  const int frag = (lane & 31) * SW + 8 * kg;
+  float* cs = patch + wave * 32 * 36;
+  const int ntile_all = d.B * g.tiles, gx = ngroups >> 3;              // ngroups is a multiple of 8 (host)
+  const int tpx = (ntile_all + 7) / 8, xbase = (grp & 7) * tpx;
+  const int ntile = min(tpx, ntile_all - xbase);
+  const int k0 = grp >> 3;
+  float4 vr[4][4][2];                                  // [R gate half | R filter half | cond gate half | cond filter half][k-step][2]
+  auto row_ok = [&](int kk) {
+    const int tile = xbase + kk;
+    const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
+    return kk < ntile && m0 + wave * 32 + (lane & 31) < Mb;
+  };
+  auto request = [&](int kk, int ks) {                 // (tiles past the end re-read row 0 of the last batch entry: harmless, rare)
+    const int kc = kk < ntile ? kk : ntile - 1;
+    const int tile = xbase + kc;
+    const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
+    const int row = m0 + wave * 32 + (lane & 31);
+    const long ro = (long)b * Mb + (row < Mb ? row : 0);
+    const float* __restrict__ ap = g.A + ro * d.lda + d.a_off + 8 * kg + 16 * ks;
+    const float* __restrict__ cp = g.AUX + ro * d.ldx + d.x_off + 8 * kg + 16 * ks;
+    vr[0][ks][0] = *reinterpret_cast<const float4*>(ap);      vr[0][ks][1] = *reinterpret_cast<const float4*>(ap + 4);
+    vr[1][ks][0] = *reinterpret_cast<const float4*>(ap + 64); vr[1][ks][1] = *reinterpret_cast<const float4*>(ap + 68);
+    vr[2][ks][0] = *reinterpret_cast<const float4*>(cp);      vr[2][ks][1] = *reinterpret_cast<const float4*>(cp + 4);
+    vr[3][ks][0] = *reinterpret_cast<const float4*>(cp + 64); vr[3][ks][1] = *reinterpret_cast<const float4*>(cp + 68);
+  };
+  if (k0 < ntile) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) request(k0, ks);
+  }
+  int b_staged = -1;
+  for (int kk = k0; kk < ntile; kk += gx) {
+    const int tile = xbase + kk;
+    const int b = tile / g.tiles, m0 = (tile - b * g.tiles) * 128;
+    const bool ok = row_ok(kk);
+    if (b != b_staged) {                               // (b is uniform over the workgroup)
+      __syncthreads();
+      ss_s[tid] = g.ps[(long)b * 256 + tid];
+      __syncthreads();
+      b_staged = b;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      asm volatile("" ::: "memory");          // one k-step's weight fragments at a time (all 32 hoisted: spills)
+      float x[8];
+      {
+        const float gr[8] = {vr[0][ks][0].x, vr[0][ks][0].y, vr[0][ks][0].z, vr[0][ks][0].w, vr[0][ks][1].x, vr[0][ks][1].y, vr[0][ks][1].z, vr[0][ks][1].w};
+        const float fr[8] = {vr[1][ks][0].x, vr[1][ks][0].y, vr[1][ks][0].z, vr[1][ks][0].w, vr[1][ks][1].x, vr[1][ks][1].y, vr[1][ks][1].z, vr[1][ks][1].w};
+        const float cg[8] = {vr[2][ks][0].x, vr[2][ks][0].y, vr[2][ks][0].z, vr[2][ks][0].w, vr[2][ks][1].x, vr[2][ks][1].y, vr[2][ks][1].z, vr[2][ks][1].w};
+        const float cf[8] = {vr[3][ks][0].x, vr[3][ks][0].y, vr[3][ks][0].z, vr[3][ks][0].w, vr[3][ks][1].x, vr[3][ks][1].y, vr[3][ks][1].z, vr[3][ks][1].w};
+        const float* sg = ss_s + 2 * (16 * ks + 8 * kg);      // (scale, shift) pairs of this lane's 8 gate channels; filter: + 128
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float4 pg = *reinterpret_cast<const float4*>(sg + 2 * j), pf = *reinterpret_cast<const float4*>(sg + 128 + 2 * j);
+          const float zg0 = fmaf(gr[j], pg.x, pg.y) + cg[j], zg1 = fmaf(gr[j + 1], pg.z, pg.w) + cg[j + 1];
+          const float zf0 = fmaf(fr[j], pf.x, pf.y) + cf[j], zf1 = fmaf(fr[j + 1], pf.z, pf.w) + cf[j + 1];
+          const float t0 = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * zf0));
+          const float t1 = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * zf1));
+          x[j] = ok ? sigmoidf_(zg0) * t0 : 0.f;
+          x[j + 1] = ok ? sigmoidf_(zg1) * t1 : 0.f;
+        }
+      }
+      bf16x8 af[2];
+      split_planes8_h(x, sa, af);
+#ifdef SE_GATE_PROJ_EARLY
+      if (ks < 2) request(kk + gx, ks);                  // (measured: the next tile's first k-steps into the registers just released --
+#endif                                                   //  15 spilled registers in the epilogues, no faster)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        bf16x8 bf0[2], bf1[2];
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wl[(cb * 2 + pl) * PW + frag + 16 * ks]);
+          bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wl[(cb * 2 + pl) * PW + 32 * SW + frag + 16 * ks]);
+        }
+        acc[2 * cb] = mfma32_<true>(af[1], bf0[0], acc[2 * cb]); acc[2 * cb + 1] = mfma32_<true>(af[1], bf1[0], acc[2 * cb + 1]);
+        acc[2 * cb] = mfma32_<true>(af[0], bf0[1], acc[2 * cb]); acc[2 * cb + 1] = mfma32_<true>(af[0], bf1[1], acc[2 * cb + 1]);
+        acc[2 * cb] = mfma32_<true>(af[0], bf0[0], acc[2 * cb]); acc[2 * cb + 1] = mfma32_<true>(af[0], bf1[0], acc[2 * cb + 1]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][r] *= unscale;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      gemm_epilogue_vec<false, false, true>(g, acc[2 * cb], acc[2 * cb + 1], m0, cb, b, cs, 36, 0u, 1.f, red, bias_s + 64 * cb, {}, &ymax);
+      if (d.epilogue & SE_EPI_STATS) __syncthreads();    // `red` is reused by the next column block / tile
+    }
+    // the next tile's rows behind the epilogues (unconditional loads; the SIMD's other workgroup covers their latency)
+#ifndef SE_GATE_PROJ_EARLY
+    request(kk + gx, 0);
+    request(kk + gx, 1);
+#endif
+    request(kk + gx, 2);
+    request(kk + gx, 3);
+  }
+  if (g.amax_out) {
+    ymax = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0) amax_raise_(g.amax_out, ymax);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // W-stationary persistent form of the row panel for the token-wise layers of the train step (qkv 64 -> 192, pointwise-GLU
 // 64 -> 256, the 64 -> 128 input gradient), scaled split-fp16: one 8-wave workgroup per CU keeps ALL column blocks of the
 // weight (two planes, <= 74 KB) in LDS and loops over 256-row tiles.  The panel kernel has one tile per workgroup: the rows'
@@ -1119,7 +1267,15 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       ngroups = (ngroups + 7) / 8 * 8;
       const dim3 wgrid((unsigned)(ncols * ngroups));
       if (tap3) hipLaunchKernelGGL(conv1d_k64_wstat_kernel<3>, wgrid, block, 0, s, g, ngroups);
-      else if (gate) hipLaunchKernelGGL((conv1d_k64_wstat_kernel<1, true>), wgrid, block, 0, s, g, ngroups);
+      else if (gate) {
+        static const bool gate_one_wg = !(getenv("SE_GATE_PROJ_SPLIT") != nullptr);      // SE_GATE_PROJ_SPLIT=1: one workgroup per column block
+        if (gate_one_wg && d->N == 128) {
+          int ng = 512;
+          if ((long)ng > (long)d->B * g.tiles) ng = d->B * g.tiles;
+          ng = (ng + 7) / 8 * 8;
+          hipLaunchKernelGGL(gate_proj_kernel, dim3((unsigned)ng), block, 0, s, g, ng);
+        } else hipLaunchKernelGGL((conv1d_k64_wstat_kernel<1, true>), wgrid, block, 0, s, g, ngroups);
+      }
       else hipLaunchKernelGGL(conv1d_k64_wstat_kernel<1>, wgrid, block, 0, s, g, ngroups);
       return se_check_launch("se_gemm_tap(W-stationary 1-D)");
     }
