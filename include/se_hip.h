@@ -571,6 +571,11 @@ int se_diff_mix(float* x, const float* R2, const float* ss, const float* d_next,
 /* the same, and y_amax (zero-filled, may be NULL) is raised to max |ynext| */
 int se_diff_mix_amax(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip, int first,
                      int B, long L, int C, float* y_amax, void* stream);
+/* one-stream form (round 5): only y = x + d_step lives between the layers of the CDiffuSE denoiser (models/DiffuSE.py:113,124-127):
+ * y <- ((y - d_cur) + residual) / sqrt 2 + d_next in place (d_next == NULL: last layer, y is left alone), skip sum as in se_diff_mix;
+ * se_diff_input(_amax) accepts x == NULL. */
+int se_diff_mix_y(float* y, const float* R2, const float* ss, const float* d_cur, const float* d_next, int dB, float* skip, int first,
+                  int B, long L, int C, float* y_amax, void* stream);
 /* nn.GroupNorm statistics -> ss [B][N][2] = (scale, shift) per (batch, channel) for channels [c_off, c_off + N) of the
  * fp64 (sum, sumsq) table stats [B][Ntot][2] a GEMM epilogue produced (SE_EPI_STATS), groups of gsize channels */
 int se_group_finalize(const double* stats, int B, int Ntot, int c_off, int N, int gsize, double count_per_channel,

@@ -52,7 +52,7 @@ __global__ void diff_input_kernel(const float* __restrict__ audio, const float* 
                           fmaxf(w4.w * a + b4.w, 0.f));
   const float4 yv = make_float4(xv.x + d4.x, xv.y + d4.y, xv.z + d4.z, xv.w + d4.w);
   if (live) {
-    *reinterpret_cast<float4*>(x + idx * 4) = xv;
+    if (x) *reinterpret_cast<float4*>(x + idx * 4) = xv;      // (x == NULL: the one-stream form keeps only y)
     *reinterpret_cast<float4*>(y + idx * 4) = yv;
   }
   if (y_amax) {        // max |y|: the operand scale of the scaled split-fp16 dilated conv that reads y
@@ -85,6 +85,46 @@ __global__ void diff_gate_kernel(const float* __restrict__ R, const float* __res
     o[j] = sigmoidf_(zg) * (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * zf)));
   }
   *reinterpret_cast<float4*>(y + idx * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// ONE-STREAM form of the mix (round 5): only y = x + d_step is kept between the layers -- x is y - d_cur (d is a per-(batch entry,
+// channel) vector), so the residual stream is read once and written once per layer instead of x read + x written + y written:
+// y <- ((y - d_cur) + residual) / sqrt 2 + d_next in place; the last layer (d_next == NULL) writes nothing but the skip sum.
+__global__ void diff_mix_y_kernel(float* __restrict__ y, const float* __restrict__ R2, const float* __restrict__ ss,
+                                  const float* __restrict__ dc, const float* __restrict__ dn, int dB, float* __restrict__ skip, int first,
+                                  long L, int C, long total, float* __restrict__ y_amax) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = idx < total;
+  if (!live) idx = total - 1;
+  const int q = C / 4, c4 = (int)(idx % q) * 4;
+  const long pos = idx / q;
+  const int b = (int)(pos / L);
+  const float* r = R2 + pos * 2 * C;
+  const float* s = ss + (long)b * C * 2;
+  const float4 sk = *reinterpret_cast<const float4*>(r + C + c4);
+  float ym = 0.f;
+  if (dn) {
+    const float4 yr = *reinterpret_cast<const float4*>(y + idx * 4);
+    const float4 rs = *reinterpret_cast<const float4*>(r + c4);
+    const float4 d0 = *reinterpret_cast<const float4*>(dc + (long)(dB > 1 ? b : 0) * C + c4);
+    const float4 d1 = *reinterpret_cast<const float4*>(dn + (long)(dB > 1 ? b : 0) * C + c4);
+    const float k = 0.70710678118654752f;
+    const float4 yv = make_float4(((yr.x - d0.x) + rs.x) * k + d1.x, ((yr.y - d0.y) + rs.y) * k + d1.y, ((yr.z - d0.z) + rs.z) * k + d1.z,
+                                  ((yr.w - d0.w) + rs.w) * k + d1.w);
+    if (live) *reinterpret_cast<float4*>(y + idx * 4) = yv;
+    ym = fmaxf(fmaxf(fabsf(yv.x), fabsf(yv.y)), fmaxf(fabsf(yv.z), fabsf(yv.w)));
+  }
+  if (y_amax) {
+    const float m = wave_max(live ? ym : 0.f);
+    if ((threadIdx.x & 63) == 0) amax_raise_(y_amax, m);
+  }
+  if (!live) return;
+  float4 acc = first ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(skip + idx * 4);
+  acc.x += sk.x * s[(c4 + 0) * 2] + s[(c4 + 0) * 2 + 1];
+  acc.y += sk.y * s[(c4 + 1) * 2] + s[(c4 + 1) * 2 + 1];
+  acc.z += sk.z * s[(c4 + 2) * 2] + s[(c4 + 2) * 2 + 1];
+  acc.w += sk.w * s[(c4 + 3) * 2] + s[(c4 + 3) * 2 + 1];
+  *reinterpret_cast<float4*>(skip + idx * 4) = acc;
 }
 
 // R2 [B, L, 2C] = (residual | skip before its GroupNorm); x updated in place; y_next written when d_next != NULL;
@@ -154,7 +194,7 @@ extern "C" int se_diff_upsample(const float* in, const float* w, const float* bi
 }
 extern "C" int se_diff_input_amax(const float* audio, const float* w, const float* bias, const float* d0, int dB, float* x, float* y,
                                   int B, long L, int C, float* y_amax, void* stream) {
-  SE_REQUIRE(audio && w && bias && d0 && x && y && B > 0 && L > 0 && C > 0 && (C % 4) == 0, "diff_input: bad arguments");
+  SE_REQUIRE(audio && w && bias && d0 && y && B > 0 && L > 0 && C > 0 && (C % 4) == 0, "diff_input: bad arguments");
   const long total = (long)B * L * (C / 4);
   DF_LAUNCH(diff_input_kernel, total, stream, audio, w, bias, d0, dB, x, y, L, C, total, y_amax);
   return se_check_launch("se_diff_input");
@@ -175,6 +215,13 @@ extern "C" int se_diff_mix_amax(float* x, const float* R2, const float* ss, cons
   const long total = (long)B * L * (C / 4);
   DF_LAUNCH(diff_mix_kernel, total, stream, x, R2, ss, d_next, dB, ynext, skip, first, L, C, total, y_amax);
   return se_check_launch("se_diff_mix");
+}
+extern "C" int se_diff_mix_y(float* y, const float* R2, const float* ss, const float* d_cur, const float* d_next, int dB, float* skip,
+                             int first, int B, long L, int C, float* y_amax, void* stream) {
+  SE_REQUIRE(y && R2 && ss && skip && (d_cur || !d_next) && B > 0 && L > 0 && C > 0 && (C % 4) == 0, "diff_mix_y: bad arguments");
+  const long total = (long)B * L * (C / 4);
+  DF_LAUNCH(diff_mix_y_kernel, total, stream, y, R2, ss, d_cur, d_next, dB, skip, first, L, C, total, y_amax);
+  return se_check_launch("se_diff_mix_y");
 }
 extern "C" int se_diff_mix(float* x, const float* R2, const float* ss, const float* d_next, int dB, float* ynext, float* skip,
                            int first, int B, long L, int C, void* stream) {

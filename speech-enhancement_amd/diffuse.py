@@ -29,6 +29,8 @@ from .weights import WeightPlan
 
 # SE_DIFF_GATE_FUSED=0: the stand-alone gate kernel in front of the projection GEMM
 GATE_FUSED = os.environ.get('SE_DIFF_GATE_FUSED', '1') != '0'
+# SE_DIFF_ONE_STREAM=0: x and y = x + d_step both stored between the layers (mix: 7 plane passes instead of 6)
+ONE_STREAM = os.environ.get('SE_DIFF_ONE_STREAM', '1') != '0'
 
 _i, _l, _f, _d = C.c_int, C.c_long, C.c_float, C.c_double
 
@@ -176,7 +178,8 @@ class DiffuSE(nn.Module):
         emb = self.diffusion_embedding(step)                                          # [N, 512], N in {1, B}
         dproj = (emb @ pk['wdp'].t() + pk['bdp']).view(emb.shape[0], nl, Cc).transpose(0, 1).contiguous()   # [nl][N][C]
         dB = emb.shape[0]
-        x = torch.empty(B, Lp, Cc, device=dev)
+        # SE_DIFF_ONE_STREAM (default on): only y = x + d_step is kept between the layers (the mix recovers x = y - d_cur)
+        x = None if ONE_STREAM else torch.empty(B, Lp, Cc, device=dev)
         y = torch.empty(B, Lp, Cc, device=dev)
         y2 = torch.empty(B, Lp, Cc, device=dev)
         skip = torch.empty(B, Lp, Cc, device=dev)
@@ -227,8 +230,12 @@ class DiffuSE(nn.Module):
             L.call('se_group_finalize', L.ptr(st2), _i(B), _i(2 * Cc), _i(Cc), _i(Cc), _i(16), _d(float(Lp)), L.ptr(gn2.weight),
                    L.ptr(gn2.bias), L.ptr(ss2), _f(gn2.eps), L.stream())
             nxt = dproj[i + 1] if i + 1 < nl else None
-            L.call('se_diff_mix_amax', L.ptr(x), L.ptr(R2), L.ptr(ss2), L.ptr(nxt), _i(dB), L.ptr(y), L.ptr(skip), _i(int(i == 0)),
-                   _i(B), _l(Lp), _i(Cc), L.ptr(yam[i + 1:i + 2] if (f16 and i + 1 < nl) else None), L.stream())
+            if ONE_STREAM:
+                L.call('se_diff_mix_y', L.ptr(y), L.ptr(R2), L.ptr(ss2), L.ptr(dproj[i]), L.ptr(nxt), _i(dB), L.ptr(skip), _i(int(i == 0)),
+                       _i(B), _l(Lp), _i(Cc), L.ptr(yam[i + 1:i + 2] if (f16 and i + 1 < nl) else None), L.stream())
+            else:
+                L.call('se_diff_mix_amax', L.ptr(x), L.ptr(R2), L.ptr(ss2), L.ptr(nxt), _i(dB), L.ptr(y), L.ptr(skip), _i(int(i == 0)),
+                       _i(B), _l(Lp), _i(Cc), L.ptr(yam[i + 1:i + 2] if (f16 and i + 1 < nl) else None), L.stream())
         GM.gemm_tap(GM.make_desc(1, 1, B * Lp, 1, B * Lp, [(0, 0)], Cc, Cc, Cc, Cc, epilogue=L.EPI_BIAS), skip, pk['ws'], y2,
                     bias=self.skip_projection.bias)
         out = torch.empty(B, Lp, device=dev)
