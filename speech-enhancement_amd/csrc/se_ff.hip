@@ -398,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
   const float s_in = exp2i_(ein), s_mid = exp2i_(emid), u1 = exp2i_(-ein - e1), u2 = exp2i_(-emid - e2);
   const unsigned thr = drop_thr(a.drop_p);
   const float inv_keep = drop_inv_keep(a.drop_p);
+  const float s_mid_k = DR ? s_mid * inv_keep : s_mid;      // hidden-dropout survivors: x inv_keep, folded into the split scale
   const int t = lane & 31, kg = lane >> 5;
   const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X, (unsigned)(a.M * 256)), Sr = make_rsrc_(a.rowstats, (unsigned)(a.M * 8)),
                                Yr = make_rsrc_(a.Y, (unsigned)(a.M * 256));
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
   request(tile, xq, st);
   for (; tile < ntile; tile += stride) {
     const long row = tile * 32 + t;
+    const unsigned rowC = ((unsigned)row * 64u + (unsigned)kg) * 0x9E3779B1u;      // (row * 256 + 4 kg) / 4 times the hash constant
     // ---- LayerNorm -> B fragments of GEMM 1 (k-step ks = 2 nt + j: quads q = 2 j, 2 j + 1 of half nt) ----
     bf16x8 af1[4][2];
 #pragma unroll
@@ -455,15 +457,17 @@ __global__ __launch_bounds__(512, 2) void ff_fwd_ws_kernel(FfArgs a) {
       for (int h = 0; h < 2; ++h) {
         const int q = 2 * j + h, hu = 64 * jb + 32 * hh + 8 * q + 4 * kg;      // hidden units hu .. hu + 3 of this token
         const float4 b4 = *reinterpret_cast<const float4*>(&b1s[hu]);
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-        if constexpr (DR) sc = drop_scale4(a.seed_h, (unsigned)(row * 256 + hu), thr, inv_keep);
-        x[4 * h] = swishf_(fmaf(acc[hh][4 * q], u1, b4.x)) * sc.x;
-        x[4 * h + 1] = swishf_(fmaf(acc[hh][4 * q + 1], u1, b4.y)) * sc.y;
-        x[4 * h + 2] = swishf_(fmaf(acc[hh][4 * q + 2], u1, b4.z)) * sc.z;
-        x[4 * h + 3] = swishf_(fmaf(acc[hh][4 * q + 3], u1, b4.w)) * sc.w;
+        // dropout: the group's hash argument (row * 64 + hu / 4) * C as a sum of the tile's row term, the lane's term and a
+        // compile-time constant (mod 2^32: one add instead of a quarter-rate multiply); 1 / keep rides on the split scale
+        unsigned km = 15u;
+        if constexpr (DR) km = drop_keep4_pre(a.seed_h, rowC + (unsigned)(16 * jb + 8 * hh + 2 * q) * 0x9E3779B1u, thr);
+        const float s0 = swishf_(fmaf(acc[hh][4 * q], u1, b4.x)), s1 = swishf_(fmaf(acc[hh][4 * q + 1], u1, b4.y));
+        const float s2 = swishf_(fmaf(acc[hh][4 * q + 2], u1, b4.z)), s3 = swishf_(fmaf(acc[hh][4 * q + 3], u1, b4.w));
+        x[4 * h] = (km & 1u) ? s0 : 0.f; x[4 * h + 1] = (km & 2u) ? s1 : 0.f;
+        x[4 * h + 2] = (km & 4u) ? s2 : 0.f; x[4 * h + 3] = (km & 8u) ? s3 : 0.f;
       }
       bf16x8 af2[2], v0[2], v1[2];
-      split_planes8_h(x, s_mid, af2);
+      split_planes8_h(x, s_mid_k, af2);
       const int pos = 64 * jb + 16 * (2 * hh + j) + 8 * kg;
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) {

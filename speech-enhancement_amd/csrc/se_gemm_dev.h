@@ -73,6 +73,15 @@ static __device__ __forceinline__ void drop_fields(unsigned seed, unsigned grp, 
   y ^= y >> 15;
   f[0] = x & 0xFFFFu; f[1] = x >> 16; f[2] = y & 0xFFFFu; f[3] = y >> 16;
 }
+// the same fields from grp * 0x9E3779B1 supplied by the caller (a kernel that walks groups at fixed distances adds constants instead of
+// paying the quarter-rate multiply per group); KEEP MASK of the 4 elements: bit j set iff element j survives
+static __device__ __forceinline__ unsigned drop_keep4_pre(unsigned seed, unsigned grp_times_c, unsigned thr) {
+  unsigned x = grp_times_c ^ seed;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  unsigned y = x * 0x9E3779B1u + 0x7F4A7C15u;
+  y ^= y >> 15;
+  return ((x & 0xFFFFu) >= thr ? 1u : 0u) | ((x >> 16) >= thr ? 2u : 0u) | ((y & 0xFFFFu) >= thr ? 4u : 0u) | ((y >> 16) >= thr ? 8u : 0u);
+}
 // scales of the 4 elements idx .. idx + 3 (idx a multiple of 4)
 static __device__ __forceinline__ float4 drop_scale4(unsigned seed, unsigned idx, unsigned thr, float inv_keep) {
   unsigned f[4];
