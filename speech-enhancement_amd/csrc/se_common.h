@@ -40,13 +40,20 @@ static __device__ __forceinline__ float swish_gradf_(float x) {
 // ds_bpermute_b32 through the LDS crossbar: ~100 cycles of latency each, and in the attention kernels they sit on the softmax chain
 // (tile maximum -> rescale decision -> exp2).  Checked against __shfl_xor on the device: tools/micro/permlane_chk.hip.
 typedef unsigned u32x2sw_ __attribute__((ext_vector_type(2)));
+// (the maximum as inline assembly: fmaxf on bit-cast values makes the compiler canonicalise both inputs first -- two v_max x, x per step
+// on the softmax chain of the attention forward)
+static __device__ __forceinline__ float max_raw_(float a, float b) {
+  float o;
+  asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+  return o;
+}
 static __device__ __forceinline__ float xor32_max_(float v) {
   const u32x2sw_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return max_raw_(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 static __device__ __forceinline__ float xor16_max_(float v) {
   const u32x2sw_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  return max_raw_(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 static __device__ __forceinline__ float xor32_sum_(float v) {
   const u32x2sw_ r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
