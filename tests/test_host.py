@@ -306,7 +306,11 @@ def test_no_scratch_in_default_path_kernels(S):
     for pat, occ in ((r'^void attn_bwd4_kernel<4, 6, 3, 21, 2, 5, 3, 6, 2, -1, 0, false>\(', 2),
                      (r'^void attn_bwd4_kernel<2, 4, 2, 7, 2, 3, 2, 4, 2, -1, 0, false>\(', 2),
                      (r'^void attn_fwd3_kernel<2, true>\(', 4), (r'^void ff_fwd_kernel<2, true, 4, true, true>\(', 2),
-                     (r'^void ff_bwd_kernel<2, true, 4, true>\(', 2)):
+                     (r'^void ff_bwd_kernel<2, true, 4, true>\(', 2),
+                     # the fused kernels of round 5 (all default path): two waves per SIMD in one workgroup per CU, four in the depthwise one
+                     (r'^void ff_fwd_ws_kernel<true>\(', 2), (r'^ff_bwd_fused_kernel\(', 2), (r'^void lnbwd_fused_kernel<256>\(', 2),
+                     (r'^void lnbwd_fused_kernel<192>\(', 2), (r'^dwconv_bwd_fused_kernel\(', 4), (r'^gate_proj_kernel\(', 2),
+                     (r'^void gemm_k64_wstat_kernel<1>\(', 2)):
         hit = [d for nm, d in by.items() if re.search(pat, nm)]
         assert hit, pat
         assert hit[0]['ScratchSize'] == 0 and hit[0]['Occupancy'] >= occ, (pat, hit[0])
