@@ -314,3 +314,30 @@ def test_no_scratch_in_default_path_kernels(S):
         hit = [d for nm, d in by.items() if re.search(pat, nm)]
         assert hit, pat
         assert hit[0]['ScratchSize'] == 0 and hit[0]['Occupancy'] >= occ, (pat, hit[0])
+
+
+def test_no_defeated_prefetch_in_persistent_kernels(tmp_path):
+    """The persistent kernels of round 5 request the NEXT tile's rows while the current one is processed.  A load the compiler has to
+    wait for at once (`s_waitcnt vmcnt(0)` inside the tile loop right behind a load: a load under `if`, a guarded atomic's plain load --
+    DESIGN_APPENDIX A00) silently turns that into no prefetch at all.  Compiles the three translation units to assembly (device only,
+    seconds) and scans their steady-state loops (tools/isa_loop_waits.py)."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location('isa_loop_waits', os.path.join(ROOT, 'tools', 'isa_loop_waits.py'))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    csrc = os.path.join(ROOT, 'speech-enhancement_amd', 'csrc')
+    procs = []
+    for tu in ('se_lnbwd_fused', 'se_dwconv', 'se_ff'):
+        fl = [] if tu == 'se_dwconv' else ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+        out = str(tmp_path / (tu + '.s'))
+        procs.append((out, subprocess.Popen(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-munsafe-fp-atomics', '-std=c++17'] + fl +
+                                            ['-S', '--cuda-device-only', '-o', out, os.path.join(csrc, tu + '.hip')],
+                                           stderr=subprocess.DEVNULL)))
+    hits = {}
+    for out, p in procs:
+        assert p.wait() == 0, out
+        hits.update(sc.scan(out, steady=True))
+    watched = ('lnbwd_fused_kernel', 'dwconv_bwd_fused_kernel', 'ff_fwd_ws_kernel')
+    bad = {k: v for k, v in hits.items() if any(w in k for w in watched)}
+    assert not bad, bad
