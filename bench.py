@@ -93,11 +93,12 @@ def _family_entry(key, v, steps, pmc):
     return e
 
 
-def cpu_baseline(budget_s=55.0):
+def cpu_baseline(budget_s=48.0):
     """The CPU oracle's CMGAN train step (torch-CPU port of the reference step: AdamW, PESQ labels supplied) timed on the host cores.
-    Protocol (bounded so that the default run stays within minutes): (1) thread sweep 16 / 64 / 128 / 256
-    (capped at the host's cores) on a generator-only forward -- a count is skipped once the previous one was already 1.5x slower than
-    the best (torch-CPU oversubscribes a 256-core host: the sweep says so instead of spending minutes proving it); (2) at the best
+    Protocol (bounded so that the default run stays within minutes): (1) thread sweep 16 / 32 / 64 / 128
+    (capped at the host's cores) on a generator-only forward, stopped at the first count that is slower than the best (torch-CPU
+    oversubscribes a 256-core host: on the round-6 box 16 threads 3.7 s, 64 5.3 s, 128 10.1 s -- the sweep says so in two forwards
+    instead of spending the budget proving it); (2) at the best
     count: 3 warm-up + 5 timed batch-2 steps, fewer when the budget runs out (what ran is stated); (3) one batch-16 step if the
     measured batch-2 rate says it fits 30 s.  `reference_in_build_container`: the IMPORTED reference's own train_gan at the same
     protocol, measured in the build container (tools/time_reference_cpu.py; the reference cannot travel to this box)."""
@@ -110,21 +111,25 @@ def cpu_baseline(budget_s=55.0):
     spec = Or.compressed_stft(nn_)
     sweep = {}
     t_start = time.time()
-    best = last = None
-    for th in sorted({min(ncpu, v) for v in (16, 64, 128, 256)}):
-        if best is not None and last > 1.5 * best:
-            sweep[th] = None                                 # skipped: the trend is already 1.5x off the best
+    best = None
+    torch.set_num_threads(min(ncpu, 16))
+    with torch.no_grad():
+        Or.tscnet_forward(gsd, spec, False)                  # warm once (allocator, thread pool)
+    stop = False
+    for th in sorted({min(ncpu, v) for v in (16, 32, 64, 128)}):
+        if stop:
+            sweep[th] = None                                 # skipped: an earlier count was already slower than the best
             continue
         torch.set_num_threads(th)
         with torch.no_grad():
-            Or.tscnet_forward(gsd, spec, False)              # warm (allocator, thread pool)
             t0 = time.time()
             Or.tscnet_forward(gsd, spec, False)
-        sweep[th] = last = round(time.time() - t0, 3)
-        best = last if best is None else min(best, last)
-    threads = min((k for k, v in sweep.items() if v is not None), key=lambda k: sweep[k])
+        sweep[th] = round(time.time() - t0, 3)
+        stop = best is not None and sweep[th] > sweep[best]
+        best = th if best is None or sweep[th] < sweep[best] else best
+    threads = best
     warm = []
-    while len(warm) < 3 and (not warm or (time.time() - t_start) + 6 * warm[-1] < budget_s):
+    while len(warm) < 3 and (not warm or (time.time() - t_start) + (8 - len(warm)) * warm[-1] < budget_s):
         warm.append(_oracle_step(2, threads))                # fewer warm-ups when 3 + 5 steps do not fit the budget
     times = []
     while len(times) < 5 and (not times or (time.time() - t_start) + times[-1] < budget_s):
@@ -135,13 +140,14 @@ def cpu_baseline(budget_s=55.0):
            'sample': f'CMGAN train step of the CPU oracle (torch-CPU port of the reference step), batch 2, 2 s clips, '
                      f'AdamW, PESQ labels supplied: {len(warm)} warm-up ({", ".join("%.1f" % x for x in warm)} s) + {len(times)} timed steps '
                      f'({", ".join("%.1f" % x for x in times)} s) on {threads} threads (the best of the forward-only sweep; '
-                     f'null = skipped, the previous count was already 1.5x slower than the best)'}
-    if 16.0 / res['value'] * 0.6 < 30.0 or os.environ.get('SE_CPU_BASELINE_B16') == '1':      # batch 16 amortises: ~0.6x the per-clip time
+                     f'null = skipped, the previous count was already slower than the best)'}
+    if os.environ.get('SE_CPU_BASELINE_B16') == '1':      # opt-in only: one batch-16 oracle step took 97 s on the round-5 driver box
         t16 = _oracle_step(16, threads)
         res['batch16'] = {'value': round(16.0 / t16, 4), 'seconds': round(t16, 1)}
     else:
         res['batch16'] = None
-        res['batch16_note'] = f'one batch-16 step would take ~{16.0 / res["value"] * 0.6:.0f} s at the measured batch-2 rate: over the 30 s bound, not run'
+        res['batch16_note'] = ('not run (SE_CPU_BASELINE_B16=1 runs it): measured once on the round-5 driver box (BENCH_r05.json): 97.3 s '
+                               'per batch-16 step = 0.1645 utterances/s, 2.8x slower per clip than batch 2 on the same host')
     try:
         rp = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r05_reference_cpu_build_container.json')
         res['reference_in_build_container'] = json.load(open(rp))
@@ -214,7 +220,7 @@ class ClockSampler:
         pw = [w for _, w in self.samples if w is not None]
         st = lambda v: {'mean': round(sum(v) / len(v), 1), 'min': round(min(v), 1), 'max': round(max(v), 1)} if v else None
         return {'sclk_mhz': st(ck), 'power_w': st(pw), 'samples': len(self.samples), 'card': os.path.basename(self.card) if self.card else None,
-                'source': 'sysfs pp_dpm_sclk (active level) / hwmon power1_average, 20 Hz host thread over the timed loop; the in-kernel clock '
+                'source': 'sysfs pp_dpm_sclk (active level) / hwmon power1_average, 20 Hz host thread over an untimed pass of the same steps right after the timed loop; the in-kernel clock '
                           'of an MFMA-dense kernel reads up to ~10 % below pp_dpm_sclk (MI355X_MICROARCH.md, DVFS)'}
 
 
@@ -380,20 +386,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    clocks = ClockSampler(local) if rank == 0 else None
     fence()
-    if clocks is not None:
-        clocks.start()
-    t0 = time.time()                     # the HEADLINE loop: no per-launch instrumentation (TIMER off), exactly K steps
+    t0 = time.time()                     # the HEADLINE loop: no per-launch instrumentation (TIMER off), no host thread, exactly K steps
     for _ in range(a.steps):
         out = step()
     fence()
     dt = time.time() - t0
-    clock_res = clocks.stop() if clocks is not None else None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    # shader clock / board power under the same load: a SEPARATE untimed pass of the same steps right after the timed region (the
+    # sampler's sysfs reads issue SMU queries and take the GIL on rank 0 only: they do not belong inside a max-over-ranks timing)
+    clock_res = None
+    if rank == 0:
+        clocks = ClockSampler(local)
+        clocks.start()
+    for _ in range(min(a.steps, 10)):
+        step()
+    fence()
+    if rank == 0:
+        clock_res = clocks.stop()
     # self-validation of the data-parallel run (every rank; the first N > 1 run on hardware must prove itself): after W + K steps all
     # ranks must hold bit-identical parameters and BatchNorm running statistics -- identical initial broadcast, identical averaged
     # gradients, deterministic kernels.  A mismatch fails the run instead of printing a throughput for diverged replicas.

@@ -93,6 +93,20 @@ static inline bool se_raise_lds(const void* fn, size_t bytes, unsigned* done) {
   return true;
 }
 
+// Compute units of the CURRENT device, cached per device ordinal (the persistent kernels size their grid with it on every launch,
+// also during graph capture: one runtime query per device and process, error-checked; unknown -> 256, never less than 8).
+static inline int se_cu_count() {
+  static int cache[32] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < 32 && cache[dev] > 0) return cache[dev];
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+  if (v < 8) v = 8;
+  if (dev >= 0 && dev < 32) cache[dev] = v;
+  return v;
+}
+
 // Raise the device scalar *p (a running maximum of non-negative floats, ordered like their bit patterns) to m; called by ONE lane
 // per wave with the wave's maximum.  The plain load first: tens of thousands of waves hammering one address with atomics are
 // serialised in the L2 (259 K atomics of a glu_bwd launch cost milliseconds); after the first few waves almost every wave sees

@@ -661,9 +661,7 @@ extern "C" int se_dwconv31_bwd_fused(const float* dH, const float* W, const floa
   DwBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, dH, W, U, G, dZ, amax_out, ws,
               (unsigned)(ntok * DW_C * 4), (unsigned)(ntok * DW_C * 8)};
   const long nitems = (long)nseq * cdiv(n, FB_TILE);
-  int dev = 0, ncu = 256;
-  hipGetDevice(&dev);
-  hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  const int ncu = se_cu_count();
   int nblk = nitems < ncu ? (int)((nitems + 7) / 8 * 8) : ncu / 8 * 8;      // one workgroup per CU; multiple of 8 (XCD split)
   if (nblk > 512) nblk = 512;                                              // rows of the workspace
   static unsigned lds_done = 0;

@@ -1446,11 +1446,7 @@ extern "C" int se_ff_fwd_f16(const float* X, const float* rowstats, const float*
   SE_REQUIRE(precision == 3 || H != nullptr, "ff_fwd: only the scaled split-fp16 form runs without storing H");
   static const bool fwd_ws = !(getenv("SE_FF_FWD_WS") && atoi(getenv("SE_FF_FWD_WS")) == 0);      // SE_FF_FWD_WS=0: the per-128-row kernel
   if (precision == 3 && !a.H && fwd_ws && M * 256 < 4294963200L) {
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-      int v = 0;
-      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
-    }
+    const int ncu = se_cu_count();
     const long need = (M + 255) / 256;
     static unsigned raised = 0;
     const bool dr = drop_p > 0.f;

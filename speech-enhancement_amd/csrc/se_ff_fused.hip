@@ -518,11 +518,7 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
   SE_REQUIRE(drop_p >= 0.f && drop_p <= 0.5f && M * (long)hid < 4294967296L, "ff_bwd_fused: drop_p (keep >= 1/2) / dropout index out of range");
   // one persistent 8-wave workgroup per CU (159 KB of LDS): rows dealt in multiples of the 64-row tile; at least 4 tiles per
   // workgroup so that the 32 768 atomics a workgroup leaves with are amortised
-  int dev = 0, ncu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
-  }
+  const int ncu = se_cu_count();
   long rpw = (M + ncu - 1) / ncu;
   if (rpw < 256) rpw = 256;
   rpw = (rpw + 63) / 64 * 64;

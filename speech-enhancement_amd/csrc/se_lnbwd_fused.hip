@@ -266,11 +266,7 @@ extern "C" int se_gemm_ln_bwd_wgrad(const float* A, const float* WT, long M, int
   SE_REQUIRE(a_amax && w_amax, "gemm_ln_bwd_wgrad: the operand amax scalars are required (scaled split-fp16)");
   SE_REQUIRE(M > 0 && (K == 192 || K == 256), "gemm_ln_bwd_wgrad: M=%ld K=%d (built for K = 192 (qkv) and 256 (pointwise-GLU))", M, K);
   SE_REQUIRE(((size_t)WT & 15) == 0 && ((size_t)A & 15) == 0, "gemm_ln_bwd_wgrad: A and the weight planes must be 16-byte aligned");
-  int dev = 0, ncu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
-  }
+  const int ncu = se_cu_count();
   long rpw = (M + ncu - 1) / ncu;
   if (rpw < 128) rpw = 128;
   rpw = (rpw + 31) / 32 * 32;

@@ -167,6 +167,10 @@ class TSCNet(nn.Module):
 
     def set_dropout(self, ff=0.2, attn=0.2):
         """train-mode dropout probabilities (parity runs use 0, like the fixtures)."""
+        # the fused feed-forward kernels prove their fp16 operand scales from keep >= 1/2 (DESIGN.md section 3): rejected here, once,
+        # instead of a forward that completes and a backward that fails
+        if not (0.0 <= float(ff) <= 0.5 and 0.0 <= float(attn) < 1.0):
+            raise ValueError(f'set_dropout: ff dropout must lie in [0, 0.5] and attn dropout in [0, 1), got {ff}, {attn}')
         self.ff_dropout, self.attn_dropout = float(ff), float(attn)
         return self
 

@@ -626,7 +626,7 @@ def _discriminator_grads_fp64(Or, clean_mag, est_mag, q_est, flips=None, rec=Non
     return {k: gi.detach() for k, gi in zip(names, gr) if gi is not None}
 
 
-def _explain_by_prelu_kinks(Or, clean_mag, est_mag, q_est, ours, d64, rec, names, tau=1e-4, cap=128):
+def _explain_by_prelu_kinks(Or, clean_mag, est_mag, q_est, ours, d64, rec, names, tau=2e-5, cap=32):
     """The discriminator gradient is piecewise smooth in its inputs: at a PReLU pre-activation of (numerically) zero either slope is
     a legitimate fp32 outcome.  Candidates = the pre-activations of the two differentiated forwards with |y| < tau (y is an
     InstanceNorm output: O(1)), at most `cap`; for each one the fp64 gradient with THAT decision flipped; the residual ours - fp64 is
@@ -728,7 +728,7 @@ def test_full_size_train_step_vs_reference(S, golden2, golden4):
                 # and carries a large back-propagated weight: either slope is a legitimate fp32 outcome and moves layers.0.weight_orig
                 # by a fixed 1.18e-3 (exactly the reference's own fp32-vs-fp64 spread; a second crossing: 1.64e-3).  So the
                 # discriminator's arithmetic is compared on IDENTICAL inputs and decisions: the fp64 gradient on the enhanced magnitude
-                # THIS run produced, with the slope choice at the pre-activations of |y| < 1e-4 fitted (0/1) -- bar 2e-4, tighter than
+                # THIS run produced, with the slope choice at the pre-activations of |y| < 2e-5 fitted (0/1; at most 4 accepted) -- bar 2e-4, tighter than
                 # any spread.  What remains against the golden (fp64 on our magnitude vs fp64 on the reference's, `e_input`) is a
                 # property of the reference's function at two inputs 1.4e-5 apart.
                 e_same = kink_res[name]
@@ -736,7 +736,12 @@ def test_full_size_train_step_vs_reference(S, golden2, golden4):
                 e_input = float(np.sqrt(np.mean((d64[name].double().numpy() - ref) ** 2))) / nrm
                 errs[name] = (e, spread, e_same, e_nofit, e_input)
                 assert e_same < 2e-4, (k, e_same, e_nofit, kinks)
-                assert e < 2e-4 + 3.0 * spread, (k, e, spread, e_nofit, e_input)      # sanity cap only: the parity statement is e_same
+                # the fit is a flexible instrument: it may only explain what the root cause allows -- a handful of decisions, each
+                # at a pre-activation within a few fp32 roundings of zero (y is an InstanceNorm output of O(1))
+                assert len(kinks) <= 4 and all(ay < 1e-5 for _, _, ay in kinks), kinks
+                # against the golden: tensors that needed no flip keep the 2.0x bar; a flipped decision moves a tensor by the
+                # reference's own fp32-vs-fp64 spread once more (sanity cap only: the parity statement is e_same)
+                assert e < 2e-4 + (3.0 if e_nofit > 2e-4 else 2.0) * spread, (k, e, spread, e_nofit, e_input)
                 continue
             errs[name] = (e, spread)
             assert e < 2e-4 + 1.5 * spread, (k, e, spread)
