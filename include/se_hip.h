@@ -47,6 +47,11 @@ enum {
   SE_EPI_ROWSTATS = 512  /* N == 64, row GEMM: AUX [M][2] receives (mean, rstd) over the 64 channels of every RESULT row,
                             eps = 1e-5 -- the statistics of the nn.LayerNorm(64) that reads this output next
                             (conformer.py:67,162), i.e. se_row_stats without its pass over the rows                  */
+  , SE_EPI_DELTA = 4096   /* N == 64, row GEMM: AUX [M][4] receives delta[m][h] = sum over the 16 columns of head h of
+                            result * R -- the softmax-backward row constant rowsum(dO . O) of the attention backward
+                            (conformer.py:119-121 backwards) when this GEMM is the to_out input gradient (result = dO) and
+                            R = the attention output O [M][64]; R is only read (no residual is added); excludes
+                            SE_EPI_RESID / SE_EPI_SWISH_GRAD / SE_EPI_ROWSTATS                                        */
 };
 
 /* One "tap GEMM":  Y[m][n] = epi( sum_tap sum_c pro(A[src(m,tap)][a_off+c]) * W[n][tap*C+c] )
@@ -100,7 +105,7 @@ int se_version(void);
 const char* se_last_error(void);
 
 /* Workspace sizes (bytes) of the entry points that take a caller-owned workspace; pure host functions, no GPU call.
- *   se_attn_bwd               : ws     = row constants [ntok][4] + split / transposed copies of E + per-wave dE tiles
+ *   se_attn_bwd               : ws     = row constants [ntok][4] + fp16-split copies of E + the replicas of dE
  *   se_norm_prelu_bwd         : red    = double [per_batch ? B : 1][C][3]
  *   se_dwconv31_wgrad         : ws     = float  [512 workgroups][32][128]
  *   se_disc_tail_fwd / _bwd   : ws     = float  [B][324]
@@ -110,18 +115,6 @@ size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n);
 size_t se_norm_prelu_bwd_workspace_bytes(int B, int C, int per_batch);
 size_t se_segnorm_workspace_bytes(int nseg);
 
-/* InstanceNorm(affine) + PReLU backward in one pass over HBM (models/generator.py:21-22 and discriminator.py:41: the backward of
- * InstanceNorm2d(affine=True) -> PReLU).  Same arithmetic and arguments as se_norm_prelu_bwd with per_batch = 1, act = 0, both
- * phases + parameter gradients; the (X, dY) tiles stay in registers between the reduction and the apply step.
- * se_inorm_prelu_bwd_fused_fits: 1 when (B, P, C) fits the resident grid (otherwise call se_norm_prelu_bwd).  ws:
- * se_inorm_prelu_bwd_fused_workspace_bytes(B, C) bytes, zero-filled by the caller.  spin_us: deadline of the in-kernel wait of an
- * entry's workgroups for each other; tiles that miss it are redone by the second launch of the same call (always correct). */
-int se_inorm_prelu_bwd_fused_fits(int B, long P, int C);
-size_t se_inorm_prelu_bwd_fused_workspace_bytes(int B, int C);
-int se_inorm_prelu_bwd_fused(const float* X, int ldx, int x_off, const float* mr, const float* g, const float* beta,
-                             const float* slope, const float* dY, int ldy, int y_off, void* ws, float* dX, int lddx, int dx_off,
-                             float* dg, float* dbeta, float* dslope, int B, long P, int C, double count, int spin_us,
-                             float* amax_out, void* stream);
 
 /* forward / input-gradient tap GEMM.  rowstats: [M][2] (mean, rstd) for SE_PRO_LN;
  * pro_scale/pro_shift: per-channel (LN gamma/beta or BN scale/shift); stats: double [B][N][2]. */
@@ -142,53 +135,27 @@ typedef struct {
   float* mid_amax;       /* se_ff_bwd_dgrad_f16: raised to max |dZ|; se_ff_fwd_f16: READ as a bound of |Swish(H) * mask| (NULL: mid_sexp) */
 } se_f16_scales;
 
-/* Fused feed-forward forward of a Conformer block (models/conformer.py:53-71,128-145: Scale(0.5, PreNorm(FeedForward))):
-   Y = X + alpha * Drop_o(W2 Drop_h(Swish(W1 LN(X) + b1)) + b2), H = W1 LN(X) + b1 [M, hid] kept for the backward.
-   X, Y: [M, 64]; rowstats: [M, 2] (mean, rstd) from se_row_stats; W1: [hid, 64]; W2: [64, hid]; hid % 64 == 0;
-   precision: 1 / 2 as in se_gemm_desc; dropout masks as in se_gemm_tap (prologue seed = seed_h on H, epilogue = seed_o).
-   precision | 16 (with 2): W1 and W2 point to weights PRE-SPLIT by se_weight_prep -- three bf16 planes of the same [rows][cols]
-   layout each, 64 * hid elements apart, 16-byte aligned (se_ff_bwd_dgrad: W2T and W1T likewise). */
-int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
-              const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid, float drop_p,
-              unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream);
-/* the same, also writing (mean, rstd) (eps 1e-5) of every row of Y to out_stats [M][2] (may be NULL): the statistics of the
-   LayerNorm(64) that reads Y next */
-int se_ff_fwd_stats(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
-                    const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M, int hid,
-                    float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream);
-
-
-/* se_ff_fwd_stats with precision 3 (| 16: pre-split planes are mandatory): W1 / W2 = two scaled fp16 planes each (se_weight_prep
-   fmt 1), sc = their amax scalars + the static activation exponents; H may be NULL (not stored).  sc == NULL: precision 1 / 2 */
+/* Fused feed-forward forward of a Conformer block (models/conformer.py:53-71,128-145: Scale(0.5, PreNorm(FeedForward))), scaled
+   split-fp16 arithmetic (se_gemm_desc.precision 3), hid == 256:
+   Y = X + alpha * Drop_o(W2 Drop_h(Swish(W1 LN(X) + b1)) + b2).  X, Y: [M, 64]; rowstats: [M, 2] (mean, rstd) from se_row_stats;
+   W1 [hid, 64], W2 [64, hid]: two scaled fp16 planes each (se_weight_prep fmt 1), 16-byte aligned; precision must be 3 | 16;
+   sc = their amax scalars + the bounds / static exponents of the activations; dropout masks as in se_gemm_tap (prologue seed =
+   seed_h on H, epilogue = seed_o); out_stats (may be NULL): (mean, rstd) (eps 1e-5) of every row of Y, the statistics of the
+   LayerNorm(64) that reads Y next.  H == NULL (the default path): the W-stationary kernel, H = W1 LN(X) + b1 is not stored (se_ff_bwd_fused
+   recomputes it); H != NULL: [M, hid] is written for se_ff_bwd_dgrad_f16 (the cross-check path). */
 int se_ff_fwd_f16(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
                   const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M, int hid,
                   float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, const se_f16_scales* sc, void* stream);
 
-/* Fused input-gradient chain of the same feed-forward module (the backward of se_ff_fwd without the weight gradients):
+/* Input-gradient chain of the same module from a STORED H (the backward of se_ff_fwd_f16 with H != NULL, without the weight gradients):
    dZ = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H)) [M, hid],  dLN = dZ W1 [M, 64].
-   W2T = (alpha * W2)^T [hid, 64], W1T = W1^T [64, hid]; masks / seeds as in se_ff_fwd.
+   W2T = (alpha * W2)^T [hid, 64], W1T = W1^T [64, hid]: scaled fp16 planes; sc->in_amax = max |dY| (device scalar); precision 3 | 16.
    With X != NULL the LayerNorm backward (se_layernorm_bwd with dR = dY, optional dR2) is applied to dLN in registers:
    dX [M, 64] is written instead of dLN and dgamma / dbeta [64] are accumulated. */
-int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN, long M,
-                    int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision, const float* X,
-                    const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
-                    void* stream);
-
-/* se_ff_bwd_dgrad with precision 3 (| 16): W2T / W1T = scaled fp16 planes, sc->in_amax = max |dY| (device scalar) */
 int se_ff_bwd_dgrad_f16(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN, long M,
                         int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision, const float* X,
                         const float* stats, const float* gamma, const float* dR2, float* dX, float* dgamma, float* dbeta,
                         const se_f16_scales* sc, void* stream);
-
-/* RECOMPUTING backward of the fused feed-forward module (scaled split-fp16 only; hid == 256): dX = dY + dR2 + LNbwd(dZ W1) with
-   dZ = ((Drop_o(dY) W2s) .* Drop_h-mask .* Swish'(H)) and H = LN(X) W1^T + b1 RECOMPUTED from X -- no H is read and no dZ written
-   (se_ff_fwd_f16 with H = NULL stores none; se_ff_wgrad_rc recomputes both for the weight gradients).  W1 [hid][64], W2T = (alpha
-   W2)^T [hid][64], W1T [64][hid]: scaled fp16 planes (se_weight_prep fmt 1) with their amax scalars; dy_amax = max |dY| (device
-   scalar raised by the producer of dY); out_amax (may be NULL) is raised to max |dX|; ln_sexp = static exponent of LN(X). */
-int se_ff_bwd_rc(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta, const float* W1,
-                 const float* b1, const float* W2T, const float* W1T, long M, int hid, float drop_p, unsigned seed_h,
-                 unsigned seed_o, const float* dR2, float* dX, float* dgamma, float* dbeta, const float* dy_amax,
-                 const float* w1_amax, const float* w2t_amax, const float* w1t_amax, float* out_amax, int ln_sexp, void* stream);
 
 /* FUSED backward of the same module, weight gradients included (scaled split-fp16 only; hid == 256; csrc/se_ff_fused.hip): one
    persistent launch computes dX = dY + dR2 + LNbwd(dZ W1) (dgamma / dbeta accumulated; out_amax, may be NULL, raised to max |dX|)
@@ -196,22 +163,12 @@ int se_ff_bwd_rc(const float* dY, const float* X, const float* stats, const floa
    with H, S = Swish(H) Drop_h-mask and dZ recomputed on chip: nothing [M, hid]-sized is read or written (the backward of
    conformer.py:53-71,128-145 behind se_ff_fwd_f16 with H = NULL).  W1 [hid][64], W2T = (alpha W2)^T [hid][64]: scaled fp16 planes
    with their amax scalars; dy_amax = max |dY|; in_amax / mid_amax (may be NULL: the static exponents ln_sexp / hid_sexp) = the
-   proven bounds of |LN(X)| / |Swish(H) mask| the forward scaled its operands with (se_act_bounds); drop_p <= 1/2.
-   W1T / w1t_amax (may be NULL): W1^T [64][hid] as scaled fp16 planes -- with them the symmetric-wave kernel (se_ff_fused3.hip) runs,
-   without them the specialised-wave kernel of se_ff_fused.hip. */
+   proven bounds of |LN(X)| / |Swish(H) mask| the forward scaled its operands with (se_act_bounds); drop_p <= 1/2. */
 int se_ff_bwd_fused(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta, const float* W1,
                     const float* b1, const float* W2T, const float* dR2, float* dX, float* dgamma, float* dbeta, float* dW1,
                     float* db1, float* dW2, float* db2, long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha,
                     const float* dy_amax, const float* w1_amax, const float* w2t_amax, const float* in_amax, int ln_sexp,
-                    const float* mid_amax, int hid_sexp, float* out_amax, const float* W1T, const float* w1t_amax, void* stream);
-
-/* RECOMPUTING weight gradients of the same module (scaled split-fp16 only; hid == 256): dW1 [hid][64] += dZ^T LN(X), db1 += sum dZ,
-   dW2 [64][hid] += alpha (Drop_o dY)^T S, db2 (may be NULL) += alpha sum Drop_o dY, with S = Swish(H) Drop_h-mask, H and dZ as in
-   se_ff_bwd_rc, all recomputed from X and dY: nothing [M, hid]-sized is read.  W1, W2T = (alpha W2)^T: scaled fp16 planes. */
-int se_ff_wgrad_rc(const float* X, const float* stats, const float* gamma, const float* beta, const float* dY, const float* W1,
-                   const float* b1, const float* W2T, float* dW1, float* db1, float* dW2, float* db2, long M, int hid,
-                   float drop_p, unsigned seed_h, unsigned seed_o, float alpha, const float* dy_amax, const float* w1_amax,
-                   const float* w2t_amax, int ln_sexp, int hid_sexp, void* stream);
+                    const float* mid_amax, int hid_sexp, float* out_amax, void* stream);
 
 /* Input-gradient GEMM of a projection that follows a LayerNorm(64), fused with that LayerNorm's backward
  * (models/conformer.py:67,162: PreNorm -> to_q/to_kv, LayerNorm -> pointwise conv):
@@ -376,38 +333,37 @@ int se_attn_fwd(const float* QKV, const float* E, float* O, float* LSE, int nseq
 int se_attn_fwd_es(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
                    int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
 /* backward: dQKV [tokens][192] written, dE accumulated (caller zeroes); ws = workspace of
- * se_attn_bwd_workspace_bytes(ntok, maxpos, nseq, n) bytes, 16-byte aligned (softmax row constants, bf16-split and
- * transposed copies of E, per-wave dE tiles).  Sequences whose padded length fits the offset table (16 * ceil(n / 16) <= maxpos, the
- * training shapes) run the decoupled split-bf16 kernel; longer ones the streaming fp32 kernels. */
+ * se_attn_bwd_workspace_bytes(ntok, maxpos, nseq, n) bytes, 16-byte aligned (softmax row constants, fp16-split copies of E, the
+ * replicas of dE the scaled split-fp16 kernel adds into).  This entry runs the fp32-MFMA kernels (dK / dV pass, dQ / dE pass) for any
+ * sequence length -- the cross-check path of se_attn_bwd_f16_phase and the backward of shapes outside it. */
 int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                 float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
                 long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws, size_t ws_bytes,
                 void* stream);
 
-/* se_attn_bwd in two phases (same arguments): phase 1 = everything but the reduction of the per-wave dE tiles, phase 2 = that
- * reduction alone (reads ws, accumulates dE) -- a leaf of the backward graph that the caller may issue on another stream behind
- * phase 1; phase 3 = both = se_attn_bwd.  Sequence shapes without per-wave tiles do everything in phase 1. */
-int se_attn_bwd_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
-                      float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
-                      long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws, size_t ws_bytes,
-                      int phase, void* stream);
 /* Scaled split-fp16 forms of the same attention (round 3; models/conformer.py:103-122): every operand is x * 2^sexp = hi + lo in
  * two fp16 planes (the scale from a measured maximum, see se_gemm_desc.precision 3), every 16-deep product three
  * v_mfma_f32_16x16x16_f16: fp32-equivalent results (tests/test_attn_gpu.py: 5e-6 / 2e-5 vs fp64 like the bf16 kernels) with
- * 8-instruction operand splits instead of 18.  Sequence shapes: n <= 384, 16 ceil(n / 16) + 128 <= maxpos, maxpos % 16 == 0,
- * 32-bit lane offsets (pos_stride * 192 * padded n < 2^31): anything else is a host error -- use se_attn_fwd_es / se_attn_bwd.
+ * 8-instruction operand splits instead of 18.  Sequence shapes of the backward: n <= 336 (21 key tiles), 16 ceil(n / 16) + 128 <=
+ * maxpos, maxpos % 16 == 0, 32-bit lane offsets (pos_stride * 192 * padded n < 2^31); of the forward: the V image of one (sequence,
+ * head) within the LDS (n <= 4079): anything else is a host error -- use se_attn_fwd_es / se_attn_bwd.
  *   Es        : TWO fp16 planes [2][>= 2 maxpos + 1][16] of E * 2^sexp(*e_amax) (se_weight_prep fmt 1), es_plane elements apart
  *   qkv_amax  : device scalar >= max |QKV| (e.g. raised by the qkv GEMM: se_gemm_desc.y_amax)
  *   do_amax   : device scalar >= max |dO|  (the to_out input-gradient GEMM likewise)
  *   dqkv_amax : optional zero-initialised device scalar raised to max |dQKV| (the scale of the gradient's consumers)
- * The backward splits E itself (and measures its maximum) in its workspace; phases as se_attn_bwd_phase. */
+ *   delta     : optional [tokens][4] table of the softmax-backward row constants rowsum(dO . O) per head (e.g. written by the
+ *               to_out input-gradient GEMM: SE_EPI_DELTA); NULL: computed here from O and dO (one more launch); O may be NULL when
+ *               delta is given
+ * The backward splits E itself (and measures its maximum) in its workspace.  phase 1 = everything but the fold of the dE replicas,
+ * phase 2 = that fold alone (reads ws, accumulates dE) -- a leaf of the backward graph that the caller may issue on another stream
+ * behind phase 1; phase 3 = both. */
 int se_attn_fwd_f16(const float* QKV, const void* Es, long es_plane, const float* qkv_amax, const float* e_amax, float* O,
                     float* LSE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos,
                     float scale, void* stream);
 int se_attn_bwd_f16_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
-                          const float* qkv_amax, const float* do_amax, float* dqkv_amax, float* dQKV, float* dE, int nseq, int n,
-                          int inner, long outer_stride, long inner_stride, long pos_stride, long ntok, int maxpos, float scale,
-                          void* ws, size_t ws_bytes, int phase, void* stream);
+                          const float* delta, const float* qkv_amax, const float* do_amax, float* dqkv_amax, float* dQKV, float* dE,
+                          int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok, int maxpos,
+                          float scale, void* ws, size_t ws_bytes, int phase, void* stream);
 
 /* ---- depthwise conv k=31 along the sequence axis (csrc/se_dwconv.hip) -------------------------- */
 /* DepthWiseConv1d forward (models/conformer.py:40-48,166) on [tokens][128] (+ fp64 BatchNorm statistics

@@ -15,6 +15,7 @@ PRO_NONE, PRO_LN, PRO_SWISH, PRO_AFFINE_SWISH, PRO_SWISH_DROP, PRO_DROP, PRO_GAT
 EPI_BIAS, EPI_ACCUM, EPI_RESID, EPI_GLU, EPI_STATS, EPI_SWISH_GRAD, EPI_SHUFFLE2, EPI_DROP = 1, 2, 4, 8, 16, 32, 64, 128
 EPI_ROWSTATS = 512
 EPI_GLU_GATE = 2048
+EPI_DELTA = 4096
 
 
 class GemmDesc(C.Structure):
@@ -52,7 +53,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.se_last_error.restype = C.c_char_p
         for f in ('se_attn_bwd_workspace_bytes', 'se_norm_prelu_bwd_workspace_bytes', 'se_segnorm_workspace_bytes',
-                  'se_dwconv31_wgrad_workspace_bytes', 'se_disc_tail_workspace_bytes', 'se_inorm_prelu_bwd_fused_workspace_bytes'):
+                  'se_dwconv31_wgrad_workspace_bytes', 'se_disc_tail_workspace_bytes'):
             getattr(_lib, f).restype = C.c_size_t
     return _lib
 

@@ -18,9 +18,6 @@
 // ([B*T, F', C], generator.py:71) both run on the one channels-last [B, T, F', C] buffer with no transposes.
 #include "se_common.h"
 #include <stdlib.h>
-#ifndef SE_ATTN_NO_XCD_MAP
-#define SE_ATTN_NO_XCD_MAP 0
-#endif
 
 struct AttnGeom {
   int nseq, n;             // sequences, positions per sequence
@@ -41,7 +38,6 @@ struct AttnArgs {
   // scaled split-fp16 form of the v3 kernel (se_attn_fwd_f16): Es = TWO fp16 planes of E * 2^sexp(*e_amax) (se_weight_prep fmt 1),
   // qkv_amax = device scalar >= max |QKV| (raised by the epilogue of the qkv GEMM: se_gemm_desc.y_amax)
   const float* qkv_amax; const float* e_amax;
-  int eager;         // (A/B switch SE_ATTN_FWD_LAZY=0: the softmax reference follows the running maximum at every key tile)
 };
 
 static __device__ __forceinline__ long tok_of(const AttnGeom& g, int s, int p) {
@@ -465,17 +461,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs a, int ite
 }
 
 
-// =====================================================================================================================
-// v2 kernels: one workgroup = one (sequence, head); K / V of the head staged once in LDS and shared by the 4 waves,
-// fragment loads are single 16-byte LDS / global accesses (contraction index d = 4g + s, so a lane's 4 MFMA steps read
-// one contiguous float4), token address arithmetic hoisted out of the loops.
-// =====================================================================================================================
 // (sequence, head) item of workgroup b when ONE workgroup handles one item: workgroups are dealt round-robin to the 8 XCDs, so with
 // item = b the four heads of a sequence -- which share every 128-B line of its QKV / dO rows (a head is 64 B of them) -- land on
 // four different L2s and every line crosses the fabric twice.  Here the heads of a sequence are the workgroups b, b + 8, b + 16,
 // b + 24: same XCD, dispatched together.  Measured (FETCH_SIZE): forward 0.86 -> see DESIGN.md; the tail (grid % 32) keeps item = b.
 static __device__ __forceinline__ int xcd_item(int b, int nb) {
-  if (b >= (nb & ~31) || SE_ATTN_NO_XCD_MAP) return b;
+  if (b >= (nb & ~31)) return b;
   return (((b >> 5) * 8 + (b & 7)) << 2) | ((b >> 3) & 3);
 }
 static __device__ __forceinline__ long seq_base(const AttnGeom& g, int s) {
@@ -483,353 +474,13 @@ static __device__ __forceinline__ long seq_base(const AttnGeom& g, int s) {
 }
 static __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
 
-// LDS: Ks[NP][16] | Vt[16][NP+4] | per-wave U ring [4][2 tiles][2 slots][256]
-template <int TQ>      // 16-query tiles per wave block: 2 amortises the K / V fragment reads, 1 balances long sequences over 8 waves
-__global__ __launch_bounds__(512) void attn_fwd2_kernel(AttnArgs a, int NP) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ks = smem;
-  float* Vt = Ks + NP * 16;
-  const int VS = NP + 4;
-  float* Ubase = Vt + 16 * VS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NT = blockDim.x, NW = NT >> 6;      // waves per workgroup: launch parameter (LDS sized to match)
-  const int c = lane & 15, g = lane >> 4;
-  const int n = a.g.n;
-  const int head = blockIdx.x & 3, seq = blockIdx.x >> 2;
-  const long base = seq_base(a.g, seq), ps = a.g.pos_stride;
-  const float* qkv = a.QKV + head * 16;
-  for (int i = tid; i < NP * 4; i += NT) {
-    int j = i >> 2, q = i & 3;
-    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
-    if (j < n) {
-      const float* p = qkv + (base + (long)j * ps) * 192;
-      k4 = *reinterpret_cast<const float4*>(p + 64 + 4 * q);
-      v4 = *reinterpret_cast<const float4*>(p + 128 + 4 * q);
-    }
-    *reinterpret_cast<float4*>(&Ks[j * 16 + 4 * q]) = k4;
-    Vt[(4 * q + 0) * VS + j] = v4.x; Vt[(4 * q + 1) * VS + j] = v4.y;
-    Vt[(4 * q + 2) * VS + j] = v4.z; Vt[(4 * q + 3) * VS + j] = v4.w;
-  }
-  __syncthreads();
-  float* Ul = Ubase + wave * (TQ * 512);      // [tile t][slot][256]
-  const float l2e = 1.4426950408889634f * a.scale;
-  const int qblocks = (n + 16 * TQ - 1) / (16 * TQ), nkt = (n + 15) / 16;
-  for (int qb = wave; qb < qblocks; qb += NW) {
-    const int i0 = qb * 16 * TQ;
-    float4 qf[TQ];
-#pragma unroll
-    for (int t = 0; t < TQ; ++t) {
-      int qi = i0 + 16 * t + c; if (qi > n - 1) qi = n - 1;
-      qf[t] = *reinterpret_cast<const float4*>(qkv + (base + (long)qi * ps) * 192 + 4 * g);
-    }
-    f32x4 o[TQ][2];
-    float m[TQ], l[TQ];
-#pragma unroll
-    for (int t = 0; t < TQ; ++t) {
-      m[t] = -1e30f; l[t] = 0.f;
-      o[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    auto u_tile = [&](int D, int t, int slot) {
-      int d = D + c;
-      d = d < -a.maxpos ? -a.maxpos : (d > a.maxpos ? a.maxpos : d);
-      float4 e = *reinterpret_cast<const float4*>(a.E + (long)(d + a.maxpos) * 16 + 4 * g);
-      f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      u = MFMA16(e.x, qf[t].x, u); u = MFMA16(e.y, qf[t].y, u); u = MFMA16(e.z, qf[t].z, u); u = MFMA16(e.w, qf[t].w, u);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ul[(t * 2 + slot) * 256 + (4 * g + r) * 16 + c] = u[r];
-    };
-#pragma unroll
-    for (int t = 0; t < TQ; ++t) u_tile(i0 + 16 * t, t, 0);
-    int hi = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-      const int j0 = kt * 16, lo = hi ^ 1;
-#pragma unroll
-      for (int t = 0; t < TQ; ++t) u_tile(i0 + 16 * t - j0 - 16, t, lo);
-      float4 kf = *reinterpret_cast<const float4*>(&Ks[(j0 + c) * 16 + 4 * g]);
-      float4 vf = *reinterpret_cast<const float4*>(&Vt[c * VS + j0 + 4 * g]);
-#pragma unroll
-      for (int t = 0; t < TQ; ++t) {
-        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-        s4 = MFMA16(kf.x, qf[t].x, s4); s4 = MFMA16(kf.y, qf[t].y, s4);
-        s4 = MFMA16(kf.z, qf[t].z, s4); s4 = MFMA16(kf.w, qf[t].w, s4);
-        float sc[4], tmax = -1e30f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int dl = c - (4 * g + r);
-          float u = dl >= 0 ? Ul[(t * 2 + hi) * 256 + dl * 16 + c] : Ul[(t * 2 + lo) * 256 + (16 + dl) * 16 + c];
-          sc[r] = (j0 + 4 * g + r < n) ? (s4[r] + u) * l2e : -1e30f;
-          tmax = fmaxf(tmax, sc[r]);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        float mn = fmaxf(m[t], tmax);
-        float corr = __builtin_amdgcn_exp2f(m[t] - mn);
-        m[t] = mn;
-        float p[4], psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[r] - mn); psum += p[r]; }
-        l[t] = l[t] * corr + psum;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { o[t][0][r] *= corr; o[t][1][r] *= corr; }
-        o[t][0] = MFMA16(vf.x, p[0], o[t][0]);
-        o[t][1] = MFMA16(vf.y, p[1], o[t][1]);
-        o[t][0] = MFMA16(vf.z, p[2], o[t][0]);
-        o[t][1] = MFMA16(vf.w, p[3], o[t][1]);
-      }
-      hi = lo;
-    }
-#pragma unroll
-    for (int t = 0; t < TQ; ++t) {
-      float lt = l[t];
-      lt += __shfl_xor(lt, 16, 64);
-      lt += __shfl_xor(lt, 32, 64);
-      int qi = i0 + 16 * t + c;
-      if (qi < n) {
-        long tok = base + (long)qi * ps;
-        float inv = 1.0f / lt;
-        *reinterpret_cast<float4*>(a.O + tok * 64 + head * 16 + 4 * g) =
-            make_float4((o[t][0][0] + o[t][1][0]) * inv, (o[t][0][1] + o[t][1][1]) * inv,
-                        (o[t][0][2] + o[t][1][2]) * inv, (o[t][0][3] + o[t][1][3]) * inv);
-        if (g == 0 && a.LSE) a.LSE[tok * 4 + head] = (m[t] + log2f(lt)) * 0.6931471805599453f;
-      }
-    }
-  }
-}
-
-// Single-pass backward: one workgroup walks (sequence, head) items; per item K, V are staged in LDS, each wave owns
-// 16-query tiles (dQ in registers, sliding rel-pos window as in the forward), dK / dV are accumulated in LDS with
-// ds_add_f32 and written once per item, dE is accumulated in LDS over ALL items of the workgroup and flushed once with
-// global atomics.  P^T / dS^T tiles are transposed through wave-private LDS to serve as the B operands of the
-// dV / dK products.  Requires |i - j| <= maxpos for all pairs (no clamp aliasing): NP <= maxpos.
-// LDS (floats): Ks[NP][16] Vs[NP][16] | dKa[16][NP+4] dVa[16][NP+4] dEa[16][2NP+4] (transposed: the 16 lanes of a
-// lane group add to 16 consecutive words, row strides = 4 mod 8 -> conflict-free ds_add) | scratch[4][6 tiles][16][20]
-// NW = waves per workgroup (8 for the long time-axis sequences: two waves per SIMD hide each other's LDS / MFMA
-// latency chains; the LDS budget then only allows K to be staged, V fragments come from global/L2), SV = V staged.
-template <int NP, int NW, bool SV>
-__global__ __launch_bounds__(NW * 64) void attn_bwd2_kernel(AttnBwdArgs a, const float* __restrict__ Et, int ET, int items_per_block) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int LK = NP + 4, LE = 2 * NP + 4, TS = 20, TILE = 16 * TS, NT = NW * 64;
-  float* Ks = smem;
-  float* Vs = Ks + NP * 16;
-  float* dKa = Vs + (SV ? NP * 16 : 0);
-  float* dVa = dKa + 16 * LK;
-  float* dEa = dVa + 16 * LK;
-  float* scratch = dEa + 16 * LE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  const int n = a.g.n;
-  float* Uf = scratch + wave * 5 * TILE;   // [2 slots]; the consumed `hi` slot doubles as the P^T tile
-  float* dU = Uf + 2 * TILE;               // [2]
-  float* dSl = dU + 2 * TILE;              // [key][query]
-  for (int i = tid; i < 16 * LE; i += NT) dEa[i] = 0.f;
-  const long nitems = (long)a.g.nseq * 4;
-  const long ibeg = (long)blockIdx.x * items_per_block;
-  const int qtiles = (n + 15) / 16, nkt = (n + 15) / 16;
-  const float l2e = 1.4426950408889634f;
-  const long ps = a.g.pos_stride;
-  for (long it = ibeg; it < ibeg + items_per_block && it < nitems; ++it) {
-    const int head = (int)(it & 3), seq = (int)(it >> 2);
-    const long base = seq_base(a.g, seq);
-    const float* qkv = a.QKV + head * 16;
-    __syncthreads();
-    for (int i = tid; i < NP * 4; i += NT) {
-      int j = i >> 2, q = i & 3;
-      float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = k4;
-      if (j < n) {
-        const float* p = qkv + (base + (long)j * ps) * 192;
-        k4 = *reinterpret_cast<const float4*>(p + 64 + 4 * q);
-        if (SV) v4 = *reinterpret_cast<const float4*>(p + 128 + 4 * q);
-      }
-      *reinterpret_cast<float4*>(&Ks[i * 4]) = k4;
-      if (SV) *reinterpret_cast<float4*>(&Vs[i * 4]) = v4;
-    }
-    for (int i = tid; i < 16 * LK; i += NT) { dKa[i] = 0.f; dVa[i] = 0.f; }
-    __syncthreads();
-    // Lock-step schedule instead of LDS atomics (ds_add_f32 costs ~500 cycles per wave-instruction here): in every
-    // step the 4 waves work on 4 DIFFERENT key tiles (wave w starts its key sweep at tile 2w and wraps), so their
-    // read-modify-writes of dKa / dVa (indexed by key tile) and dEa (indexed by the offset tile q - k, distinct
-    // because (s_w' - s_w) mod nkt != w' - w) never overlap; one barrier per phase orders successive steps.
-    // start offsets 2w need 2 (NW-1) < nkt; tiny sequences: a single wave (no conflicts possible)
-    const int nwact = nkt >= 2 * NW - 1 ? NW : (nkt >= 7 ? 4 : 1);
-    const int rounds = (qtiles + nwact - 1) / nwact;
-    const int sw = 2 * wave;
-    for (int round = 0; round < rounds; ++round) {
-      const int qt = wave + nwact * round;
-      const bool active = wave < nwact && qt < qtiles;
-      const int i0 = qt * 16;
-      int qi = i0 + c;
-      const bool qok = active && qi < n;
-      if (qi > n - 1) qi = n - 1;
-      if (qi < 0) qi = 0;
-      const long qtok = base + (long)qi * ps;
-      float4 qf = make_float4(0.f, 0.f, 0.f, 0.f), dof = qf;
-      float qT[4] = {0.f, 0.f, 0.f, 0.f}, doT[4] = {0.f, 0.f, 0.f, 0.f};
-      float lse = 0.f, dlt = 0.f;
-      if (active) {
-        qf = *reinterpret_cast<const float4*>(qkv + qtok * 192 + 4 * g);
-        dof = *reinterpret_cast<const float4*>(a.dO + qtok * 64 + head * 16 + 4 * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int qr = i0 + 4 * g + r; if (qr > n - 1) qr = n - 1;
-          long tk = base + (long)qr * ps;
-          qT[r] = qkv[tk * 192 + c];
-          doT[r] = a.dO[tk * 64 + head * 16 + c];
-        }
-        lse = a.LSE[qtok * 4 + head];
-        dlt = a.Dl[qtok * 4 + head];
-      }
-      f32x4 dq = {0.f, 0.f, 0.f, 0.f};
-      auto u_tile = [&](int D, int slot) {
-        float4 e = *reinterpret_cast<const float4*>(a.E + (long)(D + c + a.maxpos) * 16 + 4 * g);
-        f32x4 u = {0.f, 0.f, 0.f, 0.f};
-        u = MFMA16(e.x, qf.x, u); u = MFMA16(e.y, qf.y, u); u = MFMA16(e.z, qf.z, u); u = MFMA16(e.w, qf.w, u);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Uf[slot * TILE + (4 * g + r) * TS + c] = u[r];
-      };
-      // consume a finished offset tile (offsets [D, D+15]): dQ += E^T dU ; dE^T += Q^T dU^T (plain RMW, see above)
-      auto consume = [&](int D, int slot) {
-        float4 et = *reinterpret_cast<const float4*>(Et + (long)c * ET + (D + 4 * g + a.maxpos));   // E[D+4g+r][d=c]
-        dq = MFMA16(et.x, dU[slot * TILE + (4 * g + 0) * TS + c], dq);
-        dq = MFMA16(et.y, dU[slot * TILE + (4 * g + 1) * TS + c], dq);
-        dq = MFMA16(et.z, dU[slot * TILE + (4 * g + 2) * TS + c], dq);
-        dq = MFMA16(et.w, dU[slot * TILE + (4 * g + 3) * TS + c], dq);
-        float4 du = *reinterpret_cast<const float4*>(&dU[slot * TILE + c * TS + 4 * g]);       // dU[delta c][q 4g+r]
-        f32x4 de = {0.f, 0.f, 0.f, 0.f};
-        de = MFMA16(qT[0], du.x, de); de = MFMA16(qT[1], du.y, de); de = MFMA16(qT[2], du.z, de); de = MFMA16(qT[3], du.w, de);
-        int row = D + c + NP;                 // de[r] = dE[delta = D + c][d = 4g + r]
-        if (row >= 0 && row < 2 * NP) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dEa[(4 * g + r) * LE + row] += de[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { dU[slot * TILE + (4 * g + r) * TS + c] = 0.f; }
-      };
-      int hi = 0;
-      // ONE barrier per step: between two barriers all waves are in the same step, where they own distinct key tiles
-      // and distinct offset tiles (see above).  The last low offset tile of a run (16 (qt - kt - 1)) is consumed after
-      // the NEXT barrier: there it can only meet offset tiles 16 (qt' - kt') of step t + 1, and
-      // qt - (t + 2w) - 1 == qt' - (t + 1 + 2w') forces w == w' (same wave, program order).
-      bool pend = false;
-      int pendD = 0;
-      for (int t = 0; t < nkt; ++t) {
-        int kt = t + sw;
-        if (kt >= nkt) kt -= nkt;
-        if (nwact == 1) kt = t;
-        const int j0 = kt * 16, D0 = i0 - j0;
-        __syncthreads();
-        if (pend) { consume(pendD, hi); pend = false; }
-        if (active) {
-          if (t == 0 || kt == 0) {           // start of a monotone run of key tiles: prime the window
-#pragma unroll
-            for (int r = 0; r < 10; ++r) dU[r * 64 + lane] = 0.f;
-            hi = 0;
-            u_tile(D0, 0);
-          }
-          const int lo = hi ^ 1;
-          u_tile(D0 - 16, lo);
-          const float4 kf = *reinterpret_cast<const float4*>(&Ks[(j0 + c) * 16 + 4 * g]);
-          float4 vf;
-          if (SV) vf = *reinterpret_cast<const float4*>(&Vs[(j0 + c) * 16 + 4 * g]);
-          else { int kj = j0 + c; if (kj > n - 1) kj = n - 1;
-                 vf = *reinterpret_cast<const float4*>(qkv + (base + (long)kj * ps) * 192 + 128 + 4 * g); }
-          f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-          s4 = MFMA16(kf.x, qf.x, s4); dp = MFMA16(vf.x, dof.x, dp);
-          s4 = MFMA16(kf.y, qf.y, s4); dp = MFMA16(vf.y, dof.y, dp);
-          s4 = MFMA16(kf.z, qf.z, s4); dp = MFMA16(vf.z, dof.z, dp);
-          s4 = MFMA16(kf.w, qf.w, s4); dp = MFMA16(vf.w, dof.w, dp);
-          float ds[4], uu[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {            // all skew reads first: the `hi` slot is recycled as Pl below
-            int dlc = c - (4 * g + r);
-            uu[r] = dlc >= 0 ? Uf[hi * TILE + dlc * TS + c] : Uf[lo * TILE + (16 + dlc) * TS + c];
-          }
-          float* Pl = Uf + hi * TILE;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int dlc = c - (4 * g + r);
-            float u = uu[r];
-            float sv = (s4[r] + u) * a.scale;
-            bool ok = qok && (j0 + 4 * g + r < n);
-            float p = ok ? __builtin_amdgcn_exp2f((sv - lse) * l2e) : 0.f;
-            ds[r] = p * (dp[r] - dlt) * a.scale;
-            if (dlc >= 0) dU[hi * TILE + dlc * TS + c] += ds[r]; else dU[lo * TILE + (16 + dlc) * TS + c] += ds[r];
-            Pl[(4 * g + r) * TS + c] = p;
-            dSl[(4 * g + r) * TS + c] = ds[r];
-          }
-          // dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (A: lane (d=c, g) supplies K[j0+4g+r][c])
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dq = MFMA16(Ks[(j0 + 4 * g + r) * 16 + c], ds[r], dq);
-          // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
-          // B: lane (key c, k-index g) supplies X[q 4g+r][key c] = Xl[key c][4g + r]
-          const float4 pb = *reinterpret_cast<const float4*>(&Pl[c * TS + 4 * g]);
-          const float4 sb = *reinterpret_cast<const float4*>(&dSl[c * TS + 4 * g]);
-          f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f};
-          dv = MFMA16(doT[0], pb.x, dv); dk = MFMA16(qT[0], sb.x, dk);
-          dv = MFMA16(doT[1], pb.y, dv); dk = MFMA16(qT[1], sb.y, dk);
-          dv = MFMA16(doT[2], pb.z, dv); dk = MFMA16(qT[2], sb.z, dk);
-          dv = MFMA16(doT[3], pb.w, dv); dk = MFMA16(qT[3], sb.w, dk);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {      // dv[r] = dV[key j0+c][d = 4g+r]; this wave owns key tile kt in this step
-            dVa[(4 * g + r) * LK + j0 + c] += dv[r];
-            dKa[(4 * g + r) * LK + j0 + c] += dk[r];
-          }
-          consume(D0, hi);
-          hi = lo;
-          if (kt == nkt - 1 || t == nkt - 1) { pend = true; pendD = D0 - 16; }   // end of a run: the last low tile
-        }
-      }
-      __syncthreads();
-      if (pend) consume(pendD, hi);
-      if (qok) *reinterpret_cast<float4*>(a.dQKV + qtok * 192 + head * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
-    }
-    __syncthreads();
-    for (int i = tid; i < NP * 4; i += NT) {
-      int j = i >> 2, q = i & 3;
-      if (j < n) {
-        float* p = a.dQKV + (base + (long)j * ps) * 192 + head * 16 + 4 * q;
-        *reinterpret_cast<float4*>(p + 64) = make_float4(dKa[(4 * q) * LK + j], dKa[(4 * q + 1) * LK + j],
-                                                         dKa[(4 * q + 2) * LK + j], dKa[(4 * q + 3) * LK + j]);
-        *reinterpret_cast<float4*>(p + 128) = make_float4(dVa[(4 * q) * LK + j], dVa[(4 * q + 1) * LK + j],
-                                                          dVa[(4 * q + 2) * LK + j], dVa[(4 * q + 3) * LK + j]);
-      }
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < 16 * 2 * NP; i += NT) {
-    int dch = i / (2 * NP), row = i - dch * (2 * NP);
-    float v = dEa[dch * LE + row];
-    int d = row - NP;
-    if (v != 0.f && d >= -a.maxpos && d <= a.maxpos) atomicAdd(&a.dE[(long)(d + a.maxpos) * 16 + dch], v);
-  }
-}
-
-
 // =====================================================================================================================
-// v3 backward: decoupled waves, key-stationary, split-bf16 MFMA.
-//
-// Why: the v2 kernel keeps dK / dV / dE in LDS accumulators shared by the waves of a workgroup; LDS float atomics run at one
-// lane per ~3 cycles on gfx950 (ds_add_f32: 192 cycles per wave-instruction, tools/micro/lds_atomic_bench.hip), so v2 uses
-// plain read-modify-writes under a lock-step schedule with one barrier per 16x16 tile pair -- all waves of a CU sit in the
-// same phase (MFMA, then LDS, then VALU) and nothing overlaps: 0.24 of the fp32-MFMA peak.
-//
-// Here ONE WAVE owns a work item (sequence, head, group of KT3 = 7 key tiles = 112 keys) and there is no barrier and no shared
-// accumulator in the main loop:
-//   * dK^T / dV^T of its 7 key tiles stay in registers (key loop unrolled: static indices) and are stored once;
-//   * the wave sweeps the query tiles; dQ^T of a query tile is summed over the wave's 7 key tiles in registers and then
-//     either stored (one key group covers the sequence: n <= 112) or added to global memory with fp32 atomics (3 adds per
-//     element for n = 321: 0.4 GB of atomic bytes per launch, overlapped with compute, well under the chip's 1.3 TB/s);
-//   * the relative-position terms use a per-query-tile OFFSET STRIP in wave-private LDS: U[q][delta] = q . E[delta] for the
-//     8 offset tiles the 7 key tiles touch is written once per query tile, every step reads its skewed 16x16 window and
-//     overwrites it IN PLACE with dS (each (q, delta) cell belongs to exactly one key), and the finished strip W = skew(dS)
-//     feeds  dQ^T += E^T W^T  and  dE^T += Q^T W  tile by tile;
-//   * dE accumulators live in a REGISTER WINDOW of 8 offset tiles that slides with the query tile (v_mov rotation); the
-//     tile leaving the window is flushed with global atomics into one of NREP replicas of the table (summed at the end).
-// Every product is an exact 3-way bf16 split evaluated with THREE v_mfma_f32_16x16x32_bf16: the contraction length is 16, so
+// Split-operand MFMA arithmetic shared by the v3 forward and the v4 backward (se_attn_bwd4.h).
+// bf16x6: every product is an exact 3-way bf16 split evaluated with THREE v_mfma_f32_16x16x32_bf16: the contraction length is 16, so
 // the two halves of K = 32 carry two different split pairs (k slot (g, j): j < 4 -> first pair, j >= 4 -> second pair, index
 // 4g + (j & 3)):  [a_hi|a_mid].[b_lo|b_mid] + [a_hi|a_lo].[b_mid|b_hi] + [a_hi|a_mid].[b_hi|b_hi]  = the six products of the
 // fp32-equivalent split (dropped terms <= 2^-24 relative) at 48 instead of 128 matrix-pipe cycles per 16x16x16 product.
-// K is staged once per item, pre-split, in wave-private LDS: its row fragments are ds_read_b64, its column fragments (for
-// dQ^T += K^T dS^T) come from the same image through ds_read_b64_tr_b16.
+// f16x3 (default): scaled (hi, lo) fp16 planes, three v_mfma_f32_16x16x16_f16 per product.
 // =====================================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -937,7 +588,32 @@ template <bool F16> static __device__ __forceinline__ S3 splitn(const float4& v)
   else return split3(v.x, v.y, v.z, v.w);
 }
 template <bool F16> static __device__ __forceinline__ S3 splitx(const f32x4& v, float sc) { return splitx<F16>(v[0], v[1], v[2], v[3], sc); }
+// Measurement twins of the scaled-fp16 attention kernels (tools/attn_twin.py builds them as variant libraries; WRONG results, never
+// part of the product build): SE_ATTN_TWIN == 1 keeps the MFMAs, the global / LDS traffic and the barriers and compiles the vector
+// chain between the products out (softmax, rescale, operand splits of P / dS / W: the raw accumulator registers are handed on as the
+// next product's operand words, so every data dependence stays); SE_ATTN_TWIN == 2 keeps the vector chain and the traffic and
+// replaces every MFMA by two value-preserving v_fma_f32 (acc + word * 0) that read its operands (accumulators stay 0: logits 0, no
+// data-dependent branch is taken more often than in the real kernel's steady state).
+#ifndef SE_ATTN_TWIN
+#define SE_ATTN_TWIN 0
+#endif
+#if SE_ATTN_TWIN == 2
+static __device__ __forceinline__ f32x4 twin_nomfma_(u32x2 a, u32x2 b, f32x4 c) {
+  float c0 = c[0];
+  asm volatile("v_fma_f32 %0, %1, 0, %0\n\tv_fma_f32 %0, %2, 0, %0" : "+v"(c0) : "v"(a[0]), "v"(b[1]));
+  c[0] = c0;
+  return c;
+}
+#define MFMA_HF(a, b, c) twin_nomfma_((a), (b), (c))
+#else
 #define MFMA_HF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4a, (a)), __builtin_bit_cast(f16x4a, (b)), (c), 0, 0, 0)
+#endif
+// (twin 1) four fp32 registers handed on as the (hi, lo) words of a split operand without any arithmetic
+static __device__ __forceinline__ S3 twin_raw_(float a, float b, float c, float d) {
+  S3 s;
+  s.v = (u32x6){0u, 0u, __float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+  return s;
+}
 template <bool F16>
 static __device__ __forceinline__ f32x4 prodx(const S3& a, const S3& b, f32x4 acc) {
   if constexpr (F16) {
@@ -997,24 +673,9 @@ static __device__ __forceinline__ S3 tr_planes(const unsigned char* p, int pb) {
   return s;
 }
 
-constexpr int NREP3 = 1;   // (unused by the scratch-based dE reduction; kept for the workspace layout)
 
-// split tables of the relative-position embedding: Es[3][R][16] (row fragments), Ets[3][ET/16 tiles][16 d][16 offsets]
-// (column fragments; tile-major so that one offset tile is 512 contiguous bytes per plane: 4 cache lines instead of 16)
-__global__ void attn_split_tables_kernel(const float* __restrict__ E, __bf16* __restrict__ Es, __bf16* __restrict__ Ets,
-                                         int R, int ET) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= R * 16) return;
-  int row = idx >> 4, d = idx & 15;
-  float x = E[idx];
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    __bf16 h = (__bf16)x;
-    x -= (float)h;
-    Es[((long)pl * R + row) * 16 + d] = h;
-    Ets[(long)pl * ET * 16 + ((long)(row >> 4) * 16 + d) * 16 + (row & 15)] = h;      // [plane][tile][d][16 offsets]
-  }
-}
+// split tables of the relative-position embedding for the backward: Es[2][R][16] (row fragments), Ets[2][ET/16 tiles][16 d][16 offsets]
+// (column fragments; tile-major so that one offset tile is 512 contiguous bytes per plane: 4 cache lines instead of 16) as two fp16
 // the same two tables as two fp16 planes of E * 2^sexp(max |E|) (scaled split-fp16 backward): ONE workgroup measures the maximum,
 // publishes it for the main kernel (e_amax) and splits; 16 K elements
 __global__ __launch_bounds__(1024) void attn_split_tables_f16_kernel(const float* __restrict__ E, unsigned short* __restrict__ Es,
@@ -1056,468 +717,40 @@ __global__ __launch_bounds__(1024) void attn_split_tables_f16_kernel(const float
     Ets[(long)1 * ET * 16 + to] = lb;
   }
 }
-// fp32 transposed table Et[16][ld] of the v2 kernel
-__global__ void attn_transpose_table_kernel(const float* __restrict__ E, float* __restrict__ Et, int R, int ld) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= R * 16) return;
-  Et[(long)(idx & 15) * ld + (idx >> 4)] = E[idx];
-}
 
-struct AttnBwd3Args {
+struct AttnBwd4Args {
   AttnGeom g;
-  const float* QKV; const float* dO; const float* LSE; const float* Dl;
+  const float* QKV; const float* dO; const float* LSE; const float* Dl;      // Dl [tokens][4]: delta = rowsum(dO . O) per head
   float* dQKV;
-  const __bf16* Es; const __bf16* Ets;
-  float* dEs;                        // per-wave dE tiles: [wave item][nqt + KT][16 offsets][16 d]
+  const __bf16* Es; const __bf16* Ets;   // two fp16 planes of E * 2^sexp(*e_amax): row fragments [R][16] / tile-major column fragments
+  float* dEs;                        // ATTN_DE_NREP replicas of the fp32 table [R][16] the offset tiles are added into (zeroed per call)
   int R, ET, maxpos;
   float scale;
-  int dbg;                           // timing ablations: SE_ATTN_DBG bits 1 no dE flush, 4 V := K, 8 E := Q (0 in production)
-  // scaled split-fp16 form (se_attn_bwd_f16): device scalars >= max |QKV|, max |dO|, max |E| (the last one written by the table
-  // kernel of the same call); Es / Ets then hold TWO fp16 planes of E * 2^sexp(*e_amax)
+  int dbg;                           // SE_ATTN_DBG: 1 no U of the next tile, 2 no key steps, 4 no strip consumption (timing ablations), 32 stamps
+                                     // (diagnostic builds), 64 the generic body for every wave (tests); 0 in production
+  // device scalars >= max |QKV|, max |dO|, max |E| (the last one written by the table kernel of the same call)
   const float* qkv_amax; const float* do_amax; const float* e_amax;
-  float* dqkv_amax;                  // optional (F16): raised to max |dQKV| (operand scale of the consumers of the gradient)
-  const float* O;                    // the forward output (attn_bwd4: delta computed in the kernel)
+  float* dqkv_amax;                  // optional: raised to max |dQKV| (operand scale of the consumers of the gradient)
 };
 
-// key tiles of wave w when the 4 waves of a workgroup share one (sequence, head)
-static __device__ __host__ __forceinline__ void group_split(int nkt, int w, int& kt0, int& cnt) {
-  const int b = nkt >> 2, r = nkt & 3;
-  cnt = b + (w < r ? 1 : 0);
-  kt0 = w * b + (w < r ? w : r);
-}
-
-// key tiles of the register window a grouped wave with cnt tiles runs (the body is instantiated for KT and KT - 1 exactly)
-static __device__ __host__ __forceinline__ int group_window(int KT, int cnt) { return (cnt == KT || cnt == KT - 1) ? cnt : KT; }
-template <int KT, bool F16 = false>
-struct Lds3 {
-  static constexpr int NU = KT + 1;
-  static constexpr int NPLA = F16 ? 2 : 3;                    // planes of a split operand: (hi, mid, lo) bf16 / (hi, lo) fp16
-  // strip row stride (floats): + 4 makes the skewed cell accesses (row stride SW + 1) conflict free -- the three-plane images of
-  // the bf16 form at KT = 7 left no room for it within 80 KB per workgroup (two per CU); the two-plane fp16 form has it
-  static constexpr int SW = NU * 16 + ((KT == 7 && !F16) ? 0 : 4);
-  static constexpr int KPB = KT * 16 * 32;                    // bytes of one plane of the K image
-  static constexpr int KIMG = NPLA * KPB;                     // bytes: [planes][KT*16 keys][16 d] 16-bit
-  static constexpr int DIMG = NPLA * 16 * 32;                 // bytes: [planes][16][16] 16-bit (one tile, split)
-  static constexpr int STRIP = 16 * SW * 4;
-  static constexpr int WAVE = KIMG + DIMG + STRIP;
-};
-
-// raw query-side operands of one query tile (prefetched one tile ahead)
-struct QSide { float4 q4, do4; float qcf[4], docf[4], lse[4], dl[4]; };
-
-// One wave: key tiles kt0 .. kt0 + nk_w - 1 of one (sequence, head), all query tiles.
-//   NK    : key tiles the register arrays and the unrolled loops are built for;
-//   EXACT : nk_w == NK, the unrolled key loop has no branches (one basic block per query tile: the compiler overlaps the LDS /
-//           global latencies of step s + 1 with the arithmetic of step s);  otherwise NK = KT and steps s >= nk_w are skipped;
-//   GROUP : the 4 waves of the workgroup share the (sequence, head): dQ tiles are summed through LDS (one barrier per query
-//           tile) and stored once -- deterministic, no atomics.
-// F16: scaled split-fp16 operands (two planes, 8-instruction splits, three K = 16 MFMAs per product).  Scales: Q, K, V by 2^sq,
-// dO by 2^sdo, E by 2^se (measured maxima), P by 2^13 (folded into the exponent argument), dS by 2^sds with sds from the bound
-// |dS| <= P scale (|dP| + |D|) <= 32 scale max|dO| max|V| (both are 16-term dot products against V and O, |O| <= max |V|); every
-// accumulator is brought back by ONE power of two where it is stored.  dQ collects K^T dS^T (2^(sq + sds)) and E^T W^T
-// (2^(se + sds)) in two accumulators.
-// RING (grouped fp16 form, nkt <= 21): the dE tiles of the four waves of a workgroup are summed in LDS before they leave the CU.
-// Wave w flushes offset tile D at query tile D + kt0_w + cnt_w (strictly increasing in w), so the contributions to one tile arrive
-// in wave order, 5 - 6 query tiles apart, always behind the per-query-tile barrier of the dQ reduction: the first contributor
-// STORES its tile into a 16-slot ring (slot = D mod 16: at most 16 tiles are open at any time), the next ones add to it, the last
-// adds and writes the finished tile to the (sequence, head) item's table [2 nkt][256] -- 41 tile writes per item instead of 108,
-// and the reduction kernel reads as much less.  The tiles still in the register windows after the last query tile go out in four
-// rounds (wave 0 .. 3) with a barrier in between.  dQ's LDS exchange drops to one parity (+ one barrier) to make room for the ring.
-template <int KT, int NK, bool EXACT, bool GROUP, bool F16 = false, bool RING = false>
-static __device__ __forceinline__ void attn_bwd3_body(const AttnBwd3Args& a, unsigned char* smem3, const int wave, const int lane,
-                                                      const long item, const int kt0, const int nk_w) {
-  using L3 = Lds3<KT, F16>;
-  constexpr int NU = NK + 1, SW = L3::SW;
-  const int c = lane & 15, g = lane >> 4;
-  const int n = a.g.n, nkt = (n + 15) >> 4, nqt = nkt;
-  unsigned char* wl = smem3 + (size_t)wave * L3::WAVE;
-  unsigned char* Kimg = wl;
-  unsigned char* Dimg = wl + L3::KIMG;
-  float* strip = reinterpret_cast<float*>(wl + L3::KIMG + L3::DIMG);
-  float* dqs = reinterpret_cast<float*>(smem3 + (size_t)4 * L3::WAVE);      // GROUP: [2 parities (RING: 1)][4 waves][256]
-  float* ring = dqs + 4 * 256;                                              // RING: [16 slots][256]
-  const int head = (int)(item & 3), seq = (int)(item >> 2);
-  const long base = seq_base(a.g, seq);
-  const int ps = (int)a.g.pos_stride;
-  const float* qb = a.QKV + base * 192 + head * 16;             // + pos * ps * 192 (+64: K, +128: V)
-  const float* dob = a.dO + base * 64 + head * 16;
-  const float* lseb = a.LSE + base * 4 + head;
-  const float* dlb = a.Dl + base * 4 + head;
-  float* dqb = a.dQKV + base * 192 + head * 16;
-  const float l2e = 1.4426950408889634f;
-  const long witem = GROUP ? item * 4 + wave : item;
-  float* dEs = RING ? a.dEs + item * (long)(2 * nkt) * 256 : a.dEs + witem * (long)(nqt + KT) * 256;
-  // RING: the offset tiles wave w flushes are [-(kt0_w + cnt_w), nqt - kt0_w - 1]
-  int rlo[4] = {0, 0, 0, 0}, rhi[4] = {0, 0, 0, 0};
-  if (RING) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {      // (a wave whose tile count is neither KT nor KT - 1 runs the KT-wide window: group_window)
-      int k0, cn;
-      group_split(nkt, w, k0, cn);
-      rlo[w] = -(k0 + group_window(KT, cn));
-      rhi[w] = nqt - k0 - 1;
-    }
-  }
-  const int trrow = c >> 2, trcol = c & 3;                      // transposed-read address roles of this lane
-  const unsigned char* Esb = reinterpret_cast<const unsigned char*>(a.Es);      // planes (long)R * 32 bytes apart
-  const unsigned char* Etb = reinterpret_cast<const unsigned char*>(a.Ets);     // planes (long)ET * 32 bytes apart
-  const long esp = (long)a.R * 32, etp = (long)a.ET * 32;
-  float sqf = 1.f, sdof = 1.f, kU = 1.f, kD = 1.f, kdl = a.scale, cq1 = 1.f, cq2 = 1.f, cdv = 1.f, lse13 = 0.f;
-  float sc2 = a.scale * 1.4426950408889634f;
-  if (F16) {
-    f16_clamp_mode_a();
-    const float aq = *a.qkv_amax, ado = *a.do_amax;
-    const int sq = f16_sexp_a(aq), sdo = f16_sexp_a(ado), se = f16_sexp_a(*a.e_amax);
-    const int sds = f16_sexp_a(32.f * a.scale * ado * aq);
-    sqf = exp2ia(sq); sdof = exp2ia(sdo);
-    kU = exp2ia(sq - se);                          // strip cells U = q.E at the scale of S = q.k
-    sc2 *= exp2ia(-2 * sq);
-    kD = a.scale * exp2ia(sds - 13 - sdo - sq);    // (dP accumulator) -> scale (dP) 2^(sds - 13): times P 2^13 = dS 2^sds
-    kdl = a.scale * exp2ia(sds - 13);
-    cq1 = exp2ia(-sq - sds); cq2 = exp2ia(-se - sds); cdv = exp2ia(-sdo - 13);
-    lse13 = 13.f;
-  }
-
-  // ---- stage this wave's keys: K pre-split into the LDS image (row fragments b64, column fragments tr_b16) ----
-  // all NK rows are requested before the first one is split (clamped key index, zeroed by a select): with the load behind
-  // `if (key < n)` every key tile was its own dependent HBM round trip (rows of a time-axis sequence are 77 KB apart)
-  float4 k4s[NK];
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    int key = (kt0 + s) * 16 + c;
-    if (key > n - 1) key = n - 1;
-    k4s[s] = *reinterpret_cast<const float4*>(qb + (unsigned)(key * ps * 192 + 64 + 4 * g));
-  }
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    const int key = (kt0 + s) * 16 + c;
-    const bool kok = (EXACT || s < nk_w) && key < n;
-    const float4 k4 = make_float4(kok ? k4s[s].x : 0.f, kok ? k4s[s].y : 0.f, kok ? k4s[s].z : 0.f, kok ? k4s[s].w : 0.f);
-    st_planes<F16>(Kimg + ((s * 16 + c) * 16 + 4 * g) * 2, L3::KPB, splitx<F16>(k4, sqf));
-  }
-  f32x4 dk[NK], dv[NK], de[NU];
-  float omax = 0.f;                                                  // F16: max |dQKV| this wave stores
-#pragma unroll
-  for (int s = 0; s < NK; ++s) { dk[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[s] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-  for (int u = 0; u < NU; ++u) de[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // one finished offset tile of the dE window goes to this wave's slot (Dtile + kt0 + KT) of the scratch table:
-  // v[r] = dE[delta = 16 Dtile + c][d = 4g + r]; tiles no (query, key) pair can reach are neither stored nor reduced
-  auto flush = [&](const f32x4& v, int Dtile) {
-    if (Dtile < -nkt || Dtile > nkt || (a.dbg & 1)) return;
-    float4 val = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
-    if (RING) {
-      int first = 3, last = 0;                                    // (wave-uniform; this wave is one of the contributors)
-#pragma unroll
-      for (int w = 3; w >= 0; --w) if (Dtile >= rlo[w] && Dtile <= rhi[w]) first = w;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) if (Dtile >= rlo[w] && Dtile <= rhi[w]) last = w;
-      float4* rs = reinterpret_cast<float4*>(ring + ((Dtile + 64) & 15) * 256 + c * 16 + 4 * g);
-      if (wave != first) { const float4 o = *rs; val.x += o.x; val.y += o.y; val.z += o.z; val.w += o.w; }
-      if (wave == last) *reinterpret_cast<float4*>(dEs + (Dtile + nkt) * 256 + c * 16 + 4 * g) = val;
-      else *rs = val;
-      return;
-    }
-    *reinterpret_cast<float4*>(dEs + (Dtile + kt0 + KT) * 256 + c * 16 + 4 * g) = val;
-  };
-  auto load_qside = [&](int qt, QSide& o) {
-    const int q0 = qt * 16;
-    int qc = q0 + c; if (qc > n - 1) qc = n - 1;
-    o.q4 = *reinterpret_cast<const float4*>(qb + (unsigned)(qc * ps * 192 + 4 * g));        // Q[q = c][4g..]
-    o.do4 = *reinterpret_cast<const float4*>(dob + (unsigned)(qc * ps * 64 + 4 * g));
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int qr = q0 + 4 * g + j;
-      if (qr > n - 1) qr = n - 1;
-      o.qcf[j] = qb[(unsigned)(qr * ps * 192 + c)];          // Q[q = 4g + j][d = c]   (column fragment: contraction over queries)
-      o.docf[j] = dob[(unsigned)(qr * ps * 64 + c)];
-      o.lse[j] = lseb[(unsigned)(qr * ps * 4)];
-      o.dl[j] = dlb[(unsigned)(qr * ps * 4)];
-    }
-  };
-  QSide nxt;
-  load_qside(0, nxt);
-
-  for (int qt = 0; qt < nqt; ++qt) {
-    // ---- query-side operands of this tile (prefetched during the previous tile; split once, used by all key tiles) ----
-    const int q0 = qt * 16;
-    const QSide cur = nxt;
-    if (qt + 1 < nqt) load_qside(qt + 1, nxt);
-    float nlse2[4], dl4s[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // C-layout rows are queries 4g + r: p = exp2((s + u) * scale * log2e - lse * log2e); rows beyond n get -inf -> p = 0
-      nlse2[j] = (q0 + 4 * g + j < n) ? lse13 - cur.lse[j] * l2e : -__builtin_inff();      // (F16: p carries P's factor 2^13)
-      dl4s[j] = cur.dl[j] * kdl;
-    }
-    const S3 qrow = splitx<F16>(cur.q4, sqf);
-    // dP pre-scaled by `scale` (F16: the factor is part of kD instead)
-    const float dps = F16 ? sdof : a.scale;
-    const S3 dorow = F16 ? splitx<true>(cur.do4, dps) : split3(cur.do4.x * dps, cur.do4.y * dps, cur.do4.z * dps, cur.do4.w * dps);
-    const S3 qcol = splitx<F16>(cur.qcf[0], cur.qcf[1], cur.qcf[2], cur.qcf[3], sqf);
-    const S3 docol = splitx<F16>(cur.docf[0], cur.docf[1], cur.docf[2], cur.docf[3], sdof);
-
-    // ---- offset strip: U[q][delta] for the NU tiles Dtile = qt - kt0 - u, strip columns 16 (NK - u) + (delta & 15) ----
-    // the E row fragments are requested in batches of EB tiles before their products: one L2 round trip per batch, not per tile
-    constexpr int EB = 4;
-#pragma unroll
-    for (int u0 = 0; u0 < NU; u0 += EB) {
-      S3 es[EB];
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const int u = u0 + e;
-        if (u < NU) {
-          const int row = 16 * (qt - kt0 - u) + c + a.maxpos;      // in range by the launch conditions
-          const unsigned eo = (unsigned)(row * 16 + 4 * g);
-          es[e] = ld_planes<F16>(Esb + 2 * eo, esp);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const int u = u0 + e;
-        if (u < NU) {
-          const f32x4 uu = prodx<F16>(qrow, es[e], (f32x4){0.f, 0.f, 0.f, 0.f});   // C[q = 4g + r][delta_local = c]
-#pragma unroll
-          for (int r = 0; r < 4; ++r) strip[(4 * g + r) * SW + 16 * (NK - u) + c] = F16 ? uu[r] * kU : uu[r];
-        }
-      }
-    }
-    f32x4 dq = {0.f, 0.f, 0.f, 0.f};                                 // dQ^T[d = 4g + r][q = c]
-    f32x4 dq2 = {0.f, 0.f, 0.f, 0.f};                                // F16: the E^T W^T part (its own scale)
-    auto load_v = [&](int s_) {
-      int kj = (kt0 + s_) * 16 + c; if (kj > n - 1) kj = n - 1;
-      return *reinterpret_cast<const float4*>(qb + (unsigned)(kj * ps * 192 + 128 + 4 * g));
-    };
-    float4 vnext = load_v(0);
-
-    // ---- the wave's key tiles ----
-#pragma unroll
-    for (int s = 0; s < NK; ++s) {
-      if (EXACT || s < nk_w) {                                       // wave-uniform
-        const int j0 = (kt0 + s) * 16;
-        const bool kv = j0 + c < n;
-        const S3 krow = ld_planes<F16>(Kimg + ((s * 16 + c) * 16 + 4 * g) * 2, L3::KPB);
-        const float4 vcur = vnext;
-        if (s + 1 < NK) vnext = load_v(s + 1);                       // one step ahead
-        // (the run-time ablation switches double as scheduling fences: without these branch points the scheduler hoists
-        // whole steps' loads, spills, and the kernel runs 8 % slower)
-        const S3 vrow = (a.dbg & 4) ? krow : splitx<F16>(vcur, sqf);
-        f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        prodx2<F16>(qrow, krow, s4, dorow, vrow, dp);                // S[q = 4g + r][key = c], scale * dP[q][key]
-        f32x4 pp, ds;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* cell = &strip[(4 * g + r) * SW + 16 * (NK - s) + (4 * g + r) - c];    // the cell of offset q - key
-          float p = __builtin_amdgcn_exp2f(fmaf(s4[r] + *cell, sc2, nlse2[r]));
-          p = kv ? p : 0.f;
-          pp[r] = p;
-          ds[r] = F16 ? p * fmaf(dp[r], kD, -dl4s[r]) : p * (dp[r] - dl4s[r]);
-          *cell = ds[r];                                             // W = skew(dS) replaces U in place
-        }
-        // contraction over the query rows 4g + r: the accumulator registers ARE the B operands
-        const S3 pps = splitn<F16>(pp), dss = splitn<F16>(ds);
-        // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
-        prodx2<F16>(docol, pps, dv[s], qcol, dss, dk[s]);
-        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: both operands through hardware-transposed reads -- A from the K row
-        // image, B from the split dS tile stored [key][q] (each lane writes 4 consecutive queries of its key: 8 bytes)
-        st_planes<F16>(Dimg + c * 32 + g * 8, 512, dss);
-        const S3 kcol = tr_planes<F16>(Kimg + ((s * 16 + 4 * g + trrow) * 16 + 4 * trcol) * 2, L3::KPB);
-        const S3 dst = tr_planes<F16>(Dimg + (4 * g + trrow) * 32 + trcol * 8, 512);
-        dq = prodx<F16>(kcol, dst, dq);
-      }
-    }
-
-    // ---- consume the strip: dQ^T += E^T W^T, dE^T += Q^T W, one offset tile at a time ----
-    const int lim = 16 * nk_w;
-#pragma unroll
-    for (int u0 = 0; u0 < NU; u0 += EB) {
-      S3 ecs[EB];                                                    // E[Dt + 4g + j][d = c], a batch of tiles requested up front
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const int u = u0 + e;
-        if (u < NU) {
-          const unsigned eo = (unsigned)(((qt - kt0 - u) * 16 + a.maxpos + c) * 16 + 4 * g);   // tile (qt-kt0-u) + maxpos/16, row d = c
-          ecs[e] = ld_planes<F16>(Etb + 2 * eo, etp);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < EB; ++e) {
-        const int u = u0 + e;
-        if (u < NU) {
-          // a cell (q_local a, delta_local dl) of tile u belongs to key_rel = 16 u + a - dl (relative to the wave's first
-          // key); cells whose key the wave does not own still hold U values: mask them
-          float4 w4 = *reinterpret_cast<const float4*>(&strip[c * SW + 16 * (NK - u) + 4 * g]);     // W[a = c][dl = 4g + j]
-          if (!EXACT || u == 0 || u == NU - 1) {
-            const int kr = 16 * u + c - 4 * g;
-            if ((unsigned)kr >= (unsigned)lim) w4.x = 0.f;
-            if ((unsigned)(kr - 1) >= (unsigned)lim) w4.y = 0.f;
-            if ((unsigned)(kr - 2) >= (unsigned)lim) w4.z = 0.f;
-            if ((unsigned)(kr - 3) >= (unsigned)lim) w4.w = 0.f;
-          }
-          const S3 ws = splitn<F16>(w4);                           // (W = skew(dS): already at dS's scale)
-          st_planes<F16>(Dimg + c * 32 + g * 8, 512, ws);                // image [a][dl]
-          const S3 wt = tr_planes<F16>(Dimg + (4 * g + trrow) * 32 + trcol * 8, 512);      // W[a = 4g + j][dl = c]
-          // dQ^T[d][q] += E^T[d][dl] W^T[dl][q];  dE^T[d][dl] += Q^T[d][q] W[q][dl]
-          prodx2<F16>(ecs[e], ws, F16 ? dq2 : dq, qcol, wt, de[u]);
-          if (a.dbg & 16) __builtin_amdgcn_s_sleep(1);               // (branch point: see the note at the V operand)
-        }
-      }
-    }
-
-    // The next tile's query-side operands were requested a whole tile ago: make them arrive HERE, before this tile's dQ / dE
-    // stores are issued.  Left to the first use at the top of the next tile, the wait comes right after those stores, and behind
-    // their (wave-uniform, but still control-flow) conditions the wait-count pass can only emit vmcnt(0): one exposed write
-    // acknowledgement per query tile.
-    asm volatile("" : "+v"(nxt.q4.x), "+v"(nxt.q4.y), "+v"(nxt.q4.z), "+v"(nxt.q4.w), "+v"(nxt.do4.x), "+v"(nxt.do4.y), "+v"(nxt.do4.z), "+v"(nxt.do4.w));
-    asm volatile("" : "+v"(nxt.qcf[0]), "+v"(nxt.qcf[1]), "+v"(nxt.qcf[2]), "+v"(nxt.qcf[3]), "+v"(nxt.docf[0]), "+v"(nxt.docf[1]), "+v"(nxt.docf[2]), "+v"(nxt.docf[3]));
-    asm volatile("" : "+v"(nxt.lse[0]), "+v"(nxt.lse[1]), "+v"(nxt.lse[2]), "+v"(nxt.lse[3]), "+v"(nxt.dl[0]), "+v"(nxt.dl[1]), "+v"(nxt.dl[2]), "+v"(nxt.dl[3]));
-    // ---- dQ of this query tile ----
-    if (F16) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) dq[r] = fmaf(dq[r], cq1, dq2[r] * cq2);
-    }
-    if (GROUP) {
-      float* slot = dqs + (RING ? 0 : (qt & 1) * 4) * 256;
-      *reinterpret_cast<float4*>(slot + wave * 256 + c * 16 + 4 * g) = make_float4(dq[0], dq[1], dq[2], dq[3]);
-      __syncthreads();
-      if (wave == (qt & 3) && q0 + c < n) {
-        float4 t0 = *reinterpret_cast<const float4*>(slot + 0 * 256 + c * 16 + 4 * g);
-        const float4 t1 = *reinterpret_cast<const float4*>(slot + 1 * 256 + c * 16 + 4 * g);
-        const float4 t2 = *reinterpret_cast<const float4*>(slot + 2 * 256 + c * 16 + 4 * g);
-        const float4 t3 = *reinterpret_cast<const float4*>(slot + 3 * 256 + c * 16 + 4 * g);
-        t0.x += t1.x + (t2.x + t3.x); t0.y += t1.y + (t2.y + t3.y); t0.z += t1.z + (t2.z + t3.z); t0.w += t1.w + (t2.w + t3.w);
-        *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = t0;
-        if (F16) omax = fmaxf(fmaxf(omax, fmaxf(fabsf(t0.x), fabsf(t0.y))), fmaxf(fabsf(t0.z), fabsf(t0.w)));
-      }
-      if (RING) __syncthreads();            // one parity: the slots are rewritten in the next query tile
-    } else if (q0 + c < n) {
-      *reinterpret_cast<float4*>(dqb + (unsigned)((q0 + c) * ps * 192 + 4 * g)) = make_float4(dq[0], dq[1], dq[2], dq[3]);
-      if (F16) omax = fmaxf(fmaxf(omax, fmaxf(fabsf(dq[0]), fabsf(dq[1]))), fmaxf(fabsf(dq[2]), fabsf(dq[3])));
-    }
-    // ---- slide the dE window: tile qt - kt0 - NK is complete ----
-    flush(de[NU - 1], qt - kt0 - NK);
-#pragma unroll
-    for (int u = NU - 1; u > 0; --u) de[u] = de[u - 1];
-    de[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  // after the last rotation slot u holds tile nqt - kt0 - u
-  if (RING) {                                // the remaining window tiles leave in wave order (contribution order), a barrier apart
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (wave == w) {
-#pragma unroll
-        for (int u = 1; u < NU; ++u) flush(de[u], nqt - kt0 - u);
-      }
-      __syncthreads();
-    }
-  } else {
-#pragma unroll
-    for (int u = 1; u < NU; ++u) flush(de[u], nqt - kt0 - u);
-  }
-  // ---- dK, dV of the wave's keys: C layout [d = 4g + r][key = c] ----
-#pragma unroll
-  for (int s = 0; s < NK; ++s) {
-    const int key = (kt0 + s) * 16 + c;
-    if ((EXACT || s < nk_w) && key < n) {
-      float* p = dqb + (unsigned)(key * ps * 192 + 4 * g);
-      *reinterpret_cast<float4*>(p + 64) = make_float4(dk[s][0] * cq1, dk[s][1] * cq1, dk[s][2] * cq1, dk[s][3] * cq1);
-      *reinterpret_cast<float4*>(p + 128) = make_float4(dv[s][0] * cdv, dv[s][1] * cdv, dv[s][2] * cdv, dv[s][3] * cdv);
-      if (F16) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) omax = fmaxf(omax, fmaxf(fabsf(dk[s][r] * cq1), fabsf(dv[s][r] * cdv)));
-      }
-    }
-  }
-  if (F16 && a.dqkv_amax) {
-    omax = wave_max(omax);
-    if (lane == 0) amax_raise_(a.dqkv_amax, omax);
-  }
-}
-
-template <int KT, bool GROUP, bool F16 = false, bool RING = false>
-__global__ __launch_bounds__(256, 2) void attn_bwd3_kernel(AttnBwd3Args a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nkt = (a.g.n + 15) >> 4;
-  if (GROUP) {
-    int kt0, cnt;
-    group_split(nkt, wave, kt0, cnt);
-    // every wave runs nqt barriers whichever branch it takes (s_barrier counts arrivals, not program counters)
-    const long gitem = xcd_item((int)blockIdx.x, (int)gridDim.x);
-    if (cnt == KT) attn_bwd3_body<KT, KT, true, true, F16, RING>(a, smem3, wave, lane, gitem, kt0, cnt);
-    else if (cnt == KT - 1) attn_bwd3_body<KT, KT - 1, true, true, F16, RING>(a, smem3, wave, lane, gitem, kt0, cnt);
-    else attn_bwd3_body<KT, KT, false, true, F16, RING>(a, smem3, wave, lane, gitem, kt0, cnt);
-  } else {
-    const long item = (long)blockIdx.x * 4 + wave;
-    if (item >= (long)a.g.nseq * 4) return;                     // whole wave leaves: EXEC stays full for the others
-    if (nkt == KT) attn_bwd3_body<KT, KT, true, false, F16>(a, smem3, wave, lane, item, 0, nkt);
-    else attn_bwd3_body<KT, KT, false, false, F16>(a, smem3, wave, lane, item, 0, nkt);
-  }
-}
-
-// dE[delta][d] += sum over the wave items of their finished tiles.  grid = (offset tile, chunk of 256 wave items); a
-// workgroup streams 256 x 1 KB with 16-byte loads (4 items in flight per 64-lane group), sums through LDS, 1 KB of atomics.
-template <int KT, bool GROUP>
-__global__ __launch_bounds__(256) void attn_de_reduce3_kernel(const float* __restrict__ dEs, float* __restrict__ dE, long nwitems,
-                                                              int nkt, int maxpos, int R) {
-  __shared__ float4 part[4][64];
-  const int Dtile = (int)blockIdx.x - nkt;                       // -nkt .. nkt
-  const long w0 = (long)blockIdx.y * 256;
-  const int nslot = nkt + KT, t = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  // a wave with key tiles [kt0, kt0 + cnt) stores the tiles -kt0 - cnt .. nqt - kt0 - 1 in slot (tile + kt0 + KT)
-  int kt0s[4] = {0, 0, 0, 0}, cnts[4] = {nkt, nkt, nkt, nkt};
-  if (GROUP) { for (int w = 0; w < 4; ++w) group_split(nkt, w, kt0s[w], cnts[w]); }
+// dE[row][d] += the sum of the ATTN_DE_NREP replicas the cooperative backward added its offset tiles into (rows row0 .. row0 + nrows - 1
+// of the [R][16] table: the offsets a sequence of n positions reaches).  One thread per float4; this launch is the only writer of dE
+// while it runs (stream order), so a plain read-modify-write.
+__global__ __launch_bounds__(256) void attn_de_replicas_reduce_kernel(const float* __restrict__ rep, float* __restrict__ dE, int R, int row0,
+                                                                      int nrows, int nrep) {
+  const int i4 = blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= nrows * 4) return;
+  const long e = (long)row0 * 16 + 4L * i4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-  for (int i = sub; i < 256; i += 4) {                            // w0 and the stride are multiples of 4: wave role = sub
-    const long w = w0 + i;
-    const int slot = Dtile + kt0s[sub] + KT;
-    if (w < nwitems && slot >= KT - cnts[sub] && slot < nslot) {
-      const float4 v = *reinterpret_cast<const float4*>(dEs + (w * nslot + slot) * 256 + t * 4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
+  for (int r = 0; r < nrep; ++r) {
+    const float4 v = *reinterpret_cast<const float4*>(rep + (long)r * R * 16 + e);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  part[sub][t] = s;
-  __syncthreads();
-  if (sub == 0) {
-    const float4 b = part[1][t], c4 = part[2][t], d = part[3][t];
-    s.x += b.x + (c4.x + d.x); s.y += b.y + (c4.y + d.y); s.z += b.z + (c4.z + d.z); s.w += b.w + (c4.w + d.w);
-    const int row = 16 * Dtile + (t >> 2) + maxpos;              // element index in the tile = 4 t .. 4 t + 3 = [delta_l][d]
-    if (row >= 0 && row < R) {
-      float* p = &dE[(long)row * 16 + (t & 3) * 4];
-      atomicAdd(p, s.x); atomicAdd(p + 1, s.y); atomicAdd(p + 2, s.z); atomicAdd(p + 3, s.w);
-    }
-  }
+  float* p = dE + e;      // (a parameter gradient inside a flat optimizer buffer is only 4-byte aligned)
+  p[0] += s.x; p[1] += s.y; p[2] += s.z; p[3] += s.w;
 }
 
-// the same reduction over the per-ITEM tables of the ring form: dEs [items][2 nkt][256], tile slot = D + nkt, D = -nkt .. nkt - 1
-__global__ __launch_bounds__(256) void attn_de_reduce_items_kernel(const float* __restrict__ dEs, float* __restrict__ dE, long nitems,
-                                                                   int nkt, int maxpos, int R) {
-  __shared__ float4 part[4][64];
-  const int Dtile = (int)blockIdx.x - nkt;                       // -nkt .. nkt - 1
-  const long w0 = (long)blockIdx.y * 256;
-  const int nslot = 2 * nkt, t = threadIdx.x & 63, sub = threadIdx.x >> 6;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);                    // (the table is shared by the heads: every item adds to it)
-#pragma unroll 8
-  for (int i = sub; i < 256; i += 4) {
-    const long it = w0 + i;
-    const long itc = it < nitems ? it : nitems - 1;              // (unconditional load, zeroed by the select)
-    const float4 v = *reinterpret_cast<const float4*>(dEs + (itc * nslot + blockIdx.x) * 256 + t * 4);
-    if (it < nitems) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
-  }
-  part[sub][t] = s;
-  __syncthreads();
-  if (sub == 0) {
-    const float4 b = part[1][t], c4 = part[2][t], d = part[3][t];
-    s.x += b.x + (c4.x + d.x); s.y += b.y + (c4.y + d.y); s.z += b.z + (c4.z + d.z); s.w += b.w + (c4.w + d.w);
-    const int row = 16 * Dtile + (t >> 2) + maxpos;
-    if (row >= 0 && row < R) {
-      float* p = &dE[(long)row * 16 + (t & 3) * 4];
-      atomicAdd(p, s.x); atomicAdd(p + 1, s.y); atomicAdd(p + 2, s.z); atomicAdd(p + 3, s.w);
-    }
-  }
-}
 
 #include "se_attn_bwd4.h"
 
@@ -1538,13 +771,8 @@ __global__ __launch_bounds__(256) void attn_de_reduce_items_kernel(const float* 
 template <int V> struct IC_ { static constexpr int value = V; };
 template <int TQ, bool F16 = false>
 // packed fp32 VALU ops allowed in THIS kernel (se_common.h): it is VALU-bound (83 % VALU-busy, 36 % MFMA-busy); halving the issue slots of
-// part of its softmax chain pays for the matrix-pipe stalls: 0.681 -> 0.651 ms (n = 321), 0.270 -> 0.263 (n = 101); SE_ATTN_FWD_NO_PK builds: off
-#ifdef SE_ATTN_FWD_NO_PK
-#define ATTN_FWD_PK_ATTR
-#else
-#define ATTN_FWD_PK_ATTR SE_PACKED_FP32_KERNEL
-#endif
-__global__ __launch_bounds__(512) ATTN_FWD_PK_ATTR void attn_fwd3_kernel(AttnArgs a, int NP, int qsplit) {
+// part of its softmax chain pays for the matrix-pipe stalls: 0.681 -> 0.651 ms (n = 321), 0.270 -> 0.263 (n = 101)
+__global__ __launch_bounds__(512) SE_PACKED_FP32_KERNEL void attn_fwd3_kernel(AttnArgs a, int NP, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_f3[];
   static_assert(TQ == 1 || TQ == 2, "the offset-fragment ring of key_step is indexed by the step parity");
   constexpr int NPLA = F16 ? 2 : 3;
@@ -1666,6 +894,16 @@ __global__ __launch_bounds__(512) ATTN_FWD_PK_ATTR void attn_fwd3_kernel(AttnArg
 #pragma unroll
       for (int t = 0; t < TQ; ++t) {
         const f32x4 s4 = prodx<F16>(kf, qf[t], (f32x4){0.f, 0.f, 0.f, 0.f});      // S^T[key 4g + r][query c]
+#if SE_ATTN_TWIN == 1
+        {
+          float uu[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) uu[r] = Ul[t * 512 + coff[hi][r]];
+          o[t] = prodx<F16>(vcol, twin_raw_(s4[0] , s4[1], uu[0], uu[1]), o[t]);
+          asm volatile("" :: "v"(s4[2]), "v"(s4[3]), "v"(uu[2]), "v"(uu[3]));
+          continue;
+        }
+#endif
         float sc[4], tmax = -1e30f, uu[4];
         // the four window cells first, through SELECTED ADDRESSES (a ternary over the two loads compiles to one exec-masked
         // branch per cell: eight branch regions per key step)
@@ -1683,7 +921,7 @@ __global__ __launch_bounds__(512) ATTN_FWD_PK_ATTR void attn_fwd3_kernel(AttnArg
         // after the first key tiles that is rare, and the rescale of o / l (an exp2, 5 multiplies) and its dependency on this
         // tile's maximum leave the chain.  p <= 2^LAZY then, so P's fp16 scale is 2^(13 - LAZY) (hi plane <= 2^13).
         constexpr float LAZY = 4.f, PSC = F16 ? 13.f - LAZY : 0.f;
-        if (!F16 || a.eager || __builtin_amdgcn_ballot_w64(tmax > m[t] + LAZY) != 0) {
+        if (!F16 || __builtin_amdgcn_ballot_w64(tmax > m[t] + LAZY) != 0) {
           const float mn = fmaxf(m[t], tmax);
           const float corr = __builtin_amdgcn_exp2f(m[t] - mn);
           m[t] = mn;
@@ -1761,50 +999,35 @@ extern "C" int se_attn_fwd_f16(const float* QKV, const void* Es, long es_plane, 
                        pos_stride, maxpos, scale, stream, qkv_amax, e_amax);
 }
 
+// Forward: the v3 kernel (split-bf16 or scaled split-fp16 products, V of one (sequence, head) staged in LDS) whenever the sequence
+// fits it, the streaming fp32-MFMA kernel of round 1 (any length, K / V fragments straight from memory) otherwise.
 static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long es_plane, float* O, float* LSE, int nseq, int n,
                          int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream,
                          const float* qkv_amax, const float* e_amax) {
-  static const int fwd_eager = getenv("SE_ATTN_FWD_LAZY") != nullptr && atoi(getenv("SE_ATTN_FWD_LAZY")) == 0;
-  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale, Es, es_plane, qkv_amax, e_amax, fwd_eager};
+  AttnArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, O, LSE, maxpos, scale, Es, es_plane, qkv_amax, e_amax};
   const bool f16 = qkv_amax != nullptr;
   if (int e = check_geom(a.g)) return e;
   SE_REQUIRE(QKV && E && O, "attn_fwd: null operand");
   const int NP = ((n + 15) / 16) * 16;
-  // waves per workgroup: 32-query blocks are dealt round-robin to the waves; long sequences get 6 or 8 waves so that
-  // 3-4 waves share a SIMD (the per-step chain S -> softmax -> PV is latency-bound with 2), short ones 4
-  // waves per workgroup / 16-query tiles per wave block (measured at B = 16): short sequences (n <= 128) 4 waves x 1 tile
-  // (n = 101: 0.37 ms vs 0.41 with 2 tiles), long ones 8 waves x 2 tiles (n = 321: 1.09 ms vs 1.39 with 4 waves -- the
-  // per-step chain S -> softmax -> PV is latency-bound with 2 waves per SIMD, 8-wave workgroups put 4 there)
-  const int qb32 = (n + 31) / 32;
-  int nw = qb32 <= 4 ? 4 : 8, tq = qb32 <= 4 ? 1 : 2;
-  if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v == 4 || v == 6 || v == 8) nw = v; }
-  if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq = v; }
-  int use3 = pos_stride * 192 * (long)NP < 2147483647L;
-  if (const char* e = getenv("SE_ATTN_FWD")) { if (atoi(e) == 2) use3 = 0; }
-  if (use3) {
-    // split-bf16 kernel; measured at B = 16 (ms): n = 321: 8 waves x 2 tiles 0.92, 7 x 2 0.95, 8 x 1 0.94, 4 x 2 0.97, 6 x 2 1.10
-    // (fwd2: 1.07); n = 101: 4 x 1 0.342, 8 x 2 0.352, 4 x 2 0.367 (fwd2: 0.355)
-    int nw3 = qb32 <= 4 ? 4 : 8, tq3 = qb32 <= 4 ? 1 : 2;
-    if (const char* e = getenv("SE_ATTN_FWD_WAVES")) { int v = atoi(e); if (v >= 1 && v <= 8) nw3 = v; }
-    if (const char* e = getenv("SE_ATTN_FWD_TQ")) { int v = atoi(e); if (v == 1 || v == 2) tq3 = v; }
-    if (qb32 <= 4) { if (const char* e = getenv("SE_ATTN_FWD_WAVES_SMALL")) { int v = atoi(e); if (v >= 1 && v <= 8) nw3 = v; } }
+  if (pos_stride * 192 * (long)NP < 2147483647L) {
+    // waves per workgroup / 16-query tiles per wave block, measured at B = 16 (ms): n = 321: 8 waves x 2 tiles 0.92, 7 x 2 0.95,
+    // 8 x 1 0.94, 4 x 2 0.97, 6 x 2 1.10; n = 101: 4 x 1 0.342, 8 x 2 0.352, 4 x 2 0.367 -- the per-step chain S -> softmax -> PV
+    // is latency-bound with 2 waves per SIMD, 8-wave workgroups put 4 there
+    const int qb32 = (n + 31) / 32;
+    const int nw3 = qb32 <= 4 ? 4 : 8, tq3 = qb32 <= 4 ? 1 : 2;
     // fewer items than two rounds of workgroups (batch-1 inference): split the query blocks of an item over several workgroups
     int qsplit = 1;
     {
       const long items = (long)nseq * 4, qblk = (n + 16 * tq3 - 1) / (16 * tq3);
       while (items * qsplit < 1024 && (long)nw3 * qsplit * 2 <= qblk && qsplit < 8) ++qsplit;
-      if (const char* e = getenv("SE_ATTN_FWD_QSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) qsplit = v; }
+      if (const char* e = getenv("SE_ATTN_FWD_QSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) qsplit = v; }      // (tests force it)
     }
     const size_t sh3 = (size_t)(f16 ? 2 : 3) * NP * 32 + (size_t)512 * tq3 * nw3 * sizeof(float);
     if (sh3 <= 160 * 1024) {
-      static size_t raised3[2][3] = {{0, 0, 0}, {0, 0, 0}};
-      if (sh3 > 64 * 1024 && sh3 > raised3[f16][tq3]) {
-        const void* fn = f16 ? (tq3 == 1 ? (const void*)attn_fwd3_kernel<1, true> : (const void*)attn_fwd3_kernel<2, true>)
-                             : (tq3 == 1 ? (const void*)attn_fwd3_kernel<1> : (const void*)attn_fwd3_kernel<2>);
-        SE_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3) == hipSuccess,
-                   "attn_fwd: cannot raise the dynamic LDS limit to %zu", sh3);
-        raised3[f16][tq3] = sh3;
-      }
+      static unsigned raised3[2][3] = {{0, 0, 0}, {0, 0, 0}};
+      const void* fn = f16 ? (tq3 == 1 ? (const void*)attn_fwd3_kernel<1, true> : (const void*)attn_fwd3_kernel<2, true>)
+                           : (tq3 == 1 ? (const void*)attn_fwd3_kernel<1> : (const void*)attn_fwd3_kernel<2>);
+      SE_REQUIRE(se_raise_lds(fn, 160 * 1024, &raised3[f16][tq3]), "attn_fwd: cannot raise the dynamic LDS limit");
       const dim3 grid3((unsigned)(nseq * 4 * qsplit));
       if (f16 && tq3 == 1) hipLaunchKernelGGL((attn_fwd3_kernel<1, true>), grid3, dim3(64 * nw3), sh3, as_stream(stream), a, NP, qsplit);
       else if (f16) hipLaunchKernelGGL((attn_fwd3_kernel<2, true>), grid3, dim3(64 * nw3), sh3, as_stream(stream), a, NP, qsplit);
@@ -1814,258 +1037,134 @@ static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long 
     }
   }
   SE_REQUIRE(!f16, "attn_fwd_f16: the sequence does not fit the split-fp16 kernel (n = %d)", n);
-  const size_t sh = ((size_t)NP * 16 + 16 * (size_t)(NP + 4) + 512 * (size_t)tq * nw) * sizeof(float);
-  if (sh <= 160 * 1024) {       // K / V of one (sequence, head) fit in LDS: staged kernel
-    static size_t raised[3] = {0, 0, 0};
-    if (sh > 64 * 1024 && sh > raised[tq]) {
-      const void* fn = tq == 1 ? (const void*)attn_fwd2_kernel<1> : (const void*)attn_fwd2_kernel<2>;
-      SE_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) ==
-                     hipSuccess, "attn_fwd: cannot raise the dynamic LDS limit to %zu", sh);
-      raised[tq] = sh;
-    }
-    if (tq == 1) hipLaunchKernelGGL(attn_fwd2_kernel<1>, dim3(nseq * 4), dim3(64 * nw), sh, as_stream(stream), a, NP);
-    else hipLaunchKernelGGL(attn_fwd2_kernel<2>, dim3(nseq * 4), dim3(64 * nw), sh, as_stream(stream), a, NP);
-  } else {
-    long items = (long)nseq * 4 * ((n + 31) / 32);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(items, 4)), dim3(256), 0, as_stream(stream), a);
-  }
+  const long items = (long)nseq * 4 * ((n + 31) / 32);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(items, 4)), dim3(256), 0, as_stream(stream), a);
   return se_check_launch("se_attn_fwd");
 }
 
-// workspace of se_attn_bwd: Dl [ntok][4] | Es [3][R][16] bf16 | Ets [3][16][ET] bf16 | per-wave dE tiles
+// workspace of se_attn_bwd: Dl [ntok][4] | Es [2][R][16] fp16 + max |E| | Ets [2][16][ET] fp16 | ATTN_DE_NREP replicas of dE [R][16] fp32
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct AttnWs { size_t dl, es, ets, des, total; int R, ET; };
-// the v3 kernel runs when the padded sequence fits the offset table and one of its two shapes: returns KT (7: one wave per
-// (sequence, head), n <= 112; 6: four waves per (sequence, head), n <= 384) or 0
-static int attn_v3_shape(int n, int maxpos) {
+// the cooperative backward (se_attn_bwd4.h) takes a sequence when its padded length fits the offset table without a clamp and its
+// key tiles fit one of the two instantiations (<= 7: two waves, <= 21: four waves)
+static bool attn_bwd4_shape(int n, int maxpos, long pos_stride) {
   const int nkt = (n + 15) / 16;
-  if ((maxpos % 16) != 0 || 16 * nkt + 16 * 8 > maxpos) return 0;
-  if (nkt <= 7) return 7;
-  if ((nkt + 3) / 4 <= 6) return 6;
-  return 0;
+  return (maxpos % 16) == 0 && 16 * nkt + 16 * 8 <= maxpos && nkt <= 21 && pos_stride * 192 * (long)(16 * nkt) < 2147483647L;
 }
-static AttnWs attn_ws(long ntok, int maxpos, int nseq, int n) {
+static AttnWs attn_ws(long ntok, int maxpos) {
   AttnWs w;
   w.R = 2 * maxpos + 1;
   w.ET = (w.R + 16 + 15) / 16 * 16;
   w.dl = 0;
   w.es = al256((size_t)ntok * 4 * sizeof(float));
-  w.ets = w.es + al256((size_t)3 * w.R * 16 * 2);
-  w.des = w.ets + al256((size_t)3 * 16 * w.ET * 2);
-  const int kt = attn_v3_shape(n, maxpos), nkt = (n + 15) / 16;
-  const size_t witems = (size_t)nseq * 4 * (kt == 6 ? 4 : 1);
-  w.total = w.des + (kt ? al256(witems * (size_t)(nkt + kt) * 256 * sizeof(float)) : 0);
+  w.ets = w.es + al256((size_t)2 * w.R * 16 * 2) + 256;          // (+ 256: the measured max |E| behind the two planes)
+  w.des = w.ets + al256((size_t)2 * 16 * w.ET * 2);
+  w.total = w.des + al256((size_t)ATTN_DE_NREP * w.R * 16 * sizeof(float));
   return w;
 }
 extern "C" size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n) {
-  return (ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0) ? attn_ws(ntok, maxpos, nseq, n).total : 0;
+  return (ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0) ? attn_ws(ntok, maxpos).total : 0;
 }
 
-template <int KT, bool GROUP, bool F16 = false>
-static int launch_bwd3(const AttnBwd3Args& b, long nwitems, hipStream_t s, float* dE, int phase) {
-  using L3 = Lds3<KT, F16>;
-  const long items = (long)b.g.nseq * 4;
-  const int nkt = (b.g.n + 15) / 16;
-  if constexpr (GROUP && F16) {
-    // ring form: the four waves' dE tiles are summed in LDS (16 open tiles at most: nkt - cnt_0 + 1 <= 16)
-    int span_lo = 1 << 30, span_hi = 0;
-    bool ordered = true;
-    for (int w = 0, prev = -1; w < 4; ++w) {
-      int k0, cn;
-      group_split(nkt, w, k0, cn);
-      const int tq = k0 + group_window(KT, cn);          // wave w flushes tile D at query tile D + tq
-      span_lo = tq < span_lo ? tq : span_lo;
-      span_hi = tq > span_hi ? tq : span_hi;
-      ordered = ordered && tq > prev;
-      prev = tq;
-    }
-    if (ordered && span_hi - span_lo + 1 <= 16 && getenv("SE_ATTN_NO_RING") == nullptr) {
-      const size_t shr = (size_t)4 * L3::WAVE + (size_t)(4 * 256 + 16 * 256) * sizeof(float);
-      static unsigned raised_r = 0;
-      SE_REQUIRE(se_raise_lds((const void*)attn_bwd3_kernel<KT, true, true, true>, shr, &raised_r), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
-      if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, true, true, true>), dim3(items), dim3(256), shr, s, b);
-      if (phase & 2) hipLaunchKernelGGL(attn_de_reduce_items_kernel, dim3(2 * nkt, cdiv(items, 256)), dim3(256), 0, s, b.dEs, dE, items, nkt,
-                                        b.maxpos, b.R);
-      return 0;
-    }
-  }
-  const size_t sh = (size_t)4 * L3::WAVE + (GROUP ? 2 * 4 * 256 * sizeof(float) : 0);
-  static unsigned raised = 0;
-  SE_REQUIRE(se_raise_lds((const void*)attn_bwd3_kernel<KT, GROUP, F16>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit to %zu", sh);
-  if (phase & 1) hipLaunchKernelGGL((attn_bwd3_kernel<KT, GROUP, F16>), dim3(GROUP ? items : cdiv(items, 4)), dim3(256), sh, s, b);
-  if (phase & 2) hipLaunchKernelGGL((attn_de_reduce3_kernel<KT, GROUP>), dim3(2 * nkt + 1, cdiv(nwitems, 256)), dim3(256), 0, s, b.dEs,
-                                    dE, nwitems, nkt, b.maxpos, b.R);
-  return 0;
-}
-
-static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
-                         float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
-                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
+static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, const float* delta,
+                         float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride,
+                         long ntok, int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
                          const float* qkv_amax = nullptr, const float* do_amax = nullptr, float* dqkv_amax = nullptr);
 
 extern "C" int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                            float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
                            long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws,
                            size_t ws_bytes, void* stream) {
-  return attn_bwd_impl(QKV, E, O, dO, LSE, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
+  return attn_bwd_impl(QKV, E, O, dO, LSE, nullptr, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
                        ws, ws_bytes, 3, stream);
 }
 
-extern "C" int se_attn_bwd_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
-                                 float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
-                                 long inner_stride, long pos_stride, long ntok, int maxpos, float scale, void* ws,
-                                 size_t ws_bytes, int phase, void* stream) {
-  SE_REQUIRE(phase == 1 || phase == 2 || phase == 3, "attn_bwd_phase: phase must be 1, 2 or 3");
-  return attn_bwd_impl(QKV, E, O, dO, LSE, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
-                       ws, ws_bytes, phase, stream);
-}
-
 extern "C" int se_attn_bwd_f16_phase(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
-                                     const float* qkv_amax, const float* do_amax, float* dqkv_amax, float* dQKV, float* dE, int nseq,
-                                     int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok, int maxpos,
-                                     float scale, void* ws, size_t ws_bytes, int phase, void* stream) {
+                                     const float* delta, const float* qkv_amax, const float* do_amax, float* dqkv_amax, float* dQKV,
+                                     float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride,
+                                     long ntok, int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream) {
   SE_REQUIRE(phase == 1 || phase == 2 || phase == 3, "attn_bwd_f16_phase: phase must be 1, 2 or 3");
   SE_REQUIRE(qkv_amax && do_amax, "attn_bwd_f16: the maxima of QKV and dO are required");
-  SE_REQUIRE(attn_v3_shape(n, maxpos) && pos_stride * 192 * (long)(16 * ((n + 15) / 16)) < 2147483647L,
+  SE_REQUIRE(O || delta, "attn_bwd_f16: the forward output O or the table delta = rowsum(dO . O) [tokens][4] is required");
+  SE_REQUIRE(attn_bwd4_shape(n, maxpos, pos_stride),
              "attn_bwd_f16: shape outside the split-fp16 kernel (n = %d, maxpos = %d): use se_attn_bwd", n, maxpos);
-  return attn_bwd_impl(QKV, E, O, dO, LSE, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
+  return attn_bwd_impl(QKV, E, O, dO, LSE, delta, dQKV, dE, nseq, n, inner, outer_stride, inner_stride, pos_stride, ntok, maxpos, scale,
                        ws, ws_bytes, phase, stream, qkv_amax, do_amax, dqkv_amax);
 }
 
 // launch of the workgroup-cooperative backward (se_attn_bwd4.h): the exact-body kernel when every wave of the plan matches one of its
 // bodies, the generic-body kernel otherwise
-template <int NW, int KPW, int NCW, int NKTM, int MINW, int CA, int NA, int CB, int NB, int CC = -1, int NC_ = 0>
-static int launch_bwd4(const AttnBwd3Args& b, const AttnBwd4Plan& pl, int nkt, long items, size_t shr, hipStream_t s) {
-  if (attn_bwd4_exact<NW, CA, NA, CB, NB, CC, NC_>(pl, nkt, b.dbg)) {
+template <int NW, int KPW, int NCW, int NKTM, int MINW, int CA, int NA, int CB, int NB>
+static int launch_bwd4(const AttnBwd4Args& b, const AttnBwd4Plan& pl, int nkt, long items, size_t shr, hipStream_t s) {
+  if (attn_bwd4_exact<NW, CA, NA, CB, NB, -1, 0>(pl, nkt, b.dbg)) {
     static unsigned raised = 0;
-    auto kfn = attn_bwd4_kernel<NW, KPW, NCW, NKTM, MINW, CA, NA, CB, NB, CC, NC_, false>;
+    auto kfn = attn_bwd4_kernel<NW, KPW, NCW, NKTM, MINW, CA, NA, CB, NB, -1, 0, false>;
     SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
     hipLaunchKernelGGL(kfn, dim3(items), dim3(NW * 64), shr, s, b, pl);
   } else {
     static unsigned raised_g = 0;
-    auto kfn = attn_bwd4_kernel<NW, KPW, NCW, NKTM, MINW, CA, NA, CB, NB, CC, NC_, true>;
+    auto kfn = attn_bwd4_kernel<NW, KPW, NCW, NKTM, MINW, CA, NA, CB, NB, -1, 0, true>;
     SE_REQUIRE(se_raise_lds((const void*)kfn, shr, &raised_g), "attn_bwd: cannot raise dynamic LDS limit to %zu", shr);
     hipLaunchKernelGGL(kfn, dim3(items), dim3(NW * 64), shr, s, b, pl);
   }
   return 0;
 }
 
-static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, float* dQKV,
-                         float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, long ntok,
-                         int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
+// Backward.  With the operand maxima (se_attn_bwd_f16_phase): the workgroup-cooperative scaled split-fp16 kernel; phase 1 = delta (unless
+// the caller supplies the table), the split tables of E, the kernel; phase 2 = the fold of the dE replicas (a leaf of the backward
+// graph: the caller may issue it on another stream once phase 1 has been queued).  Without them (se_attn_bwd): the fp32-MFMA kernels
+// of round 1 for any sequence length (dK / dV pass + dQ / dE pass), everything in phase 1.
+static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, const float* delta,
+                         float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride,
+                         long ntok, int maxpos, float scale, void* ws, size_t ws_bytes, int phase, void* stream,
                          const float* qkv_amax, const float* do_amax, float* dqkv_amax) {
-  SE_REQUIRE(QKV && E && O && dO && LSE && dQKV && dE && ws, "attn_bwd: null operand");
+  SE_REQUIRE(QKV && E && dO && LSE && dQKV && dE && ws, "attn_bwd: null operand");
   SE_REQUIRE(ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0, "attn_bwd: bad sizes");
-  const AttnWs w = attn_ws(ntok, maxpos, nseq, n);
+  const AttnWs w = attn_ws(ntok, maxpos);
   SE_REQUIRE(ws_bytes >= w.total, "attn_bwd: workspace of %zu bytes, need %zu (se_attn_bwd_workspace_bytes)", ws_bytes, w.total);
   SE_REQUIRE(((uintptr_t)ws & 15) == 0, "attn_bwd: workspace must be 16-byte aligned");
   float* Dl = reinterpret_cast<float*>((char*)ws + w.dl);
-  AttnBwdArgs a{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, E, dO, LSE, Dl, dQKV, dE, maxpos, scale, 0};
-  if (int e = check_geom(a.g)) return e;
+  const AttnGeom geom{nseq, n, inner, outer_stride, inner_stride, pos_stride};
+  if (int e = check_geom(geom)) return e;
   hipStream_t s = as_stream(stream);
-  int kt3 = attn_v3_shape(n, maxpos);
-  if (const char* e = getenv("SE_ATTN_BWD")) { if (atoi(e) == 2) kt3 = 0; }
-  const bool v3 = kt3 && pos_stride * 192 * (long)(16 * ((n + 15) / 16)) < 2147483647L;
-  // phase 2 = the reduction of the per-wave dE tiles alone (a leaf of the backward graph: the caller may issue it on another
-  // stream once phase 1 has been queued); only the decoupled kernel has one -- the other kernels do everything in phase 1
-  if (!(phase & 1) && !v3) return 0;
-  // (the cooperative kernels compute delta from the O rows themselves: no table, no launch)
-  static const int bwd4_mode0 = getenv("SE_ATTN_BWD4") ? atoi(getenv("SE_ATTN_BWD4")) : 3;
-  static const int small_nw0 = getenv("SE_ATTN_BWD4_SMALL_NW") ? atoi(getenv("SE_ATTN_BWD4_SMALL_NW")) : 2;
-  // SE_ATTN_DELTA_IN_KERNEL=1 (opt-in): the cooperative kernels compute delta from the O rows (no attn_delta_kernel launch).  Same-box
-  // A/B: SLOWER -- n = 321 family 6.31 -> 6.51 ms per step, n = 101 2.77 -> 2.81 (the loader's extra row load and two cross-group adds
-  // sit on the per-query-tile chain; the stand-alone pass is 41 us of pure streaming)
-  static const bool delta_kernel_forced = !(getenv("SE_ATTN_DELTA_IN_KERNEL") != nullptr && atoi(getenv("SE_ATTN_DELTA_IN_KERNEL")) == 1);
-  bool delta_in_kernel = false;
-  if (v3 && qkv_amax != nullptr && (n + 15) / 16 <= 21 && (bwd4_mode0 & ((n + 15) / 16 <= 7 ? 1 : 2))) {
-    const int nkt0 = (n + 15) / 16;
-    const bool sm0 = nkt0 <= 7;
-    const AttnBwd4Plan p0 = sm0 ? (small_nw0 == 4 ? attn_bwd4_plan(nkt0, 4, 1) : attn_bwd4_plan(nkt0, 2, 2)) : attn_bwd4_plan(nkt0, 4, 3);
-    int kmax0 = 0;
-    for (int w4 = 0; w4 < 8; ++w4) kmax0 = p0.cnt[w4] > kmax0 ? p0.cnt[w4] : kmax0;
-    delta_in_kernel = !delta_kernel_forced && p0.M > 0 && (sm0 ? kmax0 <= (small_nw0 == 4 ? 2 : 4) : kmax0 <= 6);
+  const bool f16 = qkv_amax != nullptr;
+  if (!f16 && !(phase & 1)) return 0;
+  if ((phase & 1) && !delta) {
+    SE_REQUIRE(O, "attn_bwd: the forward output O is required");
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
   }
-  if ((phase & 1) && !delta_in_kernel) hipLaunchKernelGGL(attn_delta_kernel, dim3(cdiv(ntok * 16, 256)), dim3(256), 0, s, dO, O, Dl, ntok);
-  if (v3) {
-    // decoupled split-bf16 kernel: one wave per (sequence, head[, key group]); no offset clamp can be active
+  if (f16) {
     __bf16* Es = reinterpret_cast<__bf16*>((char*)ws + w.es);
     __bf16* Ets = reinterpret_cast<__bf16*>((char*)ws + w.ets);
-    const bool f16 = qkv_amax != nullptr;
-    // (F16: two planes in the room of three; the third plane's room of the Es region holds the measured max |E|)
     float* e_amax = reinterpret_cast<float*>((char*)ws + w.es + al256((size_t)2 * w.R * 16 * 2));
+    float* rep = reinterpret_cast<float*>((char*)ws + w.des);
+    const int nkt = (n + 15) / 16;
     if (phase & 1) {
-      SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.des - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
-      if (f16) hipLaunchKernelGGL(attn_split_tables_f16_kernel, dim3(16), dim3(1024), 0, s, E, reinterpret_cast<unsigned short*>(Es),
-                                  reinterpret_cast<unsigned short*>(Ets), e_amax, w.R, w.ET);
-      else hipLaunchKernelGGL(attn_split_tables_kernel, dim3(cdiv((long)w.R * 16, 256)), dim3(256), 0, s, E, Es, Ets, w.R, w.ET);
-    }
-    AttnBwd3Args b{{nseq, n, inner, outer_stride, inner_stride, pos_stride}, QKV, dO, LSE, Dl, dQKV, Es, Ets,
-                   reinterpret_cast<float*>((char*)ws + w.des), w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax, dqkv_amax, O};
-    if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
-    if (delta_kernel_forced) b.dbg |= 128;
-    const long items = (long)nseq * 4;
-    int e;
-    // round 4: the workgroup-cooperative kernel (se_attn_bwd4.h) for every shape its two instantiations cover; SE_ATTN_BWD4=0: v3
-    static const int bwd4_mode = getenv("SE_ATTN_BWD4") ? atoi(getenv("SE_ATTN_BWD4")) : 3;
-    if (f16) {
-      const int nkt = (n + 15) / 16;
+      // (the column-fragment table's padding and the dE replicas start at zero)
+      SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.total - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
+      hipLaunchKernelGGL(attn_split_tables_f16_kernel, dim3(16), dim3(1024), 0, s, E, reinterpret_cast<unsigned short*>(Es),
+                         reinterpret_cast<unsigned short*>(Ets), e_amax, w.R, w.ET);
+      AttnBwd4Args b{geom, QKV, dO, LSE, delta ? delta : Dl, dQKV, Es, Ets, rep, w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax, dqkv_amax};
+      if (const char* e = getenv("SE_ATTN_DBG")) b.dbg = atoi(e);
+      const long items = (long)nseq * 4;
       // 8 <= nkt <= 21 (n = 321): four waves (two workgroups per CU), up to 6 key tiles and 3 classes per wave; nkt <= 7 (n = 101): two
-      // waves with up to 4 key tiles and 2 classes (SE_ATTN_BWD4_SMALL_NW=4: four waves, 2 tiles / 1 class: 0.79 vs 0.77 ms)
-      static const int small_nw = getenv("SE_ATTN_BWD4_SMALL_NW") ? atoi(getenv("SE_ATTN_BWD4_SMALL_NW")) : 2;
+      // waves with up to 4 key tiles and 2 classes, 256 VGPRs: four workgroups per CU
       const bool small = nkt <= 7;
-      const AttnBwd4Plan pl = small ? (small_nw == 4 ? attn_bwd4_plan(nkt, 4, 1) : attn_bwd4_plan(nkt, 2, 2)) : attn_bwd4_plan(nkt, 4, 3);
+      const AttnBwd4Plan pl = small ? attn_bwd4_plan(nkt, 2, 2) : attn_bwd4_plan(nkt, 4, 3);
       int kmax = 0;
       for (int w4 = 0; w4 < 8; ++w4) kmax = pl.cnt[w4] > kmax ? pl.cnt[w4] : kmax;
-      const bool fits = pl.M > 0 && (small ? kmax <= (small_nw == 4 ? 2 : 4) : (kmax <= 6 && nkt <= 21));
-      const size_t shr = small ? (small_nw == 4 ? attn_bwd4_lds<4, 7>(nkt) : attn_bwd4_lds<2, 7>(nkt)) : attn_bwd4_lds<4, 21>(nkt);
-      if (fits && (bwd4_mode & (small ? 1 : 2))) {
-        if (phase & 1) {
-          if (small && small_nw == 4) e = launch_bwd4<4, 2, 1, 7, 3, 2, 1, 2, 1, 1, 1>(b, pl, nkt, items, shr, s);
-          else if (small) e = launch_bwd4<2, 4, 2, 7, 2, 3, 2, 4, 2>(b, pl, nkt, items, shr, s);     // two waves, 256 VGPRs: four workgroups per CU (168 VGPRs: spills in the key phase, 1.00 ms)
-          else e = launch_bwd4<4, 6, 3, 21, 2, 5, 3, 6, 2>(b, pl, nkt, items, shr, s);
-          if (e) return e;
-        }
-        if (phase & 2) hipLaunchKernelGGL(attn_de_reduce_items_kernel, dim3(2 * nkt, cdiv(items, 256)), dim3(256), 0, s, b.dEs, dE, items, nkt,
-                                          b.maxpos, b.R);
-        return se_check_launch("se_attn_bwd");
-      }
+      SE_REQUIRE(pl.M > 0 && kmax <= (small ? 4 : 6), "attn_bwd_f16: no plan for %d key tiles", nkt);
+      const size_t shr = small ? attn_bwd4_lds<2, 7>(nkt) : attn_bwd4_lds<4, 21>(nkt);
+      int e = small ? launch_bwd4<2, 4, 2, 7, 2, 3, 2, 4, 2>(b, pl, nkt, items, shr, s) : launch_bwd4<4, 6, 3, 21, 2, 5, 3, 6, 2>(b, pl, nkt, items, shr, s);
+      if (e) return e;
     }
-    if (f16) e = kt3 == 7 ? launch_bwd3<7, false, true>(b, items, s, dE, phase) : launch_bwd3<6, true, true>(b, items * 4, s, dE, phase);
-    else e = kt3 == 7 ? launch_bwd3<7, false>(b, items, s, dE, phase) : launch_bwd3<6, true>(b, items * 4, s, dE, phase);
-    if (e) return e;
-    return se_check_launch("se_attn_bwd");
-  }
-  // transposed table for the v2 kernel (fp32): built in the Ets region of the workspace
-  float* Et = nullptr;
-  const int et_ld = (2 * maxpos + 1 + 3) / 4 * 4;
-  if (n <= 336 && maxpos >= 352 && (size_t)16 * et_ld * sizeof(float) <= w.total - w.es) {
-    Et = reinterpret_cast<float*>((char*)ws + w.es);
-    SE_REQUIRE(hipMemsetAsync(Et, 0, (size_t)16 * et_ld * sizeof(float), s) == hipSuccess, "attn_bwd: memset failed");
-    hipLaunchKernelGGL(attn_transpose_table_kernel, dim3(cdiv((long)(2 * maxpos + 1) * 16, 256)), dim3(256), 0, s, E, Et,
-                       2 * maxpos + 1, et_ld);
-  }
-  if (Et) {
-    // single-pass staged kernel (no clamp aliasing possible: |i-j| < 352 <= maxpos)
-    const long items2 = (long)nseq * 4;
-    if (n <= 112) {
-      const size_t sh = (2 * 112 * 16 + 2 * 16 * 116 + 16 * 228 + 4 * 5 * 320) * sizeof(float);
-      static unsigned raised = 0;
-  SE_REQUIRE(se_raise_lds((const void*)attn_bwd2_kernel<112, 4, true>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit");
-      int nb = items2 < 512 ? (int)items2 : 512;
-      int ipb = (int)((items2 + nb - 1) / nb);
-      nb = (int)((items2 + ipb - 1) / ipb);
-      hipLaunchKernelGGL((attn_bwd2_kernel<112, 4, true>), dim3(nb), dim3(256), sh, s, a, Et, et_ld, ipb);
-    } else {
-      const size_t sh = (336 * 16 + 2 * 16 * 340 + 16 * 676 + 8 * 5 * 320) * sizeof(float);
-      static unsigned raised = 0;
-  SE_REQUIRE(se_raise_lds((const void*)attn_bwd2_kernel<336, 8, false>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit");
-      int nb = items2 < 256 ? (int)items2 : 256;
-      int ipb = (int)((items2 + nb - 1) / nb);
-      nb = (int)((items2 + ipb - 1) / ipb);
-      hipLaunchKernelGGL((attn_bwd2_kernel<336, 8, false>), dim3(nb), dim3(512), sh, s, a, Et, et_ld, ipb);
+    if (phase & 2) {
+      const int row0 = maxpos - 16 * nkt, nrows = 32 * nkt;
+      hipLaunchKernelGGL(attn_de_replicas_reduce_kernel, dim3(cdiv(nrows * 4, 256)), dim3(256), 0, s, rep, dE, w.R, row0, nrows, ATTN_DE_NREP);
     }
     return se_check_launch("se_attn_bwd");
   }
+  AttnBwdArgs a{geom, QKV, E, dO, LSE, delta ? delta : Dl, dQKV, dE, maxpos, scale, 0};
   long items = (long)nseq * 4 * ((n + 31) / 32);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(cdiv(items, 4)), dim3(256), 0, s, a);
   long qitems = (long)nseq * 4 * ((n + 15) / 16);
@@ -2082,9 +1181,10 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     hipLaunchKernelGGL((attn_bwd_dq_kernel<352>), dim3(nblk), dim3(256), sh, s, a, ipb);
   } else {
     size_t sh = (2 * 1024 * 16 + 4 * 4 * 256) * sizeof(float);
-    SE_REQUIRE(hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)sh) == hipSuccess, "attn_bwd: cannot raise dynamic LDS limit");
+    static unsigned raised = 0;
+    SE_REQUIRE(se_raise_lds((const void*)attn_bwd_dq_kernel<1024>, sh, &raised), "attn_bwd: cannot raise dynamic LDS limit");
     hipLaunchKernelGGL((attn_bwd_dq_kernel<1024>), dim3(nblk), dim3(256), sh, s, a, ipb);
   }
   return se_check_launch("se_attn_bwd");
 }
+

@@ -21,8 +21,13 @@
 //   * LDS: K image (nkt KB) + strip (16 x (16 (nkt + 1) + 4) floats) + stage (2.2 KB) + 1 KB per wave (dS^T / W^T transposition,
 //     at the end of a query tile the wave's dQ partial) = 50.6 KB at n = 321: three workgroups per CU at <= 168 VGPRs.
 // Three barriers per query tile: strip written | key steps done | strip consumed + dQ partials written.
-// dE tiles go to the per-item table [2 nkt][256] of the ring form (slot D + nkt): attn_de_reduce_items_kernel sums them.
+// dE tiles leave the owning wave's registers as fp32 atomics into one of ATTN_DE_NREP replicas of the [R][16] table (replica = item
+// mod ATTN_DE_NREP; a tile is turned row-major through the wave's transposition patch first, so that every atomic instruction covers
+// 256 contiguous bytes); attn_de_replicas_reduce_kernel folds the replicas into dE (round 5: per-item tables [2 nkt][256] -- 271 MB
+// written and read back by a reduction kernel per launch at n = 321).
 #pragma once
+
+constexpr int ATTN_DE_NREP = 32;     // replicas of the dE table the workgroups add into (power of two)
 
 struct AttnBwd4Plan {
   int kt0[8], cnt[8];            // key tiles of wave w: kt0 .. kt0 + cnt - 1
@@ -90,7 +95,7 @@ static __device__ __forceinline__ S3 split2h1(float x0, float x1, float x2, floa
 //       this wave's dQ partial to its slot; the fragments of qt + 1 out of the stage;
 //   then the wave whose turn it is sums the dQ slots and stores the rows of qt (during everybody's next P1).
 template <int NW, int KPW, int NCW, int NKTM, int CN, int NC, bool XT, bool TL>
-static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, const AttnBwd4Plan& pl, unsigned char* smem4,
+static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd4Args& a, const AttnBwd4Plan& pl, unsigned char* smem4,
                                                       const int wave, const int lane) {
   constexpr int SW = 16 * (NKTM + 1) + 4;                                // strip row stride (floats)
   const int c = lane & 15, g = lane >> 4;
@@ -112,13 +117,8 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   const float* dob = a.dO + base * 64 + head * 16;
   const float* lseb = a.LSE + base * 4 + head;
   const float* dlb = a.Dl + base * 4 + head;
-  // DLT: delta = rowsum(dO . O) of the head is computed by the loader from the O row (one more 16-byte load per query row and lane
-  // group, 4 FMAs, two cross-group adds) instead of read from the table of attn_delta_kernel -- that launch (41 us, 274 MB) is not
-  // issued then.  OPT-IN (dbg bit 128 clear = SE_ATTN_DELTA_IN_KERNEL=1): a same-box A/B shows it slower (se_attn.hip, attn_bwd_impl).
-  constexpr bool DLT = true;
-  const float* ob = a.O + base * 64 + head * 16;
   float* dqb = a.dQKV + base * 192 + head * 16;
-  float* dEs = a.dEs + item * (long)(2 * nkt) * 256;
+  float* const dErep = a.dEs + (item & (ATTN_DE_NREP - 1)) * ((long)a.R * 16) + (long)a.maxpos * 16;      // row 0 = offset 0
   const int trrow = c >> 2, trcol = c & 3;
   const unsigned char* Esb = reinterpret_cast<const unsigned char*>(a.Es);
   const unsigned char* Etb = reinterpret_cast<const unsigned char*>(a.Ets);
@@ -162,30 +162,18 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
   // ---- query-side stage: raw loads of one query tile (loader wave only), later split into the two images ----
   float4 lq = make_float4(0.f, 0.f, 0.f, 0.f), ldo = lq;
   float lr0 = 0.f, lr1 = 0.f;
-  float4 lo4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto stage_load = [&](int qt_) {
     int qc = qt_ * 16 + c;
     if (qc > n - 1) qc = n - 1;
     lq = *reinterpret_cast<const float4*>(qb + (unsigned)(qc * ps * 192 + 4 * g));
     ldo = *reinterpret_cast<const float4*>(dob + (unsigned)(qc * ps * 64 + 4 * g));
     lr0 = lseb[(unsigned)(qc * ps * 4)];
-    // BOTH loads unconditional (the unused one reads a line that is in flight anyway): under `if / else` the join copied the loaded
-    // registers behind s_waitcnt vmcnt(0) -- the loader wave then sat out the full memory latency of this stage AND of its dE / key
-    // prefetches at the top of every query tile instead of during phase 1 (found in the ISA, round 5)
-    const bool in_kernel_delta = DLT && !(a.dbg & 128);      // (dbg bit 128, the default: the table of attn_delta_kernel)
-    lo4 = *reinterpret_cast<const float4*>(in_kernel_delta ? ob + (unsigned)(qc * ps * 64 + 4 * g) : dob + (unsigned)(qc * ps * 64 + 4 * g));
-    lr1 = (in_kernel_delta ? lseb : dlb)[(unsigned)(qc * ps * 4)];
+    lr1 = dlb[(unsigned)(qc * ps * 4)];      // delta = rowsum(dO . O): the table the to_out input-gradient GEMM's epilogue (SE_EPI_DELTA) or attn_delta_kernel wrote
   };
   auto stage_store = [&]() {
     st_planes<true>(Qimg + rfo, 512, splitx<true>(lq, sqf));
     st_planes<true>(Oimg + rfo, 512, splitx<true>(ldo, sdof));
     if (g == 0) rowc[c] = lr0;
-    if (DLT && !(a.dbg & 128)) {
-      float dl = ldo.x * lo4.x + ldo.y * lo4.y + ldo.z * lo4.z + ldo.w * lo4.w;      // this lane group's 4 of the head's 16 dims
-      dl += __shfl_xor(dl, 16, 64);
-      dl += __shfl_xor(dl, 32, 64);
-      lr1 = dl;
-    }
     if (g == 1) rowc[16 + c] = lr1;
   };
   if (wave == 0) stage_load(0);
@@ -228,12 +216,22 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
     j0[ci] = cl == 0 ? 0 : M - cl;                           // (0 - cl) mod M
   }
   float omax = 0.f;
-  // one finished offset tile: v[r] = dE[delta = 16 D + c][d = 4g + r] -> slot D + nkt of the item's table
+  // one finished offset tile: v[r] = dE[delta = 16 D + c][d = 4g + r] is added to this item's replica of the table.  The tile goes
+  // through the wave's (idle here) transposition patch into row-major order: lane l then holds elements 64 r + l of the tile's 256
+  // consecutive floats, so each of the four atomic instructions covers 256 contiguous bytes (the full-rate shape of
+  // global_atomic_add_f32, MI355X_MICROARCH.md: lanes spread over 16 rows of 64 B run several times slower)
+  float* const patch = reinterpret_cast<float*>(Dimg);
   auto flush = [&](const f32x4& v, int D) {
-    *reinterpret_cast<float4*>(dEs + (D + nkt) * 256 + c * 16 + 4 * g) = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
+    *reinterpret_cast<float4*>(patch + c * 16 + 4 * g) = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
+    float x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = patch[64 * r + lane];
+    float* const tp = dErep + D * 256 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(tp + 64 * r, x[r]);
   };
   // (diagnostic build switch dbg & 32: shader-clock stamps of the phases of the first 64 workgroups, behind the item tables)
-  unsigned* const stamps = reinterpret_cast<unsigned*>(a.dEs + (long)gridDim.x * (2 * nkt) * 256);
+  unsigned* const stamps = reinterpret_cast<unsigned*>(a.dEs + (long)ATTN_DE_NREP * a.R * 16);
   // The stamp area lies BEYOND what se_attn_bwd_workspace_bytes reserves (only tools/attn_bwd_stamps.py over-allocates for it), so
   // the stores exist only in a diagnostic build (-DSE_ATTN_STAMPS): SE_ATTN_DBG=32 in a product build writes nothing.
   auto stamp = [&](int qt_, int k) {
@@ -354,6 +352,12 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
         kcol_p = tr_planes<true>(Kcol0 + s * 1024, 512);
         f32x4 pp, ds;
         const bool kv = kt * 16 + c < n;                                 // (TL: the last step of the last wave is the tail tile)
+#if SE_ATTN_TWIN == 1
+        (void)kv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pp[r] = s4[r]; ds[r] = dp[r]; cell[r * (SW + 1)] = cu[r]; }
+        const S3 pps = twin_raw_(pp[0], pp[1], pp[2], pp[3]), dss = twin_raw_(ds[0], ds[1], ds[2], ds[3]);
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(fmaf(s4[r] + cu[r], sc2, nlse2[r]));                   // the cell of offset q - key
@@ -363,6 +367,7 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
           cell[r * (SW + 1)] = ds[r];                                    // W = skew(dS) replaces U in place
         }
         const S3 pps = split2h1(pp[0], pp[1], pp[2], pp[3], one), dss = splitn<true>(ds);
+#endif
         // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]: the accumulator registers ARE the B operands
         prodx2<true>(docol, pps, dv[s], qcol, dss, dk[s]);
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]: both operands through hardware-transposed reads (product: next step)
@@ -445,7 +450,11 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd3Args& a, con
           const int j = j0[ci] + M * t;
           if (own(ci, j)) {
             const float4 w4 = w4s[2 * ci + t];
+#if SE_ATTN_TWIN == 1
+            const S3 ws = twin_raw_(w4.x, w4.y, w4.z, w4.w);
+#else
             const S3 ws = split2h1(w4.x, w4.y, w4.z, w4.w, one);          // (W = skew(dS): already at dS's scale)
+#endif
             st_planes<true>(Dst, 512, ws);                               // image [a][dl]
             const S3 wt = tr_planes<true>(Dtr, 512);                     // W[a = 4g + i][dl = c]
             // dQ^T[d][q] += E^T[d][dl] W^T[dl][q];  dE^T[d][dl] += Q^T[d][q] W[q][dl]
@@ -553,7 +562,9 @@ static inline bool attn_bwd4_exact(const AttnBwd4Plan& pl, int nkt, int dbg) {
   return true;
 }
 template <int NW, int KPW, int NCW, int NKTM, int MINW, int CA, int NA, int CB, int NB, int CC = -1, int NC_ = 0, bool GEN = false>
-__global__ __launch_bounds__(NW * 64, MINW) void attn_bwd4_kernel(AttnBwd3Args a, AttnBwd4Plan pl) {
+// (GEN: one wave per SIMD bounds the allocation at 512 registers -- the generic body holds KPW key tiles AND NCW classes in one wave
+// and spilled 56 bytes per lane under the two-wave bound; a fallback form may be slower, not carry scratch)
+__global__ __launch_bounds__(NW * 64, GEN ? 1 : MINW) void attn_bwd4_kernel(AttnBwd4Args a, AttnBwd4Plan pl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem4[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   if constexpr (GEN) {

@@ -603,10 +603,12 @@ extern "C" int se_dwconv31(const float* X, const float* W, const float* bias, fl
   const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
   const long nitems = (long)nseq * cdiv(n, 8 * pps);
   const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;    // persistent: 2 workgroups (<= 72 KB LDS each) per CU; multiple of 8
-  static const bool twin = getenv("SE_DW_TWIN") != nullptr;
-  if (twin && pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, false, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
-  else if (twin && pps == 14) hipLaunchKernelGGL((dwconv_kernel<14, false, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
-  else if (pps == 8) hipLaunchKernelGGL(dwconv_kernel<8>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
+#ifdef SE_DW_TWIN      // measurement build (tools/build_variant_lib.sh dwtwin -DSE_DW_TWIN se_dwconv.hip): the access-pattern twin, wrong results
+  if (pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, false, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (pps == 14) hipLaunchKernelGGL((dwconv_kernel<14, false, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else
+#endif
+  if (pps == 8) hipLaunchKernelGGL(dwconv_kernel<8>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else if (pps == 13) hipLaunchKernelGGL(dwconv_kernel<13>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else hipLaunchKernelGGL(dwconv_kernel<14>, dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31");
@@ -621,10 +623,12 @@ extern "C" int se_dwconv31_glu_bwd(const float* dH, const float* W, const float*
   const int pps = n <= 64 ? 8 : (n <= 104 ? 13 : 14);
   const long nitems = (long)nseq * cdiv(n, 8 * pps);
   const int nblk = nitems < 512 ? (int)((nitems + 7) / 8 * 8) : 512;
-  static const bool twin = getenv("SE_DW_TWIN") != nullptr;
-  if (twin && pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, true, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
-  else if (twin && pps == 14) hipLaunchKernelGGL((dwconv_kernel<14, true, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
-  else if (pps == 8) hipLaunchKernelGGL((dwconv_kernel<8, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+#ifdef SE_DW_TWIN
+  if (pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, true, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else if (pps == 14) hipLaunchKernelGGL((dwconv_kernel<14, true, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
+  else
+#endif
+  if (pps == 8) hipLaunchKernelGGL((dwconv_kernel<8, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else if (pps == 13) hipLaunchKernelGGL((dwconv_kernel<13, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
   else hipLaunchKernelGGL((dwconv_kernel<14, true>), dim3(nblk), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_dwconv31_glu_bwd");

@@ -858,535 +858,6 @@ __global__ __launch_bounds__(256, 2) void ff_bwd_kernel(FfBwdArgs a) {
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// RECOMPUTING input-gradient chain (scaled split-fp16 only): the hidden pre-activations H are not read but recomputed from X
-// (one more 64 -> 64 GEMM per hidden block: H = LN(X) W1^T + b1, the forward's own arithmetic, so bit-identical values), and dZ is
-// not written -- the weight gradients recompute both (ff_wgrad_rc_kernel).  Per module and 518 736 rows the backward then moves
-// dY, X, (dR2,) dX = 0.4 - 0.53 GB instead of 1.68 GB (H read + dZ write were 1.06 GB of it; the kernel ran at 5.5 TB/s, i.e.
-// HBM-bound).  Per 32-column half of a hidden block the H tile and the dY W2s tile are two interleaved accumulator chains.
-struct FfRcArgs {
-  const float* dY; const float* X; const float* stats; const float* gamma; const float* beta;
-  const float* W1; const float* b1; const float* W2T; const float* W1T;       // fp16 planes: [hid][64], [hid][64], [64][hid]
-  long M; int hid; float drop_p; unsigned seed_h, seed_o;
-  const float* dR2; float* dX; float* dgamma; float* dbeta;
-  const float* dy_amax; const float* w1_amax; const float* w2t_amax; const float* w1t_amax; float* out_amax; int ln_sexp;
-};
-
-template <int NB>
-__global__ __launch_bounds__(256, 2) void ff_bwd_rc_kernel(FfRcArgs a) {
-  constexpr int SB = 72, PB = 64 * SB, SP = 36;
-  __shared__ __attribute__((aligned(16))) __bf16 Wh[2 * PB];           // W1 block: rows = hidden units, k = channel
-  __shared__ __attribute__((aligned(16))) __bf16 Wa[2 * PB];           // W2T block: rows = hidden units, k = channel
-  __shared__ __attribute__((aligned(16))) __bf16 Wb[2 * PB];           // W1T block: rows = channel, k = hidden units
-  __shared__ __attribute__((aligned(16))) float patch[4 * 32 * SP];
-  __shared__ __attribute__((aligned(16))) float b1s[64];
-  __shared__ __attribute__((aligned(16))) float gbs[128];               // LayerNorm gamma | beta
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* cs = patch + wave * 32 * SP;
-  const long m0 = (long)blockIdx.x * 128;
-  const long row = m0 + wave * 32 + (lane & 31);
-  const int kg = lane >> 5;
-  const bool rok = row < a.M;
-  const unsigned thr = drop_thr(a.drop_p);
-  const float inv_keep = drop_inv_keep(a.drop_p);
-  const bool dr = a.drop_p > 0.f;
-  f16_clamp_mode_();
-  const float dy_amax = __builtin_nontemporal_load(a.dy_amax), w2_amax = __builtin_nontemporal_load(a.w2t_amax);
-  const int e_dy = f16_sexp_(dy_amax), e_w2 = f16_sexp_(w2_amax), e_w1t = f16_sexp_(__builtin_nontemporal_load(a.w1t_amax));
-  const int e_w1 = f16_sexp_(__builtin_nontemporal_load(a.w1_amax));
-  const int e_dz = f16_sexp_(dy_amax * inv_keep * inv_keep * 64.f * w2_amax * 1.1f);
-  const float s_in = exp2i_(a.ln_sexp), s_dy = exp2i_(e_dy), s_dz = exp2i_(e_dz);
-  const float uh = exp2i_(-a.ln_sexp - e_w1), u1 = exp2i_(-e_dy - e_w2), u2 = exp2i_(-e_dz - e_w1t);
-  float xmax = 0.f;
-
-  bf16x8 afx[4][2], afy[4][2];          // LN(X) and masked dY rows of this lane, A-fragment layout, split
-  {
-    const long rowl = rok ? row : a.M - 1;
-    const float* __restrict__ xp = a.X + rowl * 64 + 8 * kg;
-    const float* __restrict__ yp = a.dY + rowl * 64 + 8 * kg;
-    const float2 mr = *reinterpret_cast<const float2*>(a.stats + 2 * rowl);
-    float4 vx[4][2], vy[4][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      vx[ks][0] = *reinterpret_cast<const float4*>(xp + 16 * ks); vx[ks][1] = *reinterpret_cast<const float4*>(xp + 16 * ks + 4);
-      vy[ks][0] = *reinterpret_cast<const float4*>(yp + 16 * ks); vy[ks][1] = *reinterpret_cast<const float4*>(yp + 16 * ks + 4);
-    }
-    if (tid < 32) *reinterpret_cast<float4*>(&gbs[4 * tid]) = *reinterpret_cast<const float4*>((tid < 16 ? a.gamma : a.beta - 64) + 4 * tid);
-    __syncthreads();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float x[8], y[8];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int c = 16 * ks + 8 * kg + 4 * h;
-        const float4 gm = *reinterpret_cast<const float4*>(&gbs[c]), bt = *reinterpret_cast<const float4*>(&gbs[64 + c]);
-        const float4 w = vx[ks][h];
-        x[4 * h] = rok ? (w.x - mr.x) * mr.y * gm.x + bt.x : 0.f;
-        x[4 * h + 1] = rok ? (w.y - mr.x) * mr.y * gm.y + bt.y : 0.f;
-        x[4 * h + 2] = rok ? (w.z - mr.x) * mr.y * gm.z + bt.z : 0.f;
-        x[4 * h + 3] = rok ? (w.w - mr.x) * mr.y * gm.w + bt.w : 0.f;
-        float4 d = vy[ks][h];
-        if (dr) {
-          const float4 d4 = drop_scale4(a.seed_o, (unsigned)(row * 64 + c), thr, inv_keep);
-          d.x *= d4.x; d.y *= d4.y; d.z *= d4.z; d.w *= d4.w;
-        }
-        y[4 * h] = rok ? d.x : 0.f; y[4 * h + 1] = rok ? d.y : 0.f; y[4 * h + 2] = rok ? d.z : 0.f; y[4 * h + 3] = rok ? d.w : 0.f;
-      }
-      split_planes8_h(x, s_in, afx[ks]);
-      split_planes8_h(y, s_dy, afy[ks]);
-    }
-  }
-  constexpr int nb = NB;
-  const long rows_ok = a.M - m0 < 128 ? a.M - m0 : 128;
-  const int pr = tid >> 2, pc = tid & 3;
-  const size_t wpl = (size_t)64 * (size_t)a.hid;
-  f32x4 vh[4], va[4], vb[4];              // the next block's three weight tiles (2 planes x 2 16-B chunks each)
-  float b1n = 0.f;
-  auto load_w = [&](int jb) {
-    b1n = a.b1[jb * 64 + (tid & 63)];
-    const __bf16* wh = reinterpret_cast<const __bf16*>(a.W1) + ((unsigned)(jb * 64 + pr) * 64u + 8 * pc);
-    const __bf16* wa = reinterpret_cast<const __bf16*>(a.W2T) + ((unsigned)(jb * 64 + pr) * 64u + 8 * pc);
-    const __bf16* wb = reinterpret_cast<const __bf16*>(a.W1T) + ((unsigned)pr * (unsigned)a.hid + jb * 64 + 8 * pc);
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        vh[q * 2 + h] = *reinterpret_cast<const f32x4*>(wh + q * wpl + 32 * h);
-        va[q * 2 + h] = *reinterpret_cast<const f32x4*>(wa + q * wpl + 32 * h);
-        vb[q * 2 + h] = *reinterpret_cast<const f32x4*>(wb + q * wpl + 32 * h);
-      }
-  };
-  load_w(0);
-  f32x16 g0, g1;                              // dLN accumulators (32 rows x 64 channels)
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
-  const int frag = (lane & 31) * SB + 8 * kg;
-  const int col = lane & 31, half = lane >> 5, cq = lane & 7, rr = lane >> 3;
-#pragma unroll
-  for (int jb = 0; jb < nb; ++jb) {
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        *reinterpret_cast<f32x4*>(&Wh[q * PB + pr * SB + 8 * pc + 32 * h]) = vh[q * 2 + h];
-        *reinterpret_cast<f32x4*>(&Wa[q * PB + pr * SB + 8 * pc + 32 * h]) = va[q * 2 + h];
-        *reinterpret_cast<f32x4*>(&Wb[q * PB + pr * SB + 8 * pc + 32 * h]) = vb[q * 2 + h];
-      }
-    if (tid < 64) b1s[tid] = b1n;
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      f32x16 ah, ad;                          // H tile and dY W2s tile of this 32-column half: two independent chains
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { ah[r] = 0.f; ad[r] = 0.f; }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 bh[2], bd[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          bh[pl] = *reinterpret_cast<const bf16x8*>(&Wh[pl * PB + nt * 32 * SB + frag + 16 * ks]);
-          bd[pl] = *reinterpret_cast<const bf16x8*>(&Wa[pl * PB + nt * 32 * SB + frag + 16 * ks]);
-        }
-        ah = mfma32_<true>(afx[ks][0], bh[1], ah); ad = mfma32_<true>(afy[ks][0], bd[1], ad);
-        ah = mfma32_<true>(afx[ks][1], bh[0], ah); ad = mfma32_<true>(afy[ks][1], bd[0], ad);
-        ah = mfma32_<true>(afx[ks][0], bh[0], ah); ad = mfma32_<true>(afy[ks][0], bd[0], ad);
-      }
-      if (nt == 1 && jb + 1 < nb) load_w(jb + 1);
-      const float bb = b1s[nt * 32 + col];
-      // H tile -> row-major (4 consecutive columns per lane: the dropout hash works on aligned groups of 4)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * SP + col] = ah[r] * uh + bb;
-      float4 hz[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) hz[i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * SP + cq * 4]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * SP + col] = ad[r] * u1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rl = rr + 8 * i;
-        const long rg = m0 + wave * 32 + rl;
-        float4 v = *reinterpret_cast<const float4*>(&cs[rl * SP + cq * 4]);
-        if (dr) {
-          const float4 d4 = drop_scale4(a.seed_h, (unsigned)(rg * a.hid + jb * 64 + nt * 32 + cq * 4), thr, inv_keep);
-          v.x *= d4.x; v.y *= d4.y; v.z *= d4.z; v.w *= d4.w;
-        }
-        v.x *= swish_gradf_(hz[i].x); v.y *= swish_gradf_(hz[i].y); v.z *= swish_gradf_(hz[i].z); v.w *= swish_gradf_(hz[i].w);
-        if (rg >= a.M) v = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&cs[rl * SP + cq * 4]) = v;
-      }
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2) {
-        const int ks = 2 * nt + k2;
-        float x[8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const float4 pv = *reinterpret_cast<const float4*>(&cs[(lane & 31) * SP + 16 * k2 + 8 * kg + 4 * h]);
-          x[4 * h] = pv.x; x[4 * h + 1] = pv.y; x[4 * h + 2] = pv.z; x[4 * h + 3] = pv.w;
-        }
-        bf16x8 af2[2], bf0[2], bf1[2];
-        split_planes8_h(x, s_dz, af2);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          bf0[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + frag + 16 * ks]);
-          bf1[pl] = *reinterpret_cast<const bf16x8*>(&Wb[pl * PB + 32 * SB + frag + 16 * ks]);
-        }
-        g0 = mfma32_<true>(af2[0], bf0[1], g0); g1 = mfma32_<true>(af2[0], bf1[1], g1);
-        g0 = mfma32_<true>(af2[1], bf0[0], g0); g1 = mfma32_<true>(af2[1], bf1[0], g1);
-        g0 = mfma32_<true>(af2[0], bf0[0], g0); g1 = mfma32_<true>(af2[0], bf1[0], g1);
-      }
-    }
-    __syncthreads();
-  }
-  float4 gv[2][4];                            // dLN of rows rr + 8 i, columns nt * 32 + 4 cq .. + 3
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * half) * SP + col] = (nt ? g1[r] : g0[r]) * u2;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gv[nt][i] = *reinterpret_cast<const float4*>(&cs[(rr + 8 * i) * SP + cq * 4]);
-  }
-  // LayerNorm backward on the rows in registers (as in ff_bwd_kernel): a row's 64 channels sit in the 8 lanes cq = 0..7 of one rr group
-  float ag[2][4] = {}, ab[2][4] = {};
-  float4 gm[2];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) gm[nt] = *reinterpret_cast<const float4*>(&gbs[nt * 32 + cq * 4]);
-  float2 mrs[4];
-  float4 xvs[4][2], r1s[4][2], r2s[4][2];
-  const __amdgpu_buffer_rsrc_t Xrs = make_rsrc_(a.dX + m0 * 64, (unsigned)(rows_ok * 64 * 4));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long rg_ = m0 + wave * 32 + rr + 8 * i;
-    const long rgc = rg_ < a.M ? rg_ : a.M - 1;
-    mrs[i] = *reinterpret_cast<const float2*>(a.stats + 2 * rgc);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const long off = rgc * 64 + nt * 32 + cq * 4;
-      xvs[i][nt] = *reinterpret_cast<const float4*>(a.X + off);
-      r1s[i][nt] = *reinterpret_cast<const float4*>(a.dY + off);
-      r2s[i][nt] = a.dR2 ? *reinterpret_cast<const float4*>(a.dR2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long rg = m0 + wave * 32 + rr + 8 * i;
-    const bool ok = rg < a.M;
-    const float mean = mrs[i].x, rstd = mrs[i].y;
-    float xh[2][4], dxh[2][4], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const float4 xv = xvs[i][nt];
-      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-      const float dv[4] = {gv[nt][i].x, gv[nt][i].y, gv[nt][i].z, gv[nt][i].w};
-      const float gl[4] = {gm[nt].x, gm[nt].y, gm[nt].z, gm[nt].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xh[nt][j] = (xs[j] - mean) * rstd;
-        dxh[nt][j] = dv[j] * gl[j];
-        s1 += dxh[nt][j]; s2 += dxh[nt][j] * xh[nt][j];
-        if (ok) { ag[nt][j] += dv[j] * xh[nt][j]; ab[nt][j] += dv[j]; }
-      }
-    }
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const float4 r1 = r1s[i][nt], r2 = r2s[i][nt];
-      float o4[4] = {r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o4[j] += rstd * (dxh[nt][j] - s1 - xh[nt][j] * s2);
-      buf_store4_(Xrs, (unsigned)(((wave * 32 + rr + 8 * i) * 64 + nt * 32 + cq * 4) * 4), make_float4(o4[0], o4[1], o4[2], o4[3]));
-      if (ok) xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
-    }
-  }
-  if (a.out_amax) {
-    xmax = wave_max(xmax);
-    if (lane == 0) amax_raise_(a.out_amax, xmax);
-  }
-  float* redg = reinterpret_cast<float*>(Wa);         // [4 waves][64 channels][2]; the weight planes are free now
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float sg = ag[nt][j], sb = ab[nt][j];
-#pragma unroll
-      for (int o = 8; o < 64; o <<= 1) { sg += __shfl_xor(sg, o, 64); sb += __shfl_xor(sb, o, 64); }
-      if (rr == 0) { redg[(wave * 64 + nt * 32 + cq * 4 + j) * 2] = sg; redg[(wave * 64 + nt * 32 + cq * 4 + j) * 2 + 1] = sb; }
-    }
-  __syncthreads();
-  if (tid < 64) {
-    float sg = 0.f, sb = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { sg += redg[(w * 64 + tid) * 2]; sb += redg[(w * 64 + tid) * 2 + 1]; }
-    atomicAdd(&a.dgamma[tid], sg);
-    atomicAdd(&a.dbeta[tid], sb);
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// RECOMPUTING weight gradients of the feed-forward module (scaled split-fp16): dW1, db1, dW2, db2 from X and dY alone -- the
-// hidden activations S = Swish(H) * mask and their gradients dZ are recomputed per 32-row step (two 64 -> 32 GEMMs per wave, the
-// forward's / backward's own arithmetic) and contracted over the rows at once.  The two whole-gradient kernels this replaces read
-// H and dZ (2 x 531 MB at 518 736 rows) and ran at 4.1 - 4.7 TB/s, i.e. HBM-bound; this one reads 0.27 GB and is matrix-pipe bound.
-//   8 waves; wave w owns hidden units [32 w, 32 w + 32): its W1 / W2s rows stay in registers as MFMA B fragments for the whole
-//   launch, its [32 x 64] blocks of dW1 and dW2^T are 64 accumulator registers.  Per step the workgroup stages LN(X) and
-//   mask_o * dY (32 rows) twice in LDS: row-major (A fragments of the two recompute GEMMs) and as 8-row column cells (B fragments
-//   of the two contractions over rows).  H and dY W2s leave the MFMAs in the C layout -- lane (hidden unit j, half h) holds 16
-//   rows -- which IS the A-fragment layout of S^T / dZ^T up to a permutation of the rows: K slot (chunk ck, half h, i) is row
-//   16 ck + 4 h + (i & 3) + 8 (i >> 2), and the column cells are written in that order, so nothing is transposed.
-struct FfWgArgs {
-  const float* X; const float* stats; const float* gamma; const float* beta; const float* dY;
-  const float* W1; const float* b1; const float* W2T;                        // fp16 planes [hid][64]
-  float* dW1; float* db1; float* dW2; float* db2;                            // [hid][64], [hid], [64][hid], [64]: accumulated
-  long M; int hid; float drop_p; unsigned seed_h, seed_o; float alpha;
-  const float* dy_amax; const float* w1_amax; const float* w2t_amax; int ln_sexp, hid_sexp;
-  long rows_per_chunk;
-};
-
-__global__ __launch_bounds__(512, 2) void ff_wgrad_rc_kernel(FfWgArgs a) {
-  constexpr int SBR = 72, PR = 32 * SBR;            // row-major image: [plane][32 rows][64 + 8 pad] fp16
-  constexpr int PC = 4 * 64 * 8;                    // cell image: [plane][4 cells][64 columns][8 row slots] fp16
-  __shared__ __attribute__((aligned(16))) __bf16 Xr[2 * PR];
-  __shared__ __attribute__((aligned(16))) __bf16 Yr[2 * PR];
-  __shared__ __attribute__((aligned(16))) __bf16 Xc[2 * PC];
-  __shared__ __attribute__((aligned(16))) __bf16 Yc[2 * PC];
-  __shared__ float red2[16 * 64];
-  constexpr int SBW = 72, PW = 256 * SBW;           // W2s: all 256 rows resident for the launch (73.7 KB): 32 VGPRs less than fragments
-  __shared__ __attribute__((aligned(16))) __bf16 W2s[2 * PW];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int col = lane & 31, kg = lane >> 5;
-  const long mbeg = (long)blockIdx.x * a.rows_per_chunk;
-  long mend = mbeg + a.rows_per_chunk;
-  if (mend > a.M) mend = a.M;
-  if (mbeg >= mend) return;
-  const unsigned thr = drop_thr(a.drop_p);
-  const float inv_keep = drop_inv_keep(a.drop_p);
-  const bool dr = a.drop_p > 0.f;
-  f16_clamp_mode_();
-  const float dy_amax = __builtin_nontemporal_load(a.dy_amax), w2_amax = __builtin_nontemporal_load(a.w2t_amax);
-  const int e_dy = f16_sexp_(dy_amax), e_w2 = f16_sexp_(w2_amax), e_w1 = f16_sexp_(__builtin_nontemporal_load(a.w1_amax));
-  const int e_dz = f16_sexp_(dy_amax * inv_keep * inv_keep * 64.f * w2_amax * 1.1f);
-  const float s_x = exp2i_(a.ln_sexp), s_y = exp2i_(e_dy), s_s = exp2i_(a.hid_sexp), s_z = exp2i_(e_dz);
-  const float uh = exp2i_(-a.ln_sexp - e_w1), u1 = exp2i_(-e_dy - e_w2);
-  // ---- this wave's weight rows as B fragments: lane (hidden unit 32 w + col, kg) holds k = 16 ks + 8 kg .. + 7
-  bf16x8 w1f[4][2];
-  {
-    const size_t wpl = (size_t)64 * (size_t)a.hid;
-    const __bf16* p1 = reinterpret_cast<const __bf16*>(a.W1) + (size_t)(32 * wave + col) * 64 + 8 * kg;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) w1f[ks][pl] = *reinterpret_cast<const bf16x8*>(p1 + pl * wpl + 16 * ks);
-    // W2s planes -> LDS: 2 planes x 256 rows x 8 16-B chunks = 4096 chunks, 8 per thread
-    const __bf16* p2 = reinterpret_cast<const __bf16*>(a.W2T);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int ch = tid + 512 * i, pl = ch >> 11, rw = (ch >> 3) & 255, c8 = ch & 7;
-      *reinterpret_cast<f32x4*>(&W2s[pl * PW + rw * SBW + 8 * c8]) = *reinterpret_cast<const f32x4*>(p2 + pl * wpl + (size_t)rw * 64 + 8 * c8);
-    }
-  }
-  const __bf16* w2row = &W2s[(32 * wave + col) * SBW + 8 * kg];
-  const float b1v = a.b1[32 * wave + col];
-  // ---- staging role: operand (X / dY), cell, 4 columns, 2 consecutive rows
-  const int sop = tid >> 8, su = tid & 255, scell = su >> 6, sl = su & 63, scol = (sl & 15) * 4, srq = sl >> 4;
-  const int srow = 16 * (scell >> 1) + 4 * (scell & 1) + 8 * (srq >> 1) + 2 * (srq & 1);
-  float4 sgm = make_float4(0.f, 0.f, 0.f, 0.f), sbt = sgm;
-  if (sop == 0) { sgm = *reinterpret_cast<const float4*>(a.gamma + scol); sbt = *reinterpret_cast<const float4*>(a.beta + scol); }
-  const float* __restrict__ sptr = (sop == 0 ? a.X : a.dY) + scol;
-  float4 rv[2];
-  float2 rst[2];
-  auto load_rows = [&](long mb) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      long mg = mb + srow + i;
-      if (mg > a.M - 1) mg = a.M - 1;                                  // unconditional loads; rows >= mend are zeroed below
-      rv[i] = *reinterpret_cast<const float4*>(sptr + mg * 64);
-      if (sop == 0) rst[i] = *reinterpret_cast<const float2*>(a.stats + 2 * mg);
-    }
-  };
-  f32x16 aw1[2], aw2[2];                      // dW1 [32 j x 64 c], dW2^T [32 j x 64 n] of this wave
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { aw1[nt][r] = 0.f; aw2[nt][r] = 0.f; }
-  float zsum = 0.f;
-  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  load_rows(mbeg);
-  for (long mb = mbeg; mb < mend; mb += 32) {
-    // ---- stage: prologue (LayerNorm / output-dropout mask), scaled fp16 split, both images
-    {
-      float v[2][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const long mg = mb + srow + i;
-        const bool ok = mg < mend;
-        const float4 w = rv[i];
-        if (sop == 0) {
-          v[i][0] = ok ? ((w.x - rst[i].x) * rst[i].y * sgm.x + sbt.x) * s_x : 0.f;
-          v[i][1] = ok ? ((w.y - rst[i].x) * rst[i].y * sgm.y + sbt.y) * s_x : 0.f;
-          v[i][2] = ok ? ((w.z - rst[i].x) * rst[i].y * sgm.z + sbt.z) * s_x : 0.f;
-          v[i][3] = ok ? ((w.w - rst[i].x) * rst[i].y * sgm.w + sbt.w) * s_x : 0.f;
-        } else {
-          float4 d = w;
-          if (dr) {
-            const float4 d4 = drop_scale4(a.seed_o, (unsigned)(mg * 64 + scol), thr, inv_keep);
-            d.x *= d4.x; d.y *= d4.y; d.z *= d4.z; d.w *= d4.w;
-          }
-          if (!ok) d = make_float4(0.f, 0.f, 0.f, 0.f);
-          bsum.x += d.x; bsum.y += d.y; bsum.z += d.z; bsum.w += d.w;
-          v[i][0] = d.x * s_y; v[i][1] = d.y * s_y; v[i][2] = d.z * s_y; v[i][3] = d.w * s_y;
-        }
-      }
-      _Float16 hh[2][4], ll[2][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { hh[i][j] = (_Float16)v[i][j]; ll[i][j] = (_Float16)(v[i][j] - (float)hh[i][j]); }
-      __bf16* Ri = sop == 0 ? Xr : Yr;
-      __bf16* Ci = sop == 0 ? Xc : Yc;
-      auto pk = [](_Float16 lo_, _Float16 hi_) -> unsigned {
-        return (unsigned)__builtin_bit_cast(unsigned short, lo_) | ((unsigned)__builtin_bit_cast(unsigned short, hi_) << 16);
-      };
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<u32x2_*>(&Ri[(srow + i) * SBR + scol]) = (u32x2_){pk(hh[i][0], hh[i][1]), pk(hh[i][2], hh[i][3])};
-        *reinterpret_cast<u32x2_*>(&Ri[PR + (srow + i) * SBR + scol]) = (u32x2_){pk(ll[i][0], ll[i][1]), pk(ll[i][2], ll[i][3])};
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<unsigned*>(&Ci[((scell * 64 + scol + j) * 8) + 2 * srq]) = pk(hh[0][j], hh[1][j]);
-        *reinterpret_cast<unsigned*>(&Ci[PC + ((scell * 64 + scol + j) * 8) + 2 * srq]) = pk(ll[0][j], ll[1][j]);
-      }
-    }
-    __syncthreads();
-    if (mb + 32 < mend) load_rows(mb + 32);
-    // ---- recompute: H tile and dY W2s tile (32 rows x this wave's 32 hidden units), two interleaved chains
-    f32x16 ah, ad;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ah[r] = 0.f; ad[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 ax[2], ay[2];
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        ax[pl] = *reinterpret_cast<const bf16x8*>(&Xr[pl * PR + col * SBR + 16 * ks + 8 * kg]);
-        ay[pl] = *reinterpret_cast<const bf16x8*>(&Yr[pl * PR + col * SBR + 16 * ks + 8 * kg]);
-      }
-      const bf16x8 w20 = *reinterpret_cast<const bf16x8*>(w2row + 16 * ks), w21 = *reinterpret_cast<const bf16x8*>(w2row + PW + 16 * ks);
-      ah = mfma32_<true>(ax[0], w1f[ks][1], ah); ad = mfma32_<true>(ay[0], w21, ad);
-      ah = mfma32_<true>(ax[1], w1f[ks][0], ah); ad = mfma32_<true>(ay[1], w20, ad);
-      ah = mfma32_<true>(ax[0], w1f[ks][0], ah); ad = mfma32_<true>(ay[0], w20, ad);
-    }
-    // ---- S = Swish(H) mask_h, dZ = (dY W2s) mask_h Swish'(H) in the C layout (lane = hidden unit 32 w + col, 16 rows), eight rows
-    // (one K chunk) at a time, split at once into the A fragments of the two contractions over rows:
-    // dW2^T += S^T (mask_o dY), dW1 += dZ^T LN(X)
-#pragma unroll
-    for (int ck = 0; ck < 2; ++ck) {
-      bf16x8 sa[2], za[2];
-      {
-        float xs[8], xz[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int r = 8 * ck + i;
-          const long mg = mb + (r & 3) + 8 * (r >> 2) + 4 * kg;
-          const float h = ah[r] * uh + b1v;
-          float msk = 1.f;
-          if (dr) msk = drop_scale(a.seed_h, (unsigned)(mg * a.hid + 32 * wave + col), thr, inv_keep);
-          const bool ok = mg < mend;
-          xs[i] = ok ? swishf_(h) * msk * s_s : 0.f;
-          const float dz = ok ? ad[r] * u1 * msk * swish_gradf_(h) : 0.f;
-          zsum += dz;
-          xz[i] = dz * s_z;
-        }
-        split_planes8_h(xs, 1.f, sa);
-        split_planes8_h(xz, 1.f, za);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        bf16x8 yc[2], xc[2];
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          yc[pl] = *reinterpret_cast<const bf16x8*>(&Yc[pl * PC + (((2 * ck + kg) * 64 + nt * 32 + col) * 8)]);
-          xc[pl] = *reinterpret_cast<const bf16x8*>(&Xc[pl * PC + (((2 * ck + kg) * 64 + nt * 32 + col) * 8)]);
-        }
-        aw2[nt] = mfma32_<true>(sa[0], yc[1], aw2[nt]); aw1[nt] = mfma32_<true>(za[0], xc[1], aw1[nt]);
-        aw2[nt] = mfma32_<true>(sa[1], yc[0], aw2[nt]); aw1[nt] = mfma32_<true>(za[1], xc[0], aw1[nt]);
-        aw2[nt] = mfma32_<true>(sa[0], yc[0], aw2[nt]); aw1[nt] = mfma32_<true>(za[0], xc[0], aw1[nt]);
-      }
-    }
-    __syncthreads();
-  }
-  // ---- flush: one fp32 atomic per element per workgroup (as the whole-gradient kernels do)
-  const float un1 = exp2i_(-e_dz - a.ln_sexp), un2 = a.alpha * exp2i_(-a.hid_sexp - e_dy);
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int j = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * kg, c = nt * 32 + col;
-      atomicAdd(&a.dW1[(long)j * 64 + c], aw1[nt][r] * un1);
-      atomicAdd(&a.dW2[(long)c * a.hid + j], aw2[nt][r] * un2);
-    }
-  zsum += __shfl_xor(zsum, 32, 64);
-  if (kg == 0) atomicAdd(&a.db1[32 * wave + col], zsum);
-  if (a.db2) {
-    // column sums of mask_o dY: the 256 staging threads of operand 1 hold 2 rows x 4 columns each; fold the 16 (cell, row pair) groups
-    if (sop == 1) *reinterpret_cast<float4*>(&red2[(scell * 4 + srq) * 64 + scol]) = bsum;
-    __syncthreads();
-    if (tid < 64) {
-      float t = 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) t += red2[g * 64 + tid];
-      atomicAdd(&a.db2[tid], a.alpha * t);
-    }
-  }
-}
-
-extern "C" int se_ff_wgrad_rc(const float* X, const float* stats, const float* gamma, const float* beta, const float* dY,
-                              const float* W1, const float* b1, const float* W2T, float* dW1, float* db1, float* dW2, float* db2,
-                              long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha,
-                              const float* dy_amax, const float* w1_amax, const float* w2t_amax, int ln_sexp, int hid_sexp,
-                              void* stream) {
-  SE_REQUIRE(X && stats && gamma && beta && dY && W1 && b1 && W2T && dW1 && db1 && dW2, "ff_wgrad_rc: null operand");
-  SE_REQUIRE(dy_amax && w1_amax && w2t_amax, "ff_wgrad_rc: the operand amax scalars are required (scaled split-fp16)");
-  SE_REQUIRE(M > 0 && hid == 256, "ff_wgrad_rc: M=%ld hid=%d (built for hid == 256: 8 waves x 32 hidden units)", M, hid);
-  SE_REQUIRE((((size_t)W1 | (size_t)W2T) & 15) == 0, "ff_wgrad_rc: weight planes must be 16-byte aligned");
-  SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f && M * (long)hid < 4294967296L, "ff_wgrad_rc: drop_p / dropout index out of range");
-  // one resident round: 256 CUs x 1 workgroup of 8 waves (2 waves per SIMD at <= 256 VGPRs); at least 8 steps per workgroup
-  long rpc = (M + 255) / 256;
-  if (rpc < 256) rpc = 256;
-  rpc = (rpc + 31) / 32 * 32;
-  const int nch = (int)((M + rpc - 1) / rpc);
-  FfWgArgs a{X, stats, gamma, beta, dY, W1, b1, W2T, dW1, db1, dW2, db2, M, hid, drop_p, seed_h, seed_o, alpha,
-             dy_amax, w1_amax, w2t_amax, ln_sexp, hid_sexp, rpc};
-  hipLaunchKernelGGL(ff_wgrad_rc_kernel, dim3((unsigned)nch), dim3(512), 0, as_stream(stream), a);
-  return se_check_launch("se_ff_wgrad_rc");
-}
-
-extern "C" int se_ff_bwd_rc(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta,
-                            const float* W1, const float* b1, const float* W2T, const float* W1T, long M, int hid, float drop_p,
-                            unsigned seed_h, unsigned seed_o, const float* dR2, float* dX, float* dgamma, float* dbeta,
-                            const float* dy_amax, const float* w1_amax, const float* w2t_amax, const float* w1t_amax,
-                            float* out_amax, int ln_sexp, void* stream) {
-  SE_REQUIRE(dY && X && stats && gamma && beta && W1 && b1 && W2T && W1T && dX && dgamma && dbeta, "ff_bwd_rc: null operand");
-  SE_REQUIRE(dy_amax && w1_amax && w2t_amax && w1t_amax, "ff_bwd_rc: the operand amax scalars are required (scaled split-fp16)");
-  SE_REQUIRE(M > 0 && hid == 256, "ff_bwd_rc: M=%ld hid=%d (built for hid == 256)", M, hid);
-  SE_REQUIRE((((size_t)W1 | (size_t)W2T | (size_t)W1T) & 15) == 0, "ff_bwd_rc: weight planes must be 16-byte aligned");
-  SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f && M * (long)hid < 4294967296L, "ff_bwd_rc: drop_p / dropout index out of range");
-  FfRcArgs a{dY, X, stats, gamma, beta, W1, b1, W2T, W1T, M, hid, drop_p, seed_h, seed_o, dR2, dX, dgamma, dbeta,
-             dy_amax, w1_amax, w2t_amax, w1t_amax, out_amax, ln_sexp};
-  hipLaunchKernelGGL(ff_bwd_rc_kernel<4>, dim3((unsigned)((M + 127) / 128)), dim3(256), 0, as_stream(stream), a);
-  return se_check_launch("se_ff_bwd_rc");
-}
-
-extern "C" int se_ff_bwd_dgrad(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN,
-                               long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision,
-                               const float* X, const float* stats, const float* gamma, const float* dR2, float* dX,
-                               float* dgamma, float* dbeta, void* stream) {
-  return se_ff_bwd_dgrad_f16(dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, precision, X, stats, gamma, dR2, dX, dgamma,
-                             dbeta, nullptr, stream);
-}
-
 extern "C" int se_ff_bwd_dgrad_f16(const float* dY, const float* H, const float* W2T, const float* W1T, float* dZ, float* dLN,
                                    long M, int hid, float drop_p, unsigned seed_h, unsigned seed_o, int precision,
                                    const float* X, const float* stats, const float* gamma, const float* dR2, float* dX,
@@ -1397,70 +868,39 @@ extern "C" int se_ff_bwd_dgrad_f16(const float* dY, const float* H, const float*
   SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_bwd_dgrad: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
   const bool wpl = (precision & 16) != 0;
   precision &= 15;
-  SE_REQUIRE(precision >= 1 && precision <= 3, "ff_bwd_dgrad: precision must be 1 (bf16x3), 2 (bf16x6) or 3 (scaled fp16x3)");
-  SE_REQUIRE(!wpl || (precision >= 2 && (((size_t)W2T | (size_t)W1T) & 15) == 0), "ff_bwd_dgrad: pre-split weights need precision 2 / 3 and 16-byte alignment");
-  SE_REQUIRE(precision != 3 || (wpl && sc && sc->wa_amax && sc->wb_amax && hid == 256),
-             "ff_bwd_dgrad: precision 3 needs pre-split fp16 planes with their amax scalars (sc) and hid == 256");
+  SE_REQUIRE(precision == 3 && wpl && sc && sc->wa_amax && sc->wb_amax && hid == 256 && (((size_t)W2T | (size_t)W1T) & 15) == 0,
+             "ff_bwd_dgrad: scaled split-fp16 only (precision 3 | 16): pre-split fp16 planes, 16-byte aligned, with their amax scalars (sc), hid == 256");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_bwd_dgrad: drop_p=%f out of range", drop_p);
   SE_REQUIRE(M * (long)hid < 4294967296L, "ff_bwd_dgrad: dropout index exceeds 32 bits");
   FfBwdArgs a{dY, H, W2T, W1T, dZ, dLN, M, hid, drop_p, seed_h, seed_o, X, stats, gamma, dR2, dX, dgamma, dbeta, sc ? *sc : se_f16_scales{}};
   dim3 grid((unsigned)((M + 127) / 128)), block(256);
-  if (precision == 3) hipLaunchKernelGGL((ff_bwd_kernel<2, true, 4, true>), grid, block, 0, as_stream(stream), a);
-  else if (precision == 1) hipLaunchKernelGGL(ff_bwd_kernel<2>, grid, block, 0, as_stream(stream), a);
-  else if (wpl && hid == 256) hipLaunchKernelGGL((ff_bwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);
-  else if (wpl) hipLaunchKernelGGL((ff_bwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
-  else hipLaunchKernelGGL(ff_bwd_kernel<3>, grid, block, 0, as_stream(stream), a);
+  hipLaunchKernelGGL((ff_bwd_kernel<2, true, 4, true>), grid, block, 0, as_stream(stream), a);
   return se_check_launch("se_ff_bwd_dgrad");
-}
-
-extern "C" int se_ff_fwd(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
-                         const float* b1, const float* W2, const float* b2, float* H, float* Y, long M, int hid,
-                         float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
-  return se_ff_fwd_stats(X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, nullptr, M, hid, drop_p, seed_h, seed_o, alpha, precision,
-                         stream);
-}
-
-extern "C" int se_ff_fwd_stats(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
-                               const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M,
-                               int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision, void* stream) {
-  return se_ff_fwd_f16(X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, out_stats, M, hid, drop_p, seed_h, seed_o, alpha, precision,
-                       nullptr, stream);
 }
 
 extern "C" int se_ff_fwd_f16(const float* X, const float* rowstats, const float* gamma, const float* beta, const float* W1,
                              const float* b1, const float* W2, const float* b2, float* H, float* Y, float* out_stats, long M,
                              int hid, float drop_p, unsigned seed_h, unsigned seed_o, float alpha, int precision,
                              const se_f16_scales* sc, void* stream) {
-  SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && Y && (H || (precision & 15) == 3), "ff_fwd: null operand");
-  SE_REQUIRE(M > 0 && hid >= 64 && hid % 64 == 0, "ff_fwd: M=%ld hid=%d (hid must be a multiple of 64)", M, hid);
-  const bool wpl = (precision & 16) != 0;
-  precision &= 15;
-  SE_REQUIRE(precision >= 1 && precision <= 3, "ff_fwd: precision must be 1 (bf16x3), 2 (bf16x6) or 3 (scaled fp16x3)");
-  SE_REQUIRE(!wpl || (precision >= 2 && (((size_t)W1 | (size_t)W2) & 15) == 0), "ff_fwd: pre-split weights need precision 2 / 3 and 16-byte alignment");
-  SE_REQUIRE(precision != 3 || (wpl && sc && sc->wa_amax && sc->wb_amax && hid == 256),
-             "ff_fwd: precision 3 needs pre-split fp16 planes with their amax scalars (sc) and hid == 256");
+  SE_REQUIRE(X && rowstats && gamma && beta && W1 && b1 && W2 && b2 && Y, "ff_fwd: null operand");
+  SE_REQUIRE(M > 0 && hid == 256, "ff_fwd: M=%ld hid=%d (the Conformer's hid = 256 only)", M, hid);
+  SE_REQUIRE(precision == (3 | 16) && sc && sc->wa_amax && sc->wb_amax && (((size_t)W1 | (size_t)W2) & 15) == 0,
+             "ff_fwd: scaled split-fp16 only (precision 3 | 16): pre-split fp16 planes, 16-byte aligned, with their amax scalars (sc)");
   SE_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "ff_fwd: drop_p=%f out of range", drop_p);
-  SE_REQUIRE(M * (long)hid < 4294967296L, "ff_fwd: dropout index exceeds 32 bits");
-  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats, sc ? *sc : se_f16_scales{}};
-  dim3 grid((unsigned)((M + 127) / 128)), block(256);
-  SE_REQUIRE(precision == 3 || H != nullptr, "ff_fwd: only the scaled split-fp16 form runs without storing H");
-  static const bool fwd_ws = !(getenv("SE_FF_FWD_WS") && atoi(getenv("SE_FF_FWD_WS")) == 0);      // SE_FF_FWD_WS=0: the per-128-row kernel
-  if (precision == 3 && !a.H && fwd_ws && M * 256 < 4294963200L) {
+  SE_REQUIRE(M * (long)hid < 4294963200L, "ff_fwd: dropout index exceeds 32 bits");
+  FfArgs a{X, rowstats, gamma, beta, W1, b1, W2, b2, H, Y, M, hid, drop_p, seed_h, seed_o, alpha, out_stats, *sc};
+  if (!a.H) {      // the default: W-stationary, H not stored (the fused backward recomputes it)
     const int ncu = se_cu_count();
     const long need = (M + 255) / 256;
-    static unsigned raised = 0;
     const bool dr = drop_p > 0.f;
-    static unsigned raised0 = 0;
+    static unsigned raised = 0, raised0 = 0;
     SE_REQUIRE(se_raise_lds(dr ? (const void*)ff_fwd_ws_kernel<true> : (const void*)ff_fwd_ws_kernel<false>, FW_LDS_BYTES, dr ? &raised : &raised0),
                "ff_fwd: cannot raise the dynamic LDS limit");
     if (dr) hipLaunchKernelGGL(ff_fwd_ws_kernel<true>, dim3((unsigned)(need < ncu ? need : ncu)), dim3(512), FW_LDS_BYTES, as_stream(stream), a);
     else hipLaunchKernelGGL(ff_fwd_ws_kernel<false>, dim3((unsigned)(need < ncu ? need : ncu)), dim3(512), FW_LDS_BYTES, as_stream(stream), a);
-  } else if (precision == 3 && a.H) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, true>), grid, block, 0, as_stream(stream), a);
-  else if (precision == 3) hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, false>), grid, block, 0, as_stream(stream), a);
-  else if (precision == 1) hipLaunchKernelGGL(ff_fwd_kernel<2>, grid, block, 0, as_stream(stream), a);
-  else if (wpl && hid == 256) hipLaunchKernelGGL((ff_fwd_kernel<3, true, 4>), grid, block, 0, as_stream(stream), a);
-  else if (wpl) hipLaunchKernelGGL((ff_fwd_kernel<3, true>), grid, block, 0, as_stream(stream), a);
-  else hipLaunchKernelGGL(ff_fwd_kernel<3>, grid, block, 0, as_stream(stream), a);
+  } else {         // H stored for se_ff_bwd_dgrad_f16 (the cross-check path: SE_FF_FUSED=0)
+    hipLaunchKernelGGL((ff_fwd_kernel<2, true, 4, true, true>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, as_stream(stream), a);
+  }
   return se_check_launch("se_ff_fwd");
 }
 

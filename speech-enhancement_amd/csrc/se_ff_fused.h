@@ -1,5 +1,6 @@
-// Shared by the two fused feed-forward backward kernels (se_ff_fused.hip: specialised D / W waves, v2; se_ff_fused3.hip: symmetric
-// waves, v3): argument block, transposed-read fragments, fp16 split helpers.
+// The fused feed-forward backward kernel (se_ff_fused.hip: specialised D / W waves): argument block, transposed-read fragments,
+// fp16 split helpers.  (A symmetric-wave form, 32-row tiles with the weights in registers, was built and measured slower in round
+// 5: 669 vs 509 us per launch -- profiles/r05_ff_fused_ab.txt; removed in round 6.)
 #pragma once
 #include "se_gemm_dev.h"
 
@@ -16,9 +17,7 @@ struct FfFusedArgs {
   int ln_sexp, hid_sexp;
   int dbg;                 // timing ablations (SE_FF_DBG; 0 in production: wrong results otherwise) -- see tools/ff_fused_bench.py
   unsigned* stamps;        // -DSE_FF_STAMPS builds only (tools/ff_fused_stamps.py): s_memtime of every wave's ARRIVAL at every barrier
-  const float* W1T; const float* w1t_amax;     // v3: W1^T planes [2][64][256] (B operand of dLN straight from memory); may be NULL (v2)
 };
-int se_ff_fused3_launch(const FfFusedArgs& a, int nwg_hint, void* stream);      // se_ff_fused3.hip
 // diagnostic build: [workgroup < 4][wave 8][tile < 8][barrier 10] shader-clock stamps (low 32 bits), written by lane 0
 #ifdef SE_FF_STAMPS
 #define FF_STAMP(k) do { if (a.stamps && blockIdx.x < 4 && t < 8 && lane == 0) \

@@ -510,7 +510,7 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
                                float* dbeta, float* dW1, float* db1, float* dW2, float* db2, long M, int hid, float drop_p,
                                unsigned seed_h, unsigned seed_o, float alpha, const float* dy_amax, const float* w1_amax,
                                const float* w2t_amax, const float* in_amax, int ln_sexp, const float* mid_amax, int hid_sexp,
-                               float* out_amax, const float* W1T, const float* w1t_amax, void* stream) {
+                               float* out_amax, void* stream) {
   SE_REQUIRE(dY && X && stats && gamma && beta && W1 && b1 && W2T && dX && dgamma && dbeta && dW1 && db1 && dW2, "ff_bwd_fused: null operand");
   SE_REQUIRE(dy_amax && w1_amax && w2t_amax, "ff_bwd_fused: the operand amax scalars are required (scaled split-fp16)");
   SE_REQUIRE(M > 0 && hid == 256, "ff_bwd_fused: M=%ld hid=%d (built for hid == 256: four slots of 64 hidden units)", M, hid);
@@ -524,16 +524,11 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
   rpw = (rpw + 63) / 64 * 64;
   const int nwg = (int)((M + rpw - 1) / rpw);
   FfFusedArgs a{dY, X, stats, gamma, beta, W1, b1, W2T, dR2, dX, dgamma, dbeta, dW1, db1, dW2, db2, M, rpw, drop_p, seed_h, seed_o, alpha,
-                dy_amax, w1_amax, w2t_amax, in_amax, mid_amax, out_amax, ln_sexp, hid_sexp, 0, nullptr, W1T, w1t_amax};
+                dy_amax, w1_amax, w2t_amax, in_amax, mid_amax, out_amax, ln_sexp, hid_sexp, 0, nullptr};
+#ifdef SE_FF_STAMPS      // diagnostic builds only (tools/ff_fused_stamps.py): timing ablations + barrier-arrival stamps
   if (const char* e = getenv("SE_FF_DBG")) a.dbg = atoi(e);
-#ifdef SE_FF_STAMPS
   a.stamps = g_ff_stamps;
 #endif
-  // SE_FF_FUSED_V=3: the symmetric-wave kernel of se_ff_fused3.hip (32-row tiles, weights in registers, three barriers per tile; needs
-  // the W1^T planes).  Correct, but measured SLOWER than this file's specialised-wave kernel on one box: 669 vs 509 us per launch at the
-  // bench shape, 60.9 vs 58.2 - 58.7 ms per step (the stored-H kernels: 62.0 - 62.2) -- profiles/r05_ff_fused_ab.txt.  Default: 2.
-  const int ver = getenv("SE_FF_FUSED_V") ? atoi(getenv("SE_FF_FUSED_V")) : 2;
-  if (ver == 3 && W1T && w1t_amax) return se_ff_fused3_launch(a, ncu, stream);
   hipLaunchKernelGGL(ff_bwd_fused_kernel, dim3((unsigned)nwg), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_ff_bwd_fused");
 }

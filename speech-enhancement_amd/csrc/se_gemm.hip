@@ -1207,6 +1207,11 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     SE_REQUIRE(AUX && d->N == 64 && d->C >= 32 && d->ntap == 1 && d->B == 1 && !(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | SE_EPI_SWISH_GRAD | SE_EPI_STATS)) &&
                (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldr & 3) == 0 && (d->r_off & 3) == 0,
                "gemm: SE_EPI_ROWSTATS needs a row GEMM with N == 64, AUX = [M][2] and a vector-epilogue layout");
+  if (ep & SE_EPI_DELTA)
+    SE_REQUIRE(AUX && R && d->N == 64 && d->C >= 32 && d->ntap == 1 && d->B == 1 &&
+               !(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2 | SE_EPI_SWISH_GRAD | SE_EPI_STATS | SE_EPI_RESID | SE_EPI_ROWSTATS | SE_EPI_ACCUM | 256)) &&
+               (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && d->ldr >= 64 && (d->ldr & 3) == 0 && (d->r_off & 3) == 0,
+               "gemm: SE_EPI_DELTA needs a row GEMM with C >= 32, N == 64, R = O [M][64], AUX = [M][4] and a vector-epilogue layout");
   SE_REQUIRE(!(ep & (SE_EPI_GLU | SE_EPI_SHUFFLE2)) || (d->N % 2) == 0, "gemm: GLU/shuffle need even N");
   SE_REQUIRE(!(ep & SE_EPI_GLU_GATE) || ((ep & SE_EPI_GLU) && AUX), "gemm: SE_EPI_GLU_GATE needs SE_EPI_GLU and AUX");
   if (d->prologue == SE_PRO_LN) SE_REQUIRE(rowstats && pro_scale && pro_shift, "gemm: LN prologue operands");
@@ -1241,7 +1246,6 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     const bool glu_ok = (ep & SE_EPI_GLU) && !(ep & (SE_EPI_STATS | SE_EPI_SHUFFLE2 | SE_EPI_DROP | SE_EPI_RESID | SE_EPI_ACCUM |
                                                        SE_EPI_SWISH_GRAD | 256)) &&
                         (d->N & 7) == 0 && (d->ldc & 3) == 0 && (d->c_off & 3) == 0 && (d->ldx & 3) == 0 && (d->x_off & 3) == 0;
-    static const bool no_panel = getenv("SE_GEMM_NO_PANEL") != nullptr;
     // 1-D maps [B][L][64] (CDiffuSE: To == Ti == 1): the panel also takes batch entries, the SE_EPI_STATS sums (GroupNorm) and
     // three taps along L (scaled split-fp16 only)
     const bool map1d = d->To == 1 && d->Ti == 1 && d->Fi == d->Fo && d->st == 1 && d->sf == 1 && !d->up;
@@ -1251,7 +1255,6 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     const bool tap3 = map1d && d->ntap == 3 && d->dt[0] == 0 && d->dt[1] == 0 && d->dt[2] == 0 && d->precision == 3 && d->w_planes &&
                       d->prologue == SE_PRO_NONE && !(ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) && d->ldw == 192;
     // enough row tiles for a persistent sweep: the W-stationary kernel (weights of a column block resident in LDS)
-    static const bool no_wstat = getenv("SE_GEMM_NO_WSTAT") != nullptr;
     const bool gate = d->prologue == SE_PRO_GATE;
     if (gate)
       SE_REQUIRE(map1d && lin && d->precision == 3 && d->w_planes && d->ldw == 64 && d->C == 64 && d->lda >= 128 && d->ldx >= 128 && (d->ldx & 3) == 0 &&
@@ -1259,10 +1262,9 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
                  !(ep & (SE_EPI_ACCUM | SE_EPI_DROP | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ROWSTATS)),
                  "gemm: SE_PRO_GATE needs a 1-D row GEMM with C = 64, 128-wide A / AUX rows, scaled fp16 weight planes, a static a_sexp");
     if (map1d && (tap3 || (lin && d->precision == 3 && d->w_planes && (d->prologue == SE_PRO_NONE || gate) && d->ldw == 64)) && d->C == 64 && vec_st &&
-        !(ep & (SE_EPI_ACCUM | SE_EPI_DROP | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ROWSTATS)) && ((long)d->B * g.tiles >= 2048 || gate) &&
-        (d->w_planes % 8) == 0 && (!no_wstat || gate)) {
+        !(ep & (SE_EPI_ACCUM | SE_EPI_DROP | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_ROWSTATS | SE_EPI_DELTA)) && ((long)d->B * g.tiles >= 2048 || gate) &&
+        (d->w_planes % 8) == 0) {
       int ngroups = 512 / ncols < 8 ? 8 : 512 / ncols;
-      if (const char* e = getenv("SE_WSTAT_GROUPS")) { int v = atoi(e); if (v >= 8) ngroups = v; }
       if ((long)ngroups > (long)d->B * g.tiles) ngroups = d->B * g.tiles;
       ngroups = (ngroups + 7) / 8 * 8;
       const dim3 wgrid((unsigned)(ncols * ngroups));
@@ -1280,14 +1282,12 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       return se_check_launch("se_gemm_tap(W-stationary 1-D)");
     }
     // token-wise layers of the train step with enough 256-row tiles for every CU: the W-stationary persistent form
-    static const bool no_wstat_lin = getenv("SE_GEMM_NO_WSTAT_LIN") != nullptr;
     if (lin && d->B == 1 && d->C == 64 && ncols >= 2 && d->precision == 3 && d->w_planes && (d->w_planes % 8) == 0 && d->ldw == 64 &&
         (d->prologue == SE_PRO_NONE || d->prologue == SE_PRO_LN) && (vec_ok || glu_ok) &&
-        !(ep & (SE_EPI_ACCUM | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_STATS)) && Mb >= 128 * 1024 && !no_wstat_lin) {      // >= 2 tiles per workgroup
+        !(ep & (SE_EPI_ACCUM | SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_STATS | SE_EPI_DELTA)) && Mb >= 128 * 1024) {      // >= 2 tiles per workgroup
       const size_t shw = (size_t)2 * ncols * 64 * 72 * 2 + (size_t)8 * 32 * 36 * 4 + 128 * 4 + (size_t)ncols * 64 * 4;
       if (shw <= 160 * 1024) {
         int nwg = 256;
-        if (const char* e = getenv("SE_WSTAT_WGS")) { int v = atoi(e); if (v >= 1) nwg = v; }
         if (nwg > (Mb + 255) / 256) nwg = (Mb + 255) / 256;
         static unsigned raised_ws[2] = {0u, 0u};
         if (d->prologue == SE_PRO_LN) {
@@ -1303,14 +1303,14 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
     // one column block (N = 64): the panel form wins only with the dropout-hash prologue (dO = (mask dY) Wo: 99 -> 78 us; the
     // residual + dropout epilogue of to_out is 87 -> 103 us in it)
     if ((lin || tap3) && (d->B == 1 || map1d) && d->C == 64 && (ncols >= 2 || d->prologue == SE_PRO_DROP) && (d->precision >= 1 && d->precision <= 3) && (vec_st || glu_ok) &&
-        !(ep & SE_EPI_ACCUM) && !((ep & SE_EPI_SWISH_GRAD) && (ep & SE_EPI_RESID)) && !no_panel) {
+        !(ep & SE_EPI_ACCUM) && !((ep & SE_EPI_SWISH_GRAD) && (ep & SE_EPI_RESID))) {
       dim3 pgrid((unsigned)(d->B * g.tiles));
       if (tap3) {
         hipLaunchKernelGGL((gemm_k64_panel_kernel<SE_PRO_NONE, 2, false, true, true, 3>), pgrid, block, 0, s, g);
         return se_check_launch("se_gemm_tap(k64 panel, 3 taps)");
       }
       SE_REQUIRE(d->precision != 3 || d->w_planes, "gemm: the scaled split-fp16 row-panel kernel reads pre-split fp16 planes");
-      const bool pre2 = (ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID)) != 0;
+      const bool pre2 = (ep & (SE_EPI_SWISH_GRAD | SE_EPI_RESID | SE_EPI_DELTA)) != 0;
 #define LAUNCHP2(PRO, P2) do { if (d->precision == 3) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2, true, true>), pgrid, block, 0, s, g); \
                           else if (d->precision == 1) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 2, P2>), pgrid, block, 0, s, g); \
                           else if (d->w_planes) hipLaunchKernelGGL((gemm_k64_panel_kernel<PRO, 3, P2, true>), pgrid, block, 0, s, g); \
@@ -1347,10 +1347,9 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
       if (seen != 7) triples = false;
     }
     if (triples) {
-      const int ord = getenv("SE_CONV3_NO_ORD") != nullptr ? 0 : (fwd_order ? 1 : (rev_order ? 2 : 0));
+      const int ord = fwd_order ? 1 : (rev_order ? 2 : 0);
       if (d->precision == 3 && d->w_planes && ord) {      // the train step's shapes: compile-time tap order
-        static const bool mt2o = getenv("SE_CONV3_NO_MT2") == nullptr;
-        if (mt2o && d->C >= 192) {
+        if (d->C >= 192) {
           g.tiles = cdiv(Mb, 256);
           g.nouter = d->B * g.tiles;
           dim3 grid2((unsigned)(ncols * (((long)g.nouter + 7) / 8 * 8)));
@@ -1361,20 +1360,15 @@ extern "C" int se_gemm_tap(const se_gemm_desc* d, const float* A, const float* W
         return se_check_launch("se_gemm_tap(conv3)");
       }
       if (d->precision == 3) {
-        // two planes instead of three leave room for 4 waves per SIMD (115 VGPRs, 33 KB of LDS): 1.5 - 7 % (949 -> 934 us at
-        // Cin = 256, 226 -> 211 us at Cin = 64); SE_CONV3_OCC3=1 restores the 3-wave build for A/B runs
-        static const bool occ4 = getenv("SE_CONV3_OCC3") == nullptr;
-        // 256-row tiles (two row blocks per wave, B fragments shared) pay on the deep layers only: Cin = 256: 959 -> 904 us,
-        // Cin = 64: 197 -> 211 us (tools/microbench.py conv_one); SE_CONV3_NO_MT2=1: always 128-row tiles
-        static const bool mt2 = getenv("SE_CONV3_NO_MT2") == nullptr;
-        if (d->w_planes && mt2 && d->C >= 192) {
+        // (run-time tap order: shapes outside the two compile-time orders) two planes instead of three leave room for 4 waves per SIMD
+        // (115 VGPRs, 33 KB of LDS); 256-row tiles (two row blocks per wave, B fragments shared) pay on the deep layers only
+        if (d->w_planes && d->C >= 192) {
           g.tiles = cdiv(Mb, 256);
           g.nouter = d->B * g.tiles;
           dim3 grid2((unsigned)(ncols * (((long)g.nouter + 7) / 8 * 8)));
           hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 2, 2>), grid2, block, 0, s, g);
         }
-        else if (d->w_planes && occ4) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 4>), grid, block, 0, s, g);
-        else if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true>), grid, block, 0, s, g);
+        else if (d->w_planes) hipLaunchKernelGGL((conv3_bf16_kernel<2, true, true, 4>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((conv3_bf16_kernel<2, false, true>), grid, block, 0, s, g);
       }
       else if (d->precision == 1) hipLaunchKernelGGL((conv3_bf16_kernel<2>), grid, block, 0, s, g);

@@ -152,7 +152,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
                                                          float* vmax_defer = nullptr) {   // persistent callers: see below
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int Mb = d.To * d.Fo, ep = NOLOAD ? (d.epilogue & ~(SE_EPI_ACCUM | SE_EPI_RESID | SE_EPI_SWISH_GRAD)) : d.epilogue;
+  const int Mb = d.To * d.Fo, ep = NOLOAD ? (d.epilogue & ~(SE_EPI_ACCUM | SE_EPI_RESID | SE_EPI_SWISH_GRAD | SE_EPI_DELTA)) : d.epilogue;
   const long ptile = (long)b * Mb + m0;
   float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
   const float* __restrict__ Xb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;
@@ -185,7 +185,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
       }
       // ... and likewise the residual when it was not fetched before the K loop
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
-      const bool res_here = HOISTR && !HASPRE && (ep & SE_EPI_RESID) != 0;
+      const bool res_here = HOISTR && !HASPRE && (ep & (SE_EPI_RESID | SE_EPI_DELTA)) != 0;      // (DELTA: R = the attention output O)
       if (res_here) {
         const unsigned rb = (unsigned)(wave * 32 + rr), co = (unsigned)n;
         if (m0 + (int)rb < Mb) r0 = *reinterpret_cast<const float4*>(Rb + (rb * (unsigned)d.ldr + co));
@@ -225,6 +225,15 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
 #ifdef SE_EPI_ONE_PHASE      // (A/B builds: the store inside the first loop, as before)
         *reinterpret_cast<float4*>(Yb + ((unsigned)row * (unsigned)d.ldc + (unsigned)n)) = v;
 #endif
+        if (ep & SE_EPI_DELTA) {
+          // softmax-backward row constant of the attention backward, delta[row][head] = sum over the head's 16 columns of dO * O, where
+          // dO is THIS result (to_out input gradient): the 4 lanes cq = 4 h' .. 4 h' + 3 hold a head's columns (N == 64, host-checked)
+          const float4 ov = HASPRE ? pre[nt * 4 + i] : (i == 0 ? r0 : (i == 1 ? r1 : (i == 2 ? r2 : r3)));
+          float dl = v.x * ov.x + v.y * ov.y + v.z * ov.z + v.w * ov.w;
+          dl += __shfl_xor(dl, 1, 64);
+          dl += __shfl_xor(dl, 2, 64);
+          if ((cq & 3) == 0) g.AUX[(ptile + row) * 4 + nt * 2 + (cq >> 2)] = dl;
+        }
         if (i == 0) v0 = v; else if (i == 1) v1 = v; else if (i == 2) v2 = v; else v3 = v;
         if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         if (rowstats) kept[nt][i] = v;

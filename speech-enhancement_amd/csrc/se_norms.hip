@@ -408,168 +408,6 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_apply_kernel(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// InstanceNorm(affine) + PReLU backward in ONE pass over HBM (round 4).  The two-pass form reads (X, dY) twice: 5 plane passes.  Here
-// a workgroup keeps its K x 256 float4 pairs of (x-hat, du) in registers between the reduction and the apply step: 3 plane passes.
-// The grid is at most the 512 workgroups that are resident at once (2 per CU at <= 256 VGPRs); it walks the batch in `rounds` rounds
-// of E entries, G = grid / E workgroups per entry.  Between the two steps the G workgroups of an entry meet at a counter.  That
-// wait is BOUNDED (spin_ticks of the 100 MHz s_memtime clock): a workgroup whose entry is not complete in time (another kernel
-// holds part of the chip, a second process shares it) flags its tile as deferred and moves on; the follow-up launch
-// (CLEANUP = true, always issued, normally 512 flag reads) re-reads exactly the flagged tiles and applies them from the then
-// complete sums, and workgroup 0 of it adds the parameter gradients.  No co-residency assumption is needed for correctness and
-// no wave waits without a deadline.
-//   hand-off: the sums are fp64 agent-scope atomics (performed at the memory side, never cached in an XCD's L2) and are read back
-//   with 8-byte agent-scope atomic loads; the arrival counter is an agent-scope atomic add behind every wave's vmcnt(0) and a
-//   workgroup barrier, polled by lane 0 with relaxed agent loads, followed by an agent acquire and a workgroup barrier
-//   (MI355X_MICROARCH.md, "Valid forms": {8-B agent atomics both sides} + the Consumer bullet).
-constexpr int INF_SLOTS = 512, INF_MAXR = 16;
-
-template <int K, bool CLEANUP>
-__global__ __launch_bounds__(256, 2) void inorm_prelu_bwd_fused_kernel(
-    const float* __restrict__ X, int ldx, int x_off, const float* __restrict__ mr, const float* __restrict__ g,
-    const float* __restrict__ beta, const float* __restrict__ slope, const float* __restrict__ dY, int ldy, int y_off,
-    double* red, float* __restrict__ dX, int lddx, int dx_off, long P, int C, double count, float* amax_out,
-    int B, int E, int G, int rounds, unsigned* cnt, unsigned* deferred, long spin_ticks, float* dg, float* dbeta, float* dslope) {
-  ChanIter it(C);
-  const int tid = threadIdx.x, wg = blockIdx.x;
-  if (CLEANUP && wg == 0 && tid < C) {            // parameter gradients: every sum is complete once the main launch has ended
-    double s1 = 0, s2 = 0, s3 = 0;
-    for (int k = 0; k < B; ++k) { s1 += red[((long)k * C + tid) * 3]; s2 += red[((long)k * C + tid) * 3 + 1]; s3 += red[((long)k * C + tid) * 3 + 2]; }
-    dg[tid] += (float)s2;
-    dbeta[tid] += (float)s1;
-    if (dslope) dslope[tid] += (float)s3;
-  }
-  const int eg = wg / G, gi = wg - eg * G;
-  if (eg >= E) return;                             // (grid = E * G: never taken; kept for a caller that rounds the grid up)
-  __shared__ float m1s[256], m2s[256];
-  __shared__ int flag;
-  float gg[4], bt[4], sl[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const int c = it.q * 4 + j; gg[j] = g[c]; bt[j] = beta[c]; sl[j] = slope ? slope[c] : 1.f; }
-  float amx = 0.f;
-  const long pbase = (long)gi * it.psub * K + it.sub;       // (< 2^31: P * ld * 4 < 2^32 is host-checked)
-  for (int r = 0; r < rounds; ++r) {
-    const int b = r * E + eg;
-    if (b >= B) break;
-    if (CLEANUP) {
-      if (tid == 0) flag = (int)deferred[(long)r * gridDim.x + wg];
-      __syncthreads();
-      const int f = flag;
-      __syncthreads();
-      if (!f) continue;
-    }
-    float mean[4], rstd[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int c = it.q * 4 + j; mean[j] = mr[((long)b * C + c) * 2]; rstd[j] = mr[((long)b * C + c) * 2 + 1]; }
-    // one descriptor per entry and tensor, 32-bit byte offsets: a pixel past the entry (or past this workgroup's run) reads zeros
-    // and is not stored -- no per-line 64-bit addresses or predicates stay live across the wait
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc_(X + (long)b * P * ldx, (unsigned)(P * ldx * 4));
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc_(dY + (long)b * P * ldy, (unsigned)(P * ldy * 4));
-    const __amdgpu_buffer_rsrc_t ro = make_rsrc_(dX + (long)b * P * lddx, (unsigned)(P * lddx * 4));
-    // the per-line byte offsets are the same in every round: behind an opaque copy of their base the compiler computes them next to
-    // each load / store instead of hoisting 3 K of them out of the round loop (K = 16 spilled 70 registers that way)
-    int rem = (int)(P - pbase);                    // line k is inside the entry iff k * psub < rem
-    unsigned ox = ((unsigned)pbase * (unsigned)ldx + (unsigned)(x_off + it.q * 4)) * 4u;
-    unsigned od = ((unsigned)pbase * (unsigned)ldy + (unsigned)(y_off + it.q * 4)) * 4u;
-    asm volatile("" : "+v"(rem), "+v"(ox), "+v"(od));
-    float4 v[K], d[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const bool ok = k * it.psub < rem;
-      v[k] = buf_load4_(rx, ok ? ox + (unsigned)(k * it.psub * ldx * 4) : BUF_OOB_);
-      d[k] = buf_load4_(rd, ok ? od + (unsigned)(k * it.psub * ldy * 4) : BUF_OOB_);
-    }
-    float acc[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-    for (int k = 0; k < K; ++k) {                  // (x, dy) -> (x-hat, du) in place
-      float x[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, dy[4] = {d[k].x, d[k].y, d[k].z, d[k].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xh = (x[j] - mean[j]) * rstd[j];
-        const float u = xh * gg[j] + bt[j];
-        const float dyj = dy[j];                   // (0 past the entry)
-        const float du = u >= 0.f ? dyj : dyj * sl[j];
-        acc[0][j] += du; acc[1][j] += du * xh;
-        acc[2][j] += u >= 0.f ? 0.f : dyj * u;
-        x[j] = xh; dy[j] = du;
-      }
-      v[k] = make_float4(x[0], x[1], x[2], x[3]);
-      d[k] = make_float4(dy[0], dy[1], dy[2], dy[3]);
-    }
-    if (!CLEANUP) {
-      block_reduce_atomic_d<3>(acc, it, C, red + (long)b * C * 3);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's atomics have been performed
-      __syncthreads();
-      if (tid == 0) {
-        __hip_atomic_fetch_add(&cnt[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long t0 = (long)__builtin_amdgcn_s_memtime();
-        int ok = 0;
-        for (;;) {
-          if (__hip_atomic_load(&cnt[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)G) { ok = 1; break; }
-          if ((long)__builtin_amdgcn_s_memtime() - t0 > spin_ticks) break;
-          __builtin_amdgcn_s_sleep(4);
-        }
-        if (ok) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-          deferred[(long)r * gridDim.x + wg] = 1u;           // read by the follow-up launch
-        }
-        flag = ok;
-      }
-      __syncthreads();
-      const int f = flag;
-      if (!f) { __syncthreads(); continue; }
-    }
-    if (tid < C) {
-      m1s[tid] = (float)(__hip_atomic_load(&red[((long)b * C + tid) * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / count);
-      m2s[tid] = (float)(__hip_atomic_load(&red[((long)b * C + tid) * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / count);
-    }
-    __syncthreads();
-    float m1[4], m2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { m1[j] = m1s[it.q * 4 + j]; m2[j] = m2s[it.q * 4 + j]; }
-    int rem2 = (int)(P - pbase);
-    unsigned oo = ((unsigned)pbase * (unsigned)lddx + (unsigned)(dx_off + it.q * 4)) * 4u;
-    asm volatile("" : "+v"(rem2), "+v"(oo));
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const float xh[4] = {v[k].x, v[k].y, v[k].z, v[k].w}, du[4] = {d[k].x, d[k].y, d[k].z, d[k].w};
-      const bool ok = k * it.psub < rem2;
-      float o[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = ok ? rstd[j] * gg[j] * (du[j] - m1[j] - xh[j] * m2[j]) : 0.f;
-      buf_store4_(ro, ok ? oo + (unsigned)(k * it.psub * lddx * 4) : BUF_OOB_, make_float4(o[0], o[1], o[2], o[3]));
-      asm volatile("" ::: "memory");               // keep the K results from being computed ahead of their stores (64 more live registers)
-      amx = fmaxf(fmaxf(amx, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
-    }
-    __syncthreads();                               // m1s / m2s / flag are rewritten in the next round
-  }
-  if (amax_out) {
-    amx = wave_max(amx);
-    if ((tid & 63) == 0) amax_raise_(amax_out, amx);
-  }
-}
-
-// (rounds, E, G, K) of the one-pass kernel for (B, P, C); K = 0: does not fit (the two-pass kernels take it)
-struct InfPlan { int rounds, E, G, K; };
-static InfPlan inf_plan(int B, long P, int C) {
-  InfPlan best = {0, 0, 0, 0};
-  if (C < 4 || C > 256 || (C % 4) || (256 % (C / 4))) return best;
-  const int psub = 256 / (C / 4);
-  long bestcost = -1;
-  for (int E = 1; E <= B && E <= INF_SLOTS; ++E) {
-    const int rounds = (B + E - 1) / E;
-    if (rounds > INF_MAXR) continue;
-    const int G = INF_SLOTS / E;
-    const long need = (P + (long)G * psub - 1) / ((long)G * psub);
-    if (need > 16) continue;                       // (K = 24 spills: 168 registers of tile + the transform's temporaries)
-    const int K = need <= 4 ? 4 : need <= 8 ? 8 : 16;
-    const long cost = (long)rounds * (K + 3);
-    if (bestcost < 0 || cost < bestcost) { bestcost = cost; best = {rounds, E, G, K}; }
-  }
-  return best;
-}
 
 // parameter gradients from the reduced sums: dg[c] += sum_b S2, dbeta[c] += sum_b S1, dslope[c] += sum_b S3
 __global__ void norm_param_grad_kernel(const double* red, float* dg, float* dbeta, float* dslope, int nb, int C) {
@@ -690,51 +528,6 @@ extern "C" int se_inorm_prelu_fwd_amax(const float* X, int ldx, int x_off, const
   hipLaunchKernelGGL(inorm_prelu_fwd_kernel, dim3((int)nb, B), dim3(256), 0, as_stream(stream), X, ldx, x_off, stats, g, beta,
                      slope, Y, ldy, y_off, mr, P, C, count, eps, amax_out);
   return se_check_launch("se_inorm_prelu_fwd");
-}
-
-extern "C" int se_inorm_prelu_bwd_fused_fits(int B, long P, int C) { return B > 0 && P > 0 && inf_plan(B, P, C).K > 0; }
-extern "C" size_t se_inorm_prelu_bwd_fused_workspace_bytes(int B, int C) {
-  return (B > 0 && C > 0) ? (size_t)B * C * 3 * sizeof(double) + ((size_t)((B + 3) / 4 * 4) + (size_t)INF_MAXR * INF_SLOTS) * sizeof(unsigned) : 0;
-}
-
-template <int K>
-static void inf_launch(const InfPlan& pl, hipStream_t s, const float* X, int ldx, int x_off, const float* mr, const float* g, const float* beta,
-                       const float* slope, const float* dY, int ldy, int y_off, double* red, float* dX, int lddx, int dx_off, long P, int C,
-                       double count, float* amax_out, int B, unsigned* cnt, unsigned* deferred, long spin, float* dg, float* dbeta, float* dslope) {
-  hipLaunchKernelGGL((inorm_prelu_bwd_fused_kernel<K, false>), dim3(pl.E * pl.G), dim3(256), 0, s, X, ldx, x_off, mr, g, beta, slope, dY, ldy,
-                     y_off, red, dX, lddx, dx_off, P, C, count, amax_out, B, pl.E, pl.G, pl.rounds, cnt, deferred, spin, dg, dbeta, dslope);
-  hipLaunchKernelGGL((inorm_prelu_bwd_fused_kernel<K, true>), dim3(pl.E * pl.G), dim3(256), 0, s, X, ldx, x_off, mr, g, beta, slope, dY, ldy,
-                     y_off, red, dX, lddx, dx_off, P, C, count, amax_out, B, pl.E, pl.G, pl.rounds, cnt, deferred, spin, dg, dbeta, dslope);
-}
-
-// ws: se_inorm_prelu_bwd_fused_workspace_bytes(B, C) bytes, ZERO-FILLED by the caller (sums, arrival counters, deferred flags);
-// spin_us: deadline of the in-kernel wait (0: every workgroup but the last of an entry defers -- the test of the follow-up path)
-extern "C" int se_inorm_prelu_bwd_fused(const float* X, int ldx, int x_off, const float* mr, const float* g, const float* beta,
-                                        const float* slope, const float* dY, int ldy, int y_off, void* ws, float* dX, int lddx,
-                                        int dx_off, float* dg, float* dbeta, float* dslope, int B, long P, int C, double count,
-                                        int spin_us, float* amax_out, void* stream) {
-  SE_REQUIRE(X && mr && g && beta && dY && ws && dX && dg && dbeta && B > 0 && P > 0 && count > 0 && chan_ok(C) && spin_us >= 0,
-             "inorm_prelu_bwd_fused: bad arguments (C=%d)", C);
-  SE_REQUIRE((ldx % 4) == 0 && (x_off % 4) == 0 && (ldy % 4) == 0 && (y_off % 4) == 0 && (lddx % 4) == 0 && (dx_off % 4) == 0,
-             "inorm_prelu_bwd_fused: alignment");
-  const InfPlan pl = inf_plan(B, P, C);
-  SE_REQUIRE(P * (long)ldx * 4 < (1L << 32) - 64 && P * (long)ldy * 4 < (1L << 32) - 64 && P * (long)lddx * 4 < (1L << 32) - 64,
-             "inorm_prelu_bwd_fused: an entry must stay below 4 GiB (P=%ld)", P);
-  SE_REQUIRE(pl.K > 0, "inorm_prelu_bwd_fused: (B=%d, P=%ld, C=%d) does not fit the resident grid (se_inorm_prelu_bwd_fused_fits)", B, P, C);
-  double* red = reinterpret_cast<double*>(ws);
-  unsigned* cnt = reinterpret_cast<unsigned*>(red + (size_t)B * C * 3);
-  unsigned* deferred = cnt + (B + 3) / 4 * 4;
-  const long spin = (long)spin_us * 100;
-  hipStream_t s = as_stream(stream);
-#define SE_INF_GO(KK) inf_launch<KK>(pl, s, X, ldx, x_off, mr, g, beta, slope, dY, ldy, y_off, red, dX, lddx, dx_off, P, C, count, amax_out, B, \
-                                     cnt, deferred, spin, dg, dbeta, dslope)
-  switch (pl.K) {
-    case 4: SE_INF_GO(4); break;
-    case 8: SE_INF_GO(8); break;
-    default: SE_INF_GO(16); break;
-  }
-#undef SE_INF_GO
-  return se_check_launch("se_inorm_prelu_bwd_fused");
 }
 
 extern "C" int se_norm_prelu_bwd(const float* X, int ldx, int x_off, const float* mr, const float* g,

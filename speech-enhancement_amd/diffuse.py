@@ -306,7 +306,7 @@ def predict(model, config, noisy_signal, alpha, beta, alpha_cum, sigmas, T, c1, 
     # Clips never interact (GroupNorm is per sample), so the batch can be cut into `streams` independent parts, each stepping
     # through the whole reverse process on its own HIP stream.  Measured at batch 32 (tools/bench_diffuse.py) on two boxes:
     # 17.65 / 17.61 / 16.9 and 16.6 / 18.0 / 17.0 utt/s for 1 / 2 / 3 parts -- two parts are never slower: the default.
-    nparts = max(1, min(int(streams if streams is not None else os.environ.get('SE_DIFFUSE_STREAMS', '2')), B // 4 or 1))
+    nparts = max(1, min(int(streams if streams is not None else 2), B // 4 or 1))
     cuts = [B * i // nparts for i in range(nparts + 1)]
     parts = [slice(cuts[i], cuts[i + 1]) for i in range(nparts)]
     main = torch.cuda.current_stream(device)

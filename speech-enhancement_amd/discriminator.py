@@ -19,10 +19,10 @@ from . import layers as LY
 from . import ops as O
 
 # arithmetic of the 4x4 stride-2 convolutions with >= 32 input channels (forward, input gradients): 2 = exact three-way bf16 split, six
-# products (fp32-equivalent, the generic split kernel: K = 16 taps x C >= 512); 0 = fp32 MFMA (SE_D_PRECISION=0: A/B switch)
-D_PRECISION = int(__import__('os').environ.get('SE_D_PRECISION', '2'))
-CLASS_DGRAD = __import__('os').environ.get('SE_NO_CLASS_DGRAD') != '1'      # A/B switch: the input gradients through the `up`-mode tap GEMM
-THIN_CONV1 = __import__('os').environ.get('SE_NO_THIN_CONV1') != '1'      # A/B switch: the first stage through the tap GEMM again
+# products (fp32-equivalent, the generic split kernel: K = 16 taps x C >= 512); 0 = fp32 MFMA (module switches for A/B runs)
+D_PRECISION = 2
+CLASS_DGRAD = True      # A/B switch: the input gradients through the `up`-mode tap GEMM
+THIN_CONV1 = True      # A/B switch: the first stage through the tap GEMM again
 
 # weight index (kh over F, kw over T)  ->  tap offset on the [T, F] grid
 D_TAPS = [(kw - 1, kh - 1) for kh in range(4) for kw in range(4)]

@@ -46,7 +46,7 @@ def make_desc(B, To, Fo, Ti, Fi, taps, C_in, lda, N, ldc, a_off=0, c_off=0, ldw=
 # maximum their producer measured): fp32-equivalent like bf16x6 at half the MFMAs.  Calls without those scales (plain fp32
 # weights, e.g. direct layer calls in tests) run the six-product kernels.
 LINEAR_PRECISION = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2, 'f16x3': 3}[__import__('os').environ.get('SE_LINEAR_PRECISION', 'f16x3')]
-WGRAD_LINEAR_PRECISION = {'f32': 0, 'bf16x6': 2, 'f16x3': 3}[__import__('os').environ.get('SE_WGRAD_LINEAR_PRECISION', 'f16x3')]
+WGRAD_LINEAR_PRECISION = {'f32': 0, 'bf16x3': 2, 'bf16x6': 2, 'f16x3': 3}[__import__('os').environ.get('SE_WGRAD_PRECISION', 'f16x3')]      # (token-wise weight gradients: the convolutions' switch)
 LN_SEXP = 6        # LayerNorm(64) outputs: |x| <= 7.94 |gamma| + |beta|; 2^6 keeps |x| < 1023 below the fp16 maximum
 HID_SEXP = 3       # Swish(H) * dropout mask (FF hidden activations): |x| < 8191
 
@@ -324,85 +324,41 @@ def unpack_conv_wgrad(dwp, dw, rev_slabs=False, accumulate=False):
                   accumulate=accumulate)
 
 
-# SE_FF_RECOMPUTE=1 (opt-in): the scaled-fp16 feed-forward module stores no H and writes no dZ -- backward and weight gradients
-# recompute them from X and dY (ff_bwd_rc / ff_wgrad_rc: 0.94 GB instead of 3.6 GB of HBM traffic per module at 518 736 rows,
-# 17 GB less saved state per step at batch 16).  Measured on MI355X it is NOT faster: forward 3.76 -> 3.14 ms per step, backward
-# 4.84 -> 4.75, but the fused recomputing weight gradient takes 8.6 ms against 5.2 ms for the two whole-gradient kernels it
-# replaces (twice their matrix work, VALU- and barrier-bound at one 8-wave workgroup per CU): 77.0 vs 76.3 ms per step.
-FF_RECOMPUTE = __import__('os').environ.get('SE_FF_RECOMPUTE') == '1'
-
-
-def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, precision=None, hid=None,
-           out_stats=False, store_h=True, in_bound=None, mid_bound=None):
-    """fused Scale(alpha, PreNorm(FeedForward)) forward (csrc/se_gemm.hip: ff_fwd_kernel): returns (Y, H) with
-    H = W1 LN(x) + b1 kept for the backward."""
+def ff_fwd(x, rowstats, gamma, beta, W1, b1, W2, b2, drop_p=0.0, seed_h=0, seed_o=0, alpha=0.5, out_stats=False, store_h=True,
+           in_bound=None, mid_bound=None):
+    """fused Scale(alpha, PreNorm(FeedForward)) forward on scaled fp16 weight planes (csrc/se_ff.hip): returns (Y, H); store_h=False
+    (the default path of the train step): the W-stationary kernel, H = W1 LN(x) + b1 is not stored (H = None) -- ff_bwd_fused
+    recomputes it; store_h=True: H [M, hid] is written for ff_bwd_dgrad (the cross-check path)."""
     L.check_cuda(x, rowstats, gamma, beta, W1, b1, W2, b2)
-    pl = W1.dtype in (torch.bfloat16, torch.float16)   # pre-split planes [3|2][hid][64] / [3|2][64][hid] (weights.WeightPlan)
-    if W1.dtype != W2.dtype:
-        raise L.SeHipError('ff_fwd: W1 and W2 must both be fp32 or both pre-split planes of one kind')
-    f16 = W1.dtype == torch.float16
-    M, hid = x.shape[0], (hid or W1.shape[-2])
-    # store_h=False (scaled fp16 planes only): H is not written -- the recomputing backward (ff_bwd_rc / ff_wgrad_rc) needs none
-    H = torch.empty(M, hid, device=x.device, dtype=torch.float32) if (store_h or not f16) else None
+    if W1.dtype != torch.float16 or W2.dtype != torch.float16:
+        raise L.SeHipError('ff_fwd: needs the scaled fp16 weight planes of a WeightPlan (fp32 weights: the unfused GEMM path)')
+    M, hid = x.shape[0], W1.shape[-2]
+    H = torch.empty(M, hid, device=x.device, dtype=torch.float32) if store_h else None
     Y = torch.empty(M, 64, device=x.device, dtype=torch.float32)
-    prec = (3 if f16 else min(LINEAR_PRECISION, 2)) if precision is None else precision
     ost = torch.empty(M, 2, device=x.device, dtype=torch.float32) if out_stats else None     # (mean, rstd) of the rows of Y
     # in_bound / mid_bound: device scalars >= max |LN(x)| / max |Swish(H) mask / keep| (proven from the current parameters:
     # weights.WeightPlan.run_bounds); without them the static exponents LN_SEXP / HID_SEXP
     if mid_bound is not None and drop_p > 0.5:
         raise L.SeHipError('ff_fwd: the hidden-activation bound assumes a dropout keep probability >= 1/2')
     sc = L.F16Scales(in_bound.data_ptr() if in_bound is not None else None, LN_SEXP, HID_SEXP, W1._se_amax.data_ptr(),
-                     W2._se_amax.data_ptr(), None, mid_bound.data_ptr() if mid_bound is not None else None) if f16 else None
+                     W2._se_amax.data_ptr(), None, mid_bound.data_ptr() if mid_bound is not None else None)
     L.call('se_ff_fwd_f16', L.ptr(x), L.ptr(rowstats), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2), L.ptr(b2),
            L.ptr(H), L.ptr(Y), L.ptr(ost), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF),
-           C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(prec | (16 if pl else 0)), C.byref(sc) if f16 else None,
-           L.stream(), _key='ff_fwd_f16x3' if f16 else f'ff_fwd_bf16x{3 if prec == 1 else 6}', _flops=4.0 * M * 64 * hid,
-           _bytes=4.0 * M * (128 + (hid if H is not None else 0)))
+           C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), C.c_int(3 | 16), C.byref(sc), L.stream(), _key='ff_fwd_f16x3',
+           _flops=4.0 * M * 64 * hid, _bytes=4.0 * M * (128 + (hid if H is not None else 0)))
     if out_stats:
         return Y, H, ost
     return Y, H
 
 
-def ff_bwd_rc(dy, x, st, gamma, beta, W1, b1, W2T_scaled, W1T, drop_p, seed_h, seed_o, dR2, dgamma, dbeta, out_amax=None):
-    """RECOMPUTING backward of the fused feed-forward module (csrc/se_ff.hip: ff_bwd_rc_kernel; scaled fp16 planes only):
-    dx = dy + dR2 + LNbwd(dZ W1) with H and dZ recomputed from x -- no [M, hid] tensor is read or written."""
-    L.check_cuda(dy, x, st, W1, W2T_scaled, W1T)
-    dy_amax = getattr(dy, '_se_amax', None)
-    if dy_amax is None or W1.dtype != torch.float16:
-        raise L.SeHipError('ff_bwd_rc: needs scaled fp16 weight planes and the measured maximum of dy (dy._se_amax)')
-    M, hid = x.shape[0], W1.shape[-2]
-    dx = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
-    dx._se_amax = out_amax
-    L.call('se_ff_bwd_rc', L.ptr(dy), L.ptr(x), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(W1), L.ptr(b1), L.ptr(W2T_scaled),
-           L.ptr(W1T), C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF),
-           L.ptr(dR2), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dy_amax), L.ptr(W1._se_amax), L.ptr(W2T_scaled._se_amax),
-           L.ptr(W1T._se_amax), L.ptr(out_amax), C.c_int(LN_SEXP), L.stream(), _key='ff_bwd_rc_f16x3', _flops=6.0 * M * 64 * hid,
-           _bytes=4.0 * M * (64 * (4 if dR2 is not None else 3)))
-    return dx
-
-
-def ff_wgrad_rc(x, st, gamma, beta, dy, W1, b1, W2T_scaled, dW1, db1, dW2, db2, drop_p, seed_h, seed_o, alpha=0.5):
-    """RECOMPUTING weight gradients of the module (ff_wgrad_rc_kernel): dW1, db1, dW2, db2 accumulated from x and dy alone."""
-    L.check_cuda(x, st, dy, W1, W2T_scaled, dW1, db1, dW2, db2)
-    dy_amax = getattr(dy, '_se_amax', None)
-    if dy_amax is None or W1.dtype != torch.float16:
-        raise L.SeHipError('ff_wgrad_rc: needs scaled fp16 weight planes and the measured maximum of dy (dy._se_amax)')
-    M, hid = x.shape[0], W1.shape[-2]
-    L.call('se_ff_wgrad_rc', L.ptr(x), L.ptr(st), L.ptr(gamma), L.ptr(beta), L.ptr(dy), L.ptr(W1), L.ptr(b1), L.ptr(W2T_scaled),
-           L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), C.c_long(M), C.c_int(hid), C.c_float(drop_p),
-           C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), L.ptr(dy_amax), L.ptr(W1._se_amax),
-           L.ptr(W2T_scaled._se_amax), C.c_int(LN_SEXP), C.c_int(HID_SEXP), L.stream(), _key='ff_wgrad_rc_f16x3',
-           _flops=8.0 * M * 64 * hid, _bytes=4.0 * M * 128)
-
-
 # The fused backward (csrc/se_ff_fused.hip; default with scaled fp16 planes): ONE persistent launch for dX, dgamma / dbeta AND the four
-# weight gradients of the module -- H, S and dZ exist on chip only.  SE_FF_FUSED=0: the stored-H kernels (ff_bwd_dgrad + two
-# whole-gradient launches) again; SE_FF_RECOMPUTE=1 with SE_FF_FUSED=0: the two recomputing kernels of round 3.
+# weight gradients of the module -- H, S and dZ exist on chip only.  SE_FF_FUSED=0: the stored-H kernels (the forward writes H,
+# ff_bwd_dgrad + two whole-gradient launches) -- the cross-check path of the fused kernels.
 FF_FUSED = __import__('os').environ.get('SE_FF_FUSED', '1') != '0'
 
 
 def ff_bwd_fused(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2, dgamma, dbeta, drop_p=0.0, seed_h=0, seed_o=0,
-                 alpha=0.5, dR2=None, out_amax=None, in_bound=None, mid_bound=None, W1T=None):
+                 alpha=0.5, dR2=None, out_amax=None, in_bound=None, mid_bound=None):
     """dx = dy + dR2 + LNbwd(dZ W1) and dW1 / db1 / dW2 / db2 / dgamma / dbeta accumulated, from x and dy alone (se_ff_bwd_fused)."""
     L.check_cuda(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2, dgamma, dbeta, dR2)
     dy_amax = getattr(dy, '_se_amax', None)
@@ -415,38 +371,30 @@ def ff_bwd_fused(dy, x, st, gamma, beta, W1, b1, W2T_scaled, dW1, db1, dW2, db2,
            L.ptr(dR2), L.ptr(dx), L.ptr(dgamma), L.ptr(dbeta), L.ptr(dW1), L.ptr(db1), L.ptr(dW2), L.ptr(db2), C.c_long(M), C.c_int(hid),
            C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF), C.c_float(alpha), L.ptr(dy_amax),
            L.ptr(W1._se_amax), L.ptr(W2T_scaled._se_amax), L.ptr(in_bound), C.c_int(LN_SEXP), L.ptr(mid_bound), C.c_int(HID_SEXP),
-           L.ptr(out_amax), L.ptr(W1T), L.ptr(W1T._se_amax if W1T is not None else None), L.stream(), _key='ff_bwd_fused_f16x3',
-           _flops=10.0 * M * 64 * hid,
+           L.ptr(out_amax), L.stream(), _key='ff_bwd_fused_f16x3',
+           _flops=8.0 * M * 64 * hid,      # algorithmic: dZ chain 2 GEMMs + 2 weight gradients (the recomputed H = W1 LN(x) is not counted)
            _bytes=4.0 * M * 64 * (4 if dR2 is not None else 3))
     return dx
 
 
-def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, precision=None, ln=None, amax_out=(None, None)):
-    """fused dgrad chain of the feed-forward module (ff_bwd_kernel): returns (dZ [M, hid], dLN [M, 64]); with
-    ln = (x, rowstats, gamma, dR2 or None, dgamma, dbeta) the LayerNorm backward is applied in the same kernel and the
-    second result is dX = dy + dR2 + LNbwd(dLN).  amax_out = (zero-filled scalars for max |dX|, max |dZ|): required with scaled
-    fp16 weight planes (they travel with the results as ._se_amax)."""
+def ff_bwd_dgrad(dy, H, W2T_scaled, W1T, drop_p=0.0, seed_h=0, seed_o=0, ln=None, amax_out=(None, None)):
+    """dgrad chain of the feed-forward module from a stored H (ff_bwd_kernel; scaled fp16 planes; the cross-check path of
+    ff_bwd_fused): returns (dZ [M, hid], dLN [M, 64]); with ln = (x, rowstats, gamma, dR2 or None, dgamma, dbeta) the LayerNorm
+    backward is applied in the same kernel and the second result is dX = dy + dR2 + LNbwd(dLN).  amax_out = (zero-filled scalars
+    for max |dX|, max |dZ|): they travel with the results as ._se_amax."""
     L.check_cuda(dy, H, W2T_scaled, W1T)
     M, hid = H.shape
     dZ = torch.empty(M, hid, device=dy.device, dtype=torch.float32)
     out = torch.empty(M, 64, device=dy.device, dtype=torch.float32)
-    pl = W2T_scaled.dtype in (torch.bfloat16, torch.float16)
-    if W2T_scaled.dtype != W1T.dtype:
-        raise L.SeHipError('ff_bwd_dgrad: W2T and W1T must both be fp32 or both pre-split planes of one kind')
-    f16 = W1T.dtype == torch.float16
-    prec = (3 if f16 else min(LINEAR_PRECISION, 2)) if precision is None else precision
+    dy_amax = getattr(dy, '_se_amax', None)
+    if W2T_scaled.dtype != torch.float16 or W1T.dtype != torch.float16 or dy_amax is None:
+        raise L.SeHipError('ff_bwd_dgrad: needs scaled fp16 weight planes and the measured maximum of dy (dy._se_amax)')
     x, st, g, dR2, dg, db = ln if ln is not None else (None,) * 6
-    sc = None
-    if f16:        # dY scaled by its measured maximum (dy._se_amax, raised by the kernel that produced dy); max |dX| / |dZ| out
-        dy_amax = getattr(dy, '_se_amax', None)
-        if dy_amax is None:
-            raise L.SeHipError('ff_bwd_dgrad: scaled fp16 weight planes need the measured maximum of dy (dy._se_amax)')
-        out._se_amax, dZ._se_amax = amax_out
-        sc = L.F16Scales(dy_amax.data_ptr(), 0, 0, W2T_scaled._se_amax.data_ptr(), W1T._se_amax.data_ptr(),
-                         out._se_amax.data_ptr(), dZ._se_amax.data_ptr())
+    out._se_amax, dZ._se_amax = amax_out
+    sc = L.F16Scales(dy_amax.data_ptr(), 0, 0, W2T_scaled._se_amax.data_ptr(), W1T._se_amax.data_ptr(),
+                     out._se_amax.data_ptr(), dZ._se_amax.data_ptr())
     L.call('se_ff_bwd_dgrad_f16', L.ptr(dy), L.ptr(H), L.ptr(W2T_scaled), L.ptr(W1T), L.ptr(dZ), L.ptr(None if ln else out),
            C.c_long(M), C.c_int(hid), C.c_float(drop_p), C.c_uint(seed_h & 0xFFFFFFFF), C.c_uint(seed_o & 0xFFFFFFFF),
-           C.c_int(prec | (16 if pl else 0)), L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dR2), L.ptr(out if ln else None), L.ptr(dg), L.ptr(db),
-           C.byref(sc) if f16 else None, L.stream(), _key='ff_bwd_dgrad_f16x3' if f16 else f'ff_bwd_dgrad_bf16x{3 if prec == 1 else 6}',
-           _flops=4.0 * M * 64 * hid, _bytes=4.0 * M * (128 + 2 * hid + (128 if ln else 0)))
+           C.c_int(3 | 16), L.ptr(x), L.ptr(st), L.ptr(g), L.ptr(dR2), L.ptr(out if ln else None), L.ptr(dg), L.ptr(db),
+           C.byref(sc), L.stream(), _key='ff_bwd_dgrad_f16x3', _flops=4.0 * M * 64 * hid, _bytes=4.0 * M * (128 + 2 * hid + (128 if ln else 0)))
     return dZ, out

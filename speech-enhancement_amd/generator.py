@@ -155,8 +155,6 @@ class TSCNet(nn.Module):
     def _prepare_weights(self, P, device):
         """the step's prepared weights (weights.WeightPlan): built once per (device, parameter storage, precision setting),
         refreshed from the current parameter values by one kernel launch."""
-        if _os.environ.get('SE_NO_WEIGHT_PLAN') == '1':      # A/B switch: round-1 path (per-use repacks, weights re-split per tile)
-            return None
         key = (str(device), LY.CONV_PRECISION, LY.GM.LINEAR_PRECISION, LY.WGRAD_PRECISION[0], LY.ATTN_PRECISION[0])
         plan = self.__dict__.get('_wplan')
         if plan is None or self.__dict__.get('_wplan_key') != key or plan.stale():

@@ -40,7 +40,7 @@ CONV_PRECISION = _PREC[_os.environ.get('SE_CONV_PRECISION', 'f16x3')]
 # |beta| = 254 |gamma| + |beta|; out-of-range values would be clamped (FP16_OVFL), not turned into inf.  Gradients and weights
 # are scaled by their MEASURED maxima instead (amax scalars).
 ACT_SEXP = 4
-PW2_F16 = _os.environ.get('SE_PW2_F32') is None      # pointwise conv 128 -> 64 behind BatchNorm + Swish on the scaled-fp16 kernel
+PW2_F16 = True     # pointwise conv 128 -> 64 behind BatchNorm + Swish on the scaled-fp16 kernel (False: fp32 MFMA; module switch for A/B runs)
 ATTN_O_SEXP = 4    # attention outputs (convex combinations of the value rows): |o| < 4094
 # attention products: 'f16x3' = the scaled split-fp16 kernels (se_attn_fwd_f16 / se_attn_bwd_f16_phase; operand scales from the
 # maxima the qkv / to_out input-gradient GEMMs raise: se_gemm_desc.y_amax) wherever the sequence fits them, 'bf16x6' = the exact
@@ -55,12 +55,12 @@ WGRAD_PRECISION = [_PREC[_os.environ.get('SE_WGRAD_PRECISION', 'f16x3')]]
 
 
 # input-gradient GEMM of the qkv / pointwise-GLU projections fused with the backward of the LayerNorm in front of them
-# (se_gemm_ln_bwd); SE_NO_LN_FUSE=1 keeps the two-kernel form for A/B runs
-FUSE_LN_BWD = _os.environ.get('SE_NO_LN_FUSE') != '1'
-# LayerNorm row statistics emitted by the producer of the rows instead of a separate se_row_stats pass (SE_NO_ROWSTATS_FUSE=1: A/B)
-FUSE_ROWSTATS = _os.environ.get('SE_NO_ROWSTATS_FUSE') != '1'
-# GLU backward in the epilogue of the depthwise input-gradient kernel (se_dwconv31_glu_bwd); SE_NO_GLU_FUSE=1: two kernels (A/B)
-FUSE_GLU_BWD = _os.environ.get('SE_NO_GLU_FUSE') != '1'
+# (se_gemm_ln_bwd); module switches (no environment variables since round 6): tests flip them to cross-check the unfused forms
+FUSE_LN_BWD = True
+# LayerNorm row statistics emitted by the producer of the rows instead of a separate se_row_stats pass
+FUSE_ROWSTATS = True
+# GLU backward in the epilogue of the depthwise input-gradient kernel (se_dwconv31_glu_bwd)
+FUSE_GLU_BWD = True
 
 
 def set_conv_precision(name, wgrad=None):
@@ -133,8 +133,8 @@ def conv_fwd(x, B, Ti, Fi, lda, a_off, C_in, wp, bias, taps, N, To=None, Fo=None
     return R, stats
 
 
-# SE_NO_THIN_CONV=1: the decoders' last convolutions and the encoder's first one through the tap GEMM again (A/B switch)
-THIN_CONV = 0 if _os.environ.get('SE_NO_THIN_CONV') == '1' else int(_os.environ.get('SE_THIN_CONV', '15'))     # bits: 1 encoder fwd, 2 encoder wgrad, 4 decoders fwd, 8 decoders bwd
+# module switch (A/B runs): 0 sends the decoders' last convolutions and the encoder's first one through the tap GEMM again
+THIN_CONV = 15     # bits: 1 encoder fwd, 2 encoder wgrad, 4 decoders fwd, 8 decoders bwd
 
 
 def conv1x2_fwd(x, w, bias, B, T, F2, want_stats):
@@ -471,25 +471,20 @@ def _ff_fwd(P, p, x, M, drop=0.0, seed_h=0, seed_o=0, st=None, want_out_stats=Fa
     if st is None:
         st = O.row_stats(x, M)
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
-    if GM.LINEAR_PRECISION in (1, 2, 3) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0:
-        # one fused kernel: the hidden activations are written once (for the backward) and never re-read here
-        W1p = _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1)
-        # scaled fp16 planes: H is neither stored nor read again (recomputing backward, gemm.ff_bwd_rc / ff_wgrad_rc; inference
-        # never needed it)
-        rc = (GM.FF_RECOMPUTE or GM.FF_FUSED) and W1p.dtype == torch.float16
-        res = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'],
-                         W1p, P[f'{p}.fn.fn.net.0.bias'],
-                         _w(P, (f'{p}.fn.fn.net.3.weight', 'lin'), lambda: W2), P[f'{p}.fn.fn.net.3.bias'], drop, seed_h,
-                         seed_o, 0.5, hid=W1.shape[0], out_stats=want_out_stats, store_h=not rc,
-                         # (the round-3 recomputing kernels -- SE_FF_FUSED=0 SE_FF_RECOMPUTE=1 -- know the static exponents only: the
-                         # forward then scales with the same ones, so that the recomputed H is the forward's)
-                         in_bound=_bnd(P, ('ln', p), 0).get('a_amax') if (GM.FF_FUSED or not rc) else None,
-                         mid_bound=_bnd(P, ('hid', p), 0).get('a_amax') if (GM.FF_FUSED or not rc) else None)
+    W1p = _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: W1)
+    if W1p.dtype == torch.float16 and tuple(W1.shape) == (256, 64) and tuple(W2.shape) == (64, 256):
+        # scaled fp16 planes from the step's WeightPlan: one fused kernel.  Default: H is neither stored nor read again (the fused
+        # backward recomputes it; inference never needed it); SE_FF_FUSED=0: H is written once for the stored-H backward kernels
+        res = GM.ff_fwd(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1p, P[f'{p}.fn.fn.net.0.bias'],
+                        _w(P, (f'{p}.fn.fn.net.3.weight', 'lin'), lambda: W2), P[f'{p}.fn.fn.net.3.bias'], drop, seed_h, seed_o, 0.5,
+                        out_stats=want_out_stats, store_h=not GM.FF_FUSED,
+                        in_bound=_bnd(P, ('ln', p), 0).get('a_amax'), mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'))
         if want_out_stats:
             y, z, ost = res
             return y, (x, st, z, drop, seed_h, seed_o), ost
         y, z = res
         return y, (x, st, z, drop, seed_h, seed_o)
+    # plain fp32 weights (direct layer calls without a plan, SE_LINEAR_PRECISION != f16x3): two GEMMs with fused pro- / epilogues
     z = torch.empty(M, 256, device=x.device, dtype=torch.float32)
     GM.gemm_tap(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, epilogue=L.EPI_BIAS), x, P[f'{p}.fn.fn.net.0.weight'], z,
                 bias=P[f'{p}.fn.fn.net.0.bias'], rowstats=st, ps=P[f'{p}.fn.norm.weight'], pb=P[f'{p}.fn.norm.bias'])
@@ -509,29 +504,19 @@ def _ff_bwd(P, G, p, saved, dy, M, dR2=None):
     x, st, z, drop, seed_h, seed_o = saved
     dr = drop > 0.0
     W1, W2 = P[f'{p}.fn.fn.net.0.weight'], P[f'{p}.fn.fn.net.3.weight']
-    fused = GM.LINEAR_PRECISION in (1, 2, 3) and W1.shape[1] == 64 and W2.shape[0] == 64 and W1.shape[0] % 64 == 0
+    W2Tp = _w(P, (f'{p}.fn.fn.net.3.weight', 'T0.5'), lambda: None)
+    fused = W2Tp is not None and W2Tp.dtype == torch.float16 and getattr(dy, '_se_amax', None) is not None      # (as the forward: planes of the plan)
     if fused and z is None:
-        # recomputing path (scaled fp16): nothing [M, hid]-sized exists -- the input-gradient chain recomputes H from x; so do the
-        # weight gradients (one kernel for dW1, db1, dW2, db2 on the leaf stream, reading x and dy only)
-        W1p, W2Tp = _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: None), _w(P, (f'{p}.fn.fn.net.3.weight', 'T0.5'), lambda: None)
-        b1 = P[f'{p}.fn.fn.net.0.bias']
-        if GM.FF_FUSED:
-            # ONE launch: input gradient, LayerNorm backward and all four weight gradients (the weight gradients are no longer leaves
-            # on the side stream: they accumulate inside the sweep that produces dx)
-            return GM.ff_bwd_fused(dy, x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1p, b1, W2Tp,
-                                   G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], G[f'{p}.fn.fn.net.3.weight'],
-                                   G[f'{p}.fn.fn.net.3.bias'], G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], drop, seed_h, seed_o,
-                                   0.5, dR2=dR2, out_amax=_amax(dy.device), in_bound=_bnd(P, ('ln', p), 0).get('a_amax'),
-                                   mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'),
-                                   W1T=_w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: None))
-        dx = GM.ff_bwd_rc(dy, x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], W1p, b1, W2Tp,
-                          _w(P, (f'{p}.fn.fn.net.0.weight', 'T'), lambda: None), drop, seed_h, seed_o, dR2,
-                          G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], out_amax=_amax(dy.device))
-        with GM.leaf_stream(dy, x, st, dy._se_amax):
-            GM.ff_wgrad_rc(x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], dy, W1p, b1, W2Tp,
-                           G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], G[f'{p}.fn.fn.net.3.weight'],
-                           G[f'{p}.fn.fn.net.3.bias'], drop, seed_h, seed_o, 0.5)
-        return dx
+        # ONE launch: input gradient, LayerNorm backward and all four weight gradients, H recomputed from x (the weight gradients
+        # are no longer leaves on the side stream: they accumulate inside the sweep that produces dx)
+        return GM.ff_bwd_fused(dy, x, st, P[f'{p}.fn.norm.weight'], P[f'{p}.fn.norm.bias'], _w(P, (f'{p}.fn.fn.net.0.weight', 'lin'), lambda: None),
+                               P[f'{p}.fn.fn.net.0.bias'], W2Tp,
+                               G[f'{p}.fn.fn.net.0.weight'], G[f'{p}.fn.fn.net.0.bias'], G[f'{p}.fn.fn.net.3.weight'],
+                               G[f'{p}.fn.fn.net.3.bias'], G[f'{p}.fn.norm.weight'], G[f'{p}.fn.norm.bias'], drop, seed_h, seed_o,
+                               0.5, dR2=dR2, out_amax=_amax(dy.device), in_bound=_bnd(P, ('ln', p), 0).get('a_amax'),
+                               mid_bound=_bnd(P, ('hid', p), 0).get('a_amax'))
+    if z is None:
+        raise L.SeHipError('_ff_bwd: the forward stored no H (fused path) but dy carries no measured maximum (dy._se_amax)')
     # dz = 0.5 * ((mask_o * dy) @ W2) * mask_h * swish'(z);  dh = dz @ W1
     if fused:
         # ... and the LayerNorm backward on the rows still in registers: dx = dy (+ dR2) + LNbwd(dz @ W1)
@@ -738,8 +723,12 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
     do = torch.empty(M, 64, device=dev, dtype=torch.float32)
     WoT = _w(P, (f'{p}.attn.fn.to_out.weight', 'T'), lambda: _T(Wo))
     do_amax = O.zeros(1, device=dev) if qkv_amax is not None else None      # max |dO| for the scaled split-fp16 attention backward
+    # the softmax-backward row constants delta = rowsum(dO . O) per head leave this GEMM's epilogue (it holds dO, reads O: EPI_DELTA)
+    # whenever the cooperative backward will read them: no stand-alone pass over dO and O
+    delta = torch.empty(M, 4, device=dev, dtype=torch.float32) if (qkv_amax is not None and A.f16_shape_ok(geom, maxpos)) else None
     GM.gemm_tap(GM.linear_desc(M, 64, 64, prologue=L.PRO_DROP if pa > 0 else L.PRO_NONE, pro_seed=sa, drop_p=pa, y_amax=do_amax,
-                               **_lin3(WoT, a_amax=getattr(dy2, '_se_amax', None))), dy2, WoT, do)
+                               epilogue=L.EPI_DELTA if delta is not None else 0, ldr=64 if delta is not None else 0,
+                               **_lin3(WoT, a_amax=getattr(dy2, '_se_amax', None))), dy2, WoT, do, R=o if delta is not None else None, AUX=delta)
     with GM.leaf_stream(o, dy2, getattr(dy2, '_se_amax', None), qkv_amax):       # every scalar the side-stream kernel reads stays referenced until the join
         GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 64, epilogue=L.EPI_DROP if pa > 0 else 0, epi_seed=sa, drop_p=pa,
                                          w_amax=getattr(dy2, '_se_amax', None),
@@ -747,8 +736,7 @@ def conformer_bwd(P, G, p, ctx, dout, B, T, Fq, dp=NO_DP, train=True):
                           G[f'{p}.attn.fn.to_out.weight'], G[f'{p}.attn.fn.to_out.bias'])
     dqkv = A.attn_bwd(qkv, P[f'{p}.attn.fn.rel_pos_emb.weight'], o, do, lse, geom,
                       G[f'{p}.attn.fn.rel_pos_emb.weight'], maxpos=maxpos, scale=0.25,
-                      leaf=None if _os.environ.get('SE_ATTN_DE_MAIN') == '1' else GM.leaf_stream,
-                      qkv_amax=qkv_amax, do_amax=do_amax, dqkv_amax=_amax(dev) if (qkv_amax is not None and _os.environ.get('SE_NO_QKVT16') != '1') else None)
+                      leaf=GM.leaf_stream, qkv_amax=qkv_amax, do_amax=do_amax, dqkv_amax=_amax(dev) if qkv_amax is not None else None, delta=delta)
     dq_amax = getattr(dqkv, '_se_amax', None)
     # plan keys in order of preference: the fp16 planes exist only under LINEAR_PRECISION 3 + fp16 attention ('qkvT16'); with the
     # bf16 linear kernels next to the fp16 attention backward the six-product planes ('qkvT') serve; no plan: fp32 from the parameters

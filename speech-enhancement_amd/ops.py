@@ -26,8 +26,6 @@ class ZeroArena:
         self.buf, self.off, self.high, self.active, self.missed = None, 0, 0, False, 0
 
     def begin(self, device, min_bytes=16 << 20):
-        if _os.environ.get('SE_NO_ZERO_ARENA') == '1':     # A/B switch: one torch.zeros per request
-            return
         need = max(min_bytes, 2 * (self.high + self.missed))
         if self.buf is None or self.buf.device != device or self.buf.numel() < need:
             self.buf = torch.zeros(need, device=device, dtype=torch.uint8)
@@ -141,14 +139,6 @@ def affine_prelu(x, ldx, x_off, ss, slope, y, ldy, y_off, B, P, C_):
     return y
 
 
-# SE_NORM_BWD_FUSED=1 (opt-in): the one-pass InstanceNorm backward (inorm_prelu_bwd_fused_kernel).  Built for the round-3 review's item 5
-# and measured slower than the two-pass kernels -- standalone 242 vs 126 us at B = 16, P = 32 421, C = 64 (four rounds of load /
-# 24 K fp64 atomics / counter wait / acquire / store, none of them overlapped), in the step 188 vs 134 us per call (the weight-gradient
-# stream holds part of the chip, so entries miss their deadline and are redone): DESIGN_APPENDIX.md.  NORM_BWD_SPIN_US: that deadline.
-NORM_BWD_FUSED = [_os.environ.get('SE_NORM_BWD_FUSED', '0') == '1']
-NORM_BWD_SPIN_US = [int(_os.environ.get('SE_NORM_BWD_SPIN_US', '200'))]
-
-
 def norm_prelu_bwd(x, ldx, x_off, mr, g, beta, slope, dy, ldy, y_off, dx, lddx, dx_off, dg, dbeta, dslope, B, P, C_,
                    per_batch=True, act=0, allreduce=None, count=None, amax=None):
     """allreduce: optional callable applied to the fp64 reduction buffer between the two phases
@@ -156,15 +146,6 @@ def norm_prelu_bwd(x, ldx, x_off, mr, g, beta, slope, dy, ldy, y_off, dx, lddx, 
     scalar raised to max |dx| (operand scale of the scaled split-fp16 GEMMs that read dx)."""
     if count is None:
         count = float(P if per_batch else P * B)
-    if (per_batch and act == 0 and allreduce is None and NORM_BWD_FUSED[0] and dg is not None
-            and L.lib().se_inorm_prelu_bwd_fused_fits(_i(B), _l(P), _i(C_))):
-        # InstanceNorm: one pass over HBM (csrc/se_norms.hip: inorm_prelu_bwd_fused_kernel + its follow-up launch)
-        ws = zeros(L.lib().se_inorm_prelu_bwd_fused_workspace_bytes(_i(B), _i(C_)) // 8, device=x.device, dtype=f64)
-        L.call('se_inorm_prelu_bwd_fused', L.ptr(x), _i(ldx), _i(x_off), L.ptr(mr), L.ptr(g), L.ptr(beta), L.ptr(slope), L.ptr(dy), _i(ldy),
-               _i(y_off), L.ptr(ws), L.ptr(dx), _i(lddx), _i(dx_off), L.ptr(dg), L.ptr(dbeta), L.ptr(dslope), _i(B), _l(P), _i(C_),
-               _d(count), _i(NORM_BWD_SPIN_US[0]), L.ptr(amax), L.stream(), _key='inorm_prelu_bwd (one pass)',
-               _bytes=4.0 * 3 * B * P * C_)
-        return dx
     red = zeros(L.lib().se_norm_prelu_bwd_workspace_bytes(_i(B), _i(C_), _i(int(per_batch))) // 8, device=x.device, dtype=f64)
     args = lambda phase: (L.ptr(x), _i(ldx), _i(x_off), L.ptr(mr), L.ptr(g), L.ptr(beta), L.ptr(slope),
                           L.ptr(dy), _i(ldy), _i(y_off), L.ptr(red), L.ptr(dx), _i(lddx), _i(dx_off), L.ptr(dg),

@@ -186,7 +186,7 @@ def test_feed_forward_pair(env):
     p1, p2 = plan.linear('w1', W1, planes='f16'), plan.linear('w2', W2, planes='f16')
     p2t, p1t = plan.linear_T('w2t', W2, planes='f16', scale=0.5), plan.linear_T('w1t', W1, planes='f16')
     plan.run()
-    y, h = GM.ff_fwd(x, st, g, b, p1, b1, p2, b2, 0.0, 1, 2, 0.5, hid=256)
+    y, h = GM.ff_fwd(x, st, g, b, p1, b1, p2, b2, 0.0, 1, 2, 0.5)
     x64 = x.double().requires_grad_(True)
     h64 = _ln64(x64, g, b) @ W1.double().t() + b1.double()
     y64 = x64 + 0.5 * ((h64 * torch.sigmoid(h64)) @ W2.double().t() + b2.double())

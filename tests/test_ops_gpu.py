@@ -73,39 +73,25 @@ def test_instance_norm_prelu(C):
 
 @pytest.mark.parametrize('B,P,C,ld', [(3, 377, 64, 64), (16, 4000, 64, 256), (5, 12345, 32, 32), (2, 70001, 64, 64), (7, 250, 128, 128),
                                         (16, 32421, 64, 64), (33, 1000, 16, 16)])
-@pytest.mark.parametrize('spin_us', [200, 0])
-def test_instance_norm_prelu_backward_one_pass(B, P, C, ld, spin_us):
-    """se_inorm_prelu_bwd_fused (tiles kept in registers between the reduction and the apply step) against the two-pass kernels:
-    several rounds / entries per round / tile sizes, strided operands, ragged tails; spin_us = 0 makes every workgroup but the last
-    of an entry miss its deadline, so the follow-up launch redoes those tiles -- same result either way."""
-    from speech_enhancement_amd import ops as O, _lib as L
-    assert L.lib().se_inorm_prelu_bwd_fused_fits(B, O._l(P), C)
+def test_instance_norm_prelu_backward_strided_and_ragged(B, P, C, ld):
+    """se_norm_prelu_bwd (InstanceNorm(affine) + PReLU backward: reduce + apply launches) on strided operands (a channel slab of a wider
+    map), ragged pixel counts and every channel count of the model, accumulating parameter gradients, against torch autograd in fp64.
+    (The one-pass form of round 4 -- tiles kept in registers across an in-kernel rendezvous -- was correct but slower: removed.)"""
+    from speech_enhancement_amd import ops as O
     x = rnd(B, P, ld, seed=1) * 1.7 + 0.4
     off = ld - C
     g, be, a = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.2, rnd(C, seed=4) * 0.1 + 0.25
     dy = rnd(B, P, ld, seed=5)
     stats = O.col_stats(x, ld, off, B, P, C)
     mr, _ = O.norm_finalize(stats, g, be, B, C, float(P))
-    outs = []
-    saved = (O.NORM_BWD_FUSED[0], O.NORM_BWD_SPIN_US[0])
-    for fused in (False, True):
-        O.NORM_BWD_FUSED[0], O.NORM_BWD_SPIN_US[0] = fused, spin_us
-        try:
-            dg, db, da = (torch.full((C,), 0.5, device='cuda') for _ in range(3))
-            dx = torch.full((B, P, ld), 3.0, device='cuda')
-            amax = torch.zeros(1, device='cuda')
-            O.norm_prelu_bwd(x, ld, off, mr, g, be, a, dy, ld, off, dx, ld, off, dg, db, da, B, P, C, per_batch=True, amax=amax)
-            torch.cuda.synchronize()
-        finally:
-            O.NORM_BWD_FUSED[0], O.NORM_BWD_SPIN_US[0] = saved
-        outs.append((dx, dg, db, da, amax))
-    (dx0, dg0, db0, da0, am0), (dx1, dg1, db1, da1, am1) = outs
+    dg1, db1, da1 = (torch.full((C,), 0.5, device='cuda') for _ in range(3))
+    dx1 = torch.full((B, P, ld), 3.0, device='cuda')
+    am1 = torch.zeros(1, device='cuda')
+    O.norm_prelu_bwd(x, ld, off, mr, g, be, a, dy, ld, off, dx1, ld, off, dg1, db1, da1, B, P, C, per_batch=True, amax=am1)
+    torch.cuda.synchronize()
     if off:
         assert float((dx1[..., :off] - 3.0).abs().max()) == 0.0          # columns outside the slab untouched
-    # same arithmetic; the fp64 sums differ in the order of their atomics only
-    assert relerr(dx1[..., off:], dx0[..., off:]) < 2e-6
-    assert relerr(dg1 - 0.5, dg0 - 0.5) < 1e-5 and relerr(db1 - 0.5, db0 - 0.5) < 1e-5 and relerr(da1 - 0.5, da0 - 0.5) < 1e-5
-    assert abs(float(am1) - float(am0)) <= 1e-6 * float(am0)
+    assert abs(float(am1) - float(dx1[..., off:].abs().max())) <= 1e-6 * float(am1)
     # and against torch autograd in fp64
     x64 = x[..., off:].double().requires_grad_(True)
     p64 = [t.double().requires_grad_(True) for t in (g, be, a)]

@@ -32,7 +32,7 @@ pb, pf = plans(lambda p, k: (p.linear('w1', W1, planes=k), p.linear('w2', W2, pl
                              p.linear_T('w1t', W1, planes=k)))
 ref64 = None
 for name, p in (('bf16x6', pb), ('f16x3', pf)):
-    y, h = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, 0.0, 1, 2, 0.5, hid=256)
+    y, h = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, 0.0, 1, 2, 0.5)
     xl = ((x.double() - st[:, :1].double()) * st[:, 1:].double()) * g.double() + b.double()
     h64 = xl @ W1.double().t() + b1.double()
     y64 = x.double() + 0.5 * ((h64 * torch.sigmoid(h64)) @ W2.double().t() + b2.double())
@@ -45,35 +45,6 @@ for name, p in (('bf16x6', pb), ('f16x3', pf)):
     dh64 = (dy.double() @ (0.5 * W2.double())) * (torch.sigmoid(h64) * (1 + h64 * (1 - torch.sigmoid(h64))))
     print('ff_bwd', name, 'dZ', rel(dz, dh64), 'amax dz', float(am[1]), float(dz.abs().max()), 'amax dx', float(am[0]), float(dx.abs().max()))
 
-# recomputing feed-forward backward / weight gradients vs fp64 (dropout on: the hash is restated through the kernels themselves)
-p = pf
-for drop in (0.0, 0.2):
-    dy = torch.randn(M, 64, device=dev) * 1e-3
-    dy._se_amax = dy.abs().max().reshape(1).clone()
-    y, h = GM.ff_fwd(x, st, g, b, p.out['w1'], b1, p.out['w2'], b2, drop, 11, 12, 0.5, hid=256)            # stores H
-    dg0, db0, dg1, db1_ = (torch.zeros(64, device=dev) for _ in range(4))
-    am = (torch.zeros(1, device=dev), torch.zeros(1, device=dev))
-    dz, dx0 = GM.ff_bwd_dgrad(dy, h, p.out['w2t'], p.out['w1t'], drop, 11, 12, ln=(x, st, g, None, dg0, db0), amax_out=am)
-    dx1 = GM.ff_bwd_rc(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], p.out['w1t'], drop, 11, 12, None, dg1, db1_, out_amax=torch.zeros(1, device=dev))
-    print(f'ff_bwd_rc drop={drop}: dx vs stored-H kernel', rel(dx1, dx0), 'dgamma', rel(dg1, dg0), 'dbeta', rel(db1_, db0), 'amax', float(dx1._se_amax), float(dx1.abs().max()))
-    # weight gradients: the two whole-gradient kernels on the stored H / dZ vs the recomputing kernel
-    dW1a, db1a, dW2a, db2a = torch.zeros(256, 64, device=dev), torch.zeros(256, device=dev), torch.zeros(64, 256, device=dev), torch.zeros(64, device=dev)
-    dr = drop > 0
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 256, 64, prologue=L.PRO_SWISH_DROP if dr else L.PRO_SWISH, epilogue=L.EPI_DROP if dr else 0,
-                                     pro_seed=11, epi_seed=12, drop_p=drop, precision=0), h, dy, dW2a, db2a, scale=0.5, explicit_precision=True)
-    GM.gemm_tap_wgrad(GM.linear_desc(M, 64, 256, prologue=L.PRO_LN, precision=0), x, dz, dW1a, db1a, rowstats=st, ps=g, pb=b, explicit_precision=True)
-    dW1b, db1b, dW2b, db2b = torch.zeros(256, 64, device=dev), torch.zeros(256, device=dev), torch.zeros(64, 256, device=dev), torch.zeros(64, device=dev)
-    GM.ff_wgrad_rc(x, st, g, b, dy, p.out['w1'], b1, p.out['w2t'], dW1b, db1b, dW2b, db2b, drop, 11, 12, 0.5)
-    print(f'ff_wgrad_rc drop={drop}: dW1', rel(dW1b, dW1a), 'db1', rel(db1b, db1a), 'dW2', rel(dW2b, dW2a), 'db2', rel(db2b, db2a))
-    if not dr:
-        xl = ((x.double() - st[:, :1].double()) * st[:, 1:].double()) * g.double() + b.double()
-        h64 = xl @ W1.double().t() + b1.double()
-        sg = torch.sigmoid(h64)
-        dz64 = (dy.double() @ (0.5 * W2.double())) * (sg * (1 + h64 * (1 - sg)))
-        print('   vs fp64: dW1', rel(dW1b, dz64.t() @ xl), 'dW2', rel(dW2b, 0.5 * dy.double().t() @ (h64 * sg)), '| fp32-MFMA kernels: dW1',
-              rel(dW1a, dz64.t() @ xl), 'dW2', rel(dW2a, 0.5 * dy.double().t() @ (h64 * sg)))
-
-# K = 64 row panel: LN prologue, N = 192; GLU epilogue
 Wq = torch.randn(192, 64, device=dev) * 0.1
 Wp, bp = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
 pb, pf = plans(lambda p, k: (p.linear('q', Wq, planes=k), p.linear('p', Wp, planes=k)))

@@ -28,11 +28,11 @@ am = torch.zeros(1, device=dev)
 
 def run(n=6, drop=0.2):
     for _ in range(2):
-        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am, W1T=p.out['w1t'])
+        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(n):
-        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am, W1T=p.out['w1t'])
+        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
     torch.cuda.synchronize()
     return (time.time() - t0) / n * 1e6
 

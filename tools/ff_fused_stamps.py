@@ -23,7 +23,7 @@ gr = [torch.zeros(s, device=dev) for s in ((256, 64), (256,), (64, 256), (64,), 
 stamps = torch.zeros(4 * 8 * 8 * 10, device=dev, dtype=torch.int32)
 L.lib().se_ff_fused_debug_stamps(C.c_void_p(stamps.data_ptr()))
 for _ in range(3):
-    GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, 0.2, 11, 12, 0.5, dR2=dR2, out_amax=torch.zeros(1, device=dev), W1T=p.out['w1t'])
+    GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, 0.2, 11, 12, 0.5, dR2=dR2, out_amax=torch.zeros(1, device=dev))
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.uint32).reshape(4, 8, 8, 10).astype(np.int64)
 names = ['p', 'a0', 'b0', 'a1', 'b1', 'a2', 'b2', 'a3', 'b3', 'c']
