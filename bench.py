@@ -301,6 +301,41 @@ def secondary_configs(G, D, og, od, dev, budget_s=25.0):
         del m
     except Exception as e:      # noqa: BLE001
         res['config5_cdiffuse_sampler'] = {'error': repr(e)[:300]}
+    try:        # the front-end at a size where its launches are not latency: batch 256 (168 MB of algorithmic traffic per transform)
+        from speech_enhancement_amd import frontend as FE
+        Bs = 256
+        xs = 0.1 * torch.randn(Bs, 32000, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+        pl, _ = FE.stft_planes(xs, 400, 100, 'pow', padded=False)
+
+        def ev_time(fn, n=10):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            ev[0].record()
+            for i in range(n):
+                fn()
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))[n // 2] * 1e-3
+        with torch.no_grad():
+            t_st = ev_time(lambda: FE.stft_planes(xs, 400, 100, 'pow', padded=False))
+            t_is = ev_time(lambda: FE.istft_planes(pl, 400, 100, 'pow'))
+        alg = 0.644e6 * Bs                                  # 0.128 MB in + 0.516 MB out (complex64) per utterance and transform
+        moved_st = 4.0 * Bs * (32000 + 321 * 201 * 4)       # what the kernel moves: the plane format writes 16 B per bin (|z|, Re, Im, 0)
+        res['frontend_at_batch256'] = {
+            'workload': 'se_stft_fused / se_istft_fused (n_fft 400, hop 100, pow compression) on 256 clips of 2 s: one launch each, HIP-event median of 10',
+            'stft_ms': round(t_st * 1e3, 4), 'istft_ms': round(t_is * 1e3, 4),
+            'stft_fused.frac_of_hbm_peak_at_B256': round(alg / t_st / 1e9 / PEAK_HBM_GBS, 4),
+            'istft_fused.frac_of_hbm_peak_at_B256': round(alg / t_is / 1e9 / PEAK_HBM_GBS, 4),
+            'stft_gbs_algorithmic': round(alg / t_st / 1e9, 1), 'istft_gbs_algorithmic': round(alg / t_is / 1e9, 1),
+            'stft_gbs_moved (16-byte plane pixels)': round(moved_st / t_st / 1e9, 1), 'istft_gbs_moved': round(moved_st / t_is / 1e9, 1),
+            'stft_tflops_fp32_mfma': round(2.0 * Bs * 321 * 400 * 402 / t_st / 1e12, 2),
+            'note': 'algorithmic bytes = SURVEY 8(d) (0.644 MB per utterance and transform) against the 8 TB/s spec; the transform is a '
+                    '[400 x 402] fp32-MFMA DFT per frame (0.10 GFLOP per utterance): at this size the fp32 matrix pipe, not HBM, bounds it'}
+        del xs, pl
+    except Exception as e:      # noqa: BLE001
+        res['frontend_at_batch256'] = {'error': repr(e)[:300]}
     res['seconds_total'] = round(time.time() - t_all, 1)
     return res
 

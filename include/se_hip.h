@@ -105,7 +105,7 @@ int se_version(void);
 const char* se_last_error(void);
 
 /* Workspace sizes (bytes) of the entry points that take a caller-owned workspace; pure host functions, no GPU call.
- *   se_attn_bwd               : ws     = row constants [ntok][4] + fp16-split copies of E + the replicas of dE
+ *   se_attn_bwd               : ws     = row constants [ntok][4] + fp16-split copies of E + per-item dE tiles
  *   se_norm_prelu_bwd         : red    = double [per_batch ? B : 1][C][3]
  *   se_dwconv31_wgrad         : ws     = float  [512 workgroups][32][128]
  *   se_disc_tail_fwd / _bwd   : ws     = float  [B][324]
@@ -334,7 +334,7 @@ int se_attn_fwd_es(const float* QKV, const float* E, const void* Es, long es_pla
                    int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos, float scale, void* stream);
 /* backward: dQKV [tokens][192] written, dE accumulated (caller zeroes); ws = workspace of
  * se_attn_bwd_workspace_bytes(ntok, maxpos, nseq, n) bytes, 16-byte aligned (softmax row constants, fp16-split copies of E, the
- * replicas of dE the scaled split-fp16 kernel adds into).  This entry runs the fp32-MFMA kernels (dK / dV pass, dQ / dE pass) for any
+ * per-item dE tiles of the scaled split-fp16 kernel).  This entry runs the fp32-MFMA kernels (dK / dV pass, dQ / dE pass) for any
  * sequence length -- the cross-check path of se_attn_bwd_f16_phase and the backward of shapes outside it. */
 int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE,
                 float* dQKV, float* dE, int nseq, int n, int inner, long outer_stride,
@@ -354,8 +354,8 @@ int se_attn_bwd(const float* QKV, const float* E, const float* O, const float* d
  *   delta     : optional [tokens][4] table of the softmax-backward row constants rowsum(dO . O) per head (e.g. written by the
  *               to_out input-gradient GEMM: SE_EPI_DELTA); NULL: computed here from O and dO (one more launch); O may be NULL when
  *               delta is given
- * The backward splits E itself (and measures its maximum) in its workspace.  phase 1 = everything but the fold of the dE replicas,
- * phase 2 = that fold alone (reads ws, accumulates dE) -- a leaf of the backward graph that the caller may issue on another stream
+ * The backward splits E itself (and measures its maximum) in its workspace.  phase 1 = everything but the reduction of the per-item dE tiles,
+ * phase 2 = that reduction alone (reads ws, accumulates dE) -- a leaf of the backward graph that the caller may issue on another stream
  * behind phase 1; phase 3 = both. */
 int se_attn_fwd_f16(const float* QKV, const void* Es, long es_plane, const float* qkv_amax, const float* e_amax, float* O,
                     float* LSE, int nseq, int n, int inner, long outer_stride, long inner_stride, long pos_stride, int maxpos,

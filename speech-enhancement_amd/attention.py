@@ -56,7 +56,7 @@ def attn_fwd(qkv, E, geom, maxpos=512, scale=0.25, need_lse=True, Es=None, qkv_a
 
 def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None, qkv_amax=None, do_amax=None, dqkv_amax=None, delta=None):
     """returns dQKV [ntok,192]; accumulates into dE [2*maxpos+1, 16].  leaf: optional context-manager factory (gemm.leaf_stream):
-    the fold of the dE replicas -- a leaf of the backward graph -- is then issued inside `leaf(ws, ...)`.
+    the reduction of the per-item dE tiles -- a leaf of the backward graph -- is then issued inside `leaf(ws, ...)`.
     qkv_amax / do_amax: device scalars >= max |qkv| / max |dO| (producer epilogues): both given and a shape the cooperative kernel
     takes -> the scaled split-fp16 kernel, which raises the zero-filled scalar dqkv_amax (optional) to max |dQKV| (returned as
     dqkv._se_amax); otherwise the fp32-MFMA kernels (any length).  delta: optional [ntok, 4] table rowsum(dO . O) per head (the
@@ -68,7 +68,7 @@ def attn_bwd(qkv, E, O, dO, lse, geom, dE, maxpos=512, scale=0.25, leaf=None, qk
     nbytes = L.lib().se_attn_bwd_workspace_bytes(C.c_long(ntok), C.c_int(maxpos), C.c_int(nseq), C.c_int(n))
     ws = torch.empty((nbytes + 3) // 4, device=qkv.device, dtype=torch.float32)
     f16 = qkv_amax is not None and do_amax is not None and f16_shape_ok(geom, maxpos)
-    tk = dict(_key=('attn_bwd_f16x3 (+tables, dE fold)' if f16 else 'attn_bwd_dkv + attn_bwd_dq (+delta)') + (' n>128' if n > 128 else ' n<=128'),
+    tk = dict(_key=('attn_bwd_f16x3 (+tables, dE reduce)' if f16 else 'attn_bwd_dkv + attn_bwd_dq (+delta)') + (' n>128' if n > 128 else ' n<=128'),
               _flops=nseq * 4 * 7 * 2.0 * n * n * 16, _bytes=4.0 * ntok * 512)
     if not f16:
         if delta is not None:

@@ -723,7 +723,7 @@ struct AttnBwd4Args {
   const float* QKV; const float* dO; const float* LSE; const float* Dl;      // Dl [tokens][4]: delta = rowsum(dO . O) per head
   float* dQKV;
   const __bf16* Es; const __bf16* Ets;   // two fp16 planes of E * 2^sexp(*e_amax): row fragments [R][16] / tile-major column fragments
-  float* dEs;                        // ATTN_DE_NREP replicas of the fp32 table [R][16] the offset tiles are added into (zeroed per call)
+  float* dEs;                        // per-item dE tiles: [item][2 nkt][16 offsets][16 d]
   int R, ET, maxpos;
   float scale;
   int dbg;                           // SE_ATTN_DBG: 1 no U of the next tile, 2 no key steps, 4 no strip consumption (timing ablations), 32 stamps
@@ -733,24 +733,34 @@ struct AttnBwd4Args {
   float* dqkv_amax;                  // optional: raised to max |dQKV| (operand scale of the consumers of the gradient)
 };
 
-// dE[row][d] += the sum of the ATTN_DE_NREP replicas the cooperative backward added its offset tiles into (rows row0 .. row0 + nrows - 1
-// of the [R][16] table: the offsets a sequence of n positions reaches).  One thread per float4; this launch is the only writer of dE
-// while it runs (stream order), so a plain read-modify-write.
-__global__ __launch_bounds__(256) void attn_de_replicas_reduce_kernel(const float* __restrict__ rep, float* __restrict__ dE, int R, int row0,
-                                                                      int nrows, int nrep) {
-  const int i4 = blockIdx.x * 256 + threadIdx.x;
-  if (i4 >= nrows * 4) return;
-  const long e = (long)row0 * 16 + 4L * i4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+// dE[delta][d] += sum over the (sequence, head) items of their finished offset tiles: dEs [items][2 nkt][256], tile slot = D + nkt,
+// D = -nkt .. nkt - 1.  grid = (offset tile, chunk of 256 items); a workgroup streams 256 x 1 KB with 16-byte loads, sums through LDS, 1 KB of atomics.
+__global__ __launch_bounds__(256) void attn_de_reduce_items_kernel(const float* __restrict__ dEs, float* __restrict__ dE, long nitems,
+                                                                   int nkt, int maxpos, int R) {
+  __shared__ float4 part[4][64];
+  const int Dtile = (int)blockIdx.x - nkt;                       // -nkt .. nkt - 1
+  const long w0 = (long)blockIdx.y * 256;
+  const int nslot = 2 * nkt, t = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);                    // (the table is shared by the heads: every item adds to it)
 #pragma unroll 8
-  for (int r = 0; r < nrep; ++r) {
-    const float4 v = *reinterpret_cast<const float4*>(rep + (long)r * R * 16 + e);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  for (int i = sub; i < 256; i += 4) {
+    const long it = w0 + i;
+    const long itc = it < nitems ? it : nitems - 1;              // (unconditional load, zeroed by the select)
+    const float4 v = *reinterpret_cast<const float4*>(dEs + (itc * nslot + blockIdx.x) * 256 + t * 4);
+    if (it < nitems) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
   }
-  float* p = dE + e;      // (a parameter gradient inside a flat optimizer buffer is only 4-byte aligned)
-  p[0] += s.x; p[1] += s.y; p[2] += s.z; p[3] += s.w;
+  part[sub][t] = s;
+  __syncthreads();
+  if (sub == 0) {
+    const float4 b = part[1][t], c4 = part[2][t], d = part[3][t];
+    s.x += b.x + (c4.x + d.x); s.y += b.y + (c4.y + d.y); s.z += b.z + (c4.z + d.z); s.w += b.w + (c4.w + d.w);
+    const int row = 16 * Dtile + (t >> 2) + maxpos;
+    if (row >= 0 && row < R) {
+      float* p = &dE[(long)row * 16 + (t & 3) * 4];
+      atomicAdd(p, s.x); atomicAdd(p + 1, s.y); atomicAdd(p + 2, s.z); atomicAdd(p + 3, s.w);
+    }
+  }
 }
-
 
 #include "se_attn_bwd4.h"
 
@@ -1042,7 +1052,7 @@ static int attn_fwd_impl(const float* QKV, const float* E, const void* Es, long 
   return se_check_launch("se_attn_fwd");
 }
 
-// workspace of se_attn_bwd: Dl [ntok][4] | Es [2][R][16] fp16 + max |E| | Ets [2][16][ET] fp16 | ATTN_DE_NREP replicas of dE [R][16] fp32
+// workspace of se_attn_bwd: Dl [ntok][4] | Es [2][R][16] fp16 + max |E| | Ets [2][16][ET] fp16 | per-item dE tiles [nseq * 4][2 nkt][256] fp32
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 struct AttnWs { size_t dl, es, ets, des, total; int R, ET; };
 // the cooperative backward (se_attn_bwd4.h) takes a sequence when its padded length fits the offset table without a clamp and its
@@ -1051,7 +1061,7 @@ static bool attn_bwd4_shape(int n, int maxpos, long pos_stride) {
   const int nkt = (n + 15) / 16;
   return (maxpos % 16) == 0 && 16 * nkt + 16 * 8 <= maxpos && nkt <= 21 && pos_stride * 192 * (long)(16 * nkt) < 2147483647L;
 }
-static AttnWs attn_ws(long ntok, int maxpos) {
+static AttnWs attn_ws(long ntok, int maxpos, int nseq, int n) {
   AttnWs w;
   w.R = 2 * maxpos + 1;
   w.ET = (w.R + 16 + 15) / 16 * 16;
@@ -1059,11 +1069,12 @@ static AttnWs attn_ws(long ntok, int maxpos) {
   w.es = al256((size_t)ntok * 4 * sizeof(float));
   w.ets = w.es + al256((size_t)2 * w.R * 16 * 2) + 256;          // (+ 256: the measured max |E| behind the two planes)
   w.des = w.ets + al256((size_t)2 * 16 * w.ET * 2);
-  w.total = w.des + al256((size_t)ATTN_DE_NREP * w.R * 16 * sizeof(float));
+  const int nkt = (n + 15) / 16;
+  w.total = w.des + (attn_bwd4_shape(n, maxpos, 1) ? al256((size_t)nseq * 4 * (size_t)(2 * nkt) * 256 * sizeof(float)) : 0);
   return w;
 }
 extern "C" size_t se_attn_bwd_workspace_bytes(long ntok, int maxpos, int nseq, int n) {
-  return (ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0) ? attn_ws(ntok, maxpos).total : 0;
+  return (ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0) ? attn_ws(ntok, maxpos, nseq, n).total : 0;
 }
 
 static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, const float* delta,
@@ -1111,7 +1122,7 @@ static int launch_bwd4(const AttnBwd4Args& b, const AttnBwd4Plan& pl, int nkt, l
 }
 
 // Backward.  With the operand maxima (se_attn_bwd_f16_phase): the workgroup-cooperative scaled split-fp16 kernel; phase 1 = delta (unless
-// the caller supplies the table), the split tables of E, the kernel; phase 2 = the fold of the dE replicas (a leaf of the backward
+// the caller supplies the table), the split tables of E, the kernel; phase 2 = the reduction of the per-item dE tiles (a leaf of the backward
 // graph: the caller may issue it on another stream once phase 1 has been queued).  Without them (se_attn_bwd): the fp32-MFMA kernels
 // of round 1 for any sequence length (dK / dV pass + dQ / dE pass), everything in phase 1.
 static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const float* dO, const float* LSE, const float* delta,
@@ -1120,7 +1131,7 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
                          const float* qkv_amax, const float* do_amax, float* dqkv_amax) {
   SE_REQUIRE(QKV && E && dO && LSE && dQKV && dE && ws, "attn_bwd: null operand");
   SE_REQUIRE(ntok > 0 && maxpos >= 0 && nseq > 0 && n > 0, "attn_bwd: bad sizes");
-  const AttnWs w = attn_ws(ntok, maxpos);
+  const AttnWs w = attn_ws(ntok, maxpos, nseq, n);
   SE_REQUIRE(ws_bytes >= w.total, "attn_bwd: workspace of %zu bytes, need %zu (se_attn_bwd_workspace_bytes)", ws_bytes, w.total);
   SE_REQUIRE(((uintptr_t)ws & 15) == 0, "attn_bwd: workspace must be 16-byte aligned");
   float* Dl = reinterpret_cast<float*>((char*)ws + w.dl);
@@ -1140,8 +1151,8 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
     float* rep = reinterpret_cast<float*>((char*)ws + w.des);
     const int nkt = (n + 15) / 16;
     if (phase & 1) {
-      // (the column-fragment table's padding and the dE replicas start at zero)
-      SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.total - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
+      // (the column-fragment table's padding starts at zero)
+      SE_REQUIRE(hipMemsetAsync((char*)ws + w.ets, 0, w.des - w.ets, s) == hipSuccess, "attn_bwd: workspace memset failed");
       hipLaunchKernelGGL(attn_split_tables_f16_kernel, dim3(16), dim3(1024), 0, s, E, reinterpret_cast<unsigned short*>(Es),
                          reinterpret_cast<unsigned short*>(Ets), e_amax, w.R, w.ET);
       AttnBwd4Args b{geom, QKV, dO, LSE, delta ? delta : Dl, dQKV, Es, Ets, rep, w.R, w.ET, maxpos, scale, 0, qkv_amax, do_amax, e_amax, dqkv_amax};
@@ -1159,8 +1170,8 @@ static int attn_bwd_impl(const float* QKV, const float* E, const float* O, const
       if (e) return e;
     }
     if (phase & 2) {
-      const int row0 = maxpos - 16 * nkt, nrows = 32 * nkt;
-      hipLaunchKernelGGL(attn_de_replicas_reduce_kernel, dim3(cdiv(nrows * 4, 256)), dim3(256), 0, s, rep, dE, w.R, row0, nrows, ATTN_DE_NREP);
+      const long items = (long)nseq * 4;
+      hipLaunchKernelGGL(attn_de_reduce_items_kernel, dim3(2 * nkt, cdiv(items, 256)), dim3(256), 0, s, rep, dE, items, nkt, maxpos, w.R);
     }
     return se_check_launch("se_attn_bwd");
   }

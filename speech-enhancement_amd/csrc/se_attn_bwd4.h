@@ -21,13 +21,8 @@
 //   * LDS: K image (nkt KB) + strip (16 x (16 (nkt + 1) + 4) floats) + stage (2.2 KB) + 1 KB per wave (dS^T / W^T transposition,
 //     at the end of a query tile the wave's dQ partial) = 50.6 KB at n = 321: three workgroups per CU at <= 168 VGPRs.
 // Three barriers per query tile: strip written | key steps done | strip consumed + dQ partials written.
-// dE tiles leave the owning wave's registers as fp32 atomics into one of ATTN_DE_NREP replicas of the [R][16] table (replica = item
-// mod ATTN_DE_NREP; a tile is turned row-major through the wave's transposition patch first, so that every atomic instruction covers
-// 256 contiguous bytes); attn_de_replicas_reduce_kernel folds the replicas into dE (round 5: per-item tables [2 nkt][256] -- 271 MB
-// written and read back by a reduction kernel per launch at n = 321).
+// dE tiles go to the per-item table [2 nkt][256] (slot D + nkt): attn_de_reduce_items_kernel sums them.
 #pragma once
-
-constexpr int ATTN_DE_NREP = 32;     // replicas of the dE table the workgroups add into (power of two)
 
 struct AttnBwd4Plan {
   int kt0[8], cnt[8];            // key tiles of wave w: kt0 .. kt0 + cnt - 1
@@ -118,7 +113,7 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd4Args& a, con
   const float* lseb = a.LSE + base * 4 + head;
   const float* dlb = a.Dl + base * 4 + head;
   float* dqb = a.dQKV + base * 192 + head * 16;
-  float* const dErep = a.dEs + (item & (ATTN_DE_NREP - 1)) * ((long)a.R * 16) + (long)a.maxpos * 16;      // row 0 = offset 0
+  float* dEs = a.dEs + item * (long)(2 * nkt) * 256;
   const int trrow = c >> 2, trcol = c & 3;
   const unsigned char* Esb = reinterpret_cast<const unsigned char*>(a.Es);
   const unsigned char* Etb = reinterpret_cast<const unsigned char*>(a.Ets);
@@ -216,22 +211,17 @@ static __device__ __forceinline__ void attn_bwd4_body(const AttnBwd4Args& a, con
     j0[ci] = cl == 0 ? 0 : M - cl;                           // (0 - cl) mod M
   }
   float omax = 0.f;
-  // one finished offset tile: v[r] = dE[delta = 16 D + c][d = 4g + r] is added to this item's replica of the table.  The tile goes
-  // through the wave's (idle here) transposition patch into row-major order: lane l then holds elements 64 r + l of the tile's 256
-  // consecutive floats, so each of the four atomic instructions covers 256 contiguous bytes (the full-rate shape of
-  // global_atomic_add_f32, MI355X_MICROARCH.md: lanes spread over 16 rows of 64 B run several times slower)
-  float* const patch = reinterpret_cast<float*>(Dimg);
+  // one finished offset tile: v[r] = dE[delta = 16 D + c][d = 4g + r] -> slot D + nkt of the item's table (ONE 16-byte store per lane; the
+  // tables of all items are summed by attn_de_reduce_items_kernel on the leaf stream).  Round 6 measured the alternative the round-5
+  // review asked for -- fp32 atomics from these registers into 32 replicas of the [R][16] table, no per-item tables, no 271 MB
+  // reduction: the atomics cost the kernel +40 us per launch at n = 321 (two forms: tiles turned row-major through LDS for 256
+  // contiguous bytes per instruction, and dE = W^T Q accumulated with d on the lane for four whole 64-byte rows per instruction),
+  // more than the reduction (63 us, hidden on the leaf stream) saves: step +0.25 ms same-box -- profiles/r06_attn_de_ab.txt.
   auto flush = [&](const f32x4& v, int D) {
-    *reinterpret_cast<float4*>(patch + c * 16 + 4 * g) = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
-    float x[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = patch[64 * r + lane];
-    float* const tp = dErep + D * 256 + lane;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(tp + 64 * r, x[r]);
+    *reinterpret_cast<float4*>(dEs + (D + nkt) * 256 + c * 16 + 4 * g) = make_float4(v[0] * cq1, v[1] * cq1, v[2] * cq1, v[3] * cq1);
   };
   // (diagnostic build switch dbg & 32: shader-clock stamps of the phases of the first 64 workgroups, behind the item tables)
-  unsigned* const stamps = reinterpret_cast<unsigned*>(a.dEs + (long)ATTN_DE_NREP * a.R * 16);
+  unsigned* const stamps = reinterpret_cast<unsigned*>(a.dEs + (long)gridDim.x * (2 * nkt) * 256);
   // The stamp area lies BEYOND what se_attn_bwd_workspace_bytes reserves (only tools/attn_bwd_stamps.py over-allocates for it), so
   // the stores exist only in a diagnostic build (-DSE_ATTN_STAMPS): SE_ATTN_DBG=32 in a product build writes nothing.
   auto stamp = [&](int qt_, int k) {

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gemm_tap_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  if (SA >= 36 && vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA, thr, inv_keep, red, bias_s);
+  if (SA >= 36 && vec_ep) gemm_epilogue_vec<false, true, false, true>(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA, thr, inv_keep, red, bias_s);
   else if (SA >= 36 && epilogue_glu_vec_ok(d)) gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, b, &As[wave * 32 * SA], SA);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, (LNB && F16) ? 3 : 1) void gemm_tap_bf16x3_ker
   }
   float* cs = reinterpret_cast<float*>(Ap) + wave * 32 * 36;        // the staging planes are free now
   if (LNB) { gemm_epilogue_ln_bwd(g, acc0, acc1, m0, cs, 36, red, lnpre); return; }
-  if (vec_ep) gemm_epilogue_vec(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
+  if (vec_ep) gemm_epilogue_vec<false, true, false, true>(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s);
   else gemm_epilogue(g, acc0, acc1, m0, by, b, red, thr, inv_keep);
 }
 
@@ -356,6 +356,36 @@ __global__ __launch_bounds__(256, (LNB && F16) ? 3 : 1) void gemm_tap_bf16x3_ker
 // = 384 cycles).
 // ORD: the taps of every triple are listed as df = -1, 0, +1 (ORD = 1: gemm.conv_taps' order, the forward) or +1, 0, -1 (ORD = 2:
 // the negated taps of an input gradient) -- host-checked; the shift of the unrolled tap loop is then a compile-time constant.
+// Measurement twins of this kernel (tools/conv3_twin.py builds them as variant libraries; WRONG results, never in the product build):
+// SE_CONV3_TWIN == 1 "mfma": the LDS fragment reads, the MFMAs, the barriers and the epilogue -- no global load, no operand split, no
+// staging store (the images keep whatever the LDS held); SE_CONV3_TWIN == 2 "feed": everything but the MFMAs (each replaced by two
+// value-preserving v_fma_f32 that read its operands).
+#ifndef SE_CONV3_TWIN
+#define SE_CONV3_TWIN 0
+#endif
+#if SE_CONV3_TWIN == 2
+template <bool F16>
+static __device__ __forceinline__ f32x16 conv3_mfma_(const bf16x8& a, const bf16x8& b, f32x16 c) {
+  float c0 = c[0];
+  const u32x4_ ua = __builtin_bit_cast(u32x4_, a), ub = __builtin_bit_cast(u32x4_, b);
+  asm volatile("v_fma_f32 %0, %1, 0, %0\n\tv_fma_f32 %0, %2, 0, %0" : "+v"(c0) : "v"(ua[0]), "v"(ub[3]));
+  c[0] = c0;
+  return c;
+}
+#else
+template <bool F16>
+static __device__ __forceinline__ f32x16 conv3_mfma_(const bf16x8& a, const bf16x8& b, f32x16 c) { return mfma32_<F16>(a, b, c); }
+#endif
+// diagnostic build (-DSE_CONV3_STAMPS, tools/conv3_stamps.py): shader-clock stamps of the first groups of the first workgroups, written by
+// lane 0 of every wave to a buffer handed over through se_conv3_debug_stamps -- never part of the product build
+#ifdef SE_CONV3_STAMPS
+__device__ unsigned* g_conv3_stamps = nullptr;
+extern "C" void se_conv3_debug_stamps(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_conv3_stamps), &p, sizeof(p)); }
+#define CONV3_STAMP(k) do { if (g_conv3_stamps && blockIdx.x - 4096u < 64u && (k) < 64 && lane == 0) \
+    g_conv3_stamps[((blockIdx.x - 4096u) * 4 + wave) * 64 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CONV3_STAMP(k) do { } while (0)
+#endif
 template <int NPL, bool WPL = false, bool F16 = false, int OCC = 3, int MT = 1, int ORD = 0>
 __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
   constexpr int BM = 128 * MT, BN = 64, BK = 32, SA = 40, HR = BM + 2;
@@ -457,22 +487,30 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
     for (int r = 0; r < 16; ++r) { acc[mt][0][r] = 0.f; acc[mt][1][r] = 0.f; }
   const bool vec_ep = epilogue_vec_ok(d);
   if (vec_ep) stage_bias(g, by, bias_s);
+#if SE_CONV3_TWIN != 1
   load_a();
   if (WPL) load_bp(0); else load_b();
+#endif
+  CONV3_STAMP(0);
   const int frag = (lane & 31) * SA + 8 * (lane >> 5);
   int it = 0, gi = 0;
   for (int gq = 0; gq < nchunk * ngrp; ++gq, gi = (gi + 1 == ngrp ? 0 : gi + 1)) {
     // stage the halo tile of this (chunk, triple); the previous iteration's trailing barrier freed Ap
+    CONV3_STAMP(1 + 11 * gq);
+#if SE_CONV3_TWIN != 1
 #pragma unroll
     for (int i = 0; i < 4 * MT; ++i) split_store_x<NPL, F16>(ra[i], sa, &Ap[(1 + r0 + 32 * i) * SA + kq * 4], PA);
     // every lane consumes rh here (the lanes that do not store it too): a load still in flight on one path makes the
     // compiler drain ALL loads before the register is reused
     asm volatile("" :: "v"(rh.x), "v"(rh.y), "v"(rh.z), "v"(rh.w));
     if (tid < 16) split_store_x<NPL, F16>(rh, sa, &Ap[((tid >> 3) * (HR - 1)) * SA + kq * 4], PA);
+#endif
+    CONV3_STAMP(2 + 11 * gq);
     // the three taps are unrolled into straight-line code and every prefetch is issued unconditionally (past the last
     // tile its offsets are out of range: zeros, no memory access), so the loads in flight are counted exactly
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3, ++it) {
+#if SE_CONV3_TWIN != 1
       if (WPL) {
 #pragma unroll
         for (int q = 0; q < NPL; ++q) *reinterpret_cast<f32x4*>(&Bp[q * PB + pr * SA + pc * 8]) = rbp[s3 == 2 ? 1 : 0][q];
@@ -480,7 +518,10 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
 #pragma unroll
         for (int i = 0; i < 2; ++i) split_store_x<NPL, F16>(rb[i], sw, &Bp[(r0 + 32 * i) * SA + kq * 4], PB);
       }
+#endif
       __syncthreads();
+      CONV3_STAMP(3 + 11 * gq + 3 * s3);
+#if SE_CONV3_TWIN != 1
       if (WPL) {
         if (s3 == 0) { load_bp(0); load_bp(1); load_a(); }      // taps 1, 2 of this group, then the next group's halo tile
         else if (s3 == 1) load_bp(0);                            // tap 0 of the next group (slot 0 was stored above)
@@ -488,6 +529,7 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
         load_b();
         if (s3 == 0) load_a();
       }
+#endif
       const int df = ORD == 1 ? s3 - 1 : (ORD == 2 ? 1 - s3 : d.df[3 * gi + s3]);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -517,12 +559,14 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
 #pragma unroll
             for (int qa = 0; qa <= ord; ++qa) {
               const int qb = ord - qa;
-              acc[mt][0] = mfma32_<F16>(af[qa], bf0[qb], acc[mt][0]);
-              acc[mt][1] = mfma32_<F16>(af[qa], bf1[qb], acc[mt][1]);
+              acc[mt][0] = conv3_mfma_<F16>(af[qa], bf0[qb], acc[mt][0]);
+              acc[mt][1] = conv3_mfma_<F16>(af[qa], bf1[qb], acc[mt][1]);
             }
         }
       }
+      CONV3_STAMP(4 + 11 * gq + 3 * s3);
       __syncthreads();
+      CONV3_STAMP(5 + 11 * gq + 3 * s3);
     }
   }
   if (F16) {
@@ -541,6 +585,12 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
   }
 }
 
+// (Round 6: a group-staged form -- the weight tiles of all three taps of a (chunk, dt) group staged with the halo tile, two barriers and 36
+// straight-line MFMAs per group, 51.8 KB of LDS = three workgroups per CU -- was built on the reading of the stamps below that the six
+// barriers per group are the limiter.  Correct (all conv / model tests), and SLOWER: 0.215 -> 0.229 ms (Cin 64), 0.439 -> 0.465 (128),
+// 0.674 -> 0.687 (256), step 54.2 -> 54.6 ms same-box; its MFMA-only twin did not move (0.134 ms at Cin 64): fewer barriers at one
+// workgroup less per CU buy nothing, the MFMA phase is bound by its fragment reads and the short K loop of a tile (144 MFMAs per
+// wave at Cin 64 against a prologue + epilogue of several thousand cycles).  Removed; profiles/r06_conv3_twin.json, r06_conv3_stamps.txt.)
 // ---------------------------------------------------------------------------------------------
 // 3 workgroups per CU (<= 168 VGPRs, no spills in the shapes of the step): qkv 145 -> 133 us, GLU 200 -> 190 us; 4 spills (slower)
 #ifndef K64_OCC
@@ -719,7 +769,7 @@ __global__ __launch_bounds__(256, NT == 3 ? 2 : ((PRE2 || NPL == 3) ? 1 : K64_OC
       for (int r = 0; r < 16; ++r) { acc0[r] *= unscale; acc1[r] *= unscale; }
     }
     // (PRE2 == false: the host sends no residual / swish-gradient / accumulate flag here -> the NOLOAD form)
-    if (vec_ep) gemm_epilogue_vec<PRE2, false, !PRE2>(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s, pre);      // (residuals come in `pre`)
+    if (vec_ep) gemm_epilogue_vec<PRE2, false, !PRE2, PRE2>(g, acc0, acc1, m0, by, b, cs, 36, thr, inv_keep, red, bias_s, pre);      // (residuals come in `pre`)
     else gemm_epilogue_glu_vec(g, acc0, acc1, m0, by, b, cs, 36);
     __syncthreads();
    }

@@ -144,7 +144,8 @@ static __device__ __forceinline__ void load_pro_vec(const float* ps, const float
 // residual, swish gradient): their branches vanish at compile time.  With run-time flags every row group's store sat behind an
 // `s_waitcnt vmcnt(0)` for a load that was never issued -- which also drains the PREVIOUS group's store and any prefetch in flight:
 // the stores of a wave were serialised at one memory round trip each (24 per 256-row tile of the qkv projection = 17 us per tile).
-template <bool HASPRE = false, bool HOISTR = true, bool NOLOAD = false>      // HOISTR: request an in-place residual for all row groups up front (16 VGPRs)
+// DLT: the caller may be sent SE_EPI_DELTA (the row GEMM kernels only: conv3 / W-stationary forms compile the branch out)
+template <bool HASPRE = false, bool HOISTR = true, bool NOLOAD = false, bool DLT = false>      // HOISTR: request an in-place residual for all row groups up front (16 VGPRs)
 static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, const f32x16& acc0, const f32x16& acc1,
                                                          int m0, int by, int b, float* cs, int cs_ld, unsigned thr,
                                                          float inv_keep, float* red, const float* bias_s,
@@ -152,7 +153,7 @@ static __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& g, cons
                                                          float* vmax_defer = nullptr) {   // persistent callers: see below
   const se_gemm_desc& d = g.d;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int Mb = d.To * d.Fo, ep = NOLOAD ? (d.epilogue & ~(SE_EPI_ACCUM | SE_EPI_RESID | SE_EPI_SWISH_GRAD | SE_EPI_DELTA)) : d.epilogue;
+  const int Mb = d.To * d.Fo, ep = (NOLOAD ? (d.epilogue & ~(SE_EPI_ACCUM | SE_EPI_RESID | SE_EPI_SWISH_GRAD)) : d.epilogue) & (DLT ? ~0 : ~SE_EPI_DELTA);
   const long ptile = (long)b * Mb + m0;
   float* __restrict__ Yb = g.Y + ptile * d.ldc + d.c_off;
   const float* __restrict__ Xb = g.AUX ? g.AUX + ptile * d.ldx + d.x_off : nullptr;

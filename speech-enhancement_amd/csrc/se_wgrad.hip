@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradArgs g) {
 // of dW = dY^T X is the ROW index m, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane: both tiles are
 // therefore staged TRANSPOSED in LDS ([column][m], m contiguous).  Every thread owns a 4 (rows) x 4 (columns) block:
 // four 16-B global loads (one per row, 16 lanes = one 256-B row segment), a register transpose, and per column one
-// 8-B store of 4 consecutive m per plane.  LDS rows are laid out in 16-B cells, cell(r, ch) = 9 r + (r >> 4) + ch:
+// 8-B store of 4 consecutive m per plane.  LDS rows are laid out in 16-B cells, cell(r, ch) = 9 r + (r >> 4) + ch (this kernel):
 // the 16-lane groups of both the fragment reads (16 consecutive rows, same ch) and the transposed stores (rows 4 l + j)
 // then touch 16 distinct bank groups -- conflict-free (searched exhaustively; plain padding gives 4-way write conflicts).
 template <int PRO, int NPL>
@@ -467,8 +467,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(WgradArgs g) {
 template <int NPL, bool F16 = false, bool ORD = false>
 __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   constexpr int MR = 64;
-  constexpr int PLY = (9 * 64 + 4) * 8;       // Yt plane: [64 n][64 m],  cell(r, ch) = 9 r + (r >> 4) + ch
-  constexpr int PLX = (10 * 64 + 8) * 8;      // Xt plane: [64 c][80 positions], cell(r, ch) = 10 r + (r >> 3) + ch
+  // (round 6: the cell maps of wgrad3w_f16_kernel below -- conflict-free ds_read_b128 fragments for the hardware's lane groups)
+  constexpr int PLY = 64 * 8 * 8;             // Yt plane: [64 n][8 cells of m], cell(r, ch) = 8 r + (ch ^ gy(r)), gy = (r4, r3, r1 ^ r2)
+  constexpr int PLX = (95 * 7 + 12 * 7 + 10) * 8;      // Xt plane: [64 c][10 cells: positions 0 .. 79], cell(r, ch) = 95 (r >> 3) + 12 (r & 7) + ch
   __shared__ __attribute__((aligned(16))) __bf16 Yt[NPL * PLY];
   __shared__ __attribute__((aligned(16))) __bf16 Xt[NPL * PLX];
   const se_gemm_desc& d = g.d;
@@ -561,7 +562,8 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * q + j;
-      __bf16* dst = halo_layout ? T + (10 * r + (r >> 3)) * 8 + 8 + 4 * rg : T + (9 * r + (r >> 4)) * 8 + 4 * rg;
+      const int gy = ((r >> 2) & 6) | (((r >> 1) ^ (r >> 2)) & 1);
+      __bf16* dst = halo_layout ? T + (95 * (r >> 3) + 12 * (r & 7)) * 8 + 8 + 4 * rg : T + (8 * r + ((rg >> 1) ^ gy)) * 8 + 4 * (rg & 1);
       if constexpr (F16) {
         split_store_h(make_float4(x[0][j], x[1][j], x[2][j], x[3][j]), sc, dst, pln);
       } else {
@@ -573,8 +575,15 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
   int fbase = (int)((mbeg % Mb) % d.Fo);      // frequency index of the step's first row (wave-uniform)
   if (mbeg < mend) load_tiles(mbeg);
   const int ra_ = wn * 32 + (lane & 31), rb_ = wc * 32 + (lane & 31), kg = lane >> 5;
-  const __bf16* yfrag = Yt + (9 * ra_ + (ra_ >> 4)) * 8 + 8 * kg;
-  const __bf16* xrow = Xt + (10 * rb_ + (rb_ >> 3)) * 8;
+  const __bf16* yfrag = Yt + ra_ * 64;
+  int yoff[4];
+  {
+    const int gy = ((ra_ >> 2) & 6) | (((ra_ >> 1) ^ (ra_ >> 2)) & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) yoff[ks] = ((kg | (2 * ks)) ^ gy) * 8;
+  }
+  const __bf16* xrow = Xt + (95 * (rb_ >> 3) + 12 * (rb_ & 7)) * 8;
+  const int outer_el = kg ? 3 * 8 : 6;     // (+ 16 ks) the neighbour dword a lane cannot take from its partner lane (wgrad3w_f16_kernel)
   for (long mb = mbeg; mb < mend; mb += MR) {
     stage_t(rx, Xt, PLX, true, sx);
     stage_t(ry, Yt, PLY, false, sy);
@@ -589,11 +598,11 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
           e *= sx;
           const _Float16 h = (_Float16)e, l = (_Float16)(e - (float)h);
           unsigned short* xt = reinterpret_cast<unsigned short*>(Xt);
-          xt[(10 * r + (r >> 3)) * 8 + ph] = __builtin_bit_cast(unsigned short, h);
-          xt[PLX + (10 * r + (r >> 3)) * 8 + ph] = __builtin_bit_cast(unsigned short, l);
+          xt[(95 * (r >> 3) + 12 * (r & 7)) * 8 + ph] = __builtin_bit_cast(unsigned short, h);
+          xt[PLX + (95 * (r >> 3) + 12 * (r & 7)) * 8 + ph] = __builtin_bit_cast(unsigned short, l);
         } else {
 #pragma unroll
-          for (int pl = 0; pl < NPL; ++pl) { __bf16 h = (__bf16)e; e -= (float)h; Xt[pl * PLX + (10 * r + (r >> 3)) * 8 + ph] = h; }
+          for (int pl = 0; pl < NPL; ++pl) { __bf16 h = (__bf16)e; e -= (float)h; Xt[pl * PLX + (95 * (r >> 3) + 12 * (r & 7)) * 8 + ph] = h; }
         }
       }
     }
@@ -612,17 +621,18 @@ __global__ __launch_bounds__(256) void wgrad3_bf16_kernel(WgradArgs g) {
     if (mb + MR < mend) load_tiles(mb + MR);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int jc = 2 * ks + kg + 1;
       bf16x8 af[NPL];
       unsigned cen[NPL][4], prv[NPL], nxt[NPL];
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) {
-        af[pl] = *reinterpret_cast<const bf16x8*>(yfrag + pl * PLY + 16 * ks);
-        const __bf16* xp = xrow + pl * PLX + 8 * jc;
-        const uint4 cv = *reinterpret_cast<const uint4*>(xp);
+        af[pl] = *reinterpret_cast<const bf16x8*>(yfrag + pl * PLY + yoff[ks]);
+        const __bf16* xp = xrow + pl * PLX + 16 * ks;
+        const uint4 cv = *reinterpret_cast<const uint4*>(xp + 8 * (kg + 1));
+        const unsigned ld = *reinterpret_cast<const unsigned*>(xp + outer_el);      // the outer neighbour dword; the inner one: the partner lane's
         cen[pl][0] = cv.x; cen[pl][1] = cv.y; cen[pl][2] = cv.z; cen[pl][3] = cv.w;
-        prv[pl] = *reinterpret_cast<const unsigned*>(xp - 2);
-        nxt[pl] = *reinterpret_cast<const unsigned*>(xp + 8);
+        const u32x2sw_ s1 = __builtin_amdgcn_permlane32_swap(cv.x, cv.w, false, false);
+        prv[pl] = kg ? s1[0] : ld;
+        nxt[pl] = kg ? ld : s1[1];
       }
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3) {
