@@ -317,7 +317,12 @@ __global__ __launch_bounds__(256) void norm_prelu_bwd_reduce_kernel(
       bool ok = p < p_end;
       long pc = ok ? p : p0;
       v[k] = *reinterpret_cast<const float4*>(Xb + pc * ldx);
+#ifdef SE_NORM_REDUCE_TWIN      // measurement build (tools/inorm_bwd_ab.py): the reduction WITHOUT its dY stream -- what is left of this pass when
+      d[k] = v[k];              // the producer of dY emits the sums from its epilogue (which must still read x): wrong results
+      (void)Db;
+#else
       d[k] = *reinterpret_cast<const float4*>(Db + pc * ldy);
+#endif
       if (!ok) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll

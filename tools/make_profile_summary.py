@@ -87,13 +87,8 @@ def fam(name):
         return f'wgrad3_bf16x{3 if args[0] == "2" else 6}<0>'
     if base == 'gemm_tap_kernel':
         return f'gemm_tap_kernel<{args[0]},{args[1]}>'
-    if base == 'attn_bwd4_kernel':                    # <NW, KPW, NCW, NKTM, MINW>: round 4, scaled fp16 only
-        return 'attn_bwd_f16x3 (+delta, tables, dE reduce) ' + ('n>128' if args[1] != '2' else 'n<=128')
-    if base == 'attn_bwd3_kernel':                    # <KT, GROUP, F16, RING>
-        f16 = len(args) > 2 and args[2] == 'true'
-        return ('attn_bwd_f16x3' if f16 else 'attn_bwd3_bf16x6') + ' (+delta, tables, dE reduce) ' + ('n>128' if args[0] == '6' else 'n<=128')
-    if base == 'attn_fwd2_kernel':
-        return 'attn_fwd2_kernel'
+    if base == 'attn_bwd4_kernel':                    # <NW, KPW, NCW, NKTM, MINW>: scaled fp16 only
+        return 'attn_bwd_f16x3 (+tables, dE reduce) ' + ('n>128' if args[1] != '2' else 'n<=128')
     if base == 'attn_fwd3_kernel':
         return 'attn_fwd3_f16x3' if len(args) > 1 and args[1] == 'true' else 'attn_fwd3_bf16x6'
     if base in ('stft_fused_kernel', 'istft_fused_kernel'):
