@@ -505,6 +505,8 @@ static unsigned* g_ff_stamps = nullptr;
 extern "C" void se_ff_fused_debug_stamps(void* p) { g_ff_stamps = reinterpret_cast<unsigned*>(p); }
 #endif
 
+int se_ff_fused4_launch(const FfFusedArgs& a0, int ncu, void* stream);
+
 extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta,
                                const float* W1, const float* b1, const float* W2T, const float* dR2, float* dX, float* dgamma,
                                float* dbeta, float* dW1, float* db1, float* dW2, float* db2, long M, int hid, float drop_p,
@@ -529,6 +531,7 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
   if (const char* e = getenv("SE_FF_DBG")) a.dbg = atoi(e);
   a.stamps = g_ff_stamps;
 #endif
+  { const char* v = getenv("SE_FF_FUSED_V"); if (v && atoi(v) == 4) return se_ff_fused4_launch(a, ncu, stream); }
   hipLaunchKernelGGL(ff_bwd_fused_kernel, dim3((unsigned)nwg), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_ff_bwd_fused");
 }
