@@ -1,6 +1,5 @@
-// The fused feed-forward backward kernel (se_ff_fused.hip: specialised D / W waves): argument block, transposed-read fragments,
-// fp16 split helpers.  (A symmetric-wave form, 32-row tiles with the weights in registers, was built and measured slower in round
-// 5: 669 vs 509 us per launch -- profiles/r05_ff_fused_ab.txt; removed in round 6.)
+// The fused feed-forward backward kernel (se_ff_fused.hip): argument block; transposed-read fragments and the fp16 split helper it
+// shares with se_lnbwd_fused.hip.
 #pragma once
 #include "se_gemm_dev.h"
 
@@ -15,28 +14,11 @@ struct FfFusedArgs {
   long M; long rows_per_wg; float drop_p; unsigned seed_h, seed_o; float alpha;
   const float* dy_amax; const float* w1_amax; const float* w2t_amax; const float* in_amax; const float* mid_amax; float* out_amax;
   int ln_sexp, hid_sexp;
-  int dbg;                 // timing ablations (SE_FF_DBG; 0 in production: wrong results otherwise) -- see tools/ff_fused_bench.py
-  unsigned* stamps;        // -DSE_FF_STAMPS builds only (tools/ff_fused_stamps.py): s_memtime of every wave's ARRIVAL at every barrier
+  int dbg;                 // (unused)
+  unsigned* stamps;        // -DSE_FF_STAMPS builds only (tools/ff_fused_stamps.py): per-wave cycle accumulators, written once at the end
 };
-// diagnostic build: [workgroup < 4][wave 8][tile < 8][barrier 10] shader-clock stamps (low 32 bits), written by lane 0
-#ifdef SE_FF_STAMPS
-#define FF_STAMP(k) do { if (a.stamps && blockIdx.x < 4 && t < 8 && lane == 0) \
-    a.stamps[(((int)blockIdx.x * 8 + wave) * 8 + t) * 10 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define FF_STAMP(k) do { } while (0)
-#endif
 
 namespace fff {
-constexpr int RS = 144;                 // row stride (bytes) of the LN / dY / weight images: 64 fp16 + 16 B pad (ds_read_b128 rows conflict-free)
-constexpr int PL = 64 * RS;             // their plane stride (hi | lo)
-constexpr int IMG = 2 * PL;             // one [64][64] fp16 (hi, lo) image
-constexpr int ZRS = 136;                // row stride of the exchange images (8-byte accesses only: + 8 B pad)
-constexpr int ZPL = 64 * ZRS, ZIMG = 2 * ZPL;
-constexpr int O_LN = 0, O_DY = IMG, O_W1 = 2 * IMG, O_W2 = 3 * IMG, O_ZS = 4 * IMG;     // ZS: [buffer][Z | S] images
-constexpr int O_PATCH = O_ZS + 4 * ZIMG;            // dLN of the tile: [64 rows][64 channels] fp32
-constexpr int O_B1 = O_PATCH + 64 * 64 * 4, O_GB = O_B1 + 1024, O_BITS = O_GB + 512, LDS_BYTES = O_BITS + 2 * 64 * 8;
-static_assert(LDS_BYTES <= 163840, "one workgroup per CU: at most the CU's 160 KB");
-
 static __device__ __forceinline__ u32x2_ tr8_(const unsigned char* p) {          // ds_read_b64_tr_b16 (EXEC must be full)
   return __builtin_bit_cast(u32x2_, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4f_ __attribute__((address_space(3)))*)(p)));
 }
@@ -71,6 +53,5 @@ static __device__ __forceinline__ void split4_(float y0, float y1, float y2, flo
   y2 = __builtin_fmaf(y2, one, -(float)b[0]); y3 = __builtin_fmaf(y3, one, -(float)b[1]);
   l0 = pk_f16_(y0, y1); l1 = pk_f16_(y2, y3);
 }
-struct Scales { float s_in, s_dy, s_s, s_z, uh, u1, u2, un1, un2, ub1, ub2; };
 }  // namespace fff
 

@@ -1,511 +1,407 @@
-// Fused backward of the Conformer feed-forward module, weight gradients included (round 5).
+// Fused backward of the Conformer feed-forward module, weight gradients included (round 5; this form: round 6).
 //
 //   Scale(0.5, PreNorm(FeedForward)) backward (conformer.py:53-71, 128-145) in ONE persistent launch that reads X, dY (, dR2) and
 //   writes dX: the hidden pre-activations H are recomputed (the forward stores none), the hidden gradient dZ never leaves the CU,
-//   and dW1 / db1 / dW2 / db2 accumulate in registers over the rows a workgroup sweeps and leave once through fp32 atomics.
+//   and dW1 / db1 / dW2 / db2 accumulate on chip over the rows a workgroup sweeps and leave once through fp32 atomics.
 //   Replaces se_ff_bwd_dgrad (1.68 GB per module at 518 736 rows) + two whole-gradient launches (0.67 + 0.70 GB) by 0.53 GB.
 //
-// One 8-wave workgroup per CU, rows in tiles of 64, hidden units in four blocks of 64 ("slots"), scaled split-fp16 arithmetic
-// (se_gemm_dev.h, precision 3).  The waves are SPECIALISED; waves w and w + 4 share a SIMD (MI355X_MICROARCH.md), so every SIMD
-// runs one wave of each kind and its vector-issue slots and its matrix pipe are shared between the two kinds of work:
-//   D waves 0..3 = (row group g = w & 1, half jh = w >> 1): the matrix products of the input-gradient chain and the elementwise
-//     work between them, nothing else --
-//       H^T = W1 LN(X)^T + b1,  dP^T = W2s (mask_o dY)^T   32 hidden units x 32 rows per wave and slot (A = weight rows from LDS, B = the
-//                                                          rows' fragments in registers: the C layout then has the ROW on the lane
-//                                                          and four consecutive hidden units per register quad)
-//       S = Swish(H) mask_h,  dZ = dP mask_h Swish'(H)     registers -> fp16 (hi, lo) -> ROW-major [r][j] exchange images
-//       dLN[32 rows x 32 channels (half jh)] += dZ W1      A = dZ rows out of the exchange image (both hidden halves: the sum over the
-//                                                          slot's 64 hidden units is complete in ONE wave), B = W1 through transposed reads
-//   W waves 4..7 = (kind = dW1 | dW2, hidden half jh): everything else --
-//       dW1[j][c] += sum_r dZ[r][j] LN(X)[r][c]   or   dW2[c][j] += sum_r (mask_o dY)[r][c] S[r][j]     two 32 x 32 tiles per slot, both
-//         operands by hardware-transposed reads of the row-major images (ds_read_b64_tr_b16: the contraction index is the image
-//         row); 128 accumulator registers per wave for the four slots; db1 / db2 by packed dot products on the same fragments;
-//       the tile PROLOGUE (rows of X / dY -> LayerNorm / dropout mask -> fp16 images), the tile EPILOGUE (LayerNorm backward on the dLN
-//         patch the D waves leave, dX, gamma / beta gradients), the dropout mask BITS of the hidden units (one hash per four
-//         units, handed to the D waves as one word per row and slot), the weight blocks of the next slot (L2 -> registers -> LDS)
-//         (L2-warming touches of the next tile's rows were measured and dropped).
-//   W lags D by one slot (the exchange images are double-buffered).  Two barriers per slot: | D: H, dP, S, dZ -> images, W1
-//   fragments of dLN -> registers || W: the previous slot's tiles, mask bits and weight block of the next | D: dLN || W: weight block
-//   -> LDS |; one per tile for the dLN patch and one for the new row images.  Every wave executes the same number of barriers (D and W
-//   run different code paths: s_barrier counts arrivals).
-//   (v1 of this kernel gave the D waves the prologue, the epilogue and the hashes too: 513 us per launch at the bench shape, the D
-//   waves vector-issue-bound at one wave per SIMD -- tools/ff_fused_bench.py, profiles/r05_ff_fused_ablation.txt.)
+// One 8-wave workgroup per CU, rows in tiles of 32, scaled split-fp16 arithmetic (se_gemm_dev.h, precision 3).  Wave w owns hidden
+// units 32 w .. 32 w + 31 for the whole launch: its rows of (alpha W2)^T are REGISTER-resident B fragments, its rows of W1 come out of
+// the W1 image that is resident in LDS anyway (no weight block is staged per tile).  The products of a tile put the unit on the LANE
+// and the tile's rows in the registers:
+//   H[r][j] = LN(X) W1^T + b1,  dP[r][j] = (mask_o dY) W2s      A = the tile's rows (row images in LDS, 16-byte fragments), B = the weights;
+//                                                              C: lane = unit j, register e = row (e & 3) + 8 (e >> 2) + 4 kg
+//   S = Swish(H) mask_h,  dZ = dP mask_h Swish'(H)               registers -> fp16 (hi, lo) words that ARE the 16-deep fragments of
+//   dW1[j][c] += sum_r dZ[r][j] LN[r][c]   (A = dZ, from registers)   the row contraction: no exchange image for the weight gradients; the
+//   dW2[c][j] += sum_r dY[r][c] S[r][j]    (B = S, from registers)    other operand by hardware-transposed reads of the row images, its
+//                                                                      rows taken in the C layout's order
+//   dLN[r][c] = sum_j dZ[r][j] W1[j][c]    contraction over the LANE index: dZ goes through ONE transposed image ZT[unit][row] (S never
+//                                          leaves the registers); wave = (channel half, hidden quarter), both operands by transposed
+//                                          reads (ZT; the W1 image), four partial patches (ds_add_f32 into ONE patch: 9 - 23 K cycles
+//                                          per tile for the 128 instructions)
+// The dropout keep bits of (row, unit) are hashed once per group of four units by the four lanes that share it (each lane takes four
+// of its 16 rows) and exchanged with DPP quad broadcasts; a dropped unit gets sigmoid := 0, which makes Swish and Swish' vanish.
+// All images are unpadded and XOR-swizzled on the chunk the reads move (16 B for the row / W1 images, 8 B for ZT):
+// tools/micro/lds_ff4_bench.hip measures every pattern at the conflict-free rate except the ZT writes (2-way).  Two barriers per tile:
+//   | rows t + 1 requested; keep bits; H, dP; S, dZ, dZ -> ZT; dW2, dW1 | Q | dLN -> patches; LayerNorm / dropout / split of rows t + 1 ->
+//   images | R | LayerNorm backward of tile t out of the patches -> dX | (next tile: no barrier)
+// Measured at the bench shape (518 736 rows, same box, tools/ff_fused_bench.py): 425 - 450 us per launch against 505 - 525 of the form
+// this replaces (round 5: four waves for the input gradient, four for the weight gradients, 64-row tiles, weight blocks staged per
+// quarter of the hidden units, Z and S through row-major images, 18 barriers per 64 rows).  Built on the same segments and declined:
+//   * a two-group schedule (waves 0-3 one segment ahead of waves 4-7: the two waves of a SIMD always in a matrix and a vector segment,
+//     one barrier per segment): the same time within 10 us;
+//   * all fragment reads of a matrix segment issued up front / ring-buffered two units ahead behind scheduling barriers: slower;
+//   * db2 from the dY waves with 32 atomic instructions per workgroup on the TWO cache lines of db2: +115 us per launch -- atomics of
+//     different workgroups to one cache line are serialised at the memory side (~14 ns per wave instruction); hence the fold below.
 #include "se_ff_fused.h"
+namespace ffb {
+constexpr int RW = 128;                  // bytes of a row of the LN / dY / W1 images: 64 fp16, unpadded
+constexpr int PL = 32 * RW, IMG = 2 * PL;            // one tile image (hi | lo)
+constexpr int W1PL = 256 * RW;                        // plane of the W1 image [256 units][64 channels]
+constexpr int ZTR = 64, ZTPL = 256 * ZTR;            // ZT[unit][32 rows] fp16
+constexpr int O_W1 = 0, O_ZT = 2 * W1PL, O_ROWS = O_ZT + 2 * ZTPL;      // ROWS: [buffer][LN | dY] images
+// dLN partial sums of the four hidden quarters, [32 rows][64 channels] fp32 each: quarters 0, 1 in their own 16 KB, quarters 2, 3 over
+// the row images of the CURRENT tile (dead after barrier Q; rewritten by the prologue of tile t + 2 after barrier Q of tile t + 1)
+constexpr int O_PATCH = O_ROWS + 2 * 2 * IMG, O_GB = O_PATCH + 2 * 32 * 64 * 4, O_DB2 = O_GB + 512, LDS_BYTES = O_DB2 + 256 * 32;
+// DB2: lane-private column sums of mask_o dY (the 256 lanes of the dY waves x 8 channels): registers are the scarce resource
+static_assert(LDS_BYTES <= 163840, "one workgroup per CU");
+// swizzle of the 16-byte chunk index of row r: the four rows of one transposed read and the 16 rows of one ds_read_b128 lane group
+// all land in different banks
+static __device__ __forceinline__ int sw16(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
-// ------------------------------------------------------------------------------------------------ D waves
-static __device__ __forceinline__ void ff_fused_D(const FfFusedArgs& a, unsigned char* sm, const int wave, const int lane,
-                                                  const long mbeg, const long mend, const int ntile, const fff::Scales& sc) {
-  using namespace fff;
-  const int g = wave & 1, jh = wave >> 1;
-  const int r = lane & 31, kg = lane >> 5;
-  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const float inv_keep = drop_inv_keep(a.drop_p);
-  const bool dr = a.drop_p > 0.f;
-  float one;
-  asm volatile("s_mov_b32 %0, 1.0" : "=s"(one));
-  const float* b1s = reinterpret_cast<const float*>(sm + O_B1);
-  // per-lane LDS bases
-  const unsigned char* const fragLN = sm + O_LN + (32 * g + r) * RS + 16 * kg;          // + pl * PL + 32 * ks
-  const unsigned char* const fragDY = sm + O_DY + (32 * g + r) * RS + 16 * kg;
-  const unsigned char* const w1a = sm + O_W1 + (32 * jh + r) * RS + 16 * kg;            // A fragments: weight row 32 jh + (lane & 31)
-  const unsigned char* const w2a = sm + O_W2 + (32 * jh + r) * RS + 16 * kg;
-  // transposed reads of the W1 image for dLN's B operand: column = channel 32 jh + (lane & 31), contraction = the slot's 64 hidden units
-  const unsigned char* const w1t = sm + O_W1 + (8 * (gi >> 1) + q4) * RS + (32 * jh + 16 * (gi & 1) + 4 * p4) * 2;      // + pl * PL + 16 ks * RS
-  const int zoff = (32 * g + r) * ZRS;                                                   // this lane's row of the exchange images
-  const int zcol = (32 * jh + 4 * kg) * 2;                                               // + 16 q bytes: quad q of that row
-  const unsigned char* const bitw = sm + O_BITS + (32 * g + r) * 8 + 4 * jh;             // + 512 * (s & 1): this lane's mask word
-  float* const patch = reinterpret_cast<float*>(sm + O_PATCH);
-  const float* gbs = reinterpret_cast<const float*>(sm + O_GB);
-  const float mkS = inv_keep * sc.s_s, mkZ = inv_keep * sc.u1;
-  float agk = 0.f, abk = 0.f, xmax = 0.f;                  // gamma / beta gradients of channel 8 ecq + err (see the epilogue)
-  // ---- tile epilogue (in the window between the patch barrier (c) and the next tile's images (p), where the D waves would wait for the
-  // W waves' prologue): LayerNorm backward of rows 16 wave + err + 8 i (i = 0, 1), channels 8 ecq .. + 7, from the dLN patch ----
-  const int err = lane >> 3, ecq = lane & 7;
-  float4 ex[2][2], ey[2][2], er[2][2];
-  float2 est[2];
-  auto epilogue_load = [&](long m0) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      long mr = m0 + 16 * wave + err + 8 * i;
-      if (mr > a.M - 1) mr = a.M - 1;
-      if (a.dbg & 16) mr = mbeg + 16 * wave + err + 8 * i;            // (ablation: the first tile's rows again -- cache hits)
-      est[i] = *reinterpret_cast<const float2*>(a.stats + 2 * mr);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const long off = mr * 64 + 8 * ecq + 4 * k;
-        ex[i][k] = *reinterpret_cast<const float4*>(a.X + off);
-        ey[i][k] = *reinterpret_cast<const float4*>(a.dY + off);
-        er[i][k] = a.dR2 ? *reinterpret_cast<const float4*>(a.dR2 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  };
-  auto epilogue = [&](long m0) {
-    const long rows_ok = mend - m0 < 64 ? mend - m0 : 64;
-    const __amdgpu_buffer_rsrc_t Xrs = make_rsrc_(a.dX + m0 * 64, (unsigned)(rows_ok * 64 * 4));
-    const float4 gmA = *reinterpret_cast<const float4*>(gbs + 8 * ecq), gmB = *reinterpret_cast<const float4*>(gbs + 8 * ecq + 4);
-    const float gl8[8] = {gmA.x, gmA.y, gmA.z, gmA.w, gmB.x, gmB.y, gmB.z, gmB.w};
-    float ag[8], ab[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { ag[e] = 0.f; ab[e] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rl = 16 * wave + err + 8 * i;               // row inside the tile
-      const bool ok = m0 + rl < mend;
-      const float4 pa = *reinterpret_cast<const float4*>(patch + rl * 64 + 8 * ecq), pb = *reinterpret_cast<const float4*>(patch + rl * 64 + 8 * ecq + 4);
-      const float dv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-      const float xs[8] = {ex[i][0].x, ex[i][0].y, ex[i][0].z, ex[i][0].w, ex[i][1].x, ex[i][1].y, ex[i][1].z, ex[i][1].w};
-      const float mean = est[i].x, rstd = est[i].y;
-      float xh[8], dxh[8], s1 = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        xh[e] = (xs[e] - mean) * rstd;
-        dxh[e] = dv[e] * gl8[e];
-        s1 += dxh[e]; s2 += dxh[e] * xh[e];
-        if (ok) { ag[e] += dv[e] * xh[e]; ab[e] += dv[e]; }
-      }
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      s1 *= (1.f / 64.f); s2 *= (1.f / 64.f);
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const float4 r1 = ey[i][k], r2 = er[i][k];
-        float o4[4] = {r1.x + r2.x, r1.y + r2.y, r1.z + r2.z, r1.w + r2.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] += rstd * (dxh[4 * k + e] - s1 - xh[4 * k + e] * s2);
-        buf_store4_(Xrs, (unsigned)((rl * 64 + 8 * ecq + 4 * k) * 4), make_float4(o4[0], o4[1], o4[2], o4[3]));
-        if (ok) xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
-      }
-    }
-    // the tile's per-lane sums folded over the 8 row lanes; lane (err, ecq) keeps the total of channel 8 ecq + err
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float sg = ag[e], sb = ab[e];
-      sg += __shfl_xor(sg, 8, 64); sb += __shfl_xor(sb, 8, 64);
-      sg = xor16_sum_(sg); sb = xor16_sum_(sb);
-      sg = xor32_sum_(sg); sb = xor32_sum_(sb);
-      agk += err == e ? sg : 0.f;
-      abk += err == e ? sb : 0.f;
-    }
-  };
-
-  bf16x8 lnf[4][2], dyf[4][2];
-  f32x16 gl;
-  // (L2-warming touches of the next tile's rows were tried twice -- issued by the W waves every wait for a weight block also waited
-  // for them: +130 us per launch; issued by the D waves, whose next wait is a tile away: still +59 us -- and dropped)
-
-  __syncthreads();                                       // (0) b1 / gamma / beta staged, weight block 0 in LDS
-  for (int t = 0; t < ntile; ++t) {
-    FF_STAMP(0);
-    __syncthreads();                                     // (p) the tile's LN(X) / mask_o dY images and the mask bits of slot 0 are complete
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        lnf[ks][pl] = *reinterpret_cast<const bf16x8*>(fragLN + pl * PL + 32 * ks);
-        dyf[ks][pl] = *reinterpret_cast<const bf16x8*>(fragDY + pl * PL + 32 * ks);
-      }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) gl[e] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      // ================= A(s) =================
-      f32x16 ah, ad;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { ah[e] = 0.f; ad[e] = 0.f; }
-      // H first, THEN dP: the twelve dP products run on the matrix pipe while the vector unit already works on the part of the
-      // elementwise chain that needs H only (sigmoid, Swish, Swish') -- interleaved, both accumulators finished together and the
-      // whole chain waited behind all 24 products
-      if (!(a.dbg & 4)) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 a1h = *reinterpret_cast<const bf16x8*>(w1a + 32 * ks), a1l = *reinterpret_cast<const bf16x8*>(w1a + PL + 32 * ks);
-          ah = mfma32_<true>(a1h, lnf[ks][1], ah);
-          ah = mfma32_<true>(a1l, lnf[ks][0], ah);
-          ah = mfma32_<true>(a1h, lnf[ks][0], ah);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 a2h = *reinterpret_cast<const bf16x8*>(w2a + 32 * ks), a2l = *reinterpret_cast<const bf16x8*>(w2a + PL + 32 * ks);
-          ad = mfma32_<true>(a2h, dyf[ks][1], ad);
-          ad = mfma32_<true>(a2l, dyf[ks][0], ad);
-          ad = mfma32_<true>(a2h, dyf[ks][0], ad);
-        }
-      }
-      // keep bits of this lane's row: nibble 2 q + kg of the word = the quad's four hidden units
-      unsigned mbits = 0xffffffffu;
-      if (dr) mbits = *reinterpret_cast<const unsigned*>(bitw + 512 * (s & 1)) >> (4 * kg);
-      unsigned char* const zrow = sm + O_ZS + (s & 1) * 2 * ZIMG + zoff + zcol;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int jq = 64 * s + 32 * jh + 8 * q + 4 * kg;       // first of the quad's four consecutive hidden units
-        const float4 b4 = *reinterpret_cast<const float4*>(b1s + jq);
-        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-        float sv[4], zv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int i = 4 * q + e;
-          const float h = fmaf(ah[i], sc.uh, bb[e]);
-          const float sg = (a.dbg & 1) ? 0.5f : sigmoidf_(h);
-          const float s0 = h * sg;
-          const float sw = fmaf(s0, 1.0f - sg, sg);             // Swish'(h) = sg (1 + h (1 - sg))
-          const bool keep = (mbits >> (8 * q + e)) & 1u;
-          sv[e] = keep ? s0 * mkS : 0.f;
-          zv[e] = keep ? ad[i] * sw * mkZ : 0.f;                // (mkZ carries the un-scaling of the accumulator AND dZ's scale)
-        }
-        unsigned zh0, zh1, zl0, zl1, sh0, sh1, sl0, sl1;
-        split4_(sv[0], sv[1], sv[2], sv[3], one, sh0, sh1, sl0, sl1);
-        split4_(zv[0], zv[1], zv[2], zv[3], one, zh0, zh1, zl0, zl1);
-        *reinterpret_cast<u32x2_*>(zrow + 16 * q) = (u32x2_){zh0, zh1};
-        *reinterpret_cast<u32x2_*>(zrow + ZPL + 16 * q) = (u32x2_){zl0, zl1};
-        *reinterpret_cast<u32x2_*>(zrow + ZIMG + 16 * q) = (u32x2_){sh0, sh1};
-        *reinterpret_cast<u32x2_*>(zrow + ZIMG + ZPL + 16 * q) = (u32x2_){sl0, sl1};
-      }
-      // W1 fragments of the dLN product out of the image BEFORE the barrier (the W waves overwrite the weight images after it)
-      bf16x8 wb[4][2];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) wb[ks][pl] = trfrag_<RS>(w1t + pl * PL + 16 * ks * RS);
-      FF_STAMP(1 + 2 * s);
-      __syncthreads();                                   // (a)
-      // ================= B(s): dLN of (rows of group g) x (channels of half jh) over the slot's 64 hidden units =================
-      if (!(a.dbg & 8)) {
-        const unsigned char* zr = sm + O_ZS + (s & 1) * 2 * ZIMG + zoff + 16 * kg;       // dZ rows as A fragments (natural order)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const u32x2_ h0 = *reinterpret_cast<const u32x2_*>(zr + 32 * ks), h1 = *reinterpret_cast<const u32x2_*>(zr + 32 * ks + 8);
-          const u32x2_ l0 = *reinterpret_cast<const u32x2_*>(zr + ZPL + 32 * ks), l1 = *reinterpret_cast<const u32x2_*>(zr + ZPL + 32 * ks + 8);
-          const bf16x8 zhf = __builtin_bit_cast(bf16x8, (u32x4_){h0[0], h0[1], h1[0], h1[1]});
-          const bf16x8 zlf = __builtin_bit_cast(bf16x8, (u32x4_){l0[0], l0[1], l1[0], l1[1]});
-          gl = mfma32_<true>(zhf, wb[ks][1], gl);
-          gl = mfma32_<true>(zlf, wb[ks][0], gl);
-          gl = mfma32_<true>(zhf, wb[ks][0], gl);
-        }
-      }
-      FF_STAMP(2 + 2 * s);
-      __syncthreads();                                   // (b)
-    }
-    // the tile's dLN -> patch [row][channel] (C layout: row = (e & 3) + 8 (e >> 2) + 4 kg of the group, column = lane & 31 of the half)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) patch[(32 * g + (e & 3) + 8 * (e >> 2) + 4 * kg) * 64 + 32 * jh + r] = gl[e] * sc.u2;
-    const long m0 = mbeg + 64L * t;
-    epilogue_load(m0);                                   // (X, dY: L2 hits -- the prologue read them; dR2: warmed by the W waves)
-    FF_STAMP(9);
-    __syncthreads();                                     // (c) patch complete; the W waves have finished with the tile's row images
-    epilogue(m0);
-  }
-  if (a.out_amax) {
-    xmax = wave_max(xmax);
-    if (lane == 0) amax_raise_(a.out_amax, xmax);
-  }
-  // gamma / beta gradients: one atomic per channel and wave (lane (err, ecq) holds channel 8 ecq + err)
-  atomicAdd(&a.dgamma[8 * ecq + err], agk);
-  atomicAdd(&a.dbeta[8 * ecq + err], abk);
+static __device__ __forceinline__ bf16x8 tr2_(const unsigned char* p0, const unsigned char* p1) {
+  const u32x2_ t0 = fff::tr8_(p0), t1 = fff::tr8_(p1);
+  return __builtin_bit_cast(bf16x8, (u32x4_){t0[0], t0[1], t1[0], t1[1]});
 }
-
-// ------------------------------------------------------------------------------------------------ W waves
-// (KIND is a template parameter: as a run-time value -- wave-uniform, but the compiler did not know -- every `kind` test inside the
-// unrolled product loops became a branch of its own)
-template <int kind>
-static __device__ __forceinline__ void ff_fused_W(const FfFusedArgs& a, unsigned char* sm, const int wave, const int lane,
-                                                  const long mbeg, const long mend, const int ntile, const fff::Scales& sc) {
-  using namespace fff;
-  const int w4 = wave - 4, jh = w4 & 1;                        // kind 0: dW1 (Z, LN), kind 1: dW2 (dY, S)
-  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
-  const int tidw = w4 * 64 + lane;
-  const unsigned thr = drop_thr(a.drop_p);
-  const float inv_keep = drop_inv_keep(a.drop_p);
-  const bool dr = a.drop_p > 0.f;
-  const float* gbs = reinterpret_cast<const float*>(sm + O_GB);
-  // transposed-read address of this lane inside a [64 rows = contraction][64 cols] image with row stride STR:
-  //   (8 kg + q4) * STR + (16 (gi & 1) + 4 p4) * 2   + pl * plane + 16 ks * STR + 2 * col0
-  const int trz = (8 * (gi >> 1) + q4) * ZRS + (16 * (gi & 1) + 4 * p4) * 2;
-  const int trr = (8 * (gi >> 1) + q4) * RS + (16 * (gi & 1) + 4 * p4) * 2;
-  const unsigned char* const shb = sm + O_ZS + (kind == 0 ? 0 : ZIMG) + trz + 64 * jh;   // shared operand: Z (dW1) or S (dW2), columns 32 jh ..
-  const unsigned char* const vab = sm + (kind == 0 ? O_LN : O_DY) + trr;                  // varying operand: LN (dW1) or dY (dW2), + 64 nt
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[jb][nt][e] = 0.f;
-  float bs[4] = {0.f, 0.f, 0.f, 0.f};      // kind 0: db1 of the wave's hidden units of slot jb; kind 1 (jh == 0): bs[nt] = db2 of channel half nt
-  // ---- weight blocks: L2 -> registers -> LDS (buffer loads: one wave-uniform descriptor per matrix + ONE 32-bit lane offset) ----
-  float4 stg[8];
-  const __amdgpu_buffer_rsrc_t W1rs = make_rsrc_(a.W1, 2u * 256u * 64u * 2u), W2rs = make_rsrc_(a.W2T, 2u * 256u * 64u * 2u);
-  const unsigned stoff = (unsigned)((tidw >> 3) * 128 + (tidw & 7) * 16);               // row (tidw >> 3) of the block, 16-byte chunk tidw & 7
-  auto stage_load = [&](int jb) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)          // i = matrix * 4 + plane * 2 + row half
-      stg[i] = buf_load4_((i >> 2) ? W2rs : W1rs, stoff + (unsigned)(((i >> 1) & 1) * 256 * 128 + (64 * jb + 32 * (i & 1)) * 128));
-  };
-  auto stage_store = [&]() {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = (tidw + 256 * (i & 1)) >> 3, ch = tidw & 7;
-      *reinterpret_cast<float4*>(sm + ((i >> 2) ? O_W2 : O_W1) + ((i >> 1) & 1) * PL + row * RS + 16 * ch) = stg[i];
-    }
-  };
-  // ---- the two 32 x 32 tiles of slot jb out of exchange buffer (jb & 1) ----
-  auto wgrad = [&](auto jbc) {
-    constexpr int jb = decltype(jbc)::value;
-    if (a.dbg & 128) return;
-    const unsigned char* sh = shb + (jb & 1) * 2 * ZIMG;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 sh_h, sh_l;
-      if (kind == 0) {                    // db1 = sum over the rows of dZ: this lane's part, from the fragments it loads anyway
-        sh_h = trfrag_sum_<ZRS>(sh + 16 * ks * ZRS, bs[jb]); sh_l = trfrag_sum_<ZRS>(sh + ZPL + 16 * ks * ZRS, bs[jb]);
-      } else {
-        sh_h = trfrag_<ZRS>(sh + 16 * ks * ZRS); sh_l = trfrag_<ZRS>(sh + ZPL + 16 * ks * ZRS);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        bf16x8 va_h, va_l;
-        if (jb == 0 && kind == 1) {       // db2 = column sums of mask_o dY, once per tile (first slot; the jh = 0 wave flushes it)
-          va_h = trfrag_sum_<RS>(vab + 16 * ks * RS + 64 * nt, bs[nt]); va_l = trfrag_sum_<RS>(vab + PL + 16 * ks * RS + 64 * nt, bs[nt]);
-        } else {
-          va_h = trfrag_<RS>(vab + 16 * ks * RS + 64 * nt); va_l = trfrag_<RS>(vab + PL + 16 * ks * RS + 64 * nt);
-        }
-        if (kind == 0) {          // dW1[j][c]: A = Z^T (row j on the lane), B = LN (column c on the lane)
-          acc[jb][nt] = mfma32_<true>(sh_h, va_l, acc[jb][nt]);
-          acc[jb][nt] = mfma32_<true>(sh_l, va_h, acc[jb][nt]);
-          acc[jb][nt] = mfma32_<true>(sh_h, va_h, acc[jb][nt]);
-        } else {                  // dW2[c][j]: A = dY^T (row c), B = S (column j)
-          acc[jb][nt] = mfma32_<true>(va_h, sh_l, acc[jb][nt]);
-          acc[jb][nt] = mfma32_<true>(va_l, sh_h, acc[jb][nt]);
-          acc[jb][nt] = mfma32_<true>(va_h, sh_h, acc[jb][nt]);
-        }
-      }
-    }
-  };
-  // ---- dropout keep bits of the hidden units of slot s of the tile at m0: lane = (row tidw >> 2, groups 4 (tidw & 3) .. + 3) ----
-  auto mask_bits = [&](long m0, int s) {
-    // (compiler barriers: scheduled together with the weight-block loads and the transposed reads of the products, the four
-    // hashes' temporaries were the last registers this wave did not have)
-    asm volatile("" ::: "memory");
-    if (!dr || (a.dbg & 2)) return;
-    const int row = tidw >> 2, part = tidw & 3;
-    const unsigned grp0 = (unsigned)((m0 + row) * 64 + 16 * s + 4 * part);       // (m * 256 + 64 s + 16 part) >> 2
-    unsigned bits = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      unsigned f[4];
-      drop_fields(a.seed_h, grp0 + k, f);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) bits |= (f[e] >= thr ? 1u : 0u) << (4 * k + e);
-    }
-    *reinterpret_cast<unsigned short*>(sm + O_BITS + 512 * (s & 1) + row * 8 + 2 * part) = (unsigned short)bits;
-    asm volatile("" ::: "memory");
-  };
-  // ---- tile prologue: lane = (row tidw >> 2, channel octets part and part + 4 of X AND of dY) ----
-  const int prow = tidw >> 2, ppart = tidw & 3;
-  float4 raw[8];                         // [tensor][octet][half]
-  float2 rst;
-  // (buffer loads: wave-uniform tile bases + ONE 32-bit lane offset; rows past M come back as zeros from the range check -- flat
-  // 64-bit lane addresses were kept as precomputed pairs across the tile loop and spilled)
-  const unsigned roff = (unsigned)(prow * 256 + ppart * 32);
-  auto load_raw = [&](long m0) {
-    const long avail = a.M - m0 < 64 ? a.M - m0 : 64;
-    const __amdgpu_buffer_rsrc_t Xr = make_rsrc_(a.X + m0 * 64, (unsigned)(avail * 256)), Yr = make_rsrc_(a.dY + m0 * 64, (unsigned)(avail * 256));
-    const __amdgpu_buffer_rsrc_t Sr = make_rsrc_(a.stats + m0 * 2, (unsigned)(avail * 8));
-    rst = buf_load2_(Sr, (unsigned)(prow * 8));
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        raw[2 * o + hf] = buf_load4_(Xr, roff + (unsigned)(128 * o + 16 * hf));
-        raw[4 + 2 * o + hf] = buf_load4_(Yr, roff + (unsigned)(128 * o + 16 * hf));
-      }
-  };
-  auto prologue_store = [&](long m0) {
-    const long m = m0 + prow;
-    const bool ok = m < mend;
-    const float mean = rst.x, rstd = rst.y;
-#pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int c0 = 8 * (ppart + 4 * o);
-      float x[8], y[8];
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        const float4 gm = *reinterpret_cast<const float4*>(gbs + c0 + 4 * hf), bt = *reinterpret_cast<const float4*>(gbs + 64 + c0 + 4 * hf);
-        const float4 w = raw[2 * o + hf];
-        x[4 * hf] = (w.x - mean) * rstd * gm.x + bt.x; x[4 * hf + 1] = (w.y - mean) * rstd * gm.y + bt.y;
-        x[4 * hf + 2] = (w.z - mean) * rstd * gm.z + bt.z; x[4 * hf + 3] = (w.w - mean) * rstd * gm.w + bt.w;
-        float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (dr) d4 = drop_scale4(a.seed_o, (unsigned)(m * 64 + c0 + 4 * hf), thr, inv_keep);
-        const float4 v = raw[4 + 2 * o + hf];
-        y[4 * hf] = v.x * d4.x; y[4 * hf + 1] = v.y * d4.y; y[4 * hf + 2] = v.z * d4.z; y[4 * hf + 3] = v.w * d4.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { x[e] = ok ? x[e] : 0.f; y[e] = ok ? y[e] : 0.f; }
-      bf16x8 ox[2], oy[2];
-      split_planes8_h(x, sc.s_in, ox);
-      split_planes8_h(y, sc.s_dy, oy);
-      unsigned char* p = sm + O_LN + prow * RS + 2 * c0;
-      *reinterpret_cast<bf16x8*>(p) = ox[0];
-      *reinterpret_cast<bf16x8*>(p + PL) = ox[1];
-      *reinterpret_cast<bf16x8*>(p + (O_DY - O_LN)) = oy[0];
-      *reinterpret_cast<bf16x8*>(p + (O_DY - O_LN) + PL) = oy[1];
-    }
-  };
-  // (no run-time switch may skip a stage_load / load_raw: a skipped load makes the OLD register contents live across the whole tile
-  // loop -- 66 registers of a wave that has 128 accumulators)
-  stage_load(0);
-  load_raw(mbeg);
-  stage_store();
-  mask_bits(mbeg, 0);
-  __syncthreads();                                       // (0) gamma / beta (and b1) staged
-  for (int t = 0; t < ntile; ++t) {
-    const long m0 = mbeg + 64L * t;
-    const bool more = t + 1 < ntile;
-    // the tile's rows (warmed into L2 by the touches of the previous tile; the D waves run that tile's epilogue meanwhile).  NOT requested
-    // before the last slot's weight-gradient tiles: 34 more live registers there spilled
-    if (t > 0) load_raw(m0);
-    prologue_store(m0);
-    FF_STAMP(0);
-    __syncthreads();                                     // (p)
-    mask_bits(m0, 1);
-    stage_load(1);
-    FF_STAMP(1);
-    __syncthreads();                                     // (a0)
-    stage_store();
-    FF_STAMP(2);
-    __syncthreads();                                     // (b0)
-    wgrad(std::integral_constant<int, 0>{});
-    mask_bits(m0, 2);
-    stage_load(2);
-    FF_STAMP(3);
-    __syncthreads();                                     // (a1)
-    stage_store();
-    FF_STAMP(4);
-    __syncthreads();                                     // (b1)
-    wgrad(std::integral_constant<int, 1>{});
-    mask_bits(m0, 3);
-    stage_load(3);
-    FF_STAMP(5);
-    __syncthreads();                                     // (a2)
-    stage_store();
-    FF_STAMP(6);
-    __syncthreads();                                     // (b2)
-    wgrad(std::integral_constant<int, 2>{});
-    if (more) mask_bits(m0 + 64, 0);
-    stage_load(0);
-    FF_STAMP(7);
-    __syncthreads();                                     // (a3)
-    stage_store();
-    FF_STAMP(8);
-    __syncthreads();                                     // (b3)
-    wgrad(std::integral_constant<int, 3>{});
-    FF_STAMP(9);
-    __syncthreads();                                     // (c) every W wave has finished with the tile's row images
-  }
-  // ---- flush: C layout [row = (e & 3) + 8 (e >> 2) + 4 kg][col = lane & 31] ----
-  const int col = lane & 31, kg = lane >> 5;
-#pragma unroll
-  for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = (e & 3) + 8 * (e >> 2) + 4 * kg;
-        if (kind == 0) atomicAdd(&a.dW1[(64 * jb + 32 * jh + row) * 64 + 32 * nt + col], acc[jb][nt][e] * sc.un1);
-        else atomicAdd(&a.dW2[(32 * nt + row) * 256 + 64 * jb + 32 * jh + col], acc[jb][nt][e] * sc.un2);
-      }
-  if (kind == 0) {
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-      const float v = bs[jb] + __shfl_xor(bs[jb], 32, 64);
-      if (kg == 0) atomicAdd(&a.db1[64 * jb + 32 * jh + col], v * sc.ub1);
-    }
-  } else if (jh == 0 && a.db2) {
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const float v = bs[nt] + __shfl_xor(bs[nt], 32, 64);
-      if (kg == 0) atomicAdd(&a.db2[32 * nt + col], v * sc.ub2);
-    }
-  }
+template <int CTRL>
+static __device__ __forceinline__ float dpp_(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
 }
+// sum over the 16 lanes of a DPP row, on every lane (quad xor 1, quad xor 2, half mirror, mirror)
+static __device__ __forceinline__ float row16_sum_(float v) {
+  v += dpp_<0xB1>(v); v += dpp_<0x4E>(v); v += dpp_<0x141>(v); v += dpp_<0x140>(v);
+  return v;
+}
+}  // namespace ffb
+
 
 __global__ __launch_bounds__(512, 2) void ff_bwd_fused_kernel(FfFusedArgs a) {
-  using namespace fff;
-  __shared__ __attribute__((aligned(16))) unsigned char sm[LDS_BYTES];
+  using namespace ffb;
+  using fff::split4_;
+  __shared__ __attribute__((aligned(128))) unsigned char sm[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long mbeg = (long)blockIdx.x * a.rows_per_wg;
   long mend = mbeg + a.rows_per_wg;
   if (mend > a.M) mend = a.M;
   if (mbeg >= mend) return;                              // (whole workgroup: block-uniform)
-  const int ntile = (int)((mend - mbeg + 63) / 64);
+  const int ntile = (int)((mend - mbeg + 31) / 32);
   f16_clamp_mode_();
-  Scales sc;
+#ifdef SE_FF_STAMPS      // diagnostic build: scalar accumulators of the work (barrier release -> arrival) and the wait per barrier; no memory traffic in the loop
+  unsigned long long tp_ = __builtin_amdgcn_s_memtime();
+  const unsigned long long t00_ = tp_;
+  unsigned wk_[2] = {0, 0}, wt_[2] = {0, 0};
+#define FF_SYNC(k) do { const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); wk_[k] += (unsigned)(t1_ - tp_); __syncthreads(); \
+    tp_ = __builtin_amdgcn_s_memtime(); wt_[k] += (unsigned)(tp_ - t1_); } while (0)
+#else
+#define FF_SYNC(k) __syncthreads()
+#endif
+  const float inv_keep = drop_inv_keep(a.drop_p);
+  const unsigned thr = drop_thr(a.drop_p);
+  const bool dr = a.drop_p > 0.f;
+  float s_in, s_dy, uh, u2, un1, un2, ub1, ub2, mkS, mkZ;
   {
-    const float inv_keep = drop_inv_keep(a.drop_p);
     const float dy_amax = __builtin_nontemporal_load(a.dy_amax), w2_amax = __builtin_nontemporal_load(a.w2t_amax);
     const int e_dy = f16_sexp_(dy_amax), e_w2 = f16_sexp_(w2_amax), e_w1 = f16_sexp_(__builtin_nontemporal_load(a.w1_amax));
     const int e_in = operand_sexp_(a.in_amax, a.ln_sexp), e_mid = operand_sexp_(a.mid_amax, a.hid_sexp);
-    // |dZ| <= amax(dY) inv_keep^2 64 amax(W2s) 1.1 (64 terms, |Swish'| < 1.1): a few binades loose, as in ff_bwd_kernel
     const int e_dz = f16_sexp_(dy_amax * inv_keep * inv_keep * 64.f * w2_amax * 1.1f);
-    sc.s_in = exp2i_(e_in); sc.s_dy = exp2i_(e_dy); sc.s_s = exp2i_(e_mid); sc.s_z = exp2i_(e_dz);
-    sc.uh = exp2i_(-e_in - e_w1);
-    sc.u1 = exp2i_(-e_dy - e_w2 + e_dz);                 // accumulator of dP -> dZ at its fp16 scale
-    sc.u2 = exp2i_(-e_dz - e_w1);
-    sc.un1 = exp2i_(-e_dz - e_in); sc.un2 = a.alpha * exp2i_(-e_mid - e_dy);
-    sc.ub1 = exp2i_(-e_dz); sc.ub2 = a.alpha * exp2i_(-e_dy);
+    s_in = exp2i_(e_in); s_dy = exp2i_(e_dy);
+    uh = exp2i_(-e_in - e_w1);
+    mkS = inv_keep * exp2i_(e_mid);
+    mkZ = inv_keep * exp2i_(-e_dy - e_w2 + e_dz);
+    u2 = exp2i_(-e_dz - e_w1);
+    un1 = exp2i_(-e_dz - e_in); un2 = a.alpha * exp2i_(-e_mid - e_dy);
+    ub1 = exp2i_(-e_dz); ub2 = a.alpha * exp2i_(-e_dy);
   }
-  if (tid < 256) reinterpret_cast<float*>(sm + O_B1)[tid] = a.b1[tid];
-  if (tid < 128) reinterpret_cast<float*>(sm + O_GB)[tid] = tid < 64 ? a.gamma[tid] : a.beta[tid - 64];
-  if (wave < 4) ff_fused_D(a, sm, wave, lane, mbeg, mend, ntile, sc);
-  else if (wave < 6) ff_fused_W<0>(a, sm, wave, lane, mbeg, mend, ntile, sc);
-  else ff_fused_W<1>(a, sm, wave, lane, mbeg, mend, ntile, sc);
+  float one;
+  asm volatile("s_mov_b32 %0, 1.0" : "=s"(one));
+  const float* gbs = reinterpret_cast<const float*>(sm + O_GB);
+  float* const patch = reinterpret_cast<float*>(sm + O_PATCH);
+  const int j = lane & 31, kg = lane >> 5;
+  const int gi = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, kgt = gi >> 1;
+  {
+    const __bf16* W1p = reinterpret_cast<const __bf16*>(a.W1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int id = tid + 512 * i, pl = id >> 11, row = (id >> 3) & 255, ch = id & 7;
+      const float4 v = *reinterpret_cast<const float4*>(W1p + (size_t)pl * 256 * 64 + row * 64 + 8 * ch);
+      *reinterpret_cast<float4*>(sm + O_W1 + pl * W1PL + row * RW + ((ch ^ sw16(row)) << 4)) = v;
+    }
+    if (tid < 128) reinterpret_cast<float*>(sm + O_GB)[tid] = tid < 64 ? a.gamma[tid] : a.beta[tid - 64];
+    if (tid < 256) { float* z = reinterpret_cast<float*>(sm + O_DB2) + (tid << 3); *reinterpret_cast<float4*>(z) = make_float4(0.f, 0.f, 0.f, 0.f); *reinterpret_cast<float4*>(z + 4) = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
+  bf16x8 W2b[4][2];
+  {
+    const size_t wpl = (size_t)256 * 64;
+    const __bf16* p2 = reinterpret_cast<const __bf16*>(a.W2T) + (size_t)(32 * wave + j) * 64 + 8 * kg;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) {
+        W2b[ks][pl] = *reinterpret_cast<const bf16x8*>(p2 + pl * wpl + 16 * ks);
+      }
+  }
+  const float bias = a.b1[32 * wave + j];
+  f32x16 aw1[2], aw2[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { aw1[nt][e] = 0.f; aw2[nt][e] = 0.f; }
+  float bs1 = 0.f;
+  float agk = 0.f, abk = 0.f, xmax = 0.f;
+  const int fragA = j * RW, x16 = ((kg ^ sw16(j)) << 4);
+  const int trA0 = ((4 * kgt + q4) * RW + (((2 * (gi & 1) + (p4 >> 1)) ^ (((q4 >> 1) << 2) | kgt)) << 4) + 8 * (p4 & 1));
+  const int trA1 = (trA0 ^ 32) + 8 * RW;
+  const int ztw = O_ZT + (32 * wave + j) * ZTR + ((kg ^ ((j >> 1) & 7)) << 3);
+  const int ch = wave & 1, kq = wave >> 1;
+  const int jz = 64 * kq + 8 * kgt + q4;
+  const int ztr0 = O_ZT + jz * ZTR + (((4 * (gi & 1) + p4) ^ ((4 * kgt) | (q4 >> 1))) << 3);
+  const int ztr1 = O_ZT + (jz + 4) * ZTR + (((4 * (gi & 1) + p4) ^ ((4 * kgt) | (q4 >> 1) | 2)) << 3);
+  const int c16w = 4 * ch + 2 * (gi & 1) + (p4 >> 1);
+  const int w1r0 = O_W1 + jz * RW + ((c16w ^ (((q4 >> 1) << 2) | (2 * kgt))) << 4) + 8 * (p4 & 1);
+  const int w1r1 = O_W1 + (jz + 4) * RW + ((c16w ^ (((q4 >> 1) << 2) | (2 * kgt) | 1)) << 4) + 8 * (p4 & 1);
+  const int padd = (4 * kg * 64 + 32 * ch + j) * 4 + (kq & 1) * 8192;
+  const int err = lane >> 4, ecq = lane & 15;
+  const int pten = wave >> 2, prow = 8 * (wave & 3) + (lane >> 3), poct = lane & 7;
+  const int pst = pten * IMG + prow * RW + ((poct ^ sw16(prow)) << 4);
+  const unsigned hash_lane = (unsigned)((8 * (j & 3) + 4 * kg) * 64 + 8 * wave + (j >> 2)) * 0x9E3779B1u;
+
+  float4 raw0, raw1; float2 rst;
+  auto load_raw = [&](long m0) {
+    const long avail = a.M - m0 < 32 ? a.M - m0 : 32;
+    const __amdgpu_buffer_rsrc_t Rr = make_rsrc_((pten == 0 ? a.X : a.dY) + m0 * 64, avail > 0 ? (unsigned)(avail * 256) : 0u);
+    const __amdgpu_buffer_rsrc_t Sr = make_rsrc_(a.stats + m0 * 2, avail > 0 ? (unsigned)(avail * 8) : 0u);
+    raw0 = buf_load4_(Rr, (unsigned)(prow * 256 + poct * 32));
+    raw1 = buf_load4_(Rr, (unsigned)(prow * 256 + poct * 32 + 16));
+    rst = buf_load2_(Sr, (unsigned)(prow * 8));
+  };
+  auto prologue_store = [&](long m0, int buf) {
+    const long m = m0 + prow;
+    const bool ok = m < mend;
+    float x[8];
+    if (pten == 0) {
+      const float4 g0 = *reinterpret_cast<const float4*>(gbs + 8 * poct), g1 = *reinterpret_cast<const float4*>(gbs + 8 * poct + 4);
+      const float4 t0 = *reinterpret_cast<const float4*>(gbs + 64 + 8 * poct), t1 = *reinterpret_cast<const float4*>(gbs + 64 + 8 * poct + 4);
+      const float mean = rst.x, rstd = rst.y;
+      x[0] = (raw0.x - mean) * rstd * g0.x + t0.x; x[1] = (raw0.y - mean) * rstd * g0.y + t0.y;
+      x[2] = (raw0.z - mean) * rstd * g0.z + t0.z; x[3] = (raw0.w - mean) * rstd * g0.w + t0.w;
+      x[4] = (raw1.x - mean) * rstd * g1.x + t1.x; x[5] = (raw1.y - mean) * rstd * g1.y + t1.y;
+      x[6] = (raw1.z - mean) * rstd * g1.z + t1.z; x[7] = (raw1.w - mean) * rstd * g1.w + t1.w;
+    } else {
+      float4 d0 = make_float4(1.f, 1.f, 1.f, 1.f), d1 = d0;
+      if (dr) {
+        d0 = drop_scale4(a.seed_o, (unsigned)(m * 64 + 8 * poct), thr, inv_keep);
+        d1 = drop_scale4(a.seed_o, (unsigned)(m * 64 + 8 * poct + 4), thr, inv_keep);
+      }
+      x[0] = raw0.x * d0.x; x[1] = raw0.y * d0.y; x[2] = raw0.z * d0.z; x[3] = raw0.w * d0.w;
+      x[4] = raw1.x * d1.x; x[5] = raw1.y * d1.y; x[6] = raw1.z * d1.z; x[7] = raw1.w * d1.w;
+      float* dbc = reinterpret_cast<float*>(sm + O_DB2) + ((tid & 255) << 3);
+      float4 c0 = *reinterpret_cast<const float4*>(dbc), c1 = *reinterpret_cast<const float4*>(dbc + 4);
+      const float k = ok ? 1.f : 0.f;
+      c0.x += k * x[0]; c0.y += k * x[1]; c0.z += k * x[2]; c0.w += k * x[3]; c1.x += k * x[4]; c1.y += k * x[5]; c1.z += k * x[6]; c1.w += k * x[7];
+      *reinterpret_cast<float4*>(dbc) = c0; *reinterpret_cast<float4*>(dbc + 4) = c1;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = ok ? x[e] : 0.f;
+    bf16x8 o[2];
+    split_planes8_h(x, pten == 0 ? s_in : s_dy, o);
+    unsigned char* p = sm + O_ROWS + buf * 2 * IMG + pst;
+    *reinterpret_cast<bf16x8*>(p) = o[0];
+    *reinterpret_cast<bf16x8*>(p + PL) = o[1];
+  };
+
+  load_raw(mbeg);
+  __syncthreads();
+  prologue_store(mbeg, 0);
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const long m0 = mbeg + 32L * t;
+    const bool more = t + 1 < ntile;
+    const unsigned char* const rows = sm + O_ROWS + (t & 1) * 2 * IMG;
+    const long avail = a.M - m0 < 32 ? a.M - m0 : 32;
+    const unsigned eo = (unsigned)((4 * wave + err) * 256 + ecq * 16);
+    load_raw(m0 + 32);
+    float4 er2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.dR2) er2 = buf_load4_(make_rsrc_(a.dR2 + m0 * 64, (unsigned)(avail * 256)), eo);
+    unsigned kw[4] = {0x1111u, 0x1111u, 0x1111u, 0x1111u};
+    if (dr) {
+      const unsigned base = hash_lane + (unsigned)(m0 * 64) * 0x9E3779B1u;
+      unsigned w = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) w |= drop_keep4_pre(a.seed_h, base + (unsigned)(i * 64) * 0x9E3779B1u, thr) << (4 * i);
+      const int sh = j & 3;
+      kw[0] = (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x00, 0xf, 0xf, true) >> sh;
+      kw[1] = (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0x55, 0xf, 0xf, true) >> sh;
+      kw[2] = (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xAA, 0xf, 0xf, true) >> sh;
+      kw[3] = (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xFF, 0xf, 0xf, true) >> sh;
+    }
+    f32x16 ah, ad;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ah[e] = 0.f; ad[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned char* p = rows + fragA + (x16 ^ (32 * ks));
+      const bf16x8 lh = *reinterpret_cast<const bf16x8*>(p), ll = *reinterpret_cast<const bf16x8*>(p + PL);
+      const unsigned char* pw = sm + O_W1 + (32 * wave + j) * RW + (x16 ^ (32 * ks));
+      const bf16x8 w_h = *reinterpret_cast<const bf16x8*>(pw), w_l = *reinterpret_cast<const bf16x8*>(pw + W1PL);
+      ah = mfma32_<true>(ll, w_h, ah);
+      ah = mfma32_<true>(lh, w_l, ah);
+      ah = mfma32_<true>(lh, w_h, ah);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const unsigned char* p = rows + IMG + fragA + (x16 ^ (32 * ks));
+      const bf16x8 yh = *reinterpret_cast<const bf16x8*>(p), yl = *reinterpret_cast<const bf16x8*>(p + PL);
+      ad = mfma32_<true>(yl, W2b[ks][0], ad);
+      ad = mfma32_<true>(yh, W2b[ks][1], ad);
+      ad = mfma32_<true>(yh, W2b[ks][0], ad);
+    }
+    unsigned sh_[4][2], sl_[4][2], zh_[4][2], zl_[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float sv[4], zv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * q + e;
+        const float h = fmaf(ah[i], uh, bias);
+        float sg = sigmoidf_(h);
+        sg = __uint_as_float(__float_as_uint(sg) & (unsigned)__builtin_amdgcn_sbfe((int)kw[q], 4 * e, 1));
+        const float s0 = h * sg;
+        const float sw = fmaf(s0, 1.0f - sg, sg);
+        sv[e] = s0 * mkS;
+        zv[e] = ad[i] * sw * mkZ;
+        bs1 += zv[e];
+      }
+      split4_(sv[0], sv[1], sv[2], sv[3], one, sh_[q][0], sh_[q][1], sl_[q][0], sl_[q][1]);
+      split4_(zv[0], zv[1], zv[2], zv[3], one, zh_[q][0], zh_[q][1], zl_[q][0], zl_[q][1]);
+      *reinterpret_cast<u32x2_*>(sm + (ztw ^ (16 * q))) = (u32x2_){zh_[q][0], zh_[q][1]};
+      *reinterpret_cast<u32x2_*>(sm + (ztw ^ (16 * q)) + ZTPL) = (u32x2_){zl_[q][0], zl_[q][1]};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const bf16x8 s_h = __builtin_bit_cast(bf16x8, (u32x4_){sh_[2 * ks][0], sh_[2 * ks][1], sh_[2 * ks + 1][0], sh_[2 * ks + 1][1]});
+      const bf16x8 s_l = __builtin_bit_cast(bf16x8, (u32x4_){sl_[2 * ks][0], sl_[2 * ks][1], sl_[2 * ks + 1][0], sl_[2 * ks + 1][1]});
+      const bf16x8 z_h = __builtin_bit_cast(bf16x8, (u32x4_){zh_[2 * ks][0], zh_[2 * ks][1], zh_[2 * ks + 1][0], zh_[2 * ks + 1][1]});
+      const bf16x8 z_l = __builtin_bit_cast(bf16x8, (u32x4_){zl_[2 * ks][0], zl_[2 * ks][1], zl_[2 * ks + 1][0], zl_[2 * ks + 1][1]});
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const unsigned char* p0 = rows + ((trA0 ^ (64 * nt)) + 16 * RW * ks), *p1 = rows + ((trA1 ^ (64 * nt)) + 16 * RW * ks);
+        bf16x8 y_h, y_l;
+        y_h = tr2_(p0 + IMG, p1 + IMG); y_l = tr2_(p0 + IMG + PL, p1 + IMG + PL);
+        aw2[nt] = mfma32_<true>(y_h, s_l, aw2[nt]);
+        aw2[nt] = mfma32_<true>(y_l, s_h, aw2[nt]);
+        aw2[nt] = mfma32_<true>(y_h, s_h, aw2[nt]);
+        const bf16x8 l_h = tr2_(p0, p1), l_l = tr2_(p0 + PL, p1 + PL);
+        aw1[nt] = mfma32_<true>(z_h, l_l, aw1[nt]);
+        aw1[nt] = mfma32_<true>(z_l, l_h, aw1[nt]);
+        aw1[nt] = mfma32_<true>(z_h, l_h, aw1[nt]);
+      }
+    }
+    FF_SYNC(0);                                          // (Q) ZT complete; the row images of this tile are free
+    const float4 ex = buf_load4_(make_rsrc_(a.X + m0 * 64, (unsigned)(avail * 256)), eo);
+    const float4 ey = buf_load4_(make_rsrc_(a.dY + m0 * 64, (unsigned)(avail * 256)), eo);
+    const float2 est = buf_load2_(make_rsrc_(a.stats + m0 * 2, (unsigned)(avail * 8)), (unsigned)((4 * wave + err) * 8));
+    {
+      unsigned char* const pbase = kq < 2 ? sm + O_PATCH : sm + O_ROWS + (t & 1) * 2 * IMG;
+      f32x16 gl;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) gl[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 zh = tr2_(sm + ztr0 + 16 * ks * ZTR, sm + ztr1 + 16 * ks * ZTR);
+        const bf16x8 zl = tr2_(sm + ztr0 + ZTPL + 16 * ks * ZTR, sm + ztr1 + ZTPL + 16 * ks * ZTR);
+        const bf16x8 wh = tr2_(sm + w1r0 + 16 * ks * RW, sm + w1r1 + 16 * ks * RW);
+        const bf16x8 wl = tr2_(sm + w1r0 + W1PL + 16 * ks * RW, sm + w1r1 + W1PL + 16 * ks * RW);
+        gl = mfma32_<true>(zh, wl, gl);
+        gl = mfma32_<true>(zl, wh, gl);
+        gl = mfma32_<true>(zh, wh, gl);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) *reinterpret_cast<float*>(pbase + padd + ((e & 3) + 8 * (e >> 2)) * 256) = gl[e] * u2;
+    }
+    if (more) prologue_store(m0 + 32, (t + 1) & 1);
+    FF_SYNC(1);                                          // (R) patches complete; ZT free; images of tile t + 1 complete
+    {
+      const int rl = 4 * wave + err;
+      const bool ok = m0 + rl < mend;
+      const float* pp = patch + rl * 64 + 4 * ecq;
+      const float* pq = reinterpret_cast<const float*>(rows) + rl * 64 + 4 * ecq;
+      const float4 p0 = *reinterpret_cast<const float4*>(pp), p1 = *reinterpret_cast<const float4*>(pp + 2048);
+      const float4 p2 = *reinterpret_cast<const float4*>(pq), p3 = *reinterpret_cast<const float4*>(pq + 2048);
+      const float dv[4] = {(p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                           (p0.w + p1.w) + (p2.w + p3.w)};
+      const float4 gm = *reinterpret_cast<const float4*>(gbs + 4 * ecq);
+      const float gl4[4] = {gm.x, gm.y, gm.z, gm.w}, xs[4] = {ex.x, ex.y, ex.z, ex.w};
+      const float mean = est.x, rstd = est.y;
+      float xh[4], dxh[4], s1 = 0.f, s2 = 0.f, ag[4], ab[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[e] = (xs[e] - mean) * rstd;
+        dxh[e] = dv[e] * gl4[e];
+        s1 += dxh[e]; s2 += dxh[e] * xh[e];
+        ag[e] = ok ? dv[e] * xh[e] : 0.f; ab[e] = ok ? dv[e] : 0.f;
+      }
+      s1 = row16_sum_(s1) * (1.f / 64.f); s2 = row16_sum_(s2) * (1.f / 64.f);
+      float o4[4] = {ey.x + er2.x, ey.y + er2.y, ey.z + er2.z, ey.w + er2.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] += rstd * (dxh[e] - s1 - xh[e] * s2);
+      const long rows_ok = mend - m0 < 32 ? mend - m0 : 32;
+      buf_store4_(make_rsrc_(a.dX + m0 * 64, (unsigned)(rows_ok * 256)), (unsigned)(rl * 256 + ecq * 16), make_float4(o4[0], o4[1], o4[2], o4[3]));
+      if (ok) xmax = fmaxf(fmaxf(xmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = xor32_sum_(xor16_sum_(ag[e])), sb = xor32_sum_(xor16_sum_(ab[e]));
+        agk += err == e ? sg : 0.f;
+        abk += err == e ? sb : 0.f;
+      }
+    }
+  }
+  // ---- leave.  The SMALL vectors (gamma / beta / b2 gradients: 64 floats = two cache lines each) are folded across the workgroup in LDS
+  // and leave through ONE atomic instruction per vector: atomics of different workgroups to the same cache line are serialised at the
+  // memory side (~14 ns per wave instruction): 32 instructions per workgroup on the b2 lines cost 115 us of a 450 us launch ----
+  if (a.out_amax) {
+    xmax = wave_max(xmax);
+    if (lane == 0) amax_raise_(a.out_amax, xmax);
+  }
+  __syncthreads();                                       // (the row images are free: fold area)
+  {
+    float* fold = reinterpret_cast<float*>(sm + O_ROWS);      // [wave 8][gamma 64 | beta 64] then [dY wave 4][64]
+    fold[wave * 128 + 4 * ecq + err] = agk;
+    fold[wave * 128 + 64 + 4 * ecq + err] = abk;
+    if (pten == 1) {
+      const float* dbc = reinterpret_cast<const float*>(sm + O_DB2) + ((tid & 255) << 3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = dbc[e];
+        v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lane < 8) fold[1024 + (wave - 4) * 64 + 8 * poct + e] = v;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float* fold = reinterpret_cast<const float*>(sm + O_ROWS);
+    float g = 0.f, bt = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { g += fold[w * 128 + lane]; bt += fold[w * 128 + 64 + lane]; }
+    atomicAdd(&a.dgamma[lane], g);
+    atomicAdd(&a.dbeta[lane], bt);
+    if (a.db2) atomicAdd(&a.db2[lane], ((fold[1024 + lane] + fold[1088 + lane]) + (fold[1152 + lane] + fold[1216 + lane])) * a.alpha);
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = (e & 3) + 8 * (e >> 2) + 4 * kg;
+      atomicAdd(&a.dW1[(32 * wave + row) * 64 + 32 * nt + j], aw1[nt][e] * un1);
+      atomicAdd(&a.dW2[(32 * nt + row) * 256 + 32 * wave + j], aw2[nt][e] * un2);
+    }
+  {
+    const float v = bs1 + __shfl_xor(bs1, 32, 64);
+    if (kg == 0) atomicAdd(&a.db1[32 * wave + j], v * ub1);
+  }
+#ifdef SE_FF_STAMPS
+  if (a.stamps && tid == 0) { a.stamps[4096 + blockIdx.x] = (unsigned)(__builtin_amdgcn_s_memtime() - t00_); a.stamps[4096 + 512 + blockIdx.x] = (unsigned)(tp_ - t00_); }
+  if (a.stamps && blockIdx.x < 4 && lane == 0) {
+    for (int k = 0; k < 2; ++k) { a.stamps[((int)blockIdx.x * 8 + wave) * 16 + k] = wk_[k]; a.stamps[((int)blockIdx.x * 8 + wave) * 16 + 4 + k] = wt_[k]; }
+    a.stamps[((int)blockIdx.x * 8 + wave) * 16 + 8] = (unsigned)ntile;
+  }
+#endif
 }
 
 #ifdef SE_FF_STAMPS
 static unsigned* g_ff_stamps = nullptr;
 extern "C" void se_ff_fused_debug_stamps(void* p) { g_ff_stamps = reinterpret_cast<unsigned*>(p); }
 #endif
-
-int se_ff_fused4_launch(const FfFusedArgs& a0, int ncu, void* stream);
 
 extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* stats, const float* gamma, const float* beta,
                                const float* W1, const float* b1, const float* W2T, const float* dR2, float* dX, float* dgamma,
@@ -518,20 +414,18 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
   SE_REQUIRE(M > 0 && hid == 256, "ff_bwd_fused: M=%ld hid=%d (built for hid == 256: four slots of 64 hidden units)", M, hid);
   SE_REQUIRE((((size_t)W1 | (size_t)W2T) & 15) == 0, "ff_bwd_fused: weight planes must be 16-byte aligned");
   SE_REQUIRE(drop_p >= 0.f && drop_p <= 0.5f && M * (long)hid < 4294967296L, "ff_bwd_fused: drop_p (keep >= 1/2) / dropout index out of range");
-  // one persistent 8-wave workgroup per CU (159 KB of LDS): rows dealt in multiples of the 64-row tile; at least 4 tiles per
+  // one persistent 8-wave workgroup per CU (156 KB of LDS): rows dealt in multiples of the 32-row tile; at least 8 tiles per
   // workgroup so that the 32 768 atomics a workgroup leaves with are amortised
   const int ncu = se_cu_count();
   long rpw = (M + ncu - 1) / ncu;
   if (rpw < 256) rpw = 256;
-  rpw = (rpw + 63) / 64 * 64;
+  rpw = (rpw + 31) / 32 * 32;
   const int nwg = (int)((M + rpw - 1) / rpw);
   FfFusedArgs a{dY, X, stats, gamma, beta, W1, b1, W2T, dR2, dX, dgamma, dbeta, dW1, db1, dW2, db2, M, rpw, drop_p, seed_h, seed_o, alpha,
                 dy_amax, w1_amax, w2t_amax, in_amax, mid_amax, out_amax, ln_sexp, hid_sexp, 0, nullptr};
-#ifdef SE_FF_STAMPS      // diagnostic builds only (tools/ff_fused_stamps.py): timing ablations + barrier-arrival stamps
-  if (const char* e = getenv("SE_FF_DBG")) a.dbg = atoi(e);
+#ifdef SE_FF_STAMPS      // diagnostic builds only (tools/ff_fused_stamps.py)
   a.stamps = g_ff_stamps;
 #endif
-  { const char* v = getenv("SE_FF_FUSED_V"); if (v && atoi(v) == 4) return se_ff_fused4_launch(a, ncu, stream); }
   hipLaunchKernelGGL(ff_bwd_fused_kernel, dim3((unsigned)nwg), dim3(512), 0, as_stream(stream), a);
   return se_check_launch("se_ff_bwd_fused");
 }

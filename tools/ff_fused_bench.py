@@ -1,7 +1,6 @@
-"""se_ff_bwd_fused at the bench shape (M = 16 x 321 x 101 rows) alone: time per launch, and the same with the ablation switches of
-csrc/se_ff_fused.hip (SE_FF_DBG bits: 1 no sigmoid, 2 no dropout hash, 4 no H / dP MFMAs, 8 no dLN MFMAs, 16 epilogue operands from
-the first tile (cache hits), 128 no weight-gradient work, 512 no L2-warming touches) -- wrong results, timing
-only: what each part of the kernel costs on the critical path.  usage: python tools/ff_fused_bench.py [sweep | DBG ...]"""
+"""se_ff_bwd_fused at the bench shape (M = 16 x 321 x 101 rows) alone: time per launch with and without dropout (median of three
+groups of 20 launches).  SE_HIP_LIB selects a variant library (tools/build_variant_lib.sh) for a same-box A/B.
+usage: python tools/ff_fused_bench.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -26,20 +25,18 @@ gr = [torch.zeros(s, device=dev) for s in ((256, 64), (256,), (64, 256), (64,), 
 am = torch.zeros(1, device=dev)
 
 
-def run(n=6, drop=0.2):
-    for _ in range(2):
-        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(n):
-        GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
-    torch.cuda.synchronize()
-    return (time.time() - t0) / n * 1e6
+def run(n=20, drop=0.2):
+    ts = []
+    for _ in range(3):
+        for _ in range(2):
+            GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(n):
+            GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], *gr, drop, 11, 12, 0.5, dR2=dR2, out_amax=am)
+        torch.cuda.synchronize()
+        ts.append((time.time() - t0) / n * 1e6)
+    return sorted(ts)[1]
 
 
-args = sys.argv[1:] or ['sweep']
-flags = [0, 1, 2, 3, 4, 8, 12, 16, 128, 512, 128 + 15, 128 + 31] if args == ['sweep'] else [int(a) for a in args]
-for f in flags:
-    os.environ['SE_FF_DBG'] = str(f)
-    print(f'SE_FF_DBG={f:4d}: {run():8.1f} us per launch (drop 0.2), {run(drop=0.0):8.1f} (no dropout)', flush=True)
-os.environ['SE_FF_DBG'] = '0'
+print(f'se_ff_bwd_fused: {run():8.1f} us per launch (drop 0.2), {run(drop=0.0):8.1f} (no dropout)', flush=True)
