@@ -243,8 +243,24 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     xmax = wave_max(xmax);
     if (lane == 0) amax_raise_(a.out_amax, xmax);
   }
-  atomicAdd(&a.dgamma[4 * scq + (srow & 3)], agk);
-  atomicAdd(&a.dbeta[4 * scq + (srow & 3)], abk);
+  // gamma / beta gradients: folded across the eight waves in LDS, ONE atomic instruction per vector and workgroup (atomics of different
+  // workgroups to the same cache lines are serialised at the memory side, ~24 ns per wave instruction -- tools/micro/atomic_line_bench.hip:
+  // sixteen instructions per workgroup on these two vectors were 2 x 49 us at the end of a 230 - 260 us launch)
+  __syncthreads();                                       // (the images are free: fold area)
+  {
+    float* fold = reinterpret_cast<float*>(sm + O_A);
+    fold[wave * 128 + 4 * scq + (srow & 3)] = agk;
+    fold[wave * 128 + 64 + 4 * scq + (srow & 3)] = abk;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float* fold = reinterpret_cast<const float*>(sm + O_A);
+    float g = 0.f, bt = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { g += fold[w * 128 + lane]; bt += fold[w * 128 + 64 + lane]; }
+    atomicAdd(&a.dgamma[lane], g);
+    atomicAdd(&a.dbeta[lane], bt);
+  }
   if (wg_on) {
     const int col = lane & 31;
 #pragma unroll
