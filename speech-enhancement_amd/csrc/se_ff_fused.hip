@@ -348,13 +348,11 @@ __global__ __launch_bounds__(512, 2) void ff_bwd_fused_kernel(FfFusedArgs a) {
   // ---- leave.  The SMALL vectors (gamma / beta / b2 gradients: 64 floats = two cache lines each) are folded across the workgroup in LDS
   // and leave through ONE atomic instruction per vector: atomics of different workgroups to the same cache line are serialised at the
   // memory side (~14 ns per wave instruction): 32 instructions per workgroup on the b2 lines cost 115 us of a 450 us launch ----
-  if (a.out_amax) {
-    xmax = wave_max(xmax);
-    if (lane == 0) amax_raise_(a.out_amax, xmax);
-  }
+  xmax = wave_max(xmax);
   __syncthreads();                                       // (the row images are free: fold area)
   {
-    float* fold = reinterpret_cast<float*>(sm + O_ROWS);      // [wave 8][gamma 64 | beta 64] then [dY wave 4][64]
+    float* fold = reinterpret_cast<float*>(sm + O_ROWS);      // [wave 8][gamma 64 | beta 64], [dY wave 4][64], [wave 8] dX maxima
+    if (lane == 0) fold[1280 + wave] = xmax;
     fold[wave * 128 + 4 * ecq + err] = agk;
     fold[wave * 128 + 64 + 4 * ecq + err] = abk;
     if (pten == 1) {
@@ -375,6 +373,12 @@ __global__ __launch_bounds__(512, 2) void ff_bwd_fused_kernel(FfFusedArgs a) {
     for (int w = 0; w < 8; ++w) { g += fold[w * 128 + lane]; bt += fold[w * 128 + 64 + lane]; }
     atomicAdd(&a.dgamma[lane], g);
     atomicAdd(&a.dbeta[lane], bt);
+    if (a.out_amax && lane == 0) {
+      float m = fold[1280];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, fold[1280 + w]);
+      amax_raise_(a.out_amax, m);
+    }
     if (a.db2) atomicAdd(&a.db2[lane], ((fold[1024 + lane] + fold[1088 + lane]) + (fold[1152 + lane] + fold[1216 + lane])) * a.alpha);
   }
 #pragma unroll

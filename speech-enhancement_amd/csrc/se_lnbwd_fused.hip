@@ -239,11 +239,8 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     tile(t, B0{});
     if (t + 1 < ntile) tile(t + 1, B1{});
   }
-  if (a.out_amax) {
-    xmax = wave_max(xmax);
-    if (lane == 0) amax_raise_(a.out_amax, xmax);
-  }
-  // gamma / beta gradients: folded across the eight waves in LDS, ONE atomic instruction per vector and workgroup (atomics of different
+  xmax = wave_max(xmax);
+  // gamma / beta gradients (and the dX maximum): folded across the eight waves in LDS, ONE atomic instruction per vector and workgroup (atomics of different
   // workgroups to the same cache lines are serialised at the memory side, ~24 ns per wave instruction -- tools/micro/atomic_line_bench.hip:
   // sixteen instructions per workgroup on these two vectors were 2 x 49 us at the end of a 230 - 260 us launch)
   __syncthreads();                                       // (the images are free: fold area)
@@ -251,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     float* fold = reinterpret_cast<float*>(sm + O_A);
     fold[wave * 128 + 4 * scq + (srow & 3)] = agk;
     fold[wave * 128 + 64 + 4 * scq + (srow & 3)] = abk;
+    if (lane == 0) fold[1024 + wave] = xmax;
   }
   __syncthreads();
   if (wave == 0) {
@@ -260,6 +258,12 @@ __global__ __launch_bounds__(512, 2) void lnbwd_fused_kernel(LnBwdFusedArgs a) {
     for (int w = 0; w < 8; ++w) { g += fold[w * 128 + lane]; bt += fold[w * 128 + 64 + lane]; }
     atomicAdd(&a.dgamma[lane], g);
     atomicAdd(&a.dbeta[lane], bt);
+    if (a.out_amax && lane == 0) {
+      float m = fold[1024];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) m = fmaxf(m, fold[1024 + w]);
+      amax_raise_(a.out_amax, m);
+    }
   }
   if (wg_on) {
     const int col = lane & 31;
