@@ -194,7 +194,7 @@ def leaf_join(device):
     _LeafStream.active = False
 
 
-_W3_ROUNDS = int(__import__('os').environ.get('SE_W3_ROUNDS', '1'))      # (measurement hook; 0: the generic rule)
+W3_ROUNDS = 1      # rounds of 512 workgroups of the triple-tap weight-gradient kernels (0: the generic rule below; measured 0 / 1 / 2)
 
 
 def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, chunks=None, explicit_precision=False,
@@ -212,12 +212,12 @@ def gemm_tap_wgrad(d, A, dY, dW, dbias=None, rowstats=None, ps=None, pb=None, ch
         # rows allow it, so that the unequal start times of the first round even out
         rounds = 4 if M * nblk >= 4 * 1024 * 1024 else 2
         chunks = max(1, min((M + 255) // 256, (rounds * 1024) // nblk))
-        if _W3_ROUNDS and d.ntap % 3 == 0 and d.precision == 3 and d.prologue == L.PRO_NONE and not (d.epilogue & L.EPI_DROP):
+        if W3_ROUNDS and d.ntap % 3 == 0 and d.precision == 3 and d.prologue == L.PRO_NONE and not (d.epilogue & L.EPI_DROP):
             # the triple-tap kernels (wgrad3w_f16_kernel at C >= 128: 128 channels per block; wgrad3_bf16_kernel below) keep TWO workgroups
             # resident per CU: whole rounds of 512 workgroups -- 688 / 928 / 704 workgroups (the rule above at C = 128 / 192 / 256) ran as
             # two rounds with the second a third full: wgrad3 family 4.08 -> 3.71 ms per step with exactly one round
             blocks = (d.ntap // 3) * ((d.C + 127) // 128 if d.C >= 128 else (d.C + 63) // 64) * ((d.N + 63) // 64)
-            chunks = max(8, min((M + 255) // 256, (_W3_ROUNDS * 512 // blocks) // 8 * 8))
+            chunks = max(8, min((M + 255) // 256, (W3_ROUNDS * 512 // blocks) // 8 * 8))
     Mt = d.B * d.To * d.Fo
     lin = d.ntap == 1 and d.B == 1 and d.To == 1
     saved = d.precision
