@@ -624,6 +624,8 @@ def main():
             roof['step_profile'] = dict(pj['step'], source=traffic_source,
                                         note='time-weighted MFMA-busy over every kernel of a step and HBM-side bytes per step '
                                              '(2 FETCH_SIZE + WRITE_SIZE over all launches), from the committed PMC passes')
+        roof['peak_note'] = ('peak = the 2.4 GHz dense figure of MI355X_MICROARCH.md; with the matrix pipe kept full this part sustains 1.13 - 1.18 GHz '
+                             '(vector-only streams 1.52 GHz): profiles/r06_clock_density.txt, tools/micro/clock_density.hip')
     a = argparse.Namespace(**{**vars(a), 'steps': a_steps})
     res = {
         'metric': 'utterances/sec (2 s @16 kHz) CMGAN train step', 'value': round(world * B * a.steps / dt, 3),
