@@ -415,7 +415,7 @@ extern "C" int se_ff_bwd_fused(const float* dY, const float* X, const float* sta
                                float* out_amax, void* stream) {
   SE_REQUIRE(dY && X && stats && gamma && beta && W1 && b1 && W2T && dX && dgamma && dbeta && dW1 && db1 && dW2, "ff_bwd_fused: null operand");
   SE_REQUIRE(dy_amax && w1_amax && w2t_amax, "ff_bwd_fused: the operand amax scalars are required (scaled split-fp16)");
-  SE_REQUIRE(M > 0 && hid == 256, "ff_bwd_fused: M=%ld hid=%d (built for hid == 256: four slots of 64 hidden units)", M, hid);
+  SE_REQUIRE(M > 0 && hid == 256, "ff_bwd_fused: M=%ld hid=%d (built for hid == 256: eight waves of 32 hidden units)", M, hid);
   SE_REQUIRE((((size_t)W1 | (size_t)W2T) & 15) == 0, "ff_bwd_fused: weight planes must be 16-byte aligned");
   SE_REQUIRE(drop_p >= 0.f && drop_p <= 0.5f && M * (long)hid < 4294967296L, "ff_bwd_fused: drop_p (keep >= 1/2) / dropout index out of range");
   // one persistent 8-wave workgroup per CU (156 KB of LDS): rows dealt in multiples of the 32-row tile; at least 8 tiles per
