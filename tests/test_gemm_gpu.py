@@ -776,6 +776,46 @@ def test_feed_forward_fused_backward(M):
             assert rel(db1b - init[1], dz64.sum(0)) < 2e-6 and rel(db2b - init[3], 0.5 * dy.double().sum(0)) < 2e-6
 
 
+def test_feed_forward_fused_backward_optional_operands():
+    """se_ff_bwd_fused without its optional operands (no second residual, no b2 gradient, no output maximum) gives the same dX / dW as
+    with them, repeated launches with the same seeds are bit-identical in dX (the weight gradients are fp32 atomics: order-dependent in
+    the last bits), and a row count that is not a multiple of the 32-row tile leaves the rows past M untouched."""
+    from speech_enhancement_amd import gemm as GM, ops as O
+    from speech_enhancement_amd.weights import WeightPlan
+    dev = torch.device('cuda')
+    torch.manual_seed(7)
+    M = 3 * 2048 + 19
+    xf = torch.randn(M + 5, 64, device=dev)
+    x = xf[:M]
+    st = O.row_stats(x, M)
+    g, b = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+    W1, b1 = torch.randn(256, 64, device=dev) * 0.1, torch.randn(256, device=dev) * 0.1
+    W2 = torch.randn(64, 256, device=dev) * 0.1
+    p = WeightPlan(dev)
+    p.linear('w1', W1, planes='f16'); p.linear_T('w2t', W2, planes='f16', scale=0.5)
+    p.run()
+    dy = torch.randn(M, 64, device=dev) * 1e-3
+    dy._se_amax = dy.abs().max().reshape(1).clone()
+
+    def run(db2, amax):
+        gr = [torch.zeros(s, device=dev) for s in ((256, 64), (256,), (64, 256))]
+        dg, dbt = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+        dx = GM.ff_bwd_fused(dy, x, st, g, b, p.out['w1'], b1, p.out['w2t'], gr[0], gr[1], gr[2], db2, dg, dbt, 0.2, 11, 12, 0.5,
+                             dR2=None, out_amax=amax)
+        torch.cuda.synchronize()
+        return dx, gr, dg, dbt
+    db2, am = torch.zeros(64, device=dev), torch.zeros(1, device=dev)
+    dx0, gr0, dg0, dbt0 = run(db2, am)
+    dx1, gr1, dg1, dbt1 = run(None, None)
+    dx2, _, _, _ = run(None, None)
+    assert torch.equal(dx0, dx1) and torch.equal(dx1, dx2)
+    assert float(am) == float(dx0.abs().max())
+    rel = lambda a, r: float((a - r).abs().max() / r.abs().max())
+    for a_, r_ in zip(gr1 + [dg1, dbt1], gr0 + [dg0, dbt0]):
+        assert rel(a_, r_) < 2e-6
+    assert float(db2.abs().max()) > 0
+
+
 @pytest.mark.parametrize('K', [192, 256])
 @pytest.mark.parametrize('M', [21, 4096 + 37, 60001])
 def test_ln_bwd_gemm_with_weight_gradient_in_one_sweep(M, K):
