@@ -389,7 +389,7 @@ extern "C" void se_conv3_debug_stamps(void* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_
 template <int NPL, bool WPL = false, bool F16 = false, int OCC = 3, int MT = 1, int ORD = 0>
 __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     // 3 waves per SIMD: VGPR + AGPR <= 168
   constexpr int BM = 128 * MT, BN = 64, BK = 32, SA = 40, HR = BM + 2;
-  constexpr int PA = HR * SA, PB = BN * SA;
+  constexpr int PA = (HR + 1) * SA, PB = BN * SA;      // row HR of every plane stays ZERO: where the fragment reads of a masked tap point
   __shared__ __attribute__((aligned(16))) __bf16 Ap[NPL * PA];
   __shared__ __attribute__((aligned(16))) __bf16 Bp[NPL * PB];
   __shared__ float red[4 * 64 * 2];
@@ -409,12 +409,18 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
 #pragma unroll
   for (int i = 0; i < 2; ++i) { int n = by * 64 + r0 + 32 * i; wok[i] = n < d.N; wrow[i] = (unsigned)n * (unsigned)d.ldw; }
   // frequency-edge masks of this lane's output pixel (fragment row lane & 31 of the wave's 32 rows), per row block
-  bool edgeL[MT], edgeR[MT];
+  // (round 6: a lane whose pixel has no left / right neighbour reads the ZERO row of the image for that tap -- one select on the row
+  // offset per tile instead of four selects per fragment, plane and k-step: 48 v_cndmask + their copies per group of three taps were
+  // half of the vector instructions of the tap loop)
+  int rowL[MT], rowR[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int fpix = (m0 + mt * 128 + wave * 32 + (lane & 31)) % d.Fo;
-    edgeL[mt] = fpix == 0; edgeR[mt] = fpix == d.Fo - 1;
+    const int own = (mt * 128 + wave * 32 + (lane & 31)) * SA;
+    rowL[mt] = fpix == 0 ? HR * SA : own;                    // source row of the df = -1 tap (halo row index = pixel + 1 + df)
+    rowR[mt] = fpix == d.Fo - 1 ? HR * SA : own + 2 * SA;
   }
+  if (tid < 5 * NPL) *reinterpret_cast<float4*>(&Ap[(tid / 5) * PA + HR * SA + 8 * (tid % 5)]) = make_float4(0.f, 0.f, 0.f, 0.f);
   const int nchunk = (d.C + BK - 1) / BK, ngrp = d.ntap / 3;
   const int NI = nchunk * d.ntap;
   const unsigned thr = 0u;
@@ -542,18 +548,10 @@ __global__ __launch_bounds__(256, OCC) void conv3_bf16_kernel(GemmArgs g) {     
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const int ao = (mt * 128 + wave * 32 + 1 + df) * SA + frag + 16 * ks;
-          const bool kill = (df < 0 && edgeL[mt]) || (df > 0 && edgeR[mt]);
+          const int ao = (df < 0 ? rowL[mt] : (df > 0 ? rowR[mt] : (mt * 128 + wave * 32 + 1 + (lane & 31)) * SA)) + 8 * (lane >> 5) + 16 * ks;
           bf16x8 af[NPL];
 #pragma unroll
           for (int q = 0; q < NPL; ++q) af[q] = *reinterpret_cast<const bf16x8*>(&Ap[q * PA + ao]);
-          if (df != 0) {
-#pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-              f32x4 z = kill ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<f32x4*>(&af[q]);
-              af[q] = *reinterpret_cast<bf16x8*>(&z);
-            }
-          }
 #pragma unroll
           for (int ord = NPL - 1; ord >= 0; --ord)
 #pragma unroll
